@@ -1,0 +1,442 @@
+/*
+ * tacotron2_amd.h — C ABI of the MI355X (gfx950) Tacotron 2 mel-spectrogram engine.
+ *
+ * The reference (NVIDIA/tacotron2) has no FFI/plugin interface: its hot path is Python
+ * (`model.py`) over PyTorch/cuDNN/NCCL.  This header is the boundary the
+ * reference *would* bind if its `model.py` delegated to a native library: every entry
+ * point below names the reference lines whose arithmetic it replaces.  The Python host
+ * (`tacotron2_amd/model.py`, same class/method/state_dict surface as reference
+ * model.py:457-529) binds these symbols with ctypes; a maintainer of the reference would
+ * add exactly the same ctypes stubs.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes, no torch types.  All tensors are fp32 row-major
+ *     in HBM unless stated; `ld*` are row strides in ELEMENTS; masks are uint8 keep-masks
+ *     (1 = keep) applied as x * keep * keep_scale (keep_scale = 1/(1-p) formed in fp32).
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream) and returns immediately: T2AMD_OK or an error code; the message is
+ *     available from t2amd_last_error().  Nothing allocates or frees device memory: the
+ *     caller owns all buffers, including workspaces (graph-capture safe).
+ *   - time-major slabs: [T][B][F]; batch-major: [B][T][F].
+ */
+#ifndef TACOTRON2_AMD_H
+#define TACOTRON2_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2AMD_ABI_VERSION 1
+#define T2AMD_OK 0
+#define T2AMD_ERR_ARG 1
+#define T2AMD_ERR_LAUNCH 2
+
+/* attention geometry compiled into the kernels (reference hparams.py:66-70 defaults) */
+#define T2AMD_ATT_DIM 128
+#define T2AMD_LOC_FILTERS 32
+#define T2AMD_LOC_KERNEL 31
+#define T2AMD_LOC_TAPS (2 * T2AMD_LOC_KERNEL) /* 62 = [prev ; cumulative] x 31 */
+
+int t2amd_abi_version(void);
+const char* t2amd_last_error(void);
+/* sizeof() of every struct below, in declaration order, for binding self-checks. */
+int t2amd_struct_sizes(int* out, int max_n);
+
+/* ------------------------------------------------------------------------------------
+ * Dense / implicit-convolution GEMM on exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   C[M,N] (+)= act(A[M,K] . B[K,N] + bias[N]) * keep * keep_scale
+ * replaces every torch.nn.Linear / Conv1d forward, dgrad and wgrad on the path:
+ * reference layers.py:17-18,37-39 (LinearNorm/ConvNorm.forward), model.py:99 (Prenet),
+ * :141-146 (Postnet convs), :174-175 (Encoder convs), :288 (memory_layer), :375-378
+ * (linear_projection + gate_layer) and autograd's matching backward GEMMs.
+ * ------------------------------------------------------------------------------------ */
+typedef struct t2amd_gemm_desc {
+    const float* A;
+    const float* B;
+    float* C;
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int a_kcontig;   /* 1: A stored [M][K] (K contiguous); 0: A stored [K][M] */
+    int b_kcontig;   /* 1: B stored [N][K] (K contiguous, the nn.Linear weight layout); 0: [K][N] */
+    int batch;       /* >=1 independent problems, pointers advance by stride* */
+    long long strideA, strideB, strideC;
+    int splitk;      /* >=1; when >1 the kernel writes `splitk` partial C's (stride strideSplitC)
+                        with a plain store and the epilogue fields must be unset */
+    long long strideSplitC;
+    int accumulate;  /* 1: C += result */
+    const float* bias;      /* [N] or NULL */
+    int act;                /* 0 none, 1 relu */
+    const uint8_t* keep;    /* [M][ldkeep] or NULL */
+    long long ldkeep;
+    float keep_scale;
+    /* implicit 1-D convolution over channel-last rows r = b*T + t (stride 1, 'same' zero pad):
+     * A-side (needs a_kcontig=1): K = taps*convA_C, column (tap,c) of row r reads
+     *   A[(r + (tap-pad)*sign)*lda + c] if 0 <= t + (tap-pad)*sign < T else 0.
+     * B-side (needs b_kcontig=0, used by wgrad): N = taps*convB_C, column (tap,c) of K-row r reads
+     *   B[(r + tap - pad)*ldb + c] if 0 <= t + tap - pad < T else 0. */
+    int convA_T, convA_C, convA_pad, convA_sign;
+    int convB_T, convB_C, convB_pad;
+} t2amd_gemm_desc;
+
+int t2amd_gemm_f32(const t2amd_gemm_desc* d, void* stream);
+
+/* out[i] (+)= sum_s partials[s*stride + i]; with `perm_taps`>0 the flat index i = (co, tap, ci)
+ * is written to (co, ci, tap) (packed conv-weight grad -> torch Conv1d layout, Ci = perm_ci). */
+int t2amd_splitk_reduce_f32(const float* partials, int nsplit, long long stride, float* out,
+                            long long n, int accumulate, int perm_taps, int perm_ci, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNorm1d (+activation +dropout) over channel-last rows; replaces nn.BatchNorm1d +
+ * relu/tanh + F.dropout in reference model.py:141-146, 174-175 (train: biased batch
+ * variance for normalisation, unbiased for the running update, momentum 0.1, eps 1e-5).
+ * ------------------------------------------------------------------------------------ */
+/* column statistics of x[M][N] -> mean, invstd (=1/sqrt(var_biased+eps)); updates running
+ * stats if non-NULL.  ws: >= 2*64*N doubles. */
+int t2amd_bn_stats_f32(const float* x, long long ldx, int M, int N, double* ws, float* mean,
+                       float* invstd, float* running_mean, float* running_var, float momentum,
+                       float eps, void* stream);
+/* invstd from running variance (eval mode): invstd = 1/sqrt(var+eps) */
+int t2amd_bn_eval_invstd_f32(const float* running_var, float* invstd, int N, float eps, void* stream);
+/* y = act((x-mean)*invstd*gamma+beta) * keep*scale ; act: 0 none, 1 relu, 2 tanh.
+ * `row_valid_T`>0 with `lens`!=NULL zeroes rows whose t >= lens[b] (batched ragged inference). */
+int t2amd_bn_act_fwd_f32(const float* x, long long ldx, float* y, long long ldy, int M, int N,
+                         const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, int act, const uint8_t* keep, long long ldkeep,
+                         float keep_scale, const int* lens, int row_valid_T, void* stream);
+/* backward of the above (train mode).  dy is overwritten with dx (grad wrt the conv output x).
+ * y = forward output (post activation/dropout).  dgamma/dbeta are written (not accumulated).
+ * ws: >= 2*64*N doubles. */
+int t2amd_bn_act_bwd_f32(float* dy, long long lddy, const float* y, long long ldy, const float* x,
+                         long long ldx, int M, int N, const float* mean, const float* invstd,
+                         const float* gamma, int act, const uint8_t* keep, long long ldkeep,
+                         float keep_scale, double* ws, float* dgamma, float* dbeta, void* stream);
+/* column sums: out[N] (+)= sum_m x[m][n]  (bias gradients). ws >= 64*N doubles */
+int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, double* ws, float* out,
+                     int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * small data-movement kernels (reference model.py:503 embedding, :296-309 / :326-336
+ * parse_decoder_inputs/outputs, :487-497 parse_output).
+ * ------------------------------------------------------------------------------------ */
+int t2amd_embedding_fwd_f32(const long long* ids, const float* table, float* out, long long rows,
+                            int dim, int n_symbols, void* stream);
+int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, long long rows,
+                            int dim, int n_symbols, void* stream);
+/* Philox4x32-10 keep-mask: out[i] = uniform(seed, offset+i) >= p */
+int t2amd_philox_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed,
+                           unsigned long long offset, void* stream);
+int t2amd_fill_f32(float* p, long long n, float v, void* stream);
+/* dst[r][c] = src[r][c] (+ src2[r][c] if src2) for r<rows, c<cols */
+int t2amd_copy2d_f32(const float* src, long long lds, const float* src2, long long lds2, float* dst,
+                     long long ldd, int rows, int cols, void* stream);
+/* dst[c][r] = src[r][c], batched */
+int t2amd_transpose_f32(const float* src, long long lds, float* dst, long long ldd, int rows,
+                        int cols, int batch, long long sstride, long long dstride, void* stream);
+/* teacher frames: mels [B][C][To] -> X0 [To][B][C] with X0[0]=0, X0[t]=mels[:,:,t-1] */
+int t2amd_frames_to_time_major_f32(const float* mels, float* x0, int B, int C, int To, void* stream);
+/* projection slab PG [To][B][C+1] -> mel_cl [B][To][C] (unmasked), gate [B][To] (1e3 where
+ * t >= out_lens[b], if out_lens) */
+int t2amd_split_projection_f32(const float* pg, float* mel_cl, float* gate, const int* out_lens,
+                               int B, int C, int To, void* stream);
+/* mel_cl,[post_cl] [B][To][C] -> mel,[mel_post = mel+post] [B][C][To], zeroed where t >= out_lens[b];
+ * mel_cl itself is zeroed in place at padded frames (reference model.py:493: the in-place fill
+ * reaches the tensor the first Postnet conv saved for backward). */
+int t2amd_finalize_outputs_f32(float* mel_cl, const float* post_cl, float* mel, float* mel_post,
+                               const int* out_lens, int B, int C, int To, void* stream);
+/* backward entry: dmel,dmel_post [B][C][To] (either may be NULL) -> dpost_cl [B][To][C] = dmel_post^T,
+ * dmel_cl [B][To][C] = dmel^T + dmel_post^T */
+int t2amd_grads_to_channel_last_f32(const float* dmel, const float* dmel_post, float* dmel_cl,
+                                    float* dpost_cl, int B, int C, int To, void* stream);
+/* D_out [To][B][C+1] = [ dmel_cl[b][t][:] | dgate[b][t] ] */
+int t2amd_gather_dout_f32(const float* dmel_cl, const float* dgate, float* dout, int B, int C,
+                          int To, void* stream);
+/* alignments slab [B][To][Ti] passthrough needs no kernel. */
+
+/* ------------------------------------------------------------------------------------
+ * Recurrent cell kernels: batch x hidden "skinny" GEMM on v_mfma_f32_16x16x4_f32 with the
+ * LSTM cell fused in the epilogue.  Replace torch.nn.LSTMCell / nn.LSTM + F.dropout at
+ * reference model.py:352-356 (attention_rnn), :366-371 (decoder_rnn), :181-188 (encoder
+ * bi-LSTM, packed-sequence semantics through `lens`/`t`).
+ * ------------------------------------------------------------------------------------ */
+typedef struct t2amd_seg {
+    const float* p;  /* [B][width] rows, NULL = all zeros */
+    long long ld;
+    int width;       /* multiple of 64 */
+} t2amd_seg;
+
+typedef struct t2amd_lstm_step {
+    t2amd_seg x[3];
+    int nseg;
+    const float* W;     /* [4H][Ktot], K contiguous, Ktot = sum widths; row g*H+j = gate g unit j */
+    int Ktot, H, B;
+    const float* gin;   /* [B][4H] pre-activation addend or NULL */
+    long long ld_gin;
+    const float* bias;  /* [4H] or NULL */
+    const float* c_prev; /* [B][H] or NULL (zeros) */
+    long long ld_cprev;
+    float* gates_out;   /* [B][4H] activated gates i,f,g,o (may alias gin) */
+    long long ld_gates;
+    float* c_out;
+    long long ld_c;
+    float* h_out;       /* dropped-out hidden state */
+    long long ld_h;
+    const uint8_t* keep; /* [B][H] or NULL */
+    long long ld_keep;
+    float keep_scale;
+    const int* lens;    /* NULL, or per-row valid length: rows with t >= lens[b] write h=c=gates=0 */
+    int t;
+} t2amd_lstm_step;
+
+int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream);
+
+/* Y[s][B][N] = X[B][K-range s] . W[N][K]^T  (W K-contiguous), s < nsplit */
+typedef struct t2amd_skinny_gemm {
+    t2amd_seg x[3];
+    int nseg;
+    const float* W;   /* [N][Ktot] */
+    int Ktot, N, B;
+    float* Y;         /* [nsplit][B][ldy] */
+    long long ldy;
+    int nsplit;
+    long long split_stride;
+} t2amd_skinny_gemm;
+
+int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream);
+
+typedef struct t2amd_addend {
+    const float* p;   /* NULL = absent */
+    long long ld;
+    int nsplit;       /* >=1 partial slabs summed */
+    long long split_stride;
+} t2amd_addend;
+
+typedef struct t2amd_lstm_bwd {
+    int B, H;
+    t2amd_addend dh[3];   /* gradient wrt the dropped-out h, summed */
+    const float* gates;   /* [B][4H] activated */
+    long long ld_gates;
+    const float* c_prev;  /* NULL = zeros */
+    long long ld_cprev;
+    const float* c;       /* [B][H] */
+    long long ld_c;
+    const uint8_t* keep;
+    long long ld_keep;
+    float keep_scale;
+    float* dc;            /* [B][H] carry, in: dL/dc_t from step t+1, out: dL/dc_{t-1} */
+    long long ld_dc;
+    float* dgates;        /* [B][4H] out */
+    long long ld_dgates;
+    const int* lens;
+    int t;
+} t2amd_lstm_bwd;
+
+int t2amd_lstm_pointwise_bwd_f32(const t2amd_lstm_bwd* a, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Location-sensitive attention, one decoder step (reference model.py:43-86 Attention.forward /
+ * get_alignment_energies, :22-26 LocationLayer, :358-365 concat + cumulative update).
+ * U[d][c][k] = sum_f Wdense[d][f]*Wconv[f][c][k] is the location conv and dense folded
+ * into one 62-tap filter per attention dim (t2amd_fold_location_f32).
+ * ------------------------------------------------------------------------------------ */
+int t2amd_fold_location_f32(const float* wdense, const float* wconv, float* U, void* stream);
+/* dWdense[d][f] = sum_ck dU[d][ck]*Wconv[f][ck]; dWconv[f][ck] = sum_d Wdense[d][f]*dU[d][ck];
+ * dU = sum over nb per-utterance accumulators dU_acc[nb][128][62]; dv = sum_b dv_acc[nb][128] */
+int t2amd_unfold_location_grads_f32(const float* dU_acc, const float* dv_acc, int nb,
+                                    const float* wdense, const float* wconv, float* dwdense,
+                                    float* dwconv, float* dv, void* stream);
+
+typedef struct t2amd_attn_fwd {
+    int B, Ti, E, Hq;        /* E = encoder dim, Hq = attention_rnn_dim */
+    const float* h;          /* [B][Hq] query source (dropped-out attention hidden) */
+    long long ld_h;
+    const float* WqT;        /* [Hq][128] */
+    const float* U;          /* [128][62] */
+    const float* v;          /* [128] */
+    const float* pm;         /* [B][Ti][128] processed memory */
+    const float* memory;     /* [B][Ti][E] */
+    const int* lens;         /* [B] or NULL (no mask: reference inference) */
+    const float* w_prev;     /* previous weights, row b at w_prev + b*ld_wprev; NULL = zeros */
+    long long ld_wprev;
+    float* cum;              /* [B][Ti] running cumulative weights, updated in place */
+    float* cum_save;         /* [B][Ti] copy of cum BEFORE the update, or NULL */
+    float* w_out;            /* row b at w_out + b*ld_wout */
+    long long ld_wout;
+    float* ctx_out;          /* [B][E] */
+    long long ld_ctx;
+    float* q_out;            /* [B][128] or NULL */
+    long long ld_q;
+    const uint8_t* active;   /* [B] or NULL: rows with active[b]==0 are skipped (batched inference) */
+} t2amd_attn_fwd;
+
+int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
+
+typedef struct t2amd_attn_bwd {
+    int B, Ti, E, Hq;
+    t2amd_addend dctx[3];    /* gradient wrt the context vector, column offset pre-applied to p */
+    float* dctx_total;       /* [B][E] out (saved for the deferred d_memory GEMM) */
+    long long ld_dctx_total;
+    const float* d_w_extra;  /* upstream grad wrt this step's weights (alignments output) or NULL */
+    long long ld_dwextra;
+    const float* q;          /* [B][128] saved */
+    long long ld_q;
+    const float* Wq;         /* [128][Hq] */
+    const float* U;          /* [128][62] */
+    const float* v;
+    const float* pm;
+    const float* memory;
+    const int* lens;
+    const float* w;          /* this step's weights, row stride ld_w */
+    long long ld_w;
+    const float* w_prev;     /* NULL = zeros */
+    long long ld_wprev;
+    const float* cum_before; /* [B][Ti] */
+    float* dw_carry;         /* [B][Ti] in: grad wrt w_t from step t+1's location input; out: same for t-1 */
+    float* dcum_carry;       /* [B][Ti] in/out */
+    float* d_pm;             /* [B][Ti][128] accumulated */
+    float* dU_acc;           /* [B][128][62] accumulated */
+    float* dv_acc;           /* [B][128] accumulated */
+    float* dq_out;           /* [B][128] */
+    long long ld_dq;
+    float* dh_out;           /* [B][Hq] = Wq^T dq */
+    long long ld_dh;
+} t2amd_attn_bwd;
+
+int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Device-resident time loops.  One host call enqueues every step's kernels.
+ * ------------------------------------------------------------------------------------ */
+/* Teacher-forced decoder loop, forward: reference model.py:405-411 (the while loop) around
+ * Decoder.decode :340-379.  Prenet, input projection, memory_layer and the mel/gate
+ * projection are hoisted out of the loop by the host (dense GEMMs over all steps). */
+typedef struct t2amd_dec_train {
+    int B, Ti, To, E, Ha, Hd;
+    /* weights */
+    const float* Wa_rec;   /* [4Ha][E+Ha] = [W_ih_att[:, P:P+E] | W_hh_att] */
+    const float* Wd_cat;   /* [4Hd][Ha+E+Hd] = [W_ih_dec | W_hh_dec] */
+    const float* bias_d;   /* [4Hd] = b_ih + b_hh */
+    const float* WqT;      /* [Ha][128] */
+    const float* U;        /* [128][62] */
+    const float* v;        /* [128] */
+    /* inputs */
+    float* GA;             /* [To][B][4Ha] in: prenet input projection + att biases; out: activated gates */
+    const float* memory;   /* [B][Ti][E] */
+    const float* pm;       /* [B][Ti][128] */
+    const int* lens;       /* [B] */
+    const uint8_t* keep_att; /* [To][B][Ha] */
+    const uint8_t* keep_dec; /* [To][B][Hd] */
+    float scale_att, scale_dec;
+    /* saved slabs (outputs) */
+    float* HA;  /* [To][B][Ha] */
+    float* CA;  /* [To][B][Ha] */
+    float* GD;  /* [To][B][4Hd] */
+    float* HD;  /* [To][B][Hd] */
+    float* CD;  /* [To][B][Hd] */
+    float* CTX; /* [To][B][E] */
+    float* Q;   /* [To][B][128] */
+    float* ALIGN; /* [B][To][Ti] */
+    float* CUM;   /* [To][B][Ti] cumulative weights before each step */
+    float* cum_work; /* [B][Ti] scratch (zeroed by the call) */
+} t2amd_dec_train;
+
+int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream);
+
+/* BPTT through the same loop (what autograd replays for reference train.py:226). */
+typedef struct t2amd_dec_train_bwd {
+    t2amd_dec_train f;       /* the forward description (slabs now inputs) */
+    const float* Wa_recT;    /* [E+Ha][4Ha] */
+    const float* Wd_catT;    /* [Ha+E+Hd][4Hd] */
+    const float* Wq;         /* [128][Ha] */
+    const float* DHC;        /* [To][B][Hd+E] grad wrt [h_dec | ctx] from the projection */
+    const float* d_align;    /* [B][To][Ti] or NULL */
+    int nsplit;              /* split-K factor of the two backward skinny GEMMs */
+    /* outputs */
+    float* DGA;  /* [To][B][4Ha] */
+    float* DGD;  /* [To][B][4Hd] */
+    float* DCTX; /* [To][B][E] */
+    float* DQ;   /* [To][B][128] */
+    float* d_pm; /* [B][Ti][128] (zeroed by the call) */
+    float* dU_acc; /* [B][128][62] (zeroed by the call) */
+    float* dv_acc; /* [B][128] (zeroed by the call) */
+    /* workspaces */
+    float* dXd;  /* [nsplit][B][Ha+E+Hd] */
+    float* dXa;  /* [nsplit][B][E+Ha] */
+    float* dc_a; /* [B][Ha] */
+    float* dc_d; /* [B][Hd] */
+    float* dw_carry;   /* [B][Ti] */
+    float* dcum_carry; /* [B][Ti] */
+    float* dq_h;       /* [B][Ha] */
+} t2amd_dec_train_bwd;
+
+int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream);
+
+/* Encoder bi-LSTM over [B][T][.] with packed-sequence semantics (reference model.py:180-188).
+ * GX [B][T][4H] holds x.W_ih^T + b_ih + b_hh (hoisted dense GEMM) and is overwritten with the
+ * activated gates.  out: [B][T][ld_out] slice (direction offset pre-applied). */
+typedef struct t2amd_lstm_seq {
+    int B, T, H, reverse;
+    const float* Whh;   /* [4H][H] */
+    const float* WhhT;  /* [H][4H] (backward only) */
+    float* GX;          /* [B][T][4H] */
+    float* out;         /* h outputs, element (b,t,j) at out[(b*T+t)*ld_out + j] */
+    long long ld_out;
+    float* C;           /* [T][B][H] cell states */
+    const int* lens;
+    /* backward only */
+    const float* dout;  /* grad wrt out, same indexing with ld_dout */
+    long long ld_dout;
+    float* DG;          /* [B][T][4H] out: gate pre-activation grads */
+    float* dX;          /* [B][H] workspace */
+    float* dc;          /* [B][H] workspace */
+} t2amd_lstm_seq;
+
+int t2amd_lstm_seq_fwd_f32(const t2amd_lstm_seq* p, void* stream);
+int t2amd_lstm_seq_bwd_f32(const t2amd_lstm_seq* p, void* stream);
+
+/* Free-running decoder (reference model.py:418-454 Decoder.inference), any B: per-utterance
+ * stop flags on the device, stop test sigmoid(gate) > threshold (strict) after the frame is
+ * emitted.  Runs `n_steps` steps starting at step `t0` (host polls `done_count` between calls). */
+typedef struct t2amd_dec_infer {
+    int B, Ti, E, Ha, Hd, P, C;   /* P = prenet dim, C = n_mel_channels */
+    int t0, n_steps, max_steps;
+    float gate_threshold;
+    const float* W1;       /* prenet layer 0 [P][C] */
+    const float* W2;       /* prenet layer 1 [P][P] */
+    const float* Wa_cat;   /* [4Ha][P+E+Ha] = [W_ih_att | W_hh_att] */
+    const float* bias_a;   /* [4Ha] */
+    const float* Wd_cat;   /* [4Hd][Ha+E+Hd] */
+    const float* bias_d;
+    const float* WqT;
+    const float* U;
+    const float* v;
+    const float* Wpg;      /* [C+1][Hd+E] = [linear_projection ; gate_layer] rows */
+    const float* bias_pg;  /* [C+1] */
+    const float* memory;
+    const float* pm;
+    const int* lens;       /* NULL = unmasked (reference B==1 path) */
+    const uint8_t* keep_prenet; /* [max_steps][2][B][P] */
+    /* state (persist across calls; zeroed by the caller before t0 == 0) */
+    float* h_a;            /* [2][B][Ha] ping-pong: step t reads slot t&1, writes slot (t+1)&1 */
+    float* c_a;            /* [2][B][Ha] */
+    float* c_d;            /* [2][B][Hd] */
+    float* hc;             /* [2][B][Hd+E] = [h_dec | ctx] ping-pong */
+    float* cum;            /* [B][Ti] */
+    float* x_prenet;       /* [2][B][P] scratch */
+    float* gates;          /* [B][4*max(Ha,Hd)] scratch */
+    const float* zero_frame; /* [B][C] zeros (go frame) */
+    /* outputs */
+    float* PG;             /* [max_steps][B][C+1] mel frame + gate logit per step */
+    float* ALIGN;          /* [B][max_steps][Ti] */
+    int* out_lengths;      /* [B] frames emitted incl. the stopping frame (0 while running) */
+    uint8_t* active;       /* [B] 1 while the utterance is still decoding */
+    int* done_count;       /* [1] number of finished utterances */
+} t2amd_dec_infer;
+
+int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TACOTRON2_AMD_H */

@@ -1,0 +1,57 @@
+// Shared device/host helpers for the MI355X (gfx950 / CDNA4) Tacotron 2 mel engine.
+// Wave = 64 lanes everywhere; MFMA f32 forms are exact-f32 (k-ordered fmaf chain).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tacotron2_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define T2_WAVE 64
+
+// Last error text, readable through t2amd_last_error().
+extern "C" void t2amd_set_error_(const char* msg);
+
+#define T2_FAIL(msg)                                                                   \
+    do {                                                                               \
+        t2amd_set_error_(msg);                                                         \
+        return T2AMD_ERR_ARG;                                                          \
+    } while (0)
+
+#define T2_REQUIRE(cond, msg)                                                          \
+    do {                                                                               \
+        if (!(cond)) T2_FAIL(msg);                                                     \
+    } while (0)
+
+#define T2_LAUNCH_CHECK()                                                              \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess) {                                                        \
+            t2amd_set_error_(hipGetErrorString(e_));                                   \
+            return T2AMD_ERR_LAUNCH;                                                   \
+        }                                                                              \
+    } while (0)
+
+#define T2_PROPAGATE(call)                                                             \
+    do {                                                                               \
+        int rc_ = (call);                                                              \
+        if (rc_ != T2AMD_OK) return rc_;                                               \
+    } while (0)
+
+__device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+static inline bool t2_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int t2_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,573 @@
+// HBM-bound kernels of the Tacotron 2 path for gfx950: BatchNorm statistics / apply / backward
+// over channel-last rows, column sums, embedding gather + deterministic scatter, Philox
+// keep-masks and the layout shuffles at the model boundary.  All are coalesced along the
+// channel (fastest) dimension; reductions over rows are two-stage with fp64 partials so the
+// result does not depend on launch geometry beyond a fixed 64-way split.
+#include "common.h"
+
+#define RB 64   // row-blocks of the two-stage column reductions
+
+// ---------------------------------------------------------------------------------------
+// column reductions
+// ---------------------------------------------------------------------------------------
+// partial[rb][n] = sum over rows r = rb, rb+RB, ... of f(x[r][n]);  two quantities.
+template <int MODE>   // 0: (x, x^2)   1: (x) only
+__global__ void colreduce_partial_kernel(const float* __restrict__ x, long long ldx, int M, int N,
+                                         double* __restrict__ ws) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rsub = threadIdx.x >> 6;          // 0..3
+    const int rb = blockIdx.y;
+    __shared__ double s1[4][64], s2[4][64];
+    double a = 0.0, q = 0.0;
+    if (col < N) {
+        for (long long r = (long long)rb * 4 + rsub; r < M; r += (long long)RB * 4) {
+            const float v = x[r * ldx + col];
+            a += (double)v;
+            if (MODE == 0) q += (double)v * (double)v;
+        }
+    }
+    s1[rsub][threadIdx.x & 63] = a;
+    s2[rsub][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rsub == 0 && col < N) {
+        const int c = threadIdx.x & 63;
+        ws[(long long)rb * N + col] = s1[0][c] + s1[1][c] + s1[2][c] + s1[3][c];
+        if (MODE == 0) ws[(long long)(RB + rb) * N + col] = s2[0][c] + s2[1][c] + s2[2][c] + s2[3][c];
+    }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, int M, int N, float* mean,
+                                         float* invstd, float* rmean, float* rvar, float momentum, float eps) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0, q = 0.0;
+    for (int rb = 0; rb < RB; ++rb) {
+        s += ws[(long long)rb * N + n];
+        q += ws[(long long)(RB + rb) * N + n];
+    }
+    const double mu = s / M;
+    double var = q / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[n] = (float)mu;
+    invstd[n] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[n] = (1.f - momentum) * rmean[n] + momentum * (float)mu;
+    if (rvar) {
+        const double unb = (M > 1) ? var * ((double)M / (double)(M - 1)) : var;
+        rvar[n] = (1.f - momentum) * rvar[n] + momentum * (float)unb;
+    }
+}
+
+extern "C" int t2amd_bn_stats_f32(const float* x, long long ldx, int M, int N, double* ws, float* mean,
+                                  float* invstd, float* running_mean, float* running_var, float momentum,
+                                  float eps, void* stream) {
+    T2_REQUIRE(x && ws && mean && invstd && M > 0 && N > 0, "bn_stats: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((colreduce_partial_kernel<0>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, M, N, mean, invstd,
+                       running_mean, running_var, momentum, eps);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+__global__ void bn_eval_invstd_kernel(const float* rvar, float* invstd, int N, float eps) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) invstd[n] = (float)(1.0 / sqrt((double)rvar[n] + (double)eps));
+}
+
+extern "C" int t2amd_bn_eval_invstd_f32(const float* running_var, float* invstd, int N, float eps, void* stream) {
+    T2_REQUIRE(running_var && invstd && N > 0, "bn_eval_invstd: bad args");
+    hipLaunchKernelGGL(bn_eval_invstd_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, running_var,
+                       invstd, N, eps);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+__global__ void colsum_finalize_kernel(const double* __restrict__ ws, int N, float* out, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0;
+    for (int rb = 0; rb < RB; ++rb) s += ws[(long long)rb * N + n];
+    out[n] = accumulate ? out[n] + (float)s : (float)s;
+}
+
+extern "C" int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, double* ws, float* out,
+                                int accumulate, void* stream) {
+    T2_REQUIRE(x && ws && out && M > 0 && N > 0, "colsum: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((colreduce_partial_kernel<1>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, out, accumulate);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm apply (+ activation + dropout)
+// ---------------------------------------------------------------------------------------
+__global__ void bn_act_fwd_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+                                  long long ldy, int M, int N, const float* __restrict__ mean,
+                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, int act, const uint8_t* __restrict__ keep,
+                                  long long ldkeep, float keep_scale, const int* __restrict__ lens, int T) {
+    const long long total = (long long)M * N;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / N;
+        const int n = (int)(i - r * N);
+        float v = (x[r * ldx + n] - mean[n]) * invstd[n] * gamma[n] + beta[n];
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = tanhf(v);
+        if (keep) v = keep[r * ldkeep + n] ? v * keep_scale : 0.f;
+        if (lens) {
+            const int b = (int)(r / T), t = (int)(r - (long long)b * T);
+            if (t >= lens[b]) v = 0.f;
+        }
+        y[r * ldy + n] = v;
+    }
+}
+
+extern "C" int t2amd_bn_act_fwd_f32(const float* x, long long ldx, float* y, long long ldy, int M, int N,
+                                    const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, int act, const uint8_t* keep, long long ldkeep,
+                                    float keep_scale, const int* lens, int row_valid_T, void* stream) {
+    T2_REQUIRE(x && y && mean && invstd && gamma && beta && M > 0 && N > 0, "bn_act_fwd: bad args");
+    T2_REQUIRE(!lens || row_valid_T > 0, "bn_act_fwd: lens needs row_valid_T");
+    int blocks = t2_cdiv((long long)M * N, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, N, mean,
+                       invstd, gamma, beta, act, keep, ldkeep, keep_scale, lens, row_valid_T);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// backward stage 1: dbn = dy * keep*scale * act'(y);  dy <- dbn;  partial sums of dbn and dbn*xhat
+__global__ void bn_act_bwd_stage1_kernel(float* __restrict__ dy, long long lddy, const float* __restrict__ y,
+                                         long long ldy, const float* __restrict__ x, long long ldx, int M, int N,
+                                         const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+                                         const uint8_t* __restrict__ keep, long long ldkeep, float keep_scale,
+                                         double* __restrict__ ws) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rsub = threadIdx.x >> 6;
+    const int rb = blockIdx.y;
+    __shared__ double s1[4][64], s2[4][64];
+    double a = 0.0, q = 0.0;
+    if (col < N) {
+        const float mu = mean[col], is = invstd[col];
+        for (long long r = (long long)rb * 4 + rsub; r < M; r += (long long)RB * 4) {
+            float g = dy[r * lddy + col];
+            const float yv = y[r * ldy + col];
+            if (keep) {
+                if (keep[r * ldkeep + col]) {
+                    g *= keep_scale;
+                    if (act == 1) g = (yv > 0.f) ? g : 0.f;
+                    else if (act == 2) { const float th = yv / keep_scale; g *= (1.f - th * th); }
+                } else {
+                    g = 0.f;
+                }
+            } else {
+                if (act == 1) g = (yv > 0.f) ? g : 0.f;
+                else if (act == 2) g *= (1.f - yv * yv);
+            }
+            dy[r * lddy + col] = g;
+            const float xhat = (x[r * ldx + col] - mu) * is;
+            a += (double)g;
+            q += (double)g * (double)xhat;
+        }
+    }
+    s1[rsub][threadIdx.x & 63] = a;
+    s2[rsub][threadIdx.x & 63] = q;
+    __syncthreads();
+    if (rsub == 0 && col < N) {
+        const int c = threadIdx.x & 63;
+        ws[(long long)rb * N + col] = s1[0][c] + s1[1][c] + s1[2][c] + s1[3][c];
+        ws[(long long)(RB + rb) * N + col] = s2[0][c] + s2[1][c] + s2[2][c] + s2[3][c];
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int N, float* dgamma, float* dbeta) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0, q = 0.0;
+    for (int rb = 0; rb < RB; ++rb) {
+        s += ws[(long long)rb * N + n];
+        q += ws[(long long)(RB + rb) * N + n];
+    }
+    dbeta[n] = (float)s;
+    dgamma[n] = (float)q;
+}
+
+// stage 2: dx = gamma*invstd * (dbn - dbeta/M - xhat*dgamma/M), in place over dy
+__global__ void bn_act_bwd_stage2_kernel(float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                         long long ldx, int M, int N, const float* __restrict__ mean,
+                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                         const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    const long long total = (long long)M * N;
+    const float invM = 1.0f / (float)M;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / N;
+        const int n = (int)(i - r * N);
+        const float is = invstd[n];
+        const float xhat = (x[r * ldx + n] - mean[n]) * is;
+        const float g = dy[r * lddy + n];
+        dy[r * lddy + n] = gamma[n] * is * (g - dbeta[n] * invM - xhat * dgamma[n] * invM);
+    }
+}
+
+extern "C" int t2amd_bn_act_bwd_f32(float* dy, long long lddy, const float* y, long long ldy, const float* x,
+                                    long long ldx, int M, int N, const float* mean, const float* invstd,
+                                    const float* gamma, int act, const uint8_t* keep, long long ldkeep,
+                                    float keep_scale, double* ws, float* dgamma, float* dbeta, void* stream) {
+    T2_REQUIRE(dy && y && x && mean && invstd && gamma && ws && dgamma && dbeta && M > 0 && N > 0, "bn_act_bwd: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_act_bwd_stage1_kernel, dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, M,
+                       N, mean, invstd, act, keep, ldkeep, keep_scale, ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, dgamma, dbeta);
+    int blocks = t2_cdiv((long long)M * N, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_act_bwd_stage2_kernel, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, M, N, mean, invstd,
+                       gamma, dgamma, dbeta);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// embedding
+// ---------------------------------------------------------------------------------------
+__global__ void embedding_fwd_kernel(const long long* __restrict__ ids, const float* __restrict__ table,
+                                     float* __restrict__ out, long long rows, int dim, int nsym) {
+    const long long total = rows * dim;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / dim;
+        const int c = (int)(i - r * dim);
+        long long id = ids[r];
+        if (id < 0) id = 0;
+        if (id >= nsym) id = nsym - 1;
+        out[i] = table[id * dim + c];
+    }
+}
+
+extern "C" int t2amd_embedding_fwd_f32(const long long* ids, const float* table, float* out, long long rows,
+                                       int dim, int n_symbols, void* stream) {
+    T2_REQUIRE(ids && table && out && rows > 0 && dim > 0 && n_symbols > 0, "embedding_fwd: bad args");
+    int blocks = t2_cdiv(rows * dim, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, table, out, rows, dim,
+                       n_symbols);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// one workgroup per (symbol, 256-column slab): deterministic row order, no atomics
+__global__ void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout,
+                                     float* __restrict__ dtable, long long rows, int dim) {
+    const int sym = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    __shared__ long long idbuf[256];
+    float acc = 0.f;
+    for (long long r0 = 0; r0 < rows; r0 += 256) {
+        const long long r = r0 + threadIdx.x;
+        idbuf[threadIdx.x] = (r < rows) ? ids[r] : -1;
+        __syncthreads();
+        const int lim = (rows - r0 < 256) ? (int)(rows - r0) : 256;
+        if (c < dim)
+            for (int k = 0; k < lim; ++k)
+                if (idbuf[k] == sym) acc += dout[(r0 + k) * dim + c];
+        __syncthreads();
+    }
+    if (c < dim) dtable[(long long)sym * dim + c] = acc;
+}
+
+extern "C" int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, long long rows,
+                                       int dim, int n_symbols, void* stream) {
+    T2_REQUIRE(ids && dout && dtable && rows > 0 && dim > 0 && n_symbols > 0, "embedding_bwd: bad args");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                       dout, dtable, rows, dim);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 keep mask
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void philox_keep_kernel(uint8_t* __restrict__ out, long long n, float p, unsigned long long seed,
+                                   unsigned long long offset) {
+    const long long nquad = (n + 3) / 4;
+    for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nquad;
+         q += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long ctr = offset / 4 + (unsigned long long)q;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long i = q * 4 + j;
+            if (i < n) {
+                const float uu = (float)(c[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+                out[i] = (uu >= p) ? 1 : 0;
+            }
+        }
+    }
+}
+
+extern "C" int t2amd_philox_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed,
+                                      unsigned long long offset, void* stream) {
+    T2_REQUIRE(out && n > 0 && p >= 0.f && p < 1.f, "philox: bad args");
+    T2_REQUIRE(offset % 4 == 0, "philox: offset must be a multiple of 4");
+    int blocks = t2_cdiv((n + 3) / 4, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(philox_keep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n, p, seed, offset);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// fill / copy / transpose
+// ---------------------------------------------------------------------------------------
+__global__ void fill_kernel(float* p, long long n, float v) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+extern "C" int t2amd_fill_f32(float* p, long long n, float v, void* stream) {
+    T2_REQUIRE(p && n > 0, "fill: bad args");
+    int blocks = t2_cdiv(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, long long lds_, const float* __restrict__ src2,
+                              long long lds2, float* __restrict__ dst, long long ldd, int rows, int cols) {
+    const long long total = (long long)rows * cols;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cols;
+        const int c = (int)(i - r * cols);
+        float v = src[r * lds_ + c];
+        if (src2) v += src2[r * lds2 + c];
+        dst[r * ldd + c] = v;
+    }
+}
+extern "C" int t2amd_copy2d_f32(const float* src, long long lds_, const float* src2, long long lds2, float* dst,
+                                long long ldd, int rows, int cols, void* stream) {
+    T2_REQUIRE(src && dst && rows > 0 && cols > 0, "copy2d: bad args");
+    int blocks = t2_cdiv((long long)rows * cols, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, lds_, src2, lds2, dst, ldd,
+                       rows, cols);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// 32x32 LDS-tiled transpose, batched
+__global__ void transpose_kernel(const float* __restrict__ src, long long lds_, float* __restrict__ dst, long long ldd,
+                                 int rows, int cols, long long sstride, long long dstride) {
+    __shared__ float tile[32][33];
+    const float* s = src + (long long)blockIdx.z * sstride;
+    float* d = dst + (long long)blockIdx.z * dstride;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? s[(long long)r * lds_ + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < cols && r < rows) d[(long long)c * ldd + r] = tile[tx][j];
+    }
+}
+extern "C" int t2amd_transpose_f32(const float* src, long long lds_, float* dst, long long ldd, int rows, int cols,
+                                   int batch, long long sstride, long long dstride, void* stream) {
+    T2_REQUIRE(src && dst && rows > 0 && cols > 0 && batch > 0, "transpose: bad args");
+    dim3 grid(t2_cdiv(cols, 32), t2_cdiv(rows, 32), batch);
+    T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "transpose: grid too large");
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, rows, cols, sstride,
+                       dstride);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// model-boundary layout kernels
+// ---------------------------------------------------------------------------------------
+// mels [B][C][To] -> X0 [To][B][C], shifted by one frame (X0[0] = go frame = 0)
+__global__ void frames_to_tm_kernel(const float* __restrict__ mels, float* __restrict__ x0, int B, int C, int To) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // read mels[b][c][t-1] coalesced along t
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, t = t0 + tx;          // destination frame index t
+        float v = 0.f;
+        if (c < C && t < To && t >= 1) v = mels[((long long)b * C + c) * To + (t - 1)];
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int t = t0 + j, c = c0 + tx;
+        if (t < To && c < C) x0[((long long)t * B + b) * C + c] = tile[tx][j];
+    }
+}
+extern "C" int t2amd_frames_to_time_major_f32(const float* mels, float* x0, int B, int C, int To, void* stream) {
+    T2_REQUIRE(mels && x0 && B > 0 && C > 0 && To > 0, "frames_to_tm: bad args");
+    dim3 grid(t2_cdiv(To, 32), t2_cdiv(C, 32), B);
+    hipLaunchKernelGGL(frames_to_tm_kernel, grid, dim3(256), 0, (hipStream_t)stream, mels, x0, B, C, To);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+__global__ void split_projection_kernel(const float* __restrict__ pg, float* __restrict__ mel_cl,
+                                        float* __restrict__ gate, const int* __restrict__ out_lens, int B, int C,
+                                        int To) {
+    const long long total = (long long)To * B * (C + 1);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / (C + 1);           // = t*B + b
+        const int c = (int)(i - row * (C + 1));
+        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
+        const float v = pg[i];
+        if (c < C) {
+            mel_cl[((long long)b * To + t) * C + c] = v;
+        } else {
+            const bool pad = out_lens && t >= out_lens[b];
+            gate[(long long)b * To + t] = pad ? 1e3f : v;
+        }
+    }
+}
+extern "C" int t2amd_split_projection_f32(const float* pg, float* mel_cl, float* gate, const int* out_lens, int B,
+                                          int C, int To, void* stream) {
+    T2_REQUIRE(pg && mel_cl && gate && B > 0 && C > 0 && To > 0, "split_projection: bad args");
+    int blocks = t2_cdiv((long long)To * B * (C + 1), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_projection_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pg, mel_cl, gate,
+                       out_lens, B, C, To);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// [B][To][C] -> [B][C][To] with padding mask; mel_cl zeroed in place at padded frames
+__global__ void finalize_outputs_kernel(float* __restrict__ mel_cl, const float* __restrict__ post_cl,
+                                        float* __restrict__ mel, float* __restrict__ mel_post,
+                                        const int* __restrict__ out_lens, int B, int C, int To) {
+    __shared__ float t1[32][33], t2[32][33];
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int len = out_lens ? out_lens[b] : To;
+    for (int j = ty; j < 32; j += 8) {
+        const int t = t0 + j, c = c0 + tx;
+        float m = 0.f, q = 0.f;
+        if (t < To && c < C) {
+            const long long idx = ((long long)b * To + t) * C + c;
+            if (t < len) {
+                m = mel_cl[idx];
+                q = post_cl ? m + post_cl[idx] : 0.f;
+            } else {
+                mel_cl[idx] = 0.f;
+            }
+        }
+        t1[j][tx] = m;
+        t2[j][tx] = q;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, t = t0 + tx;
+        if (c < C && t < To) {
+            const long long o = ((long long)b * C + c) * To + t;
+            mel[o] = t1[tx][j];
+            if (mel_post) mel_post[o] = t2[tx][j];
+        }
+    }
+}
+extern "C" int t2amd_finalize_outputs_f32(float* mel_cl, const float* post_cl, float* mel, float* mel_post,
+                                          const int* out_lens, int B, int C, int To, void* stream) {
+    T2_REQUIRE(mel_cl && mel && B > 0 && C > 0 && To > 0, "finalize_outputs: bad args");
+    T2_REQUIRE((post_cl != nullptr) == (mel_post != nullptr), "finalize_outputs: post_cl and mel_post go together");
+    dim3 grid(t2_cdiv(C, 32), t2_cdiv(To, 32), B);
+    T2_REQUIRE(grid.y <= 65535, "finalize_outputs: To too large");
+    hipLaunchKernelGGL(finalize_outputs_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel_cl, post_cl, mel, mel_post,
+                       out_lens, B, C, To);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// dmel, dmel_post [B][C][To] -> dpost_cl = dmel_post^T ; dmel_cl = dmel^T + dmel_post^T
+__global__ void grads_to_cl_kernel(const float* __restrict__ dmel, const float* __restrict__ dmel_post,
+                                   float* __restrict__ dmel_cl, float* __restrict__ dpost_cl, int B, int C, int To) {
+    __shared__ float t1[32][33], t2[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, t = t0 + tx;
+        float a = 0.f, q = 0.f;
+        if (c < C && t < To) {
+            const long long idx = ((long long)b * C + c) * To + t;
+            if (dmel) a = dmel[idx];
+            if (dmel_post) q = dmel_post[idx];
+        }
+        t1[j][tx] = a;
+        t2[j][tx] = q;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int t = t0 + j, c = c0 + tx;
+        if (t < To && c < C) {
+            const long long o = ((long long)b * To + t) * C + c;
+            dmel_cl[o] = t1[tx][j] + t2[tx][j];
+            dpost_cl[o] = t2[tx][j];
+        }
+    }
+}
+extern "C" int t2amd_grads_to_channel_last_f32(const float* dmel, const float* dmel_post, float* dmel_cl,
+                                               float* dpost_cl, int B, int C, int To, void* stream) {
+    T2_REQUIRE(dmel_cl && dpost_cl && B > 0 && C > 0 && To > 0, "grads_to_cl: bad args");
+    dim3 grid(t2_cdiv(To, 32), t2_cdiv(C, 32), B);
+    hipLaunchKernelGGL(grads_to_cl_kernel, grid, dim3(256), 0, (hipStream_t)stream, dmel, dmel_post, dmel_cl, dpost_cl, B,
+                       C, To);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+__global__ void gather_dout_kernel(const float* __restrict__ dmel_cl, const float* __restrict__ dgate,
+                                   float* __restrict__ dout, int B, int C, int To) {
+    const long long total = (long long)To * B * (C + 1);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / (C + 1);
+        const int c = (int)(i - row * (C + 1));
+        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
+        float v;
+        if (c < C) v = dmel_cl[((long long)b * To + t) * C + c];
+        else v = dgate ? dgate[(long long)b * To + t] : 0.f;
+        dout[i] = v;
+    }
+}
+extern "C" int t2amd_gather_dout_f32(const float* dmel_cl, const float* dgate, float* dout, int B, int C, int To,
+                                     void* stream) {
+    T2_REQUIRE(dmel_cl && dout && B > 0 && C > 0 && To > 0, "gather_dout: bad args");
+    int blocks = t2_cdiv((long long)To * B * (C + 1), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gather_dout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dmel_cl, dgate, dout, B, C,
+                       To);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}

@@ -1,0 +1,358 @@
+// Dense / implicit-conv GEMM for gfx950 on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Tile: 128 x 128 x 16, 256 threads = 4 waves (2 x 2), each wave a 64 x 64 block of
+// 2 x 2 MFMA tiles (4 x 16 accumulator registers).  Both operands are staged k-major in
+// LDS ([k][m], row stride 132 floats) so that the MFMA fragment read (lane -> one f32 at
+// [k = lane>>5][i = lane&31]) is 32 consecutive floats per half-wave: conflict-free.
+// K-contiguous operands are transposed on the LDS store (2-way ds_write_b32 conflicts are
+// free on CDNA4), M/N-contiguous operands go straight in with ds_write_b128.
+// Register double-buffering: tile k+1 is in flight from HBM while tile k is multiplied.
+//
+// Replaces: every nn.Linear / nn.Conv1d forward + dgrad + wgrad on the Tacotron 2 hot path
+// (reference layers.py:17-18, 37-39 and their call sites in model.py; see include/tacotron2_amd.h).
+#include "common.h"
+
+#define GBM 128
+#define GBN 128
+#define GBK 16
+#define GLD 132
+
+struct GemmParams {
+    t2amd_gemm_desc d;
+    int avec, bvec;
+    int ktiles_per_split;
+};
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GBK][GLD];
+
+    const t2amd_gemm_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int z = blockIdx.z;
+    const int bidx = z / d.splitk;
+    const int split = z - bidx * d.splitk;
+    const float* __restrict__ A = d.A + (long long)bidx * d.strideA;
+    const float* __restrict__ B = d.B + (long long)bidx * d.strideB;
+    float* __restrict__ C = d.C + (long long)bidx * d.strideC + (long long)split * d.strideSplitC;
+
+    const int row0 = blockIdx.y * GBM;
+    const int col0 = blockIdx.x * GBN;
+    const int M = d.M, N = d.N;
+    const int kbeg = split * p.ktiles_per_split * GBK;
+    int kend = kbeg + p.ktiles_per_split * GBK;
+    if (kend > d.K) kend = d.K;
+    const int nk = (kend > kbeg) ? (kend - kbeg + GBK - 1) / GBK : 0;
+
+    // ---- per-thread load coordinates -------------------------------------------------
+    // K-contiguous operand: 128 rows x 16 k = 512 float4, f = tid + 256*i -> (row = f>>2, kq = f&3)
+    // M-contiguous operand: 16 k x 128 m  = 512 float4, f -> (kk = f>>5, m4 = f&31)
+    int a_t[2] = {0, 0};          // conv: t index of the thread's rows
+    if (AK && d.convA_T > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = row0 + ((tid + 256 * i) >> 2);
+            a_t[i] = r % d.convA_T;
+        }
+    }
+    int b_tap[2] = {0, 0}, b_ci[2] = {0, 0};
+    if (!BKC && d.convB_T > 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int gn = col0 + ((tid + 256 * i) & 31) * 4;
+            b_tap[i] = gn / d.convB_C;
+            b_ci[i] = gn - b_tap[i] * d.convB_C;
+        }
+    }
+
+    float4 ra[2], rb[2];
+
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (AK) {
+                const int r = f >> 2, kq = f & 3;
+                const int gm = row0 + r;
+                const int gk = k0 + kq * 4;
+                if (gm < M && gk < kend) {
+                    long long srow = gm;
+                    int col = gk;
+                    bool ok = true;
+                    if (d.convA_T > 0) {
+                        const int tap = k0 / d.convA_C;
+                        col = (k0 - tap * d.convA_C) + kq * 4;
+                        const int sh = (tap - d.convA_pad) * d.convA_sign;
+                        const int tt = a_t[i] + sh;
+                        ok = (tt >= 0) && (tt < d.convA_T);
+                        srow = (long long)gm + sh;
+                    }
+                    if (ok) {
+                        const float* src = A + srow * d.lda + col;
+                        if (p.avec) {
+                            v = *reinterpret_cast<const float4*>(src);
+                        } else {
+                            v.x = src[0];
+                            if (gk + 1 < kend) v.y = src[1];
+                            if (gk + 2 < kend) v.z = src[2];
+                            if (gk + 3 < kend) v.w = src[3];
+                        }
+                    }
+                }
+            } else {
+                const int kk = f >> 5, m4 = f & 31;
+                const int gk = k0 + kk;
+                const int gm = row0 + m4 * 4;
+                if (gk < kend && gm < M) {
+                    const float* src = A + (long long)gk * d.lda + gm;
+                    if (p.avec) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (gm + 1 < M) v.y = src[1];
+                        if (gm + 2 < M) v.z = src[2];
+                        if (gm + 3 < M) v.w = src[3];
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+    };
+
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BKC) {
+                const int r = f >> 2, kq = f & 3;
+                const int gn = col0 + r;
+                const int gk = k0 + kq * 4;
+                if (gn < N && gk < kend) {
+                    const float* src = B + (long long)gn * d.ldb + gk;
+                    if (p.bvec) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (gk + 1 < kend) v.y = src[1];
+                        if (gk + 2 < kend) v.z = src[2];
+                        if (gk + 3 < kend) v.w = src[3];
+                    }
+                }
+            } else {
+                const int kk = f >> 5, n4 = f & 31;
+                const int gk = k0 + kk;
+                const int gn = col0 + n4 * 4;
+                if (gk < kend && gn < N) {
+                    long long srow = gk;
+                    int col = gn;
+                    bool ok = true;
+                    if (d.convB_T > 0) {
+                        const int sh = b_tap[i] - d.convB_pad;
+                        const int tt = (gk % d.convB_T) + sh;
+                        ok = (tt >= 0) && (tt < d.convB_T);
+                        srow = (long long)gk + sh;
+                        col = b_ci[i];
+                    }
+                    if (ok) {
+                        const float* src = B + srow * d.ldb + col;
+                        if (p.bvec) {
+                            v = *reinterpret_cast<const float4*>(src);
+                        } else {
+                            v.x = src[0];
+                            if (gn + 1 < N) v.y = src[1];
+                            if (gn + 2 < N) v.z = src[2];
+                            if (gn + 3 < N) v.w = src[3];
+                        }
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            if (AK) {
+                const int r = f >> 2, kq = f & 3;
+                As[buf][kq * 4 + 0][r] = ra[i].x;
+                As[buf][kq * 4 + 1][r] = ra[i].y;
+                As[buf][kq * 4 + 2][r] = ra[i].z;
+                As[buf][kq * 4 + 3][r] = ra[i].w;
+            } else {
+                const int kk = f >> 5, m4 = f & 31;
+                *reinterpret_cast<float4*>(&As[buf][kk][m4 * 4]) = ra[i];
+            }
+            if (BKC) {
+                const int r = f >> 2, kq = f & 3;
+                Bs[buf][kq * 4 + 0][r] = rb[i].x;
+                Bs[buf][kq * 4 + 1][r] = rb[i].y;
+                Bs[buf][kq * 4 + 2][r] = rb[i].z;
+                Bs[buf][kq * 4 + 3][r] = rb[i].w;
+            } else {
+                const int kk = f >> 5, n4 = f & 31;
+                *reinterpret_cast<float4*>(&Bs[buf][kk][n4 * 4]) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        load_a(kbeg);
+        load_b(kbeg);
+        store_lds(0);
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_a(kbeg + (kt + 1) * GBK);
+            load_b(kbeg + (kt + 1) * GBK);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GBK / 2; ++kk) {
+            const int krow = kk * 2 + lhi;
+            const float a0 = As[cur][krow][wm * 64 + l31];
+            const float a1 = As[cur][krow][wm * 64 + 32 + l31];
+            const float b0 = Bs[cur][krow][wn * 64 + l31];
+            const float b1 = Bs[cur][krow][wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue --------------------------------------------------------------------
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int gn = col0 + wn * 64 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int gm = row0 + wm * 64 + tm * 32 + row;
+                if (gm < M && gn < N) {
+                    float val = acc[tm][tn][r];
+                    float* cp = C + (long long)gm * d.ldc + gn;
+                    if (d.bias) val += d.bias[gn];
+                    if (d.accumulate) val += *cp;
+                    if (d.act == 1) val = fmaxf(val, 0.f);
+                    if (d.keep) val = d.keep[(long long)gm * d.ldkeep + gn] ? val * d.keep_scale : 0.f;
+                    *cp = val;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
+    T2_REQUIRE(dp != nullptr, "gemm: null descriptor");
+    GemmParams p;
+    p.d = *dp;
+    t2amd_gemm_desc& d = p.d;
+    T2_REQUIRE(d.A && d.B && d.C, "gemm: null operand");
+    T2_REQUIRE(d.M > 0 && d.N > 0 && d.K >= 0, "gemm: bad dims");
+    if (d.batch < 1) d.batch = 1;
+    if (d.splitk < 1) d.splitk = 1;
+    if (d.convA_T > 0) {
+        T2_REQUIRE(d.a_kcontig == 1, "gemm: convA needs K-contiguous A");
+        T2_REQUIRE(d.convA_C % GBK == 0 && d.K % d.convA_C == 0, "gemm: convA_C must be a multiple of 16 dividing K");
+        T2_REQUIRE(d.convA_sign == 1 || d.convA_sign == -1, "gemm: convA_sign must be +-1");
+        T2_REQUIRE(d.M % d.convA_T == 0, "gemm: convA rows must be whole utterances");
+    }
+    if (d.convB_T > 0) {
+        T2_REQUIRE(d.b_kcontig == 0, "gemm: convB needs N-contiguous B");
+        T2_REQUIRE(d.convB_C % 4 == 0 && d.N % d.convB_C == 0, "gemm: convB_C must be a multiple of 4 dividing N");
+        T2_REQUIRE(d.K % d.convB_T == 0, "gemm: convB rows must be whole utterances");
+    }
+    if (d.splitk > 1) {
+        T2_REQUIRE(!d.bias && !d.keep && d.act == 0 && !d.accumulate, "gemm: split-K needs a plain epilogue");
+    }
+    T2_REQUIRE(d.act == 0 || d.act == 1, "gemm: act must be 0 or 1");
+    // vector-load eligibility
+    if (d.a_kcontig) {
+        const int kdim = d.convA_T > 0 ? d.convA_C : d.K;
+        p.avec = (kdim % 4 == 0) && (d.lda % 4 == 0) && t2_aligned16(d.A) && (d.strideA % 4 == 0);
+    } else {
+        p.avec = (d.M % 4 == 0) && (d.lda % 4 == 0) && t2_aligned16(d.A) && (d.strideA % 4 == 0);
+    }
+    if (d.b_kcontig) {
+        p.bvec = (d.K % 4 == 0) && (d.ldb % 4 == 0) && t2_aligned16(d.B) && (d.strideB % 4 == 0);
+    } else {
+        const int ndim = d.convB_T > 0 ? d.convB_C : d.N;
+        p.bvec = (ndim % 4 == 0) && (d.ldb % 4 == 0) && t2_aligned16(d.B) && (d.strideB % 4 == 0);
+    }
+    const int nkt = t2_cdiv(d.K, GBK);
+    p.ktiles_per_split = t2_cdiv(nkt > 0 ? nkt : 1, d.splitk);
+    dim3 grid(t2_cdiv(d.N, GBN), t2_cdiv(d.M, GBM), d.batch * d.splitk);
+    T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (d.a_kcontig && d.b_kcontig)
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
+    else if (d.a_kcontig && !d.b_kcontig)
+        hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
+    else if (!d.a_kcontig && d.b_kcontig)
+        hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// out[i] (+)= sum_s partials[s][i], optional (co, tap, ci) -> (co, ci, tap) permutation.
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit, long long stride,
+                                     float* __restrict__ out, long long n, int accumulate,
+                                     int taps, int ci_dim) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * stride + i];
+        long long o = i;
+        if (taps > 0) {
+            const long long per_co = (long long)taps * ci_dim;
+            const long long co = i / per_co;
+            const long long rem = i - co * per_co;
+            const long long tap = rem / ci_dim;
+            const long long ci = rem - tap * ci_dim;
+            o = co * per_co + ci * taps + tap;
+        }
+        if (accumulate) s += out[o];
+        out[o] = s;
+    }
+}
+
+extern "C" int t2amd_splitk_reduce_f32(const float* partials, int nsplit, long long stride, float* out,
+                                       long long n, int accumulate, int perm_taps, int perm_ci,
+                                       void* stream) {
+    T2_REQUIRE(partials && out && nsplit >= 1 && n > 0, "splitk_reduce: bad args");
+    if (perm_taps > 0) T2_REQUIRE(perm_ci > 0 && n % ((long long)perm_taps * perm_ci) == 0, "splitk_reduce: bad permutation dims");
+    int blocks = t2_cdiv(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partials,
+                       nsplit, stride, out, n, accumulate, perm_taps, perm_ci);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}

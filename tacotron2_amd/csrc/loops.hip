@@ -1,0 +1,334 @@
+// Host-side time loops: one C call enqueues every step's kernels on the caller's stream.
+// The decoder's ~870 strictly sequential steps run as a chain of three
+// launches per step forward (attention LSTM, attention, decoder LSTM) and five per step
+// backward; nothing returns to Python and nothing synchronises with the host inside a loop.
+#include "common.h"
+
+static inline t2amd_seg seg(const float* p, long long ld, int width) {
+    t2amd_seg s;
+    s.p = p; s.ld = ld; s.width = width;
+    return s;
+}
+static inline t2amd_addend addend(const float* p, long long ld, int nsplit, long long split_stride) {
+    t2amd_addend a;
+    a.p = p; a.ld = ld; a.nsplit = nsplit; a.split_stride = split_stride;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------
+// Decoder, teacher forced, forward  (reference model.py:405-411 around :340-379)
+// ---------------------------------------------------------------------------------------
+extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream) {
+    T2_REQUIRE(p != nullptr, "dec_train_fwd: null args");
+    const int B = p->B, Ti = p->Ti, To = p->To, E = p->E, Ha = p->Ha, Hd = p->Hd;
+    T2_REQUIRE(B > 0 && Ti > 0 && To > 0, "dec_train_fwd: bad dims");
+    T2_REQUIRE(E % 64 == 0 && Ha % 64 == 0 && Hd % 64 == 0, "dec_train_fwd: E, Ha, Hd must be multiples of 64");
+    T2_REQUIRE(p->Wa_rec && p->Wd_cat && p->bias_d && p->WqT && p->U && p->v && p->GA && p->memory && p->pm && p->lens,
+               "dec_train_fwd: null weights/inputs");
+    T2_REQUIRE(p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work,
+               "dec_train_fwd: null slabs");
+    T2_PROPAGATE(t2amd_fill_f32(p->cum_work, (long long)B * Ti, 0.f, stream));
+    const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
+    for (int t = 0; t < To; ++t) {
+        // attention LSTM: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T
+        t2amd_lstm_step a = {};
+        a.nseg = 2;
+        a.x[0] = seg(t ? p->CTX + (t - 1) * sE : nullptr, E, E);
+        a.x[1] = seg(t ? p->HA + (t - 1) * sHa : nullptr, Ha, Ha);
+        a.W = p->Wa_rec; a.Ktot = E + Ha; a.H = Ha; a.B = B;
+        a.gin = p->GA + (long long)t * B * 4 * Ha; a.ld_gin = 4 * Ha;
+        a.bias = nullptr;
+        a.c_prev = t ? p->CA + (t - 1) * sHa : nullptr; a.ld_cprev = Ha;
+        a.gates_out = p->GA + (long long)t * B * 4 * Ha; a.ld_gates = 4 * Ha;
+        a.c_out = p->CA + t * sHa; a.ld_c = Ha;
+        a.h_out = p->HA + t * sHa; a.ld_h = Ha;
+        a.keep = p->keep_att ? p->keep_att + t * sHa : nullptr; a.ld_keep = Ha; a.keep_scale = p->scale_att;
+        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
+
+        // location-sensitive attention
+        t2amd_attn_fwd at = {};
+        at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
+        at.h = p->HA + t * sHa; at.ld_h = Ha;
+        at.WqT = p->WqT; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
+        at.w_prev = t ? p->ALIGN + (long long)(t - 1) * Ti : nullptr; at.ld_wprev = (long long)To * Ti;
+        at.cum = p->cum_work;
+        at.cum_save = p->CUM + (long long)t * B * Ti;
+        at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)To * Ti;
+        at.ctx_out = p->CTX + t * sE; at.ld_ctx = E;
+        at.q_out = p->Q + (long long)t * B * T2AMD_ATT_DIM; at.ld_q = T2AMD_ATT_DIM;
+        T2_PROPAGATE(t2amd_attention_step_fwd_f32(&at, stream));
+
+        // decoder LSTM: gates = bias_d + [h_att_t | ctx_t | h_dec_{t-1}] . Wd_cat^T
+        t2amd_lstm_step d = {};
+        d.nseg = 3;
+        d.x[0] = seg(p->HA + t * sHa, Ha, Ha);
+        d.x[1] = seg(p->CTX + t * sE, E, E);
+        d.x[2] = seg(t ? p->HD + (t - 1) * sHd : nullptr, Hd, Hd);
+        d.W = p->Wd_cat; d.Ktot = Ha + E + Hd; d.H = Hd; d.B = B;
+        d.gin = nullptr; d.bias = p->bias_d;
+        d.c_prev = t ? p->CD + (t - 1) * sHd : nullptr; d.ld_cprev = Hd;
+        d.gates_out = p->GD + (long long)t * B * 4 * Hd; d.ld_gates = 4 * Hd;
+        d.c_out = p->CD + t * sHd; d.ld_c = Hd;
+        d.h_out = p->HD + t * sHd; d.ld_h = Hd;
+        d.keep = p->keep_dec ? p->keep_dec + t * sHd : nullptr; d.ld_keep = Hd; d.keep_scale = p->scale_dec;
+        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
+    }
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Decoder, teacher forced, backward through time
+// ---------------------------------------------------------------------------------------
+extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream) {
+    T2_REQUIRE(p != nullptr, "dec_train_bwd: null args");
+    const t2amd_dec_train& f = p->f;
+    const int B = f.B, Ti = f.Ti, To = f.To, E = f.E, Ha = f.Ha, Hd = f.Hd;
+    const int ns = p->nsplit < 1 ? 1 : p->nsplit;
+    T2_REQUIRE(p->Wa_recT && p->Wd_catT && p->Wq && p->DHC && p->DGA && p->DGD && p->DCTX && p->DQ && p->d_pm &&
+                   p->dU_acc && p->dv_acc && p->dXd && p->dXa && p->dc_a && p->dc_d && p->dw_carry &&
+                   p->dcum_carry && p->dq_h,
+               "dec_train_bwd: null pointer");
+    T2_REQUIRE((4 * Ha) % 64 == 0 && (4 * Hd) % 64 == 0, "dec_train_bwd: 4H must be a multiple of 64");
+    const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
+    const int Kd = Ha + E + Hd, Ka = E + Ha;
+    const long long strXd = (long long)B * Kd, strXa = (long long)B * Ka;
+
+    T2_PROPAGATE(t2amd_fill_f32(p->d_pm, (long long)B * Ti * T2AMD_ATT_DIM, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dU_acc, (long long)B * T2AMD_ATT_DIM * T2AMD_LOC_TAPS, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dv_acc, (long long)B * T2AMD_ATT_DIM, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dc_a, sHa, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dc_d, sHd, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dw_carry, (long long)B * Ti, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dcum_carry, (long long)B * Ti, 0.f, stream));
+
+    for (int t = To - 1; t >= 0; --t) {
+        const bool last = (t == To - 1);
+        // 1. decoder LSTM cell backward
+        t2amd_lstm_bwd lb = {};
+        lb.B = B; lb.H = Hd;
+        lb.dh[0] = addend(p->DHC + (long long)t * B * (Hd + E), Hd + E, 1, 0);
+        lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXd + Ha + E, Kd, ns, strXd);
+        lb.dh[2] = addend(nullptr, 0, 1, 0);
+        lb.gates = f.GD + (long long)t * B * 4 * Hd; lb.ld_gates = 4 * Hd;
+        lb.c_prev = t ? f.CD + (t - 1) * sHd : nullptr; lb.ld_cprev = Hd;
+        lb.c = f.CD + t * sHd; lb.ld_c = Hd;
+        lb.keep = f.keep_dec ? f.keep_dec + t * sHd : nullptr; lb.ld_keep = Hd; lb.keep_scale = f.scale_dec;
+        lb.dc = p->dc_d; lb.ld_dc = Hd;
+        lb.dgates = p->DGD + (long long)t * B * 4 * Hd; lb.ld_dgates = 4 * Hd;
+        T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, stream));
+
+        // 2. d[h_att_t | ctx_t | h_dec_{t-1}] = dgates_d . Wd_cat
+        t2amd_skinny_gemm g = {};
+        g.nseg = 1;
+        g.x[0] = seg(p->DGD + (long long)t * B * 4 * Hd, 4 * Hd, 4 * Hd);
+        g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
+        g.Y = p->dXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd;
+        T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
+
+        // 3. attention backward
+        t2amd_attn_bwd ab = {};
+        ab.B = B; ab.Ti = Ti; ab.E = E; ab.Hq = Ha;
+        ab.dctx[0] = addend(p->DHC + (long long)t * B * (Hd + E) + Hd, Hd + E, 1, 0);
+        ab.dctx[1] = addend(p->dXd + Ha, Kd, ns, strXd);
+        ab.dctx[2] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXa, Ka, ns, strXa);
+        ab.dctx_total = p->DCTX + t * sE; ab.ld_dctx_total = E;
+        ab.d_w_extra = p->d_align ? p->d_align + (long long)t * Ti : nullptr; ab.ld_dwextra = (long long)To * Ti;
+        ab.q = f.Q + (long long)t * B * T2AMD_ATT_DIM; ab.ld_q = T2AMD_ATT_DIM;
+        ab.Wq = p->Wq; ab.U = f.U; ab.v = f.v; ab.pm = f.pm; ab.memory = f.memory; ab.lens = f.lens;
+        ab.w = f.ALIGN + (long long)t * Ti; ab.ld_w = (long long)To * Ti;
+        ab.w_prev = t ? f.ALIGN + (long long)(t - 1) * Ti : nullptr; ab.ld_wprev = (long long)To * Ti;
+        ab.cum_before = f.CUM + (long long)t * B * Ti;
+        ab.dw_carry = p->dw_carry; ab.dcum_carry = p->dcum_carry;
+        ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
+        ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
+        ab.dh_out = p->dq_h; ab.ld_dh = Ha;
+        T2_PROPAGATE(t2amd_attention_step_bwd_f32(&ab, stream));
+
+        // 4. attention LSTM cell backward
+        t2amd_lstm_bwd la = {};
+        la.B = B; la.H = Ha;
+        la.dh[0] = addend(p->dXd, Kd, ns, strXd);
+        la.dh[1] = addend(p->dq_h, Ha, 1, 0);
+        la.dh[2] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXa + E, Ka, ns, strXa);
+        la.gates = f.GA + (long long)t * B * 4 * Ha; la.ld_gates = 4 * Ha;
+        la.c_prev = t ? f.CA + (t - 1) * sHa : nullptr; la.ld_cprev = Ha;
+        la.c = f.CA + t * sHa; la.ld_c = Ha;
+        la.keep = f.keep_att ? f.keep_att + t * sHa : nullptr; la.ld_keep = Ha; la.keep_scale = f.scale_att;
+        la.dc = p->dc_a; la.ld_dc = Ha;
+        la.dgates = p->DGA + (long long)t * B * 4 * Ha; la.ld_dgates = 4 * Ha;
+        T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&la, stream));
+
+        // 5. d[ctx_{t-1} | h_att_{t-1}] = dgates_a . Wa_rec
+        t2amd_skinny_gemm ga = {};
+        ga.nseg = 1;
+        ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
+        ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
+        ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa;
+        T2_PROPAGATE(t2amd_skinny_gemm_f32(&ga, stream));
+    }
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Encoder LSTM direction  (reference model.py:181-188)
+// ---------------------------------------------------------------------------------------
+extern "C" int t2amd_lstm_seq_fwd_f32(const t2amd_lstm_seq* p, void* stream) {
+    T2_REQUIRE(p && p->Whh && p->GX && p->out && p->C && p->lens, "lstm_seq_fwd: null pointer");
+    const int B = p->B, T = p->T, H = p->H;
+    T2_REQUIRE(B > 0 && T > 0 && H % 64 == 0, "lstm_seq_fwd: H must be a multiple of 64");
+    for (int s = 0; s < T; ++s) {
+        const int t = p->reverse ? T - 1 - s : s;
+        const int tp = p->reverse ? t + 1 : t - 1;       // previous step in processing order
+        const bool first = (s == 0);
+        t2amd_lstm_step a = {};
+        a.nseg = 1;
+        a.x[0] = seg(first ? nullptr : p->out + (long long)tp * p->ld_out, (long long)T * p->ld_out, H);
+        a.W = p->Whh; a.Ktot = H; a.H = H; a.B = B;
+        a.gin = p->GX + (long long)t * 4 * H; a.ld_gin = (long long)T * 4 * H;
+        a.c_prev = first ? nullptr : p->C + (long long)tp * B * H; a.ld_cprev = H;
+        a.gates_out = p->GX + (long long)t * 4 * H; a.ld_gates = (long long)T * 4 * H;
+        a.c_out = p->C + (long long)t * B * H; a.ld_c = H;
+        a.h_out = p->out + (long long)t * p->ld_out; a.ld_h = (long long)T * p->ld_out;
+        a.lens = p->lens; a.t = t;
+        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
+    }
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_lstm_seq_bwd_f32(const t2amd_lstm_seq* p, void* stream) {
+    T2_REQUIRE(p && p->WhhT && p->GX && p->C && p->lens && p->dout && p->DG && p->dX && p->dc,
+               "lstm_seq_bwd: null pointer");
+    const int B = p->B, T = p->T, H = p->H;
+    T2_REQUIRE(B > 0 && T > 0 && H % 64 == 0, "lstm_seq_bwd: H must be a multiple of 64");
+    T2_PROPAGATE(t2amd_fill_f32(p->dc, (long long)B * H, 0.f, stream));
+    for (int s = T - 1; s >= 0; --s) {        // reverse of the processing order
+        const int t = p->reverse ? T - 1 - s : s;
+        const int tp = p->reverse ? t + 1 : t - 1;
+        const bool last = (s == T - 1);
+        t2amd_lstm_bwd lb = {};
+        lb.B = B; lb.H = H;
+        lb.dh[0] = addend(p->dout + (long long)t * p->ld_dout, (long long)T * p->ld_dout, 1, 0);
+        lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dX, H, 1, 0);
+        lb.dh[2] = addend(nullptr, 0, 1, 0);
+        lb.gates = p->GX + (long long)t * 4 * H; lb.ld_gates = (long long)T * 4 * H;
+        lb.c_prev = (s == 0) ? nullptr : p->C + (long long)tp * B * H; lb.ld_cprev = H;
+        lb.c = p->C + (long long)t * B * H; lb.ld_c = H;
+        lb.dc = p->dc; lb.ld_dc = H;
+        lb.dgates = p->DG + (long long)t * 4 * H; lb.ld_dgates = (long long)T * 4 * H;
+        lb.lens = p->lens; lb.t = t;
+        T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, stream));
+        if (s > 0) {
+            t2amd_skinny_gemm g = {};
+            g.nseg = 1;
+            g.x[0] = seg(p->DG + (long long)t * 4 * H, (long long)T * 4 * H, 4 * H);
+            g.W = p->WhhT; g.Ktot = 4 * H; g.N = H; g.B = B;
+            g.Y = p->dX; g.ldy = H; g.nsplit = 1; g.split_stride = 0;
+            T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
+        }
+    }
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Free-running decoder (reference model.py:418-454)
+// ---------------------------------------------------------------------------------------
+// stop test after the frame is emitted: sigmoid(gate) > threshold (strict); the stopping frame
+// is part of the output (reference model.py:439-444).  One thread per utterance.
+__global__ void infer_finish_step_kernel(const float* __restrict__ pg_t, int B, int C, int t, int max_steps,
+                                         float thr, int* __restrict__ out_lengths, uint8_t* __restrict__ active,
+                                         int* __restrict__ done_count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || !active[b]) return;
+    const float g = pg_t[(long long)b * (C + 1) + C];
+    const float sg = 1.0f / (1.0f + expf(-g));
+    if (sg > thr || t + 1 >= max_steps) {
+        out_lengths[b] = t + 1;
+        active[b] = 0;
+        atomicAdd(done_count, 1);
+    }
+}
+
+extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream) {
+    T2_REQUIRE(p != nullptr, "dec_infer: null args");
+    const int B = p->B, Ti = p->Ti, E = p->E, Ha = p->Ha, Hd = p->Hd, P = p->P, C = p->C;
+    T2_REQUIRE(B > 0 && Ti > 0 && p->n_steps > 0 && p->t0 >= 0 && p->t0 + p->n_steps <= p->max_steps,
+               "dec_infer: bad step range");
+    T2_REQUIRE(E % 64 == 0 && Ha % 64 == 0 && Hd % 64 == 0 && P % 64 == 0, "dec_infer: E, Ha, Hd, P must be multiples of 64");
+    T2_REQUIRE(p->W1 && p->W2 && p->Wa_cat && p->bias_a && p->Wd_cat && p->bias_d && p->WqT && p->U && p->v &&
+                   p->Wpg && p->bias_pg && p->memory && p->pm && p->keep_prenet,
+               "dec_infer: null weights/inputs");
+    T2_REQUIRE(p->h_a && p->c_a && p->c_d && p->hc && p->cum && p->x_prenet && p->gates && p->zero_frame && p->PG &&
+                   p->ALIGN && p->out_lengths && p->active && p->done_count,
+               "dec_infer: null state/outputs");
+    const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sHC = (long long)B * (Hd + E);
+    const long long sP = (long long)B * P, sPG = (long long)B * (C + 1);
+    const float two = 1.0f / (1.0f - 0.5f);
+    hipStream_t s = (hipStream_t)stream;
+    for (int t = p->t0; t < p->t0 + p->n_steps; ++t) {
+        const int rd = t & 1, wr = rd ^ 1;
+        // prenet (dropout p = 0.5 always on, reference model.py:99)
+        t2amd_gemm_desc g1 = {};
+        g1.A = t ? p->PG + (long long)(t - 1) * sPG : p->zero_frame;
+        g1.lda = t ? C + 1 : C;
+        g1.B = p->W1; g1.ldb = C; g1.C = p->x_prenet; g1.ldc = P;
+        g1.M = B; g1.N = P; g1.K = C; g1.a_kcontig = 1; g1.b_kcontig = 1; g1.batch = 1; g1.splitk = 1;
+        g1.act = 1; g1.keep = p->keep_prenet + ((long long)t * 2 + 0) * sP; g1.ldkeep = P; g1.keep_scale = two;
+        T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
+        t2amd_gemm_desc g2 = {};
+        g2.A = p->x_prenet; g2.lda = P; g2.B = p->W2; g2.ldb = P; g2.C = p->x_prenet + sP; g2.ldc = P;
+        g2.M = B; g2.N = P; g2.K = P; g2.a_kcontig = 1; g2.b_kcontig = 1; g2.batch = 1; g2.splitk = 1;
+        g2.act = 1; g2.keep = p->keep_prenet + ((long long)t * 2 + 1) * sP; g2.ldkeep = P; g2.keep_scale = two;
+        T2_PROPAGATE(t2amd_gemm_f32(&g2, stream));
+
+        // attention LSTM on [prenet | ctx_{t-1} | h_att_{t-1}]  (no dropout in eval)
+        t2amd_lstm_step a = {};
+        a.nseg = 3;
+        a.x[0] = seg(p->x_prenet + sP, P, P);
+        a.x[1] = seg(p->hc + rd * sHC + Hd, Hd + E, E);
+        a.x[2] = seg(p->h_a + rd * sHa, Ha, Ha);
+        a.W = p->Wa_cat; a.Ktot = P + E + Ha; a.H = Ha; a.B = B;
+        a.bias = p->bias_a;
+        a.c_prev = p->c_a + rd * sHa; a.ld_cprev = Ha;
+        a.gates_out = p->gates; a.ld_gates = 4 * Ha;
+        a.c_out = p->c_a + wr * sHa; a.ld_c = Ha;
+        a.h_out = p->h_a + wr * sHa; a.ld_h = Ha;
+        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
+
+        t2amd_attn_fwd at = {};
+        at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
+        at.h = p->h_a + wr * sHa; at.ld_h = Ha;
+        at.WqT = p->WqT; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
+        at.w_prev = t ? p->ALIGN + (long long)(t - 1) * Ti : nullptr; at.ld_wprev = (long long)p->max_steps * Ti;
+        at.cum = p->cum; at.cum_save = nullptr;
+        at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)p->max_steps * Ti;
+        at.ctx_out = p->hc + wr * sHC + Hd; at.ld_ctx = Hd + E;
+        at.q_out = nullptr;
+        T2_PROPAGATE(t2amd_attention_step_fwd_f32(&at, stream));
+
+        t2amd_lstm_step d = {};
+        d.nseg = 3;
+        d.x[0] = seg(p->h_a + wr * sHa, Ha, Ha);
+        d.x[1] = seg(p->hc + wr * sHC + Hd, Hd + E, E);
+        d.x[2] = seg(p->hc + rd * sHC, Hd + E, Hd);
+        d.W = p->Wd_cat; d.Ktot = Ha + E + Hd; d.H = Hd; d.B = B;
+        d.bias = p->bias_d;
+        d.c_prev = p->c_d + rd * sHd; d.ld_cprev = Hd;
+        d.gates_out = p->gates; d.ld_gates = 4 * Hd;
+        d.c_out = p->c_d + wr * sHd; d.ld_c = Hd;
+        d.h_out = p->hc + wr * sHC; d.ld_h = Hd + E;
+        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
+
+        // frame + gate: PG[t] = [h_dec | ctx] . Wpg^T + bias
+        t2amd_gemm_desc gp = {};
+        gp.A = p->hc + wr * sHC; gp.lda = Hd + E; gp.B = p->Wpg; gp.ldb = Hd + E;
+        gp.C = p->PG + (long long)t * sPG; gp.ldc = C + 1;
+        gp.M = B; gp.N = C + 1; gp.K = Hd + E; gp.a_kcontig = 1; gp.b_kcontig = 1; gp.batch = 1; gp.splitk = 1;
+        gp.bias = p->bias_pg;
+        T2_PROPAGATE(t2amd_gemm_f32(&gp, stream));
+
+        hipLaunchKernelGGL(infer_finish_step_kernel, dim3(t2_cdiv(B, 64)), dim3(64), 0, s, p->PG + (long long)t * sPG, B,
+                           C, t, p->max_steps, p->gate_threshold, p->out_lengths, p->active, p->done_count);
+        T2_LAUNCH_CHECK();
+    }
+    return T2AMD_OK;
+}
