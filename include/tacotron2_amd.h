@@ -43,6 +43,9 @@ int t2amd_abi_version(void);
 const char* t2amd_last_error(void);
 /* sizeof() of every struct below, in declaration order, for binding self-checks. */
 int t2amd_struct_sizes(int* out, int max_n);
+/* Validate-only mode: all argument checks and host loops run, no kernel is launched (outputs are
+ * left untouched).  For CPU-side tests of the binding; not a compute path. */
+int t2amd_set_validate_only(int on);
 
 /* ------------------------------------------------------------------------------------
  * Dense / implicit-convolution GEMM on exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -152,6 +155,9 @@ int t2amd_grads_to_channel_last_f32(const float* dmel, const float* dmel_post, f
 /* D_out [To][B][C+1] = [ dmel_cl[b][t][:] | dgate[b][t] ] */
 int t2amd_gather_dout_f32(const float* dmel_cl, const float* dgate, float* dout, int B, int C,
                           int To, void* stream);
+/* Prenet backward, elementwise part (reference model.py:99 F.dropout(F.relu(.)) under autograd):
+ * dy <- (y > 0) ? dy*scale : 0, y being the forward output relu(pre)*keep*scale. */
+int t2amd_relu_dropout_bwd_f32(float* dy, const float* y, float scale, long long n, void* stream);
 /* alignments slab [B][To][Ti] passthrough needs no kernel. */
 
 /* ------------------------------------------------------------------------------------

@@ -298,9 +298,14 @@ def decoder_inference(memory, sd, hp, prenet_keep, max_decoder_steps=None, gate_
 # ----------------------------------------------------------------------------
 # Postnet  (reference model.py:103-146)
 # ----------------------------------------------------------------------------
-def postnet_forward(x, sd, hp, masks, training, new_buffers=None):
+def postnet_forward(x, sd, hp, masks, training, new_buffers=None, frame_valid=None):
+    """``frame_valid`` (B,1,T) is only used by batched inference: frames beyond an
+    utterance's own stop are zeroed before every convolution, which is the zero padding a B == 1
+    run of that utterance sees."""
     n = hp.postnet_n_convolutions
     for i in range(n):
+        if frame_valid is not None:
+            x = x * frame_valid
         x = _conv_bn(x, sd, 'postnet.convolutions.%d' % i, training, new_buffers)
         if i < n - 1:
             x = torch.tanh(x)
@@ -359,8 +364,15 @@ def tacotron2_inference(sd, hp, text, prenet_keep, max_decoder_steps=None, gate_
         memory = bilstm(x.transpose(1, 2)[:, :T], input_lengths, sd)
     mel, gate, align, lengths, hit_max = decoder_inference(
         memory, sd, hp, prenet_keep, max_decoder_steps, gate_threshold, input_lengths)
-    post = postnet_forward(mel, sd, hp, None, False)
-    return [mel, mel + post, gate, align], lengths, hit_max
+    frame_valid = None
+    if input_lengths is not None:
+        frame_valid = get_mask_from_lengths(lengths, mel.shape[2]).unsqueeze(1).to(mel.dtype)
+        mel = mel * frame_valid
+    post = postnet_forward(mel, sd, hp, None, False, frame_valid=frame_valid)
+    mel_post = mel + post
+    if frame_valid is not None:
+        mel_post = mel_post * frame_valid
+    return [mel, mel_post, gate, align], lengths, hit_max
 
 
 def tacotron2_loss(outputs, targets):

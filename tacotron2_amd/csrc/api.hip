@@ -9,6 +9,9 @@ extern "C" void t2amd_set_error_(const char* msg) {
     g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* t2amd_last_error(void) { return g_err; }
+static int g_validate_only = 0;
+extern "C" int t2amd_validate_only_flag_(void) { return g_validate_only; }
+extern "C" int t2amd_set_validate_only(int on) { g_validate_only = on ? 1 : 0; return T2AMD_OK; }
 extern "C" int t2amd_abi_version(void) { return T2AMD_ABI_VERSION; }
 
 extern "C" int t2amd_struct_sizes(int* out, int max_n) {

@@ -198,8 +198,8 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     const size_t lds = sizeof(float) * ((size_t)a->Hq + scratch + AD + 2 * p.tip + 2 * a->Ti + 32);
     T2_REQUIRE(lds <= 160 * 1024, "attn_fwd: Ti/Hq/E need more than 160 KiB of LDS");
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(a->B), dim3(1024), lds, (hipStream_t)stream, p);
+        if (!t2amd_validate_only_flag_()) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    T2_LAUNCH(attn_fwd_kernel, dim3(a->B), dim3(1024), lds, (hipStream_t)stream, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -466,8 +466,8 @@ static int attn_bwd_launch(const t2amd_attn_bwd* a, const float* UT, void* strea
     T2_REQUIRE((size_t)TC * DP_LD >= (size_t)AD * 63, "attn_bwd: alias size");
     T2_REQUIRE(lds <= 160 * 1024, "attn_bwd: needs more than 160 KiB of LDS");
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(a->B), dim3(BT), lds, (hipStream_t)stream, p);
+        if (!t2amd_validate_only_flag_()) (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    T2_LAUNCH(attn_bwd_kernel, dim3(a->B), dim3(BT), lds, (hipStream_t)stream, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -498,7 +498,7 @@ __global__ void fold_location_kernel(const float* __restrict__ wd, const float* 
 
 extern "C" int t2amd_fold_location_f32(const float* wdense, const float* wconv, float* U, void* stream) {
     T2_REQUIRE(wdense && wconv && U && t2_aligned16(U), "fold_location: bad pointers");
-    hipLaunchKernelGGL(fold_location_kernel, dim3(AD * 64 / 256), dim3(256), 0, (hipStream_t)stream, wdense, wconv, U);
+    T2_LAUNCH(fold_location_kernel, dim3(AD * 64 / 256), dim3(256), 0, (hipStream_t)stream, wdense, wconv, U);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -540,7 +540,7 @@ extern "C" int t2amd_unfold_location_grads_f32(const float* dU_acc, const float*
     T2_REQUIRE(dU_acc && dv_acc && nb > 0 && wdense && wconv && dwdense && dwconv && dv, "unfold_location: bad args");
     // dU_acc[0] is reused as the reduction target after its own contribution has been read:
     // write the sum into slot 0 (the caller treats dU_acc as scratch after this call).
-    hipLaunchKernelGGL(unfold_location_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dU_acc, dv_acc, nb,
+    T2_LAUNCH(unfold_location_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dU_acc, dv_acc, nb,
                        wdense, wconv, dwdense, dwconv, dv, const_cast<float*>(dU_acc));
     T2_LAUNCH_CHECK();
     return T2AMD_OK;

@@ -25,8 +25,20 @@ extern "C" void t2amd_set_error_(const char* msg);
         if (!(cond)) T2_FAIL(msg);                                                     \
     } while (0)
 
+// Validate-only mode (t2amd_set_validate_only): every host-side check and loop runs, no kernel is
+// launched.  Used by the CPU test-suite to exercise argument plumbing without a GPU; outputs are
+// left untouched, so it is NOT a compute path.
+extern "C" int t2amd_validate_only_flag_(void);
+
+#define T2_LAUNCH(kern, grid, block, lds, stream, ...)                                 \
+    do {                                                                               \
+        if (!t2amd_validate_only_flag_())                                              \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);           \
+    } while (0)
+
 #define T2_LAUNCH_CHECK()                                                              \
     do {                                                                               \
+        if (t2amd_validate_only_flag_()) break;                                        \
         hipError_t e_ = hipGetLastError();                                             \
         if (e_ != hipSuccess) {                                                        \
             t2amd_set_error_(hipGetErrorString(e_));                                   \

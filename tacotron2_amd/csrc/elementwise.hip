@@ -62,8 +62,8 @@ extern "C" int t2amd_bn_stats_f32(const float* x, long long ldx, int M, int N, d
                                   float eps, void* stream) {
     T2_REQUIRE(x && ws && mean && invstd && M > 0 && N > 0, "bn_stats: bad args");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((colreduce_partial_kernel<0>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, M, N, mean, invstd,
+    T2_LAUNCH((colreduce_partial_kernel<0>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    T2_LAUNCH(bn_stats_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, M, N, mean, invstd,
                        running_mean, running_var, momentum, eps);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -76,7 +76,7 @@ __global__ void bn_eval_invstd_kernel(const float* rvar, float* invstd, int N, f
 
 extern "C" int t2amd_bn_eval_invstd_f32(const float* running_var, float* invstd, int N, float eps, void* stream) {
     T2_REQUIRE(running_var && invstd && N > 0, "bn_eval_invstd: bad args");
-    hipLaunchKernelGGL(bn_eval_invstd_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, running_var,
+    T2_LAUNCH(bn_eval_invstd_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, (hipStream_t)stream, running_var,
                        invstd, N, eps);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -94,8 +94,8 @@ extern "C" int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, dou
                                 int accumulate, void* stream) {
     T2_REQUIRE(x && ws && out && M > 0 && N > 0, "colsum: bad args");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((colreduce_partial_kernel<1>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, out, accumulate);
+    T2_LAUNCH((colreduce_partial_kernel<1>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    T2_LAUNCH(colsum_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, out, accumulate);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -133,7 +133,7 @@ extern "C" int t2amd_bn_act_fwd_f32(const float* x, long long ldx, float* y, lon
     T2_REQUIRE(!lens || row_valid_T > 0, "bn_act_fwd: lens needs row_valid_T");
     int blocks = t2_cdiv((long long)M * N, 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, N, mean,
+    T2_LAUNCH(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, N, mean,
                        invstd, gamma, beta, act, keep, ldkeep, keep_scale, lens, row_valid_T);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -219,12 +219,12 @@ extern "C" int t2amd_bn_act_bwd_f32(float* dy, long long lddy, const float* y, l
                                     float keep_scale, double* ws, float* dgamma, float* dbeta, void* stream) {
     T2_REQUIRE(dy && y && x && mean && invstd && gamma && ws && dgamma && dbeta && M > 0 && N > 0, "bn_act_bwd: bad args");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_act_bwd_stage1_kernel, dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, M,
+    T2_LAUNCH(bn_act_bwd_stage1_kernel, dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, M,
                        N, mean, invstd, act, keep, ldkeep, keep_scale, ws);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, dgamma, dbeta);
+    T2_LAUNCH(bn_bwd_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, dgamma, dbeta);
     int blocks = t2_cdiv((long long)M * N, 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_act_bwd_stage2_kernel, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, M, N, mean, invstd,
+    T2_LAUNCH(bn_act_bwd_stage2_kernel, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, M, N, mean, invstd,
                        gamma, dgamma, dbeta);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -252,7 +252,7 @@ extern "C" int t2amd_embedding_fwd_f32(const long long* ids, const float* table,
     T2_REQUIRE(ids && table && out && rows > 0 && dim > 0 && n_symbols > 0, "embedding_fwd: bad args");
     int blocks = t2_cdiv(rows * dim, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(embedding_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, table, out, rows, dim,
+    T2_LAUNCH(embedding_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, table, out, rows, dim,
                        n_symbols);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -281,7 +281,7 @@ __global__ void embedding_bwd_kernel(const long long* __restrict__ ids, const fl
 extern "C" int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, long long rows,
                                        int dim, int n_symbols, void* stream) {
     T2_REQUIRE(ids && dout && dtable && rows > 0 && dim > 0 && n_symbols > 0, "embedding_bwd: bad args");
-    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream, ids,
+    T2_LAUNCH(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream, ids,
                        dout, dtable, rows, dim);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -331,7 +331,7 @@ extern "C" int t2amd_philox_keep_mask(uint8_t* out, long long n, float p, unsign
     T2_REQUIRE(offset % 4 == 0, "philox: offset must be a multiple of 4");
     int blocks = t2_cdiv((n + 3) / 4, 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(philox_keep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n, p, seed, offset);
+    T2_LAUNCH(philox_keep_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, n, p, seed, offset);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -347,7 +347,7 @@ extern "C" int t2amd_fill_f32(float* p, long long n, float v, void* stream) {
     T2_REQUIRE(p && n > 0, "fill: bad args");
     int blocks = t2_cdiv(n, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    T2_LAUNCH(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, v);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -369,7 +369,7 @@ extern "C" int t2amd_copy2d_f32(const float* src, long long lds_, const float* s
     T2_REQUIRE(src && dst && rows > 0 && cols > 0, "copy2d: bad args");
     int blocks = t2_cdiv((long long)rows * cols, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(copy2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, lds_, src2, lds2, dst, ldd,
+    T2_LAUNCH(copy2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, lds_, src2, lds2, dst, ldd,
                        rows, cols);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -398,7 +398,7 @@ extern "C" int t2amd_transpose_f32(const float* src, long long lds_, float* dst,
     T2_REQUIRE(src && dst && rows > 0 && cols > 0 && batch > 0, "transpose: bad args");
     dim3 grid(t2_cdiv(cols, 32), t2_cdiv(rows, 32), batch);
     T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "transpose: grid too large");
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, rows, cols, sstride,
+    T2_LAUNCH(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, lds_, dst, ldd, rows, cols, sstride,
                        dstride);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -429,7 +429,7 @@ __global__ void frames_to_tm_kernel(const float* __restrict__ mels, float* __res
 extern "C" int t2amd_frames_to_time_major_f32(const float* mels, float* x0, int B, int C, int To, void* stream) {
     T2_REQUIRE(mels && x0 && B > 0 && C > 0 && To > 0, "frames_to_tm: bad args");
     dim3 grid(t2_cdiv(To, 32), t2_cdiv(C, 32), B);
-    hipLaunchKernelGGL(frames_to_tm_kernel, grid, dim3(256), 0, (hipStream_t)stream, mels, x0, B, C, To);
+    T2_LAUNCH(frames_to_tm_kernel, grid, dim3(256), 0, (hipStream_t)stream, mels, x0, B, C, To);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -457,7 +457,7 @@ extern "C" int t2amd_split_projection_f32(const float* pg, float* mel_cl, float*
     T2_REQUIRE(pg && mel_cl && gate && B > 0 && C > 0 && To > 0, "split_projection: bad args");
     int blocks = t2_cdiv((long long)To * B * (C + 1), 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(split_projection_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pg, mel_cl, gate,
+    T2_LAUNCH(split_projection_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pg, mel_cl, gate,
                        out_lens, B, C, To);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -503,7 +503,7 @@ extern "C" int t2amd_finalize_outputs_f32(float* mel_cl, const float* post_cl, f
     T2_REQUIRE((post_cl != nullptr) == (mel_post != nullptr), "finalize_outputs: post_cl and mel_post go together");
     dim3 grid(t2_cdiv(C, 32), t2_cdiv(To, 32), B);
     T2_REQUIRE(grid.y <= 65535, "finalize_outputs: To too large");
-    hipLaunchKernelGGL(finalize_outputs_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel_cl, post_cl, mel, mel_post,
+    T2_LAUNCH(finalize_outputs_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel_cl, post_cl, mel, mel_post,
                        out_lens, B, C, To);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -541,7 +541,7 @@ extern "C" int t2amd_grads_to_channel_last_f32(const float* dmel, const float* d
                                                float* dpost_cl, int B, int C, int To, void* stream) {
     T2_REQUIRE(dmel_cl && dpost_cl && B > 0 && C > 0 && To > 0, "grads_to_cl: bad args");
     dim3 grid(t2_cdiv(To, 32), t2_cdiv(C, 32), B);
-    hipLaunchKernelGGL(grads_to_cl_kernel, grid, dim3(256), 0, (hipStream_t)stream, dmel, dmel_post, dmel_cl, dpost_cl, B,
+    T2_LAUNCH(grads_to_cl_kernel, grid, dim3(256), 0, (hipStream_t)stream, dmel, dmel_post, dmel_cl, dpost_cl, B,
                        C, To);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -566,8 +566,23 @@ extern "C" int t2amd_gather_dout_f32(const float* dmel_cl, const float* dgate, f
     T2_REQUIRE(dmel_cl && dout && B > 0 && C > 0 && To > 0, "gather_dout: bad args");
     int blocks = t2_cdiv((long long)To * B * (C + 1), 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gather_dout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dmel_cl, dgate, dout, B, C,
+    T2_LAUNCH(gather_dout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dmel_cl, dgate, dout, B, C,
                        To);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// Prenet backward elementwise part: y = relu(pre) * keep * scale  =>  dpre = (y > 0) ? dy*scale : 0
+// (y > 0 exactly when the unit was kept and the relu was active).  In place over dy.
+__global__ void relu_dropout_bwd_kernel(float* __restrict__ dy, const float* __restrict__ y, float scale, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dy[i] = (y[i] > 0.f) ? dy[i] * scale : 0.f;
+}
+extern "C" int t2amd_relu_dropout_bwd_f32(float* dy, const float* y, float scale, long long n, void* stream) {
+    T2_REQUIRE(dy && y && n > 0, "relu_dropout_bwd: bad args");
+    int blocks = t2_cdiv(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    T2_LAUNCH(relu_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, scale, n);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -311,13 +311,13 @@ extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
     T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     hipStream_t s = (hipStream_t)stream;
     if (d.a_kcontig && d.b_kcontig)
-        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
+        T2_LAUNCH((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
     else if (d.a_kcontig && !d.b_kcontig)
-        hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
+        T2_LAUNCH((gemm_f32_kernel<true, false>), grid, dim3(256), 0, s, p);
     else if (!d.a_kcontig && d.b_kcontig)
-        hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
+        T2_LAUNCH((gemm_f32_kernel<false, true>), grid, dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
+        T2_LAUNCH((gemm_f32_kernel<false, false>), grid, dim3(256), 0, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -351,7 +351,7 @@ extern "C" int t2amd_splitk_reduce_f32(const float* partials, int nsplit, long l
     if (perm_taps > 0) T2_REQUIRE(perm_ci > 0 && n % ((long long)perm_taps * perm_ci) == 0, "splitk_reduce: bad permutation dims");
     int blocks = t2_cdiv(n, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partials,
+    T2_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partials,
                        nsplit, stride, out, n, accumulate, perm_taps, perm_ci);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;

@@ -326,7 +326,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         gp.bias = p->bias_pg;
         T2_PROPAGATE(t2amd_gemm_f32(&gp, stream));
 
-        hipLaunchKernelGGL(infer_finish_step_kernel, dim3(t2_cdiv(B, 64)), dim3(64), 0, s, p->PG + (long long)t * sPG, B,
+        T2_LAUNCH(infer_finish_step_kernel, dim3(t2_cdiv(B, 64)), dim3(64), 0, s, p->PG + (long long)t * sPG, B,
                            C, t, p->max_steps, p->gate_threshold, p->out_lengths, p->active, p->done_count);
         T2_LAUNCH_CHECK();
     }

@@ -225,7 +225,7 @@ extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
     p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     p.lens = a->lens; p.t = a->t;
     dim3 grid(a->H / 4, t2_cdiv(a->B, SK_ROWS), 1);
-    hipLaunchKernelGGL((skinny_gemm_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    T2_LAUNCH((skinny_gemm_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -243,7 +243,7 @@ extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
     const int ktiles = a->Ktot / SK_BK;
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     dim3 grid(t2_cdiv(a->N, 16), t2_cdiv(a->B, SK_ROWS), a->nsplit);
-    hipLaunchKernelGGL((skinny_gemm_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    T2_LAUNCH((skinny_gemm_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -306,7 +306,7 @@ extern "C" int t2amd_lstm_pointwise_bwd_f32(const t2amd_lstm_bwd* a, void* strea
     const long long n = (long long)a->B * a->H;
     int blocks = t2_cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    T2_LAUNCH(lstm_pointwise_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

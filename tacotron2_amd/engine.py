@@ -1,0 +1,770 @@
+"""Host-side orchestration of the HIP kernels for the Tacotron 2 hot path.
+
+One ``torch.autograd.Function`` covers the whole of ``Tacotron2.forward``: the forward pass
+enqueues the native encoder / decoder-loop / postnet kernels and keeps the activation slabs
+the backward pass needs; the backward pass enqueues the BPTT loop and the deferred dense
+weight-gradient GEMMs and returns one gradient per parameter.  Nothing here computes:
+PyTorch supplies device buffers (caching allocator) and the current stream.
+
+Data layout in HBM (fp32): activations are channel-last.  Encoder / postnet rows are
+batch-major ``(b, t)``; decoder slabs are time-major ``[T][B][F]`` so that one step's slice is
+contiguous.  Reference call sites are cited next to each stage.
+"""
+import torch
+
+from . import native as nv
+from .native import NativeError
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def check_hparams(hp):
+    """Geometry the kernels are compiled / tiled for.  Anything else fails loudly."""
+    if hp.n_frames_per_step != 1:
+        raise ValueError("n_frames_per_step != 1 is not supported (nor by the reference, hparams.py:56)")
+    if hp.attention_dim != nv.ATT_DIM or hp.attention_location_n_filters != nv.LOC_FILTERS \
+            or hp.attention_location_kernel_size != nv.LOC_KERNEL:
+        raise ValueError("the attention kernels are built for attention_dim=128, 32 location filters, "
+                         "kernel 31 (reference defaults)")
+    for name in ('encoder_embedding_dim', 'attention_rnn_dim', 'decoder_rnn_dim', 'prenet_dim'):
+        if getattr(hp, name) % 64 != 0:
+            raise ValueError("%s must be a multiple of 64 for the MFMA recurrent kernels" % name)
+    if (hp.encoder_embedding_dim // 2) % 64 != 0:
+        raise ValueError("encoder_embedding_dim/2 must be a multiple of 64")
+    if hp.symbols_embedding_dim != hp.encoder_embedding_dim:
+        raise ValueError("symbols_embedding_dim must equal encoder_embedding_dim")
+    for name in ('encoder_embedding_dim', 'postnet_embedding_dim', 'n_mel_channels'):
+        if getattr(hp, name) % 16 != 0:
+            raise ValueError("%s must be a multiple of 16 (implicit-GEMM convolution tiles)" % name)
+    if hp.encoder_kernel_size % 2 != 1 or hp.postnet_kernel_size % 2 != 1:
+        raise ValueError("convolution kernel sizes must be odd")
+
+
+# ----------------------------------------------------------------------------
+# dropout masks
+# ----------------------------------------------------------------------------
+class MaskSource(object):
+    """Keep-masks (uint8, 1 = keep) in ENGINE layout.  Injected masks (tests: the oracle's masks,
+    transposed to channel-last) win; otherwise a Philox4x32-10 stream seeded from torch's RNG.
+
+    engine layouts:  enc[i] (B,Ti,E)   prenet[i] (To,B,P)   att (To,B,Ha)   dec (To,B,Hd)
+                     post[i] (B,To,C)  prenet_infer (steps,2,B,P)"""
+
+    def __init__(self, injected, device):
+        self.injected = injected or {}
+        self.device = device
+        self.seed = None
+        self.offset = 0
+
+    def get(self, name, index, shape, p):
+        src = self.injected.get(name)
+        if src is not None:
+            m = src[index] if index is not None else src
+            if tuple(m.shape) != tuple(shape) or m.dtype != torch.uint8 or not m.is_contiguous():
+                raise NativeError("injected mask %s[%s] must be contiguous uint8 of shape %s, got %s %s"
+                                  % (name, index, tuple(shape), tuple(m.shape), m.dtype))
+            return m
+        if self.seed is None:
+            self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        nv.philox_keep_mask(out, p, self.seed, self.offset)
+        self.offset += (out.numel() + 3) // 4 * 4
+        return out
+
+
+# ----------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------
+def _choose_splitk(M, N, K, batch=1):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    if tiles >= 256:
+        return 1
+    s = (768 + tiles - 1) // tiles
+    s = min(s, 64, max(1, K // 256))
+    return max(1, s)
+
+
+class _Ctx(object):
+    pass
+
+
+class _Run(object):
+    """Allocation + kernel helpers bound to one device."""
+
+    def __init__(self, device):
+        self.dev = device
+        self._ws = None
+
+    def empty(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def zeros(self, *shape):
+        t = self.empty(*shape)
+        nv.fill(t, 0.0)
+        return t
+
+    def ws(self, n):
+        need = 2 * 64 * n
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.float64, device=self.dev)
+        return self._ws
+
+    # C[M,N] (+)= A.B with automatic split-K for skinny outputs over a long K
+    def gemm(self, Cm, A, B, a_km=False, b_kn=False, accumulate=False, convB=None, perm=None,
+             batch=1, strides=(0, 0, 0), **kw):
+        M, N = Cm.shape
+        K = A.shape[0] if a_km else A.shape[1]
+        plain = kw.get('bias') is None and kw.get('act', 0) == 0 and kw.get('keep') is None \
+            and kw.get('convA') is None
+        sk = _choose_splitk(M, N, K, batch) if (plain and batch == 1) else 1
+        if perm is not None and sk == 1:
+            sk = 2 if K >= 512 else 1
+        if sk == 1 and perm is None:
+            nv.gemm(Cm, A, B, a_km=a_km, b_kn=b_kn, accumulate=accumulate, convB=convB, batch=batch,
+                    strides=strides, **kw)
+            return
+        if not Cm.is_contiguous():
+            raise NativeError("split-K / permuted GEMM output must be contiguous")
+        part = self.empty(max(sk, 1), M * N)
+        if sk == 1:
+            nv.gemm(part[0].view(M, N), A, B, a_km=a_km, b_kn=b_kn, convB=convB)
+        else:
+            nv.gemm(part[0].view(M, N), A, B, a_km=a_km, b_kn=b_kn, convB=convB, splitk=sk, partials=part)
+        pt, pc = perm if perm is not None else (0, 0)
+        nv.splitk_reduce(part, max(sk, 1), Cm, accumulate=accumulate, perm_taps=pt, perm_ci=pc)
+
+    def colsum(self, x, out, accumulate=False):
+        nv.colsum(x, self.ws(x.shape[1]), out, accumulate)
+
+    # ---- conv helpers: weights (Co, Ci, k) ------------------------------------------------
+    def pack_conv_fwd(self, W):
+        Co, Ci, k = W.shape
+        Wp = self.empty(Co, k * Ci)
+        nv.transpose(Wp.view(Co, k, Ci)[0], W[0], batch=Co, sstride=Ci * k, dstride=k * Ci)
+        return Wp
+
+    def pack_conv_dgrad(self, W):
+        Co, Ci, k = W.shape
+        Wd = self.empty(Ci, k * Co)
+        nv.transpose(Wd.view(Ci * k, Co), W.view(Co, Ci * k))
+        return Wd
+
+
+def _bias_sum(run, b1, b2):
+    out = run.empty(b1.numel())
+    nv.copy2d(out.view(1, -1), b1.view(1, -1), b2.view(1, -1))
+    return out
+
+
+# ----------------------------------------------------------------------------
+# conv + BN (+act +dropout) stack, shared by encoder and postnet
+# ----------------------------------------------------------------------------
+def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training, lens=None):
+    """x: (rows, C0) channel-last rows (b, t).  Returns the last activation and the saved slabs.
+    reference model.py:141-146 (Postnet.forward), :174-175 (Encoder.forward)."""
+    saved = []
+    rows = x.shape[0]
+    for i in range(n_layers):
+        W = P['%s.%d.0.conv.weight' % (prefix, i)]
+        bias = P['%s.%d.0.conv.bias' % (prefix, i)]
+        gamma = P['%s.%d.1.weight' % (prefix, i)]
+        beta = P['%s.%d.1.bias' % (prefix, i)]
+        rm = bufs['%s.%d.1.running_mean' % (prefix, i)]
+        rv = bufs['%s.%d.1.running_var' % (prefix, i)]
+        Co, Ci, k = W.shape
+        pad = (k - 1) // 2
+        Wp = run.pack_conv_fwd(W)
+        y = run.empty(rows, Co)
+        nv.gemm(y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
+        invstd = run.empty(Co)
+        if training:
+            mean = run.empty(Co)
+            nv.bn_stats(y, run.ws(Co), mean, invstd, rm, rv, BN_MOMENTUM, BN_EPS)
+            bufs['%s.%d.1.num_batches_tracked' % (prefix, i)].add_(1)
+        else:
+            mean = rm
+            nv.bn_eval_invstd(rv, invstd, BN_EPS)
+        z = run.empty(rows, Co)
+        keep = masks[i] if masks is not None else None
+        nv.bn_act_fwd(y, z, mean, invstd, gamma, beta, acts[i],
+                      keep.view(rows, Co) if keep is not None else None, 2.0, lens, T if lens is not None else 0)
+        saved.append(dict(x=x, y=y, z=z, mean=mean, invstd=invstd, keep=keep, W=W, act=acts[i]))
+        x = z
+    return x, saved
+
+
+def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_accumulate=False):
+    """g: grad wrt the last activation (rows, C_last), overwritten.  Returns grad wrt the stack input
+    (written to ``first_dx`` if given)."""
+    for i in range(len(saved) - 1, -1, -1):
+        s = saved[i]
+        W = s['W']
+        Co, Ci, k = W.shape
+        pad = (k - 1) // 2
+        rows = g.shape[0]
+        gamma = P['%s.%d.1.weight' % (prefix, i)]
+        dgamma = run.empty(Co)
+        dbeta = run.empty(Co)
+        keep = s['keep']
+        nv.bn_act_bwd(g, s['z'], s['y'], s['mean'], s['invstd'], gamma, s['act'],
+                      keep.view(rows, Co) if keep is not None else None, 2.0, run.ws(Co), dgamma, dbeta)
+        grads['%s.%d.1.weight' % (prefix, i)] = dgamma
+        grads['%s.%d.1.bias' % (prefix, i)] = dbeta
+        dbias = run.empty(Co)
+        run.colsum(g, dbias)
+        grads['%s.%d.0.conv.bias' % (prefix, i)] = dbias
+        # weight gradient: dW[co][(tap,ci)] = sum_r g[r][co] * x[r + tap - pad][ci]
+        dW = run.empty(Co, Ci, k)
+        run.gemm(dW.view(Co, Ci * k), g, s['x'], a_km=True, b_kn=True, convB=(T, Ci, pad), perm=(k, Ci))
+        grads['%s.%d.0.conv.weight' % (prefix, i)] = dW
+        # data gradient
+        if i > 0 or first_dx is not None:
+            Wd = run.pack_conv_dgrad(W)
+            if i == 0:
+                dx = first_dx
+                acc = first_dx_accumulate
+            else:
+                dx = run.empty(rows, Ci)
+                acc = False
+            nv.gemm(dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
+            g = dx
+    return g
+
+
+# ----------------------------------------------------------------------------
+# forward (training / teacher-forced)
+# ----------------------------------------------------------------------------
+def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
+    hp = model.hparams
+    dev = text.device
+    if not text.is_cuda and not nv.validate_only():
+        raise NativeError("tacotron2_amd: the engine runs on the MI355X only (got %s tensors). "
+                          "There is no CPU path; the CPU oracle lives in oracle/ for tests." % dev)
+    nv.load()
+    run = _Run(dev)
+    ms = MaskSource(model.dropout_masks, dev)
+    c = _Ctx()
+    B = text.shape[0]
+    Ti = int(max_len)
+    To = mels.shape[2]
+    E = hp.encoder_embedding_dim
+    Ha, Hd, Pd = hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.prenet_dim
+    Cm = hp.n_mel_channels
+    He = E // 2
+    A = nv.ATT_DIM
+    if text.shape[1] != Ti:
+        text = text[:, :Ti]
+    text = text.contiguous()
+    mels = mels.contiguous().float()
+    lens32 = in_lens.to(torch.int32).contiguous()
+    olens32 = out_lens.to(torch.int32).contiguous() if (model.mask_padding and out_lens is not None) else None
+    c.B, c.Ti, c.To, c.text, c.lens32, c.olens32 = B, Ti, To, text, lens32, olens32
+    c.training = training
+
+    # ---- encoder: embedding -> 3 x (conv k5 + BN + relu + dropout) -> bi-LSTM -----------------
+    rowsE = B * Ti
+    emb = run.empty(rowsE, E)
+    nv.embedding_fwd(text, P['embedding.weight'], emb)                                   # model.py:503
+    nconv = hp.encoder_n_convolutions
+    enc_masks = [ms.get('enc', i, (B, Ti, E), 0.5) for i in range(nconv)] if training else None
+    x3, c.enc_saved = _conv_stack_fwd(run, P, bufs, 'encoder.convolutions', nconv, emb, Ti,
+                                      [1] * nconv, enc_masks, training)                  # model.py:174-175
+    memory = run.empty(B, Ti, E)
+    c.enc_lstm = []
+    for d, sfx in enumerate(('', '_reverse')):                                           # model.py:181-188
+        Wih = P['encoder.lstm.weight_ih_l0' + sfx]
+        Whh = P['encoder.lstm.weight_hh_l0' + sfx]
+        bsum = _bias_sum(run, P['encoder.lstm.bias_ih_l0' + sfx], P['encoder.lstm.bias_hh_l0' + sfx])
+        GX = run.empty(rowsE, 4 * He)
+        nv.gemm(GX, x3, Wih, bias=bsum)
+        Cst = run.empty(Ti, B, He)
+        desc = nv.LstmSeq()
+        desc.B, desc.T, desc.H, desc.reverse = B, Ti, He, d
+        desc.Whh = nv.ptr(Whh)
+        desc.GX = nv.ptr(GX)
+        out_view = memory.view(rowsE, E)[:, d * He:(d + 1) * He]
+        desc.out, desc.ld_out = nv.ptr(out_view), E
+        desc.C = nv.ptr(Cst)
+        desc.lens = nv.ptr(lens32, torch.int32)
+        nv.lstm_seq_fwd(desc)
+        c.enc_lstm.append(dict(GX=GX, C=Cst, Whh=Whh, Wih=Wih))
+    c.x3, c.memory = x3, memory
+
+    # ---- decoder: hoisted dense parts ------------------------------------------------------
+    rowsD = To * B
+    x0 = run.empty(To, B, Cm)
+    nv.frames_to_time_major(mels, x0)                                                    # model.py:396-398
+    W1 = P['decoder.prenet.layers.0.linear_layer.weight']
+    W2 = P['decoder.prenet.layers.1.linear_layer.weight']
+    k0 = ms.get('prenet', 0, (To, B, Pd), 0.5)
+    k1 = ms.get('prenet', 1, (To, B, Pd), 0.5)
+    p1 = run.empty(rowsD, Pd)
+    p2 = run.empty(rowsD, Pd)
+    nv.gemm(p1, x0.view(rowsD, Cm), W1, act=1, keep=k0.view(rowsD, Pd), keep_scale=2.0)  # model.py:99, 399
+    nv.gemm(p2, p1, W2, act=1, keep=k1.view(rowsD, Pd), keep_scale=2.0)
+    Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
+    pm = run.empty(B, Ti, A)
+    nv.gemm(pm.view(rowsE, A), memory.view(rowsE, E), Wmem)                              # model.py:288
+
+    Wih_a, Whh_a = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
+    Wih_d, Whh_d = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
+    bias_a = _bias_sum(run, P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
+    bias_d = _bias_sum(run, P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
+    Wa_rec = run.empty(4 * Ha, E + Ha)
+    nv.copy2d(Wa_rec[:, :E], Wih_a[:, Pd:Pd + E])
+    nv.copy2d(Wa_rec[:, E:], Whh_a)
+    Wd_cat = run.empty(4 * Hd, Ha + E + Hd)
+    nv.copy2d(Wd_cat[:, :Ha + E], Wih_d)
+    nv.copy2d(Wd_cat[:, Ha + E:], Whh_d)
+    Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']                    # (A, Ha)
+    WqT = run.empty(Ha, A)
+    nv.transpose(WqT, Wq)
+    Wdense = P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']
+    Wconv = P['decoder.attention_layer.location_layer.location_conv.conv.weight']
+    U = run.empty(A * nv.LOC_TAPS + 64 * A)
+    nv.fold_location(Wdense, Wconv, U)
+    vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
+
+    GA = run.empty(To, B, 4 * Ha)
+    nv.gemm(GA.view(rowsD, 4 * Ha), p2, Wih_a[:, :Pd], bias=bias_a)
+
+    att_p, dec_p = hp.p_attention_dropout, hp.p_decoder_dropout
+    keep_att = ms.get('att', None, (To, B, Ha), att_p) if training else None
+    keep_dec = ms.get('dec', None, (To, B, Hd), dec_p) if training else None
+
+    d = nv.DecTrain()
+    d.B, d.Ti, d.To, d.E, d.Ha, d.Hd = B, Ti, To, E, Ha, Hd
+    slabs = dict(HA=run.empty(To, B, Ha), CA=run.empty(To, B, Ha), GD=run.empty(To, B, 4 * Hd),
+                 HD=run.empty(To, B, Hd), CD=run.empty(To, B, Hd), CTX=run.empty(To, B, E),
+                 Q=run.empty(To, B, A), ALIGN=run.empty(B, To, Ti), CUM=run.empty(To, B, Ti),
+                 cum_work=run.empty(B, Ti))
+    d.Wa_rec, d.Wd_cat, d.bias_d = nv.ptr(Wa_rec), nv.ptr(Wd_cat), nv.ptr(bias_d)
+    d.WqT, d.U, d.v = nv.ptr(WqT), nv.ptr(U), nv.ptr(vvec)
+    d.GA, d.memory, d.pm = nv.ptr(GA), nv.ptr(memory), nv.ptr(pm)
+    d.lens = nv.ptr(lens32, torch.int32)
+    d.keep_att = nv.ptr(keep_att, torch.uint8)
+    d.keep_dec = nv.ptr(keep_dec, torch.uint8)
+    d.scale_att, d.scale_dec = nv.scale_for(att_p), nv.scale_for(dec_p)
+    for k_, v_ in slabs.items():
+        setattr(d, k_, nv.ptr(v_))
+    nv.decoder_train_fwd_loop(d)                                                         # model.py:405-411
+
+    # mel + gate projection over all steps (model.py:373-378)
+    Wp = P['decoder.linear_projection.linear_layer.weight']      # (Cm, Hd+E)
+    Wg = P['decoder.gate_layer.linear_layer.weight']             # (1, Hd+E)
+    Wpg = run.empty(Cm + 1, Hd + E)
+    nv.copy2d(Wpg[:Cm], Wp)
+    nv.copy2d(Wpg[Cm:], Wg)
+    bpg = run.empty(Cm + 1)
+    nv.copy2d(bpg[:Cm].view(1, Cm), P['decoder.linear_projection.linear_layer.bias'].view(1, Cm))
+    nv.copy2d(bpg[Cm:].view(1, 1), P['decoder.gate_layer.linear_layer.bias'].view(1, 1))
+    PG = run.empty(rowsD, Cm + 1)
+    nv.gemm(PG, slabs['HD'].view(rowsD, Hd), Wpg[:, :Hd])
+    nv.gemm(PG, slabs['CTX'].view(rowsD, E), Wpg[:, Hd:], accumulate=True, bias=bpg)
+    mel_cl = run.empty(B, To, Cm)
+    gate = run.empty(B, To)
+    nv.split_projection(PG, mel_cl, gate, olens32)                                       # model.py:326-336, 495
+
+    # ---- postnet (model.py:141-146) -------------------------------------------------------
+    npost = hp.postnet_n_convolutions
+    rowsP = B * To
+    post_chans = [hp.postnet_embedding_dim] * (npost - 1) + [Cm]
+    post_masks = [ms.get('post', i, (B, To, post_chans[i]), 0.5) for i in range(npost)] if training else None
+    post_cl, c.post_saved = _conv_stack_fwd(run, P, bufs, 'postnet.convolutions', npost,
+                                            mel_cl.view(rowsP, Cm), To, [2] * (npost - 1) + [0],
+                                            post_masks, training)
+    mel = run.empty(B, Cm, To)
+    mel_post = run.empty(B, Cm, To)
+    nv.finalize_outputs(mel_cl, post_cl.view(B, To, Cm), mel, mel_post, olens32)         # model.py:511, 487-497
+
+    c.run = run
+    c.dec = d
+    c.keep = dict(att=keep_att, dec=keep_dec, k0=k0, k1=k1)
+    c.slabs = slabs
+    c.tensors = dict(x0=x0, p1=p1, p2=p2, pm=pm, GA=GA, Wa_rec=Wa_rec, Wd_cat=Wd_cat, bias_d=bias_d,
+                     WqT=WqT, U=U, Wpg=Wpg, mel_cl=mel_cl, vvec=vvec, lens32=lens32)
+    return (mel, mel_post, gate, slabs['ALIGN']), c
+
+
+# ----------------------------------------------------------------------------
+# backward
+# ----------------------------------------------------------------------------
+def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
+    hp = model.hparams
+    run = c.run
+    g = {}
+    B, Ti, To = c.B, c.Ti, c.To
+    E = hp.encoder_embedding_dim
+    Ha, Hd, Pd = hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.prenet_dim
+    Cm = hp.n_mel_channels
+    He = E // 2
+    A = nv.ATT_DIM
+    rowsD, rowsE, rowsP = To * B, B * Ti, B * To
+    S, T = c.slabs, c.tensors
+
+    def cont(t):
+        return t.contiguous() if t is not None else None
+
+    # ---- output boundary -> postnet backward ----------------------------------------------
+    dmel_cl = run.empty(B, To, Cm)
+    dpost_cl = run.empty(B, To, Cm)
+    nv.grads_to_channel_last(cont(d_mel), cont(d_post), dmel_cl, dpost_cl)
+    _conv_stack_bwd(run, P, g, 'postnet.convolutions', c.post_saved, dpost_cl.view(rowsP, Cm), To,
+                    first_dx=dmel_cl.view(rowsP, Cm), first_dx_accumulate=True)
+    dout = run.empty(rowsD, Cm + 1)
+    nv.gather_dout(dmel_cl, cont(d_gate), dout)
+
+    # ---- projection backward --------------------------------------------------------------
+    Wpg = T['Wpg']
+    DHC = run.empty(rowsD, Hd + E)
+    nv.gemm(DHC, dout, Wpg, b_kn=True)
+    dWpg_h = run.empty(Cm + 1, Hd)
+    dWpg_c = run.empty(Cm + 1, E)
+    run.gemm(dWpg_h, dout, S['HD'].view(rowsD, Hd), a_km=True, b_kn=True)
+    run.gemm(dWpg_c, dout, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
+    dWp = run.empty(Cm, Hd + E)
+    dWg = run.empty(1, Hd + E)
+    nv.copy2d(dWp[:, :Hd], dWpg_h[:Cm]); nv.copy2d(dWp[:, Hd:], dWpg_c[:Cm])
+    nv.copy2d(dWg[:, :Hd], dWpg_h[Cm:]); nv.copy2d(dWg[:, Hd:], dWpg_c[Cm:])
+    dbpg = run.empty(Cm + 1)
+    run.colsum(dout, dbpg)
+    g['decoder.linear_projection.linear_layer.weight'] = dWp
+    g['decoder.gate_layer.linear_layer.weight'] = dWg
+    g['decoder.linear_projection.linear_layer.bias'] = dbpg[:Cm].clone()
+    g['decoder.gate_layer.linear_layer.bias'] = dbpg[Cm:].clone()
+
+    # ---- BPTT through the decoder loop ----------------------------------------------------
+    Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
+    Wa_recT = run.empty(E + Ha, 4 * Ha)
+    nv.transpose(Wa_recT, T['Wa_rec'])
+    Wd_catT = run.empty(Ha + E + Hd, 4 * Hd)
+    nv.transpose(Wd_catT, T['Wd_cat'])
+    ns = 4
+    bw = nv.DecTrainBwd()
+    bw.f = c.dec
+    bw.Wa_recT, bw.Wd_catT, bw.Wq = nv.ptr(Wa_recT), nv.ptr(Wd_catT), nv.ptr(Wq)
+    bw.DHC = nv.ptr(DHC)
+    bw.d_align = nv.ptr(cont(d_align))
+    bw.nsplit = ns
+    out = dict(DGA=run.empty(To, B, 4 * Ha), DGD=run.empty(To, B, 4 * Hd), DCTX=run.empty(To, B, E),
+               DQ=run.empty(To, B, A), d_pm=run.empty(B, Ti, A), dU_acc=run.empty(B, A, nv.LOC_TAPS),
+               dv_acc=run.empty(B, A), dXd=run.empty(ns, B, Ha + E + Hd), dXa=run.empty(ns, B, E + Ha),
+               dc_a=run.empty(B, Ha), dc_d=run.empty(B, Hd), dw_carry=run.empty(B, Ti),
+               dcum_carry=run.empty(B, Ti), dq_h=run.empty(B, Ha))
+    for k_, v_ in out.items():
+        setattr(bw, k_, nv.ptr(v_))
+    nv.decoder_train_bwd_loop(bw)
+    DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
+    DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)
+
+    # location layer + v
+    Wdense = P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']
+    Wconv = P['decoder.attention_layer.location_layer.location_conv.conv.weight']
+    dWdense = run.empty(A, nv.LOC_FILTERS)
+    dWconv = run.empty(nv.LOC_FILTERS, 2, nv.LOC_KERNEL)
+    dv = run.empty(1, A)
+    nv.unfold_location_grads(out['dU_acc'], out['dv_acc'], B, Wdense, Wconv, dWdense, dWconv, dv)
+    g['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'] = dWdense
+    g['decoder.attention_layer.location_layer.location_conv.conv.weight'] = dWconv
+    g['decoder.attention_layer.v.linear_layer.weight'] = dv
+    # query layer: dWq = DQ^T . HA
+    dWq = run.empty(A, Ha)
+    run.gemm(dWq, DQ.view(rowsD, A), S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
+    g['decoder.attention_layer.query_layer.linear_layer.weight'] = dWq
+
+    # attention LSTM weights: inputs [prenet_t | ctx_{t-1} | h_att_{t-1}]
+    dWih_a = run.empty(4 * Ha, Pd + E)
+    dWhh_a = run.empty(4 * Ha, Ha)
+    tmp = run.empty(4 * Ha, Pd)
+    run.gemm(tmp, DGA2, T['p2'], a_km=True, b_kn=True)
+    nv.copy2d(dWih_a[:, :Pd], tmp)
+    if To > 1:
+        sh = (To - 1) * B
+        tmp2 = run.empty(4 * Ha, E)
+        run.gemm(tmp2, DGA2[B:], S['CTX'].view(rowsD, E)[:sh], a_km=True, b_kn=True)
+        nv.copy2d(dWih_a[:, Pd:], tmp2)
+        run.gemm(dWhh_a, DGA2[B:], S['HA'].view(rowsD, Ha)[:sh], a_km=True, b_kn=True)
+    else:
+        nv.fill(dWhh_a, 0.0)
+        z = run.zeros(4 * Ha, E)
+        nv.copy2d(dWih_a[:, Pd:], z)
+    db_a = run.empty(4 * Ha)
+    run.colsum(DGA2, db_a)
+    g['decoder.attention_rnn.weight_ih'] = dWih_a
+    g['decoder.attention_rnn.weight_hh'] = dWhh_a
+    g['decoder.attention_rnn.bias_ih'] = db_a
+    g['decoder.attention_rnn.bias_hh'] = db_a.clone()
+
+    # decoder LSTM weights: inputs [h_att_t | ctx_t | h_dec_{t-1}]
+    dWih_d = run.empty(4 * Hd, Ha + E)
+    dWhh_d = run.empty(4 * Hd, Hd)
+    tmp3 = run.empty(4 * Hd, Ha)
+    run.gemm(tmp3, DGD2, S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
+    nv.copy2d(dWih_d[:, :Ha], tmp3)
+    tmp4 = run.empty(4 * Hd, E)
+    run.gemm(tmp4, DGD2, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
+    nv.copy2d(dWih_d[:, Ha:], tmp4)
+    if To > 1:
+        sh = (To - 1) * B
+        run.gemm(dWhh_d, DGD2[B:], S['HD'].view(rowsD, Hd)[:sh], a_km=True, b_kn=True)
+    else:
+        nv.fill(dWhh_d, 0.0)
+    db_d = run.empty(4 * Hd)
+    run.colsum(DGD2, db_d)
+    g['decoder.decoder_rnn.weight_ih'] = dWih_d
+    g['decoder.decoder_rnn.weight_hh'] = dWhh_d
+    g['decoder.decoder_rnn.bias_ih'] = db_d
+    g['decoder.decoder_rnn.bias_hh'] = db_d.clone()
+
+    # prenet backward (model.py:99 under autograd)
+    Wih_a = P['decoder.attention_rnn.weight_ih']
+    W2 = P['decoder.prenet.layers.1.linear_layer.weight']
+    dp2 = run.empty(rowsD, Pd)
+    nv.gemm(dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
+    nv.relu_dropout_bwd(dp2, T['p2'], 2.0)
+    dW2 = run.empty(Pd, Pd)
+    run.gemm(dW2, dp2, T['p1'], a_km=True, b_kn=True)
+    dp1 = run.empty(rowsD, Pd)
+    nv.gemm(dp1, dp2, W2, b_kn=True)
+    nv.relu_dropout_bwd(dp1, T['p1'], 2.0)
+    dW1 = run.empty(Pd, Cm)
+    run.gemm(dW1, dp1, T['x0'].view(rowsD, Cm), a_km=True, b_kn=True)
+    g['decoder.prenet.layers.0.linear_layer.weight'] = dW1
+    g['decoder.prenet.layers.1.linear_layer.weight'] = dW2
+
+    # memory gradient: d_mem[b] = ALIGN[b]^T . DCTX[:, b] + d_pm[b] . Wmem ; dWmem = d_pm^T . memory
+    Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']     # (A, E)
+    dmem = run.empty(B, Ti, E)
+    nv.gemm(dmem[0], S['ALIGN'][0], DCTX[:, 0, :], a_km=True, b_kn=True, batch=B,
+            strides=(To * Ti, E, Ti * E))
+    nv.gemm(dmem.view(rowsE, E), d_pm.view(rowsE, A), Wmem, b_kn=True, accumulate=True)
+    dWmem = run.empty(A, E)
+    run.gemm(dWmem, d_pm.view(rowsE, A), c.memory.view(rowsE, E), a_km=True, b_kn=True)
+    g['decoder.attention_layer.memory_layer.linear_layer.weight'] = dWmem
+
+    # ---- encoder backward -----------------------------------------------------------------
+    dx3 = run.empty(rowsE, E)
+    for d, sfx in enumerate(('', '_reverse')):
+        L = c.enc_lstm[d]
+        WhhT = run.empty(He, 4 * He)
+        nv.transpose(WhhT, L['Whh'])
+        DG = run.empty(rowsE, 4 * He)
+        desc = nv.LstmSeq()
+        desc.B, desc.T, desc.H, desc.reverse = B, Ti, He, d
+        desc.WhhT = nv.ptr(WhhT)
+        desc.GX = nv.ptr(L['GX'])
+        desc.C = nv.ptr(L['C'])
+        desc.lens = nv.ptr(c.lens32, torch.int32)
+        dout_view = dmem.view(rowsE, E)[:, d * He:(d + 1) * He]
+        desc.dout, desc.ld_dout = nv.ptr(dout_view), E
+        desc.DG = nv.ptr(DG)
+        dX = run.empty(B, He)
+        dc = run.empty(B, He)
+        desc.dX, desc.dc = nv.ptr(dX), nv.ptr(dc)
+        nv.lstm_seq_bwd(desc)
+        dWih = run.empty(4 * He, E)
+        run.gemm(dWih, DG, c.x3, a_km=True, b_kn=True)
+        # h_prev of row (b,t) is the output at (b, t-1) forward / (b, t+1) reverse, zero outside [0,T)
+        dWhh = run.empty(4 * He, He)
+        hview = c.memory.view(rowsE, E)[:, d * He:(d + 1) * He]
+        run.gemm(dWhh, DG, hview, a_km=True, b_kn=True, convB=(Ti, He, 1 if d == 0 else -1))
+        db = run.empty(4 * He)
+        run.colsum(DG, db)
+        g['encoder.lstm.weight_ih_l0' + sfx] = dWih
+        g['encoder.lstm.weight_hh_l0' + sfx] = dWhh
+        g['encoder.lstm.bias_ih_l0' + sfx] = db
+        g['encoder.lstm.bias_hh_l0' + sfx] = db.clone()
+        nv.gemm(dx3, DG, L['Wih'], b_kn=True, accumulate=(d == 1))
+    demb = run.empty(rowsE, E)
+    _conv_stack_bwd(run, P, g, 'encoder.convolutions', c.enc_saved, dx3, Ti, first_dx=demb)
+    dtable = run.empty(*P['embedding.weight'].shape)
+    nv.embedding_bwd(c.text, demb, dtable)
+    g['embedding.weight'] = dtable
+    return g
+
+
+class Tacotron2TrainFunction(torch.autograd.Function):
+    """forward(model, names, buffers, text, in_lens, mels, max_len, out_lens, *params)."""
+
+    @staticmethod
+    def forward(ctx, model, names, buffers, text, in_lens, mels, max_len, out_lens, *params):
+        P = dict(zip(names, [p.detach() for p in params]))
+        for n, p in P.items():
+            if p.dtype != torch.float32:
+                raise NativeError("parameter %s is %s: this build of the engine computes in fp32" % (n, p.dtype))
+        outs, c = _forward(model, P, buffers, text, in_lens, mels, max_len, out_lens, model.training)
+        ctx.model, ctx.names, ctx.c, ctx.P = model, names, c, P
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, d_mel, d_post, d_gate, d_align):
+        if not ctx.c.training:
+            raise NativeError("backward through an eval-mode forward is not supported")
+        grads = _backward(ctx.model, ctx.P, ctx.c, d_mel, d_post, d_gate, d_align)
+        out = []
+        for n in ctx.names:
+            if n not in grads:
+                raise NativeError("internal error: no gradient produced for %s" % n)
+            out.append(grads[n].view(ctx.P[n].shape))
+        ctx.c = None
+        return (None,) * 8 + tuple(out)
+
+
+# ----------------------------------------------------------------------------
+# inference (reference model.py:517-529)
+# ----------------------------------------------------------------------------
+def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
+    hp = model.hparams
+    dev = text.device
+    if not text.is_cuda and not nv.validate_only():
+        raise NativeError("tacotron2_amd: the engine runs on the MI355X only (got %s tensors)" % dev)
+    nv.load()
+    P = {k: v.detach() for k, v in P.items()}
+    for n, p in P.items():
+        if p.dtype != torch.float32:
+            raise NativeError("parameter %s is %s: this build of the engine computes in fp32" % (n, p.dtype))
+    run = _Run(dev)
+    ms = MaskSource(model.dropout_masks, dev)
+    B, Ti = text.shape
+    E = hp.encoder_embedding_dim
+    Ha, Hd, Pd, Cm = hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.prenet_dim, hp.n_mel_channels
+    He, A = E // 2, nv.ATT_DIM
+    max_steps = hp.max_decoder_steps
+    if input_lengths is not None:
+        lens32 = input_lengths.to(torch.int32).contiguous()
+        Ti = int(input_lengths.max().item())
+        text = text[:, :Ti]
+    else:
+        lens32 = torch.full((B,), Ti, dtype=torch.int32, device=dev)
+    text = text.contiguous()
+    rowsE = B * Ti
+    ragged = input_lengths is not None
+
+    # encoder, eval mode (model.py:192-201); ragged batches zero the activations beyond each length
+    emb = run.empty(rowsE, E)
+    nv.embedding_fwd(text, P['embedding.weight'], emb)
+    x = emb
+    if ragged:
+        # zero padded positions of the embedding so the first conv sees exact zero padding
+        ones = run.empty(E); nv.fill(ones, 1.0)
+        zeros = run.zeros(E)
+        xm = run.empty(rowsE, E)
+        nv.bn_act_fwd(x, xm, zeros, ones, ones, zeros, 0, None, 1.0, lens32, Ti)
+        x = xm
+    x3, _ = _conv_stack_fwd(run, P, bufs, 'encoder.convolutions', hp.encoder_n_convolutions, x, Ti,
+                            [1] * hp.encoder_n_convolutions, None, False, lens=lens32 if ragged else None)
+    memory = run.empty(B, Ti, E)
+    for d, sfx in enumerate(('', '_reverse')):
+        Wih = P['encoder.lstm.weight_ih_l0' + sfx]
+        Whh = P['encoder.lstm.weight_hh_l0' + sfx]
+        bsum = _bias_sum(run, P['encoder.lstm.bias_ih_l0' + sfx], P['encoder.lstm.bias_hh_l0' + sfx])
+        GX = run.empty(rowsE, 4 * He)
+        nv.gemm(GX, x3, Wih, bias=bsum)
+        Cst = run.empty(Ti, B, He)
+        desc = nv.LstmSeq()
+        desc.B, desc.T, desc.H, desc.reverse = B, Ti, He, d
+        desc.Whh, desc.GX = nv.ptr(Whh), nv.ptr(GX)
+        out_view = memory.view(rowsE, E)[:, d * He:(d + 1) * He]
+        desc.out, desc.ld_out = nv.ptr(out_view), E
+        desc.C = nv.ptr(Cst)
+        desc.lens = nv.ptr(lens32, torch.int32)
+        nv.lstm_seq_fwd(desc)
+
+    Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
+    pm = run.empty(B, Ti, A)
+    nv.gemm(pm.view(rowsE, A), memory.view(rowsE, E), Wmem)
+
+    Wih_a, Whh_a = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
+    Wih_d, Whh_d = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
+    bias_a = _bias_sum(run, P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
+    bias_d = _bias_sum(run, P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
+    Wa_cat = run.empty(4 * Ha, Pd + E + Ha)
+    nv.copy2d(Wa_cat[:, :Pd + E], Wih_a)
+    nv.copy2d(Wa_cat[:, Pd + E:], Whh_a)
+    Wd_cat = run.empty(4 * Hd, Ha + E + Hd)
+    nv.copy2d(Wd_cat[:, :Ha + E], Wih_d)
+    nv.copy2d(Wd_cat[:, Ha + E:], Whh_d)
+    Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
+    WqT = run.empty(Ha, A)
+    nv.transpose(WqT, Wq)
+    U = run.empty(A * nv.LOC_TAPS + 64 * A)
+    nv.fold_location(P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'],
+                     P['decoder.attention_layer.location_layer.location_conv.conv.weight'], U)
+    vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
+    Wpg = run.empty(Cm + 1, Hd + E)
+    nv.copy2d(Wpg[:Cm], P['decoder.linear_projection.linear_layer.weight'])
+    nv.copy2d(Wpg[Cm:], P['decoder.gate_layer.linear_layer.weight'])
+    bpg = run.empty(Cm + 1)
+    nv.copy2d(bpg[:Cm].view(1, Cm), P['decoder.linear_projection.linear_layer.bias'].view(1, Cm))
+    nv.copy2d(bpg[Cm:].view(1, 1), P['decoder.gate_layer.linear_layer.bias'].view(1, 1))
+
+    keep = ms.get('prenet_infer', None, (max_steps, 2, B, Pd), 0.5)
+
+    d = nv.DecInfer()
+    d.B, d.Ti, d.E, d.Ha, d.Hd, d.P, d.C = B, Ti, E, Ha, Hd, Pd, Cm
+    d.max_steps = max_steps
+    d.gate_threshold = float(hp.gate_threshold)
+    st = dict(h_a=run.zeros(2, B, Ha), c_a=run.zeros(2, B, Ha), c_d=run.zeros(2, B, Hd),
+              hc=run.zeros(2, B, Hd + E), cum=run.zeros(B, Ti), x_prenet=run.empty(2, B, Pd),
+              gates=run.empty(B, 4 * max(Ha, Hd)), zero_frame=run.zeros(B, Cm),
+              PG=run.zeros(max_steps, B, Cm + 1), ALIGN=run.zeros(B, max_steps, Ti))
+    out_lengths = torch.zeros(B, dtype=torch.int32, device=dev)
+    active = torch.ones(B, dtype=torch.uint8, device=dev)
+    done = torch.zeros(1, dtype=torch.int32, device=dev)
+    d.W1 = nv.ptr(P['decoder.prenet.layers.0.linear_layer.weight'])
+    d.W2 = nv.ptr(P['decoder.prenet.layers.1.linear_layer.weight'])
+    d.Wa_cat, d.bias_a, d.Wd_cat, d.bias_d = nv.ptr(Wa_cat), nv.ptr(bias_a), nv.ptr(Wd_cat), nv.ptr(bias_d)
+    d.WqT, d.U, d.v, d.Wpg, d.bias_pg = nv.ptr(WqT), nv.ptr(U), nv.ptr(vvec), nv.ptr(Wpg), nv.ptr(bpg)
+    d.memory, d.pm = nv.ptr(memory), nv.ptr(pm)
+    d.lens = nv.ptr(lens32, torch.int32) if ragged else None
+    d.keep_prenet = nv.ptr(keep, torch.uint8)
+    for k_, v_ in st.items():
+        setattr(d, k_, nv.ptr(v_))
+    d.out_lengths = nv.ptr(out_lengths, torch.int32)
+    d.active = nv.ptr(active, torch.uint8)
+    d.done_count = nv.ptr(done, torch.int32)
+
+    t = 0
+    while t < max_steps:
+        n = min(poll_steps, max_steps - t)
+        d.t0, d.n_steps = t, n
+        nv.decoder_infer_steps(d)
+        t += n
+        if int(done.item()) >= B:       # one device->host sync per poll_steps steps
+            break
+    lengths = out_lengths.to(torch.long)
+    Tout = int(lengths.max().item())
+    hit_max = bool((lengths >= max_steps).any().item()) and Tout >= max_steps
+    # if the stop fired exactly on the last allowed step the reference does not warn; it warns
+    # only when the loop ends through the max_decoder_steps branch.
+    if hit_max:
+        PGl = st['PG'][max_steps - 1]
+        sg = torch.sigmoid(PGl[:, Cm])
+        hit_max = bool(((lengths >= max_steps) & ~(sg > hp.gate_threshold)).any().item())
+
+    # outputs, padded to the longest utterance; frames past an utterance's own length are zeroed
+    Tout = max(Tout, 1)
+    PG = st['PG'][:Tout].contiguous()
+    mel_cl = run.empty(B, Tout, Cm)
+    gate_bt = run.empty(B, Tout)
+    nv.split_projection(PG, mel_cl, gate_bt, None)
+    olens32 = out_lengths if ragged else None
+    xin = mel_cl.view(B * Tout, Cm)
+    if ragged:
+        # every utterance must see zero padding beyond its own last frame, as a B == 1 run would
+        ones = run.empty(Cm); nv.fill(ones, 1.0)
+        zeros = run.zeros(Cm)
+        xm = run.empty(B * Tout, Cm)
+        nv.bn_act_fwd(xin, xm, zeros, ones, ones, zeros, 0, None, 1.0, olens32, Tout)
+        xin = xm
+    post_cl, _ = _conv_stack_fwd(run, P, bufs, 'postnet.convolutions', hp.postnet_n_convolutions,
+                                 xin, Tout, [2] * (hp.postnet_n_convolutions - 1) + [0], None, False,
+                                 lens=olens32)
+    mel = run.empty(B, Cm, Tout)
+    mel_post = run.empty(B, Cm, Tout)
+    nv.finalize_outputs(mel_cl, post_cl.view(B, Tout, Cm), mel, mel_post, olens32)
+    align = st['ALIGN'][:, :Tout].contiguous()
+    gate_out = gate_bt.unsqueeze(-1)                      # (B, T, 1) like model.py:440
+    return [mel, mel_post, gate_out, align], lengths, hit_max

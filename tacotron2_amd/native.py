@@ -1,0 +1,726 @@
+"""ctypes binding of ``libtacotron2_amd.so`` (C ABI: ``include/tacotron2_amd.h``).
+
+The engine has exactly one compute path: the HIP kernels behind this module.
+There is no CPU or eager-PyTorch fallback — if the library is missing or a
+tensor is not a device tensor the call fails loudly.  PyTorch is used for
+device memory and streams only: every wrapper takes ``torch`` tensors, checks
+dtype/layout, and hands raw device pointers plus the current HIP stream to the
+library.
+
+Build the library with ``python -m tacotron2_amd.build`` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtacotron2_amd.so")
+
+ATT_DIM = 128
+LOC_FILTERS = 32
+LOC_KERNEL = 31
+LOC_TAPS = 62
+
+_f32p = C.c_void_p
+_i64 = C.c_longlong
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", _f32p), ("B", _f32p), ("C", _f32p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", _i64), ("ldb", _i64), ("ldc", _i64),
+        ("a_kcontig", C.c_int), ("b_kcontig", C.c_int),
+        ("batch", C.c_int),
+        ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
+        ("splitk", C.c_int), ("strideSplitC", _i64),
+        ("accumulate", C.c_int),
+        ("bias", _f32p), ("act", C.c_int),
+        ("keep", C.c_void_p), ("ldkeep", _i64), ("keep_scale", C.c_float),
+        ("convA_T", C.c_int), ("convA_C", C.c_int), ("convA_pad", C.c_int), ("convA_sign", C.c_int),
+        ("convB_T", C.c_int), ("convB_C", C.c_int), ("convB_pad", C.c_int),
+    ]
+
+
+class Seg(C.Structure):
+    _fields_ = [("p", _f32p), ("ld", _i64), ("width", C.c_int)]
+
+
+class LstmStep(C.Structure):
+    _fields_ = [
+        ("x", Seg * 3), ("nseg", C.c_int),
+        ("W", _f32p), ("Ktot", C.c_int), ("H", C.c_int), ("B", C.c_int),
+        ("gin", _f32p), ("ld_gin", _i64),
+        ("bias", _f32p),
+        ("c_prev", _f32p), ("ld_cprev", _i64),
+        ("gates_out", _f32p), ("ld_gates", _i64),
+        ("c_out", _f32p), ("ld_c", _i64),
+        ("h_out", _f32p), ("ld_h", _i64),
+        ("keep", C.c_void_p), ("ld_keep", _i64), ("keep_scale", C.c_float),
+        ("lens", C.c_void_p), ("t", C.c_int),
+    ]
+
+
+class SkinnyGemm(C.Structure):
+    _fields_ = [
+        ("x", Seg * 3), ("nseg", C.c_int),
+        ("W", _f32p), ("Ktot", C.c_int), ("N", C.c_int), ("B", C.c_int),
+        ("Y", _f32p), ("ldy", _i64), ("nsplit", C.c_int), ("split_stride", _i64),
+    ]
+
+
+class Addend(C.Structure):
+    _fields_ = [("p", _f32p), ("ld", _i64), ("nsplit", C.c_int), ("split_stride", _i64)]
+
+
+class LstmBwd(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("H", C.c_int),
+        ("dh", Addend * 3),
+        ("gates", _f32p), ("ld_gates", _i64),
+        ("c_prev", _f32p), ("ld_cprev", _i64),
+        ("c", _f32p), ("ld_c", _i64),
+        ("keep", C.c_void_p), ("ld_keep", _i64), ("keep_scale", C.c_float),
+        ("dc", _f32p), ("ld_dc", _i64),
+        ("dgates", _f32p), ("ld_dgates", _i64),
+        ("lens", C.c_void_p), ("t", C.c_int),
+    ]
+
+
+class AttnFwd(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("Ti", C.c_int), ("E", C.c_int), ("Hq", C.c_int),
+        ("h", _f32p), ("ld_h", _i64),
+        ("WqT", _f32p), ("U", _f32p), ("v", _f32p), ("pm", _f32p), ("memory", _f32p),
+        ("lens", C.c_void_p),
+        ("w_prev", _f32p), ("ld_wprev", _i64),
+        ("cum", _f32p), ("cum_save", _f32p),
+        ("w_out", _f32p), ("ld_wout", _i64),
+        ("ctx_out", _f32p), ("ld_ctx", _i64),
+        ("q_out", _f32p), ("ld_q", _i64),
+        ("active", C.c_void_p),
+    ]
+
+
+class AttnBwd(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("Ti", C.c_int), ("E", C.c_int), ("Hq", C.c_int),
+        ("dctx", Addend * 3),
+        ("dctx_total", _f32p), ("ld_dctx_total", _i64),
+        ("d_w_extra", _f32p), ("ld_dwextra", _i64),
+        ("q", _f32p), ("ld_q", _i64),
+        ("Wq", _f32p), ("U", _f32p), ("v", _f32p), ("pm", _f32p), ("memory", _f32p),
+        ("lens", C.c_void_p),
+        ("w", _f32p), ("ld_w", _i64),
+        ("w_prev", _f32p), ("ld_wprev", _i64),
+        ("cum_before", _f32p),
+        ("dw_carry", _f32p), ("dcum_carry", _f32p),
+        ("d_pm", _f32p), ("dU_acc", _f32p), ("dv_acc", _f32p),
+        ("dq_out", _f32p), ("ld_dq", _i64),
+        ("dh_out", _f32p), ("ld_dh", _i64),
+    ]
+
+
+class DecTrain(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("Ti", C.c_int), ("To", C.c_int), ("E", C.c_int), ("Ha", C.c_int), ("Hd", C.c_int),
+        ("Wa_rec", _f32p), ("Wd_cat", _f32p), ("bias_d", _f32p), ("WqT", _f32p), ("U", _f32p), ("v", _f32p),
+        ("GA", _f32p), ("memory", _f32p), ("pm", _f32p), ("lens", C.c_void_p),
+        ("keep_att", C.c_void_p), ("keep_dec", C.c_void_p),
+        ("scale_att", C.c_float), ("scale_dec", C.c_float),
+        ("HA", _f32p), ("CA", _f32p), ("GD", _f32p), ("HD", _f32p), ("CD", _f32p), ("CTX", _f32p),
+        ("Q", _f32p), ("ALIGN", _f32p), ("CUM", _f32p), ("cum_work", _f32p),
+    ]
+
+
+class DecTrainBwd(C.Structure):
+    _fields_ = [
+        ("f", DecTrain),
+        ("Wa_recT", _f32p), ("Wd_catT", _f32p), ("Wq", _f32p), ("DHC", _f32p), ("d_align", _f32p),
+        ("nsplit", C.c_int),
+        ("DGA", _f32p), ("DGD", _f32p), ("DCTX", _f32p), ("DQ", _f32p), ("d_pm", _f32p),
+        ("dU_acc", _f32p), ("dv_acc", _f32p),
+        ("dXd", _f32p), ("dXa", _f32p), ("dc_a", _f32p), ("dc_d", _f32p),
+        ("dw_carry", _f32p), ("dcum_carry", _f32p), ("dq_h", _f32p),
+    ]
+
+
+class LstmSeq(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("reverse", C.c_int),
+        ("Whh", _f32p), ("WhhT", _f32p), ("GX", _f32p),
+        ("out", _f32p), ("ld_out", _i64),
+        ("C", _f32p), ("lens", C.c_void_p),
+        ("dout", _f32p), ("ld_dout", _i64),
+        ("DG", _f32p), ("dX", _f32p), ("dc", _f32p),
+    ]
+
+
+class DecInfer(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("Ti", C.c_int), ("E", C.c_int), ("Ha", C.c_int), ("Hd", C.c_int),
+        ("P", C.c_int), ("C", C.c_int),
+        ("t0", C.c_int), ("n_steps", C.c_int), ("max_steps", C.c_int),
+        ("gate_threshold", C.c_float),
+        ("W1", _f32p), ("W2", _f32p), ("Wa_cat", _f32p), ("bias_a", _f32p), ("Wd_cat", _f32p),
+        ("bias_d", _f32p), ("WqT", _f32p), ("U", _f32p), ("v", _f32p), ("Wpg", _f32p), ("bias_pg", _f32p),
+        ("memory", _f32p), ("pm", _f32p), ("lens", C.c_void_p), ("keep_prenet", C.c_void_p),
+        ("h_a", _f32p), ("c_a", _f32p), ("c_d", _f32p), ("hc", _f32p), ("cum", _f32p),
+        ("x_prenet", _f32p), ("gates", _f32p), ("zero_frame", _f32p),
+        ("PG", _f32p), ("ALIGN", _f32p), ("out_lengths", C.c_void_p), ("active", C.c_void_p),
+        ("done_count", C.c_void_p),
+    ]
+
+
+_STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnBwd, DecTrain,
+            DecTrainBwd, LstmSeq, DecInfer]
+
+# every exported symbol of include/tacotron2_amd.h
+SYMBOLS = [
+    "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only",
+    "t2amd_gemm_f32", "t2amd_splitk_reduce_f32",
+    "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
+    "t2amd_colsum_f32",
+    "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
+    "t2amd_copy2d_f32", "t2amd_transpose_f32", "t2amd_frames_to_time_major_f32",
+    "t2amd_split_projection_f32", "t2amd_finalize_outputs_f32", "t2amd_grads_to_channel_last_f32",
+    "t2amd_gather_dout_f32", "t2amd_relu_dropout_bwd_f32",
+    "t2amd_lstm_step_fwd_f32", "t2amd_skinny_gemm_f32", "t2amd_lstm_pointwise_bwd_f32",
+    "t2amd_fold_location_f32", "t2amd_unfold_location_grads_f32",
+    "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
+    "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
+    "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
+]
+
+_P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
+
+
+def _argtypes():
+    pt = C.POINTER
+    return {
+        "t2amd_gemm_f32": [pt(GemmDesc), _P],
+        "t2amd_splitk_reduce_f32": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
+        "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
+        "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
+        "t2amd_bn_act_fwd_f32": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _L, _F, _P, _I, _P],
+        "t2amd_bn_act_bwd_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P, _P, _P, _I, _P, _L, _F, _P, _P, _P, _P],
+        "t2amd_colsum_f32": [_P, _L, _I, _I, _P, _P, _I, _P],
+        "t2amd_embedding_fwd_f32": [_P, _P, _P, _L, _I, _I, _P],
+        "t2amd_embedding_bwd_f32": [_P, _P, _P, _L, _I, _I, _P],
+        "t2amd_philox_keep_mask": [_P, _L, _F, _UL, _UL, _P],
+        "t2amd_fill_f32": [_P, _L, _F, _P],
+        "t2amd_copy2d_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P],
+        "t2amd_transpose_f32": [_P, _L, _P, _L, _I, _I, _I, _L, _L, _P],
+        "t2amd_frames_to_time_major_f32": [_P, _P, _I, _I, _I, _P],
+        "t2amd_split_projection_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
+        "t2amd_finalize_outputs_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+        "t2amd_grads_to_channel_last_f32": [_P, _P, _P, _P, _I, _I, _I, _P],
+        "t2amd_gather_dout_f32": [_P, _P, _P, _I, _I, _I, _P],
+        "t2amd_relu_dropout_bwd_f32": [_P, _P, _F, _L, _P],
+        "t2amd_lstm_step_fwd_f32": [pt(LstmStep), _P],
+        "t2amd_skinny_gemm_f32": [pt(SkinnyGemm), _P],
+        "t2amd_lstm_pointwise_bwd_f32": [pt(LstmBwd), _P],
+        "t2amd_fold_location_f32": [_P, _P, _P, _P],
+        "t2amd_unfold_location_grads_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P],
+        "t2amd_attention_step_fwd_f32": [pt(AttnFwd), _P],
+        "t2amd_attention_step_bwd_f32": [pt(AttnBwd), _P],
+        "t2amd_decoder_train_fwd_loop_f32": [pt(DecTrain), _P],
+        "t2amd_decoder_train_bwd_loop_f32": [pt(DecTrainBwd), _P],
+        "t2amd_lstm_seq_fwd_f32": [pt(LstmSeq), _P],
+        "t2amd_lstm_seq_bwd_f32": [pt(LstmSeq), _P],
+        "t2amd_decoder_infer_steps_f32": [pt(DecInfer), _P],
+        "t2amd_struct_sizes": [pt(C.c_int), _I],
+        "t2amd_set_validate_only": [_I],
+    }
+
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (once).  Raises NativeError when it is missing —
+    there is no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "tacotron2_amd: %s not found. The MI355X engine has no fallback path; build it with "
+            "`python -m tacotron2_amd.build` (needs hipcc)." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name in SYMBOLS:
+        if not hasattr(lib, name):
+            raise NativeError("tacotron2_amd: symbol %s missing from %s" % (name, LIB_PATH))
+    for name, at in _argtypes().items():
+        fn = getattr(lib, name)
+        fn.argtypes = at
+        fn.restype = C.c_int
+    lib.t2amd_last_error.restype = C.c_char_p
+    lib.t2amd_abi_version.restype = C.c_int
+    if lib.t2amd_abi_version() != 1:
+        raise NativeError("tacotron2_amd: ABI version mismatch")
+    sizes = (C.c_int * 32)()
+    n = lib.t2amd_struct_sizes(sizes, 32)
+    if n != len(_STRUCTS):
+        raise NativeError("tacotron2_amd: struct count mismatch (%d vs %d)" % (n, len(_STRUCTS)))
+    for i, st in enumerate(_STRUCTS):
+        if C.sizeof(st) != sizes[i]:
+            raise NativeError("tacotron2_amd: sizeof(%s) = %d in Python, %d in the library"
+                              % (st.__name__, C.sizeof(st), sizes[i]))
+    _lib = lib
+    return lib
+
+
+_validate_only = False
+
+
+def set_validate_only(on):
+    """Argument-check mode for CPU tests: host logic runs, kernels are not launched, tensors may
+    live on the CPU and outputs stay uninitialised.  Never a compute path."""
+    global _validate_only
+    load().t2amd_set_validate_only(1 if on else 0)
+    _validate_only = bool(on)
+
+
+def validate_only():
+    return _validate_only
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _lib.t2amd_last_error()
+        raise NativeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def _stream():
+    if _validate_only:
+        return None
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, dtype=torch.float32):
+    """Raw device pointer of a tensor (None -> NULL), with dtype/device checks."""
+    if t is None:
+        return None
+    if not t.is_cuda and not _validate_only:
+        raise NativeError("tacotron2_amd: expected a device (HIP) tensor, got a %s tensor; the engine "
+                          "has no CPU path" % t.device)
+    if dtype is not None and t.dtype != dtype:
+        raise NativeError("tacotron2_amd: expected %s, got %s" % (dtype, t.dtype))
+    return C.c_void_p(t.data_ptr())
+
+
+def _mat(t):
+    """2-D view with unit inner stride -> (ptr, ld, rows, cols)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise NativeError("expected a 2-D tensor with contiguous rows, got shape %s stride %s"
+                          % (tuple(t.shape), t.stride()))
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+    return ptr(t), ld, t.shape[0], t.shape[1]
+
+
+def _fullc(t):
+    if not t.is_contiguous():
+        raise NativeError("expected a contiguous tensor, got shape %s stride %s" % (tuple(t.shape), t.stride()))
+    return t
+
+
+def scale_for(p):
+    """fp32 1/(1-p), formed like ATen's dropout (noise.div_(1-p))."""
+    return float(torch.tensor(1.0, dtype=torch.float32) / torch.tensor(1.0 - p, dtype=torch.float32))
+
+
+# ----------------------------------------------------------------------------
+# GEMM
+# ----------------------------------------------------------------------------
+def gemm(Cm, A, B, a_km=False, b_kn=False, accumulate=False, bias=None, act=0, keep=None,
+         keep_scale=1.0, convA=None, convB=None, batch=1, strides=(0, 0, 0), splitk=1, partials=None):
+    """Cm[M,N] (+)= act(A.B + bias)*keep.
+
+    A is a view [M,K] (default) or [K,M] when ``a_km``;  B is a view [N,K] (default, the
+    nn.Linear weight layout) or [K,N] when ``b_kn``.  ``convA=(T,C,pad,sign)`` / ``convB=(T,C,pad)``
+    switch on implicit-convolution addressing (see the header).  With ``splitk>1`` the partial
+    results go to ``partials`` ([splitk, M*N] contiguous) and Cm is not written."""
+    lib = load()
+    d = GemmDesc()
+    pa, lda, r0, c0 = _mat(A)
+    pb, ldb, r1, c1 = _mat(B)
+    pc, ldc, M, N = _mat(Cm)
+    Ka, Ma = (r0, c0) if a_km else (c0, r0)
+    Kb, Nb = (r1, c1) if b_kn else (c1, r1)
+    if convA is not None:
+        # A is the plain activation matrix [rows, C]; the virtual K is taps*C, taken from B
+        if a_km or Ka != convA[1] or Kb % convA[1] != 0:
+            raise NativeError("gemm: convA needs A=[rows,C] and K(B) a multiple of C")
+        K = Kb
+    else:
+        K = Ka
+    if convB is not None:
+        # B is the plain activation matrix [rows, C] (K = rows); the virtual N is taps*C, taken from C
+        if not b_kn or Nb != convB[1] or N % convB[1] != 0:
+            raise NativeError("gemm: convB needs B=[rows,C] (b_kn) and N(C) a multiple of C")
+        Nb = N
+    if Ma != M or Nb != N or Kb != K:
+        raise NativeError("gemm: shape mismatch C=%s A=%s B=%s (a_km=%s b_kn=%s K=%d)"
+                          % (tuple(Cm.shape), tuple(A.shape), tuple(B.shape), a_km, b_kn, K))
+    d.A, d.B, d.C = pa, pb, pc
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc = lda, ldb, ldc
+    d.a_kcontig = 0 if a_km else 1
+    d.b_kcontig = 0 if b_kn else 1
+    d.batch = batch
+    d.strideA, d.strideB, d.strideC = strides
+    d.splitk = splitk
+    d.accumulate = 1 if accumulate else 0
+    d.bias = ptr(bias)
+    d.act = act
+    if keep is not None:
+        if keep.dim() != 2 or tuple(keep.shape) != (M, N) or keep.stride(1) != 1:
+            raise NativeError("gemm: keep mask must be a [M,N] uint8 view, got %s" % (tuple(keep.shape),))
+        d.keep, d.ldkeep, d.keep_scale = ptr(keep, torch.uint8), keep.stride(0), keep_scale
+    if convA is not None:
+        d.convA_T, d.convA_C, d.convA_pad, d.convA_sign = convA
+    if convB is not None:
+        d.convB_T, d.convB_C, d.convB_pad = convB
+    if splitk > 1:
+        if partials is None or partials.numel() < splitk * M * N or not partials.is_contiguous():
+            raise NativeError("gemm: split-K needs a contiguous partials buffer")
+        d.C = ptr(partials)
+        d.ldc = N
+        d.strideSplitC = M * N
+    _check(lib.t2amd_gemm_f32(C.byref(d), _stream()), "t2amd_gemm_f32")
+
+
+def splitk_reduce(partials, nsplit, out, accumulate=False, perm_taps=0, perm_ci=0):
+    lib = load()
+    n = out.numel()
+    _fullc(out)
+    _check(lib.t2amd_splitk_reduce_f32(ptr(partials), nsplit, _i64(n), ptr(out), _i64(n),
+                                       1 if accumulate else 0, perm_taps, perm_ci, _stream()),
+           "t2amd_splitk_reduce_f32")
+
+
+# ----------------------------------------------------------------------------
+# normalisation / elementwise
+# ----------------------------------------------------------------------------
+def bn_stats(x, ws, mean, invstd, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    lib = load()
+    px, ldx, M, N = _mat(x)
+    _check(lib.t2amd_bn_stats_f32(px, _i64(ldx), M, N, ptr(ws, torch.float64), ptr(mean), ptr(invstd),
+                                  ptr(running_mean), ptr(running_var), C.c_float(momentum), C.c_float(eps),
+                                  _stream()), "t2amd_bn_stats_f32")
+
+
+def bn_eval_invstd(running_var, invstd, eps=1e-5):
+    lib = load()
+    _check(lib.t2amd_bn_eval_invstd_f32(ptr(running_var), ptr(invstd), running_var.numel(), C.c_float(eps),
+                                        _stream()), "t2amd_bn_eval_invstd_f32")
+
+
+def bn_act_fwd(x, y, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0, lens=None, T=0):
+    lib = load()
+    px, ldx, M, N = _mat(x)
+    py, ldy, M2, N2 = _mat(y)
+    assert (M, N) == (M2, N2)
+    pk, ldk = (None, 0)
+    if keep is not None:
+        assert tuple(keep.shape) == (M, N) and keep.stride(1) == 1
+        pk, ldk = ptr(keep, torch.uint8), keep.stride(0)
+    _check(lib.t2amd_bn_act_fwd_f32(px, _i64(ldx), py, _i64(ldy), M, N, ptr(mean), ptr(invstd), ptr(gamma),
+                                    ptr(beta), act, pk, _i64(ldk), C.c_float(keep_scale),
+                                    ptr(lens, torch.int32), T, _stream()), "t2amd_bn_act_fwd_f32")
+
+
+def bn_act_bwd(dy, y, x, mean, invstd, gamma, act, keep, keep_scale, ws, dgamma, dbeta):
+    lib = load()
+    pd, ldd, M, N = _mat(dy)
+    py, ldy, _, _ = _mat(y)
+    px, ldx, _, _ = _mat(x)
+    pk, ldk = (None, 0)
+    if keep is not None:
+        assert tuple(keep.shape) == (M, N) and keep.stride(1) == 1
+        pk, ldk = ptr(keep, torch.uint8), keep.stride(0)
+    _check(lib.t2amd_bn_act_bwd_f32(pd, _i64(ldd), py, _i64(ldy), px, _i64(ldx), M, N, ptr(mean), ptr(invstd),
+                                    ptr(gamma), act, pk, _i64(ldk), C.c_float(keep_scale),
+                                    ptr(ws, torch.float64), ptr(dgamma), ptr(dbeta), _stream()),
+           "t2amd_bn_act_bwd_f32")
+
+
+def colsum(x, ws, out, accumulate=False):
+    lib = load()
+    px, ldx, M, N = _mat(x)
+    assert out.numel() == N
+    _check(lib.t2amd_colsum_f32(px, _i64(ldx), M, N, ptr(ws, torch.float64), ptr(out), 1 if accumulate else 0,
+                                _stream()), "t2amd_colsum_f32")
+
+
+def embedding_fwd(ids, table, out):
+    lib = load()
+    rows = ids.numel()
+    _check(lib.t2amd_embedding_fwd_f32(ptr(_fullc(ids), torch.int64), ptr(_fullc(table)), ptr(_fullc(out)),
+                                       _i64(rows), table.shape[1], table.shape[0], _stream()),
+           "t2amd_embedding_fwd_f32")
+
+
+def embedding_bwd(ids, dout, dtable):
+    lib = load()
+    rows = ids.numel()
+    _check(lib.t2amd_embedding_bwd_f32(ptr(_fullc(ids), torch.int64), ptr(_fullc(dout)), ptr(_fullc(dtable)),
+                                       _i64(rows), dtable.shape[1], dtable.shape[0], _stream()),
+           "t2amd_embedding_bwd_f32")
+
+
+def philox_keep_mask(out, p, seed, offset=0):
+    lib = load()
+    _check(lib.t2amd_philox_keep_mask(ptr(_fullc(out), torch.uint8), _i64(out.numel()), C.c_float(p),
+                                      C.c_ulonglong(seed), C.c_ulonglong(offset), _stream()),
+           "t2amd_philox_keep_mask")
+
+
+def fill(t, v):
+    lib = load()
+    _check(lib.t2amd_fill_f32(ptr(_fullc(t)), _i64(t.numel()), C.c_float(v), _stream()), "t2amd_fill_f32")
+
+
+def copy2d(dst, src, src2=None):
+    lib = load()
+    pd, ldd, R, Cc = _mat(dst)
+    ps, lds, R1, C1 = _mat(src)
+    assert (R, Cc) == (R1, C1), (dst.shape, src.shape)
+    p2, ld2 = (None, 0)
+    if src2 is not None:
+        p2, ld2, R2, C2 = _mat(src2)
+        assert (R, Cc) == (R2, C2)
+    _check(lib.t2amd_copy2d_f32(ps, _i64(lds), p2, _i64(ld2), pd, _i64(ldd), R, Cc, _stream()), "t2amd_copy2d_f32")
+
+
+def transpose(dst, src, batch=1, sstride=0, dstride=0):
+    """dst[c][r] = src[r][c] for 2-D views (per batch item)."""
+    lib = load()
+    ps, lds, R, Cc = _mat(src)
+    pd, ldd, R1, C1 = _mat(dst)
+    assert (R1, C1) == (Cc, R), (dst.shape, src.shape)
+    _check(lib.t2amd_transpose_f32(ps, _i64(lds), pd, _i64(ldd), R, Cc, batch, _i64(sstride), _i64(dstride),
+                                   _stream()), "t2amd_transpose_f32")
+
+
+def frames_to_time_major(mels, x0):
+    lib = load()
+    B, Cm, To = mels.shape
+    assert tuple(x0.shape) == (To, B, Cm)
+    _check(lib.t2amd_frames_to_time_major_f32(ptr(_fullc(mels)), ptr(_fullc(x0)), B, Cm, To, _stream()),
+           "t2amd_frames_to_time_major_f32")
+
+
+def split_projection(pg, mel_cl, gate, out_lens):
+    lib = load()
+    B, To, Cm = mel_cl.shape
+    assert pg.numel() == To * B * (Cm + 1)
+    _check(lib.t2amd_split_projection_f32(ptr(_fullc(pg)), ptr(_fullc(mel_cl)), ptr(_fullc(gate)),
+                                          ptr(out_lens, torch.int32), B, Cm, To, _stream()),
+           "t2amd_split_projection_f32")
+
+
+def finalize_outputs(mel_cl, post_cl, mel, mel_post, out_lens):
+    lib = load()
+    B, To, Cm = mel_cl.shape
+    _check(lib.t2amd_finalize_outputs_f32(ptr(_fullc(mel_cl)), ptr(post_cl), ptr(_fullc(mel)), ptr(mel_post),
+                                          ptr(out_lens, torch.int32), B, Cm, To, _stream()),
+           "t2amd_finalize_outputs_f32")
+
+
+def grads_to_channel_last(dmel, dmel_post, dmel_cl, dpost_cl):
+    lib = load()
+    B, To, Cm = dmel_cl.shape
+    _check(lib.t2amd_grads_to_channel_last_f32(ptr(dmel), ptr(dmel_post), ptr(_fullc(dmel_cl)),
+                                               ptr(_fullc(dpost_cl)), B, Cm, To, _stream()),
+           "t2amd_grads_to_channel_last_f32")
+
+
+def gather_dout(dmel_cl, dgate, dout):
+    lib = load()
+    B, To, Cm = dmel_cl.shape
+    _check(lib.t2amd_gather_dout_f32(ptr(_fullc(dmel_cl)), ptr(dgate), ptr(_fullc(dout)), B, Cm, To, _stream()),
+           "t2amd_gather_dout_f32")
+
+
+def relu_dropout_bwd(dy, y, scale):
+    lib = load()
+    assert dy.shape == y.shape
+    _check(lib.t2amd_relu_dropout_bwd_f32(ptr(_fullc(dy)), ptr(_fullc(y)), C.c_float(scale), _i64(dy.numel()),
+                                          _stream()), "t2amd_relu_dropout_bwd_f32")
+
+
+# ----------------------------------------------------------------------------
+# recurrent / attention single steps (used by the unit tests; the loops call them in C)
+# ----------------------------------------------------------------------------
+def _seg(t, width):
+    s = Seg()
+    if t is None:
+        s.p, s.ld, s.width = None, width, width
+    else:
+        p, ld, _, cols = _mat(t)
+        assert cols == width
+        s.p, s.ld, s.width = p, ld, width
+    return s
+
+
+def lstm_step_fwd(xs, widths, W, H, B, gates_out, c_out, h_out, gin=None, bias=None, c_prev=None,
+                  keep=None, keep_scale=1.0, lens=None, t=0):
+    lib = load()
+    a = LstmStep()
+    a.nseg = len(xs)
+    for i, (x, w) in enumerate(zip(xs, widths)):
+        a.x[i] = _seg(x, w)
+    a.W = ptr(_fullc(W))
+    a.Ktot, a.H, a.B = sum(widths), H, B
+    if gin is not None:
+        a.gin, a.ld_gin = _mat(gin)[:2]
+    a.bias = ptr(bias)
+    if c_prev is not None:
+        a.c_prev, a.ld_cprev = _mat(c_prev)[:2]
+    a.gates_out, a.ld_gates = _mat(gates_out)[:2]
+    a.c_out, a.ld_c = _mat(c_out)[:2]
+    a.h_out, a.ld_h = _mat(h_out)[:2]
+    if keep is not None:
+        a.keep, a.ld_keep, a.keep_scale = ptr(keep, torch.uint8), keep.stride(0), keep_scale
+    a.lens = ptr(lens, torch.int32)
+    a.t = t
+    _check(lib.t2amd_lstm_step_fwd_f32(C.byref(a), _stream()), "t2amd_lstm_step_fwd_f32")
+
+
+def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1):
+    """Y[nsplit, B, N] = [xs...] . W[N, K]^T"""
+    lib = load()
+    a = SkinnyGemm()
+    a.nseg = len(xs)
+    for i, (x, w) in enumerate(zip(xs, widths)):
+        a.x[i] = _seg(x, w)
+    a.W = ptr(_fullc(W))
+    a.Ktot, a.N, a.B = sum(widths), N, B
+    _fullc(Y)
+    a.Y, a.ldy, a.nsplit, a.split_stride = ptr(Y), N, nsplit, B * N
+    _check(lib.t2amd_skinny_gemm_f32(C.byref(a), _stream()), "t2amd_skinny_gemm_f32")
+
+
+def _addend(t, nsplit=1, split_stride=0):
+    a = Addend()
+    if t is None:
+        a.p, a.ld, a.nsplit, a.split_stride = None, 0, 1, 0
+    else:
+        p, ld, _, _ = _mat(t)
+        a.p, a.ld, a.nsplit, a.split_stride = p, ld, nsplit, split_stride
+    return a
+
+
+def lstm_pointwise_bwd(B, H, dh_list, gates, c_prev, c, keep, keep_scale, dc, dgates, lens=None, t=0):
+    lib = load()
+    a = LstmBwd()
+    a.B, a.H = B, H
+    for i in range(3):
+        a.dh[i] = _addend(dh_list[i] if i < len(dh_list) else None)
+    a.gates, a.ld_gates = _mat(gates)[:2]
+    if c_prev is not None:
+        a.c_prev, a.ld_cprev = _mat(c_prev)[:2]
+    a.c, a.ld_c = _mat(c)[:2]
+    if keep is not None:
+        a.keep, a.ld_keep, a.keep_scale = ptr(keep, torch.uint8), keep.stride(0), keep_scale
+    a.dc, a.ld_dc = _mat(dc)[:2]
+    a.dgates, a.ld_dgates = _mat(dgates)[:2]
+    a.lens = ptr(lens, torch.int32)
+    a.t = t
+    _check(lib.t2amd_lstm_pointwise_bwd_f32(C.byref(a), _stream()), "t2amd_lstm_pointwise_bwd_f32")
+
+
+def fold_location(wdense, wconv, U):
+    """U buffer: 128*62 floats of U followed by 64*128 floats of U^T."""
+    lib = load()
+    assert U.numel() == ATT_DIM * LOC_TAPS + 64 * ATT_DIM
+    assert tuple(wdense.shape) == (ATT_DIM, LOC_FILTERS) and tuple(wconv.shape) == (LOC_FILTERS, 2, LOC_KERNEL)
+    _check(lib.t2amd_fold_location_f32(ptr(_fullc(wdense)), ptr(_fullc(wconv)), ptr(_fullc(U)), _stream()),
+           "t2amd_fold_location_f32")
+
+
+def unfold_location_grads(dU_acc, dv_acc, nb, wdense, wconv, dwdense, dwconv, dv):
+    lib = load()
+    _check(lib.t2amd_unfold_location_grads_f32(ptr(_fullc(dU_acc)), ptr(_fullc(dv_acc)), nb, ptr(_fullc(wdense)),
+                                               ptr(_fullc(wconv)), ptr(_fullc(dwdense)), ptr(_fullc(dwconv)),
+                                               ptr(_fullc(dv)), _stream()), "t2amd_unfold_location_grads_f32")
+
+
+def attention_step_fwd(h, WqT, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, active=None):
+    lib = load()
+    a = AttnFwd()
+    B, Ti, E = memory.shape
+    a.B, a.Ti, a.E, a.Hq = B, Ti, E, h.shape[1]
+    a.h, a.ld_h = _mat(h)[:2]
+    a.WqT, a.U, a.v, a.pm, a.memory = ptr(_fullc(WqT)), ptr(U), ptr(v), ptr(_fullc(pm)), ptr(_fullc(memory))
+    a.lens = ptr(lens, torch.int32)
+    if w_prev is not None:
+        a.w_prev, a.ld_wprev = _mat(w_prev)[:2]
+    a.cum = ptr(_fullc(cum))
+    a.cum_save = ptr(cum_save)
+    a.w_out, a.ld_wout = _mat(w_out)[:2]
+    a.ctx_out, a.ld_ctx = _mat(ctx_out)[:2]
+    if q_out is not None:
+        a.q_out, a.ld_q = _mat(q_out)[:2]
+    a.active = ptr(active, torch.uint8)
+    _check(lib.t2amd_attention_step_fwd_f32(C.byref(a), _stream()), "t2amd_attention_step_fwd_f32")
+
+
+def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory, lens, w, w_prev, cum_before,
+                       dw_carry, dcum_carry, d_pm, dU_acc, dv_acc, dq_out, dh_out):
+    lib = load()
+    a = AttnBwd()
+    B, Ti, E = memory.shape
+    a.B, a.Ti, a.E, a.Hq = B, Ti, E, Wq.shape[1]
+    for i in range(3):
+        a.dctx[i] = _addend(dctx_list[i] if i < len(dctx_list) else None)
+    a.dctx_total, a.ld_dctx_total = _mat(dctx_total)[:2]
+    if d_w_extra is not None:
+        a.d_w_extra, a.ld_dwextra = _mat(d_w_extra)[:2]
+    a.q, a.ld_q = _mat(q)[:2]
+    a.Wq, a.U, a.v, a.pm, a.memory = ptr(_fullc(Wq)), ptr(U), ptr(v), ptr(_fullc(pm)), ptr(_fullc(memory))
+    a.lens = ptr(lens, torch.int32)
+    a.w, a.ld_w = _mat(w)[:2]
+    if w_prev is not None:
+        a.w_prev, a.ld_wprev = _mat(w_prev)[:2]
+    a.cum_before = ptr(_fullc(cum_before))
+    a.dw_carry, a.dcum_carry = ptr(_fullc(dw_carry)), ptr(_fullc(dcum_carry))
+    a.d_pm, a.dU_acc, a.dv_acc = ptr(_fullc(d_pm)), ptr(_fullc(dU_acc)), ptr(_fullc(dv_acc))
+    a.dq_out, a.ld_dq = _mat(dq_out)[:2]
+    a.dh_out, a.ld_dh = _mat(dh_out)[:2]
+    _check(lib.t2amd_attention_step_bwd_f32(C.byref(a), _stream()), "t2amd_attention_step_bwd_f32")
+
+
+# ----------------------------------------------------------------------------
+# loops
+# ----------------------------------------------------------------------------
+def decoder_train_fwd_loop(desc):
+    lib = load()
+    _check(lib.t2amd_decoder_train_fwd_loop_f32(C.byref(desc), _stream()), "t2amd_decoder_train_fwd_loop_f32")
+
+
+def decoder_train_bwd_loop(desc):
+    lib = load()
+    _check(lib.t2amd_decoder_train_bwd_loop_f32(C.byref(desc), _stream()), "t2amd_decoder_train_bwd_loop_f32")
+
+
+def lstm_seq_fwd(desc):
+    lib = load()
+    _check(lib.t2amd_lstm_seq_fwd_f32(C.byref(desc), _stream()), "t2amd_lstm_seq_fwd_f32")
+
+
+def lstm_seq_bwd(desc):
+    lib = load()
+    _check(lib.t2amd_lstm_seq_bwd_f32(C.byref(desc), _stream()), "t2amd_lstm_seq_bwd_f32")
+
+
+def decoder_infer_steps(desc):
+    lib = load()
+    _check(lib.t2amd_decoder_infer_steps_f32(C.byref(desc), _stream()), "t2amd_decoder_infer_steps_f32")

@@ -1,0 +1,101 @@
+"""Drop-in boundary, host logic and C-ABI surface (CPU only, no compute calls)."""
+import ctypes
+import re
+import os
+
+import pytest
+import torch
+
+import golden_util as gu
+from tacotron2_amd.hparams import create_hparams
+from tacotron2_amd.model import Tacotron2
+from tacotron2_amd import native
+
+
+def test_hparams_defaults_and_parsing():
+    hp = create_hparams()
+    assert hp.n_symbols == 148 and hp.batch_size == 64 and hp.mask_padding is True
+    assert len(hp.values()) == 48                               # 48 fields
+    hp = create_hparams("batch_size=2,fp16_run=True,ignore_layers=[a.b,c],learning_rate=0.01,dist_url=tcp://x:1")
+    assert hp.batch_size == 2 and hp.fp16_run is True and hp.ignore_layers == ['a.b', 'c']
+    assert hp.learning_rate == 0.01 and hp.dist_url == "tcp://x:1"
+    with pytest.raises(ValueError):
+        create_hparams("no_such_field=1")
+
+
+def test_state_dict_surface():
+    torch.manual_seed(0)
+    m = Tacotron2(create_hparams())
+    sd = m.state_dict()
+    params = dict(m.named_parameters())
+    assert len(params) == 60 and len(sd) == 84
+    assert sum(p.numel() for p in params.values()) == 28193153
+    for k in ('embedding.weight', 'encoder.convolutions.2.0.conv.bias', 'encoder.lstm.weight_hh_l0_reverse',
+              'decoder.prenet.layers.1.linear_layer.weight', 'decoder.attention_rnn.bias_hh',
+              'decoder.attention_layer.location_layer.location_conv.conv.weight',
+              'decoder.attention_layer.v.linear_layer.weight', 'decoder.gate_layer.linear_layer.bias',
+              'postnet.convolutions.4.1.num_batches_tracked'):
+        assert k in sd, k
+    assert m.decoder.attention_layer.score_mask_value == -float("inf")
+    assert hasattr(m, 'parse_batch') and hasattr(m, 'inference') and hasattr(m, 'parse_output')
+
+
+def test_unsupported_geometry_fails_loudly():
+    with pytest.raises(ValueError):
+        Tacotron2(create_hparams("attention_dim=64"))
+    with pytest.raises(ValueError):
+        Tacotron2(create_hparams("n_frames_per_step=2"))
+
+
+def test_library_exports_every_header_symbol(native_lib):
+    hdr = open(os.path.join(gu.ROOT, "include", "tacotron2_amd.h")).read()
+    declared = set(re.findall(r"\b(t2amd_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 34
+    assert declared == set(native.SYMBOLS), declared ^ set(native.SYMBOLS)
+    for name in declared:
+        assert hasattr(native_lib, name), name
+    assert native_lib.t2amd_abi_version() == 1
+    sizes = (ctypes.c_int * 32)()
+    n = native_lib.t2amd_struct_sizes(sizes, 32)
+    assert [ctypes.sizeof(s) for s in native._STRUCTS] == list(sizes)[:n]
+
+
+def test_no_cpu_fallback(native_lib):
+    """CPU tensors must be refused: the product has one compute path."""
+    m = Tacotron2(create_hparams(gu.TINY_HP))
+    batch = gu.make_train_batch([5, 3], [7, 6], 80, 1)
+    x = (batch[0], batch[1], batch[2], 5, batch[4])
+    with pytest.raises(native.NativeError):
+        m(x)
+    with pytest.raises(native.NativeError):
+        m.inference(batch[0][:1])
+
+
+def test_argument_validation_errors_are_reported(native_lib):
+    d = native.GemmDesc()
+    rc = native_lib.t2amd_gemm_f32(ctypes.byref(d), None)
+    assert rc == 1 and b"null operand" in native_lib.t2amd_last_error()
+
+
+@pytest.mark.parametrize("hpstr,in_lens,out_lens", [(gu.TINY_HP, [12, 9, 5], [20, 16, 11]), ("", [17, 11], [30, 23])])
+def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens):
+    """Every host-side check / loop of forward, backward and inference runs (kernels skipped):
+    catches shape, stride, alignment and pointer-plumbing errors without a GPU."""
+    native.set_validate_only(True)
+    try:
+        hp = create_hparams((hpstr + "," if hpstr else "") + "max_decoder_steps=6")
+        m = Tacotron2(hp)
+        batch = gu.make_train_batch(in_lens, out_lens, 80, 1)
+        x, y = m.parse_batch(batch)
+        out = m(x)
+        assert [tuple(o.shape) for o in out] == [(len(in_lens), 80, max(out_lens))] * 2 + \
+            [(len(in_lens), max(out_lens)), (len(in_lens), max(out_lens), max(in_lens))]
+        (out[0].sum() + out[1].sum() + out[2].sum()).backward()
+        assert all(p.grad is not None and p.grad.shape == p.shape for p in m.parameters())
+        m.eval()
+        o = m.inference(batch[0][:1, :in_lens[0]])
+        assert o[2].dim() == 3 and o[2].shape[2] == 1
+        o = m.inference(batch[0], batch[1])
+        assert o[0].shape[0] == len(in_lens)
+    finally:
+        native.set_validate_only(False)
