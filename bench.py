@@ -1,0 +1,196 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of the reference loop (reference train.py:208-236) on one
+synthetic LJSpeech-shaped batch per GPU: parse_batch -> forward -> Tacotron2Loss -> backward
+(-> bucketed RCCL gradient all-reduce when N > 1) -> clip_grad_norm_ -> Adam.  Inputs are resident
+in HBM before the timed region.  Metric: VALID mel frames per second, whole job.
+
+Extra objects in the JSON line:
+  roofline      decoder-LSTM step kernel (skinny_gemm_kernel<true,2>): algorithmic bytes per launch
+                 / average launch duration measured live with HIP events on the
+                launch stream during one extra, untimed, step.
+  cpu_baseline  the CPU oracle (oracle/tacotron2_oracle.py, a port of the reference) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--cpu-sample", type=int, default=12, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_b, seed):
+    """Time the oracle (CPU port of the reference hot path) on a strided sub-batch of the bench batch."""
+    from oracle import tacotron2_oracle as orc
+    from tacotron2_amd.hparams import create_hparams
+    from tacotron2_amd.model import Tacotron2
+    from tacotron2_amd.synth import synth_batch
+    hp = create_hparams()
+    torch.manual_seed(1234)
+    sd = {k: v.detach().clone() for k, v in Tacotron2(hp).state_dict().items()}
+    full = synth_batch(64, seed)
+    idx = torch.arange(0, 64, 64 // sample_b)[:sample_b]
+    text, il, mel, gate, ol = (t[idx] for t in full)
+    Ti, To = int(il.max()), int(ol.max())
+    batch = (text[:, :Ti].contiguous(), il, mel[:, :, :To].contiguous(), gate[:, :To].contiguous(), ol)
+    g = torch.Generator().manual_seed(seed)
+    masks = orc.draw_masks_train(hp, sample_b, Ti, To, g)
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    orc.train_step_grads(sd, hp, batch, masks)
+    dt = time.perf_counter() - t0
+    frames = int(ol.sum())
+    return {"value": frames / dt, "unit": "valid mel-frames/s", "cores": threads, "kind": "port",
+            "sample": "1 fwd+bwd step (no optimiser) of oracle/tacotron2_oracle.py on %d of the 64 utterances "
+                      "(every %dth, Ti_max=%d, To_max=%d, %d valid frames), fp32, %.1f s"
+                      % (sample_b, 64 // sample_b, Ti, To, frames, dt)}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+
+    from tacotron2_amd import build, native
+    if rank == 0 or not os.path.exists(native.LIB_PATH):
+        build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    native.load()
+    from tacotron2_amd.hparams import create_hparams
+    from tacotron2_amd.model import Tacotron2
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    from tacotron2_amd.distributed import apply_gradient_allreduce
+    from tacotron2_amd.synth import synth_batch
+
+    hp = create_hparams()
+    hp.batch_size = args.batch_size
+    torch.manual_seed(hp.seed)                                  # every rank: same seed (train.py:165)
+    model = Tacotron2(hp).to(dev)
+    if world > 1:
+        model = apply_gradient_allreduce(model)
+    optimizer = torch.optim.Adam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    criterion = Tacotron2Loss()
+    model.train()
+
+    n_iter = args.warmup + args.steps
+    batches, frames = [], []
+    for i in range(n_iter):
+        b = synth_batch(args.batch_size, 1234 + 1000 * rank + i)          # per-rank shard, weak scaling
+        batches.append(tuple(t.to(dev) for t in b))
+        frames.append(int(b[4].sum()))
+    torch.cuda.synchronize()
+
+    def step(batch):
+        model.zero_grad()
+        x, y = model.parse_batch(batch)
+        y_pred = model(x)
+        loss = criterion(y_pred, y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), hp.grad_clip_thresh)
+        optimizer.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(batches[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_iter):
+        loss = step(batches[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timed_frames = sum(frames[args.warmup:])
+    if world > 1:
+        t = torch.tensor([elapsed, float(timed_frames)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, timed_frames = tmax[0].item(), t[1].item()
+    final_loss = float(loss.item())
+
+    # ---- roofline of the dominant kernel: one extra untimed step with HIP-event brackets ------
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        To = batches[-1][2].shape[2]
+        native.profile_enable(2, To)                                      # role 2 = decoder LSTM step
+        step(batches[-1])
+        torch.cuda.synchronize()
+        ms, cnt = native.profile_read()
+        B, Ha, Hd, E = args.batch_size, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.encoder_embedding_dim
+        K = Ha + E + Hd
+        alg_bytes = 4.0 * (4 * Hd * K + B * K + B * 4 * Hd + 4 * Hd + 3 * B * Hd + 0.25 * B * Hd)
+        avg_s = (ms / 1e3) / max(cnt, 1)
+        achieved = alg_bytes / avg_s / 1e9
+        roofline = {"kernel": "skinny_gemm_kernel<true,2> (decoder LSTM step: 64x2560x4096 f32 MFMA GEMM + cell)",
+                    "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": None,
+                    "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "mel-frames/sec (train fwd+bwd) LJSpeech hparams",
+            "value": timed_frames / elapsed, "unit": "valid mel-frames/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: LJSpeech default hparams, batch_size=%d per GPU, "
+                                   "synthetic LJSpeech-shaped batches (Ti<=187, To<=870), full train step "
+                                   "(fwd+loss+bwd+clip+Adam)" % args.batch_size,
+                       "global_batch": args.batch_size * args.gpus, "parallelism": "dp%d" % args.gpus,
+                       "compute": "fp32 storage, exact-f32 MFMA (bf16 path not built yet)"},
+            "padded_frames_per_s": None, "final_loss": final_loss,
+        }
+        out["padded_frames_per_s"] = sum(b[2].shape[2] * args.batch_size for b in batches[args.warmup:]) \
+            * args.gpus / elapsed if world == 1 else None
+        if roofline:
+            out["roofline"] = roofline
+        if args.gpus == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1234)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,6 +46,11 @@ int t2amd_struct_sizes(int* out, int max_n);
 /* Validate-only mode: all argument checks and host loops run, no kernel is launched (outputs are
  * left untouched).  For CPU-side tests of the binding; not a compute path. */
 int t2amd_set_validate_only(int on);
+/* Live kernel timing for bench.py's roofline: while enabled, every LSTM-step launch whose tag equals
+ * `tag` is bracketed by two hipEvents on its own stream (at most `max_launches` launches).
+ * t2amd_profile_read synchronises those events and returns the summed elapsed time and the count. */
+int t2amd_profile_enable(int tag, int max_launches);
+int t2amd_profile_read(float* total_ms, int* count);
 
 /* ------------------------------------------------------------------------------------
  * Dense / implicit-convolution GEMM on exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -193,6 +198,7 @@ typedef struct t2amd_lstm_step {
     float keep_scale;
     const int* lens;    /* NULL, or per-row valid length: rows with t >= lens[b] write h=c=gates=0 */
     int t;
+    int tag;            /* kernel-symbol / profiling role: 0 generic, 1 attention LSTM, 2 decoder LSTM */
 } t2amd_lstm_step;
 
 int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream);
@@ -207,6 +213,7 @@ typedef struct t2amd_skinny_gemm {
     long long ldy;
     int nsplit;
     long long split_stride;
+    int tag;          /* kernel-symbol role, as in t2amd_lstm_step */
 } t2amd_skinny_gemm;
 
 int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream);

@@ -1,6 +1,7 @@
 // Library-level glue of libtacotron2_amd.so: ABI version, last-error text, struct sizes.
 #include "common.h"
 #include <string.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -24,4 +25,52 @@ extern "C" int t2amd_struct_sizes(int* out, int max_n) {
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < max_n; ++i) out[i] = sizes[i];
     return n;
+}
+
+// ---- live kernel timing (bench.py roofline) ---------------------------------------------------
+static int g_prof_tag = -1, g_prof_max = 0, g_prof_n = 0;
+static std::vector<hipEvent_t> g_prof_ev;
+
+extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s) {
+    if (g_prof_tag < 0 || tag != g_prof_tag || g_validate_only) return;
+    if (!end) {
+        if (g_prof_n >= g_prof_max) return;
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
+    } else {
+        if (g_prof_n >= g_prof_max) return;
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_n + 1], s);
+        ++g_prof_n;
+    }
+}
+
+extern "C" int t2amd_profile_enable(int tag, int max_launches) {
+    g_prof_n = 0;
+    if (tag < 0 || max_launches <= 0) {
+        g_prof_tag = -1;
+        return T2AMD_OK;
+    }
+    while ((int)g_prof_ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) T2_FAIL("profile_enable: hipEventCreate failed");
+        g_prof_ev.push_back(e);
+    }
+    g_prof_max = max_launches;
+    g_prof_tag = tag;
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_profile_read(float* total_ms, int* count) {
+    T2_REQUIRE(total_ms && count, "profile_read: null args");
+    float tot = 0.f;
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess) T2_FAIL("profile_read: event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess)
+            T2_FAIL("profile_read: elapsed time failed");
+        tot += ms;
+    }
+    *total_ms = tot;
+    *count = g_prof_n;
+    g_prof_tag = -1;
+    return T2AMD_OK;
 }

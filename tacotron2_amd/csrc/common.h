@@ -30,6 +30,8 @@ extern "C" void t2amd_set_error_(const char* msg);
 // left untouched, so it is NOT a compute path.
 extern "C" int t2amd_validate_only_flag_(void);
 
+extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s);
+
 #define T2_LAUNCH(kern, grid, block, lds, stream, ...)                                 \
     do {                                                                               \
         if (!t2amd_validate_only_flag_())                                              \

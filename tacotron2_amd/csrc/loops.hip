@@ -43,6 +43,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         a.c_out = p->CA + t * sHa; a.ld_c = Ha;
         a.h_out = p->HA + t * sHa; a.ld_h = Ha;
         a.keep = p->keep_att ? p->keep_att + t * sHa : nullptr; a.ld_keep = Ha; a.keep_scale = p->scale_att;
+        a.tag = 1;
         T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
 
         // location-sensitive attention
@@ -71,6 +72,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         d.c_out = p->CD + t * sHd; d.ld_c = Hd;
         d.h_out = p->HD + t * sHd; d.ld_h = Hd;
         d.keep = p->keep_dec ? p->keep_dec + t * sHd : nullptr; d.ld_keep = Hd; d.keep_scale = p->scale_dec;
+        d.tag = 2;
         T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
     }
     return T2AMD_OK;
@@ -122,7 +124,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         g.nseg = 1;
         g.x[0] = seg(p->DGD + (long long)t * B * 4 * Hd, 4 * Hd, 4 * Hd);
         g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
-        g.Y = p->dXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd;
+        g.Y = p->dXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
         T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
 
         // 3. attention backward
@@ -163,7 +165,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ga.nseg = 1;
         ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
         ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
-        ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa;
+        ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa; ga.tag = 1;
         T2_PROPAGATE(t2amd_skinny_gemm_f32(&ga, stream));
     }
     return T2AMD_OK;
@@ -292,6 +294,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         a.gates_out = p->gates; a.ld_gates = 4 * Ha;
         a.c_out = p->c_a + wr * sHa; a.ld_c = Ha;
         a.h_out = p->h_a + wr * sHa; a.ld_h = Ha;
+        a.tag = 1;
         T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
 
         t2amd_attn_fwd at = {};
@@ -316,6 +319,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         d.gates_out = p->gates; d.ld_gates = 4 * Hd;
         d.c_out = p->c_d + wr * sHd; d.ld_c = Hd;
         d.h_out = p->hc + wr * sHC; d.ld_h = Hd + E;
+        d.tag = 2;
         T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
 
         // frame + gate: PG[t] = [h_dec | ctx] . Wpg^T + bias

@@ -39,7 +39,9 @@ struct SkinnyParams {
     float* Y; long long ldy; int nsplit; long long split_stride; int ktiles_per_split;
 };
 
-template <bool LSTM>
+// TAG only gives each role its own kernel symbol, so that rocprofv3 --kernel-trace --stats reports
+// the decoder's attention-LSTM (1) / decoder-LSTM (2) launches separately from the rest (0).
+template <bool LSTM, int TAG>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyParams p) {
     __shared__ __attribute__((aligned(16))) float Xs[2][SK_ROWS][SK_LD];
     __shared__ __attribute__((aligned(16))) float Ws[2][16][SK_LD];
@@ -225,7 +227,12 @@ extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
     p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     p.lens = a->lens; p.t = a->t;
     dim3 grid(a->H / 4, t2_cdiv(a->B, SK_ROWS), 1);
-    T2_LAUNCH((skinny_gemm_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipStream_t s = (hipStream_t)stream;
+    t2amd_profile_mark_(a->tag, 0, s);
+    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1>), grid, dim3(256), 0, s, p);
+    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2>), grid, dim3(256), 0, s, p);
+    else T2_LAUNCH((skinny_gemm_kernel<true, 0>), grid, dim3(256), 0, s, p);
+    t2amd_profile_mark_(a->tag, 1, s);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -243,7 +250,10 @@ extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
     const int ktiles = a->Ktot / SK_BK;
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     dim3 grid(t2_cdiv(a->N, 16), t2_cdiv(a->B, SK_ROWS), a->nsplit);
-    T2_LAUNCH((skinny_gemm_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    hipStream_t s = (hipStream_t)stream;
+    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1>), grid, dim3(256), 0, s, p);
+    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2>), grid, dim3(256), 0, s, p);
+    else T2_LAUNCH((skinny_gemm_kernel<false, 0>), grid, dim3(256), 0, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -406,12 +406,19 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     def cont(t):
         return t.contiguous() if t is not None else None
 
+    # data parallel: buckets are all-reduced over RCCL as soon as they are complete (distributed.py)
+    sync = getattr(model, '_grad_sync', None)
+    if sync is not None:
+        sync.start()
+
     # ---- output boundary -> postnet backward ----------------------------------------------
     dmel_cl = run.empty(B, To, Cm)
     dpost_cl = run.empty(B, To, Cm)
     nv.grads_to_channel_last(cont(d_mel), cont(d_post), dmel_cl, dpost_cl)
     _conv_stack_bwd(run, P, g, 'postnet.convolutions', c.post_saved, dpost_cl.view(rowsP, Cm), To,
                     first_dx=dmel_cl.view(rowsP, Cm), first_dx_accumulate=True)
+    if sync is not None:
+        sync.bucket_ready('postnet', g)          # travels while the decoder BPTT below runs
     dout = run.empty(rowsD, Cm + 1)
     nv.gather_dout(dmel_cl, cont(d_gate), dout)
 
@@ -543,6 +550,8 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     run.gemm(dWmem, d_pm.view(rowsE, A), c.memory.view(rowsE, E), a_km=True, b_kn=True)
     g['decoder.attention_layer.memory_layer.linear_layer.weight'] = dWmem
 
+    if sync is not None:
+        sync.bucket_ready('decoder', g)          # travels while the encoder backward runs
     # ---- encoder backward -----------------------------------------------------------------
     dx3 = run.empty(rowsE, E)
     for d, sfx in enumerate(('', '_reverse')):
@@ -581,6 +590,9 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     dtable = run.empty(*P['embedding.weight'].shape)
     nv.embedding_bwd(c.text, demb, dtable)
     g['embedding.weight'] = dtable
+    if sync is not None:
+        sync.bucket_ready('encoder', g)
+        sync.finish()
     return g
 
 

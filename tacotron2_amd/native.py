@@ -58,7 +58,7 @@ class LstmStep(C.Structure):
         ("c_out", _f32p), ("ld_c", _i64),
         ("h_out", _f32p), ("ld_h", _i64),
         ("keep", C.c_void_p), ("ld_keep", _i64), ("keep_scale", C.c_float),
-        ("lens", C.c_void_p), ("t", C.c_int),
+        ("lens", C.c_void_p), ("t", C.c_int), ("tag", C.c_int),
     ]
 
 
@@ -66,7 +66,7 @@ class SkinnyGemm(C.Structure):
     _fields_ = [
         ("x", Seg * 3), ("nseg", C.c_int),
         ("W", _f32p), ("Ktot", C.c_int), ("N", C.c_int), ("B", C.c_int),
-        ("Y", _f32p), ("ldy", _i64), ("nsplit", C.c_int), ("split_stride", _i64),
+        ("Y", _f32p), ("ldy", _i64), ("nsplit", C.c_int), ("split_stride", _i64), ("tag", C.c_int),
     ]
 
 
@@ -178,7 +178,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
-    "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only",
+    "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read",
     "t2amd_gemm_f32", "t2amd_splitk_reduce_f32",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
@@ -232,6 +232,8 @@ def _argtypes():
         "t2amd_decoder_infer_steps_f32": [pt(DecInfer), _P],
         "t2amd_struct_sizes": [pt(C.c_int), _I],
         "t2amd_set_validate_only": [_I],
+        "t2amd_profile_enable": [_I, _I],
+        "t2amd_profile_read": [pt(C.c_float), pt(C.c_int)],
     }
 
 
@@ -289,6 +291,18 @@ def set_validate_only(on):
 
 def validate_only():
     return _validate_only
+
+
+def profile_enable(tag, max_launches):
+    """Bracket every LSTM-step launch with role `tag` (1 attention LSTM, 2 decoder LSTM) by HIP events."""
+    _check(load().t2amd_profile_enable(tag, max_launches), "t2amd_profile_enable")
+
+
+def profile_read():
+    """-> (total_ms, count) of the bracketed launches; disables profiling."""
+    ms, n = C.c_float(0), C.c_int(0)
+    _check(load().t2amd_profile_read(C.byref(ms), C.byref(n)), "t2amd_profile_read")
+    return ms.value, n.value
 
 
 def _check(rc, what):

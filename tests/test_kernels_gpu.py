@@ -1,0 +1,412 @@
+"""Per-kernel parity tests: every C-ABI kernel against a plain PyTorch fp32 CPU reference of the
+same operation, on seeded inputs.  Tolerances (stated per test) are fp32 round-off class: the
+kernels compute in exact f32 (MFMA f32 forms are a k-ordered fmaf chain) but in a different
+summation order than ATen."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tacotron2_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def nv(native_lib):
+    from tacotron2_amd import native
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return native
+
+
+def G(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=G(seed)) * scale
+
+
+def dv(t):
+    return t.to(DEV)
+
+
+def err(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(130, 81, 50), (300, 257, 96), (64, 4096, 256), (7, 5, 3), (256, 128, 1024)])
+@pytest.mark.parametrize("a_km,b_kn", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_layouts(nv, M, N, K, a_km, b_kn):
+    A = rnd(M, K, seed=1)
+    B = rnd(K, N, seed=2)
+    ref = A @ B
+    Ad = dv(A.t().contiguous()) if a_km else dv(A)
+    Bd = dv(B) if b_kn else dv(B.t().contiguous())
+    C = torch.full((M, N), float('nan'), device=DEV)
+    nv.gemm(C, Ad, Bd, a_km=a_km, b_kn=b_kn)
+    assert err(C, ref) < 2e-5
+
+
+def test_gemm_epilogue_and_views(nv):
+    M, N, K = 200, 96, 72
+    A, W, bias, C0 = rnd(M, K, seed=3), rnd(N + 10, K + 8, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
+    keep = (torch.rand(M, N, generator=G(7)) >= 0.5).to(torch.uint8)
+    Wv = W[5:5 + N, 4:4 + K]                      # strided view, 16-byte aligned offset
+    ref = torch.relu(A @ Wv.t() + bias) * keep * 2.0
+    C = torch.empty(M, N, device=DEV)
+    nv.gemm(C, dv(A), dv(W)[5:5 + N, 4:4 + K], bias=dv(bias), act=1, keep=dv(keep), keep_scale=2.0)
+    assert err(C, ref) < 2e-5
+    C = dv(C0.clone())
+    nv.gemm(C, dv(A), dv(W)[5:5 + N, 4:4 + K], bias=dv(bias), accumulate=True)
+    assert err(C, C0 + A @ Wv.t() + bias) < 2e-5
+    # unaligned view -> scalar path
+    Wv2 = W[1:1 + N, 3:3 + K]
+    C = torch.empty(M, N, device=DEV)
+    nv.gemm(C, dv(A), dv(W)[1:1 + N, 3:3 + K])
+    assert err(C, A @ Wv2.t()) < 2e-5
+
+
+def test_gemm_batched_and_splitk(nv):
+    Bn, M, N, K = 5, 37, 64, 90
+    A, Bm = rnd(Bn, K, M, seed=8), rnd(K, Bn, N, seed=9)        # A^T per batch; B strided like DCTX[:, b, :]
+    ref = torch.stack([A[b].t() @ Bm[:, b, :] for b in range(Bn)])
+    Ad, Bd = dv(A), dv(Bm)
+    C = torch.empty(Bn, M, N, device=DEV)
+    nv.gemm(C[0], Ad[0], Bd[:, 0, :], a_km=True, b_kn=True, batch=Bn, strides=(K * M, N, M * N))
+    assert err(C, ref) < 2e-5
+    M, N, K = 81, 200, 5000
+    A2, B2 = rnd(K, M, seed=10), rnd(K, N, seed=11)
+    part = torch.empty(8, M * N, device=DEV)
+    Cs = torch.empty(M, N, device=DEV)
+    nv.gemm(part[0].view(M, N), dv(A2), dv(B2), a_km=True, b_kn=True, splitk=8, partials=part)
+    nv.splitk_reduce(part, 8, Cs)
+    assert err(Cs, A2.t() @ B2) < 5e-5
+
+
+@pytest.mark.parametrize("Bn,T,Ci,Co,k", [(3, 20, 80, 128, 5), (2, 13, 128, 80, 5), (1, 4, 16, 16, 5)])
+def test_conv_forward_dgrad_wgrad(nv, Bn, T, Ci, Co, k):
+    """implicit-GEMM conv1d (channel-last) vs F.conv1d and its autograd."""
+    x = rnd(Bn, Ci, T, seed=12).requires_grad_(True)
+    W = rnd(Co, Ci, k, seed=13, scale=0.2).requires_grad_(True)
+    bias = rnd(Co, seed=14)
+    y = F.conv1d(x, W, bias, padding=k // 2)
+    gy = rnd(Bn, Co, T, seed=15)
+    y.backward(gy)
+    pad = k // 2
+    rows = Bn * T
+    x_cl = dv(x.detach().permute(0, 2, 1).contiguous().view(rows, Ci))
+    gy_cl = dv(gy.permute(0, 2, 1).contiguous().view(rows, Co))
+    Wd = dv(W.detach())
+    Wp = torch.empty(Co, k * Ci, device=DEV)
+    nv.transpose(Wp.view(Co, k, Ci)[0], Wd[0], batch=Co, sstride=Ci * k, dstride=k * Ci)
+    assert torch.equal(Wp.view(Co, k, Ci).cpu(), W.detach().permute(0, 2, 1))
+    yk = torch.empty(rows, Co, device=DEV)
+    nv.gemm(yk, x_cl, Wp, bias=dv(bias), convA=(T, Ci, pad, 1))
+    assert err(yk.view(Bn, T, Co).permute(0, 2, 1), y) < 2e-5
+    Wdg = torch.empty(Ci, k * Co, device=DEV)
+    nv.transpose(Wdg.view(Ci * k, Co), Wd.view(Co, Ci * k))
+    dx = torch.empty(rows, Ci, device=DEV)
+    nv.gemm(dx, gy_cl, Wdg, convA=(T, Co, pad, -1))
+    assert err(dx.view(Bn, T, Ci).permute(0, 2, 1), x.grad) < 2e-5
+    part = torch.empty(2, Co * k * Ci, device=DEV)
+    nv.gemm(part[0].view(Co, k * Ci), gy_cl, x_cl, a_km=True, b_kn=True, convB=(T, Ci, pad), splitk=2, partials=part)
+    dW = torch.empty(Co, Ci, k, device=DEV)
+    nv.splitk_reduce(part, 2, dW, perm_taps=k, perm_ci=Ci)
+    assert err(dW, W.grad) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm / elementwise / layout
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_bn_act_forward_backward(nv, act):
+    M, N = 333, 80
+    x = (rnd(M, N, seed=20) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (0.5 + torch.rand(N, generator=G(21))).requires_grad_(True)
+    beta = rnd(N, seed=22).requires_grad_(True)
+    keep = (torch.rand(M, N, generator=G(23)) >= 0.5).to(torch.uint8)
+    rm, rv = torch.zeros(N), torch.ones(N)
+    y = F.batch_norm(x, rm, rv, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    y = torch.relu(y) if act == 1 else torch.tanh(y) if act == 2 else y
+    y = y * keep * 2.0
+    gy = rnd(M, N, seed=24)
+    y.backward(gy)
+    xd = dv(x.detach())
+    ws = torch.empty(2 * 64 * N, dtype=torch.float64, device=DEV)
+    mean, invstd = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    rmd, rvd = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    nv.bn_stats(xd, ws, mean, invstd, rmd, rvd, 0.1, 1e-5)
+    assert err(rmd, rm) < 1e-6 and err(rvd, rv) < 1e-6
+    yd = torch.empty(M, N, device=DEV)
+    nv.bn_act_fwd(xd, yd, mean, invstd, dv(gamma.detach()), dv(beta.detach()), act, dv(keep), 2.0)
+    assert err(yd, y) < 1e-5
+    g = dv(gy.clone())
+    dgamma, dbeta = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    nv.bn_act_bwd(g, yd, xd, mean, invstd, dv(gamma.detach()), act, dv(keep), 2.0, ws, dgamma, dbeta)
+    assert err(g, x.grad) < 2e-5
+    assert err(dgamma, gamma.grad) < 2e-5 and err(dbeta, beta.grad) < 2e-5
+    # eval mode
+    inv2 = torch.empty(N, device=DEV)
+    nv.bn_eval_invstd(rvd, inv2)
+    nv.bn_act_fwd(xd, yd, rmd, inv2, dv(gamma.detach()), dv(beta.detach()), 0)
+    ref = F.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), training=False, eps=1e-5)
+    assert err(yd, ref) < 1e-5
+
+
+def test_small_kernels(nv):
+    ws = torch.empty(128 * 300, dtype=torch.float64, device=DEV)
+    x = rnd(1000, 300, seed=30)
+    out = torch.empty(300, device=DEV)
+    nv.colsum(dv(x), ws, out)
+    assert err(out, x.sum(0)) < 1e-6
+    # embedding
+    ids = torch.randint(0, 148, (7, 19), generator=G(31))
+    table = rnd(148, 128, seed=32)
+    e = torch.empty(7 * 19, 128, device=DEV)
+    nv.embedding_fwd(dv(ids), dv(table), e)
+    assert torch.equal(e.cpu(), table[ids.view(-1)])
+    de = rnd(7 * 19, 128, seed=33)
+    dt = torch.empty(148, 128, device=DEV)
+    nv.embedding_bwd(dv(ids), dv(de), dt)
+    ref = torch.zeros(148, 128).index_add_(0, ids.view(-1), de)
+    assert err(dt, ref) < 1e-6
+    # philox: deterministic, right rate, offset-consistent
+    m1 = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    m2 = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    nv.philox_keep_mask(m1, 0.1, 1234, 0)
+    nv.philox_keep_mask(m2, 0.1, 1234, 0)
+    assert torch.equal(m1, m2)
+    assert abs(m1.float().mean().item() - 0.9) < 2e-3
+    nv.philox_keep_mask(m2[:4096], 0.1, 1234, 8192)
+    assert torch.equal(m2[:4096], m1[8192:8192 + 4096])
+    nv.philox_keep_mask(m2, 0.1, 99, 0)
+    assert not torch.equal(m1, m2)
+    # copy2d / transpose / fill
+    a, b = rnd(33, 70, seed=34), rnd(33, 70, seed=35)
+    d = torch.zeros(40, 100, device=DEV)
+    nv.copy2d(d[3:36, 10:80], dv(a), dv(b))
+    assert torch.equal(d[3:36, 10:80].cpu(), a + b) and d[0].abs().sum().item() == 0
+    t = torch.empty(70, 33, device=DEV)
+    nv.transpose(t, dv(a))
+    assert torch.equal(t.cpu(), a.t())
+    nv.fill(t, 2.5)
+    assert (t == 2.5).all().item()
+    # relu-dropout backward
+    y = torch.relu(rnd(50, 64, seed=36)) * (torch.rand(50, 64, generator=G(37)) >= 0.5) * 2.0
+    g = rnd(50, 64, seed=38)
+    gd = dv(g.clone())
+    nv.relu_dropout_bwd(gd, dv(y), 2.0)
+    assert torch.equal(gd.cpu(), torch.where(y > 0, g * 2.0, torch.zeros_like(g)))
+
+
+def test_boundary_layout_kernels(nv):
+    B, C, To = 3, 80, 37
+    mels = rnd(B, C, To, seed=40)
+    x0 = torch.empty(To, B, C, device=DEV)
+    nv.frames_to_time_major(dv(mels), x0)
+    ref = torch.cat((torch.zeros(1, B, C), mels.permute(2, 0, 1)[:-1]), 0)
+    assert torch.equal(x0.cpu(), ref)
+    pg = rnd(To, B, C + 1, seed=41)
+    olens = torch.tensor([37, 20, 5], dtype=torch.int32)
+    mel_cl, gate = torch.empty(B, To, C, device=DEV), torch.empty(B, To, device=DEV)
+    nv.split_projection(dv(pg), mel_cl, gate, dv(olens))
+    assert torch.equal(mel_cl.cpu(), pg[:, :, :C].permute(1, 0, 2))
+    gref = pg[:, :, C].t().clone()
+    pad = torch.arange(To)[None, :] >= olens[:, None]
+    gref[pad] = 1e3
+    assert torch.equal(gate.cpu(), gref)
+    post = rnd(B, To, C, seed=42)
+    mel, mel_post = torch.empty(B, C, To, device=DEV), torch.empty(B, C, To, device=DEV)
+    mcl0 = mel_cl.cpu().clone()
+    nv.finalize_outputs(mel_cl, dv(post), mel, mel_post, dv(olens))
+    m_ref = mcl0.permute(0, 2, 1).clone()
+    p_ref = (mcl0 + post).permute(0, 2, 1).clone()
+    m_ref[pad[:, None, :].expand(-1, C, -1)] = 0
+    p_ref[pad[:, None, :].expand(-1, C, -1)] = 0
+    assert torch.equal(mel.cpu(), m_ref) and torch.equal(mel_post.cpu(), p_ref)
+    assert torch.equal(mel_cl.cpu(), m_ref.permute(0, 2, 1))          # in-place fill (H2.3)
+    dm, dp = rnd(B, C, To, seed=43), rnd(B, C, To, seed=44)
+    dmel_cl, dpost_cl = torch.empty(B, To, C, device=DEV), torch.empty(B, To, C, device=DEV)
+    nv.grads_to_channel_last(dv(dm), dv(dp), dmel_cl, dpost_cl)
+    assert torch.equal(dmel_cl.cpu(), (dm + dp).permute(0, 2, 1)) and torch.equal(dpost_cl.cpu(), dp.permute(0, 2, 1))
+    nv.grads_to_channel_last(None, dv(dp), dmel_cl, dpost_cl)
+    assert torch.equal(dmel_cl.cpu(), dp.permute(0, 2, 1))
+    dg = rnd(B, To, seed=45)
+    dout = torch.empty(To, B, C + 1, device=DEV)
+    nv.gather_dout(dmel_cl, dv(dg), dout)
+    assert torch.equal(dout[:, :, :C].cpu(), dp.permute(2, 0, 1)) and torch.equal(dout[:, :, C].cpu(), dg.t())
+
+
+# ------------------------------------------------------------------------------------------------
+# recurrent cell
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,widths", [(5, 128, (64, 128)), (70, 256, (128, 64, 256)), (64, 1024, (1024, 512, 1024))])
+def test_lstm_step_forward(nv, B, H, widths):
+    K = sum(widths)
+    xs = [rnd(B, w, seed=50 + i) for i, w in enumerate(widths)]
+    W = rnd(4 * H, K, seed=54, scale=0.05)
+    gin, bias, c_prev = rnd(B, 4 * H, seed=55), rnd(4 * H, seed=56), rnd(B, H, seed=57)
+    keep = (torch.rand(B, H, generator=G(58)) >= 0.1).to(torch.uint8)
+    lens = torch.randint(1, 6, (B,), generator=G(59)).to(torch.int32)
+    t = 3
+    pre = torch.cat(xs, 1) @ W.t() + gin + bias
+    i, f, g, o = pre.chunk(4, 1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c = f * c_prev + i * g
+    h = o * torch.tanh(c) * keep * nv.scale_for(0.1)
+    gates = torch.full((B, 4 * H), float('nan'), device=DEV)
+    c_out, h_out = torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+    nv.lstm_step_fwd([dv(x) for x in xs], list(widths), dv(W), H, B, gates, c_out, h_out, gin=dv(gin), bias=dv(bias),
+                     c_prev=dv(c_prev), keep=dv(keep), keep_scale=nv.scale_for(0.1))
+    assert err(gates, torch.cat((i, f, g, o), 1)) < 1e-5
+    assert err(c_out, c) < 1e-5 and err(h_out, h) < 1e-5
+    # zero segment (None) and packed-sequence masking
+    nv.lstm_step_fwd([None] + [dv(x) for x in xs[1:]], list(widths), dv(W), H, B, gates, c_out, h_out,
+                     bias=dv(bias), lens=dv(lens), t=t)
+    xs0 = [torch.zeros_like(xs[0])] + xs[1:]
+    pre = torch.cat(xs0, 1) @ W.t() + bias
+    i, f, g, o = pre.chunk(4, 1)
+    c2 = torch.sigmoid(i) * torch.tanh(g)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    valid = (t < lens).float()[:, None]
+    assert err(c_out, c2 * valid) < 1e-5 and err(h_out, h2 * valid) < 1e-5
+
+
+def test_skinny_gemm_and_lstm_backward(nv):
+    B, N, K = 37, 200, 512
+    x, W = rnd(B, K, seed=60), rnd(N, K, seed=61, scale=0.1)
+    for ns in (1, 4):
+        Y = torch.empty(ns, B, N, device=DEV)
+        nv.skinny_gemm([dv(x)], [K], dv(W), N, B, Y, nsplit=ns)
+        assert err(Y.sum(0), x @ W.t()) < 2e-5
+    H = 128
+    gates_pre = rnd(B, 4 * H, seed=62).requires_grad_(True)
+    c_prev = rnd(B, H, seed=63).requires_grad_(True)
+    keep = (torch.rand(B, H, generator=G(64)) >= 0.1).to(torch.uint8)
+    sc = nv.scale_for(0.1)
+    i, f, g, o = gates_pre.chunk(4, 1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c = f * c_prev + i * g
+    h = o * torch.tanh(c) * keep * sc
+    dh1, dh2, dc_in = rnd(B, H, seed=65), rnd(2, B, H, seed=66), rnd(B, H, seed=67)
+    ((h * (dh1 + dh2.sum(0))).sum() + (c * dc_in).sum()).backward()
+    dc = dv(dc_in.clone())
+    dgates = torch.empty(B, 4 * H, device=DEV)
+    a2 = nv._addend(dv(dh2)[0], nsplit=2, split_stride=B * H)
+    # use the low-level entry to exercise split addends
+    st = nv.LstmBwd()
+    st.B, st.H = B, H
+    st.dh[0] = nv._addend(dv(dh1))
+    st.dh[1] = a2
+    st.dh[2] = nv._addend(None)
+    gact = dv(torch.cat((i, f, g, o), 1).detach())
+    cd, cpd, kd = dv(c.detach()), dv(c_prev.detach()), dv(keep)
+    st.gates, st.ld_gates = nv.ptr(gact), 4 * H
+    st.c_prev, st.ld_cprev = nv.ptr(cpd), H
+    st.c, st.ld_c = nv.ptr(cd), H
+    st.keep, st.ld_keep, st.keep_scale = nv.ptr(kd, torch.uint8), H, sc
+    st.dc, st.ld_dc = nv.ptr(dc), H
+    st.dgates, st.ld_dgates = nv.ptr(dgates), 4 * H
+    import ctypes
+    nv._check(nv.load().t2amd_lstm_pointwise_bwd_f32(ctypes.byref(st), nv._stream()), "lstm_bwd")
+    assert err(dgates, gates_pre.grad) < 1e-5
+    assert err(dc, c_prev.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_inputs(B, Ti, E, Hq, seed):
+    sd = {
+        'decoder.attention_layer.query_layer.linear_layer.weight': rnd(128, Hq, seed=seed, scale=0.05),
+        'decoder.attention_layer.location_layer.location_conv.conv.weight': rnd(32, 2, 31, seed=seed + 1, scale=0.3),
+        'decoder.attention_layer.location_layer.location_dense.linear_layer.weight': rnd(128, 32, seed=seed + 2, scale=0.3),
+        'decoder.attention_layer.v.linear_layer.weight': rnd(1, 128, seed=seed + 3),
+    }
+    h, mem, pm = rnd(B, Hq, seed=seed + 4), rnd(B, Ti, E, seed=seed + 5), rnd(B, Ti, 128, seed=seed + 6)
+    lens = torch.randint(max(1, Ti // 3), Ti + 1, (B,), generator=G(seed + 7))
+    lens[0] = Ti
+    w_prev = torch.softmax(rnd(B, Ti, seed=seed + 8), 1)
+    cum = torch.rand(B, Ti, generator=G(seed + 9)) * 2
+    return sd, h, mem, pm, lens, w_prev, cum
+
+
+@pytest.mark.parametrize("B,Ti,E,Hq", [(3, 37, 128, 128), (4, 175, 512, 1024), (2, 70, 512, 1024)])
+def test_attention_forward_backward(nv, B, Ti, E, Hq):
+    sd, h, mem, pm, lens, w_prev, cum = _attn_inputs(B, Ti, E, Hq, 70)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hL, pmL, wpL, cumL = (t.clone().requires_grad_(True) for t in (h, pm, w_prev, cum))
+    mask = ~orc.get_mask_from_lengths(lens, Ti)
+    ctx, w = orc.attention_step(hL, mem, pmL, wpL, cumL, mask, leaf, -float('inf'))
+    cum_new = cumL + w
+    d_ctx, d_w_extra, d_w_carry, d_cum_carry = rnd(B, E, seed=80), rnd(B, Ti, seed=81), rnd(B, Ti, seed=82), rnd(B, Ti, seed=83)
+    ((ctx * d_ctx).sum() + (w * (d_w_extra + d_w_carry)).sum() + (cum_new * d_cum_carry).sum()).backward()
+
+    Wq = dv(sd['decoder.attention_layer.query_layer.linear_layer.weight'])
+    Wd = dv(sd['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'])
+    Wc = dv(sd['decoder.attention_layer.location_layer.location_conv.conv.weight'])
+    v = dv(sd['decoder.attention_layer.v.linear_layer.weight']).view(-1)
+    WqT = torch.empty(Hq, 128, device=DEV)
+    nv.transpose(WqT, Wq)
+    U = torch.empty(128 * 62 + 64 * 128, device=DEV)
+    nv.fold_location(Wd, Wc, U)
+    Uref = torch.einsum('df,fck->dck', sd['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'],
+                        sd['decoder.attention_layer.location_layer.location_conv.conv.weight']).reshape(128, 62)
+    assert err(U[:128 * 62].view(128, 62), Uref) < 1e-5
+    assert err(U[128 * 62:].view(64, 128)[:62], Uref.t()) < 1e-5
+
+    lens32 = dv(lens.to(torch.int32))
+    cum_d, cum_save = dv(cum.clone()), torch.empty(B, Ti, device=DEV)
+    w_out, ctx_out, q_out = torch.empty(B, Ti, device=DEV), torch.empty(B, E, device=DEV), torch.empty(B, 128, device=DEV)
+    memd, pmd, hd, wpd = dv(mem), dv(pm), dv(h), dv(w_prev)
+    nv.attention_step_fwd(hd, WqT, U, v, pmd, memd, lens32, wpd, cum_d, cum_save, w_out, ctx_out, q_out)
+    assert err(w_out, w) < 1e-5 and err(ctx_out, ctx) < 1e-5
+    assert err(cum_d, cum_new) < 1e-5 and torch.equal(cum_save.cpu(), cum)
+    assert err(q_out, h @ sd['decoder.attention_layer.query_layer.linear_layer.weight'].t()) < 1e-5
+    assert (w_out.cpu()[mask] == 0).all()
+
+    # backward
+    dctx_total = torch.empty(B, E, device=DEV)
+    dw_c, dcum_c = dv(d_w_carry.clone()), dv(d_cum_carry.clone())
+    d_pm = torch.zeros(B, Ti, 128, device=DEV)
+    dU_acc, dv_acc = torch.zeros(B, 128, 62, device=DEV), torch.zeros(B, 128, device=DEV)
+    dq, dh = torch.empty(B, 128, device=DEV), torch.empty(B, Hq, device=DEV)
+    half = dv(d_ctx * 0.5)
+    nv.attention_step_bwd([half, half], dctx_total, dv(d_w_extra), q_out, Wq, U, v, pmd, memd, lens32, w_out, wpd,
+                          cum_save, dw_c, dcum_c, d_pm, dU_acc, dv_acc, dq, dh)
+    assert err(dctx_total, d_ctx) < 1e-6
+    assert err(dh, hL.grad) < 2e-5
+    assert err(d_pm, pmL.grad) < 2e-5
+    assert err(dw_c, wpL.grad) < 2e-5
+    assert err(dcum_c, cumL.grad) < 2e-5
+    dWd, dWc, dvv = torch.empty(128, 32, device=DEV), torch.empty(32, 2, 31, device=DEV), torch.empty(1, 128, device=DEV)
+    nv.unfold_location_grads(dU_acc, dv_acc, B, Wd, Wc, dWd, dWc, dvv)
+    assert err(dWd, leaf['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'].grad) < 5e-5
+    assert err(dWc, leaf['decoder.attention_layer.location_layer.location_conv.conv.weight'].grad) < 5e-5
+    assert err(dvv, leaf['decoder.attention_layer.v.linear_layer.weight'].grad) < 5e-5
+    dWq_ref = leaf['decoder.attention_layer.query_layer.linear_layer.weight'].grad
+    assert err(dq.cpu().t() @ h, dWq_ref) < 5e-5
+
+
+def test_attention_no_mask_and_first_step(nv):
+    """Inference semantics: no length mask (reference model.py:432) and zero previous weights."""
+    B, Ti, E, Hq = 1, 29, 512, 1024
+    sd, h, mem, pm, lens, w_prev, cum = _attn_inputs(B, Ti, E, Hq, 90)
+    ctx, w = orc.attention_step(h, mem, pm, torch.zeros(B, Ti), torch.zeros(B, Ti), None, sd, -float('inf'))
+    Wq = dv(sd['decoder.attention_layer.query_layer.linear_layer.weight'])
+    WqT = torch.empty(Hq, 128, device=DEV)
+    nv.transpose(WqT, Wq)
+    U = torch.empty(128 * 62 + 64 * 128, device=DEV)
+    nv.fold_location(dv(sd['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']),
+                     dv(sd['decoder.attention_layer.location_layer.location_conv.conv.weight']), U)
+    cum_d = torch.zeros(B, Ti, device=DEV)
+    w_out, ctx_out = torch.empty(B, Ti, device=DEV), torch.empty(B, E, device=DEV)
+    nv.attention_step_fwd(dv(h), WqT, U, dv(sd['decoder.attention_layer.v.linear_layer.weight']).view(-1), dv(pm), dv(mem),
+                          None, None, cum_d, None, w_out, ctx_out, None)
+    assert err(w_out, w) < 1e-5 and err(ctx_out, ctx) < 1e-5 and err(cum_d, w) < 1e-5

@@ -1,0 +1,207 @@
+"""End-to-end parity of the HIP engine (called through the C ABI) against
+  (a) the committed golden vectors produced by the real reference, and
+  (b) the CPU oracle run live on the same seeded weights, inputs and dropout masks.
+
+Tolerances (fp32 engine mode; north-star: mel L1 < 1e-4, gate-stop index exact):
+  outputs:   mean |diff| < 1e-4 and max |diff| < 5e-4 * max(1, max|ref|)
+  gradients: max |diff| < 1e-3 * max|ref| + 2e-6 per tensor (BPTT over tens of steps in a different
+             summation order; typical observed values are far below)
+  BN buffers: 1e-5 relative;  stop lengths: exact.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import tacotron2_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OUT = os.path.join(gu.ROOT, "gpurun_out")
+
+
+def _model(hp, sd):
+    from tacotron2_amd.model import Tacotron2
+    m = Tacotron2(hp)
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def _stats(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    d = (a - b).abs()
+    return d.mean().item(), d.max().item(), b.abs().max().item()
+
+
+def _report(name, rows):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_%s.json" % name), "w") as f:
+        json.dump(rows, f, indent=1)
+
+
+@pytest.mark.parametrize("name", ["tiny_train", "default_train"])
+def test_train_step_matches_reference_and_oracle(native_lib, name):
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    fx = gu.load_fixture(name)
+    hp = gu.make_hparams(fx['hp'])
+    sd = gu.build_state_dict(hp, fx['seed'])
+    batch = gu.make_train_batch(fx['in_lens'], fx['out_lens'], hp.n_mel_channels, fx['seed'])
+    masks = gu.unpack_masks(fx['masks'])
+    oloss, oout, ograds, obufs = orc.train_step_grads(sd, hp, batch, masks)      # oracle, CPU
+
+    model = _model(hp, sd).train()
+    model.dropout_masks = gu.masks_to_engine(masks, DEV)
+    x, y = model.parse_batch(tuple(t.clone() for t in batch))
+    out = model(x)
+    loss = Tacotron2Loss()(out, y)
+    loss.backward()
+    torch.cuda.synchronize()
+
+    rows, bad = [], []
+    for i, nm in enumerate(('mel', 'mel_post', 'gate', 'align')):
+        for tag, ref in (('golden', fx['outputs'][i]), ('oracle', oout[i])):
+            mean, mx, rmax = _stats(out[i], ref)
+            rows.append(dict(what='%s vs %s' % (nm, tag), mean=mean, max=mx, refmax=rmax))
+            if not (mean < 1e-4 and mx < 5e-4 * max(1.0, rmax)):
+                bad.append(rows[-1])
+    mean, mx, rmax = _stats(loss, fx['loss'])
+    rows.append(dict(what='loss vs golden', mean=mean, max=mx, refmax=rmax))
+    if not mx < 1e-4 * max(1.0, rmax):
+        bad.append(rows[-1])
+    for k, p in model.named_parameters():
+        mean, mx, rmax = _stats(p.grad, ograds[k])
+        rows.append(dict(what='grad %s vs oracle' % k, mean=mean, max=mx, refmax=rmax))
+        if not mx < 1e-3 * rmax + 2e-6:
+            bad.append(rows[-1])
+        d = fx['grad_digest'][k]
+        g = p.grad.detach().cpu().double().reshape(-1)
+        smx = (g[d['idx']] - d['sample'].double()).abs().max().item()
+        if not (smx < 1e-3 * rmax + 2e-6 and abs(g.norm().item() - d['l2']) < 1e-3 * d['l2'] + 2e-5):
+            bad.append(dict(what='grad %s vs golden digest' % k, max=smx, l2=g.norm().item(), ref_l2=d['l2']))
+    msd = model.state_dict()
+    for k, v in fx['buffers'].items():
+        mean, mx, rmax = _stats(msd[k].float(), v.float())
+        rows.append(dict(what='buffer %s' % k, mean=mean, max=mx, refmax=rmax))
+        if not mx < 1e-5 * max(1.0, rmax):
+            bad.append(rows[-1])
+    _report(name, dict(rows=rows, bad=bad))
+    assert not bad, bad[:8]
+
+
+def test_eval_forward_matches_oracle(native_lib):
+    """Validation path (reference train.py:133 under model.eval()): BN running stats, only the
+    Prenet dropout live."""
+    fx = gu.load_fixture("tiny_train")
+    hp = gu.make_hparams(fx['hp'])
+    sd = gu.build_state_dict(hp, fx['seed'], perturb_bn=True)
+    batch = gu.make_train_batch(fx['in_lens'], fx['out_lens'], hp.n_mel_channels, fx['seed'])
+    masks = gu.unpack_masks(fx['masks'])
+    em = dict(prenet=masks['prenet'])
+    inputs = (batch[0], batch[1], batch[2], int(batch[1].max()), batch[4])
+    ref = orc.tacotron2_forward(sd, hp, inputs, em, training=False)
+    model = _model(hp, sd).eval()
+    model.dropout_masks = gu.masks_to_engine(em, DEV)
+    with torch.no_grad():
+        x, _ = model.parse_batch(tuple(t.clone() for t in batch))
+        out = model(x)
+    for i in range(4):
+        mean, mx, rmax = _stats(out[i], ref[i])
+        assert mean < 1e-4 and mx < 5e-4 * max(1.0, rmax), (i, mean, mx)
+
+
+def test_inference_gate_stop_exact(native_lib):
+    fx = gu.load_fixture("default_infer")
+    hp = gu.make_hparams(fx['hp'])
+    hp.gate_threshold = fx['threshold']
+    sd = gu.build_state_dict(hp, fx['seed'], perturb_bn=True)
+    model = _model(hp, sd).eval()
+    model.dropout_masks = dict(prenet_infer=gu.unpack_mask(fx['masks']).to(DEV))
+    out = model.inference(fx['text'].to(DEV))
+    ref = fx['outputs'][0]
+    assert model.last_inference_lengths.tolist() == fx['lengths']        # bit-exact stop index
+    assert out[2].shape == ref[2].shape                                   # (1, T, 1)
+    for i in range(4):
+        mean, mx, rmax = _stats(out[i], ref[i])
+        assert mean < 1e-4 and mx < 5e-4 * max(1.0, rmax), (i, mean, mx)
+
+
+def test_batched_inference_equals_per_utterance_reference(native_lib):
+    fx = gu.load_fixture("tiny_infer_batched")
+    hp = gu.make_hparams(fx['hp'])
+    hp.gate_threshold = fx['threshold']
+    sd = gu.build_state_dict(hp, fx['seed'], perturb_bn=True)
+    model = _model(hp, sd).eval()
+    model.dropout_masks = dict(prenet_infer=gu.unpack_mask(fx['masks']).to(DEV))
+    out = model.inference(fx['text'].to(DEV), torch.tensor(fx['in_lens']).to(DEV))
+    assert model.last_inference_lengths.tolist() == fx['lengths']
+    for b, L in enumerate(fx['lengths']):
+        ref = fx['outputs'][b]
+        Tb = fx['in_lens'][b]
+        for got, want in ((out[0][b, :, :L], ref[0][0]), (out[1][b, :, :L], ref[1][0]),
+                          (out[3][b, :L, :Tb], ref[3][0])):
+            mean, mx, rmax = _stats(got, want)
+            assert mean < 1e-4 and mx < 5e-4 * max(1.0, rmax), (b, mean, mx)
+        assert out[0][b, :, L:].abs().sum().item() == 0 and out[1][b, :, L:].abs().sum().item() == 0
+
+
+def test_max_decoder_steps_warning_path(native_lib, capsys):
+    fx = gu.load_fixture("default_infer")
+    hp = gu.make_hparams("max_decoder_steps=9")
+    hp.gate_threshold = 2.0                                  # never fires
+    sd = gu.build_state_dict(hp, fx['seed'], perturb_bn=True)
+    model = _model(hp, sd).eval()
+    out = model.inference(fx['text'].to(DEV))
+    assert out[0].shape[2] == 9 and "Reached max decoder steps" in capsys.readouterr().out
+
+
+def test_full_size_properties(native_lib):
+    """BASELINE config 2 shape (B=64 LJSpeech-shaped, default hparams): properties that hold at any
+    size — determinism, attention rows are distributions supported on valid positions, padded
+    outputs hold the padding values, gradients are linear in the upstream gradient."""
+    from tacotron2_amd.model import Tacotron2
+    from tacotron2_amd.synth import synth_batch
+    hp = gu.make_hparams("")
+    torch.manual_seed(1234)
+    model = Tacotron2(hp).to(DEV).train()
+    batch = synth_batch(64, 1234)
+    x, y = model.parse_batch(batch)
+    B, Ti, To = 64, x[0].shape[1], x[2].shape[2]
+    from tacotron2_amd.engine import MaskSource
+    ms = MaskSource(None, DEV)
+    ms.seed = 77
+    masks = dict(enc=[ms.get('enc', i, (B, Ti, 512), 0.5) for i in range(3)],
+                 prenet=[ms.get('prenet', i, (To, B, 256), 0.5) for i in range(2)],
+                 att=ms.get('att', None, (To, B, 1024), 0.1), dec=ms.get('dec', None, (To, B, 1024), 0.1),
+                 post=[ms.get('post', i, (B, To, c), 0.5) for i, c in enumerate([512] * 4 + [80])])
+    model.dropout_masks = masks
+
+    def run(scale):
+        model.zero_grad()
+        out = model(x)
+        up = [torch.randn(o.shape, generator=torch.Generator().manual_seed(5 + i)).to(DEV) * scale
+              for i, o in enumerate(out[:3])]
+        torch.autograd.backward(out[:3], up)
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in out], {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    o1, g1 = run(1.0)
+    o2, g2 = run(1.0)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)                                   # bitwise deterministic
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    o3, g3 = run(2.0)
+    for k in g1:
+        ref = g1[k].double() * 2
+        assert (g3[k].double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-7, k
+    mel, post, gate, align = o1
+    assert torch.isfinite(mel).all() and torch.isfinite(post).all() and all(torch.isfinite(g).all() for g in g1.values())
+    in_len, out_len = x[1], x[4]
+    tpad = torch.arange(To, device=DEV)[None, :] >= out_len[:, None]
+    assert (mel.permute(0, 2, 1)[tpad] == 0).all() and (post.permute(0, 2, 1)[tpad] == 0).all()
+    assert (gate[tpad] == 1e3).all()
+    assert (align.sum(2) - 1).abs().max().item() < 1e-4
+    ipad = torch.arange(Ti, device=DEV)[None, :] >= in_len[:, None]
+    assert (align.permute(0, 2, 1)[ipad] == 0).all()
