@@ -298,11 +298,12 @@ def test_skinny_gemm_and_lstm_backward(nv):
     ((h * (dh1 + dh2.sum(0))).sum() + (c * dc_in).sum()).backward()
     dc = dv(dc_in.clone())
     dgates = torch.empty(B, 4 * H, device=DEV)
-    a2 = nv._addend(dv(dh2)[0], nsplit=2, split_stride=B * H)
+    dh1d, dh2d = dv(dh1), dv(dh2)          # keep the device buffers alive while the kernel runs
+    a2 = nv._addend(dh2d[0], nsplit=2, split_stride=B * H)
     # use the low-level entry to exercise split addends
     st = nv.LstmBwd()
     st.B, st.H = B, H
-    st.dh[0] = nv._addend(dv(dh1))
+    st.dh[0] = nv._addend(dh1d)
     st.dh[1] = a2
     st.dh[2] = nv._addend(None)
     gact = dv(torch.cat((i, f, g, o), 1).detach())
