@@ -33,12 +33,13 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=12, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(sample_b, seed):
+def cpu_baseline(sample_b, seed, threads=16):
     """Time the oracle (CPU port of the reference hot path) on a strided sub-batch of the bench batch."""
     from oracle import tacotron2_oracle as orc
     from tacotron2_amd.hparams import create_hparams
@@ -54,7 +55,10 @@ def cpu_baseline(sample_b, seed):
     batch = (text[:, :Ti].contiguous(), il, mel[:, :, :To].contiguous(), gate[:, :To].contiguous(), ol)
     g = torch.Generator().manual_seed(seed)
     masks = orc.draw_masks_train(hp, sample_b, Ti, To, g)
-    threads = torch.get_num_threads()
+    # The per-step matmuls are tiny: beyond ~16 threads ATen's intra-op pool only adds contention
+    # (128 threads measured 4x SLOWER than 8), so the baseline pins the pool and states the count.
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
     t0 = time.perf_counter()
     orc.train_step_grads(sd, hp, batch, masks)
     dt = time.perf_counter() - t0
@@ -186,7 +190,7 @@ def main():
         if roofline:
             out["roofline"] = roofline
         if args.gpus == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1234)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1234, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
