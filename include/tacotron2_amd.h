@@ -38,6 +38,7 @@ extern "C" {
 #define T2AMD_LOC_FILTERS 32
 #define T2AMD_LOC_KERNEL 31
 #define T2AMD_LOC_TAPS (2 * T2AMD_LOC_KERNEL) /* 62 = [prev ; cumulative] x 31 */
+#define T2AMD_ATT_SLICES 4 /* workgroups per utterance in every attention kernel; partial slabs have this many slices */
 
 int t2amd_abi_version(void);
 const char* t2amd_last_error(void);
@@ -250,8 +251,10 @@ int t2amd_lstm_pointwise_bwd_f32(const t2amd_lstm_bwd* a, void* stream);
 /* ------------------------------------------------------------------------------------
  * Location-sensitive attention, one decoder step (reference model.py:43-86 Attention.forward /
  * get_alignment_energies, :22-26 LocationLayer, :358-365 concat + cumulative update).
- * U[d][c][k] = sum_f Wdense[d][f]*Wconv[f][c][k] is the location conv and dense folded
- * into one 62-tap filter per attention dim (t2amd_fold_location_f32).
+ * U[d][c*31+k] = sum_f Wdense[d][f]*Wconv[f][c][k] is the location conv and dense folded
+ * into one 62-tap filter per attention dim (t2amd_fold_location_f32, U = 128*62 floats).
+ * Each step is two launches of T2AMD_ATT_SLICES x B workgroups (energies over dim slices, then
+ * softmax + context over channel slices); partial results cross between them through `ws`.
  * ------------------------------------------------------------------------------------ */
 int t2amd_fold_location_f32(const float* wdense, const float* wconv, float* U, void* stream);
 /* dWdense[d][f] = sum_ck dU[d][ck]*Wconv[f][ck]; dWconv[f][ck] = sum_d Wdense[d][f]*dU[d][ck];
@@ -261,10 +264,10 @@ int t2amd_unfold_location_grads_f32(const float* dU_acc, const float* dv_acc, in
                                     float* dwconv, float* dv, void* stream);
 
 typedef struct t2amd_attn_fwd {
-    int B, Ti, E, Hq;        /* E = encoder dim, Hq = attention_rnn_dim */
-    const float* h;          /* [B][Hq] query source (dropped-out attention hidden) */
+    int B, Ti, E, Hq;        /* E = encoder dim (multiple of 16), Hq = attention_rnn_dim (multiple of 32) */
+    const float* h;          /* [B][Hq] query source (dropped-out attention hidden), 16-byte aligned rows */
     long long ld_h;
-    const float* WqT;        /* [Hq][128] */
+    const float* Wq;         /* [128][Hq] query_layer weight, as stored by nn.Linear */
     const float* U;          /* [128][62] */
     const float* v;          /* [128] */
     const float* pm;         /* [B][Ti][128] processed memory */
@@ -281,6 +284,7 @@ typedef struct t2amd_attn_fwd {
     float* q_out;            /* [B][128] or NULL */
     long long ld_q;
     const uint8_t* active;   /* [B] or NULL: rows with active[b]==0 are skipped (batched inference) */
+    float* ws;               /* workspace, >= T2AMD_ATT_SLICES*B*Ti floats (partial energies) */
 } t2amd_attn_fwd;
 
 int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
@@ -305,15 +309,22 @@ typedef struct t2amd_attn_bwd {
     const float* w_prev;     /* NULL = zeros */
     long long ld_wprev;
     const float* cum_before; /* [B][Ti] */
-    float* dw_carry;         /* [B][Ti] in: grad wrt w_t from step t+1's location input; out: same for t-1 */
-    float* dcum_carry;       /* [B][Ti] in/out */
+    /* Carries between steps, in partial form.  dwin_part[s][b][c][ti], s < T2AMD_ATT_SLICES, c = 0: grad
+     * wrt the PREVIOUS weights (the next-processed step's w), c = 1: grad wrt the cumulative weights, both
+     * from the location input of the step processed before this call.  In: partials of step t+1; out:
+     * partials of this step.  dcum_acc[b][ti]: running gradient wrt the cumulative weights; on return it
+     * includes the incoming c = 1 partials.  Zero both before the last time step. */
+    float* dwin_part;        /* [T2AMD_ATT_SLICES][B][2][Ti] in/out */
+    float* dcum_acc;         /* [B][Ti] in/out */
     float* d_pm;             /* [B][Ti][128] accumulated */
     float* dU_acc;           /* [B][128][62] accumulated */
     float* dv_acc;           /* [B][128] accumulated */
     float* dq_out;           /* [B][128] */
     long long ld_dq;
-    float* dh_out;           /* [B][Hq] = Wq^T dq */
+    float* dh_out;           /* [T2AMD_ATT_SLICES] partial slabs of Wq^T dq: slice s, row b at dh_out + s*dh_split_stride + b*ld_dh */
     long long ld_dh;
+    long long dh_split_stride;
+    float* ws;               /* workspace, >= B*Ti + T2AMD_ATT_SLICES*B floats */
 } t2amd_attn_bwd;
 
 int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);
@@ -330,7 +341,7 @@ typedef struct t2amd_dec_train {
     const float* Wa_rec;   /* [4Ha][E+Ha] = [W_ih_att[:, P:P+E] | W_hh_att] */
     const float* Wd_cat;   /* [4Hd][Ha+E+Hd] = [W_ih_dec | W_hh_dec] */
     const float* bias_d;   /* [4Hd] = b_ih + b_hh */
-    const float* WqT;      /* [Ha][128] */
+    const float* Wq;       /* [128][Ha] */
     const float* U;        /* [128][62] */
     const float* v;        /* [128] */
     /* inputs */
@@ -352,6 +363,7 @@ typedef struct t2amd_dec_train {
     float* ALIGN; /* [B][To][Ti] */
     float* CUM;   /* [To][B][Ti] cumulative weights before each step */
     float* cum_work; /* [B][Ti] scratch (zeroed by the call) */
+    float* attn_ws;  /* >= T2AMD_ATT_SLICES*B*Ti + B*Ti floats: attention workspace (forward and backward) */
 } t2amd_dec_train;
 
 int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream);
@@ -361,7 +373,6 @@ typedef struct t2amd_dec_train_bwd {
     t2amd_dec_train f;       /* the forward description (slabs now inputs) */
     const float* Wa_recT;    /* [E+Ha][4Ha] */
     const float* Wd_catT;    /* [Ha+E+Hd][4Hd] */
-    const float* Wq;         /* [128][Ha] */
     const float* DHC;        /* [To][B][Hd+E] grad wrt [h_dec | ctx] from the projection */
     const float* d_align;    /* [B][To][Ti] or NULL */
     int nsplit;              /* split-K factor of the two backward skinny GEMMs */
@@ -378,9 +389,9 @@ typedef struct t2amd_dec_train_bwd {
     float* dXa;  /* [nsplit][B][E+Ha] */
     float* dc_a; /* [B][Ha] */
     float* dc_d; /* [B][Hd] */
-    float* dw_carry;   /* [B][Ti] */
-    float* dcum_carry; /* [B][Ti] */
-    float* dq_h;       /* [B][Ha] */
+    float* dwin_part;  /* [T2AMD_ATT_SLICES][B][2][Ti] (zeroed by the call) */
+    float* dcum_acc;   /* [B][Ti] (zeroed by the call) */
+    float* dq_h;       /* [T2AMD_ATT_SLICES][B][Ha] */
 } t2amd_dec_train_bwd;
 
 int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream);
@@ -421,7 +432,7 @@ typedef struct t2amd_dec_infer {
     const float* bias_a;   /* [4Ha] */
     const float* Wd_cat;   /* [4Hd][Ha+E+Hd] */
     const float* bias_d;
-    const float* WqT;
+    const float* Wq;       /* [128][Ha] */
     const float* U;
     const float* v;
     const float* Wpg;      /* [C+1][Hd+E] = [linear_projection ; gate_layer] rows */
@@ -439,6 +450,7 @@ typedef struct t2amd_dec_infer {
     float* x_prenet;       /* [2][B][P] scratch */
     float* gates;          /* [B][4*max(Ha,Hd)] scratch */
     const float* zero_frame; /* [B][C] zeros (go frame) */
+    float* attn_ws;        /* >= T2AMD_ATT_SLICES*B*Ti floats */
     /* outputs */
     float* PG;             /* [max_steps][B][C+1] mel frame + gate logit per step */
     float* ALIGN;          /* [B][max_steps][Ti] */

@@ -23,9 +23,10 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
     const int B = p->B, Ti = p->Ti, To = p->To, E = p->E, Ha = p->Ha, Hd = p->Hd;
     T2_REQUIRE(B > 0 && Ti > 0 && To > 0, "dec_train_fwd: bad dims");
     T2_REQUIRE(E % 64 == 0 && Ha % 64 == 0 && Hd % 64 == 0, "dec_train_fwd: E, Ha, Hd must be multiples of 64");
-    T2_REQUIRE(p->Wa_rec && p->Wd_cat && p->bias_d && p->WqT && p->U && p->v && p->GA && p->memory && p->pm && p->lens,
+    T2_REQUIRE(p->Wa_rec && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->GA && p->memory && p->pm && p->lens,
                "dec_train_fwd: null weights/inputs");
-    T2_REQUIRE(p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work,
+    T2_REQUIRE(p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work &&
+                   p->attn_ws,
                "dec_train_fwd: null slabs");
     T2_PROPAGATE(t2amd_fill_f32(p->cum_work, (long long)B * Ti, 0.f, stream));
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
@@ -50,7 +51,8 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         t2amd_attn_fwd at = {};
         at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
         at.h = p->HA + t * sHa; at.ld_h = Ha;
-        at.WqT = p->WqT; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
+        at.Wq = p->Wq; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
+        at.ws = p->attn_ws;
         at.w_prev = t ? p->ALIGN + (long long)(t - 1) * Ti : nullptr; at.ld_wprev = (long long)To * Ti;
         at.cum = p->cum_work;
         at.cum_save = p->CUM + (long long)t * B * Ti;
@@ -86,9 +88,9 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     const t2amd_dec_train& f = p->f;
     const int B = f.B, Ti = f.Ti, To = f.To, E = f.E, Ha = f.Ha, Hd = f.Hd;
     const int ns = p->nsplit < 1 ? 1 : p->nsplit;
-    T2_REQUIRE(p->Wa_recT && p->Wd_catT && p->Wq && p->DHC && p->DGA && p->DGD && p->DCTX && p->DQ && p->d_pm &&
-                   p->dU_acc && p->dv_acc && p->dXd && p->dXa && p->dc_a && p->dc_d && p->dw_carry &&
-                   p->dcum_carry && p->dq_h,
+    T2_REQUIRE(p->Wa_recT && p->Wd_catT && f.Wq && p->DHC && p->DGA && p->DGD && p->DCTX && p->DQ && p->d_pm &&
+                   p->dU_acc && p->dv_acc && p->dXd && p->dXa && p->dc_a && p->dc_d && p->dwin_part &&
+                   p->dcum_acc && p->dq_h && f.attn_ws,
                "dec_train_bwd: null pointer");
     T2_REQUIRE((4 * Ha) % 64 == 0 && (4 * Hd) % 64 == 0, "dec_train_bwd: 4H must be a multiple of 64");
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
@@ -100,8 +102,8 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     T2_PROPAGATE(t2amd_fill_f32(p->dv_acc, (long long)B * T2AMD_ATT_DIM, 0.f, stream));
     T2_PROPAGATE(t2amd_fill_f32(p->dc_a, sHa, 0.f, stream));
     T2_PROPAGATE(t2amd_fill_f32(p->dc_d, sHd, 0.f, stream));
-    T2_PROPAGATE(t2amd_fill_f32(p->dw_carry, (long long)B * Ti, 0.f, stream));
-    T2_PROPAGATE(t2amd_fill_f32(p->dcum_carry, (long long)B * Ti, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dwin_part, (long long)T2AMD_ATT_SLICES * B * 2 * Ti, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->dcum_acc, (long long)B * Ti, 0.f, stream));
 
     for (int t = To - 1; t >= 0; --t) {
         const bool last = (t == To - 1);
@@ -136,21 +138,21 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.dctx_total = p->DCTX + t * sE; ab.ld_dctx_total = E;
         ab.d_w_extra = p->d_align ? p->d_align + (long long)t * Ti : nullptr; ab.ld_dwextra = (long long)To * Ti;
         ab.q = f.Q + (long long)t * B * T2AMD_ATT_DIM; ab.ld_q = T2AMD_ATT_DIM;
-        ab.Wq = p->Wq; ab.U = f.U; ab.v = f.v; ab.pm = f.pm; ab.memory = f.memory; ab.lens = f.lens;
+        ab.Wq = f.Wq; ab.U = f.U; ab.v = f.v; ab.pm = f.pm; ab.memory = f.memory; ab.lens = f.lens;
         ab.w = f.ALIGN + (long long)t * Ti; ab.ld_w = (long long)To * Ti;
         ab.w_prev = t ? f.ALIGN + (long long)(t - 1) * Ti : nullptr; ab.ld_wprev = (long long)To * Ti;
         ab.cum_before = f.CUM + (long long)t * B * Ti;
-        ab.dw_carry = p->dw_carry; ab.dcum_carry = p->dcum_carry;
+        ab.dwin_part = p->dwin_part; ab.dcum_acc = p->dcum_acc; ab.ws = f.attn_ws;
         ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
-        ab.dh_out = p->dq_h; ab.ld_dh = Ha;
+        ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;
         T2_PROPAGATE(t2amd_attention_step_bwd_f32(&ab, stream));
 
         // 4. attention LSTM cell backward
         t2amd_lstm_bwd la = {};
         la.B = B; la.H = Ha;
         la.dh[0] = addend(p->dXd, Kd, ns, strXd);
-        la.dh[1] = addend(p->dq_h, Ha, 1, 0);
+        la.dh[1] = addend(p->dq_h, Ha, T2AMD_ATT_SLICES, sHa);
         la.dh[2] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXa + E, Ka, ns, strXa);
         la.gates = f.GA + (long long)t * B * 4 * Ha; la.ld_gates = 4 * Ha;
         la.c_prev = t ? f.CA + (t - 1) * sHa : nullptr; la.ld_cprev = Ha;
@@ -256,7 +258,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
     T2_REQUIRE(B > 0 && Ti > 0 && p->n_steps > 0 && p->t0 >= 0 && p->t0 + p->n_steps <= p->max_steps,
                "dec_infer: bad step range");
     T2_REQUIRE(E % 64 == 0 && Ha % 64 == 0 && Hd % 64 == 0 && P % 64 == 0, "dec_infer: E, Ha, Hd, P must be multiples of 64");
-    T2_REQUIRE(p->W1 && p->W2 && p->Wa_cat && p->bias_a && p->Wd_cat && p->bias_d && p->WqT && p->U && p->v &&
+    T2_REQUIRE(p->W1 && p->W2 && p->Wa_cat && p->bias_a && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->attn_ws &&
                    p->Wpg && p->bias_pg && p->memory && p->pm && p->keep_prenet,
                "dec_infer: null weights/inputs");
     T2_REQUIRE(p->h_a && p->c_a && p->c_d && p->hc && p->cum && p->x_prenet && p->gates && p->zero_frame && p->PG &&
@@ -300,7 +302,8 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         t2amd_attn_fwd at = {};
         at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
         at.h = p->h_a + wr * sHa; at.ld_h = Ha;
-        at.WqT = p->WqT; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
+        at.Wq = p->Wq; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
+        at.ws = p->attn_ws; at.active = p->active;
         at.w_prev = t ? p->ALIGN + (long long)(t - 1) * Ti : nullptr; at.ld_wprev = (long long)p->max_steps * Ti;
         at.cum = p->cum; at.cum_save = nullptr;
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)p->max_steps * Ti;

@@ -317,12 +317,10 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     Wd_cat = run.empty(4 * Hd, Ha + E + Hd)
     nv.copy2d(Wd_cat[:, :Ha + E], Wih_d)
     nv.copy2d(Wd_cat[:, Ha + E:], Whh_d)
-    Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']                    # (A, Ha)
-    WqT = run.empty(Ha, A)
-    nv.transpose(WqT, Wq)
+    Wq = P['decoder.attention_layer.query_layer.linear_layer.weight'].contiguous()       # (A, Ha)
     Wdense = P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']
     Wconv = P['decoder.attention_layer.location_layer.location_conv.conv.weight']
-    U = run.empty(A * nv.LOC_TAPS + 64 * A)
+    U = run.empty(A * nv.LOC_TAPS)
     nv.fold_location(Wdense, Wconv, U)
     vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
 
@@ -338,9 +336,10 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     slabs = dict(HA=run.empty(To, B, Ha), CA=run.empty(To, B, Ha), GD=run.empty(To, B, 4 * Hd),
                  HD=run.empty(To, B, Hd), CD=run.empty(To, B, Hd), CTX=run.empty(To, B, E),
                  Q=run.empty(To, B, A), ALIGN=run.empty(B, To, Ti), CUM=run.empty(To, B, Ti),
-                 cum_work=run.empty(B, Ti))
+                 cum_work=run.empty(B, Ti),
+                 attn_ws=run.empty(nv.attn_fwd_ws_floats(B, Ti) + nv.attn_bwd_ws_floats(B, Ti)))
     d.Wa_rec, d.Wd_cat, d.bias_d = nv.ptr(Wa_rec), nv.ptr(Wd_cat), nv.ptr(bias_d)
-    d.WqT, d.U, d.v = nv.ptr(WqT), nv.ptr(U), nv.ptr(vvec)
+    d.Wq, d.U, d.v = nv.ptr(Wq), nv.ptr(U), nv.ptr(vvec)
     d.GA, d.memory, d.pm = nv.ptr(GA), nv.ptr(memory), nv.ptr(pm)
     d.lens = nv.ptr(lens32, torch.int32)
     d.keep_att = nv.ptr(keep_att, torch.uint8)
@@ -383,7 +382,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     c.keep = dict(att=keep_att, dec=keep_dec, k0=k0, k1=k1)
     c.slabs = slabs
     c.tensors = dict(x0=x0, p1=p1, p2=p2, pm=pm, GA=GA, Wa_rec=Wa_rec, Wd_cat=Wd_cat, bias_d=bias_d,
-                     WqT=WqT, U=U, Wpg=Wpg, mel_cl=mel_cl, vvec=vvec, lens32=lens32)
+                     Wq=Wq, U=U, Wpg=Wpg, mel_cl=mel_cl, vvec=vvec, lens32=lens32)
     return (mel, mel_post, gate, slabs['ALIGN']), c
 
 
@@ -450,15 +449,15 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     ns = 4
     bw = nv.DecTrainBwd()
     bw.f = c.dec
-    bw.Wa_recT, bw.Wd_catT, bw.Wq = nv.ptr(Wa_recT), nv.ptr(Wd_catT), nv.ptr(Wq)
+    bw.Wa_recT, bw.Wd_catT = nv.ptr(Wa_recT), nv.ptr(Wd_catT)
     bw.DHC = nv.ptr(DHC)
     bw.d_align = nv.ptr(cont(d_align))
     bw.nsplit = ns
     out = dict(DGA=run.empty(To, B, 4 * Ha), DGD=run.empty(To, B, 4 * Hd), DCTX=run.empty(To, B, E),
                DQ=run.empty(To, B, A), d_pm=run.empty(B, Ti, A), dU_acc=run.empty(B, A, nv.LOC_TAPS),
                dv_acc=run.empty(B, A), dXd=run.empty(ns, B, Ha + E + Hd), dXa=run.empty(ns, B, E + Ha),
-               dc_a=run.empty(B, Ha), dc_d=run.empty(B, Hd), dw_carry=run.empty(B, Ti),
-               dcum_carry=run.empty(B, Ti), dq_h=run.empty(B, Ha))
+               dc_a=run.empty(B, Ha), dc_d=run.empty(B, Hd), dwin_part=run.empty(nv.ATT_SLICES, B, 2, Ti),
+               dcum_acc=run.empty(B, Ti), dq_h=run.empty(nv.ATT_SLICES, B, Ha))
     for k_, v_ in out.items():
         setattr(bw, k_, nv.ptr(v_))
     nv.decoder_train_bwd_loop(bw)
@@ -698,10 +697,8 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     Wd_cat = run.empty(4 * Hd, Ha + E + Hd)
     nv.copy2d(Wd_cat[:, :Ha + E], Wih_d)
     nv.copy2d(Wd_cat[:, Ha + E:], Whh_d)
-    Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
-    WqT = run.empty(Ha, A)
-    nv.transpose(WqT, Wq)
-    U = run.empty(A * nv.LOC_TAPS + 64 * A)
+    Wq = P['decoder.attention_layer.query_layer.linear_layer.weight'].contiguous()
+    U = run.empty(A * nv.LOC_TAPS)
     nv.fold_location(P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'],
                      P['decoder.attention_layer.location_layer.location_conv.conv.weight'], U)
     vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
@@ -721,6 +718,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     st = dict(h_a=run.zeros(2, B, Ha), c_a=run.zeros(2, B, Ha), c_d=run.zeros(2, B, Hd),
               hc=run.zeros(2, B, Hd + E), cum=run.zeros(B, Ti), x_prenet=run.empty(2, B, Pd),
               gates=run.empty(B, 4 * max(Ha, Hd)), zero_frame=run.zeros(B, Cm),
+              attn_ws=run.empty(nv.attn_fwd_ws_floats(B, Ti)),
               PG=run.zeros(max_steps, B, Cm + 1), ALIGN=run.zeros(B, max_steps, Ti))
     out_lengths = torch.zeros(B, dtype=torch.int32, device=dev)
     active = torch.ones(B, dtype=torch.uint8, device=dev)
@@ -728,7 +726,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     d.W1 = nv.ptr(P['decoder.prenet.layers.0.linear_layer.weight'])
     d.W2 = nv.ptr(P['decoder.prenet.layers.1.linear_layer.weight'])
     d.Wa_cat, d.bias_a, d.Wd_cat, d.bias_d = nv.ptr(Wa_cat), nv.ptr(bias_a), nv.ptr(Wd_cat), nv.ptr(bias_d)
-    d.WqT, d.U, d.v, d.Wpg, d.bias_pg = nv.ptr(WqT), nv.ptr(U), nv.ptr(vvec), nv.ptr(Wpg), nv.ptr(bpg)
+    d.Wq, d.U, d.v, d.Wpg, d.bias_pg = nv.ptr(Wq), nv.ptr(U), nv.ptr(vvec), nv.ptr(Wpg), nv.ptr(bpg)
     d.memory, d.pm = nv.ptr(memory), nv.ptr(pm)
     d.lens = nv.ptr(lens32, torch.int32) if ragged else None
     d.keep_prenet = nv.ptr(keep, torch.uint8)

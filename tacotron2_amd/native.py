@@ -21,6 +21,7 @@ ATT_DIM = 128
 LOC_FILTERS = 32
 LOC_KERNEL = 31
 LOC_TAPS = 62
+ATT_SLICES = 4
 
 _f32p = C.c_void_p
 _i64 = C.c_longlong
@@ -92,7 +93,7 @@ class AttnFwd(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("Ti", C.c_int), ("E", C.c_int), ("Hq", C.c_int),
         ("h", _f32p), ("ld_h", _i64),
-        ("WqT", _f32p), ("U", _f32p), ("v", _f32p), ("pm", _f32p), ("memory", _f32p),
+        ("Wq", _f32p), ("U", _f32p), ("v", _f32p), ("pm", _f32p), ("memory", _f32p),
         ("lens", C.c_void_p),
         ("w_prev", _f32p), ("ld_wprev", _i64),
         ("cum", _f32p), ("cum_save", _f32p),
@@ -100,6 +101,7 @@ class AttnFwd(C.Structure):
         ("ctx_out", _f32p), ("ld_ctx", _i64),
         ("q_out", _f32p), ("ld_q", _i64),
         ("active", C.c_void_p),
+        ("ws", _f32p),
     ]
 
 
@@ -115,34 +117,35 @@ class AttnBwd(C.Structure):
         ("w", _f32p), ("ld_w", _i64),
         ("w_prev", _f32p), ("ld_wprev", _i64),
         ("cum_before", _f32p),
-        ("dw_carry", _f32p), ("dcum_carry", _f32p),
+        ("dwin_part", _f32p), ("dcum_acc", _f32p),
         ("d_pm", _f32p), ("dU_acc", _f32p), ("dv_acc", _f32p),
         ("dq_out", _f32p), ("ld_dq", _i64),
-        ("dh_out", _f32p), ("ld_dh", _i64),
+        ("dh_out", _f32p), ("ld_dh", _i64), ("dh_split_stride", _i64),
+        ("ws", _f32p),
     ]
 
 
 class DecTrain(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("Ti", C.c_int), ("To", C.c_int), ("E", C.c_int), ("Ha", C.c_int), ("Hd", C.c_int),
-        ("Wa_rec", _f32p), ("Wd_cat", _f32p), ("bias_d", _f32p), ("WqT", _f32p), ("U", _f32p), ("v", _f32p),
+        ("Wa_rec", _f32p), ("Wd_cat", _f32p), ("bias_d", _f32p), ("Wq", _f32p), ("U", _f32p), ("v", _f32p),
         ("GA", _f32p), ("memory", _f32p), ("pm", _f32p), ("lens", C.c_void_p),
         ("keep_att", C.c_void_p), ("keep_dec", C.c_void_p),
         ("scale_att", C.c_float), ("scale_dec", C.c_float),
         ("HA", _f32p), ("CA", _f32p), ("GD", _f32p), ("HD", _f32p), ("CD", _f32p), ("CTX", _f32p),
-        ("Q", _f32p), ("ALIGN", _f32p), ("CUM", _f32p), ("cum_work", _f32p),
+        ("Q", _f32p), ("ALIGN", _f32p), ("CUM", _f32p), ("cum_work", _f32p), ("attn_ws", _f32p),
     ]
 
 
 class DecTrainBwd(C.Structure):
     _fields_ = [
         ("f", DecTrain),
-        ("Wa_recT", _f32p), ("Wd_catT", _f32p), ("Wq", _f32p), ("DHC", _f32p), ("d_align", _f32p),
+        ("Wa_recT", _f32p), ("Wd_catT", _f32p), ("DHC", _f32p), ("d_align", _f32p),
         ("nsplit", C.c_int),
         ("DGA", _f32p), ("DGD", _f32p), ("DCTX", _f32p), ("DQ", _f32p), ("d_pm", _f32p),
         ("dU_acc", _f32p), ("dv_acc", _f32p),
         ("dXd", _f32p), ("dXa", _f32p), ("dc_a", _f32p), ("dc_d", _f32p),
-        ("dw_carry", _f32p), ("dcum_carry", _f32p), ("dq_h", _f32p),
+        ("dwin_part", _f32p), ("dcum_acc", _f32p), ("dq_h", _f32p),
     ]
 
 
@@ -164,10 +167,10 @@ class DecInfer(C.Structure):
         ("t0", C.c_int), ("n_steps", C.c_int), ("max_steps", C.c_int),
         ("gate_threshold", C.c_float),
         ("W1", _f32p), ("W2", _f32p), ("Wa_cat", _f32p), ("bias_a", _f32p), ("Wd_cat", _f32p),
-        ("bias_d", _f32p), ("WqT", _f32p), ("U", _f32p), ("v", _f32p), ("Wpg", _f32p), ("bias_pg", _f32p),
+        ("bias_d", _f32p), ("Wq", _f32p), ("U", _f32p), ("v", _f32p), ("Wpg", _f32p), ("bias_pg", _f32p),
         ("memory", _f32p), ("pm", _f32p), ("lens", C.c_void_p), ("keep_prenet", C.c_void_p),
         ("h_a", _f32p), ("c_a", _f32p), ("c_d", _f32p), ("hc", _f32p), ("cum", _f32p),
-        ("x_prenet", _f32p), ("gates", _f32p), ("zero_frame", _f32p),
+        ("x_prenet", _f32p), ("gates", _f32p), ("zero_frame", _f32p), ("attn_ws", _f32p),
         ("PG", _f32p), ("ALIGN", _f32p), ("out_lengths", C.c_void_p), ("active", C.c_void_p),
         ("done_count", C.c_void_p),
     ]
@@ -652,9 +655,9 @@ def lstm_pointwise_bwd(B, H, dh_list, gates, c_prev, c, keep, keep_scale, dc, dg
 
 
 def fold_location(wdense, wconv, U):
-    """U buffer: 128*62 floats of U followed by 64*128 floats of U^T."""
+    """U buffer: 128*62 floats."""
     lib = load()
-    assert U.numel() == ATT_DIM * LOC_TAPS + 64 * ATT_DIM
+    assert U.numel() == ATT_DIM * LOC_TAPS
     assert tuple(wdense.shape) == (ATT_DIM, LOC_FILTERS) and tuple(wconv.shape) == (LOC_FILTERS, 2, LOC_KERNEL)
     _check(lib.t2amd_fold_location_f32(ptr(_fullc(wdense)), ptr(_fullc(wconv)), ptr(_fullc(U)), _stream()),
            "t2amd_fold_location_f32")
@@ -667,13 +670,21 @@ def unfold_location_grads(dU_acc, dv_acc, nb, wdense, wconv, dwdense, dwconv, dv
                                                ptr(_fullc(dv)), _stream()), "t2amd_unfold_location_grads_f32")
 
 
-def attention_step_fwd(h, WqT, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, active=None):
+def attn_fwd_ws_floats(B, Ti):
+    return ATT_SLICES * B * Ti
+
+
+def attn_bwd_ws_floats(B, Ti):
+    return B * Ti + ATT_SLICES * B
+
+
+def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None):
     lib = load()
     a = AttnFwd()
     B, Ti, E = memory.shape
     a.B, a.Ti, a.E, a.Hq = B, Ti, E, h.shape[1]
     a.h, a.ld_h = _mat(h)[:2]
-    a.WqT, a.U, a.v, a.pm, a.memory = ptr(_fullc(WqT)), ptr(U), ptr(v), ptr(_fullc(pm)), ptr(_fullc(memory))
+    a.Wq, a.U, a.v, a.pm, a.memory = ptr(_fullc(Wq)), ptr(U), ptr(v), ptr(_fullc(pm)), ptr(_fullc(memory))
     a.lens = ptr(lens, torch.int32)
     if w_prev is not None:
         a.w_prev, a.ld_wprev = _mat(w_prev)[:2]
@@ -684,11 +695,15 @@ def attention_step_fwd(h, WqT, U, v, pm, memory, lens, w_prev, cum, cum_save, w_
     if q_out is not None:
         a.q_out, a.ld_q = _mat(q_out)[:2]
     a.active = ptr(active, torch.uint8)
+    if ws.numel() < attn_fwd_ws_floats(B, Ti):
+        raise NativeError("attention_step_fwd: workspace too small")
+    a.ws = ptr(_fullc(ws))
     _check(lib.t2amd_attention_step_fwd_f32(C.byref(a), _stream()), "t2amd_attention_step_fwd_f32")
 
 
 def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory, lens, w, w_prev, cum_before,
-                       dw_carry, dcum_carry, d_pm, dU_acc, dv_acc, dq_out, dh_out):
+                       dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws):
+    """dwin_part: (ATT_SLICES, B, 2, Ti) in/out; dcum_acc: (B, Ti) in/out; dh_parts: (ATT_SLICES, B, Hq) out."""
     lib = load()
     a = AttnBwd()
     B, Ti, E = memory.shape
@@ -705,10 +720,15 @@ def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory
     if w_prev is not None:
         a.w_prev, a.ld_wprev = _mat(w_prev)[:2]
     a.cum_before = ptr(_fullc(cum_before))
-    a.dw_carry, a.dcum_carry = ptr(_fullc(dw_carry)), ptr(_fullc(dcum_carry))
+    if tuple(dwin_part.shape) != (ATT_SLICES, B, 2, Ti) or tuple(dh_parts.shape) != (ATT_SLICES, B, Wq.shape[1]):
+        raise NativeError("attention_step_bwd: dwin_part / dh_parts have the wrong shape")
+    a.dwin_part, a.dcum_acc = ptr(_fullc(dwin_part)), ptr(_fullc(dcum_acc))
     a.d_pm, a.dU_acc, a.dv_acc = ptr(_fullc(d_pm)), ptr(_fullc(dU_acc)), ptr(_fullc(dv_acc))
     a.dq_out, a.ld_dq = _mat(dq_out)[:2]
-    a.dh_out, a.ld_dh = _mat(dh_out)[:2]
+    a.dh_out, a.ld_dh, a.dh_split_stride = ptr(_fullc(dh_parts)), Wq.shape[1], B * Wq.shape[1]
+    if ws.numel() < attn_bwd_ws_floats(B, Ti):
+        raise NativeError("attention_step_bwd: workspace too small")
+    a.ws = ptr(_fullc(ws))
     _check(lib.t2amd_attention_step_bwd_f32(C.byref(a), _stream()), "t2amd_attention_step_bwd_f32")
 
 

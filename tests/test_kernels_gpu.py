@@ -353,20 +353,18 @@ def test_attention_forward_backward(nv, B, Ti, E, Hq):
     Wd = dv(sd['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'])
     Wc = dv(sd['decoder.attention_layer.location_layer.location_conv.conv.weight'])
     v = dv(sd['decoder.attention_layer.v.linear_layer.weight']).view(-1)
-    WqT = torch.empty(Hq, 128, device=DEV)
-    nv.transpose(WqT, Wq)
-    U = torch.empty(128 * 62 + 64 * 128, device=DEV)
+    U = torch.empty(128 * 62, device=DEV)
     nv.fold_location(Wd, Wc, U)
     Uref = torch.einsum('df,fck->dck', sd['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'],
                         sd['decoder.attention_layer.location_layer.location_conv.conv.weight']).reshape(128, 62)
-    assert err(U[:128 * 62].view(128, 62), Uref) < 1e-5
-    assert err(U[128 * 62:].view(64, 128)[:62], Uref.t()) < 1e-5
+    assert err(U.view(128, 62), Uref) < 1e-5
 
     lens32 = dv(lens.to(torch.int32))
     cum_d, cum_save = dv(cum.clone()), torch.empty(B, Ti, device=DEV)
     w_out, ctx_out, q_out = torch.empty(B, Ti, device=DEV), torch.empty(B, E, device=DEV), torch.empty(B, 128, device=DEV)
     memd, pmd, hd, wpd = dv(mem), dv(pm), dv(h), dv(w_prev)
-    nv.attention_step_fwd(hd, WqT, U, v, pmd, memd, lens32, wpd, cum_d, cum_save, w_out, ctx_out, q_out)
+    ws = torch.full((nv.attn_fwd_ws_floats(B, Ti) + nv.attn_bwd_ws_floats(B, Ti),), float('nan'), device=DEV)
+    nv.attention_step_fwd(hd, Wq, U, v, pmd, memd, lens32, wpd, cum_d, cum_save, w_out, ctx_out, q_out, ws)
     assert err(w_out, w) < 1e-5 and err(ctx_out, ctx) < 1e-5
     assert err(cum_d, cum_new) < 1e-5 and torch.equal(cum_save.cpu(), cum)
     assert err(q_out, h @ sd['decoder.attention_layer.query_layer.linear_layer.weight'].t()) < 1e-5
@@ -374,18 +372,26 @@ def test_attention_forward_backward(nv, B, Ti, E, Hq):
 
     # backward
     dctx_total = torch.empty(B, E, device=DEV)
-    dw_c, dcum_c = dv(d_w_carry.clone()), dv(d_cum_carry.clone())
+    # incoming carries in partial form: spread the w-carry over the slices, keep part of the cum-carry
+    # in the running accumulator and part in the c = 1 partials
+    S = nv.ATT_SLICES
+    dwin = torch.zeros(S, B, 2, Ti)
+    for s_ in range(S):
+        dwin[s_, :, 0] = d_w_carry / S
+        dwin[s_, :, 1] = d_cum_carry * 0.125
+    dwin_d, dcum_d = dv(dwin), dv(d_cum_carry * 0.5)
     d_pm = torch.zeros(B, Ti, 128, device=DEV)
     dU_acc, dv_acc = torch.zeros(B, 128, 62, device=DEV), torch.zeros(B, 128, device=DEV)
-    dq, dh = torch.empty(B, 128, device=DEV), torch.empty(B, Hq, device=DEV)
+    dq, dh = torch.empty(B, 128, device=DEV), torch.full((S, B, Hq), float('nan'), device=DEV)
     half = dv(d_ctx * 0.5)
     nv.attention_step_bwd([half, half], dctx_total, dv(d_w_extra), q_out, Wq, U, v, pmd, memd, lens32, w_out, wpd,
-                          cum_save, dw_c, dcum_c, d_pm, dU_acc, dv_acc, dq, dh)
+                          cum_save, dwin_d, dcum_d, d_pm, dU_acc, dv_acc, dq, dh, ws)
     assert err(dctx_total, d_ctx) < 1e-6
-    assert err(dh, hL.grad) < 2e-5
+    assert err(dh.sum(0), hL.grad) < 2e-5
     assert err(d_pm, pmL.grad) < 2e-5
-    assert err(dw_c, wpL.grad) < 2e-5
-    assert err(dcum_c, cumL.grad) < 2e-5
+    assert err(dcum_d, d_cum_carry) < 1e-6                      # running accumulator now holds the full carry
+    assert err(dwin_d[:, :, 0].sum(0), wpL.grad) < 2e-5
+    assert err(dcum_d + dwin_d[:, :, 1].sum(0), cumL.grad) < 2e-5
     dWd, dWc, dvv = torch.empty(128, 32, device=DEV), torch.empty(32, 2, 31, device=DEV), torch.empty(1, 128, device=DEV)
     nv.unfold_location_grads(dU_acc, dv_acc, B, Wd, Wc, dWd, dWc, dvv)
     assert err(dWd, leaf['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'].grad) < 5e-5
@@ -401,13 +407,12 @@ def test_attention_no_mask_and_first_step(nv):
     sd, h, mem, pm, lens, w_prev, cum = _attn_inputs(B, Ti, E, Hq, 90)
     ctx, w = orc.attention_step(h, mem, pm, torch.zeros(B, Ti), torch.zeros(B, Ti), None, sd, -float('inf'))
     Wq = dv(sd['decoder.attention_layer.query_layer.linear_layer.weight'])
-    WqT = torch.empty(Hq, 128, device=DEV)
-    nv.transpose(WqT, Wq)
-    U = torch.empty(128 * 62 + 64 * 128, device=DEV)
+    U = torch.empty(128 * 62, device=DEV)
     nv.fold_location(dv(sd['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']),
                      dv(sd['decoder.attention_layer.location_layer.location_conv.conv.weight']), U)
     cum_d = torch.zeros(B, Ti, device=DEV)
     w_out, ctx_out = torch.empty(B, Ti, device=DEV), torch.empty(B, E, device=DEV)
-    nv.attention_step_fwd(dv(h), WqT, U, dv(sd['decoder.attention_layer.v.linear_layer.weight']).view(-1), dv(pm), dv(mem),
-                          None, None, cum_d, None, w_out, ctx_out, None)
+    ws = torch.empty(nv.attn_fwd_ws_floats(B, Ti), device=DEV)
+    nv.attention_step_fwd(dv(h), Wq, U, dv(sd['decoder.attention_layer.v.linear_layer.weight']).view(-1), dv(pm), dv(mem),
+                          None, None, cum_d, None, w_out, ctx_out, None, ws)
     assert err(w_out, w) < 1e-5 and err(ctx_out, ctx) < 1e-5 and err(cum_d, w) < 1e-5
