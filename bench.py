@@ -9,7 +9,7 @@ synthetic LJSpeech-shaped batch per GPU: parse_batch -> forward -> Tacotron2Loss
 in HBM before the timed region.  Metric: VALID mel frames per second, whole job.
 
 Extra objects in the JSON line:
-  roofline      decoder-LSTM step kernel (skinny_gemm_kernel<true,2>): algorithmic bytes per launch
+  roofline      fused LSTM step launch (skinny_gemm_kernel<true,3>): algorithmic bytes per launch
                  / average launch duration measured live with HIP events on the
                 launch stream during one extra, untimed, step.
   cpu_baseline  the CPU oracle (oracle/tacotron2_oracle.py, a port of the reference) timed on this
@@ -155,19 +155,27 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         To = batches[-1][2].shape[2]
-        native.profile_enable(2, To)                                      # role 2 = decoder LSTM step
+        native.profile_enable(3, To)                  # role 3 = fused launch LSTM_d(t-1) || LSTM_a(t)
         step(batches[-1])
         torch.cuda.synchronize()
         ms, cnt = native.profile_read()
         B, Ha, Hd, E = args.batch_size, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.encoder_embedding_dim
-        K = Ha + E + Hd
-        alg_bytes = 4.0 * (4 * Hd * K + B * K + B * 4 * Hd + 4 * Hd + 3 * B * Hd + 0.25 * B * Hd)
+
+        def lstm_bytes(K, H, with_gin):
+            # weights once + activations in + (pre-activation addend) + bias + gates/c/h out + c_prev + keep mask
+            return 4.0 * (4 * H * K + B * K + (B * 4 * H if with_gin else 0) + 4 * H + B * 4 * H
+                          + 3 * B * H + 0.25 * B * H)
+        alg_bytes = lstm_bytes(Ha + E + Hd, Hd, False) + lstm_bytes(E + Ha, Ha, True)
+        alg_flops = 2.0 * B * (4 * Hd * (Ha + E + Hd) + 4 * Ha * (E + Ha))
         avg_s = (ms / 1e3) / max(cnt, 1)
         achieved = alg_bytes / avg_s / 1e9
-        roofline = {"kernel": "skinny_gemm_kernel<true,2> (decoder LSTM step: 64x2560x4096 f32 MFMA GEMM + cell)",
+        roofline = {"kernel": "skinny_gemm_kernel<true,3> (one decoder time step: decoder LSTM of step t-1 "
+                              "(64x2560x4096) + attention LSTM of step t (64x1536x4096), exact-f32 MFMA + fused cells)",
                     "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": None,
-                    "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes}
+                    "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes,
+                    "mfma_f32": {"achieved_tflops": alg_flops / avg_s / 1e12, "peak_tflops": 157.3,
+                                 "frac": alg_flops / avg_s / 1e12 / 157.3}}
     if world > 1:
         dist.barrier()
 

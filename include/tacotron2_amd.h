@@ -203,6 +203,9 @@ typedef struct t2amd_lstm_step {
 } t2amd_lstm_step;
 
 int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream);
+/* Two independent steps in ONE launch (b may be NULL): the time loops pair the decoder LSTM of step
+ * t-1 with the attention LSTM of step t, neither depends on the other (reference model.py:352-371). */
+int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_lstm_step* b, void* stream);
 
 /* Y[s][B][N] = X[B][K-range s] . W[N][K]^T  (W K-contiguous), s < nsplit */
 typedef struct t2amd_skinny_gemm {
@@ -218,6 +221,7 @@ typedef struct t2amd_skinny_gemm {
 } t2amd_skinny_gemm;
 
 int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream);
+int t2amd_skinny_gemm2_f32(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, void* stream);
 
 typedef struct t2amd_addend {
     const float* p;   /* NULL = absent */
@@ -247,6 +251,7 @@ typedef struct t2amd_lstm_bwd {
 } t2amd_lstm_bwd;
 
 int t2amd_lstm_pointwise_bwd_f32(const t2amd_lstm_bwd* a, void* stream);
+int t2amd_lstm_pointwise_bwd2_f32(const t2amd_lstm_bwd* a, const t2amd_lstm_bwd* b, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Location-sensitive attention, one decoder step (reference model.py:43-86 Attention.forward /

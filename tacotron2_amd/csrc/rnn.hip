@@ -5,19 +5,27 @@
 // over the whole K (no split: the cell needs the complete pre-activation), so 4H/16
 // workgroups stream disjoint 16-row slices of the packed weight [4H][K] exactly once per
 // step from HBM/MALL; the activations (64 x K) are re-read by every workgroup from L2.
-// Both operands sit row-major (K contiguous) in LDS with a row stride of 72 floats:
-// a lane reads ONE ds_read_b128 = 4 consecutive k for (row = lane&15, k-group = lane>>4) and
-// feeds element j to MFMA j of a group of four — the k order inside a 16-wide block is
-// permuted identically for A and B, which a dot product does not care about, and stride
-// 72 (= 8 mod 64 banks) makes the b128 reads conflict-free.
+//
+// Operand staging is LDS-DMA (global_load_lds_dwordx4): no VGPRs, no ds_write pass, and the DMA of
+// tiles kt+1, kt+2 stays in flight across the one barrier per k-tile (raw s_barrier + counted
+// vmcnt, never __syncthreads()).  A DMA instruction writes 64 lanes x 16 B contiguously, so the
+// LDS image is plain row-major [row][64 floats]; bank conflicts on the b128 fragment reads are
+// removed by permuting the SOURCE: LDS chunk p of row r holds global chunk p ^ (r & 15), and the
+// reader asks for chunk (4s+lg) ^ (row & 15).  Wave w DMAs exactly the 16 activation rows it
+// multiplies itself, plus 4 of the 16 weight rows everybody reads.
 //
 // Replaces torch.nn.LSTMCell + F.dropout (reference model.py:352-356, 366-371) and the
 // per-timestep work of nn.LSTM (model.py:181-188).
 #include "common.h"
 
 #define SK_BK 64      // k per LDS tile
-#define SK_LD 72      // LDS row stride (floats)
 #define SK_ROWS 64    // batch rows per workgroup
+#define SK_NBUF 3     // LDS ring: tile kt is multiplied while kt+1, kt+2 are in flight
+#define SK_XT (SK_ROWS * SK_BK)   // floats per X tile
+#define SK_WT (16 * SK_BK)        // floats per W tile
+
+typedef __attribute__((address_space(1))) const void* t2_gptr;
+typedef __attribute__((address_space(3))) void* t2_lptr;
 
 struct SkinnyParams {
     t2amd_seg x[3];
@@ -37,114 +45,224 @@ struct SkinnyParams {
     const int* lens; int t;
     // plain epilogue
     float* Y; long long ldy; int nsplit; long long split_stride; int ktiles_per_split;
+    int gx, gy, gz;   // logical grid of this problem
 };
+
+// Two independent problems in one launch (blocks [0, nblk0) -> p[0], the rest -> p[1]): the decoder
+// LSTM of step t-1 rides along with the attention LSTM of step t (and likewise their BPTT dgrads),
+// which puts two workgroups on every CU so that one's MFMAs cover the other's loads and barriers.
+struct SkinnyDual { SkinnyParams p[2]; int nblk0; };
+
+#define SK_DEPTH 4    // register ring: tiles kt+1 .. kt+3 are in flight from HBM/L2 while tile kt is multiplied
 
 // TAG only gives each role its own kernel symbol, so that rocprofv3 --kernel-trace --stats reports
 // the decoder's attention-LSTM (1) / decoder-LSTM (2) launches separately from the rest (0).
 template <bool LSTM, int TAG>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyParams p) {
-    __shared__ __attribute__((aligned(16))) float Xs[2][SK_ROWS][SK_LD];
-    __shared__ __attribute__((aligned(16))) float Ws[2][16][SK_LD];
-    __shared__ float Os[SK_ROWS][17];
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
+    // ONE shared array (a second __shared__ object makes hipcc drain the DMA queue before every ds_read)
+    __shared__ __attribute__((aligned(16))) float smem[SK_NBUF * (SK_XT + SK_WT) + SK_ROWS * 17];
+    float* const Xs = smem;                               // [NBUF][64][64]
+    float* const Ws = smem + SK_NBUF * SK_XT;             // [NBUF][16][64]
+    float* const Os = smem + SK_NBUF * (SK_XT + SK_WT);   // [64][17]
+
+    const bool second = (int)blockIdx.x >= dp.nblk0;
+    const SkinnyParams& p = second ? dp.p[1] : dp.p[0];
+    const int lb = (int)blockIdx.x - (second ? dp.nblk0 : 0);
+    const int bx = lb % p.gx;
+    const int by = (lb / p.gx) % p.gy;
+    const int bz = lb / (p.gx * p.gy);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int rowbase = blockIdx.y * SK_ROWS;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int rowbase = by * SK_ROWS;
     const int B = p.B;
 
-    // weight row handled by this thread's W-tile load: c = tid>>4 (0..15), kq = tid&15
-    const int wc = tid >> 4;
-    const int wkq = tid & 15;
-    long long wrow;
-    bool wrow_ok = true;
-    if (LSTM) {
-        const int j0 = blockIdx.x * 4;
-        wrow = (long long)(wc >> 2) * p.H + j0 + (wc & 3);
-    } else {
-        wrow = (long long)blockIdx.x * 16 + wc;
-        wrow_ok = wrow < p.N;
-    }
-    const float* __restrict__ wsrc = p.W + wrow * p.Ktot + wkq * 4;
-
-    int kt_beg = 0, kt_end = p.Ktot / SK_BK;
+    // Virtual k-tiles: absent (all-zero) segments contribute nothing and are skipped outright.
+    const int n0 = p.x[0].p ? p.x[0].width / SK_BK : 0;
+    const int n1 = (p.nseg > 1 && p.x[1].p) ? p.x[1].width / SK_BK : 0;
+    const int n2 = (p.nseg > 2 && p.x[2].p) ? p.x[2].width / SK_BK : 0;
+    const int wo1 = p.x[0].width, wo2 = p.x[0].width + (p.nseg > 1 ? p.x[1].width : 0);
+    const int nvt = n0 + n1 + n2;
+    int kt_beg = 0, kt_end = nvt;
     if (!LSTM) {
-        kt_beg = blockIdx.z * p.ktiles_per_split;
+        kt_beg = bz * p.ktiles_per_split;
         kt_end = kt_beg + p.ktiles_per_split;
-        const int all = p.Ktot / SK_BK;
-        if (kt_end > all) kt_end = all;
+        if (kt_end > nvt) kt_end = nvt;
     }
 
-    float4 rx[4];
-    float4 rw;
+    // LSTM epilogue operands: fetched up front so that their latency hides behind the main loop
+    const int erow = tid >> 2, ejj = tid & 3;
+    const int egr = rowbase + erow;
+    const int ej = bx * 4 + ejj;
+    float e_gin[4] = {0.f, 0.f, 0.f, 0.f}, e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f;
+    bool e_keep = true, e_valid = true;
+    if (LSTM && egr < B) {
+        const int H = p.H;
+        if (p.lens) e_valid = p.t < p.lens[egr];
+        if (p.gin) {
+            const float* g = p.gin + (long long)egr * p.ld_gin;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e_gin[q] = g[q * H + ej];
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e_bias[q] = p.bias[q * H + ej];
+        }
+        if (p.c_prev) e_cp = p.c_prev[(long long)egr * p.ld_cprev + ej];
+        if (p.keep) e_keep = p.keep[(long long)egr * p.ld_keep + ej] != 0;
+    }
 
-    auto load_tile = [&](int kt) {
-        // locate segment (widths are multiples of 64, so a tile never straddles segments)
-        int koff = kt * SK_BK;
-        const float* sp = p.x[0].p;
-        long long sld = p.x[0].ld;
-        if (p.nseg > 1 && koff >= p.x[0].width) {
-            koff -= p.x[0].width;
-            sp = p.x[1].p;
-            sld = p.x[1].ld;
-            if (p.nseg > 2 && koff >= p.x[1].width) {
-                koff -= p.x[1].width;
-                sp = p.x[2].p;
-                sld = p.x[2].ld;
-            }
-        }
+    // ---- DMA source offsets (loop invariant) ------------------------------------------------------
+    // X: instruction i of this wave fills LDS rows 16*wave + 4*i + lg, LDS chunk l15 <- global chunk
+    // l15 ^ (row & 15).  Rows past B are clamped (their results are never stored).
+    long long xo0[4], xo1[4], xo2[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i;
-            const int r = f >> 4, kq = f & 15;
-            const int gr = rowbase + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sp != nullptr && gr < B)
-                v = *reinterpret_cast<const float4*>(sp + (long long)gr * sld + koff + kq * 4);
-            rx[i] = v;
+    for (int i = 0; i < 4; ++i) {
+        const int r = 16 * wave + 4 * i + lg;
+        int gr = rowbase + r;
+        if (gr > B - 1) gr = B - 1;
+        const int c4 = 4 * (l15 ^ (r & 15));
+        xo0[i] = (long long)gr * p.x[0].ld + c4;
+        xo1[i] = (long long)gr * p.x[1].ld + c4;
+        xo2[i] = (long long)gr * p.x[2].ld + c4;
+    }
+    // W: this wave fills weight-tile rows 4*wave + lg.  Rows past N (plain kernel, ragged last block)
+    // are clamped: their columns are never stored.
+    long long wo;
+    {
+        const int c = 4 * wave + lg;
+        long long wrow;
+        if (LSTM) {
+            wrow = (long long)(c >> 2) * p.H + bx * 4 + (c & 3);
+        } else {
+            wrow = (long long)bx * 16 + c;
+            if (wrow > p.N - 1) wrow = p.N - 1;
         }
-        rw = wrow_ok ? *reinterpret_cast<const float4*>(wsrc + (long long)kt * SK_BK)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 256 * i;
-            const int r = f >> 4, kq = f & 15;
-            *reinterpret_cast<float4*>(&Xs[buf][r][kq * 4]) = rx[i];
-        }
-        *reinterpret_cast<float4*>(&Ws[buf][wc][wkq * 4]) = rw;
-    };
+        wo = wrow * p.Ktot + 4 * (l15 ^ (c & 15));
+    }
+    const float* const sp0 = p.x[0].p;
+    const float* const sp1 = p.x[1].p;
+    const float* const sp2 = p.x[2].p;
+    const float* const Wp = p.W;
+    const int kt_last = kt_end - 1;
+
+#define SK_ISSUE(BUF, KT_REQ)                                                                          \
+    {                                                                                                  \
+        int kt_ = (KT_REQ) < kt_last ? (KT_REQ) : kt_last;                                             \
+        const float* sp_;                                                                              \
+        int wk_;                                                                                       \
+        long long o0_, o1_, o2_, o3_;                                                                  \
+        if (kt_ < n0) {                                                                                \
+            sp_ = sp0 + kt_ * SK_BK; wk_ = kt_ * SK_BK;                                                \
+            o0_ = xo0[0]; o1_ = xo0[1]; o2_ = xo0[2]; o3_ = xo0[3];                                    \
+        } else if (kt_ < n0 + n1) {                                                                    \
+            kt_ -= n0;                                                                                 \
+            sp_ = sp1 + kt_ * SK_BK; wk_ = wo1 + kt_ * SK_BK;                                          \
+            o0_ = xo1[0]; o1_ = xo1[1]; o2_ = xo1[2]; o3_ = xo1[3];                                    \
+        } else {                                                                                       \
+            kt_ -= n0 + n1;                                                                            \
+            sp_ = sp2 + kt_ * SK_BK; wk_ = wo2 + kt_ * SK_BK;                                          \
+            o0_ = xo2[0]; o1_ = xo2[1]; o2_ = xo2[2]; o3_ = xo2[3];                                    \
+        }                                                                                              \
+        float* xd_ = Xs + (BUF) * SK_XT + wave * (16 * SK_BK);                                         \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o0_), (t2_lptr)(xd_), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o1_), (t2_lptr)(xd_ + 256), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o2_), (t2_lptr)(xd_ + 512), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o3_), (t2_lptr)(xd_ + 768), 16, 0, 0);       \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(Wp + wo + wk_),                                     \
+                                         (t2_lptr)(Ws + (BUF) * SK_WT + wave * 256), 16, 0, 0);        \
+    }
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const int l15 = lane & 15, lg = lane >> 4;
+    // Fragment reads: row l15 (of this wave's 16 rows / of the 16 weight rows), chunk (4s+lg)^l15.
+    // They are issued from inline asm: hipcc orders every ds_read it can see behind ALL pending LDS-DMA
+    // (s_waitcnt vmcnt(0)), which would drain the ring each tile; the DMA/read ordering is ours
+    // (counted vmcnt + barrier above each tile), the LDS wait is inside the statement.
+    unsigned aa[4], ba[4];
+    {
+        const unsigned xbase = (unsigned)reinterpret_cast<size_t>((t2_lptr)(Xs + wave * (16 * SK_BK)));
+        const unsigned wbase = (unsigned)reinterpret_cast<size_t>((t2_lptr)(Ws));
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const unsigned fo = 4u * (unsigned)(l15 * SK_BK + 4 * ((4 * s_ + lg) ^ l15));
+            aa[s_] = xbase + fo;
+            ba[s_] = wbase + fo;
+        }
+    }
+
+#define SK_MMA(BUF)                                                                                     \
+    {                                                                                                   \
+        f32x4 a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_;                                                   \
+        asm volatile(                                                                                   \
+            "ds_read_b128 %0, %8 offset:%16\n\t"                                                        \
+            "ds_read_b128 %4, %12 offset:%17\n\t"                                                       \
+            "ds_read_b128 %1, %9 offset:%16\n\t"                                                        \
+            "ds_read_b128 %5, %13 offset:%17\n\t"                                                       \
+            "ds_read_b128 %2, %10 offset:%16\n\t"                                                       \
+            "ds_read_b128 %6, %14 offset:%17\n\t"                                                       \
+            "ds_read_b128 %3, %11 offset:%16\n\t"                                                       \
+            "ds_read_b128 %7, %15 offset:%17\n\t"                                                       \
+            "s_waitcnt lgkmcnt(0)"                                                                      \
+            : "=&v"(a0_), "=&v"(a1_), "=&v"(a2_), "=&v"(a3_), "=&v"(b0_), "=&v"(b1_), "=&v"(b2_), "=&v"(b3_) \
+            : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba[0]), "v"(ba[1]), "v"(ba[2]), "v"(ba[3]), \
+              "i"((BUF) * SK_XT * 4), "i"((BUF) * SK_WT * 4)                                            \
+            : "memory");                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[0], b0_[0], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[1], b0_[1], acc1, 0, 0, 0);                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[2], b0_[2], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[3], b0_[3], acc1, 0, 0, 0);                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[0], b1_[0], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[1], b1_[1], acc1, 0, 0, 0);                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[2], b1_[2], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[3], b1_[3], acc1, 0, 0, 0);                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[0], b2_[0], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[1], b2_[1], acc1, 0, 0, 0);                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[2], b2_[2], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[3], b2_[3], acc1, 0, 0, 0);                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[0], b3_[0], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[1], b3_[1], acc1, 0, 0, 0);                     \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[2], b3_[2], acc0, 0, 0, 0);                     \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[3], b3_[3], acc1, 0, 0, 0);                     \
+    }
+    // One k-tile.  Every wave has issued exactly 5 DMA instructions per tile, always (tile indices are
+    // clamped, never branched on), so "tile kt landed" is vmcnt(5): only tile kt+1's five may be pending.
+    // The barrier then (a) makes the other waves' weight rows of tile kt visible and (b) proves everybody
+    // finished reading the buffer tile kt+2 is about to overwrite (it held tile kt-1).
+#define SK_STEP(BUF, KT)                                                     \
+    {                                                                        \
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                     \
+        __builtin_amdgcn_s_barrier();                                        \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        SK_ISSUE(((BUF) + 2) % SK_NBUF, (KT) + 2)                            \
+        SK_MMA(BUF)                                                          \
+    }
 
     if (kt_end > kt_beg) {
-        load_tile(kt_beg);
-        store_tile(0);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_beg; kt < kt_end; ++kt) {
-        const bool more = (kt + 1 < kt_end);
-        if (more) load_tile(kt + 1);
-#pragma unroll
-        for (int s = 0; s < SK_BK / 16; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(&Xs[cur][wave * 16 + l15][s * 16 + lg * 4]);
-            const float4 b = *reinterpret_cast<const float4*>(&Ws[cur][l15][s * 16 + lg * 4]);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
+        SK_ISSUE(0, kt_beg)
+        SK_ISSUE(1, kt_beg + 1)
+        int kt = kt_beg;
+        for (; kt + 3 <= kt_end; kt += 3) {
+            SK_STEP(0, kt)
+            SK_STEP(1, kt + 1)
+            SK_STEP(2, kt + 2)
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (kt < kt_end) {
+            SK_STEP(0, kt)
+            if (kt + 1 < kt_end) SK_STEP(1, kt + 1)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped duplicate tiles
     }
+#undef SK_ISSUE
+#undef SK_MMA
+#undef SK_STEP
+
     // D layout (16x16): col = lane&15, row = (lane>>4)*4 + reg
     if (!LSTM) {
-        float* __restrict__ Y = p.Y + (long long)blockIdx.z * p.split_stride;
-        const int gn = blockIdx.x * 16 + l15;
+        float* __restrict__ Y = p.Y + (long long)bz * p.split_stride;
+        const int gn = bx * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gr = rowbase + wave * 16 + lg * 4 + r;
@@ -153,49 +271,33 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyParams p) {
         return;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Os[wave * 16 + lg * 4 + r][l15] = acc0[r] + acc1[r];
+    for (int r = 0; r < 4; ++r) Os[(wave * 16 + lg * 4 + r) * 17 + l15] = acc0[r] + acc1[r];
     __syncthreads();
 
     // LSTM cell: thread -> (row = tid>>2, unit jj = tid&3); gate g lives in column g*4+jj
-    const int row = tid >> 2, jj = tid & 3;
-    const int gr = rowbase + row;
-    if (gr >= B) return;
-    const int j = blockIdx.x * 4 + jj;
+    if (egr >= B) return;
     const int H = p.H;
-    bool valid = true;
-    if (p.lens) valid = p.t < p.lens[gr];
     float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cn = 0.f, hn = 0.f;
-    if (valid) {
-        float pi = Os[row][jj], pf = Os[row][4 + jj], pg = Os[row][8 + jj], po = Os[row][12 + jj];
-        if (p.gin) {
-            const float* g = p.gin + (long long)gr * p.ld_gin;
-            pi += g[j];
-            pf += g[H + j];
-            pg += g[2 * H + j];
-            po += g[3 * H + j];
-        }
-        if (p.bias) {
-            pi += p.bias[j];
-            pf += p.bias[H + j];
-            pg += p.bias[2 * H + j];
-            po += p.bias[3 * H + j];
-        }
+    if (e_valid) {
+        const float pi = Os[erow * 17 + ejj] + e_gin[0] + e_bias[0];
+        const float pf = Os[erow * 17 + 4 + ejj] + e_gin[1] + e_bias[1];
+        const float pg = Os[erow * 17 + 8 + ejj] + e_gin[2] + e_bias[2];
+        const float po = Os[erow * 17 + 12 + ejj] + e_gin[3] + e_bias[3];
         gi = t2_sigmoid(pi);
         gf = t2_sigmoid(pf);
         gg = tanhf(pg);
         go = t2_sigmoid(po);
-        const float cp = p.c_prev ? p.c_prev[(long long)gr * p.ld_cprev + j] : 0.f;
-        cn = gf * cp + gi * gg;
+        cn = gf * e_cp + gi * gg;
         hn = go * tanhf(cn);
-        if (p.keep) hn = p.keep[(long long)gr * p.ld_keep + j] ? hn * p.keep_scale : 0.f;
+        if (p.keep) hn = e_keep ? hn * p.keep_scale : 0.f;
     }
-    float* go_ = p.gates_out + (long long)gr * p.ld_gates;
-    go_[j] = gi;
-    go_[H + j] = gf;
-    go_[2 * H + j] = gg;
-    go_[3 * H + j] = go;
-    p.c_out[(long long)gr * p.ld_c + j] = cn;
-    p.h_out[(long long)gr * p.ld_h + j] = hn;
+    float* go_ = p.gates_out + (long long)egr * p.ld_gates;
+    go_[ej] = gi;
+    go_[H + ej] = gf;
+    go_[2 * H + ej] = gg;
+    go_[3 * H + ej] = go;
+    p.c_out[(long long)egr * p.ld_c + ej] = cn;
+    p.h_out[(long long)egr * p.ld_h + ej] = hn;
 }
 
 static int check_segs(const t2amd_seg* x, int nseg, int Ktot) {
@@ -210,13 +312,13 @@ static int check_segs(const t2amd_seg* x, int nseg, int Ktot) {
     return T2AMD_OK;
 }
 
-extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
+static int fill_lstm(const t2amd_lstm_step* a, SkinnyParams& p) {
     T2_REQUIRE(a != nullptr, "lstm_step: null args");
     T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot));
     T2_REQUIRE(a->W && t2_aligned16(a->W), "lstm_step: W must be 16-byte aligned");
     T2_REQUIRE(a->H > 0 && a->H % 4 == 0 && a->B > 0, "lstm_step: H must be a multiple of 4");
     T2_REQUIRE(a->gates_out && a->c_out && a->h_out, "lstm_step: null outputs");
-    SkinnyParams p = {};
+    p = SkinnyParams{};
     for (int i = 0; i < 3; ++i) p.x[i] = a->x[i];
     p.nseg = a->nseg;
     p.W = a->W; p.Ktot = a->Ktot; p.B = a->B; p.H = a->H; p.N = 4 * a->H;
@@ -226,43 +328,83 @@ extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
     p.c_out = a->c_out; p.ld_c = a->ld_c; p.h_out = a->h_out; p.ld_h = a->ld_h;
     p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     p.lens = a->lens; p.t = a->t;
-    dim3 grid(a->H / 4, t2_cdiv(a->B, SK_ROWS), 1);
+    p.gx = a->H / 4; p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = 1;
+    return T2AMD_OK;
+}
+
+// One launch for one or two independent LSTM steps (b may be NULL).  The kernel symbol / profiling
+// role is a's tag.
+extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_lstm_step* b, void* stream) {
+    SkinnyDual d;
+    T2_PROPAGATE(fill_lstm(a, d.p[0]));
+    d.nblk0 = d.p[0].gx * d.p[0].gy;
+    int total = d.nblk0;
+    if (b) {
+        T2_PROPAGATE(fill_lstm(b, d.p[1]));
+        total += d.p[1].gx * d.p[1].gy;
+    } else {
+        d.p[1] = d.p[0];
+    }
     hipStream_t s = (hipStream_t)stream;
     t2amd_profile_mark_(a->tag, 0, s);
-    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1>), grid, dim3(256), 0, s, p);
-    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2>), grid, dim3(256), 0, s, p);
-    else T2_LAUNCH((skinny_gemm_kernel<true, 0>), grid, dim3(256), 0, s, p);
+    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1>), dim3(total), dim3(256), 0, s, d);
+    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2>), dim3(total), dim3(256), 0, s, d);
+    else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<true, 3>), dim3(total), dim3(256), 0, s, d);
+    else T2_LAUNCH((skinny_gemm_kernel<true, 0>), dim3(total), dim3(256), 0, s, d);
     t2amd_profile_mark_(a->tag, 1, s);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
 
-extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
+extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
+    return t2amd_lstm_step_fwd2_f32(a, nullptr, stream);
+}
+
+static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     T2_REQUIRE(a != nullptr, "skinny_gemm: null args");
     T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot));
     T2_REQUIRE(a->W && t2_aligned16(a->W) && a->Y, "skinny_gemm: bad pointers");
     T2_REQUIRE(a->N > 0 && a->B > 0 && a->nsplit >= 1, "skinny_gemm: bad dims");
-    SkinnyParams p = {};
+    p = SkinnyParams{};
     for (int i = 0; i < 3; ++i) p.x[i] = a->x[i];
     p.nseg = a->nseg;
     p.W = a->W; p.Ktot = a->Ktot; p.B = a->B; p.N = a->N; p.H = 0;
     p.Y = a->Y; p.ldy = a->ldy; p.nsplit = a->nsplit; p.split_stride = a->split_stride;
     const int ktiles = a->Ktot / SK_BK;
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
-    dim3 grid(t2_cdiv(a->N, 16), t2_cdiv(a->B, SK_ROWS), a->nsplit);
+    p.gx = t2_cdiv(a->N, 16); p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = a->nsplit;
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_skinny_gemm2_f32(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, void* stream) {
+    SkinnyDual d;
+    T2_PROPAGATE(fill_plain(a, d.p[0]));
+    d.nblk0 = d.p[0].gx * d.p[0].gy * d.p[0].gz;
+    int total = d.nblk0;
+    if (b) {
+        T2_PROPAGATE(fill_plain(b, d.p[1]));
+        total += d.p[1].gx * d.p[1].gy * d.p[1].gz;
+    } else {
+        d.p[1] = d.p[0];
+    }
     hipStream_t s = (hipStream_t)stream;
-    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1>), grid, dim3(256), 0, s, p);
-    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2>), grid, dim3(256), 0, s, p);
-    else T2_LAUNCH((skinny_gemm_kernel<false, 0>), grid, dim3(256), 0, s, p);
+    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1>), dim3(total), dim3(256), 0, s, d);
+    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2>), dim3(total), dim3(256), 0, s, d);
+    else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<false, 3>), dim3(total), dim3(256), 0, s, d);
+    else T2_LAUNCH((skinny_gemm_kernel<false, 0>), dim3(total), dim3(256), 0, s, d);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
+}
+
+extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
+    return t2amd_skinny_gemm2_f32(a, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------
 // LSTM cell backward (pointwise part): given dL/dh' (dropped-out hidden) and the carried
 // dL/dc, produce the gate pre-activation gradients and the new dL/dc carry.
 // ---------------------------------------------------------------------------------------
-struct LstmBwdParams { t2amd_lstm_bwd a; };
+struct LstmBwdParams { t2amd_lstm_bwd a[2]; int nblk0; };
 
 __device__ __forceinline__ float addend_sum(const t2amd_addend& ad, int row, int col) {
     if (!ad.p) return 0.f;
@@ -272,51 +414,72 @@ __device__ __forceinline__ float addend_sum(const t2amd_addend& ad, int row, int
     return s;
 }
 
-__global__ void lstm_pointwise_bwd_kernel(LstmBwdParams p) {
-    const t2amd_lstm_bwd& a = p.a;
+// one thread per (row, unit); blocks [0, nblk0) serve a[0], the rest a[1]
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p) {
+    const bool second = (int)blockIdx.x >= p.nblk0;
+    const t2amd_lstm_bwd& a = second ? p.a[1] : p.a[0];
+    const int lb = (int)blockIdx.x - (second ? p.nblk0 : 0);
     const int H = a.H;
     const long long n = (long long)a.B * H;
-    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / H);
-        const int j = (int)(idx - (long long)b * H);
-        float* dg = a.dgates + (long long)b * a.ld_dgates;
-        float* dcp = a.dc + (long long)b * a.ld_dc + j;
-        bool valid = true;
-        if (a.lens) valid = a.t < a.lens[b];
-        if (!valid) {
-            dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
-            *dcp = 0.f;
-            continue;
-        }
-        float dh = addend_sum(a.dh[0], b, j) + addend_sum(a.dh[1], b, j) + addend_sum(a.dh[2], b, j);
-        if (a.keep) dh = a.keep[(long long)b * a.ld_keep + j] ? dh * a.keep_scale : 0.f;
-        const float* g = a.gates + (long long)b * a.ld_gates;
-        const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
-        const float c = a.c[(long long)b * a.ld_c + j];
-        const float cprev = a.c_prev ? a.c_prev[(long long)b * a.ld_cprev + j] : 0.f;
-        const float tc = tanhf(c);
-        const float d_o = dh * tc;
-        const float dc = *dcp + dh * go * (1.f - tc * tc);
-        dg[j] = dc * gg * gi * (1.f - gi);
-        dg[H + j] = dc * cprev * gf * (1.f - gf);
-        dg[2 * H + j] = dc * gi * (1.f - gg * gg);
-        dg[3 * H + j] = d_o * go * (1.f - go);
-        *dcp = dc * gf;
+    const long long idx = (long long)lb * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int b = (int)(idx / H);
+    const int j = (int)(idx - (long long)b * H);
+    float* dg = a.dgates + (long long)b * a.ld_dgates;
+    float* dcp = a.dc + (long long)b * a.ld_dc + j;
+    bool valid = true;
+    if (a.lens) valid = a.t < a.lens[b];
+    if (!valid) {
+        dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
+        *dcp = 0.f;
+        return;
     }
+    // issue every independent load before the first use
+    const float* g = a.gates + (long long)b * a.ld_gates;
+    const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
+    const float c = a.c[(long long)b * a.ld_c + j];
+    const float cprev = a.c_prev ? a.c_prev[(long long)b * a.ld_cprev + j] : 0.f;
+    const float dc_in = *dcp;
+    const bool kp = a.keep ? a.keep[(long long)b * a.ld_keep + j] != 0 : true;
+    float dh = addend_sum(a.dh[0], b, j) + addend_sum(a.dh[1], b, j) + addend_sum(a.dh[2], b, j);
+    if (a.keep) dh = kp ? dh * a.keep_scale : 0.f;
+    const float tc = tanhf(c);
+    const float d_o = dh * tc;
+    const float dc = dc_in + dh * go * (1.f - tc * tc);
+    dg[j] = dc * gg * gi * (1.f - gi);
+    dg[H + j] = dc * cprev * gf * (1.f - gf);
+    dg[2 * H + j] = dc * gi * (1.f - gg * gg);
+    dg[3 * H + j] = d_o * go * (1.f - go);
+    *dcp = dc * gf;
+}
+
+static int check_lstm_bwd(const t2amd_lstm_bwd* a) {
+    T2_REQUIRE(a && a->gates && a->c && a->dc && a->dgates, "lstm_bwd: null args");
+    T2_REQUIRE(a->B > 0 && a->H > 0, "lstm_bwd: bad dims");
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_lstm_pointwise_bwd2_f32(const t2amd_lstm_bwd* a, const t2amd_lstm_bwd* b, void* stream) {
+    T2_PROPAGATE(check_lstm_bwd(a));
+    LstmBwdParams p;
+    p.a[0] = *a;
+    p.nblk0 = t2_cdiv((long long)a->B * a->H, 256);
+    int total = p.nblk0;
+    if (b) {
+        T2_PROPAGATE(check_lstm_bwd(b));
+        p.a[1] = *b;
+        total += t2_cdiv((long long)b->B * b->H, 256);
+    } else {
+        p.a[1] = *a;
+    }
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < 3; ++i)
+            if (p.a[k].dh[i].p && p.a[k].dh[i].nsplit < 1) p.a[k].dh[i].nsplit = 1;
+    T2_LAUNCH(lstm_pointwise_bwd_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, p);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
 }
 
 extern "C" int t2amd_lstm_pointwise_bwd_f32(const t2amd_lstm_bwd* a, void* stream) {
-    T2_REQUIRE(a && a->gates && a->c && a->dc && a->dgates, "lstm_bwd: null args");
-    T2_REQUIRE(a->B > 0 && a->H > 0, "lstm_bwd: bad dims");
-    LstmBwdParams p;
-    p.a = *a;
-    for (int i = 0; i < 3; ++i)
-        if (p.a.dh[i].p && p.a.dh[i].nsplit < 1) p.a.dh[i].nsplit = 1;
-    const long long n = (long long)a->B * a->H;
-    int blocks = t2_cdiv(n, 256);
-    if (blocks > 2048) blocks = 2048;
-    T2_LAUNCH(lstm_pointwise_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-    T2_LAUNCH_CHECK();
-    return T2AMD_OK;
+    return t2amd_lstm_pointwise_bwd2_f32(a, nullptr, stream);
 }

@@ -446,7 +446,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     nv.transpose(Wa_recT, T['Wa_rec'])
     Wd_catT = run.empty(Ha + E + Hd, 4 * Hd)
     nv.transpose(Wd_catT, T['Wd_cat'])
-    ns = 4
+    ns = 2
     bw = nv.DecTrainBwd()
     bw.f = c.dec
     bw.Wa_recT, bw.Wd_catT = nv.ptr(Wa_recT), nv.ptr(Wd_catT)

@@ -190,6 +190,7 @@ SYMBOLS = [
     "t2amd_split_projection_f32", "t2amd_finalize_outputs_f32", "t2amd_grads_to_channel_last_f32",
     "t2amd_gather_dout_f32", "t2amd_relu_dropout_bwd_f32",
     "t2amd_lstm_step_fwd_f32", "t2amd_skinny_gemm_f32", "t2amd_lstm_pointwise_bwd_f32",
+    "t2amd_lstm_step_fwd2_f32", "t2amd_skinny_gemm2_f32", "t2amd_lstm_pointwise_bwd2_f32",
     "t2amd_fold_location_f32", "t2amd_unfold_location_grads_f32",
     "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
@@ -224,6 +225,9 @@ def _argtypes():
         "t2amd_lstm_step_fwd_f32": [pt(LstmStep), _P],
         "t2amd_skinny_gemm_f32": [pt(SkinnyGemm), _P],
         "t2amd_lstm_pointwise_bwd_f32": [pt(LstmBwd), _P],
+        "t2amd_lstm_step_fwd2_f32": [pt(LstmStep), pt(LstmStep), _P],
+        "t2amd_skinny_gemm2_f32": [pt(SkinnyGemm), pt(SkinnyGemm), _P],
+        "t2amd_lstm_pointwise_bwd2_f32": [pt(LstmBwd), pt(LstmBwd), _P],
         "t2amd_fold_location_f32": [_P, _P, _P, _P],
         "t2amd_unfold_location_grads_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P],
         "t2amd_attention_step_fwd_f32": [pt(AttnFwd), _P],
