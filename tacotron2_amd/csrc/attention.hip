@@ -78,7 +78,8 @@ struct AttnFwdParams { t2amd_attn_fwd a; int tip; };
 // ---------------------------------------------------------------------------------------
 // K_e: partial energies over 32 attention dims
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_energy_kernel(AttnFwdParams p) {
+#define KE_NT 512
+__global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const t2amd_attn_fwd& a = p.a;
     const int ds = blockIdx.x, b = blockIdx.y;
@@ -88,41 +89,59 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnFwdParams p) {
     const int Ti = a.Ti, Hq = a.Hq, TIP = p.tip;
     float* win_s = smem;             // [2][TIP]
     float* q_s = win_s + 2 * TIP;    // [32]
+    float* u_s = q_s + DSL;          // [32][62] the slice's rows of U (contiguous in HBM)
     const int len = a.lens ? a.lens[b] : Ti;
 
-    stage_windows(win_s, TIP, Ti, a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr,
-                  a.cum + (long long)b * Ti, tid, 256);
-    {   // q[d] = W_q[d][:] . h   for the slice's 32 dims: 8 threads per row, 128 contiguous bytes per group
-        const int d = tid >> 3, part = tid & 7;
+    // q[d] = W_q[d][:] . h for the slice's 32 dims: 16 threads per row, 256 contiguous bytes per group
+    // and instruction; all loads are issued before the first use.
+    float qacc = 0.f;
+    {
+        const int d = tid >> 4, part = tid & 15;
         const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq + (long long)(ds * DSL + d) * Hq);
         const float4* __restrict__ h4 = reinterpret_cast<const float4*>(a.h + (long long)b * a.ld_h);
-        float acc = 0.f;
         const int n4 = Hq >> 2;
-#pragma unroll 4
-        for (int i = part; i < n4; i += 8) {
-            const float4 w = W4[i];
-            const float4 x = h4[i];
-            acc = fmaf(w.x, x.x, acc);
-            acc = fmaf(w.y, x.y, acc);
-            acc = fmaf(w.z, x.z, acc);
-            acc = fmaf(w.w, x.w, acc);
-        }
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if (part == 0) {
-            q_s[d] = acc;
-            if (a.q_out) a.q_out[(long long)b * a.ld_q + ds * DSL + d] = acc;
+        for (int i0 = part; i0 < n4; i0 += 16 * 8) {
+            float4 w[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 16 * u;
+                const int ic = i < n4 ? i : part;
+                w[u] = W4[ic];
+                x[u] = h4[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + 16 * u < n4) {
+                    qacc = fmaf(w[u].x, x[u].x, qacc);
+                    qacc = fmaf(w[u].y, x[u].y, qacc);
+                    qacc = fmaf(w[u].z, x[u].z, qacc);
+                    qacc = fmaf(w[u].w, x[u].w, qacc);
+                }
+            }
         }
     }
-    float ua[2][16];
-    load_u_frag(ua, a.U, ds * DSL, l15, lg);
+    stage_windows(win_s, TIP, Ti, a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr,
+                  a.cum + (long long)b * Ti, tid, KE_NT);
+    for (int i = tid; i < DSL * NTAP; i += KE_NT) u_s[i] = a.U[(long long)ds * DSL * NTAP + i];
+    {
+        const int d = tid >> 4, part = tid & 15;
+        qacc += __shfl_xor(qacc, 1, 64);
+        qacc += __shfl_xor(qacc, 2, 64);
+        qacc += __shfl_xor(qacc, 4, 64);
+        qacc += __shfl_xor(qacc, 8, 64);
+        if (part == 0) {
+            q_s[d] = qacc;
+            if (a.q_out) a.q_out[(long long)b * a.ld_q + ds * DSL + d] = qacc;
+        }
+    }
     float vv[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) vv[dt][r] = a.v[ds * DSL + dt * 16 + 4 * lg + r];
     __syncthreads();
+    float ua[2][16];
+    load_u_frag(ua, u_s, 0, l15, lg);
     float qv[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -132,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnFwdParams p) {
     float* __restrict__ eout = a.ws + ((long long)ds * a.B + b) * Ti;
     const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + ds * DSL + 4 * lg;
     const int nmt = (len + 15) >> 4;
-    for (int mt = wv; mt < nmt; mt += 4) {
+    for (int mt = wv; mt < nmt; mt += KE_NT / 64) {
         const int pos = mt * 16 + l15;
         float4 pm0 = make_float4(0.f, 0.f, 0.f, 0.f), pm1 = pm0;
         if (pos < Ti) {
@@ -158,7 +177,9 @@ __global__ __launch_bounds__(256) void attn_energy_kernel(AttnFwdParams p) {
 // ---------------------------------------------------------------------------------------
 // K_c: softmax over the utterance + one quarter of the context channels
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_context_kernel(AttnFwdParams p) {
+#define KC_NT 512
+#define KC_MAXR 12      // memory rows a thread keeps in registers; longer utterances take extra passes
+__global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const t2amd_attn_fwd& a = p.a;
     const int cs = blockIdx.x, b = blockIdx.y;
@@ -166,14 +187,29 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnFwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Ti = a.Ti, E = a.E, B = a.B;
     float* w_s = smem;                    // [Ti rounded to 4]
-    float* red_s = w_s + ((Ti + 3) & ~3); // [8]
-    float* part_s = red_s + 8;            // [parts][EC]
+    float* red_s = w_s + ((Ti + 3) & ~3); // [16]
+    float* part_s = red_s + 16;           // [parts][EC]
     const int len = a.lens ? a.lens[b] : Ti;
+
+    // The context rows do not depend on the softmax: fetch this thread's share of memory[b] first so
+    // that the HBM/L2 latency overlaps the three dependent reductions below.
+    const int EC = E / NSL, EC4 = EC >> 2, E4 = E >> 2;
+    int parts = KC_NT / EC4;
+    if (parts > 32) parts = 32;
+    const int c4 = tid % EC4, part = tid / EC4;
+    const bool worker = part < parts;
+    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4 + cs * EC4 + c4;
+    float4 mrow[KC_MAXR];
+#pragma unroll
+    for (int i = 0; i < KC_MAXR; ++i) {
+        const int ti = part + i * parts;
+        mrow[i] = (worker && ti < len) ? M4[(long long)ti * E4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     const float* __restrict__ e0 = a.ws + (long long)b * Ti;
     const long long es = (long long)B * Ti;
     float lmax = -INFINITY;
-    for (int ti = tid; ti < Ti; ti += 256) {
+    for (int ti = tid; ti < Ti; ti += KC_NT) {
         float e = -INFINITY;
         if (ti < len) e = ((e0[ti] + e0[es + ti]) + e0[2 * es + ti]) + e0[3 * es + ti];
         w_s[ti] = e;
@@ -182,22 +218,27 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnFwdParams p) {
     lmax = wave_reduce_max(lmax);
     if (lane == 0) red_s[wv] = lmax;
     __syncthreads();
-    const float gmax = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+    float gmax = red_s[0];
+#pragma unroll
+    for (int i = 1; i < KC_NT / 64; ++i) gmax = fmaxf(gmax, red_s[i]);
     float lsum = 0.f;
-    for (int ti = tid; ti < Ti; ti += 256) {
+    for (int ti = tid; ti < Ti; ti += KC_NT) {
         const float ex = (ti < len) ? expf(w_s[ti] - gmax) : 0.f;
         w_s[ti] = ex;
         lsum += ex;
     }
     lsum = wave_reduce_sum(lsum);
-    if (lane == 0) red_s[4 + wv] = lsum;
+    if (lane == 0) red_s[8 + wv] = lsum;
     __syncthreads();
-    const float inv = 1.0f / (((red_s[4] + red_s[5]) + red_s[6]) + red_s[7]);
+    float gsum = red_s[8];
+#pragma unroll
+    for (int i = 1; i < KC_NT / 64; ++i) gsum += red_s[8 + i];
+    const float inv = 1.0f / gsum;
     {
         float* wout = a.w_out + (long long)b * a.ld_wout;
         float* cum = a.cum + (long long)b * Ti;
         float* csave = a.cum_save ? a.cum_save + (long long)b * Ti : nullptr;
-        for (int ti = tid; ti < Ti; ti += 256) {
+        for (int ti = tid; ti < Ti; ti += KC_NT) {
             const float w = w_s[ti] * inv;
             w_s[ti] = w;
             if (cs == 0) {
@@ -210,26 +251,16 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnFwdParams p) {
     }
     __syncthreads();
     // context channels [cs*EC, (cs+1)*EC)
-    const int EC = E / NSL, EC4 = EC >> 2, E4 = E >> 2;
-    int parts = 256 / EC4;
-    if (parts > 16) parts = 16;
-    const int c4 = tid % EC4, part = tid / EC4;
-    if (part < parts) {
-        const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4 + cs * EC4 + c4;
+    if (worker) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int ti = part;
-        for (; ti + 3 * parts < len; ti += 4 * parts) {
-            const float4 m0 = M4[(long long)ti * E4];
-            const float4 m1 = M4[(long long)(ti + parts) * E4];
-            const float4 m2 = M4[(long long)(ti + 2 * parts) * E4];
-            const float4 m3 = M4[(long long)(ti + 3 * parts) * E4];
-            const float w0 = w_s[ti], w1 = w_s[ti + parts], w2 = w_s[ti + 2 * parts], w3 = w_s[ti + 3 * parts];
-            acc.x = fmaf(w0, m0.x, acc.x); acc.y = fmaf(w0, m0.y, acc.y); acc.z = fmaf(w0, m0.z, acc.z); acc.w = fmaf(w0, m0.w, acc.w);
-            acc.x = fmaf(w1, m1.x, acc.x); acc.y = fmaf(w1, m1.y, acc.y); acc.z = fmaf(w1, m1.z, acc.z); acc.w = fmaf(w1, m1.w, acc.w);
-            acc.x = fmaf(w2, m2.x, acc.x); acc.y = fmaf(w2, m2.y, acc.y); acc.z = fmaf(w2, m2.z, acc.z); acc.w = fmaf(w2, m2.w, acc.w);
-            acc.x = fmaf(w3, m3.x, acc.x); acc.y = fmaf(w3, m3.y, acc.y); acc.z = fmaf(w3, m3.z, acc.z); acc.w = fmaf(w3, m3.w, acc.w);
+#pragma unroll
+        for (int i = 0; i < KC_MAXR; ++i) {
+            const int ti = part + i * parts;
+            const float w = ti < len ? w_s[ti] : 0.f;
+            acc.x = fmaf(w, mrow[i].x, acc.x); acc.y = fmaf(w, mrow[i].y, acc.y);
+            acc.z = fmaf(w, mrow[i].z, acc.z); acc.w = fmaf(w, mrow[i].w, acc.w);
         }
-        for (; ti < len; ti += parts) {
+        for (int ti = part + KC_MAXR * parts; ti < len; ti += parts) {      // utterances longer than MAXR*parts
             const float4 m = M4[(long long)ti * E4];
             const float w = w_s[ti];
             acc.x = fmaf(w, m.x, acc.x); acc.y = fmaf(w, m.y, acc.y); acc.z = fmaf(w, m.z, acc.z); acc.w = fmaf(w, m.w, acc.w);
@@ -237,7 +268,7 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnFwdParams p) {
         *reinterpret_cast<float4*>(&part_s[part * EC + c4 * 4]) = acc;
     }
     __syncthreads();
-    for (int c = tid; c < EC; c += 256) {
+    for (int c = tid; c < EC; c += KC_NT) {
         float s = 0.f;
         for (int q = 0; q < parts; ++q) s += part_s[q * EC + c];
         a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c] = s;
@@ -257,14 +288,15 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     p.a = *a;
     p.tip = attn_tip(a->Ti);
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL);
+    const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP);
     const int EC = a->E / NSL;
-    int parts = 256 / (EC / 4);
-    if (parts > 16) parts = 16;
-    const size_t lds_c = sizeof(float) * ((size_t)((a->Ti + 3) & ~3) + 8 + (size_t)parts * EC);
+    int parts = KC_NT / (EC / 4);
+    if (parts > 32) parts = 32;
+    T2_REQUIRE(parts >= 1, "attn_fwd: E too large");
+    const size_t lds_c = sizeof(float) * ((size_t)((a->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
     T2_REQUIRE(lds_e <= 64 * 1024 && lds_c <= 64 * 1024, "attn_fwd: Ti too large for the LDS windows");
-    T2_LAUNCH(attn_energy_kernel, dim3(NSL, a->B), dim3(256), lds_e, s, p);
-    T2_LAUNCH(attn_context_kernel, dim3(NSL, a->B), dim3(256), lds_c, s, p);
+    T2_LAUNCH(attn_energy_kernel, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    T2_LAUNCH(attn_context_kernel, dim3(NSL, a->B), dim3(KC_NT), lds_c, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -274,16 +306,25 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // =========================================================================================
 struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; };
 
-// K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions
+// K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
+// Half a wave (32 lanes) per memory row, 8 rows per pass, every load of a pass issued before its first use.
+#define KB1_MAXP 8      // passes kept in registers: 8 rows x 8 passes = 64 positions per slice (Ti <= 256)
 __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const t2amd_attn_bwd& a = p.a;
     const int ts = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Ti = a.Ti, E = a.E, B = a.B;
-    float* dctx_s = smem;          // [E]
-    float* red_s = dctx_s + E;     // [4]
+    const int tsz = (Ti + NSL - 1) / NSL;
+    float* dctx_s = smem;            // [E]
+    float* base_s = dctx_s + E;      // [tsz] carries + running dcum (+ extra) per position of the slice
+    float* wl_s = base_s + tsz;      // [tsz] this step's weights
+    float* red_s = wl_s + tsz;       // [8]
     const int len = a.lens ? a.lens[b] : Ti;
+    const int t0 = ts * tsz;
+    int t1 = t0 + tsz;
+    if (t1 > Ti) t1 = Ti;
+
     for (int c = tid; c < E; c += 256) {
         float s = 0.f;
 #pragma unroll
@@ -297,52 +338,79 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         dctx_s[c] = s;
         if (ts == 0) a.dctx_total[(long long)b * a.ld_dctx_total + c] = s;
     }
-    __syncthreads();
-    const int tsz = (Ti + NSL - 1) / NSL;
-    const int t0 = ts * tsz;
-    int t1 = t0 + tsz;
-    if (t1 > Ti) t1 = Ti;
-    const int E4 = E >> 2;
-    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4;
-    const float* __restrict__ wrow = a.w + (long long)b * a.ld_w;
-    const float* __restrict__ dwx = a.d_w_extra ? a.d_w_extra + (long long)b * a.ld_dwextra : nullptr;
-    const long long ps = (long long)B * 2 * Ti;                 // stride between dim-slice partials
-    const float* __restrict__ cw = a.dwin_part + ((long long)b * 2 + 0) * Ti;
-    const float* __restrict__ cc = a.dwin_part + ((long long)b * 2 + 1) * Ti;
-    float* __restrict__ dcum = a.dcum_acc + (long long)b * Ti;
-    float* __restrict__ dwo = a.ws + (long long)b * Ti;
-    float psum = 0.f;
-    for (int ti = t0 + wv; ti < t1; ti += 4) {
-        float s = 0.f;
-        if (ti < len) {
-            for (int c4 = lane; c4 < E4; c4 += 64) {
-                const float4 m = M4[(long long)ti * E4 + c4];
-                const float4 g = *reinterpret_cast<const float4*>(&dctx_s[c4 * 4]);
-                s = fmaf(m.x, g.x, s);
-                s = fmaf(m.y, g.y, s);
-                s = fmaf(m.z, g.z, s);
-                s = fmaf(m.w, g.w, s);
+    {   // carries: one thread per position of the slice
+        const long long ps = (long long)B * 2 * Ti;                 // stride between dim-slice partials
+        const float* __restrict__ cw = a.dwin_part + ((long long)b * 2 + 0) * Ti;
+        const float* __restrict__ cc = a.dwin_part + ((long long)b * 2 + 1) * Ti;
+        float* __restrict__ dcum = a.dcum_acc + (long long)b * Ti;
+        for (int i = tid; i < tsz; i += 256) {
+            const int ti = t0 + i;
+            float base = 0.f, w = 0.f;
+            if (ti < t1) {
+                const float carry_w = ((cw[ti] + cw[ps + ti]) + cw[2 * ps + ti]) + cw[3 * ps + ti];
+                const float carry_c = ((cc[ti] + cc[ps + ti]) + cc[2 * ps + ti]) + cc[3 * ps + ti];
+                const float dc = dcum[ti] + carry_c;
+                dcum[ti] = dc;
+                base = carry_w + dc;
+                if (a.d_w_extra) base += a.d_w_extra[(long long)b * a.ld_dwextra + ti];
+                w = a.w[(long long)b * a.ld_w + ti];
             }
-            s = wave_reduce_sum(s);
-        }
-        if (lane == 0) {
-            const float carry_w = ((cw[ti] + cw[ps + ti]) + cw[2 * ps + ti]) + cw[3 * ps + ti];
-            const float carry_c = ((cc[ti] + cc[ps + ti]) + cc[2 * ps + ti]) + cc[3 * ps + ti];
-            const float dc = dcum[ti] + carry_c;
-            dcum[ti] = dc;
-            float dw = s + carry_w + dc;
-            if (dwx) dw += dwx[ti];
-            dwo[ti] = dw;
-            psum = fmaf(wrow[ti], dw, psum);
+            base_s[i] = base;
+            wl_s[i] = w;
         }
     }
+    __syncthreads();
+    const int E4 = E >> 2;
+    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4;
+    float* __restrict__ dwo = a.ws + (long long)b * Ti;
+    const int grp = tid >> 5, l32 = tid & 31;      // 8 row groups of 32 lanes
+    float psum = 0.f;
+    for (int r0 = 0; r0 < tsz; r0 += 8 * KB1_MAXP) {
+        float acc[KB1_MAXP];
+#pragma unroll
+        for (int i = 0; i < KB1_MAXP; ++i) acc[i] = 0.f;
+        for (int c4 = l32; c4 < E4; c4 += 32) {
+            const float4 g = *reinterpret_cast<const float4*>(&dctx_s[c4 * 4]);
+            float4 m[KB1_MAXP];
+#pragma unroll
+            for (int i = 0; i < KB1_MAXP; ++i) {
+                const int ti = t0 + r0 + grp + 8 * i;
+                const int tc = (ti < t1 && ti < len) ? ti : 0;        // clamped: loaded, then ignored
+                m[i] = M4[(long long)tc * E4 + c4];
+            }
+#pragma unroll
+            for (int i = 0; i < KB1_MAXP; ++i) {
+                acc[i] = fmaf(m[i].x, g.x, acc[i]);
+                acc[i] = fmaf(m[i].y, g.y, acc[i]);
+                acc[i] = fmaf(m[i].z, g.z, acc[i]);
+                acc[i] = fmaf(m[i].w, g.w, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KB1_MAXP; ++i) {
+            float s = acc[i];
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
+            const int li = r0 + grp + 8 * i;
+            const int ti = t0 + li;
+            if (l32 == 0 && ti < t1) {
+                const float dw = ((ti < len) ? s : 0.f) + base_s[li];
+                dwo[ti] = dw;
+                psum = fmaf(wl_s[li], dw, psum);
+            }
+        }
+    }
+    // psum lives in lanes 0 and 32 of every wave
+    psum += __shfl_xor(psum, 32, 64);
     if (lane == 0) red_s[wv] = psum;
     __syncthreads();
     if (tid == 0) a.ws[(long long)B * Ti + (long long)ts * B + b] = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
 }
 
-// K_b2: everything that lives in attention-dim space, for 32 dims
-__global__ __launch_bounds__(256) void attn_bwd_main_kernel(AttnBwdParams p) {
+// K_b2: everything that lives in attention-dim space, for 32 dims (8 waves)
+#define KB2_NT 512
+#define KB2_NW (KB2_NT / 64)
+__global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const t2amd_attn_bwd& a = p.a;
     const int ds = blockIdx.x, b = blockIdx.y;
@@ -353,36 +421,25 @@ __global__ __launch_bounds__(256) void attn_bwd_main_kernel(AttnBwdParams p) {
     float* de_s = win_s + 2 * TIP;            // [NP]
     float* dcol_s = de_s + NP;                // [NP][DCL]
     float* dpre_s = dcol_s + (size_t)NP * DCL;  // [NP][DPL]
-    float* red_s = dpre_s + (size_t)NP * DPL;   // [4 waves][2][32]
-    float* dq_s = red_s + 4 * 2 * DSL;        // [32]
+    float* red_s = dpre_s + (size_t)NP * DPL;   // [NW][2][32]
+    float* dq_s = red_s + KB2_NW * 2 * DSL;   // [32]
+    float* u_s = dq_s + DSL;                  // [32][62]
+    float* dh_s = u_s + DSL * NTAP;           // [Hq] second-half partial of dh
     const int len = a.lens ? a.lens[b] : Ti;
     const int nmt = (len + 15) >> 4;
     const int npos = nmt * 16;                // positions covered by the MFMA tiles
+    const int dbase = ds * DSL;
 
     {
         const float* sd = a.ws + (long long)B * Ti;
         const float sdot = ((sd[b] + sd[B + b]) + sd[2 * B + b]) + sd[3 * B + b];
         const float* __restrict__ wrow = a.w + (long long)b * a.ld_w;
         const float* __restrict__ dwi = a.ws + (long long)b * Ti;
-        for (int ti = tid; ti < NP; ti += 256) de_s[ti] = (ti < len) ? wrow[ti] * (dwi[ti] - sdot) : 0.f;
+        for (int ti = tid; ti < NP; ti += KB2_NT) de_s[ti] = (ti < len) ? wrow[ti] * (dwi[ti] - sdot) : 0.f;
     }
     stage_windows(win_s, TIP, Ti, a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr,
-                  a.cum_before + (long long)b * Ti, tid, 256);
-
-    const int dbase = ds * DSL;
-    float ua[2][16];
-    load_u_frag(ua, a.U, dbase, l15, lg);
-    // U^T as the A operand of dcol^T = U^T dpre: A[i = tap][k = lg], k-step (dt, r) <-> dim dt*16 + 4*lg + r
-    float ut[4][2][4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tap = tt * 16 + l15;
-                ut[tt][dt][r] = tap < NTAP ? a.U[(long long)(dbase + dt * 16 + 4 * lg + r) * NTAP + tap] : 0.f;
-            }
+                  a.cum_before + (long long)b * Ti, tid, KB2_NT);
+    for (int i = tid; i < DSL * NTAP; i += KB2_NT) u_s[i] = a.U[(long long)dbase * NTAP + i];
     float vv[2][4], qv[2][4], dva[2][4], dqa[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -395,15 +452,32 @@ __global__ __launch_bounds__(256) void attn_bwd_main_kernel(AttnBwdParams p) {
             dqa[dt][r] = 0.f;
         }
     __syncthreads();
+    float ua[2][16];
+    load_u_frag(ua, u_s, 0, l15, lg);
+    // U^T as the A operand of dcol^T = U^T dpre: A[i = tap][k = lg], k-step (dt, r) <-> dim dt*16 + 4*lg + r
+    float ut[4][2][4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tap = tt * 16 + l15;
+                ut[tt][dt][r] = tap < NTAP ? u_s[(dt * 16 + 4 * lg + r) * NTAP + tap] : 0.f;
+            }
 
     const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + dbase + 4 * lg;
     float* __restrict__ dpmb = a.d_pm + (long long)b * Ti * AD + dbase + 4 * lg;
-    for (int mt = wv; mt < nmt; mt += 4) {
+    for (int mt = wv; mt < nmt; mt += KB2_NW) {
         const int pos = mt * 16 + l15;
-        float4 pm0 = make_float4(0.f, 0.f, 0.f, 0.f), pm1 = pm0;
+        float4 pm0 = make_float4(0.f, 0.f, 0.f, 0.f), pm1 = pm0, o0 = pm0, o1 = pm0;
         if (pos < Ti) {
             pm0 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
             pm1 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+        }
+        if (pos < len) {      // d_pm read-modify-write: fetch now, add and store after the tile math
+            o0 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD);
+            o1 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16);
         }
         f32x4 acc0, acc1;
         loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
@@ -421,14 +495,6 @@ __global__ __launch_bounds__(256) void attn_bwd_main_kernel(AttnBwdParams p) {
                 dqa[dt][r] += g;
                 dp[dt][r] = g;
             }
-        if (pos < len) {
-            float4 o0 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD);
-            float4 o1 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16);
-            o0.x += dp[0][0]; o0.y += dp[0][1]; o0.z += dp[0][2]; o0.w += dp[0][3];
-            o1.x += dp[1][0]; o1.y += dp[1][1]; o1.z += dp[1][2]; o1.w += dp[1][3];
-            *reinterpret_cast<float4*>(dpmb + (long long)pos * AD) = o0;
-            *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16) = o1;
-        }
         // dcol^T[tap][pos] = sum_d U[d][tap] dpre[d][pos]: B operand = this lane's own dpre registers
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
@@ -441,6 +507,12 @@ __global__ __launch_bounds__(256) void attn_bwd_main_kernel(AttnBwdParams p) {
         }
         *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * DPL + 4 * lg]) = make_float4(dp[0][0], dp[0][1], dp[0][2], dp[0][3]);
         *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * DPL + 16 + 4 * lg]) = make_float4(dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
+        if (pos < len) {
+            o0.x += dp[0][0]; o0.y += dp[0][1]; o0.z += dp[0][2]; o0.w += dp[0][3];
+            o1.x += dp[1][0]; o1.y += dp[1][1]; o1.z += dp[1][2]; o1.w += dp[1][3];
+            *reinterpret_cast<float4*>(dpmb + (long long)pos * AD) = o0;
+            *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16) = o1;
+        }
     }
     // dv / dq: reduce over the positions held by the 16 lanes of a lane group
 #pragma unroll
@@ -460,38 +532,45 @@ __global__ __launch_bounds__(256) void attn_bwd_main_kernel(AttnBwdParams p) {
         }
     __syncthreads();
     if (tid < DSL) {
-        const float dvs = ((red_s[0 * DSL + tid] + red_s[2 * DSL + tid]) + red_s[4 * DSL + tid]) + red_s[6 * DSL + tid];
-        const float dqs = ((red_s[1 * DSL + tid] + red_s[3 * DSL + tid]) + red_s[5 * DSL + tid]) + red_s[7 * DSL + tid];
+        float dvs = 0.f, dqs = 0.f;
+#pragma unroll
+        for (int w = 0; w < KB2_NW; ++w) {
+            dvs += red_s[(w * 2 + 0) * DSL + tid];
+            dqs += red_s[(w * 2 + 1) * DSL + tid];
+        }
         a.dv_acc[(long long)b * AD + dbase + tid] += dvs;
         dq_s[tid] = dqs;
         a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
     }
-    // dU[d][tap] += sum_pos dpre[pos][d] * win[c(tap)][pos + k(tap)]   (wave w owns tap tile w)
+    // dU[d][tap] += sum_pos dpre[pos][d] * win[c(tap)][pos + k(tap)]: wave w owns (tap tile w&3, dim tile w>>2)
     {
-        const int tt = wv;
+        const int tt = wv & 3, dt = wv >> 2;
         const int tap = tt * 16 + l15;
         const int toff = tap_offset(tap, TIP);
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < npos; s += 4) {
-            const float a0 = dpre_s[(size_t)(s + lg) * DPL + l15];
-            const float a1 = dpre_s[(size_t)(s + lg) * DPL + 16 + l15];
-            const float bw = win_s[toff + s + lg];
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bw, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw, c1, 0, 0, 0);
-        }
-        if (tap < NTAP) {
-            float* dUg = a.dU_acc + ((long long)b * AD + dbase) * NTAP + tap;
+        float* dUg = a.dU_acc + ((long long)b * AD + dbase + dt * 16 + 4 * lg) * NTAP + (tap < NTAP ? tap : 0);
+        float old[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dUg[(long long)(4 * lg + r) * NTAP] += c0[r];
-                dUg[(long long)(16 + 4 * lg + r) * NTAP] += c1[r];
-            }
+        for (int r = 0; r < 4; ++r) old[r] = dUg[(long long)r * NTAP];      // fetch early
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = dpre_s + (size_t)lg * DPL + dt * 16 + l15;
+        const float* bp = win_s + toff + lg;
+        int s = 0;
+        for (; s + 8 <= npos; s += 8) {
+            const float a0 = ap[(size_t)s * DPL], a1 = ap[(size_t)(s + 4) * DPL];
+            const float b0 = bp[s], b1 = bp[s + 4];
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, c1, 0, 0, 0);
+        }
+        // npos is a multiple of 16, so no tail
+        if (tap < NTAP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dUg[(long long)r * NTAP] = old[r] + (c0[r] + c1[r]);
         }
     }
     // col2im: partial carry dwin[c][ti'] = sum_k dcol[ti' - k + 15][c*31 + k] over this slice's dims
     {
         float* __restrict__ out = a.dwin_part + (((long long)ds * B + b) * 2) * Ti;
-        for (int i = tid; i < 2 * Ti; i += 256) {
+        for (int i = tid; i < 2 * Ti; i += KB2_NT) {
             const int c = i >= Ti;
             const int tip_ = i - c * Ti;
             float s = 0.f;
@@ -504,23 +583,34 @@ __global__ __launch_bounds__(256) void attn_bwd_main_kernel(AttnBwdParams p) {
         }
     }
     __syncthreads();   // dq_s
-    // partial dh = sum_{d in slice} dq[d] * W_q[d][:]
+    // partial dh = sum_{d in slice} dq[d] * W_q[d][:]; the two halves of the block take 16 dims each
     {
         const int H4 = Hq >> 2;
-        const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)dbase * H4;
+        const int half = tid >> 8, t8 = tid & 255;
+        const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(dbase + half * 16) * H4;
         float* __restrict__ dh = a.dh_out + (long long)ds * a.dh_split_stride + (long long)b * a.ld_dh;
-        for (int k4 = tid; k4 < H4; k4 += 256) {
+        for (int k0 = 0; k0 < H4; k0 += 256) {
+            const int k4 = k0 + t8;
+            const bool ok = k4 < H4;
+            float4 w[16];
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) w[dd] = W4[(long long)dd * H4 + (ok ? k4 : 0)];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-            for (int dd = 0; dd < DSL; ++dd) {
-                const float g = dq_s[dd];
-                const float4 w = W4[(long long)dd * H4 + k4];
-                acc.x = fmaf(g, w.x, acc.x);
-                acc.y = fmaf(g, w.y, acc.y);
-                acc.z = fmaf(g, w.z, acc.z);
-                acc.w = fmaf(g, w.w, acc.w);
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const float g = dq_s[half * 16 + dd];
+                acc.x = fmaf(g, w[dd].x, acc.x);
+                acc.y = fmaf(g, w[dd].y, acc.y);
+                acc.z = fmaf(g, w[dd].z, acc.z);
+                acc.w = fmaf(g, w[dd].w, acc.w);
             }
-            *reinterpret_cast<float4*>(dh + k4 * 4) = acc;
+            if (half == 1 && ok) *reinterpret_cast<float4*>(dh_s + k4 * 4) = acc;
+            __syncthreads();
+            if (half == 0 && ok) {
+                const float4 o = *reinterpret_cast<const float4*>(dh_s + k4 * 4);
+                acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                *reinterpret_cast<float4*>(dh + k4 * 4) = acc;
+            }
         }
     }
 }
@@ -543,8 +633,9 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     p.tip = attn_tip(a->Ti);
     p.np = ((a->Ti + 15) / 16) * 16;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds1 = sizeof(float) * ((size_t)a->E + 4);
-    const size_t lds2 = sizeof(float) * (2 * (size_t)p.tip + p.np + (size_t)p.np * (DCL + DPL) + 8 * DSL + DSL);
+    const size_t lds1 = sizeof(float) * ((size_t)a->E + 2 * (size_t)((a->Ti + NSL - 1) / NSL) + 8);
+    const size_t lds2 = sizeof(float) * (2 * (size_t)p.tip + p.np + (size_t)p.np * (DCL + DPL) + KB2_NW * 2 * DSL + DSL +
+                                         DSL * NTAP + (size_t)a->Hq);
     T2_REQUIRE(lds1 <= 64 * 1024, "attn_bwd: E too large");
     T2_REQUIRE(lds2 <= 160 * 1024, "attn_bwd: Ti needs more than 160 KiB of LDS");
     if ((int)lds2 > 64 * 1024 && (int)lds2 > g_attn_bwd_lds && !t2amd_validate_only_flag_()) {
@@ -552,7 +643,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         g_attn_bwd_lds = (int)lds2;
     }
     T2_LAUNCH(attn_bwd_dw_kernel, dim3(NSL, a->B), dim3(256), lds1, s, p);
-    T2_LAUNCH(attn_bwd_main_kernel, dim3(NSL, a->B), dim3(256), lds2, s, p);
+    T2_LAUNCH(attn_bwd_main_kernel, dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
