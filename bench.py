@@ -169,10 +169,18 @@ def main():
         alg_flops = 2.0 * B * (4 * Hd * (Ha + E + Hd) + 4 * Ha * (E + Ha))
         avg_s = (ms / 1e3) / max(cnt, 1)
         achieved = alg_bytes / avg_s / 1e9
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler
+        # around itself); null if the file is absent.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                traffic = json.load(fh)["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"kernel": "skinny_gemm_kernel<true,3> (one decoder time step: decoder LSTM of step t-1 "
                               "(64x2560x4096) + attention LSTM of step t (64x1536x4096), exact-f32 MFMA + fused cells)",
                     "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": None,
+                    "frac": achieved / 8000.0, "traffic": traffic,
                     "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes,
                     "mfma_f32": {"achieved_tflops": alg_flops / avg_s / 1e12, "peak_tflops": 157.3,
                                  "frac": alg_flops / avg_s / 1e12 / 157.3}}

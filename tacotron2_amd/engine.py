@@ -78,7 +78,7 @@ class MaskSource(object):
 # ----------------------------------------------------------------------------
 def _choose_splitk(M, N, K, batch=1):
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if tiles >= 256:
+    if tiles >= 512:        # >= 2 workgroups per CU already: one's loads hide behind the other's MFMAs
         return 1
     s = (768 + tiles - 1) // tiles
     s = min(s, 64, max(1, K // 256))
