@@ -87,6 +87,10 @@ typedef struct t2amd_gemm_desc {
      *   B[(r + tap - pad)*ldb + c] if 0 <= t + tap - pad < T else 0. */
     int convA_T, convA_C, convA_pad, convA_sign;
     int convB_T, convB_C, convB_pad;
+    /* 0: exact f32 MFMA (bitwise an fmaf chain).  1: split-bf16: A = Ah+Al, B = Bh+Bl in bf16, product =
+     * Ah.Bh + Ah.Bl + Al.Bh on the bf16 MFMA with f32 accumulation (~2^-17 relative per product, 5.3x the
+     * f32 MFMA ceiling).  The engine requests 1 for gradient GEMMs only. */
+    int precision;
 } t2amd_gemm_desc;
 
 int t2amd_gemm_f32(const t2amd_gemm_desc* d, void* stream);

@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p);
+
 extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
     T2_REQUIRE(dp != nullptr, "gemm: null descriptor");
     GemmParams p;
@@ -305,11 +308,27 @@ extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
         const int ndim = d.convB_T > 0 ? d.convB_C : d.N;
         p.bvec = (ndim % 4 == 0) && (d.ldb % 4 == 0) && t2_aligned16(d.B) && (d.strideB % 4 == 0);
     }
-    const int nkt = t2_cdiv(d.K, GBK);
+    T2_REQUIRE(d.precision == 0 || d.precision == 1, "gemm: precision must be 0 (exact f32) or 1 (split-bf16 x3)");
+    // the split-bf16 kernel steps K by 32: implicit-conv channel counts must be multiples of 32
+    const bool fast = d.precision == 1 && (d.convA_T == 0 || d.convA_C % 32 == 0);
+    const int bk = fast ? 32 : GBK;
+    const int nkt = t2_cdiv(d.K, bk);
     p.ktiles_per_split = t2_cdiv(nkt > 0 ? nkt : 1, d.splitk);
     dim3 grid(t2_cdiv(d.N, GBN), t2_cdiv(d.M, GBM), d.batch * d.splitk);
     T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    if (fast) {
+        if (d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, s, p);
+        else if (d.a_kcontig && !d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, s, p);
+        else if (!d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, s, p);
+        else
+            T2_LAUNCH((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, s, p);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
     if (d.a_kcontig && d.b_kcontig)
         T2_LAUNCH((gemm_f32_kernel<true, true>), grid, dim3(256), 0, s, p);
     else if (d.a_kcontig && !d.b_kcontig)
@@ -355,4 +374,325 @@ extern "C" int t2amd_splitk_reduce_f32(const float* partials, int nsplit, long l
                        nsplit, stride, out, n, accumulate, perm_taps, perm_ci);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
+}
+
+// =========================================================================================
+// Split-bf16 GEMM ("bf16x3"): every f32 operand element x is split on its way into LDS into
+// hi = bf16(x) and lo = bf16(x - hi) (round-to-nearest-even, v_cvt_pk_bf16_f32), and the product
+// is formed as Ah.Bh + Ah.Bl + Al.Bh on v_mfma_f32_32x32x16_bf16 with f32 accumulation: three
+// matrix instructions at 16x the f32-MFMA rate = 5.3x the exact-f32 kernel's MFMA ceiling, at a
+// relative error of ~2^-17 per product (f32: 2^-24, plain bf16: 2^-9).  The engine uses it for
+// GRADIENT GEMMs only (tolerance 1e-3 of the gradient's max); every forward GEMM stays on the
+// exact-f32 kernel above so that outputs remain bit-faithful to an fmaf chain.
+//
+// Tile 128 x 128 x 32, 4 waves (2 x 2), each wave 2 x 2 MFMA tiles of 32 x 32.  Both operands sit
+// K-contiguous in LDS ([row][32 k] bf16, row stride 40 = 80 B: conflict-free ds_read_b128 fragment
+// reads); M/N-contiguous operands are transposed in registers (4 k x 4 m blocks) before the store.
+// =========================================================================================
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define HBM_ 128
+#define HBN_ 128
+#define HBK_ 32
+#define HLD_ 40     // LDS row stride in bf16 elements
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// four consecutive-k f32 values -> packed hi (2 dwords) and lo (2 dwords)
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
+    hi.x = cvt_pk_bf16(x0, x1);
+    hi.y = cvt_pk_bf16(x2, x3);
+    const float h0 = __uint_as_float(hi.x << 16), h1 = __uint_as_float(hi.x & 0xffff0000u);
+    const float h2 = __uint_as_float(hi.y << 16), h3 = __uint_as_float(hi.y & 0xffff0000u);
+    lo.x = cvt_pk_bf16(x0 - h0, x1 - h1);
+    lo.y = cvt_pk_bf16(x2 - h2, x3 - h3);
+}
+
+template <bool AK, bool BKC>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
+    // [buf][hi/lo][row][HLD_]
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][2][HBM_][HLD_];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2][HBN_][HLD_];
+
+    const t2amd_gemm_desc& d = p.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int z = blockIdx.z;
+    const int bidx = z / d.splitk;
+    const int split = z - bidx * d.splitk;
+    const float* __restrict__ A = d.A + (long long)bidx * d.strideA;
+    const float* __restrict__ B = d.B + (long long)bidx * d.strideB;
+    float* __restrict__ C = d.C + (long long)bidx * d.strideC + (long long)split * d.strideSplitC;
+
+    const int row0 = blockIdx.y * HBM_;
+    const int col0 = blockIdx.x * HBN_;
+    const int M = d.M, N = d.N;
+    const int kbeg = split * p.ktiles_per_split * HBK_;
+    int kend = kbeg + p.ktiles_per_split * HBK_;
+    if (kend > d.K) kend = d.K;
+    const int nk = (kend > kbeg) ? (kend - kbeg + HBK_ - 1) / HBK_ : 0;
+
+    // K-contiguous operand: 128 rows x 32 k = 1024 float4, f = tid + 256*i -> (row = f>>3, kq = f&7)
+    // M-contiguous operand: 32 k x 128 m: thread -> (m4 = tid&31, kq = tid>>5), 4 float4 = k 4kq..4kq+3
+    int a_t[4] = {0, 0, 0, 0};
+    if (AK && d.convA_T > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_t[i] = (row0 + ((tid + 256 * i) >> 3)) % d.convA_T;
+    }
+    int b_tap = 0, b_ci = 0;
+    if (!BKC && d.convB_T > 0) {
+        const int gn = col0 + (tid & 31) * 4;
+        b_tap = gn / d.convB_C;
+        b_ci = gn - b_tap * d.convB_C;
+    }
+
+    float4 ra[4], rb[4];
+
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (AK) {
+                const int f = tid + 256 * i;
+                const int r = f >> 3, kq = f & 7;
+                const int gm = row0 + r;
+                const int gk = k0 + kq * 4;
+                if (gm < M && gk < kend) {
+                    long long srow = gm;
+                    int col = gk;
+                    bool ok = true;
+                    if (d.convA_T > 0) {
+                        const int tap = k0 / d.convA_C;
+                        col = (k0 - tap * d.convA_C) + kq * 4;
+                        const int sh = (tap - d.convA_pad) * d.convA_sign;
+                        const int tt = a_t[i] + sh;
+                        ok = (tt >= 0) && (tt < d.convA_T);
+                        srow = (long long)gm + sh;
+                    }
+                    if (ok) {
+                        const float* src = A + srow * d.lda + col;
+                        if (p.avec) {
+                            v = *reinterpret_cast<const float4*>(src);
+                        } else {
+                            v.x = src[0];
+                            if (gk + 1 < kend) v.y = src[1];
+                            if (gk + 2 < kend) v.z = src[2];
+                            if (gk + 3 < kend) v.w = src[3];
+                        }
+                    }
+                }
+            } else {
+                const int m4 = tid & 31, kq = tid >> 5;
+                const int gk = k0 + kq * 4 + i;
+                const int gm = row0 + m4 * 4;
+                if (gk < kend && gm < M) {
+                    const float* src = A + (long long)gk * d.lda + gm;
+                    if (p.avec) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (gm + 1 < M) v.y = src[1];
+                        if (gm + 2 < M) v.z = src[2];
+                        if (gm + 3 < M) v.w = src[3];
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+    };
+
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BKC) {
+                const int f = tid + 256 * i;
+                const int r = f >> 3, kq = f & 7;
+                const int gn = col0 + r;
+                const int gk = k0 + kq * 4;
+                if (gn < N && gk < kend) {
+                    const float* src = B + (long long)gn * d.ldb + gk;
+                    if (p.bvec) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v.x = src[0];
+                        if (gk + 1 < kend) v.y = src[1];
+                        if (gk + 2 < kend) v.z = src[2];
+                        if (gk + 3 < kend) v.w = src[3];
+                    }
+                }
+            } else {
+                const int n4 = tid & 31, kq = tid >> 5;
+                const int gk = k0 + kq * 4 + i;
+                const int gn = col0 + n4 * 4;
+                if (gk < kend && gn < N) {
+                    long long srow = gk;
+                    int col = gn;
+                    bool ok = true;
+                    if (d.convB_T > 0) {
+                        const int sh = b_tap - d.convB_pad;
+                        const int tt = (gk % d.convB_T) + sh;
+                        ok = (tt >= 0) && (tt < d.convB_T);
+                        srow = (long long)gk + sh;
+                        col = b_ci;
+                    }
+                    if (ok) {
+                        const float* src = B + srow * d.ldb + col;
+                        if (p.bvec) {
+                            v = *reinterpret_cast<const float4*>(src);
+                        } else {
+                            v.x = src[0];
+                            if (gn + 1 < N) v.y = src[1];
+                            if (gn + 2 < N) v.z = src[2];
+                            if (gn + 3 < N) v.w = src[3];
+                        }
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    auto store_one = [&](unsigned short (*S)[HBM_][HLD_], bool kc, const float4 (&r)[4]) {
+        // S = As[buf] or Bs[buf] : [hi/lo][row][HLD_]
+        if (kc) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = tid + 256 * i;
+                const int row = f >> 3, kq = f & 7;
+                uint2 hi, lo;
+                split4(r[i].x, r[i].y, r[i].z, r[i].w, hi, lo);
+                *reinterpret_cast<uint2*>(&S[0][row][kq * 4]) = hi;
+                *reinterpret_cast<uint2*>(&S[1][row][kq * 4]) = lo;
+            }
+        } else {
+            // M-contiguous operand: "pair-interleaved" image P[k/2][m] (one dword = the bf16 pair (k, k+1) of
+            // row m), aliased onto the same storage.  This thread holds k = 4kq..4kq+3 for m = 4m4..4m4+3:
+            // two 16-byte stores per half, consecutive lanes -> consecutive 16 B: conflict-free.
+            const int m4 = tid & 31, kq = tid >> 5;
+            unsigned* Ph = reinterpret_cast<unsigned*>(&S[0][0][0]);
+            unsigned* Pl = reinterpret_cast<unsigned*>(&S[1][0][0]);
+            uint4 h0, h1, l0, l1;
+            {
+                const float a0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};   // k = 4kq
+                const float a1[4] = {r[1].x, r[1].y, r[1].z, r[1].w};   // k = 4kq + 1
+                const float a2[4] = {r[2].x, r[2].y, r[2].z, r[2].w};
+                const float a3[4] = {r[3].x, r[3].y, r[3].z, r[3].w};
+                unsigned hh0[4], hh1[4], ll0[4], ll1[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    hh0[mm] = cvt_pk_bf16(a0[mm], a1[mm]);
+                    hh1[mm] = cvt_pk_bf16(a2[mm], a3[mm]);
+                    ll0[mm] = cvt_pk_bf16(a0[mm] - __uint_as_float(hh0[mm] << 16),
+                                          a1[mm] - __uint_as_float(hh0[mm] & 0xffff0000u));
+                    ll1[mm] = cvt_pk_bf16(a2[mm] - __uint_as_float(hh1[mm] << 16),
+                                          a3[mm] - __uint_as_float(hh1[mm] & 0xffff0000u));
+                }
+                h0 = make_uint4(hh0[0], hh0[1], hh0[2], hh0[3]);
+                h1 = make_uint4(hh1[0], hh1[1], hh1[2], hh1[3]);
+                l0 = make_uint4(ll0[0], ll0[1], ll0[2], ll0[3]);
+                l1 = make_uint4(ll1[0], ll1[1], ll1[2], ll1[3]);
+            }
+            *reinterpret_cast<uint4*>(&Ph[(2 * kq + 0) * HBM_ + m4 * 4]) = h0;
+            *reinterpret_cast<uint4*>(&Ph[(2 * kq + 1) * HBM_ + m4 * 4]) = h1;
+            *reinterpret_cast<uint4*>(&Pl[(2 * kq + 0) * HBM_ + m4 * 4]) = l0;
+            *reinterpret_cast<uint4*>(&Pl[(2 * kq + 1) * HBM_ + m4 * 4]) = l1;
+        }
+    };
+
+    // fragment (8 consecutive k of one row) from either LDS image
+    auto frag = [&](const unsigned short (*S)[HLD_], bool kc, int row, int ks, int lhi_) -> bf16x8 {
+        if (kc) {
+            return *reinterpret_cast<const bf16x8*>(&S[row][ks * 16 + lhi_ * 8]);
+        } else {
+            const unsigned* P = reinterpret_cast<const unsigned*>(&S[0][0]);
+            const int p0 = ks * 8 + lhi_ * 4;
+            union { unsigned u[4]; bf16x8 v; } t;
+            t.u[0] = P[(p0 + 0) * HBM_ + row];
+            t.u[1] = P[(p0 + 1) * HBM_ + row];
+            t.u[2] = P[(p0 + 2) * HBM_ + row];
+            t.u[3] = P[(p0 + 3) * HBM_ + row];
+            return t.v;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        load_a(kbeg);
+        load_b(kbeg);
+        store_one(As[0], AK, ra);
+        store_one(Bs[0], BKC, rb);
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_a(kbeg + (kt + 1) * HBK_);
+            load_b(kbeg + (kt + 1) * HBK_);
+        }
+#pragma unroll
+        for (int ks = 0; ks < HBK_ / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                ah[t] = frag(As[cur][0], AK, wm * 64 + t * 32 + l31, ks, lhi);
+                al[t] = frag(As[cur][1], AK, wm * 64 + t * 32 + l31, ks, lhi);
+                bh[t] = frag(Bs[cur][0], BKC, wn * 64 + t * 32 + l31, ks, lhi);
+                bl[t] = frag(Bs[cur][1], BKC, wn * 64 + t * 32 + l31, ks, lhi);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) {
+            store_one(As[cur ^ 1], AK, ra);
+            store_one(Bs[cur ^ 1], BKC, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA is dtype independent) -------------------
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int gn = col0 + wn * 64 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int gm = row0 + wm * 64 + tm * 32 + row;
+                if (gm < M && gn < N) {
+                    float val = acc[tm][tn][r];
+                    float* cp = C + (long long)gm * d.ldc + gn;
+                    if (d.bias) val += d.bias[gn];
+                    if (d.accumulate) val += *cp;
+                    if (d.act == 1) val = fmaxf(val, 0.f);
+                    if (d.keep) val = d.keep[(long long)gm * d.ldkeep + gn] ? val * d.keep_scale : 0.f;
+                    *cp = val;
+                }
+            }
+        }
+    }
 }

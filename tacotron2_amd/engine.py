@@ -89,6 +89,20 @@ class _Ctx(object):
     pass
 
 
+# Gradient GEMMs (dgrad / wgrad, tolerance 1e-3 of the gradient's max in the parity tests) run on the
+# split-bf16 MFMA kernel (include/tacotron2_amd.h: t2amd_gemm_desc.precision = 1, ~2^-17 relative per
+# product).  Every forward GEMM stays on the exact-f32 MFMA.  Set to False for bit-faithful f32 gradients.
+FAST_GRAD_GEMM = True
+
+
+def _rg(run, *a, **k):
+    return run.gemm(*a, fast=FAST_GRAD_GEMM, **k)
+
+
+def _ng(*a, **k):
+    return nv.gemm(*a, fast=FAST_GRAD_GEMM, **k)
+
+
 class _Run(object):
     """Allocation + kernel helpers bound to one device."""
 
@@ -112,7 +126,7 @@ class _Run(object):
 
     # C[M,N] (+)= A.B with automatic split-K for skinny outputs over a long K
     def gemm(self, Cm, A, B, a_km=False, b_kn=False, accumulate=False, convB=None, perm=None,
-             batch=1, strides=(0, 0, 0), **kw):
+             batch=1, strides=(0, 0, 0), fast=False, **kw):
         M, N = Cm.shape
         K = A.shape[0] if a_km else A.shape[1]
         plain = kw.get('bias') is None and kw.get('act', 0) == 0 and kw.get('keep') is None \
@@ -122,15 +136,15 @@ class _Run(object):
             sk = 2 if K >= 512 else 1
         if sk == 1 and perm is None:
             nv.gemm(Cm, A, B, a_km=a_km, b_kn=b_kn, accumulate=accumulate, convB=convB, batch=batch,
-                    strides=strides, **kw)
+                    strides=strides, fast=fast, **kw)
             return
         if not Cm.is_contiguous():
             raise NativeError("split-K / permuted GEMM output must be contiguous")
         part = self.empty(max(sk, 1), M * N)
         if sk == 1:
-            nv.gemm(part[0].view(M, N), A, B, a_km=a_km, b_kn=b_kn, convB=convB)
+            nv.gemm(part[0].view(M, N), A, B, a_km=a_km, b_kn=b_kn, convB=convB, fast=fast)
         else:
-            nv.gemm(part[0].view(M, N), A, B, a_km=a_km, b_kn=b_kn, convB=convB, splitk=sk, partials=part)
+            nv.gemm(part[0].view(M, N), A, B, a_km=a_km, b_kn=b_kn, convB=convB, splitk=sk, partials=part, fast=fast)
         pt, pc = perm if perm is not None else (0, 0)
         nv.splitk_reduce(part, max(sk, 1), Cm, accumulate=accumulate, perm_taps=pt, perm_ci=pc)
 
@@ -216,7 +230,7 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
         grads['%s.%d.0.conv.bias' % (prefix, i)] = dbias
         # weight gradient: dW[co][(tap,ci)] = sum_r g[r][co] * x[r + tap - pad][ci]
         dW = run.empty(Co, Ci, k)
-        run.gemm(dW.view(Co, Ci * k), g, s['x'], a_km=True, b_kn=True, convB=(T, Ci, pad), perm=(k, Ci))
+        _rg(run, dW.view(Co, Ci * k), g, s['x'], a_km=True, b_kn=True, convB=(T, Ci, pad), perm=(k, Ci))
         grads['%s.%d.0.conv.weight' % (prefix, i)] = dW
         # data gradient
         if i > 0 or first_dx is not None:
@@ -227,7 +241,7 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
             else:
                 dx = run.empty(rows, Ci)
                 acc = False
-            nv.gemm(dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
+            _ng(dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
             g = dx
     return g
 
@@ -424,11 +438,11 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # ---- projection backward --------------------------------------------------------------
     Wpg = T['Wpg']
     DHC = run.empty(rowsD, Hd + E)
-    nv.gemm(DHC, dout, Wpg, b_kn=True)
+    _ng(DHC, dout, Wpg, b_kn=True)
     dWpg_h = run.empty(Cm + 1, Hd)
     dWpg_c = run.empty(Cm + 1, E)
-    run.gemm(dWpg_h, dout, S['HD'].view(rowsD, Hd), a_km=True, b_kn=True)
-    run.gemm(dWpg_c, dout, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
+    _rg(run, dWpg_h, dout, S['HD'].view(rowsD, Hd), a_km=True, b_kn=True)
+    _rg(run, dWpg_c, dout, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
     dWp = run.empty(Cm, Hd + E)
     dWg = run.empty(1, Hd + E)
     nv.copy2d(dWp[:, :Hd], dWpg_h[:Cm]); nv.copy2d(dWp[:, Hd:], dWpg_c[:Cm])
@@ -476,21 +490,21 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     g['decoder.attention_layer.v.linear_layer.weight'] = dv
     # query layer: dWq = DQ^T . HA
     dWq = run.empty(A, Ha)
-    run.gemm(dWq, DQ.view(rowsD, A), S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
+    _rg(run, dWq, DQ.view(rowsD, A), S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
     g['decoder.attention_layer.query_layer.linear_layer.weight'] = dWq
 
     # attention LSTM weights: inputs [prenet_t | ctx_{t-1} | h_att_{t-1}]
     dWih_a = run.empty(4 * Ha, Pd + E)
     dWhh_a = run.empty(4 * Ha, Ha)
     tmp = run.empty(4 * Ha, Pd)
-    run.gemm(tmp, DGA2, T['p2'], a_km=True, b_kn=True)
+    _rg(run, tmp, DGA2, T['p2'], a_km=True, b_kn=True)
     nv.copy2d(dWih_a[:, :Pd], tmp)
     if To > 1:
         sh = (To - 1) * B
         tmp2 = run.empty(4 * Ha, E)
-        run.gemm(tmp2, DGA2[B:], S['CTX'].view(rowsD, E)[:sh], a_km=True, b_kn=True)
+        _rg(run, tmp2, DGA2[B:], S['CTX'].view(rowsD, E)[:sh], a_km=True, b_kn=True)
         nv.copy2d(dWih_a[:, Pd:], tmp2)
-        run.gemm(dWhh_a, DGA2[B:], S['HA'].view(rowsD, Ha)[:sh], a_km=True, b_kn=True)
+        _rg(run, dWhh_a, DGA2[B:], S['HA'].view(rowsD, Ha)[:sh], a_km=True, b_kn=True)
     else:
         nv.fill(dWhh_a, 0.0)
         z = run.zeros(4 * Ha, E)
@@ -506,14 +520,14 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     dWih_d = run.empty(4 * Hd, Ha + E)
     dWhh_d = run.empty(4 * Hd, Hd)
     tmp3 = run.empty(4 * Hd, Ha)
-    run.gemm(tmp3, DGD2, S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
+    _rg(run, tmp3, DGD2, S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
     nv.copy2d(dWih_d[:, :Ha], tmp3)
     tmp4 = run.empty(4 * Hd, E)
-    run.gemm(tmp4, DGD2, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
+    _rg(run, tmp4, DGD2, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
     nv.copy2d(dWih_d[:, Ha:], tmp4)
     if To > 1:
         sh = (To - 1) * B
-        run.gemm(dWhh_d, DGD2[B:], S['HD'].view(rowsD, Hd)[:sh], a_km=True, b_kn=True)
+        _rg(run, dWhh_d, DGD2[B:], S['HD'].view(rowsD, Hd)[:sh], a_km=True, b_kn=True)
     else:
         nv.fill(dWhh_d, 0.0)
     db_d = run.empty(4 * Hd)
@@ -527,26 +541,26 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     Wih_a = P['decoder.attention_rnn.weight_ih']
     W2 = P['decoder.prenet.layers.1.linear_layer.weight']
     dp2 = run.empty(rowsD, Pd)
-    nv.gemm(dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
+    _ng(dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
     nv.relu_dropout_bwd(dp2, T['p2'], 2.0)
     dW2 = run.empty(Pd, Pd)
-    run.gemm(dW2, dp2, T['p1'], a_km=True, b_kn=True)
+    _rg(run, dW2, dp2, T['p1'], a_km=True, b_kn=True)
     dp1 = run.empty(rowsD, Pd)
-    nv.gemm(dp1, dp2, W2, b_kn=True)
+    _ng(dp1, dp2, W2, b_kn=True)
     nv.relu_dropout_bwd(dp1, T['p1'], 2.0)
     dW1 = run.empty(Pd, Cm)
-    run.gemm(dW1, dp1, T['x0'].view(rowsD, Cm), a_km=True, b_kn=True)
+    _rg(run, dW1, dp1, T['x0'].view(rowsD, Cm), a_km=True, b_kn=True)
     g['decoder.prenet.layers.0.linear_layer.weight'] = dW1
     g['decoder.prenet.layers.1.linear_layer.weight'] = dW2
 
     # memory gradient: d_mem[b] = ALIGN[b]^T . DCTX[:, b] + d_pm[b] . Wmem ; dWmem = d_pm^T . memory
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']     # (A, E)
     dmem = run.empty(B, Ti, E)
-    nv.gemm(dmem[0], S['ALIGN'][0], DCTX[:, 0, :], a_km=True, b_kn=True, batch=B,
+    _ng(dmem[0], S['ALIGN'][0], DCTX[:, 0, :], a_km=True, b_kn=True, batch=B,
             strides=(To * Ti, E, Ti * E))
-    nv.gemm(dmem.view(rowsE, E), d_pm.view(rowsE, A), Wmem, b_kn=True, accumulate=True)
+    _ng(dmem.view(rowsE, E), d_pm.view(rowsE, A), Wmem, b_kn=True, accumulate=True)
     dWmem = run.empty(A, E)
-    run.gemm(dWmem, d_pm.view(rowsE, A), c.memory.view(rowsE, E), a_km=True, b_kn=True)
+    _rg(run, dWmem, d_pm.view(rowsE, A), c.memory.view(rowsE, E), a_km=True, b_kn=True)
     g['decoder.attention_layer.memory_layer.linear_layer.weight'] = dWmem
 
     if sync is not None:
@@ -572,18 +586,18 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         desc.dX, desc.dc = nv.ptr(dX), nv.ptr(dc)
         nv.lstm_seq_bwd(desc)
         dWih = run.empty(4 * He, E)
-        run.gemm(dWih, DG, c.x3, a_km=True, b_kn=True)
+        _rg(run, dWih, DG, c.x3, a_km=True, b_kn=True)
         # h_prev of row (b,t) is the output at (b, t-1) forward / (b, t+1) reverse, zero outside [0,T)
         dWhh = run.empty(4 * He, He)
         hview = c.memory.view(rowsE, E)[:, d * He:(d + 1) * He]
-        run.gemm(dWhh, DG, hview, a_km=True, b_kn=True, convB=(Ti, He, 1 if d == 0 else -1))
+        _rg(run, dWhh, DG, hview, a_km=True, b_kn=True, convB=(Ti, He, 1 if d == 0 else -1))
         db = run.empty(4 * He)
         run.colsum(DG, db)
         g['encoder.lstm.weight_ih_l0' + sfx] = dWih
         g['encoder.lstm.weight_hh_l0' + sfx] = dWhh
         g['encoder.lstm.bias_ih_l0' + sfx] = db
         g['encoder.lstm.bias_hh_l0' + sfx] = db.clone()
-        nv.gemm(dx3, DG, L['Wih'], b_kn=True, accumulate=(d == 1))
+        _ng(dx3, DG, L['Wih'], b_kn=True, accumulate=(d == 1))
     demb = run.empty(rowsE, E)
     _conv_stack_bwd(run, P, g, 'encoder.convolutions', c.enc_saved, dx3, Ti, first_dx=demb)
     dtable = run.empty(*P['embedding.weight'].shape)

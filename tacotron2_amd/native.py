@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("keep", C.c_void_p), ("ldkeep", _i64), ("keep_scale", C.c_float),
         ("convA_T", C.c_int), ("convA_C", C.c_int), ("convA_pad", C.c_int), ("convA_sign", C.c_int),
         ("convB_T", C.c_int), ("convB_C", C.c_int), ("convB_pad", C.c_int),
+        ("precision", C.c_int),
     ]
 
 
@@ -360,7 +361,8 @@ def scale_for(p):
 # GEMM
 # ----------------------------------------------------------------------------
 def gemm(Cm, A, B, a_km=False, b_kn=False, accumulate=False, bias=None, act=0, keep=None,
-         keep_scale=1.0, convA=None, convB=None, batch=1, strides=(0, 0, 0), splitk=1, partials=None):
+         keep_scale=1.0, convA=None, convB=None, batch=1, strides=(0, 0, 0), splitk=1, partials=None,
+         fast=False):
     """Cm[M,N] (+)= act(A.B + bias)*keep.
 
     A is a view [M,K] (default) or [K,M] when ``a_km``;  B is a view [N,K] (default, the
@@ -397,6 +399,7 @@ def gemm(Cm, A, B, a_km=False, b_kn=False, accumulate=False, bias=None, act=0, k
     d.batch = batch
     d.strideA, d.strideB, d.strideC = strides
     d.splitk = splitk
+    d.precision = 1 if fast else 0
     d.accumulate = 1 if accumulate else 0
     d.bias = ptr(bias)
     d.act = act

@@ -53,6 +53,27 @@ def test_gemm_layouts(nv, M, N, K, a_km, b_kn):
     assert err(C, ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(130, 81, 50), (300, 257, 96), (64, 4096, 256), (7, 5, 3), (256, 128, 1024), (512, 384, 4000)])
+@pytest.mark.parametrize("a_km,b_kn", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_split_bf16(nv, M, N, K, a_km, b_kn):
+    """precision=1 (Ah.Bh + Ah.Bl + Al.Bh on the bf16 MFMA): error class 2^-17 per product, far from plain
+    bf16 (2^-9); asymmetric operands so that a transposed fragment layout cannot pass."""
+    A = rnd(M, K, seed=1) * (1.0 + torch.arange(M).float().unsqueeze(1) / M)
+    B = rnd(K, N, seed=2) * (0.5 + torch.arange(N).float().unsqueeze(0) / N)
+    ref = A.double() @ B.double()
+    Ad = dv(A.t().contiguous()) if a_km else dv(A)
+    Bd = dv(B) if b_kn else dv(B.t().contiguous())
+    C = torch.full((M, N), float('nan'), device=DEV)
+    nv.gemm(C, Ad, Bd, a_km=a_km, b_kn=b_kn, fast=True)
+    scale = (A.abs().double() @ B.abs().double())          # sum |a||b| bounds the rounding error
+    rel = ((C.cpu().double() - ref).abs() / scale).max().item()
+    assert rel < 2.5e-5, rel                                 # measured ~3e-6; plain bf16 would be ~4e-3
+    C32 = torch.empty(M, N, device=DEV)
+    nv.gemm(C32, Ad, Bd, a_km=a_km, b_kn=b_kn)
+    rel32 = ((C32.cpu().double() - ref).abs() / scale).max().item()
+    assert rel32 < 2e-6
+
+
 def test_gemm_epilogue_and_views(nv):
     M, N, K = 200, 96, 72
     A, W, bias, C0 = rnd(M, K, seed=3), rnd(N + 10, K + 8, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
@@ -117,6 +138,14 @@ def test_conv_forward_dgrad_wgrad(nv, Bn, T, Ci, Co, k):
     part = torch.empty(2, Co * k * Ci, device=DEV)
     nv.gemm(part[0].view(Co, k * Ci), gy_cl, x_cl, a_km=True, b_kn=True, convB=(T, Ci, pad), splitk=2, partials=part)
     dW = torch.empty(Co, Ci, k, device=DEV)
+    nv.splitk_reduce(part, 2, dW, perm_taps=k, perm_ci=Ci)
+    assert err(dW, W.grad) < 5e-5
+    # the same two gradient GEMMs on the split-bf16 kernel (what the engine's backward uses)
+    dx2 = torch.empty(rows, Ci, device=DEV)
+    nv.gemm(dx2, gy_cl, Wdg, convA=(T, Co, pad, -1), fast=True)      # Co % 32 != 0 falls back to exact f32
+    assert err(dx2.view(Bn, T, Ci).permute(0, 2, 1), x.grad) < 5e-5
+    nv.gemm(part[0].view(Co, k * Ci), gy_cl, x_cl, a_km=True, b_kn=True, convB=(T, Ci, pad), splitk=2, partials=part,
+            fast=True)
     nv.splitk_reduce(part, 2, dW, perm_taps=k, perm_ci=Ci)
     assert err(dW, W.grad) < 5e-5
 
