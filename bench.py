@@ -33,7 +33,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=8, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()

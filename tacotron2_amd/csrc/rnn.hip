@@ -142,37 +142,58 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
         }
         wo = wrow * p.Ktot + 4 * (l15 ^ (c & 15));
     }
-    const float* const sp0 = p.x[0].p;
-    const float* const sp1 = p.x[1].p;
-    const float* const sp2 = p.x[2].p;
-    const float* const Wp = p.W;
+    const float* const Wp = p.W + wo;
     const int kt_last = kt_end - 1;
 
-#define SK_ISSUE(BUF, KT_REQ)                                                                          \
+    // Running DMA source pointers: the tile sequence only moves forward (and sticks at the last tile),
+    // so each issue is five DMA instructions plus five pointer bumps; the segment switch is a rare,
+    // wave-uniform branch.  iss_seg/iss_rem: segment of the next tile to issue / tiles left in it.
+    const float* xq0; const float* xq1; const float* xq2; const float* xq3; const float* wq;
+    int iss_kt = kt_beg, iss_seg = 0, iss_rem = 0;
+    // position the pointers on tile LOCAL of segment SEG (wave-uniform arguments; static array indices only)
+#define SK_SEEK(SEG, LOCAL)                                                                            \
     {                                                                                                  \
-        int kt_ = (KT_REQ) < kt_last ? (KT_REQ) : kt_last;                                             \
-        const float* sp_;                                                                              \
-        int wk_;                                                                                       \
-        long long o0_, o1_, o2_, o3_;                                                                  \
-        if (kt_ < n0) {                                                                                \
-            sp_ = sp0 + kt_ * SK_BK; wk_ = kt_ * SK_BK;                                                \
-            o0_ = xo0[0]; o1_ = xo0[1]; o2_ = xo0[2]; o3_ = xo0[3];                                    \
-        } else if (kt_ < n0 + n1) {                                                                    \
-            kt_ -= n0;                                                                                 \
-            sp_ = sp1 + kt_ * SK_BK; wk_ = wo1 + kt_ * SK_BK;                                          \
-            o0_ = xo1[0]; o1_ = xo1[1]; o2_ = xo1[2]; o3_ = xo1[3];                                    \
+        const int seg_ = (SEG), loc_ = (LOCAL);                                                        \
+        if (seg_ == 0) {                                                                               \
+            const float* sp_ = p.x[0].p + loc_ * SK_BK;                                                \
+            xq0 = sp_ + xo0[0]; xq1 = sp_ + xo0[1]; xq2 = sp_ + xo0[2]; xq3 = sp_ + xo0[3];            \
+            wq = Wp + loc_ * SK_BK; iss_rem = n0 - loc_;                                               \
+        } else if (seg_ == 1) {                                                                        \
+            const float* sp_ = p.x[1].p + loc_ * SK_BK;                                                \
+            xq0 = sp_ + xo1[0]; xq1 = sp_ + xo1[1]; xq2 = sp_ + xo1[2]; xq3 = sp_ + xo1[3];            \
+            wq = Wp + wo1 + loc_ * SK_BK; iss_rem = n1 - loc_;                                         \
         } else {                                                                                       \
-            kt_ -= n0 + n1;                                                                            \
-            sp_ = sp2 + kt_ * SK_BK; wk_ = wo2 + kt_ * SK_BK;                                          \
-            o0_ = xo2[0]; o1_ = xo2[1]; o2_ = xo2[2]; o3_ = xo2[3];                                    \
+            const float* sp_ = p.x[2].p + loc_ * SK_BK;                                                \
+            xq0 = sp_ + xo2[0]; xq1 = sp_ + xo2[1]; xq2 = sp_ + xo2[2]; xq3 = sp_ + xo2[3];            \
+            wq = Wp + wo2 + loc_ * SK_BK; iss_rem = n2 - loc_;                                         \
         }                                                                                              \
+        iss_seg = seg_;                                                                                \
+    }
+    xq0 = xq1 = xq2 = xq3 = wq = p.W;
+    if (kt_end > kt_beg) {
+        if (kt_beg < n0) SK_SEEK(0, kt_beg)
+        else if (kt_beg < n0 + n1) SK_SEEK(1, kt_beg - n0)
+        else SK_SEEK(2, kt_beg - n0 - n1)
+    }
+
+#define SK_ISSUE(BUF)                                                                                  \
+    {                                                                                                  \
         float* xd_ = Xs + (BUF) * SK_XT + wave * (16 * SK_BK);                                         \
-        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o0_), (t2_lptr)(xd_), 16, 0, 0);              \
-        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o1_), (t2_lptr)(xd_ + 256), 16, 0, 0);       \
-        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o2_), (t2_lptr)(xd_ + 512), 16, 0, 0);       \
-        __builtin_amdgcn_global_load_lds((t2_gptr)(sp_ + o3_), (t2_lptr)(xd_ + 768), 16, 0, 0);       \
-        __builtin_amdgcn_global_load_lds((t2_gptr)(Wp + wo + wk_),                                     \
-                                         (t2_lptr)(Ws + (BUF) * SK_WT + wave * 256), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq0), (t2_lptr)(xd_), 16, 0, 0);                    \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq1), (t2_lptr)(xd_ + 256), 16, 0, 0);             \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq2), (t2_lptr)(xd_ + 512), 16, 0, 0);             \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq3), (t2_lptr)(xd_ + 768), 16, 0, 0);             \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(wq), (t2_lptr)(Ws + (BUF) * SK_WT + wave * 256), 16, 0, 0); \
+        if (iss_kt < kt_last) {                                                                        \
+            ++iss_kt;                                                                                  \
+            if (--iss_rem > 0) {                                                                       \
+                xq0 += SK_BK; xq1 += SK_BK; xq2 += SK_BK; xq3 += SK_BK; wq += SK_BK;                   \
+            } else if (iss_seg == 0 && n1 > 0) {                                                       \
+                SK_SEEK(1, 0)                                                                          \
+            } else {                                                                                   \
+                SK_SEEK(2, 0)                                                                          \
+            }                                                                                          \
+        }                                                                                              \
     }
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -192,72 +213,99 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
         }
     }
 
-#define SK_MMA(BUF)                                                                                     \
-    {                                                                                                   \
-        f32x4 a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_;                                                   \
-        asm volatile(                                                                                   \
-            "ds_read_b128 %0, %8 offset:%16\n\t"                                                        \
-            "ds_read_b128 %4, %12 offset:%17\n\t"                                                       \
-            "ds_read_b128 %1, %9 offset:%16\n\t"                                                        \
-            "ds_read_b128 %5, %13 offset:%17\n\t"                                                       \
-            "ds_read_b128 %2, %10 offset:%16\n\t"                                                       \
-            "ds_read_b128 %6, %14 offset:%17\n\t"                                                       \
-            "ds_read_b128 %3, %11 offset:%16\n\t"                                                       \
-            "ds_read_b128 %7, %15 offset:%17\n\t"                                                       \
-            "s_waitcnt lgkmcnt(0)"                                                                      \
-            : "=&v"(a0_), "=&v"(a1_), "=&v"(a2_), "=&v"(a3_), "=&v"(b0_), "=&v"(b1_), "=&v"(b2_), "=&v"(b3_) \
-            : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba[0]), "v"(ba[1]), "v"(ba[2]), "v"(ba[3]), \
-              "i"((BUF) * SK_XT * 4), "i"((BUF) * SK_WT * 4)                                            \
-            : "memory");                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[0], b0_[0], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[1], b0_[1], acc1, 0, 0, 0);                     \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[2], b0_[2], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0_[3], b0_[3], acc1, 0, 0, 0);                     \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[0], b1_[0], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[1], b1_[1], acc1, 0, 0, 0);                     \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[2], b1_[2], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1_[3], b1_[3], acc1, 0, 0, 0);                     \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[0], b2_[0], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[1], b2_[1], acc1, 0, 0, 0);                     \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[2], b2_[2], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2_[3], b2_[3], acc1, 0, 0, 0);                     \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[0], b3_[0], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[1], b3_[1], acc1, 0, 0, 0);                     \
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[2], b3_[2], acc0, 0, 0, 0);                     \
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3_[3], b3_[3], acc1, 0, 0, 0);                     \
-    }
-    // One k-tile.  Every wave has issued exactly 5 DMA instructions per tile, always (tile indices are
-    // clamped, never branched on), so "tile kt landed" is vmcnt(5): only tile kt+1's five may be pending.
-    // The barrier then (a) makes the other waves' weight rows of tile kt visible and (b) proves everybody
-    // finished reading the buffer tile kt+2 is about to overwrite (it held tile kt-1).
-#define SK_STEP(BUF, KT)                                                     \
+    // Two fragment register sets: while the MFMAs consume set X (tile kt), the ds_reads of tile kt+1
+    // fill set Y; the statement that waits for them closes the same step, so nothing the compiler
+    // might do at the loop back-edge can touch a register whose LDS data is still in flight.
+    f32x4 fa0, fa1, fa2, fa3, ga0, ga1, ga2, ga3;     // set A: activations / weights
+    f32x4 fb0, fb1, fb2, fb3, gb0, gb1, gb2, gb3;     // set B
+
+#define SK_READ(BUF, X0, X1, X2, X3, W0, W1, W2, W3)                                                   \
+    asm volatile(                                                                                      \
+        "ds_read_b128 %0, %8 offset:%16\n\t"                                                           \
+        "ds_read_b128 %4, %12 offset:%17\n\t"                                                          \
+        "ds_read_b128 %1, %9 offset:%16\n\t"                                                           \
+        "ds_read_b128 %5, %13 offset:%17\n\t"                                                          \
+        "ds_read_b128 %2, %10 offset:%16\n\t"                                                          \
+        "ds_read_b128 %6, %14 offset:%17\n\t"                                                          \
+        "ds_read_b128 %3, %11 offset:%16\n\t"                                                          \
+        "ds_read_b128 %7, %15 offset:%17"                                                              \
+        : "=&v"(X0), "=&v"(X1), "=&v"(X2), "=&v"(X3), "=&v"(W0), "=&v"(W1), "=&v"(W2), "=&v"(W3)       \
+        : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ba[0]), "v"(ba[1]), "v"(ba[2]), "v"(ba[3]), \
+          "i"((BUF) * SK_XT * 4), "i"((BUF) * SK_WT * 4)                                               \
+        : "memory");
+#define SK_WAITR(X0, X1, X2, X3, W0, W1, W2, W3)                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                \
+                 : "+v"(X0), "+v"(X1), "+v"(X2), "+v"(X3), "+v"(W0), "+v"(W1), "+v"(W2), "+v"(W3)      \
+                 :                                                                                     \
+                 : "memory");
+#define SK_FMA4(X, W)                                                                                  \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[0], (W)[0], acc0, 0, 0, 0);                        \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[1], (W)[1], acc1, 0, 0, 0);                        \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[2], (W)[2], acc0, 0, 0, 0);                        \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[3], (W)[3], acc1, 0, 0, 0);
+#define SK_FMA(X0, X1, X2, X3, W0, W1, W2, W3) SK_FMA4(X0, W0) SK_FMA4(X1, W1) SK_FMA4(X2, W2) SK_FMA4(X3, W3)
+#define SK_SETA fa0, fa1, fa2, fa3, ga0, ga1, ga2, ga3
+#define SK_SETB fb0, fb1, fb2, fb3, gb0, gb1, gb2, gb3
+#define SK_X(M, ...) M(__VA_ARGS__)
+    // One k-tile (tile KT sits in LDS buffer BUF and, already, in register set CUR).  Every wave has
+    // issued exactly 5 DMA instructions per tile, always (tile indices are clamped, never branched on),
+    // so "tile KT+1 landed" is vmcnt(5): only tile KT+2's five may be pending.  The barrier then (a) makes
+    // the other waves' weight rows of tile KT+1 visible and (b) proves everybody has the fragments of
+    // tile KT in registers, so its buffer can take the DMA of tile KT+3.
+#define SK_STEP(BUF, KT, CUR, NXT)                                           \
     {                                                                        \
         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                     \
         __builtin_amdgcn_s_barrier();                                        \
         __builtin_amdgcn_sched_barrier(0);                                   \
-        SK_ISSUE(((BUF) + 2) % SK_NBUF, (KT) + 2)                            \
-        SK_MMA(BUF)                                                          \
+        SK_X(SK_READ, ((BUF) + 1) % SK_NBUF, NXT)                            \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        SK_ISSUE(BUF)                                                        \
+        SK_X(SK_FMA, CUR)                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        SK_X(SK_WAITR, NXT)                                                  \
     }
 
     if (kt_end > kt_beg) {
-        SK_ISSUE(0, kt_beg)
-        SK_ISSUE(1, kt_beg + 1)
+        SK_ISSUE(0)
+        SK_ISSUE(1)
+        SK_ISSUE(2)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        SK_X(SK_READ, 0, SK_SETA)
+        SK_X(SK_WAITR, SK_SETA)
         int kt = kt_beg;
-        for (; kt + 3 <= kt_end; kt += 3) {
-            SK_STEP(0, kt)
-            SK_STEP(1, kt + 1)
-            SK_STEP(2, kt + 2)
+        for (; kt + 6 <= kt_end; kt += 6) {
+            SK_STEP(0, kt, SK_SETA, SK_SETB)
+            SK_STEP(1, kt + 1, SK_SETB, SK_SETA)
+            SK_STEP(2, kt + 2, SK_SETA, SK_SETB)
+            SK_STEP(0, kt + 3, SK_SETB, SK_SETA)
+            SK_STEP(1, kt + 4, SK_SETA, SK_SETB)
+            SK_STEP(2, kt + 5, SK_SETB, SK_SETA)
         }
         if (kt < kt_end) {
-            SK_STEP(0, kt)
-            if (kt + 1 < kt_end) SK_STEP(1, kt + 1)
+            SK_STEP(0, kt, SK_SETA, SK_SETB)
+            if (kt + 1 < kt_end) {
+                SK_STEP(1, kt + 1, SK_SETB, SK_SETA)
+                if (kt + 2 < kt_end) {
+                    SK_STEP(2, kt + 2, SK_SETA, SK_SETB)
+                    if (kt + 3 < kt_end) {
+                        SK_STEP(0, kt + 3, SK_SETB, SK_SETA)
+                        if (kt + 4 < kt_end) SK_STEP(1, kt + 4, SK_SETA, SK_SETB)
+                    }
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped duplicate tiles
     }
 #undef SK_ISSUE
-#undef SK_MMA
+#undef SK_SEEK
+#undef SK_READ
+#undef SK_WAITR
+#undef SK_FMA4
+#undef SK_FMA
 #undef SK_STEP
+#undef SK_X
 
     // D layout (16x16): col = lane&15, row = (lane>>4)*4 + reg
     if (!LSTM) {

@@ -15,7 +15,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtacotron2_amd.so")
+LIB_PATH = os.environ.get("T2AMD_LIB", os.path.join(_HERE, "lib", "libtacotron2_amd.so"))
 
 ATT_DIM = 128
 LOC_FILTERS = 32
