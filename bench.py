@@ -36,6 +36,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--decoder-streams", type=int, default=1, choices=(1, 2),
+                    help="1: single stream, fused launches (default); 2: decoder-LSTM chain on a side stream")
     return ap.parse_args()
 
 
@@ -94,6 +96,7 @@ def main():
     if world > 1:
         dist.barrier()
     native.load()
+    native.set_decoder_streams(args.decoder_streams)
     from tacotron2_amd.hparams import create_hparams
     from tacotron2_amd.model import Tacotron2
     from tacotron2_amd.loss_function import Tacotron2Loss
@@ -155,7 +158,8 @@ def main():
     roofline = None
     if not args.no_roofline and rank == 0:
         To = batches[-1][2].shape[2]
-        native.profile_enable(3, To)                  # role 3 = fused launch LSTM_d(t-1) || LSTM_a(t)
+        fused = args.decoder_streams == 1
+        native.profile_enable(3 if fused else 2, To)  # role 3 = fused LSTM_d(t-1) || LSTM_a(t); role 2 = LSTM_d(t)
         step(batches[-1])
         torch.cuda.synchronize()
         ms, cnt = native.profile_read()
@@ -165,21 +169,23 @@ def main():
             # weights once + activations in + (pre-activation addend) + bias + gates/c/h out + c_prev + keep mask
             return 4.0 * (4 * H * K + B * K + (B * 4 * H if with_gin else 0) + 4 * H + B * 4 * H
                           + 3 * B * H + 0.25 * B * H)
-        alg_bytes = lstm_bytes(Ha + E + Hd, Hd, False) + lstm_bytes(E + Ha, Ha, True)
-        alg_flops = 2.0 * B * (4 * Hd * (Ha + E + Hd) + 4 * Ha * (E + Ha))
+        alg_bytes = lstm_bytes(Ha + E + Hd, Hd, False) + (lstm_bytes(E + Ha, Ha, True) if fused else 0.0)
+        alg_flops = 2.0 * B * (4 * Hd * (Ha + E + Hd) + (4 * Ha * (E + Ha) if fused else 0))
         avg_s = (ms / 1e3) / max(cnt, 1)
         achieved = alg_bytes / avg_s / 1e9
+        kname = ("skinny_gemm_kernel<true,3> (one decoder time step: decoder LSTM of step t-1 (64x2560x4096) + attention "
+                 "LSTM of step t (64x1536x4096), exact-f32 MFMA + fused cells)") if fused else \
+                ("skinny_gemm_kernel<true,2> (decoder LSTM step: 64x2560x4096 exact-f32 MFMA GEMM + fused cell; runs on the "
+                 "side stream concurrently with the attention chain, so its duration includes sharing the CUs)")
         # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler
         # around itself); null if the file is absent.
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_launch"]
+                traffic = json.load(fh)["hbm_bytes_per_launch_fused" if fused else "hbm_bytes_per_launch"]
         except Exception:
             traffic = None
-        roofline = {"kernel": "skinny_gemm_kernel<true,3> (one decoder time step: decoder LSTM of step t-1 "
-                              "(64x2560x4096) + attention LSTM of step t (64x1536x4096), exact-f32 MFMA + fused cells)",
-                    "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+        roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic,
                     "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes,
                     "mfma_f32": {"achieved_tflops": alg_flops / avg_s / 1e12, "peak_tflops": 157.3,

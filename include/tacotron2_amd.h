@@ -394,7 +394,7 @@ typedef struct t2amd_dec_train_bwd {
     float* dU_acc; /* [B][128][62] (zeroed by the call) */
     float* dv_acc; /* [B][128] (zeroed by the call) */
     /* workspaces */
-    float* dXd;  /* [nsplit][B][Ha+E+Hd] */
+    float* dXd;  /* [To][nsplit][B][Ha+E+Hd]: per step, the decoder-LSTM chain runs ahead of its consumers */
     float* dXa;  /* [nsplit][B][E+Ha] */
     float* dc_a; /* [B][Ha] */
     float* dc_d; /* [B][Hd] */
@@ -404,6 +404,11 @@ typedef struct t2amd_dec_train_bwd {
 } t2amd_dec_train_bwd;
 
 int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream);
+/* 1 (default): everything on the caller's stream; the decoder-LSTM chain (off the attention recurrence under
+ * teacher forcing) shares fused launches with the attention-LSTM chain.  2: the decoder-LSTM chain of both
+ * training loops runs on an internal side stream, ordered against the caller's stream with one hipEvent per
+ * 8 steps. */
+int t2amd_set_decoder_streams(int n);
 
 /* Encoder bi-LSTM over [B][T][.] with packed-sequence semantics (reference model.py:180-188).
  * GX [B][T][4H] holds x.W_ih^T + b_ih + b_hh (hoisted dense GEMM) and is overwritten with the

@@ -1,8 +1,52 @@
-// Host-side time loops: one C call enqueues every step's kernels on the caller's stream.
-// The decoder's ~870 strictly sequential steps run as a chain of three
-// launches per step forward (attention LSTM, attention, decoder LSTM) and five per step
-// backward; nothing returns to Python and nothing synchronises with the host inside a loop.
+// Host-side time loops: one C call enqueues every step's kernels; nothing returns to Python and nothing
+// synchronises with the host inside a loop.  The decoder's ~870 strictly sequential steps
+// are two chains: the attention recurrence (attention LSTM -> energies -> softmax/context) on the caller's
+// stream and the decoder LSTM, which never feeds back into it, on a side stream (see below).
 #include "common.h"
+
+#include <vector>
+
+// ---- second HIP stream for the chain that is off the critical recurrence ------------------------------
+// Under teacher forcing the decoder LSTM (and, in BPTT, its cell-backward -> dgrad chain) never feeds the
+// attention recurrence: it only trails (forward) or leads (backward) it.  With two streams the two chains
+// are enqueued independently and the GPU co-schedules their kernels: the latency-bound attention launches
+// of one chain run beside the MFMA-bound launches of the other.  Cross-stream order is a hipEvent per
+// chunk of T2_CHUNK steps.  Default is 1 (single stream, the two chains share fused launches): on this chip
+// the two queues did not overlap any better than the fused launches do (round-1 A/B).
+#define T2_CHUNK 8
+static int g_dec_streams = 1;   // measured on MI355X: 2 streams 134.3 ms/step vs 131.5 ms fused single stream
+static hipStream_t g_side = nullptr;
+static std::vector<hipEvent_t> g_events;
+
+extern "C" int t2amd_set_decoder_streams(int n) {
+    T2_REQUIRE(n == 1 || n == 2, "set_decoder_streams: 1 or 2");
+    g_dec_streams = n;
+    return T2AMD_OK;
+}
+static int side_stream(hipStream_t* out) {
+    if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess)
+        T2_FAIL("decoder loop: cannot create the side stream");
+    *out = g_side;
+    return T2AMD_OK;
+}
+static int event_at(size_t i, hipEvent_t* out) {
+    while (g_events.size() <= i) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) T2_FAIL("decoder loop: hipEventCreate failed");
+        g_events.push_back(e);
+    }
+    *out = g_events[i];
+    return T2AMD_OK;
+}
+// `waiter` will not start work enqueued after this call before everything enqueued so far on `signaller` is done
+static int order_after(hipStream_t waiter, hipStream_t signaller, size_t ev_index) {
+    if (t2amd_validate_only_flag_()) return T2AMD_OK;
+    hipEvent_t e;
+    T2_PROPAGATE(event_at(ev_index, &e));
+    if (hipEventRecord(e, signaller) != hipSuccess || hipStreamWaitEvent(waiter, e, 0) != hipSuccess)
+        T2_FAIL("decoder loop: event record/wait failed");
+    return T2AMD_OK;
+}
 
 static inline t2amd_seg seg(const float* p, long long ld, int width) {
     t2amd_seg s;
@@ -30,53 +74,39 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
                "dec_train_fwd: null slabs");
     T2_PROPAGATE(t2amd_fill_f32(p->cum_work, (long long)B * Ti, 0.f, stream));
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
-    // Software-pipelined by one step: the decoder LSTM never feeds back into the attention recurrence
-    // under teacher forcing (reference model.py:352-371: attention_rnn sees prenet(frame_t), ctx_{t-1} and
-    // its own state only), so LSTM_d(t-1) shares one launch with LSTM_a(t).
-    for (int t = 0; t <= To; ++t) {
-        t2amd_lstm_step a = {}, d = {};
-        if (t < To) {
-            // attention LSTM: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T
-            a.nseg = 2;
-            a.x[0] = seg(t ? p->CTX + (t - 1) * sE : nullptr, E, E);
-            a.x[1] = seg(t ? p->HA + (t - 1) * sHa : nullptr, Ha, Ha);
-            a.W = p->Wa_rec; a.Ktot = E + Ha; a.H = Ha; a.B = B;
-            a.gin = p->GA + (long long)t * B * 4 * Ha; a.ld_gin = 4 * Ha;
-            a.bias = nullptr;
-            a.c_prev = t ? p->CA + (t - 1) * sHa : nullptr; a.ld_cprev = Ha;
-            a.gates_out = p->GA + (long long)t * B * 4 * Ha; a.ld_gates = 4 * Ha;
-            a.c_out = p->CA + t * sHa; a.ld_c = Ha;
-            a.h_out = p->HA + t * sHa; a.ld_h = Ha;
-            a.keep = p->keep_att ? p->keep_att + t * sHa : nullptr; a.ld_keep = Ha; a.keep_scale = p->scale_att;
-            a.tag = 1;
-        }
-        if (t > 0) {
-            // decoder LSTM of step u = t-1: gates = bias_d + [h_att_u | ctx_u | h_dec_{u-1}] . Wd_cat^T
-            const int u = t - 1;
-            d.nseg = 3;
-            d.x[0] = seg(p->HA + u * sHa, Ha, Ha);
-            d.x[1] = seg(p->CTX + u * sE, E, E);
-            d.x[2] = seg(u ? p->HD + (u - 1) * sHd : nullptr, Hd, Hd);
-            d.W = p->Wd_cat; d.Ktot = Ha + E + Hd; d.H = Hd; d.B = B;
-            d.gin = nullptr; d.bias = p->bias_d;
-            d.c_prev = u ? p->CD + (u - 1) * sHd : nullptr; d.ld_cprev = Hd;
-            d.gates_out = p->GD + (long long)u * B * 4 * Hd; d.ld_gates = 4 * Hd;
-            d.c_out = p->CD + u * sHd; d.ld_c = Hd;
-            d.h_out = p->HD + u * sHd; d.ld_h = Hd;
-            d.keep = p->keep_dec ? p->keep_dec + u * sHd : nullptr; d.ld_keep = Hd; d.keep_scale = p->scale_dec;
-            d.tag = 2;
-        }
-        if (t == 0) {
-            T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
-        } else if (t == To) {
-            T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
-        } else {
-            d.tag = 3;     // the pair is profiled as role 3 (its symbol is skinny_gemm_kernel<true, 3>)
-            T2_PROPAGATE(t2amd_lstm_step_fwd2_f32(&d, &a, stream));
-        }
-        if (t == To) break;
-
-        // location-sensitive attention
+    auto fill_a = [&](int t, t2amd_lstm_step& a) {
+        // attention LSTM: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T
+        a = t2amd_lstm_step{};
+        a.nseg = 2;
+        a.x[0] = seg(t ? p->CTX + (t - 1) * sE : nullptr, E, E);
+        a.x[1] = seg(t ? p->HA + (t - 1) * sHa : nullptr, Ha, Ha);
+        a.W = p->Wa_rec; a.Ktot = E + Ha; a.H = Ha; a.B = B;
+        a.gin = p->GA + (long long)t * B * 4 * Ha; a.ld_gin = 4 * Ha;
+        a.bias = nullptr;
+        a.c_prev = t ? p->CA + (t - 1) * sHa : nullptr; a.ld_cprev = Ha;
+        a.gates_out = p->GA + (long long)t * B * 4 * Ha; a.ld_gates = 4 * Ha;
+        a.c_out = p->CA + t * sHa; a.ld_c = Ha;
+        a.h_out = p->HA + t * sHa; a.ld_h = Ha;
+        a.keep = p->keep_att ? p->keep_att + t * sHa : nullptr; a.ld_keep = Ha; a.keep_scale = p->scale_att;
+        a.tag = 1;
+    };
+    auto fill_d = [&](int u, t2amd_lstm_step& d) {
+        // decoder LSTM of step u: gates = bias_d + [h_att_u | ctx_u | h_dec_{u-1}] . Wd_cat^T
+        d = t2amd_lstm_step{};
+        d.nseg = 3;
+        d.x[0] = seg(p->HA + u * sHa, Ha, Ha);
+        d.x[1] = seg(p->CTX + u * sE, E, E);
+        d.x[2] = seg(u ? p->HD + (u - 1) * sHd : nullptr, Hd, Hd);
+        d.W = p->Wd_cat; d.Ktot = Ha + E + Hd; d.H = Hd; d.B = B;
+        d.gin = nullptr; d.bias = p->bias_d;
+        d.c_prev = u ? p->CD + (u - 1) * sHd : nullptr; d.ld_cprev = Hd;
+        d.gates_out = p->GD + (long long)u * B * 4 * Hd; d.ld_gates = 4 * Hd;
+        d.c_out = p->CD + u * sHd; d.ld_c = Hd;
+        d.h_out = p->HD + u * sHd; d.ld_h = Hd;
+        d.keep = p->keep_dec ? p->keep_dec + u * sHd : nullptr; d.ld_keep = Hd; d.keep_scale = p->scale_dec;
+        d.tag = 2;
+    };
+    auto attention = [&](int t, void* st) -> int {
         t2amd_attn_fwd at = {};
         at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
         at.h = p->HA + t * sHa; at.ld_h = Ha;
@@ -88,7 +118,49 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)To * Ti;
         at.ctx_out = p->CTX + t * sE; at.ld_ctx = E;
         at.q_out = p->Q + (long long)t * B * T2AMD_ATT_DIM; at.ld_q = T2AMD_ATT_DIM;
-        T2_PROPAGATE(t2amd_attention_step_fwd_f32(&at, stream));
+        return t2amd_attention_step_fwd_f32(&at, st);
+    };
+
+    if (g_dec_streams == 2) {
+        // chain A (caller's stream): LSTM_a(t) -> K_e(t) -> K_c(t);  chain D (side stream): LSTM_d(t), trailing
+        hipStream_t main_s = (hipStream_t)stream, side = nullptr;
+        if (!t2amd_validate_only_flag_()) T2_PROPAGATE(side_stream(&side));
+        size_t ev = 0;
+        T2_PROPAGATE(order_after(side, main_s, ev++));            // inputs (GA, weights, ...) are ready
+        for (int t0 = 0; t0 < To; t0 += T2_CHUNK) {
+            const int t1 = t0 + T2_CHUNK < To ? t0 + T2_CHUNK : To;
+            for (int t = t0; t < t1; ++t) {
+                t2amd_lstm_step a;
+                fill_a(t, a);
+                T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, main_s));
+                T2_PROPAGATE(attention(t, main_s));
+            }
+            T2_PROPAGATE(order_after(side, main_s, ev++));        // HA, CTX of this chunk exist
+            for (int t = t0; t < t1; ++t) {
+                t2amd_lstm_step d;
+                fill_d(t, d);
+                T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, side));
+            }
+        }
+        T2_PROPAGATE(order_after(main_s, side, ev++));            // join
+        return T2AMD_OK;
+    }
+
+    // Single stream, software-pipelined by one step: LSTM_d(t-1) shares one launch with LSTM_a(t).
+    for (int t = 0; t <= To; ++t) {
+        t2amd_lstm_step a = {}, d = {};
+        if (t < To) fill_a(t, a);
+        if (t > 0) fill_d(t - 1, d);
+        if (t == 0) {
+            T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
+        } else if (t == To) {
+            T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
+        } else {
+            d.tag = 3;     // the pair is profiled as role 3 (its symbol is skinny_gemm_kernel<true, 3>)
+            T2_PROPAGATE(t2amd_lstm_step_fwd2_f32(&d, &a, stream));
+        }
+        if (t == To) break;
+        T2_PROPAGATE(attention(t, stream));
     }
     return T2AMD_OK;
 }
@@ -121,12 +193,14 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     // The decoder-LSTM BPTT chain (cell backward -> dgrad GEMM) depends only on itself and on the
     // projection gradient; the attention chain consumes its dX one step later.  So the loop is
     // software-pipelined: cell_d(t-1) shares a launch with cell_a(t), dgrad_d(t-1) with dgrad_a(t).
+    // dXd is a per-step slab [To][ns][B][Kd]: the decoder-LSTM chain may run far ahead of its consumers.
+    const long long stepXd = (long long)ns * strXd;
     auto cell_d = [&](int t, t2amd_lstm_bwd& lb) {
         const bool last = (t == To - 1);
         lb = t2amd_lstm_bwd{};
         lb.B = B; lb.H = Hd;
         lb.dh[0] = addend(p->DHC + (long long)t * B * (Hd + E), Hd + E, 1, 0);
-        lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXd + Ha + E, Kd, ns, strXd);
+        lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXd + (t + 1) * stepXd + Ha + E, Kd, ns, strXd);
         lb.dh[2] = addend(nullptr, 0, 1, 0);
         lb.gates = f.GD + (long long)t * B * 4 * Hd; lb.ld_gates = 4 * Hd;
         lb.c_prev = t ? f.CD + (t - 1) * sHd : nullptr; lb.ld_cprev = Hd;
@@ -140,23 +214,14 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         g.nseg = 1;
         g.x[0] = seg(p->DGD + (long long)t * B * 4 * Hd, 4 * Hd, 4 * Hd);
         g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
-        g.Y = p->dXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
+        g.Y = p->dXd + t * stepXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
     };
-    {
-        t2amd_lstm_bwd lb;
-        cell_d(To - 1, lb);
-        T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, stream));
-        t2amd_skinny_gemm g;
-        dgrad_d(To - 1, g);
-        T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
-    }
-    for (int t = To - 1; t >= 0; --t) {
+    auto attn_bwd = [&](int t, void* st) -> int {        // needs dXd(t), dXa(t+1)
         const bool last = (t == To - 1);
-        // attention backward of step t (needs dXd(t), dXa(t+1))
         t2amd_attn_bwd ab = {};
         ab.B = B; ab.Ti = Ti; ab.E = E; ab.Hq = Ha;
         ab.dctx[0] = addend(p->DHC + (long long)t * B * (Hd + E) + Hd, Hd + E, 1, 0);
-        ab.dctx[1] = addend(p->dXd + Ha, Kd, ns, strXd);
+        ab.dctx[1] = addend(p->dXd + t * stepXd + Ha, Kd, ns, strXd);
         ab.dctx[2] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXa, Ka, ns, strXa);
         ab.dctx_total = p->DCTX + t * sE; ab.ld_dctx_total = E;
         ab.d_w_extra = p->d_align ? p->d_align + (long long)t * Ti : nullptr; ab.ld_dwextra = (long long)To * Ti;
@@ -169,12 +234,13 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;
-        T2_PROPAGATE(t2amd_attention_step_bwd_f32(&ab, stream));
-
-        // attention LSTM cell backward of step t  ||  decoder LSTM cell backward of step t-1
-        t2amd_lstm_bwd la = {};
+        return t2amd_attention_step_bwd_f32(&ab, st);
+    };
+    auto cell_a = [&](int t, t2amd_lstm_bwd& la) {
+        const bool last = (t == To - 1);
+        la = t2amd_lstm_bwd{};
         la.B = B; la.H = Ha;
-        la.dh[0] = addend(p->dXd, Kd, ns, strXd);
+        la.dh[0] = addend(p->dXd + t * stepXd, Kd, ns, strXd);
         la.dh[1] = addend(p->dq_h, Ha, T2AMD_ATT_SLICES, sHa);
         la.dh[2] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXa + E, Ka, ns, strXa);
         la.gates = f.GA + (long long)t * B * 4 * Ha; la.ld_gates = 4 * Ha;
@@ -183,25 +249,73 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         la.keep = f.keep_att ? f.keep_att + t * sHa : nullptr; la.ld_keep = Ha; la.keep_scale = f.scale_att;
         la.dc = p->dc_a; la.ld_dc = Ha;
         la.dgates = p->DGA + (long long)t * B * 4 * Ha; la.ld_dgates = 4 * Ha;
+    };
+    auto dgrad_a = [&](int t, t2amd_skinny_gemm& ga) {    // d[ctx_{t-1} | h_att_{t-1}] = dgates_a(t) . Wa_rec
+        ga = t2amd_skinny_gemm{};
+        ga.nseg = 1;
+        ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
+        ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
+        ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa; ga.tag = 1;
+    };
+
+    if (g_dec_streams == 2) {
+        // chain D (side stream, leads): cell_d(t) -> dgrad_d(t) for t = To-1 .. 0, nothing else feeds it;
+        // chain A (caller's stream): attention bwd -> cell_a -> dgrad_a, consuming dXd(t) a chunk behind.
+        hipStream_t main_s = (hipStream_t)stream, side = nullptr;
+        if (!t2amd_validate_only_flag_()) T2_PROPAGATE(side_stream(&side));
+        size_t ev = 0;
+        T2_PROPAGATE(order_after(side, main_s, ev++));            // DHC, zero fills, transposed weights are ready
+        for (int t0 = To - 1; t0 >= 0; t0 -= T2_CHUNK) {
+            const int t1 = t0 - T2_CHUNK + 1 > 0 ? t0 - T2_CHUNK + 1 : 0;
+            for (int t = t0; t >= t1; --t) {
+                t2amd_lstm_bwd lb;
+                cell_d(t, lb);
+                T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, side));
+                t2amd_skinny_gemm g;
+                dgrad_d(t, g);
+                T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, side));
+            }
+            T2_PROPAGATE(order_after(main_s, side, ev++));        // dXd of this chunk exists
+            for (int t = t0; t >= t1; --t) {
+                T2_PROPAGATE(attn_bwd(t, main_s));
+                t2amd_lstm_bwd la;
+                cell_a(t, la);
+                T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&la, main_s));
+                if (t > 0) {
+                    t2amd_skinny_gemm ga;
+                    dgrad_a(t, ga);
+                    T2_PROPAGATE(t2amd_skinny_gemm_f32(&ga, main_s));
+                }
+            }
+        }
+        return T2AMD_OK;      // the last wait above already ordered the caller's stream behind all of chain D
+    }
+
+    // Single stream, software-pipelined: cell_d(t-1) shares a launch with cell_a(t), dgrad_d(t-1) with dgrad_a(t).
+    {
+        t2amd_lstm_bwd lb;
+        cell_d(To - 1, lb);
+        T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, stream));
+        t2amd_skinny_gemm g;
+        dgrad_d(To - 1, g);
+        T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
+    }
+    for (int t = To - 1; t >= 0; --t) {
+        T2_PROPAGATE(attn_bwd(t, stream));
+        t2amd_lstm_bwd la;
+        cell_a(t, la);
         if (t > 0) {
             t2amd_lstm_bwd lb;
             cell_d(t - 1, lb);
             T2_PROPAGATE(t2amd_lstm_pointwise_bwd2_f32(&la, &lb, stream));
-        } else {
-            T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&la, stream));
-        }
-
-        // d[ctx_{t-1} | h_att_{t-1}] = dgates_a(t) . Wa_rec  ||  dgrad of the decoder LSTM, step t-1
-        if (t > 0) {
-            t2amd_skinny_gemm ga = {};
-            ga.nseg = 1;
-            ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
-            ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
-            ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa; ga.tag = 3;
-            t2amd_skinny_gemm gd;
+            t2amd_skinny_gemm ga, gd;
+            dgrad_a(t, ga);
             dgrad_d(t - 1, gd);
+            ga.tag = 3;
             gd.tag = 3;
             T2_PROPAGATE(t2amd_skinny_gemm2_f32(&gd, &ga, stream));
+        } else {
+            T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&la, stream));
         }
     }
     return T2AMD_OK;

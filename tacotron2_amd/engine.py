@@ -469,7 +469,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     bw.nsplit = ns
     out = dict(DGA=run.empty(To, B, 4 * Ha), DGD=run.empty(To, B, 4 * Hd), DCTX=run.empty(To, B, E),
                DQ=run.empty(To, B, A), d_pm=run.empty(B, Ti, A), dU_acc=run.empty(B, A, nv.LOC_TAPS),
-               dv_acc=run.empty(B, A), dXd=run.empty(ns, B, Ha + E + Hd), dXa=run.empty(ns, B, E + Ha),
+               dv_acc=run.empty(B, A), dXd=run.empty(To, ns, B, Ha + E + Hd), dXa=run.empty(ns, B, E + Ha),
                dc_a=run.empty(B, Ha), dc_d=run.empty(B, Hd), dwin_part=run.empty(nv.ATT_SLICES, B, 2, Ti),
                dcum_acc=run.empty(B, Ti), dq_h=run.empty(nv.ATT_SLICES, B, Ha))
     for k_, v_ in out.items():

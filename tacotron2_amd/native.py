@@ -196,6 +196,7 @@ SYMBOLS = [
     "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
+    "t2amd_set_decoder_streams",
 ]
 
 _P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
@@ -240,6 +241,7 @@ def _argtypes():
         "t2amd_decoder_infer_steps_f32": [pt(DecInfer), _P],
         "t2amd_struct_sizes": [pt(C.c_int), _I],
         "t2amd_set_validate_only": [_I],
+        "t2amd_set_decoder_streams": [_I],
         "t2amd_profile_enable": [_I, _I],
         "t2amd_profile_read": [pt(C.c_float), pt(C.c_int)],
     }
@@ -287,6 +289,11 @@ def load():
 
 
 _validate_only = False
+
+
+def set_decoder_streams(n):
+    """1 (default): single stream, fused launches; 2: decoder-LSTM chain of the training loops on a side stream."""
+    _check(load().t2amd_set_decoder_streams(int(n)), "t2amd_set_decoder_streams")
 
 
 def set_validate_only(on):
