@@ -205,3 +205,34 @@ def test_full_size_properties(native_lib):
     assert (align.sum(2) - 1).abs().max().item() < 1e-4
     ipad = torch.arange(Ti, device=DEV)[None, :] >= in_len[:, None]
     assert (align.permute(0, 2, 1)[ipad] == 0).all()
+
+
+def test_two_stream_loops_are_bitwise_identical(native_lib):
+    """t2amd_set_decoder_streams(2) moves the decoder-LSTM chain to a side stream with per-chunk events: the
+    arithmetic per element is unchanged, so outputs and every gradient must equal the single-stream run bit
+    for bit (a missing cross-stream dependency would show up here as a mismatch or a NaN)."""
+    from tacotron2_amd import native
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    fx = gu.load_fixture("default_train")
+    hp = gu.make_hparams(fx['hp'])
+    sd = gu.build_state_dict(hp, fx['seed'])
+    batch = gu.make_train_batch(fx['in_lens'], fx['out_lens'], hp.n_mel_channels, fx['seed'])
+    masks = gu.unpack_masks(fx['masks'])
+    res = []
+    try:
+        for mode in (1, 2, 2):
+            native.set_decoder_streams(mode)
+            model = _model(hp, sd).train()
+            model.dropout_masks = gu.masks_to_engine(masks, DEV)
+            x, y = model.parse_batch(tuple(t.clone() for t in batch))
+            out = model(x)
+            Tacotron2Loss()(out, y).backward()
+            torch.cuda.synchronize()
+            res.append(([o.detach().cpu() for o in out], {k: p.grad.cpu() for k, p in model.named_parameters()}))
+    finally:
+        native.set_decoder_streams(1)
+    for other in res[1:]:
+        for a, b in zip(res[0][0], other[0]):
+            assert torch.equal(a, b)
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], other[1][k]), k
