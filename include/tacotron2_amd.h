@@ -211,6 +211,26 @@ int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream);
  * t-1 with the attention LSTM of step t, neither depends on the other (reference model.py:352-371). */
 int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_lstm_step* b, void* stream);
 
+/* Small-batch (B <= 8) variants for free-running decode (reference model.py:418-454 at B = 1, BASELINE
+ * config 4): matrix-vector kernels bound by the weight stream instead of 64-row MFMA tiles. */
+int t2amd_lstm_step_small_f32(const t2amd_lstm_step* a, void* stream);
+typedef struct t2amd_small_linear {
+    const float* X;      /* [B][ldx] */
+    long long ldx;
+    const float* W;      /* [N][ldw], K-contiguous (nn.Linear layout), 16-byte aligned rows */
+    long long ldw;
+    const float* bias;   /* [N] or NULL */
+    float* Y;            /* [B][ldy] */
+    long long ldy;
+    int B, N, K;         /* B <= 8, K % 4 == 0 */
+    int act;             /* 0 none, 1 relu */
+    const uint8_t* keep; /* [B][ldkeep] or NULL */
+    long long ldkeep;
+    float keep_scale;
+} t2amd_small_linear;
+/* Y = act(X . W^T + bias) * keep * keep_scale   (Prenet linears model.py:99, projection + gate :373-378) */
+int t2amd_linear_small_f32(const t2amd_small_linear* a, void* stream);
+
 /* Y[s][B][N] = X[B][K-range s] . W[N][K]^T  (W K-contiguous), s < nsplit */
 typedef struct t2amd_skinny_gemm {
     t2amd_seg x[3];

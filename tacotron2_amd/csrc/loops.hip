@@ -425,12 +425,27 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         g1.B = p->W1; g1.ldb = C; g1.C = p->x_prenet; g1.ldc = P;
         g1.M = B; g1.N = P; g1.K = C; g1.a_kcontig = 1; g1.b_kcontig = 1; g1.batch = 1; g1.splitk = 1;
         g1.act = 1; g1.keep = p->keep_prenet + ((long long)t * 2 + 0) * sP; g1.ldkeep = P; g1.keep_scale = two;
-        T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
+        const bool small = B <= 8;        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
+        if (small) {
+            t2amd_small_linear l1 = {};
+            l1.X = g1.A; l1.ldx = g1.lda; l1.W = p->W1; l1.ldw = C; l1.Y = p->x_prenet; l1.ldy = P;
+            l1.B = B; l1.N = P; l1.K = C; l1.act = 1; l1.keep = g1.keep; l1.ldkeep = P; l1.keep_scale = two;
+            T2_PROPAGATE(t2amd_linear_small_f32(&l1, stream));
+        } else {
+            T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
+        }
         t2amd_gemm_desc g2 = {};
         g2.A = p->x_prenet; g2.lda = P; g2.B = p->W2; g2.ldb = P; g2.C = p->x_prenet + sP; g2.ldc = P;
         g2.M = B; g2.N = P; g2.K = P; g2.a_kcontig = 1; g2.b_kcontig = 1; g2.batch = 1; g2.splitk = 1;
         g2.act = 1; g2.keep = p->keep_prenet + ((long long)t * 2 + 1) * sP; g2.ldkeep = P; g2.keep_scale = two;
-        T2_PROPAGATE(t2amd_gemm_f32(&g2, stream));
+        if (small) {
+            t2amd_small_linear l2 = {};
+            l2.X = p->x_prenet; l2.ldx = P; l2.W = p->W2; l2.ldw = P; l2.Y = p->x_prenet + sP; l2.ldy = P;
+            l2.B = B; l2.N = P; l2.K = P; l2.act = 1; l2.keep = g2.keep; l2.ldkeep = P; l2.keep_scale = two;
+            T2_PROPAGATE(t2amd_linear_small_f32(&l2, stream));
+        } else {
+            T2_PROPAGATE(t2amd_gemm_f32(&g2, stream));
+        }
 
         // attention LSTM on [prenet | ctx_{t-1} | h_att_{t-1}]  (no dropout in eval)
         t2amd_lstm_step a = {};
@@ -445,7 +460,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         a.c_out = p->c_a + wr * sHa; a.ld_c = Ha;
         a.h_out = p->h_a + wr * sHa; a.ld_h = Ha;
         a.tag = 1;
-        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
+        T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&a, stream) : t2amd_lstm_step_fwd_f32(&a, stream));
 
         t2amd_attn_fwd at = {};
         at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
@@ -471,7 +486,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         d.c_out = p->c_d + wr * sHd; d.ld_c = Hd;
         d.h_out = p->hc + wr * sHC; d.ld_h = Hd + E;
         d.tag = 2;
-        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
+        T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&d, stream) : t2amd_lstm_step_fwd_f32(&d, stream));
 
         // frame + gate: PG[t] = [h_dec | ctx] . Wpg^T + bias
         t2amd_gemm_desc gp = {};
@@ -479,7 +494,14 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         gp.C = p->PG + (long long)t * sPG; gp.ldc = C + 1;
         gp.M = B; gp.N = C + 1; gp.K = Hd + E; gp.a_kcontig = 1; gp.b_kcontig = 1; gp.batch = 1; gp.splitk = 1;
         gp.bias = p->bias_pg;
-        T2_PROPAGATE(t2amd_gemm_f32(&gp, stream));
+        if (small) {
+            t2amd_small_linear lp = {};
+            lp.X = gp.A; lp.ldx = gp.lda; lp.W = p->Wpg; lp.ldw = Hd + E; lp.bias = p->bias_pg;
+            lp.Y = gp.C; lp.ldy = C + 1; lp.B = B; lp.N = C + 1; lp.K = Hd + E;
+            T2_PROPAGATE(t2amd_linear_small_f32(&lp, stream));
+        } else {
+            T2_PROPAGATE(t2amd_gemm_f32(&gp, stream));
+        }
 
         T2_LAUNCH(infer_finish_step_kernel, dim3(t2_cdiv(B, 64)), dim3(64), 0, s, p->PG + (long long)t * sPG, B,
                            C, t, p->max_steps, p->gate_threshold, p->out_lengths, p->active, p->done_count);

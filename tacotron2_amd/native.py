@@ -161,6 +161,15 @@ class LstmSeq(C.Structure):
     ]
 
 
+class SmallLinear(C.Structure):
+    _fields_ = [
+        ("X", _f32p), ("ldx", _i64), ("W", _f32p), ("ldw", _i64), ("bias", _f32p),
+        ("Y", _f32p), ("ldy", _i64),
+        ("B", C.c_int), ("N", C.c_int), ("K", C.c_int), ("act", C.c_int),
+        ("keep", C.c_void_p), ("ldkeep", _i64), ("keep_scale", C.c_float),
+    ]
+
+
 class DecInfer(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("Ti", C.c_int), ("E", C.c_int), ("Ha", C.c_int), ("Hd", C.c_int),
@@ -178,7 +187,7 @@ class DecInfer(C.Structure):
 
 
 _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnBwd, DecTrain,
-            DecTrainBwd, LstmSeq, DecInfer]
+            DecTrainBwd, LstmSeq, DecInfer, SmallLinear]
 
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
@@ -196,7 +205,7 @@ SYMBOLS = [
     "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
-    "t2amd_set_decoder_streams",
+    "t2amd_set_decoder_streams", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
 ]
 
 _P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
@@ -242,6 +251,8 @@ def _argtypes():
         "t2amd_struct_sizes": [pt(C.c_int), _I],
         "t2amd_set_validate_only": [_I],
         "t2amd_set_decoder_streams": [_I],
+        "t2amd_lstm_step_small_f32": [pt(LstmStep), _P],
+        "t2amd_linear_small_f32": [pt(SmallLinear), _P],
         "t2amd_profile_enable": [_I, _I],
         "t2amd_profile_read": [pt(C.c_float), pt(C.c_int)],
     }
@@ -602,7 +613,7 @@ def _seg(t, width):
 
 
 def lstm_step_fwd(xs, widths, W, H, B, gates_out, c_out, h_out, gin=None, bias=None, c_prev=None,
-                  keep=None, keep_scale=1.0, lens=None, t=0):
+                  keep=None, keep_scale=1.0, lens=None, t=0, small=False):
     lib = load()
     a = LstmStep()
     a.nseg = len(xs)
@@ -622,7 +633,26 @@ def lstm_step_fwd(xs, widths, W, H, B, gates_out, c_out, h_out, gin=None, bias=N
         a.keep, a.ld_keep, a.keep_scale = ptr(keep, torch.uint8), keep.stride(0), keep_scale
     a.lens = ptr(lens, torch.int32)
     a.t = t
-    _check(lib.t2amd_lstm_step_fwd_f32(C.byref(a), _stream()), "t2amd_lstm_step_fwd_f32")
+    if small:
+        _check(lib.t2amd_lstm_step_small_f32(C.byref(a), _stream()), "t2amd_lstm_step_small_f32")
+    else:
+        _check(lib.t2amd_lstm_step_fwd_f32(C.byref(a), _stream()), "t2amd_lstm_step_fwd_f32")
+
+
+def linear_small(X, W, Y, bias=None, act=0, keep=None, keep_scale=1.0):
+    """Y[B,N] = act(X[B,K] . W[N,K]^T + bias) * keep, B <= 8 (matrix-vector kernel)."""
+    lib = load()
+    a = SmallLinear()
+    a.X, a.ldx, Bx, K = _mat(X)
+    a.W, a.ldw, N, Kw = _mat(W)
+    a.Y, a.ldy, By, Ny = _mat(Y)
+    if K != Kw or N != Ny or Bx != By:
+        raise NativeError("linear_small: shape mismatch")
+    a.B, a.N, a.K, a.act = Bx, N, K, act
+    a.bias = ptr(bias)
+    if keep is not None:
+        a.keep, a.ldkeep, a.keep_scale = ptr(keep, torch.uint8), keep.stride(0), keep_scale
+    _check(lib.t2amd_linear_small_f32(C.byref(a), _stream()), "t2amd_linear_small_f32")
 
 
 def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1):

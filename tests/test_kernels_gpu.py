@@ -445,3 +445,44 @@ def test_attention_no_mask_and_first_step(nv):
     nv.attention_step_fwd(dv(h), Wq, U, dv(sd['decoder.attention_layer.v.linear_layer.weight']).view(-1), dv(pm), dv(mem),
                           None, None, cum_d, None, w_out, ctx_out, None, ws)
     assert err(w_out, w) < 1e-5 and err(ctx_out, ctx) < 1e-5 and err(cum_d, w) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# small-batch (B <= 8) decode kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 8])
+def test_small_batch_lstm_step_and_linear(nv, B):
+    H, widths = 256, (256, 512, 64)
+    K = sum(widths)
+    xs = [rnd(B, w, seed=100 + i) for i, w in enumerate(widths)]
+    W, gin, bias = rnd(4 * H, K, seed=104, scale=0.05), rnd(B, 4 * H, seed=105), rnd(4 * H, seed=106)
+    c_prev = rnd(B, H, seed=107)
+    pre = torch.cat(xs, 1) @ W.t() + gin + bias
+    i, f, g, o = pre.chunk(4, 1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c = f * c_prev + i * g
+    h = o * torch.tanh(c)
+    gates = torch.full((B, 4 * H), float('nan'), device=DEV)
+    c_out, h_out = torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+    xd = [dv(x) for x in xs]
+    nv.lstm_step_fwd(xd, list(widths), dv(W), H, B, gates, c_out, h_out, gin=dv(gin), bias=dv(bias),
+                     c_prev=dv(c_prev), small=True)
+    assert err(gates, torch.cat((i, f, g, o), 1)) < 1e-5
+    assert err(c_out, c) < 1e-5 and err(h_out, h) < 1e-5
+    # absent middle segment = zeros; the MFMA kernel must agree with the matrix-vector kernel
+    g2, c2, h2 = torch.empty_like(gates), torch.empty_like(c_out), torch.empty_like(h_out)
+    nv.lstm_step_fwd([xd[0], None, xd[2]], list(widths), dv(W), H, B, gates, c_out, h_out, bias=dv(bias), small=True)
+    nv.lstm_step_fwd([xd[0], None, xd[2]], list(widths), dv(W), H, B, g2, c2, h2, bias=dv(bias))
+    assert err(gates, g2) < 1e-5 and err(h_out, h2) < 1e-5
+    # plain linear with a ragged N, an unaligned input row stride (81 floats, like the PG slab), relu + mask
+    N, Kl = 81, 80
+    Xbig = rnd(B, 81, seed=110)
+    Wl, bl = rnd(N, Kl, seed=111), rnd(N, seed=112)
+    keep = (torch.rand(B, N, generator=G(113)) >= 0.5).to(torch.uint8)
+    Xd = dv(Xbig)
+    Y = torch.full((B, N), float('nan'), device=DEV)
+    nv.linear_small(Xd[:, :Kl], dv(Wl), Y, bias=dv(bl), act=1, keep=dv(keep), keep_scale=2.0)
+    assert err(Y, torch.relu(Xbig[:, :Kl] @ Wl.t() + bl) * keep * 2.0) < 1e-5
+    Y2 = torch.empty(B, N, device=DEV)
+    nv.linear_small(Xd[:, :Kl], dv(Wl), Y2)
+    assert err(Y2, Xbig[:, :Kl] @ Wl.t()) < 1e-5
