@@ -203,7 +203,13 @@ typedef struct t2amd_lstm_step {
     float keep_scale;
     const int* lens;    /* NULL, or per-row valid length: rows with t >= lens[b] write h=c=gates=0 */
     int t;
-    int tag;            /* kernel-symbol / profiling role: 0 generic, 1 attention LSTM, 2 decoder LSTM */
+    int tag;            /* kernel-symbol / profiling role: 0 generic, 1 attention LSTM, 2 decoder LSTM, 3 fused pair */
+    /* bf16 operand mode: x[i].p and W point at bf16 (widths / ld / Ktot count ELEMENTS, widths multiples of 128);
+     * the product runs on v_mfma_f32_16x16x32_bf16 with f32 accumulation; gin, bias, cell state and all f32
+     * outputs are unchanged.  h16_out (optional) receives a bf16 copy of h, the next step's operand. */
+    int bf16;
+    void* h16_out;
+    long long ld_h16;
 } t2amd_lstm_step;
 
 int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream);
@@ -242,6 +248,7 @@ typedef struct t2amd_skinny_gemm {
     int nsplit;
     long long split_stride;
     int tag;          /* kernel-symbol role, as in t2amd_lstm_step */
+    int bf16;         /* 1: x[i].p and W are bf16 (see t2amd_lstm_step) */
 } t2amd_skinny_gemm;
 
 int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream);
@@ -272,6 +279,8 @@ typedef struct t2amd_lstm_bwd {
     long long ld_dgates;
     const int* lens;
     int t;
+    void* dgates16;       /* optional bf16 copy of dgates (bf16 operand mode of the dgrad GEMM) */
+    long long ld_dgates16;
 } t2amd_lstm_bwd;
 
 int t2amd_lstm_pointwise_bwd_f32(const t2amd_lstm_bwd* a, void* stream);

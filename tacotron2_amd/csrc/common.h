@@ -54,6 +54,13 @@ extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s);
         if (rc_ != T2AMD_OK) return rc_;                                               \
     } while (0)
 
+// f32 -> bf16 bits, round to nearest even
+__device__ __forceinline__ unsigned short t2_f32_to_bf16(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
 __device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {

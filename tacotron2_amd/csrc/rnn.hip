@@ -24,6 +24,7 @@
 #define SK_XT (SK_ROWS * SK_BK)   // floats per X tile
 #define SK_WT (16 * SK_BK)        // floats per W tile
 
+typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) const void* t2_gptr;
 typedef __attribute__((address_space(3))) void* t2_lptr;
 
@@ -41,6 +42,7 @@ struct SkinnyParams {
     float* gates_out; long long ld_gates;
     float* c_out; long long ld_c;
     float* h_out; long long ld_h;
+    unsigned short* h16_out; long long ld_h16;   // optional bf16 copy of h (the next step's MFMA operand)
     const uint8_t* keep; long long ld_keep; float keep_scale;
     const int* lens; int t;
     // plain epilogue
@@ -57,8 +59,14 @@ struct SkinnyDual { SkinnyParams p[2]; int nblk0; };
 
 // TAG only gives each role its own kernel symbol, so that rocprofv3 --kernel-trace --stats reports
 // the decoder's attention-LSTM (1) / decoder-LSTM (2) launches separately from the rest (0).
-template <bool LSTM, int TAG>
+// BF = true: the activation segments and W hold bf16 (widths, ld, Ktot in ELEMENTS); a 256-byte tile row is
+// then 128 k, one 16-byte chunk is one v_mfma_f32_16x16x32_bf16 fragment, and everything byte-shaped (DMA,
+// LDS image, swizzle, fragment reads) is unchanged.  Accumulation, cell state and all outputs stay f32.
+template <bool LSTM, int TAG, bool BF>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
+    constexpr int ES = BF ? 2 : 4;          // bytes per operand element
+    constexpr int BK = 256 / ES;            // k per tile (tile rows are 256 bytes)
+    constexpr int EPC = 16 / ES;            // elements per 16-byte chunk
     // ONE shared array (a second __shared__ object makes hipcc drain the DMA queue before every ds_read)
     __shared__ __attribute__((aligned(16))) float smem[SK_NBUF * (SK_XT + SK_WT) + SK_ROWS * 17];
     float* const Xs = smem;                               // [NBUF][64][64]
@@ -80,9 +88,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
     const int B = p.B;
 
     // Virtual k-tiles: absent (all-zero) segments contribute nothing and are skipped outright.
-    const int n0 = p.x[0].p ? p.x[0].width / SK_BK : 0;
-    const int n1 = (p.nseg > 1 && p.x[1].p) ? p.x[1].width / SK_BK : 0;
-    const int n2 = (p.nseg > 2 && p.x[2].p) ? p.x[2].width / SK_BK : 0;
+    const int n0 = p.x[0].p ? p.x[0].width / BK : 0;
+    const int n1 = (p.nseg > 1 && p.x[1].p) ? p.x[1].width / BK : 0;
+    const int n2 = (p.nseg > 2 && p.x[2].p) ? p.x[2].width / BK : 0;
     const int wo1 = p.x[0].width, wo2 = p.x[0].width + (p.nseg > 1 ? p.x[1].width : 0);
     const int nvt = n0 + n1 + n2;
     int kt_beg = 0, kt_end = nvt;
@@ -123,10 +131,10 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
         const int r = 16 * wave + 4 * i + lg;
         int gr = rowbase + r;
         if (gr > B - 1) gr = B - 1;
-        const int c4 = 4 * (l15 ^ (r & 15));
-        xo0[i] = (long long)gr * p.x[0].ld + c4;
-        xo1[i] = (long long)gr * p.x[1].ld + c4;
-        xo2[i] = (long long)gr * p.x[2].ld + c4;
+        const int c4 = EPC * (l15 ^ (r & 15));
+        xo0[i] = ((long long)gr * p.x[0].ld + c4) * ES;      // byte offsets
+        xo1[i] = ((long long)gr * p.x[1].ld + c4) * ES;
+        xo2[i] = ((long long)gr * p.x[2].ld + c4) * ES;
     }
     // W: this wave fills weight-tile rows 4*wave + lg.  Rows past N (plain kernel, ragged last block)
     // are clamped: their columns are never stored.
@@ -140,36 +148,39 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
             wrow = (long long)bx * 16 + c;
             if (wrow > p.N - 1) wrow = p.N - 1;
         }
-        wo = wrow * p.Ktot + 4 * (l15 ^ (c & 15));
+        wo = (wrow * p.Ktot + EPC * (l15 ^ (c & 15))) * ES;   // bytes
     }
-    const float* const Wp = p.W + wo;
+    const char* const Wp = reinterpret_cast<const char*>(p.W) + wo;
+    const char* const xp0 = reinterpret_cast<const char*>(p.x[0].p);
+    const char* const xp1 = reinterpret_cast<const char*>(p.x[1].p);
+    const char* const xp2 = reinterpret_cast<const char*>(p.x[2].p);
     const int kt_last = kt_end - 1;
 
     // Running DMA source pointers: the tile sequence only moves forward (and sticks at the last tile),
     // so each issue is five DMA instructions plus five pointer bumps; the segment switch is a rare,
     // wave-uniform branch.  iss_seg/iss_rem: segment of the next tile to issue / tiles left in it.
-    const float* xq0; const float* xq1; const float* xq2; const float* xq3; const float* wq;
+    const char* xq0; const char* xq1; const char* xq2; const char* xq3; const char* wq;   // byte pointers
     int iss_kt = kt_beg, iss_seg = 0, iss_rem = 0;
     // position the pointers on tile LOCAL of segment SEG (wave-uniform arguments; static array indices only)
 #define SK_SEEK(SEG, LOCAL)                                                                            \
     {                                                                                                  \
         const int seg_ = (SEG), loc_ = (LOCAL);                                                        \
         if (seg_ == 0) {                                                                               \
-            const float* sp_ = p.x[0].p + loc_ * SK_BK;                                                \
+            const char* sp_ = xp0 + loc_ * 256;                                                        \
             xq0 = sp_ + xo0[0]; xq1 = sp_ + xo0[1]; xq2 = sp_ + xo0[2]; xq3 = sp_ + xo0[3];            \
-            wq = Wp + loc_ * SK_BK; iss_rem = n0 - loc_;                                               \
+            wq = Wp + loc_ * 256; iss_rem = n0 - loc_;                                                 \
         } else if (seg_ == 1) {                                                                        \
-            const float* sp_ = p.x[1].p + loc_ * SK_BK;                                                \
+            const char* sp_ = xp1 + loc_ * 256;                                                        \
             xq0 = sp_ + xo1[0]; xq1 = sp_ + xo1[1]; xq2 = sp_ + xo1[2]; xq3 = sp_ + xo1[3];            \
-            wq = Wp + wo1 + loc_ * SK_BK; iss_rem = n1 - loc_;                                         \
+            wq = Wp + wo1 * ES + loc_ * 256; iss_rem = n1 - loc_;                                      \
         } else {                                                                                       \
-            const float* sp_ = p.x[2].p + loc_ * SK_BK;                                                \
+            const char* sp_ = xp2 + loc_ * 256;                                                        \
             xq0 = sp_ + xo2[0]; xq1 = sp_ + xo2[1]; xq2 = sp_ + xo2[2]; xq3 = sp_ + xo2[3];            \
-            wq = Wp + wo2 + loc_ * SK_BK; iss_rem = n2 - loc_;                                         \
+            wq = Wp + wo2 * ES + loc_ * 256; iss_rem = n2 - loc_;                                      \
         }                                                                                              \
         iss_seg = seg_;                                                                                \
     }
-    xq0 = xq1 = xq2 = xq3 = wq = p.W;
+    xq0 = xq1 = xq2 = xq3 = wq = reinterpret_cast<const char*>(p.W);
     if (kt_end > kt_beg) {
         if (kt_beg < n0) SK_SEEK(0, kt_beg)
         else if (kt_beg < n0 + n1) SK_SEEK(1, kt_beg - n0)
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
         if (iss_kt < kt_last) {                                                                        \
             ++iss_kt;                                                                                  \
             if (--iss_rem > 0) {                                                                       \
-                xq0 += SK_BK; xq1 += SK_BK; xq2 += SK_BK; xq3 += SK_BK; wq += SK_BK;                   \
+                xq0 += 256; xq1 += 256; xq2 += 256; xq3 += 256; wq += 256;                             \
             } else if (iss_seg == 0 && n1 > 0) {                                                       \
                 SK_SEEK(1, 0)                                                                          \
             } else {                                                                                   \
@@ -238,12 +249,17 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
                  : "+v"(X0), "+v"(X1), "+v"(X2), "+v"(X3), "+v"(W0), "+v"(W1), "+v"(W2), "+v"(W3)      \
                  :                                                                                     \
                  : "memory");
-#define SK_FMA4(X, W)                                                                                  \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[0], (W)[0], acc0, 0, 0, 0);                        \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[1], (W)[1], acc1, 0, 0, 0);                        \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[2], (W)[2], acc0, 0, 0, 0);                        \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[3], (W)[3], acc1, 0, 0, 0);
-#define SK_FMA(X0, X1, X2, X3, W0, W1, W2, W3) SK_FMA4(X0, W0) SK_FMA4(X1, W1) SK_FMA4(X2, W2) SK_FMA4(X3, W3)
+#define SK_FMA4(X, W, ACC)                                                                             \
+    if constexpr (BF) {                                                                                \
+        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, (X)),              \
+                                                      __builtin_bit_cast(sk_bf16x8, (W)), ACC, 0, 0, 0); \
+    } else {                                                                                           \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[0], (W)[0], acc0, 0, 0, 0);                    \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[1], (W)[1], acc1, 0, 0, 0);                    \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[2], (W)[2], acc0, 0, 0, 0);                    \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((X)[3], (W)[3], acc1, 0, 0, 0);                    \
+    }
+#define SK_FMA(X0, X1, X2, X3, W0, W1, W2, W3) SK_FMA4(X0, W0, acc0) SK_FMA4(X1, W1, acc1) SK_FMA4(X2, W2, acc0) SK_FMA4(X3, W3, acc1)
 #define SK_SETA fa0, fa1, fa2, fa3, ga0, ga1, ga2, ga3
 #define SK_SETB fb0, fb1, fb2, fb3, gb0, gb1, gb2, gb3
 #define SK_X(M, ...) M(__VA_ARGS__)
@@ -346,14 +362,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
     go_[3 * H + ej] = go;
     p.c_out[(long long)egr * p.ld_c + ej] = cn;
     p.h_out[(long long)egr * p.ld_h + ej] = hn;
+    if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
 }
 
-static int check_segs(const t2amd_seg* x, int nseg, int Ktot) {
+static int check_segs(const t2amd_seg* x, int nseg, int Ktot, int bk) {
     if (nseg < 1 || nseg > 3) T2_FAIL("skinny: nseg must be 1..3");
     int sum = 0;
     for (int i = 0; i < nseg; ++i) {
-        if (x[i].width <= 0 || x[i].width % SK_BK != 0) T2_FAIL("skinny: segment widths must be positive multiples of 64");
-        if (x[i].p && (!t2_aligned16(x[i].p) || x[i].ld % 4 != 0)) T2_FAIL("skinny: segment must be 16-byte aligned with ld % 4 == 0");
+        if (x[i].width <= 0 || x[i].width % bk != 0) T2_FAIL("skinny: segment widths must be positive multiples of 64 (f32) / 128 (bf16)");
+        if (x[i].p && (!t2_aligned16(x[i].p) || x[i].ld % 8 != 0)) T2_FAIL("skinny: segment must be 16-byte aligned with ld % 8 == 0");
         sum += x[i].width;
     }
     if (sum != Ktot) T2_FAIL("skinny: segment widths do not add up to Ktot");
@@ -362,7 +379,7 @@ static int check_segs(const t2amd_seg* x, int nseg, int Ktot) {
 
 static int fill_lstm(const t2amd_lstm_step* a, SkinnyParams& p) {
     T2_REQUIRE(a != nullptr, "lstm_step: null args");
-    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot));
+    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot, a->bf16 ? 128 : 64));
     T2_REQUIRE(a->W && t2_aligned16(a->W), "lstm_step: W must be 16-byte aligned");
     T2_REQUIRE(a->H > 0 && a->H % 4 == 0 && a->B > 0, "lstm_step: H must be a multiple of 4");
     T2_REQUIRE(a->gates_out && a->c_out && a->h_out, "lstm_step: null outputs");
@@ -374,6 +391,7 @@ static int fill_lstm(const t2amd_lstm_step* a, SkinnyParams& p) {
     p.c_prev = a->c_prev; p.ld_cprev = a->ld_cprev;
     p.gates_out = a->gates_out; p.ld_gates = a->ld_gates;
     p.c_out = a->c_out; p.ld_c = a->ld_c; p.h_out = a->h_out; p.ld_h = a->ld_h;
+    p.h16_out = (unsigned short*)a->h16_out; p.ld_h16 = a->ld_h16;
     p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     p.lens = a->lens; p.t = a->t;
     p.gx = a->H / 4; p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = 1;
@@ -395,10 +413,18 @@ extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_ls
     }
     hipStream_t s = (hipStream_t)stream;
     t2amd_profile_mark_(a->tag, 0, s);
-    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1>), dim3(total), dim3(256), 0, s, d);
-    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2>), dim3(total), dim3(256), 0, s, d);
-    else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<true, 3>), dim3(total), dim3(256), 0, s, d);
-    else T2_LAUNCH((skinny_gemm_kernel<true, 0>), dim3(total), dim3(256), 0, s, d);
+    T2_REQUIRE(!b || (a->bf16 != 0) == (b->bf16 != 0), "lstm_step: both problems of a launch must share the operand type");
+    if (a->bf16) {
+        if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1, true>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2, true>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<true, 3, true>), dim3(total), dim3(256), 0, s, d);
+        else T2_LAUNCH((skinny_gemm_kernel<true, 0, true>), dim3(total), dim3(256), 0, s, d);
+    } else {
+        if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1, false>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2, false>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<true, 3, false>), dim3(total), dim3(256), 0, s, d);
+        else T2_LAUNCH((skinny_gemm_kernel<true, 0, false>), dim3(total), dim3(256), 0, s, d);
+    }
     t2amd_profile_mark_(a->tag, 1, s);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -410,7 +436,7 @@ extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
 
 static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     T2_REQUIRE(a != nullptr, "skinny_gemm: null args");
-    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot));
+    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot, a->bf16 ? 128 : 64));
     T2_REQUIRE(a->W && t2_aligned16(a->W) && a->Y, "skinny_gemm: bad pointers");
     T2_REQUIRE(a->N > 0 && a->B > 0 && a->nsplit >= 1, "skinny_gemm: bad dims");
     p = SkinnyParams{};
@@ -418,7 +444,7 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     p.nseg = a->nseg;
     p.W = a->W; p.Ktot = a->Ktot; p.B = a->B; p.N = a->N; p.H = 0;
     p.Y = a->Y; p.ldy = a->ldy; p.nsplit = a->nsplit; p.split_stride = a->split_stride;
-    const int ktiles = a->Ktot / SK_BK;
+    const int ktiles = a->Ktot / (a->bf16 ? 128 : 64);
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     p.gx = t2_cdiv(a->N, 16); p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = a->nsplit;
     return T2AMD_OK;
@@ -436,10 +462,18 @@ extern "C" int t2amd_skinny_gemm2_f32(const t2amd_skinny_gemm* a, const t2amd_sk
         d.p[1] = d.p[0];
     }
     hipStream_t s = (hipStream_t)stream;
-    if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1>), dim3(total), dim3(256), 0, s, d);
-    else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2>), dim3(total), dim3(256), 0, s, d);
-    else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<false, 3>), dim3(total), dim3(256), 0, s, d);
-    else T2_LAUNCH((skinny_gemm_kernel<false, 0>), dim3(total), dim3(256), 0, s, d);
+    T2_REQUIRE(!b || (a->bf16 != 0) == (b->bf16 != 0), "skinny_gemm: both problems of a launch must share the operand type");
+    if (a->bf16) {
+        if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1, true>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2, true>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<false, 3, true>), dim3(total), dim3(256), 0, s, d);
+        else T2_LAUNCH((skinny_gemm_kernel<false, 0, true>), dim3(total), dim3(256), 0, s, d);
+    } else {
+        if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1, false>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2, false>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<false, 3, false>), dim3(total), dim3(256), 0, s, d);
+        else T2_LAUNCH((skinny_gemm_kernel<false, 0, false>), dim3(total), dim3(256), 0, s, d);
+    }
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -479,6 +513,10 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
     if (a.lens) valid = a.t < a.lens[b];
     if (!valid) {
         dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
+        if (a.dgates16) {
+            unsigned short* d16 = reinterpret_cast<unsigned short*>(a.dgates16) + (long long)b * a.ld_dgates16;
+            d16[j] = 0; d16[H + j] = 0; d16[2 * H + j] = 0; d16[3 * H + j] = 0;
+        }
         *dcp = 0.f;
         return;
     }
@@ -494,10 +532,19 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
     const float tc = tanhf(c);
     const float d_o = dh * tc;
     const float dc = dc_in + dh * go * (1.f - tc * tc);
-    dg[j] = dc * gg * gi * (1.f - gi);
-    dg[H + j] = dc * cprev * gf * (1.f - gf);
-    dg[2 * H + j] = dc * gi * (1.f - gg * gg);
-    dg[3 * H + j] = d_o * go * (1.f - go);
+    const float d0 = dc * gg * gi * (1.f - gi), d1 = dc * cprev * gf * (1.f - gf);
+    const float d2 = dc * gi * (1.f - gg * gg), d3 = d_o * go * (1.f - go);
+    dg[j] = d0;
+    dg[H + j] = d1;
+    dg[2 * H + j] = d2;
+    dg[3 * H + j] = d3;
+    if (a.dgates16) {       // bf16 copy: the dgrad GEMM's MFMA operand in bf16 mode
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(a.dgates16) + (long long)b * a.ld_dgates16;
+        d16[j] = t2_f32_to_bf16(d0);
+        d16[H + j] = t2_f32_to_bf16(d1);
+        d16[2 * H + j] = t2_f32_to_bf16(d2);
+        d16[3 * H + j] = t2_f32_to_bf16(d3);
+    }
     *dcp = dc * gf;
 }
 

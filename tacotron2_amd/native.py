@@ -61,6 +61,7 @@ class LstmStep(C.Structure):
         ("h_out", _f32p), ("ld_h", _i64),
         ("keep", C.c_void_p), ("ld_keep", _i64), ("keep_scale", C.c_float),
         ("lens", C.c_void_p), ("t", C.c_int), ("tag", C.c_int),
+        ("bf16", C.c_int), ("h16_out", C.c_void_p), ("ld_h16", _i64),
     ]
 
 
@@ -69,6 +70,7 @@ class SkinnyGemm(C.Structure):
         ("x", Seg * 3), ("nseg", C.c_int),
         ("W", _f32p), ("Ktot", C.c_int), ("N", C.c_int), ("B", C.c_int),
         ("Y", _f32p), ("ldy", _i64), ("nsplit", C.c_int), ("split_stride", _i64), ("tag", C.c_int),
+        ("bf16", C.c_int),
     ]
 
 
@@ -87,6 +89,7 @@ class LstmBwd(C.Structure):
         ("dc", _f32p), ("ld_dc", _i64),
         ("dgates", _f32p), ("ld_dgates", _i64),
         ("lens", C.c_void_p), ("t", C.c_int),
+        ("dgates16", C.c_void_p), ("ld_dgates16", _i64),
     ]
 
 
@@ -355,13 +358,13 @@ def ptr(t, dtype=torch.float32):
     return C.c_void_p(t.data_ptr())
 
 
-def _mat(t):
+def _mat(t, dtype=torch.float32):
     """2-D view with unit inner stride -> (ptr, ld, rows, cols)."""
     if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
         raise NativeError("expected a 2-D tensor with contiguous rows, got shape %s stride %s"
                           % (tuple(t.shape), t.stride()))
     ld = t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
-    return ptr(t), ld, t.shape[0], t.shape[1]
+    return ptr(t, dtype), ld, t.shape[0], t.shape[1]
 
 
 def _fullc(t):
@@ -601,25 +604,30 @@ def relu_dropout_bwd(dy, y, scale):
 # ----------------------------------------------------------------------------
 # recurrent / attention single steps (used by the unit tests; the loops call them in C)
 # ----------------------------------------------------------------------------
-def _seg(t, width):
+def _seg(t, width, dtype=torch.float32):
     s = Seg()
     if t is None:
         s.p, s.ld, s.width = None, width, width
     else:
-        p, ld, _, cols = _mat(t)
+        p, ld, _, cols = _mat(t, dtype)
         assert cols == width
         s.p, s.ld, s.width = p, ld, width
     return s
 
 
 def lstm_step_fwd(xs, widths, W, H, B, gates_out, c_out, h_out, gin=None, bias=None, c_prev=None,
-                  keep=None, keep_scale=1.0, lens=None, t=0, small=False):
+                  keep=None, keep_scale=1.0, lens=None, t=0, small=False, bf16=False, h16_out=None):
+    """``bf16=True``: xs and W are torch.bfloat16 (MFMA operands), everything else stays f32."""
     lib = load()
     a = LstmStep()
     a.nseg = len(xs)
+    odt = torch.bfloat16 if bf16 else torch.float32
     for i, (x, w) in enumerate(zip(xs, widths)):
-        a.x[i] = _seg(x, w)
-    a.W = ptr(_fullc(W))
+        a.x[i] = _seg(x, w, odt)
+    a.W = ptr(_fullc(W), odt)
+    a.bf16 = 1 if bf16 else 0
+    if h16_out is not None:
+        a.h16_out, a.ld_h16 = _mat(h16_out, torch.bfloat16)[:2]
     a.Ktot, a.H, a.B = sum(widths), H, B
     if gin is not None:
         a.gin, a.ld_gin = _mat(gin)[:2]
@@ -655,14 +663,16 @@ def linear_small(X, W, Y, bias=None, act=0, keep=None, keep_scale=1.0):
     _check(lib.t2amd_linear_small_f32(C.byref(a), _stream()), "t2amd_linear_small_f32")
 
 
-def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1):
+def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1, bf16=False):
     """Y[nsplit, B, N] = [xs...] . W[N, K]^T"""
     lib = load()
     a = SkinnyGemm()
     a.nseg = len(xs)
+    odt = torch.bfloat16 if bf16 else torch.float32
     for i, (x, w) in enumerate(zip(xs, widths)):
-        a.x[i] = _seg(x, w)
-    a.W = ptr(_fullc(W))
+        a.x[i] = _seg(x, w, odt)
+    a.W = ptr(_fullc(W), odt)
+    a.bf16 = 1 if bf16 else 0
     a.Ktot, a.N, a.B = sum(widths), N, B
     _fullc(Y)
     a.Y, a.ldy, a.nsplit, a.split_stride = ptr(Y), N, nsplit, B * N

@@ -486,3 +486,38 @@ def test_small_batch_lstm_step_and_linear(nv, B):
     Y2 = torch.empty(B, N, device=DEV)
     nv.linear_small(Xd[:, :Kl], dv(Wl), Y2)
     assert err(Y2, Xbig[:, :Kl] @ Wl.t()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 operand mode of the recurrent kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,widths", [(64, 256, (256, 128, 256)), (37, 128, (128,)), (3, 64, (128, 256))])
+def test_lstm_step_bf16_operands(nv, B, H, widths):
+    """bf16 X and W on v_mfma_f32_16x16x32_bf16, f32 accumulate / cell: must equal an f32 product of the
+    bf16-ROUNDED operands to f32 summation-order accuracy (products of bf16 values are exact in f32)."""
+    K = sum(widths)
+    xs = [rnd(B, w, seed=120 + i).bfloat16() for i, w in enumerate(widths)]
+    W = (rnd(4 * H, K, seed=124, scale=0.05) * (1 + torch.arange(4 * H).float().unsqueeze(1) / H)).bfloat16()
+    gin, bias, c_prev = rnd(B, 4 * H, seed=125), rnd(4 * H, seed=126), rnd(B, H, seed=127)
+    pre = torch.cat([x.float() for x in xs], 1) @ W.float().t() + gin + bias
+    i, f, g, o = pre.chunk(4, 1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c = f * c_prev + i * g
+    h = o * torch.tanh(c)
+    gates = torch.full((B, 4 * H), float('nan'), device=DEV)
+    c_out, h_out = torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+    h16 = torch.empty(B, H, device=DEV, dtype=torch.bfloat16)
+    nv.lstm_step_fwd([x.to(DEV) for x in xs], list(widths), W.to(DEV), H, B, gates, c_out, h_out, gin=dv(gin), bias=dv(bias),
+                     c_prev=dv(c_prev), bf16=True, h16_out=h16)
+    assert err(gates, torch.cat((i, f, g, o), 1)) < 1e-5
+    assert err(c_out, c) < 1e-5 and err(h_out, h) < 1e-5
+    assert torch.equal(h16.cpu(), h_out.cpu().bfloat16())
+    # plain (dgrad-shaped) product with split-K
+    N = 200
+    W2 = rnd(N, K, seed=128, scale=0.1).bfloat16()
+    for ns in (1, 2):
+        if (K // 128) % ns:
+            continue
+        Y = torch.empty(ns, B, N, device=DEV)
+        nv.skinny_gemm([x.to(DEV) for x in xs], list(widths), W2.to(DEV), N, B, Y, nsplit=ns, bf16=True)
+        assert err(Y.sum(0), torch.cat([x.float() for x in xs], 1) @ W2.float().t()) < 2e-5
