@@ -36,6 +36,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
+                    help="fp32: exact-f32 MFMA forward, split-bf16 gradient GEMMs (parity mode); bf16: bf16 matrix "
+                         "operands, f32 accumulation/state/master weights (BASELINE configs[1] names bf16)")
     ap.add_argument("--decoder-streams", type=int, default=1, choices=(1, 2),
                     help="1: single stream, fused launches (default); 2: decoder-LSTM chain on a side stream")
     return ap.parse_args()
@@ -107,6 +110,7 @@ def main():
     hp.batch_size = args.batch_size
     torch.manual_seed(hp.seed)                                  # every rank: same seed (train.py:165)
     model = Tacotron2(hp).to(dev)
+    model.precision = args.precision
     if world > 1:
         model = apply_gradient_allreduce(model)
     optimizer = torch.optim.Adam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
@@ -199,12 +203,14 @@ def main():
             "value": timed_frames / elapsed, "unit": "valid mel-frames/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: LJSpeech default hparams, batch_size=%d per GPU, "
                                    "synthetic LJSpeech-shaped batches (Ti<=187, To<=870), full train step "
                                    "(fwd+loss+bwd+clip+Adam)" % args.batch_size,
                        "global_batch": args.batch_size * args.gpus, "parallelism": "dp%d" % args.gpus,
-                       "compute": "fp32 storage, exact-f32 MFMA (bf16 path not built yet)"},
+                       "compute": ("bf16 matrix operands (MFMA bf16), f32 accumulation, f32 cell state / saved activations / "
+                                   "master weights / optimiser" if args.precision == "bf16" else
+                                   "fp32 storage; forward on the exact-f32 MFMA, gradient GEMMs on split-bf16 (x3) MFMA")},
             "padded_frames_per_s": None, "final_loss": final_loss,
         }
         out["padded_frames_per_s"] = sum(b[2].shape[2] * args.batch_size for b in batches[args.warmup:]) \

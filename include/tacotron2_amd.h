@@ -89,7 +89,8 @@ typedef struct t2amd_gemm_desc {
     int convB_T, convB_C, convB_pad;
     /* 0: exact f32 MFMA (bitwise an fmaf chain).  1: split-bf16: A = Ah+Al, B = Bh+Bl in bf16, product =
      * Ah.Bh + Ah.Bl + Al.Bh on the bf16 MFMA with f32 accumulation (~2^-17 relative per product, 5.3x the
-     * f32 MFMA ceiling).  The engine requests 1 for gradient GEMMs only. */
+     * f32 MFMA ceiling).  The engine requests 1 for gradient GEMMs in f32 mode.  2: plain bf16 product
+     * (operands rounded to bf16, f32 accumulation) — the engine's bf16 compute mode. */
     int precision;
 } t2amd_gemm_desc;
 
@@ -141,6 +142,8 @@ int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtab
 int t2amd_philox_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed,
                            unsigned long long offset, void* stream);
 int t2amd_fill_f32(float* p, long long n, float v, void* stream);
+/* dst[i] = bf16(src[i]) (round to nearest even); n % 4 == 0 */
+int t2amd_cast_bf16_f32(const float* src, void* dst, long long n, void* stream);
 /* dst[r][c] = src[r][c] (+ src2[r][c] if src2) for r<rows, c<cols */
 int t2amd_copy2d_f32(const float* src, long long lds, const float* src2, long long lds2, float* dst,
                      long long ldd, int rows, int cols, void* stream);
@@ -323,6 +326,8 @@ typedef struct t2amd_attn_fwd {
     long long ld_q;
     const uint8_t* active;   /* [B] or NULL: rows with active[b]==0 are skipped (batched inference) */
     float* ws;               /* workspace, >= T2AMD_ATT_SLICES*B*Ti floats (partial energies) */
+    void* ctx16_out;         /* optional bf16 copy of the context [B][ld_ctx16] (bf16 operand mode) */
+    long long ld_ctx16;
 } t2amd_attn_fwd;
 
 int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
@@ -402,6 +407,14 @@ typedef struct t2amd_dec_train {
     float* CUM;   /* [To][B][Ti] cumulative weights before each step */
     float* cum_work; /* [B][Ti] scratch (zeroed by the call) */
     float* attn_ws;  /* >= T2AMD_ATT_SLICES*B*Ti + B*Ti floats: attention workspace (forward and backward) */
+    /* bf16 operand mode (all NULL / 0 for f32): bf16 copies of the packed weights and of the three recurrent
+     * operand slabs; the LSTM products then run on the bf16 MFMA, state and slabs above stay f32. */
+    int bf16;
+    const void* Wa_rec16;  /* [4Ha][E+Ha] bf16 */
+    const void* Wd_cat16;  /* [4Hd][Ha+E+Hd] bf16 */
+    void* HA16;            /* [To][B][Ha] bf16 */
+    void* HD16;            /* [To][B][Hd] bf16 */
+    void* CTX16;           /* [To][B][E] bf16 */
 } t2amd_dec_train;
 
 int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream);
@@ -430,6 +443,11 @@ typedef struct t2amd_dec_train_bwd {
     float* dwin_part;  /* [T2AMD_ATT_SLICES][B][2][Ti] (zeroed by the call) */
     float* dcum_acc;   /* [B][Ti] (zeroed by the call) */
     float* dq_h;       /* [T2AMD_ATT_SLICES][B][Ha] */
+    /* bf16 operand mode (f.bf16 != 0) */
+    const void* Wa_recT16; /* [E+Ha][4Ha] bf16 */
+    const void* Wd_catT16; /* [Ha+E+Hd][4Hd] bf16 */
+    void* DGA16;           /* [B][4Ha] bf16 scratch: this step's attention-LSTM gate gradients */
+    void* DGD16;           /* [B][4Hd] bf16 scratch */
 } t2amd_dec_train_bwd;
 
 int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream);

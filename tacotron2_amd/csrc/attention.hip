@@ -272,6 +272,7 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
         float s = 0.f;
         for (int q = 0; q < parts; ++q) s += part_s[q * EC + c];
         a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c] = s;
+        if (a.ctx16_out) reinterpret_cast<unsigned short*>(a.ctx16_out)[(long long)b * a.ld_ctx16 + cs * EC + c] = t2_f32_to_bf16(s);
     }
 }
 

@@ -343,6 +343,28 @@ __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         p[i] = v;
 }
+// f32 -> bf16 (round to nearest even), n a multiple of 4, both 8-byte aligned
+__global__ void cast_bf16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = src[i];
+        uint2 o;
+        o.x = (unsigned)t2_f32_to_bf16(v.x) | ((unsigned)t2_f32_to_bf16(v.y) << 16);
+        o.y = (unsigned)t2_f32_to_bf16(v.z) | ((unsigned)t2_f32_to_bf16(v.w) << 16);
+        dst[i] = o;
+    }
+}
+
+extern "C" int t2amd_cast_bf16_f32(const float* src, void* dst, long long n, void* stream) {
+    T2_REQUIRE(src && dst && n > 0 && n % 4 == 0, "cast_bf16: n must be a positive multiple of 4");
+    T2_REQUIRE(t2_aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0, "cast_bf16: alignment");
+    int blocks = t2_cdiv(n / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    T2_LAUNCH(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src),
+              reinterpret_cast<uint2*>(dst), n / 4);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 extern "C" int t2amd_fill_f32(float* p, long long n, float v, void* stream) {
     T2_REQUIRE(p && n > 0, "fill: bad args");
     int blocks = t2_cdiv(n, 256);

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-template <bool AK, bool BKC>
+template <bool AK, bool BKC, bool X3>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p);
 
 extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
@@ -308,24 +308,36 @@ extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
         const int ndim = d.convB_T > 0 ? d.convB_C : d.N;
         p.bvec = (ndim % 4 == 0) && (d.ldb % 4 == 0) && t2_aligned16(d.B) && (d.strideB % 4 == 0);
     }
-    T2_REQUIRE(d.precision == 0 || d.precision == 1, "gemm: precision must be 0 (exact f32) or 1 (split-bf16 x3)");
-    // the split-bf16 kernel steps K by 32: implicit-conv channel counts must be multiples of 32
-    const bool fast = d.precision == 1 && (d.convA_T == 0 || d.convA_C % 32 == 0);
+    T2_REQUIRE(d.precision >= 0 && d.precision <= 2, "gemm: precision must be 0 (exact f32), 1 (split-bf16 x3) or 2 (bf16)");
+    // the bf16 kernels step K by 32: implicit-conv channel counts must be multiples of 32
+    const bool fast = d.precision >= 1 && (d.convA_T == 0 || d.convA_C % 32 == 0);
     const int bk = fast ? 32 : GBK;
     const int nkt = t2_cdiv(d.K, bk);
     p.ktiles_per_split = t2_cdiv(nkt > 0 ? nkt : 1, d.splitk);
     dim3 grid(t2_cdiv(d.N, GBN), t2_cdiv(d.M, GBM), d.batch * d.splitk);
     T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    if (fast && d.precision == 1) {
+        if (d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, true, true>), grid, dim3(256), 0, s, p);
+        else if (d.a_kcontig && !d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, false, true>), grid, dim3(256), 0, s, p);
+        else if (!d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<false, true, true>), grid, dim3(256), 0, s, p);
+        else
+            T2_LAUNCH((gemm_bf16x3_kernel<false, false, true>), grid, dim3(256), 0, s, p);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
     if (fast) {
         if (d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<true, true, false>), grid, dim3(256), 0, s, p);
         else if (d.a_kcontig && !d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<true, false, false>), grid, dim3(256), 0, s, p);
         else if (!d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<false, true, false>), grid, dim3(256), 0, s, p);
         else
-            T2_LAUNCH((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<false, false, false>), grid, dim3(256), 0, s, p);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
@@ -411,7 +423,8 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
     lo.y = cvt_pk_bf16(x2 - h2, x3 - h3);
 }
 
-template <bool AK, bool BKC>
+// X3 = false is the plain bf16 product (precision 2): only the hi halves are formed, stored and multiplied.
+template <bool AK, bool BKC, bool X3>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
     // [buf][hi/lo][row][HLD_]
     __shared__ __attribute__((aligned(16))) unsigned short As[2][2][HBM_][HLD_];
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
                 uint2 hi, lo;
                 split4(r[i].x, r[i].y, r[i].z, r[i].w, hi, lo);
                 *reinterpret_cast<uint2*>(&S[0][row][kq * 4]) = hi;
-                *reinterpret_cast<uint2*>(&S[1][row][kq * 4]) = lo;
+                if (X3) *reinterpret_cast<uint2*>(&S[1][row][kq * 4]) = lo;
             }
         } else {
             // M-contiguous operand: "pair-interleaved" image P[k/2][m] (one dword = the bf16 pair (k, k+1) of
@@ -601,8 +614,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
             }
             *reinterpret_cast<uint4*>(&Ph[(2 * kq + 0) * HBM_ + m4 * 4]) = h0;
             *reinterpret_cast<uint4*>(&Ph[(2 * kq + 1) * HBM_ + m4 * 4]) = h1;
-            *reinterpret_cast<uint4*>(&Pl[(2 * kq + 0) * HBM_ + m4 * 4]) = l0;
-            *reinterpret_cast<uint4*>(&Pl[(2 * kq + 1) * HBM_ + m4 * 4]) = l1;
+            if (X3) {
+                *reinterpret_cast<uint4*>(&Pl[(2 * kq + 0) * HBM_ + m4 * 4]) = l0;
+                *reinterpret_cast<uint4*>(&Pl[(2 * kq + 1) * HBM_ + m4 * 4]) = l1;
+            }
         }
     };
 
@@ -652,16 +667,20 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 ah[t] = frag(As[cur][0], AK, wm * 64 + t * 32 + l31, ks, lhi);
-                al[t] = frag(As[cur][1], AK, wm * 64 + t * 32 + l31, ks, lhi);
                 bh[t] = frag(Bs[cur][0], BKC, wn * 64 + t * 32 + l31, ks, lhi);
-                bl[t] = frag(Bs[cur][1], BKC, wn * 64 + t * 32 + l31, ks, lhi);
+                if (X3) {
+                    al[t] = frag(As[cur][1], AK, wm * 64 + t * 32 + l31, ks, lhi);
+                    bl[t] = frag(Bs[cur][1], BKC, wn * 64 + t * 32 + l31, ks, lhi);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    if (X3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }

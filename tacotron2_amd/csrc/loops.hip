@@ -72,6 +72,10 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
     T2_REQUIRE(p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work &&
                    p->attn_ws,
                "dec_train_fwd: null slabs");
+    if (p->bf16) {
+        T2_REQUIRE(p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16, "dec_train_fwd: bf16 mode needs the bf16 buffers");
+        T2_REQUIRE(E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0, "dec_train_fwd: bf16 mode needs E, Ha, Hd multiples of 128");
+    }
     T2_PROPAGATE(t2amd_fill_f32(p->cum_work, (long long)B * Ti, 0.f, stream));
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
     auto fill_a = [&](int t, t2amd_lstm_step& a) {
@@ -89,6 +93,15 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         a.h_out = p->HA + t * sHa; a.ld_h = Ha;
         a.keep = p->keep_att ? p->keep_att + t * sHa : nullptr; a.ld_keep = Ha; a.keep_scale = p->scale_att;
         a.tag = 1;
+        if (p->bf16) {          // bf16 operands: same geometry, element pointers into the bf16 copies
+            const unsigned short* c16 = (const unsigned short*)p->CTX16;
+            const unsigned short* h16 = (const unsigned short*)p->HA16;
+            a.x[0].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr;
+            a.x[1].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr;
+            a.W = (const float*)p->Wa_rec16;
+            a.bf16 = 1;
+            a.h16_out = (void*)((unsigned short*)p->HA16 + t * sHa); a.ld_h16 = Ha;
+        }
     };
     auto fill_d = [&](int u, t2amd_lstm_step& d) {
         // decoder LSTM of step u: gates = bias_d + [h_att_u | ctx_u | h_dec_{u-1}] . Wd_cat^T
@@ -105,6 +118,17 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         d.h_out = p->HD + u * sHd; d.ld_h = Hd;
         d.keep = p->keep_dec ? p->keep_dec + u * sHd : nullptr; d.ld_keep = Hd; d.keep_scale = p->scale_dec;
         d.tag = 2;
+        if (p->bf16) {
+            const unsigned short* c16 = (const unsigned short*)p->CTX16;
+            const unsigned short* ha16 = (const unsigned short*)p->HA16;
+            unsigned short* hd16 = (unsigned short*)p->HD16;
+            d.x[0].p = (const float*)(ha16 + u * sHa);
+            d.x[1].p = (const float*)(c16 + u * sE);
+            d.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd) : nullptr;
+            d.W = (const float*)p->Wd_cat16;
+            d.bf16 = 1;
+            d.h16_out = (void*)(hd16 + u * sHd); d.ld_h16 = Hd;
+        }
     };
     auto attention = [&](int t, void* st) -> int {
         t2amd_attn_fwd at = {};
@@ -118,6 +142,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)To * Ti;
         at.ctx_out = p->CTX + t * sE; at.ld_ctx = E;
         at.q_out = p->Q + (long long)t * B * T2AMD_ATT_DIM; at.ld_q = T2AMD_ATT_DIM;
+        if (p->bf16) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; }
         return t2amd_attention_step_fwd_f32(&at, st);
     };
 
@@ -178,6 +203,9 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
                    p->dcum_acc && p->dq_h && f.attn_ws,
                "dec_train_bwd: null pointer");
     T2_REQUIRE((4 * Ha) % 64 == 0 && (4 * Hd) % 64 == 0, "dec_train_bwd: 4H must be a multiple of 64");
+    if (f.bf16) {
+        T2_REQUIRE(p->Wa_recT16 && p->Wd_catT16 && p->DGA16 && p->DGD16, "dec_train_bwd: bf16 mode needs the bf16 buffers");
+    }
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
     const int Kd = Ha + E + Hd, Ka = E + Ha;
     const long long strXd = (long long)B * Kd, strXa = (long long)B * Ka;
@@ -208,6 +236,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         lb.keep = f.keep_dec ? f.keep_dec + t * sHd : nullptr; lb.ld_keep = Hd; lb.keep_scale = f.scale_dec;
         lb.dc = p->dc_d; lb.ld_dc = Hd;
         lb.dgates = p->DGD + (long long)t * B * 4 * Hd; lb.ld_dgates = 4 * Hd;
+        if (f.bf16) { lb.dgates16 = p->DGD16; lb.ld_dgates16 = 4 * Hd; }
     };
     auto dgrad_d = [&](int t, t2amd_skinny_gemm& g) {     // d[h_att_t | ctx_t | h_dec_{t-1}] = dgates_d . Wd_cat
         g = t2amd_skinny_gemm{};
@@ -215,6 +244,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         g.x[0] = seg(p->DGD + (long long)t * B * 4 * Hd, 4 * Hd, 4 * Hd);
         g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
         g.Y = p->dXd + t * stepXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
+        if (f.bf16) { g.x[0].p = (const float*)p->DGD16; g.W = (const float*)p->Wd_catT16; g.bf16 = 1; }
     };
     auto attn_bwd = [&](int t, void* st) -> int {        // needs dXd(t), dXa(t+1)
         const bool last = (t == To - 1);
@@ -249,6 +279,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         la.keep = f.keep_att ? f.keep_att + t * sHa : nullptr; la.ld_keep = Ha; la.keep_scale = f.scale_att;
         la.dc = p->dc_a; la.ld_dc = Ha;
         la.dgates = p->DGA + (long long)t * B * 4 * Ha; la.ld_dgates = 4 * Ha;
+        if (f.bf16) { la.dgates16 = p->DGA16; la.ld_dgates16 = 4 * Ha; }
     };
     auto dgrad_a = [&](int t, t2amd_skinny_gemm& ga) {    // d[ctx_{t-1} | h_att_{t-1}] = dgates_a(t) . Wa_rec
         ga = t2amd_skinny_gemm{};
@@ -256,6 +287,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
         ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
         ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa; ga.tag = 1;
+        if (f.bf16) { ga.x[0].p = (const float*)p->DGA16; ga.W = (const float*)p->Wa_recT16; ga.bf16 = 1; }
     };
 
     if (g_dec_streams == 2) {

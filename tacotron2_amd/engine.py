@@ -96,19 +96,37 @@ FAST_GRAD_GEMM = True
 
 
 def _rg(run, *a, **k):
-    return run.gemm(*a, fast=FAST_GRAD_GEMM, **k)
+    return run.gemm(*a, fast=run.gradp, **k)
 
 
-def _ng(*a, **k):
-    return nv.gemm(*a, fast=FAST_GRAD_GEMM, **k)
+def _ng(run, *a, **k):
+    return nv.gemm(*a, fast=run.gradp, **k)
+
+
+def _fg(run, *a, **k):          # forward GEMM: exact f32, or plain bf16 in the bf16 compute mode
+    return nv.gemm(*a, fast=run.fwdp, **k)
 
 
 class _Run(object):
     """Allocation + kernel helpers bound to one device."""
 
-    def __init__(self, device):
+    def __init__(self, device, precision='fp32'):
         self.dev = device
         self._ws = None
+        if precision not in ('fp32', 'bf16'):
+            raise NativeError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+        self.bf16 = precision == 'bf16'
+        # t2amd_gemm_desc.precision: 0 exact f32 MFMA, 1 split-bf16 x3 (f32-class), 2 plain bf16
+        self.fwdp = 2 if self.bf16 else 0
+        self.gradp = 2 if self.bf16 else (1 if FAST_GRAD_GEMM else 0)
+
+    def empty16(self, *shape):
+        return torch.empty(shape, dtype=torch.bfloat16, device=self.dev)
+
+    def cast16(self, t):
+        out = self.empty16(*t.shape)
+        nv.cast_bf16(t.contiguous(), out)
+        return out
 
     def empty(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
@@ -190,7 +208,7 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         pad = (k - 1) // 2
         Wp = run.pack_conv_fwd(W)
         y = run.empty(rows, Co)
-        nv.gemm(y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
+        _fg(run, y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
         invstd = run.empty(Co)
         if training:
             mean = run.empty(Co)
@@ -241,7 +259,7 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
             else:
                 dx = run.empty(rows, Ci)
                 acc = False
-            _ng(dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
+            _ng(run, dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
             g = dx
     return g
 
@@ -256,7 +274,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         raise NativeError("tacotron2_amd: the engine runs on the MI355X only (got %s tensors). "
                           "There is no CPU path; the CPU oracle lives in oracle/ for tests." % dev)
     nv.load()
-    run = _Run(dev)
+    run = _Run(dev, getattr(model, 'precision', 'fp32'))
     ms = MaskSource(model.dropout_masks, dev)
     c = _Ctx()
     B = text.shape[0]
@@ -291,7 +309,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         Whh = P['encoder.lstm.weight_hh_l0' + sfx]
         bsum = _bias_sum(run, P['encoder.lstm.bias_ih_l0' + sfx], P['encoder.lstm.bias_hh_l0' + sfx])
         GX = run.empty(rowsE, 4 * He)
-        nv.gemm(GX, x3, Wih, bias=bsum)
+        _fg(run, GX, x3, Wih, bias=bsum)
         Cst = run.empty(Ti, B, He)
         desc = nv.LstmSeq()
         desc.B, desc.T, desc.H, desc.reverse = B, Ti, He, d
@@ -315,11 +333,11 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     k1 = ms.get('prenet', 1, (To, B, Pd), 0.5)
     p1 = run.empty(rowsD, Pd)
     p2 = run.empty(rowsD, Pd)
-    nv.gemm(p1, x0.view(rowsD, Cm), W1, act=1, keep=k0.view(rowsD, Pd), keep_scale=2.0)  # model.py:99, 399
-    nv.gemm(p2, p1, W2, act=1, keep=k1.view(rowsD, Pd), keep_scale=2.0)
+    _fg(run, p1, x0.view(rowsD, Cm), W1, act=1, keep=k0.view(rowsD, Pd), keep_scale=2.0)  # model.py:99, 399
+    _fg(run, p2, p1, W2, act=1, keep=k1.view(rowsD, Pd), keep_scale=2.0)
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
     pm = run.empty(B, Ti, A)
-    nv.gemm(pm.view(rowsE, A), memory.view(rowsE, E), Wmem)                              # model.py:288
+    _fg(run, pm.view(rowsE, A), memory.view(rowsE, E), Wmem)                              # model.py:288
 
     Wih_a, Whh_a = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
     Wih_d, Whh_d = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
@@ -339,7 +357,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
 
     GA = run.empty(To, B, 4 * Ha)
-    nv.gemm(GA.view(rowsD, 4 * Ha), p2, Wih_a[:, :Pd], bias=bias_a)
+    _fg(run, GA.view(rowsD, 4 * Ha), p2, Wih_a[:, :Pd], bias=bias_a)
 
     att_p, dec_p = hp.p_attention_dropout, hp.p_decoder_dropout
     keep_att = ms.get('att', None, (To, B, Ha), att_p) if training else None
@@ -361,6 +379,14 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     d.scale_att, d.scale_dec = nv.scale_for(att_p), nv.scale_for(dec_p)
     for k_, v_ in slabs.items():
         setattr(d, k_, nv.ptr(v_))
+    if run.bf16:
+        # bf16 compute mode: bf16 copies of the packed weights and of the recurrent operand slabs (the LSTM
+        # products run on the bf16 MFMA; cell state, gates and every saved slab stay f32)
+        c.bf16 = dict(Wa_rec16=run.cast16(Wa_rec), Wd_cat16=run.cast16(Wd_cat), HA16=run.empty16(To, B, Ha),
+                      HD16=run.empty16(To, B, Hd), CTX16=run.empty16(To, B, E))
+        d.bf16 = 1
+        for k_, v_ in c.bf16.items():
+            setattr(d, k_, nv.ptr(v_, torch.bfloat16))
     nv.decoder_train_fwd_loop(d)                                                         # model.py:405-411
 
     # mel + gate projection over all steps (model.py:373-378)
@@ -373,8 +399,8 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     nv.copy2d(bpg[:Cm].view(1, Cm), P['decoder.linear_projection.linear_layer.bias'].view(1, Cm))
     nv.copy2d(bpg[Cm:].view(1, 1), P['decoder.gate_layer.linear_layer.bias'].view(1, 1))
     PG = run.empty(rowsD, Cm + 1)
-    nv.gemm(PG, slabs['HD'].view(rowsD, Hd), Wpg[:, :Hd])
-    nv.gemm(PG, slabs['CTX'].view(rowsD, E), Wpg[:, Hd:], accumulate=True, bias=bpg)
+    _fg(run, PG, slabs['HD'].view(rowsD, Hd), Wpg[:, :Hd])
+    _fg(run, PG, slabs['CTX'].view(rowsD, E), Wpg[:, Hd:], accumulate=True, bias=bpg)
     mel_cl = run.empty(B, To, Cm)
     gate = run.empty(B, To)
     nv.split_projection(PG, mel_cl, gate, olens32)                                       # model.py:326-336, 495
@@ -438,7 +464,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # ---- projection backward --------------------------------------------------------------
     Wpg = T['Wpg']
     DHC = run.empty(rowsD, Hd + E)
-    _ng(DHC, dout, Wpg, b_kn=True)
+    _ng(run, DHC, dout, Wpg, b_kn=True)
     dWpg_h = run.empty(Cm + 1, Hd)
     dWpg_c = run.empty(Cm + 1, E)
     _rg(run, dWpg_h, dout, S['HD'].view(rowsD, Hd), a_km=True, b_kn=True)
@@ -474,6 +500,11 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
                dcum_acc=run.empty(B, Ti), dq_h=run.empty(nv.ATT_SLICES, B, Ha))
     for k_, v_ in out.items():
         setattr(bw, k_, nv.ptr(v_))
+    if run.bf16:
+        b16 = dict(Wa_recT16=run.cast16(Wa_recT), Wd_catT16=run.cast16(Wd_catT),
+                   DGA16=run.empty16(B, 4 * Ha), DGD16=run.empty16(B, 4 * Hd))
+        for k_, v_ in b16.items():
+            setattr(bw, k_, nv.ptr(v_, torch.bfloat16))
     nv.decoder_train_bwd_loop(bw)
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
     DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)
@@ -541,12 +572,12 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     Wih_a = P['decoder.attention_rnn.weight_ih']
     W2 = P['decoder.prenet.layers.1.linear_layer.weight']
     dp2 = run.empty(rowsD, Pd)
-    _ng(dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
+    _ng(run, dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
     nv.relu_dropout_bwd(dp2, T['p2'], 2.0)
     dW2 = run.empty(Pd, Pd)
     _rg(run, dW2, dp2, T['p1'], a_km=True, b_kn=True)
     dp1 = run.empty(rowsD, Pd)
-    _ng(dp1, dp2, W2, b_kn=True)
+    _ng(run, dp1, dp2, W2, b_kn=True)
     nv.relu_dropout_bwd(dp1, T['p1'], 2.0)
     dW1 = run.empty(Pd, Cm)
     _rg(run, dW1, dp1, T['x0'].view(rowsD, Cm), a_km=True, b_kn=True)
@@ -556,9 +587,9 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # memory gradient: d_mem[b] = ALIGN[b]^T . DCTX[:, b] + d_pm[b] . Wmem ; dWmem = d_pm^T . memory
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']     # (A, E)
     dmem = run.empty(B, Ti, E)
-    _ng(dmem[0], S['ALIGN'][0], DCTX[:, 0, :], a_km=True, b_kn=True, batch=B,
+    _ng(run, dmem[0], S['ALIGN'][0], DCTX[:, 0, :], a_km=True, b_kn=True, batch=B,
             strides=(To * Ti, E, Ti * E))
-    _ng(dmem.view(rowsE, E), d_pm.view(rowsE, A), Wmem, b_kn=True, accumulate=True)
+    _ng(run, dmem.view(rowsE, E), d_pm.view(rowsE, A), Wmem, b_kn=True, accumulate=True)
     dWmem = run.empty(A, E)
     _rg(run, dWmem, d_pm.view(rowsE, A), c.memory.view(rowsE, E), a_km=True, b_kn=True)
     g['decoder.attention_layer.memory_layer.linear_layer.weight'] = dWmem
@@ -597,7 +628,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         g['encoder.lstm.weight_hh_l0' + sfx] = dWhh
         g['encoder.lstm.bias_ih_l0' + sfx] = db
         g['encoder.lstm.bias_hh_l0' + sfx] = db.clone()
-        _ng(dx3, DG, L['Wih'], b_kn=True, accumulate=(d == 1))
+        _ng(run, dx3, DG, L['Wih'], b_kn=True, accumulate=(d == 1))
     demb = run.empty(rowsE, E)
     _conv_stack_bwd(run, P, g, 'encoder.convolutions', c.enc_saved, dx3, Ti, first_dx=demb)
     dtable = run.empty(*P['embedding.weight'].shape)

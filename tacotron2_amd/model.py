@@ -133,6 +133,9 @@ class Tacotron2(nn.Module):
         # None = Philox masks seeded from torch's RNG.
         self.dropout_masks = None
         self.last_inference_lengths = None
+        # 'fp32': exact-f32 MFMA forward (parity mode).  'bf16': matrix operands rounded to bf16, f32
+        # accumulation, f32 master weights / cell state / saved activations (throughput mode, training only).
+        self.precision = 'fp32'
 
     # -- reference model.py:473-485 ---------------------------------------------------------
     def parse_batch(self, batch):

@@ -106,6 +106,7 @@ class AttnFwd(C.Structure):
         ("q_out", _f32p), ("ld_q", _i64),
         ("active", C.c_void_p),
         ("ws", _f32p),
+        ("ctx16_out", C.c_void_p), ("ld_ctx16", _i64),
     ]
 
 
@@ -138,6 +139,8 @@ class DecTrain(C.Structure):
         ("scale_att", C.c_float), ("scale_dec", C.c_float),
         ("HA", _f32p), ("CA", _f32p), ("GD", _f32p), ("HD", _f32p), ("CD", _f32p), ("CTX", _f32p),
         ("Q", _f32p), ("ALIGN", _f32p), ("CUM", _f32p), ("cum_work", _f32p), ("attn_ws", _f32p),
+        ("bf16", C.c_int), ("Wa_rec16", C.c_void_p), ("Wd_cat16", C.c_void_p),
+        ("HA16", C.c_void_p), ("HD16", C.c_void_p), ("CTX16", C.c_void_p),
     ]
 
 
@@ -150,6 +153,7 @@ class DecTrainBwd(C.Structure):
         ("dU_acc", _f32p), ("dv_acc", _f32p),
         ("dXd", _f32p), ("dXa", _f32p), ("dc_a", _f32p), ("dc_d", _f32p),
         ("dwin_part", _f32p), ("dcum_acc", _f32p), ("dq_h", _f32p),
+        ("Wa_recT16", C.c_void_p), ("Wd_catT16", C.c_void_p), ("DGA16", C.c_void_p), ("DGD16", C.c_void_p),
     ]
 
 
@@ -199,7 +203,7 @@ SYMBOLS = [
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
-    "t2amd_copy2d_f32", "t2amd_transpose_f32", "t2amd_frames_to_time_major_f32",
+    "t2amd_copy2d_f32", "t2amd_cast_bf16_f32", "t2amd_transpose_f32", "t2amd_frames_to_time_major_f32",
     "t2amd_split_projection_f32", "t2amd_finalize_outputs_f32", "t2amd_grads_to_channel_last_f32",
     "t2amd_gather_dout_f32", "t2amd_relu_dropout_bwd_f32",
     "t2amd_lstm_step_fwd_f32", "t2amd_skinny_gemm_f32", "t2amd_lstm_pointwise_bwd_f32",
@@ -228,6 +232,7 @@ def _argtypes():
         "t2amd_embedding_bwd_f32": [_P, _P, _P, _L, _I, _I, _P],
         "t2amd_philox_keep_mask": [_P, _L, _F, _UL, _UL, _P],
         "t2amd_fill_f32": [_P, _L, _F, _P],
+        "t2amd_cast_bf16_f32": [_P, _P, _L, _P],
         "t2amd_copy2d_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P],
         "t2amd_transpose_f32": [_P, _L, _P, _L, _I, _I, _I, _L, _L, _P],
         "t2amd_frames_to_time_major_f32": [_P, _P, _I, _I, _I, _P],
@@ -303,6 +308,14 @@ def load():
 
 
 _validate_only = False
+
+
+def cast_bf16(src, dst):
+    """dst (torch.bfloat16, contiguous) = bf16(src) with round-to-nearest-even."""
+    _fullc(src), _fullc(dst)
+    if src.numel() != dst.numel() or dst.dtype != torch.bfloat16:
+        raise NativeError("cast_bf16: dst must be a bfloat16 tensor of the same size")
+    _check(load().t2amd_cast_bf16_f32(ptr(src), ptr(dst, torch.bfloat16), src.numel(), _stream()), "t2amd_cast_bf16_f32")
 
 
 def set_decoder_streams(n):
@@ -420,7 +433,7 @@ def gemm(Cm, A, B, a_km=False, b_kn=False, accumulate=False, bias=None, act=0, k
     d.batch = batch
     d.strideA, d.strideB, d.strideC = strides
     d.splitk = splitk
-    d.precision = 1 if fast else 0
+    d.precision = int(fast)          # False/0 exact f32, True/1 split-bf16 x3, 2 plain bf16
     d.accumulate = 1 if accumulate else 0
     d.bias = ptr(bias)
     d.act = act

@@ -236,3 +236,55 @@ def test_two_stream_loops_are_bitwise_identical(native_lib):
             assert torch.equal(a, b)
         for k in res[0][1]:
             assert torch.equal(res[0][1][k], other[1][k]), k
+
+
+def test_bf16_compute_mode_train_step(native_lib):
+    """precision='bf16' (throughput mode): matrix operands rounded to bf16, f32 accumulation / state / master
+    weights.  Its own, stated tolerance (the reference under bf16 autocast already drifts from
+    f32 by mean 6.7e-4 on the decoder mel and 1.6e-2 on the postnet mel): decoder mel and gate mean |diff|
+    <= 2e-3, postnet mel mean |diff| <= 3e-2, alignments <= 1e-3; whole-gradient cosine > 0.999, relative L2
+    error of every gradient tensor < 0.25 (typically 1-3 %; the small, far-upstream encoder conv gradients are
+    the noisy ones)."""
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    fx = gu.load_fixture("default_train")
+    hp = gu.make_hparams(fx['hp'])
+    sd = gu.build_state_dict(hp, fx['seed'])
+    batch = gu.make_train_batch(fx['in_lens'], fx['out_lens'], hp.n_mel_channels, fx['seed'])
+    masks = gu.unpack_masks(fx['masks'])
+    oloss, oout, ograds, _ = orc.train_step_grads(sd, hp, batch, masks)
+    model = _model(hp, sd).train()
+    model.precision = 'bf16'
+    model.dropout_masks = gu.masks_to_engine(masks, DEV)
+    x, y = model.parse_batch(tuple(t.clone() for t in batch))
+    out = model(x)
+    loss = Tacotron2Loss()(out, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    rows = []
+    lim = [2e-3, 3e-2, 2e-3, 1e-3]
+    for i, nm in enumerate(("mel", "mel_post", "gate", "align")):
+        mean, mx, refmax = _stats(out[i], oout[i])
+        rows.append(dict(what="bf16 " + nm, mean=mean, max=mx, refmax=refmax))
+        assert mean < lim[i], (nm, mean)
+    # Gradients: relative L2 error per tensor and cosine of the whole gradient vector.  Convolution biases that
+    # feed a BatchNorm have an analytically ZERO gradient (BN removes any per-channel shift): both sides hold
+    # rounding noise there, so they are only required to stay tiny next to the weight gradient of the same layer.
+    worst, dot, n1, n2 = 0.0, 0.0, 0.0, 0.0
+    for k, p in model.named_parameters():
+        ref = ograds[k].double()
+        g = p.grad.cpu().double()
+        assert torch.isfinite(g).all()
+        if k.endswith('.0.conv.bias'):
+            wk = k.replace('.bias', '.weight')
+            assert g.abs().max().item() < 1e-3 * max(ograds[wk].abs().max().item(), 1e-12) + 1e-6, k
+            continue
+        rel = ((g - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        rows.append(dict(what="bf16 grad " + k, rel_l2=rel))
+        worst = max(worst, rel)
+        dot += float((g * ref).sum()); n1 += float((g * g).sum()); n2 += float((ref * ref).sum())
+    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
+    rows.append(dict(what="bf16 loss", engine=float(loss.detach()), oracle=float(oloss), grad_cosine=cos, worst_rel_l2=worst))
+    _report("bf16_train", rows)
+    assert abs(float(loss.detach()) - float(oloss)) < 2e-2 * abs(float(oloss))
+    assert cos > 0.999, cos
+    assert worst < 0.25, worst
