@@ -21,6 +21,7 @@
 // Every cross-workgroup reduction is a small slab of partials summed in a fixed order by the next
 // kernel: results are bit-reproducible run to run.
 #include "common.h"
+#include <stdlib.h>
 
 #define AD T2AMD_ATT_DIM       // 128
 #define NTAP T2AMD_LOC_TAPS    // 62
@@ -73,7 +74,14 @@ __device__ __forceinline__ void load_u_frag(float (&ua)[2][16], const float* __r
         }
 }
 
-struct AttnFwdParams { t2amd_attn_fwd a; int tip; };
+struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; };
+
+// timing experiments only (tools/microbench_attn.py): T2AMD_ATTN_STAGE=n makes the kernels return after stage n
+static int attn_dbg_stage() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("T2AMD_ATTN_STAGE"); v = e ? atoi(e) : 0; }
+    return v;
+}
 
 // ---------------------------------------------------------------------------------------
 // K_e: partial energies over 32 attention dims
@@ -92,6 +100,19 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     float* u_s = q_s + DSL;          // [32][62] the slice's rows of U (contiguous in HBM)
     const int len = a.lens ? a.lens[b] : Ti;
 
+    // processed-memory rows of this wave's first two position tiles: issued now, consumed after the q phase
+    const int nmt = (len + 15) >> 4;
+    const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + ds * DSL + 4 * lg;
+    float4 pmA[2], pmB[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int pos = (wv + rr * (KE_NT / 64)) * 16 + l15;
+        pmA[rr] = pmB[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pos < Ti && wv + rr * (KE_NT / 64) < nmt) {
+            pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
+            pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+        }
+    }
     // q[d] = W_q[d][:] . h for the slice's 32 dims: 16 threads per row, 256 contiguous bytes per group
     // and instruction; all loads are issued before the first use.
     float qacc = 0.f;
@@ -140,6 +161,7 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) vv[dt][r] = a.v[ds * DSL + dt * 16 + 4 * lg + r];
     __syncthreads();
+    if (p.dbg == 1) return;
     float ua[2][16];
     load_u_frag(ua, u_s, 0, l15, lg);
     float qv[2][4];
@@ -149,14 +171,18 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
         for (int r = 0; r < 4; ++r) qv[dt][r] = q_s[dt * 16 + 4 * lg + r];
 
     float* __restrict__ eout = a.ws + ((long long)ds * a.B + b) * Ti;
-    const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + ds * DSL + 4 * lg;
-    const int nmt = (len + 15) >> 4;
-    for (int mt = wv; mt < nmt; mt += KE_NT / 64) {
+    int round = 0;
+    for (int mt = wv; mt < nmt; mt += KE_NT / 64, ++round) {
         const int pos = mt * 16 + l15;
-        float4 pm0 = make_float4(0.f, 0.f, 0.f, 0.f), pm1 = pm0;
-        if (pos < Ti) {
-            pm0 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
-            pm1 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+        float4 pm0, pm1;
+        if (round == 0) { pm0 = pmA[0]; pm1 = pmB[0]; }
+        else if (round == 1) { pm0 = pmA[1]; pm1 = pmB[1]; }
+        else {
+            pm0 = pm1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < Ti) {
+                pm0 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
+                pm1 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+            }
         }
         f32x4 acc0, acc1;
         loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
@@ -288,6 +314,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     AttnFwdParams p;
     p.a = *a;
     p.tip = attn_tip(a->Ti);
+    p.dbg = attn_dbg_stage();
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP);
     const int EC = a->E / NSL;
@@ -305,7 +332,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // =========================================================================================
 // Backward of one attention step.
 // =========================================================================================
-struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; };
+struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; };
 
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
 // Half a wave (32 lanes) per memory row, 8 rows per pass, every load of a pass issued before its first use.
@@ -370,21 +397,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         float acc[KB1_MAXP];
 #pragma unroll
         for (int i = 0; i < KB1_MAXP; ++i) acc[i] = 0.f;
-        for (int c4 = l32; c4 < E4; c4 += 32) {
-            const float4 g = *reinterpret_cast<const float4*>(&dctx_s[c4 * 4]);
-            float4 m[KB1_MAXP];
+        for (int c0 = l32; c0 < E4; c0 += 64) {          // two 32-float4 column groups per trip: 16 loads in flight
+            const int c1 = c0 + 32;
+            const bool two = c1 < E4;
+            float4 m0[KB1_MAXP], m1[KB1_MAXP];
 #pragma unroll
             for (int i = 0; i < KB1_MAXP; ++i) {
                 const int ti = t0 + r0 + grp + 8 * i;
                 const int tc = (ti < t1 && ti < len) ? ti : 0;        // clamped: loaded, then ignored
-                m[i] = M4[(long long)tc * E4 + c4];
+                m0[i] = M4[(long long)tc * E4 + c0];
+                m1[i] = M4[(long long)tc * E4 + (two ? c1 : c0)];
             }
+            const float4 g0 = *reinterpret_cast<const float4*>(&dctx_s[c0 * 4]);
+            float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (two) g1 = *reinterpret_cast<const float4*>(&dctx_s[c1 * 4]);
 #pragma unroll
             for (int i = 0; i < KB1_MAXP; ++i) {
-                acc[i] = fmaf(m[i].x, g.x, acc[i]);
-                acc[i] = fmaf(m[i].y, g.y, acc[i]);
-                acc[i] = fmaf(m[i].z, g.z, acc[i]);
-                acc[i] = fmaf(m[i].w, g.w, acc[i]);
+                acc[i] = fmaf(m0[i].x, g0.x, acc[i]);
+                acc[i] = fmaf(m0[i].y, g0.y, acc[i]);
+                acc[i] = fmaf(m0[i].z, g0.z, acc[i]);
+                acc[i] = fmaf(m0[i].w, g0.w, acc[i]);
+                acc[i] = fmaf(m1[i].x, g1.x, acc[i]);
+                acc[i] = fmaf(m1[i].y, g1.y, acc[i]);
+                acc[i] = fmaf(m1[i].z, g1.z, acc[i]);
+                acc[i] = fmaf(m1[i].w, g1.w, acc[i]);
             }
         }
 #pragma unroll
@@ -431,6 +467,23 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     const int npos = nmt * 16;                // positions covered by the MFMA tiles
     const int dbase = ds * DSL;
 
+    const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + dbase + 4 * lg;
+    float* __restrict__ dpmb = a.d_pm + (long long)b * Ti * AD + dbase + 4 * lg;
+    float4 pmA[2], pmB[2], opA[2], opB[2];      // issued now, consumed in the tile loop
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int mt_ = wv + rr * KB2_NW;
+        const int pos = mt_ * 16 + l15;
+        pmA[rr] = pmB[rr] = opA[rr] = opB[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mt_ < nmt && pos < Ti) {
+            pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
+            pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+        }
+        if (mt_ < nmt && pos < len) {
+            opA[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD);
+            opB[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD + 16);
+        }
+    }
     {
         const float* sd = a.ws + (long long)B * Ti;
         const float sdot = ((sd[b] + sd[B + b]) + sd[2 * B + b]) + sd[3 * B + b];
@@ -453,6 +506,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dqa[dt][r] = 0.f;
         }
     __syncthreads();
+    if (p.dbg == 1) return;
     float ua[2][16];
     load_u_frag(ua, u_s, 0, l15, lg);
     // U^T as the A operand of dcol^T = U^T dpre: A[i = tap][k = lg], k-step (dt, r) <-> dim dt*16 + 4*lg + r
@@ -467,18 +521,22 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 ut[tt][dt][r] = tap < NTAP ? u_s[(dt * 16 + 4 * lg + r) * NTAP + tap] : 0.f;
             }
 
-    const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + dbase + 4 * lg;
-    float* __restrict__ dpmb = a.d_pm + (long long)b * Ti * AD + dbase + 4 * lg;
-    for (int mt = wv; mt < nmt; mt += KB2_NW) {
+    int round = 0;
+    for (int mt = wv; mt < nmt; mt += KB2_NW, ++round) {
         const int pos = mt * 16 + l15;
-        float4 pm0 = make_float4(0.f, 0.f, 0.f, 0.f), pm1 = pm0, o0 = pm0, o1 = pm0;
-        if (pos < Ti) {
-            pm0 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
-            pm1 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
-        }
-        if (pos < len) {      // d_pm read-modify-write: fetch now, add and store after the tile math
-            o0 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD);
-            o1 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16);
+        float4 pm0, pm1, o0, o1;
+        if (round == 0) { pm0 = pmA[0]; pm1 = pmB[0]; o0 = opA[0]; o1 = opB[0]; }
+        else if (round == 1) { pm0 = pmA[1]; pm1 = pmB[1]; o0 = opA[1]; o1 = opB[1]; }
+        else {
+            pm0 = pm1 = o0 = o1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < Ti) {
+                pm0 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
+                pm1 = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+            }
+            if (pos < len) {      // d_pm read-modify-write: fetch now, add and store after the tile math
+                o0 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD);
+                o1 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16);
+            }
         }
         f32x4 acc0, acc1;
         loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
@@ -515,6 +573,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16) = o1;
         }
     }
+    if (p.dbg == 2) return;
     // dv / dq: reduce over the positions held by the 16 lanes of a lane group
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -543,6 +602,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         dq_s[tid] = dqs;
         a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
     }
+    if (p.dbg == 3) return;
     // dU[d][tap] += sum_pos dpre[pos][d] * win[c(tap)][pos + k(tap)]: wave w owns (tap tile w&3, dim tile w>>2)
     {
         const int tt = wv & 3, dt = wv >> 2;
@@ -568,6 +628,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             for (int r = 0; r < 4; ++r) dUg[(long long)r * NTAP] = old[r] + (c0[r] + c1[r]);
         }
     }
+    if (p.dbg == 4) return;
     // col2im: partial carry dwin[c][ti'] = sum_k dcol[ti' - k + 15][c*31 + k] over this slice's dims
     {
         float* __restrict__ out = a.dwin_part + (((long long)ds * B + b) * 2) * Ti;
@@ -583,6 +644,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             out[i] = s;
         }
     }
+    if (p.dbg == 5) return;
     __syncthreads();   // dq_s
     // partial dh = sum_{d in slice} dq[d] * W_q[d][:]; the two halves of the block take 16 dims each
     {
@@ -633,6 +695,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         if (p.a.dctx[i].p && p.a.dctx[i].nsplit < 1) p.a.dctx[i].nsplit = 1;
     p.tip = attn_tip(a->Ti);
     p.np = ((a->Ti + 15) / 16) * 16;
+    p.dbg = attn_dbg_stage();
     hipStream_t s = (hipStream_t)stream;
     const size_t lds1 = sizeof(float) * ((size_t)a->E + 2 * (size_t)((a->Ti + NSL - 1) / NSL) + 8);
     const size_t lds2 = sizeof(float) * (2 * (size_t)p.tip + p.np + (size_t)p.np * (DCL + DPL) + KB2_NW * 2 * DSL + DSL +

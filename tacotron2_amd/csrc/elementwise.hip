@@ -258,31 +258,49 @@ extern "C" int t2amd_embedding_fwd_f32(const long long* ids, const float* table,
     return T2AMD_OK;
 }
 
-// one workgroup per (symbol, 256-column slab): deterministic row order, no atomics
+// one workgroup per (symbol, 256-column slab, row chunk): deterministic row order, no atomics; the
+// EMB_SPLIT row-chunk partials of a (symbol, column) are summed in chunk order by the last-launched pass
+#define EMB_SPLIT 8
 __global__ void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout,
-                                     float* __restrict__ dtable, long long rows, int dim) {
+                                     float* __restrict__ part, long long rows, int dim, int n_symbols) {
     const int sym = blockIdx.x;
     const int c = blockIdx.y * 256 + threadIdx.x;
+    const int chunk = blockIdx.z;
+    const long long per = (rows + EMB_SPLIT - 1) / EMB_SPLIT;
+    const long long rbeg = chunk * per;
+    long long rend = rbeg + per;
+    if (rend > rows) rend = rows;
     __shared__ long long idbuf[256];
     float acc = 0.f;
-    for (long long r0 = 0; r0 < rows; r0 += 256) {
+    for (long long r0 = rbeg; r0 < rend; r0 += 256) {
         const long long r = r0 + threadIdx.x;
-        idbuf[threadIdx.x] = (r < rows) ? ids[r] : -1;
+        idbuf[threadIdx.x] = (r < rend) ? ids[r] : -1;
         __syncthreads();
-        const int lim = (rows - r0 < 256) ? (int)(rows - r0) : 256;
+        const int lim = (rend - r0 < 256) ? (int)(rend - r0) : 256;
         if (c < dim)
             for (int k = 0; k < lim; ++k)
                 if (idbuf[k] == sym) acc += dout[(r0 + k) * dim + c];
         __syncthreads();
     }
-    if (c < dim) dtable[(long long)sym * dim + c] = acc;
+    if (c < dim) part[((long long)chunk * n_symbols + sym) * dim + c] = acc;
 }
 
-extern "C" int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, long long rows,
-                                       int dim, int n_symbols, void* stream) {
-    T2_REQUIRE(ids && dout && dtable && rows > 0 && dim > 0 && n_symbols > 0, "embedding_bwd: bad args");
-    T2_LAUNCH(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream, ids,
-                       dout, dtable, rows, dim);
+__global__ void embedding_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dtable, long long n) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < EMB_SPLIT; ++k) s += part[(long long)k * n + i];
+    dtable[i] = s;
+}
+
+extern "C" int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, float* ws,
+                                       long long rows, int dim, int n_symbols, void* stream) {
+    T2_REQUIRE(ids && dout && dtable && ws && rows > 0 && dim > 0 && n_symbols > 0, "embedding_bwd: bad args");
+    T2_LAUNCH(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256), EMB_SPLIT), dim3(256), 0, (hipStream_t)stream,
+              ids, dout, ws, rows, dim, n_symbols);
+    const long long n = (long long)n_symbols * dim;
+    T2_LAUNCH(embedding_bwd_reduce_kernel, dim3(t2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, dtable, n);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -229,7 +229,7 @@ def _argtypes():
         "t2amd_bn_act_bwd_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P, _P, _P, _I, _P, _L, _F, _P, _P, _P, _P],
         "t2amd_colsum_f32": [_P, _L, _I, _I, _P, _P, _I, _P],
         "t2amd_embedding_fwd_f32": [_P, _P, _P, _L, _I, _I, _P],
-        "t2amd_embedding_bwd_f32": [_P, _P, _P, _L, _I, _I, _P],
+        "t2amd_embedding_bwd_f32": [_P, _P, _P, _P, _L, _I, _I, _P],
         "t2amd_philox_keep_mask": [_P, _L, _F, _UL, _UL, _P],
         "t2amd_fill_f32": [_P, _L, _F, _P],
         "t2amd_cast_bf16_f32": [_P, _P, _L, _P],
@@ -525,11 +525,15 @@ def embedding_fwd(ids, table, out):
            "t2amd_embedding_fwd_f32")
 
 
-def embedding_bwd(ids, dout, dtable):
+def embedding_bwd(ids, dout, dtable, ws=None):
     lib = load()
     rows = ids.numel()
+    if ws is None:
+        ws = torch.empty(8 * dtable.numel(), dtype=torch.float32, device=dtable.device)
+    if ws.numel() < 8 * dtable.numel():
+        raise NativeError("embedding_bwd: workspace too small")
     _check(lib.t2amd_embedding_bwd_f32(ptr(_fullc(ids), torch.int64), ptr(_fullc(dout)), ptr(_fullc(dtable)),
-                                       _i64(rows), dtable.shape[1], dtable.shape[0], _stream()),
+                                       ptr(_fullc(ws)), _i64(rows), dtable.shape[1], dtable.shape[0], _stream()),
            "t2amd_embedding_bwd_f32")
 
 

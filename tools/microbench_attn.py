@@ -1,0 +1,42 @@
+"""Timing of the attention step launches (tools only).  T2AMD_ATTN_STAGE=n truncates the kernels after stage n."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tacotron2_amd import native as nv
+dev = torch.device('cuda')
+B, Ti, E, Hq = 64, 177, 512, 1024
+g = torch.Generator(device='cpu').manual_seed(0)
+def rnd(*s): return torch.randn(*s, generator=g).to(dev)
+h, mem, pm = rnd(B, Hq), rnd(B, Ti, E), rnd(B, Ti, 128)
+Wq, U, v = rnd(128, Hq) * 0.05, rnd(128 * 62) * 0.1, rnd(128)
+lens = torch.randint(60, Ti + 1, (B,), generator=g).sort(descending=True)[0].to(torch.int32).to(dev)
+wprev = torch.softmax(rnd(B, Ti), 1); cum = torch.rand(B, Ti, device=dev)
+cum_save, w_out, ctx, q = torch.empty(B, Ti, device=dev), torch.empty(B, Ti, device=dev), torch.empty(B, E, device=dev), torch.empty(B, 128, device=dev)
+ws = torch.empty(nv.attn_fwd_ws_floats(B, Ti) + nv.attn_bwd_ws_floats(B, Ti), device=dev)
+dctx, dctx_total = rnd(B, E), torch.empty(B, E, device=dev)
+dwin, dcum = torch.zeros(4, B, 2, Ti, device=dev), torch.zeros(B, Ti, device=dev)
+d_pm, dU, dv_, dq, dh = torch.zeros(B, Ti, 128, device=dev), torch.zeros(B, 128, 62, device=dev), torch.zeros(B, 128, device=dev), torch.empty(B, 128, device=dev), torch.empty(4, B, Hq, device=dev)
+import ctypes as C
+lib = nv.load()
+# build the descriptors once (the python wrappers rebuild them per call, which is slower than the kernels)
+_cap = {}
+_of, _ob = lib.t2amd_attention_step_fwd_f32, lib.t2amd_attention_step_bwd_f32
+class _Grab:
+    def __init__(self, key): self.key = key
+    def __call__(self, ref, stream):
+        _cap[self.key] = (type(ref._obj).from_buffer_copy(ref._obj), stream); return 0
+lib.t2amd_attention_step_fwd_f32 = _Grab('f'); lib.t2amd_attention_step_bwd_f32 = _Grab('b')
+nv.attention_step_fwd(h, Wq, U, v, pm, mem, lens, wprev, cum, cum_save, w_out, ctx, q, ws)
+nv.attention_step_bwd([dctx], dctx_total, None, q, Wq, U, v, pm, mem, lens, w_out, wprev, cum_save, dwin, dcum, d_pm, dU, dv_, dq, dh, ws)
+lib.t2amd_attention_step_fwd_f32, lib.t2amd_attention_step_bwd_f32 = _of, _ob
+fa, fs = _cap['f']; ba, bs = _cap['b']
+def fwd(): _of(C.byref(fa), fs)
+def bwd(): _ob(C.byref(ba), bs)
+def timeit(fn, n=200):
+    for _ in range(10): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+print("stage", os.environ.get("T2AMD_ATTN_STAGE", "0"), "fwd (K_e+K_c) %.2f us   bwd (K_b1+K_b2) %.2f us" % (timeit(fwd), timeit(bwd)))
