@@ -480,6 +480,9 @@ typedef struct t2amd_lstm_seq {
 
 int t2amd_lstm_seq_fwd_f32(const t2amd_lstm_seq* p, void* stream);
 int t2amd_lstm_seq_bwd_f32(const t2amd_lstm_seq* p, void* stream);
+/* Both directions of the bi-LSTM in lockstep, one launch per step for the pair (q may be NULL). */
+int t2amd_lstm_seq_fwd2_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, void* stream);
+int t2amd_lstm_seq_bwd2_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, void* stream);
 
 /* Free-running decoder (reference model.py:418-454 Decoder.inference), any B: per-utterance
  * stop flags on the device, stop test sigmoid(gate) > threshold (strict) after the frame is

@@ -356,61 +356,99 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
 // ---------------------------------------------------------------------------------------
 // Encoder LSTM direction  (reference model.py:181-188)
 // ---------------------------------------------------------------------------------------
-extern "C" int t2amd_lstm_seq_fwd_f32(const t2amd_lstm_seq* p, void* stream) {
+static int check_seq_fwd(const t2amd_lstm_seq* p) {
     T2_REQUIRE(p && p->Whh && p->GX && p->out && p->C && p->lens, "lstm_seq_fwd: null pointer");
+    T2_REQUIRE(p->B > 0 && p->T > 0 && p->H % 64 == 0, "lstm_seq_fwd: H must be a multiple of 64");
+    return T2AMD_OK;
+}
+static void seq_fwd_step(const t2amd_lstm_seq* p, int s, t2amd_lstm_step& a) {
     const int B = p->B, T = p->T, H = p->H;
-    T2_REQUIRE(B > 0 && T > 0 && H % 64 == 0, "lstm_seq_fwd: H must be a multiple of 64");
-    for (int s = 0; s < T; ++s) {
-        const int t = p->reverse ? T - 1 - s : s;
-        const int tp = p->reverse ? t + 1 : t - 1;       // previous step in processing order
-        const bool first = (s == 0);
-        t2amd_lstm_step a = {};
-        a.nseg = 1;
-        a.x[0] = seg(first ? nullptr : p->out + (long long)tp * p->ld_out, (long long)T * p->ld_out, H);
-        a.W = p->Whh; a.Ktot = H; a.H = H; a.B = B;
-        a.gin = p->GX + (long long)t * 4 * H; a.ld_gin = (long long)T * 4 * H;
-        a.c_prev = first ? nullptr : p->C + (long long)tp * B * H; a.ld_cprev = H;
-        a.gates_out = p->GX + (long long)t * 4 * H; a.ld_gates = (long long)T * 4 * H;
-        a.c_out = p->C + (long long)t * B * H; a.ld_c = H;
-        a.h_out = p->out + (long long)t * p->ld_out; a.ld_h = (long long)T * p->ld_out;
-        a.lens = p->lens; a.t = t;
-        T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
+    const int t = p->reverse ? T - 1 - s : s;
+    const int tp = p->reverse ? t + 1 : t - 1;       // previous step in processing order
+    const bool first = (s == 0);
+    a = t2amd_lstm_step{};
+    a.nseg = 1;
+    a.x[0] = seg(first ? nullptr : p->out + (long long)tp * p->ld_out, (long long)T * p->ld_out, H);
+    a.W = p->Whh; a.Ktot = H; a.H = H; a.B = B;
+    a.gin = p->GX + (long long)t * 4 * H; a.ld_gin = (long long)T * 4 * H;
+    a.c_prev = first ? nullptr : p->C + (long long)tp * B * H; a.ld_cprev = H;
+    a.gates_out = p->GX + (long long)t * 4 * H; a.ld_gates = (long long)T * 4 * H;
+    a.c_out = p->C + (long long)t * B * H; a.ld_c = H;
+    a.h_out = p->out + (long long)t * p->ld_out; a.ld_h = (long long)T * p->ld_out;
+    a.lens = p->lens; a.t = t;
+}
+
+// q may be NULL.  With two descriptors (the two directions of the bi-LSTM: independent chains of the same
+// length) every step is ONE launch for both (reference model.py:181-188 runs them inside one cuDNN call).
+extern "C" int t2amd_lstm_seq_fwd2_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, void* stream) {
+    T2_PROPAGATE(check_seq_fwd(p));
+    if (q) {
+        T2_PROPAGATE(check_seq_fwd(q));
+        T2_REQUIRE(q->T == p->T, "lstm_seq_fwd2: both sequences must have the same length");
+    }
+    for (int s = 0; s < p->T; ++s) {
+        t2amd_lstm_step a, b;
+        seq_fwd_step(p, s, a);
+        if (q) seq_fwd_step(q, s, b);
+        T2_PROPAGATE(t2amd_lstm_step_fwd2_f32(&a, q ? &b : nullptr, stream));
+    }
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_lstm_seq_fwd_f32(const t2amd_lstm_seq* p, void* stream) {
+    return t2amd_lstm_seq_fwd2_f32(p, nullptr, stream);
+}
+
+static int check_seq_bwd(const t2amd_lstm_seq* p) {
+    T2_REQUIRE(p && p->WhhT && p->GX && p->C && p->lens && p->dout && p->DG && p->dX && p->dc,
+               "lstm_seq_bwd: null pointer");
+    T2_REQUIRE(p->B > 0 && p->T > 0 && p->H % 64 == 0, "lstm_seq_bwd: H must be a multiple of 64");
+    return T2AMD_OK;
+}
+static void seq_bwd_step(const t2amd_lstm_seq* p, int s, t2amd_lstm_bwd& lb, t2amd_skinny_gemm& g) {
+    const int B = p->B, T = p->T, H = p->H;
+    const int t = p->reverse ? T - 1 - s : s;
+    const int tp = p->reverse ? t + 1 : t - 1;
+    const bool last = (s == T - 1);
+    lb = t2amd_lstm_bwd{};
+    lb.B = B; lb.H = H;
+    lb.dh[0] = addend(p->dout + (long long)t * p->ld_dout, (long long)T * p->ld_dout, 1, 0);
+    lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dX, H, 1, 0);
+    lb.dh[2] = addend(nullptr, 0, 1, 0);
+    lb.gates = p->GX + (long long)t * 4 * H; lb.ld_gates = (long long)T * 4 * H;
+    lb.c_prev = (s == 0) ? nullptr : p->C + (long long)tp * B * H; lb.ld_cprev = H;
+    lb.c = p->C + (long long)t * B * H; lb.ld_c = H;
+    lb.dc = p->dc; lb.ld_dc = H;
+    lb.dgates = p->DG + (long long)t * 4 * H; lb.ld_dgates = (long long)T * 4 * H;
+    lb.lens = p->lens; lb.t = t;
+    g = t2amd_skinny_gemm{};
+    g.nseg = 1;
+    g.x[0] = seg(p->DG + (long long)t * 4 * H, (long long)T * 4 * H, 4 * H);
+    g.W = p->WhhT; g.Ktot = 4 * H; g.N = H; g.B = B;
+    g.Y = p->dX; g.ldy = H; g.nsplit = 1; g.split_stride = 0;
+}
+
+extern "C" int t2amd_lstm_seq_bwd2_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, void* stream) {
+    T2_PROPAGATE(check_seq_bwd(p));
+    if (q) {
+        T2_PROPAGATE(check_seq_bwd(q));
+        T2_REQUIRE(q->T == p->T, "lstm_seq_bwd2: both sequences must have the same length");
+    }
+    T2_PROPAGATE(t2amd_fill_f32(p->dc, (long long)p->B * p->H, 0.f, stream));
+    if (q) T2_PROPAGATE(t2amd_fill_f32(q->dc, (long long)q->B * q->H, 0.f, stream));
+    for (int s = p->T - 1; s >= 0; --s) {        // reverse of the processing order
+        t2amd_lstm_bwd la, lb;
+        t2amd_skinny_gemm ga, gb;
+        seq_bwd_step(p, s, la, ga);
+        if (q) seq_bwd_step(q, s, lb, gb);
+        T2_PROPAGATE(t2amd_lstm_pointwise_bwd2_f32(&la, q ? &lb : nullptr, stream));
+        if (s > 0) T2_PROPAGATE(t2amd_skinny_gemm2_f32(&ga, q ? &gb : nullptr, stream));
     }
     return T2AMD_OK;
 }
 
 extern "C" int t2amd_lstm_seq_bwd_f32(const t2amd_lstm_seq* p, void* stream) {
-    T2_REQUIRE(p && p->WhhT && p->GX && p->C && p->lens && p->dout && p->DG && p->dX && p->dc,
-               "lstm_seq_bwd: null pointer");
-    const int B = p->B, T = p->T, H = p->H;
-    T2_REQUIRE(B > 0 && T > 0 && H % 64 == 0, "lstm_seq_bwd: H must be a multiple of 64");
-    T2_PROPAGATE(t2amd_fill_f32(p->dc, (long long)B * H, 0.f, stream));
-    for (int s = T - 1; s >= 0; --s) {        // reverse of the processing order
-        const int t = p->reverse ? T - 1 - s : s;
-        const int tp = p->reverse ? t + 1 : t - 1;
-        const bool last = (s == T - 1);
-        t2amd_lstm_bwd lb = {};
-        lb.B = B; lb.H = H;
-        lb.dh[0] = addend(p->dout + (long long)t * p->ld_dout, (long long)T * p->ld_dout, 1, 0);
-        lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dX, H, 1, 0);
-        lb.dh[2] = addend(nullptr, 0, 1, 0);
-        lb.gates = p->GX + (long long)t * 4 * H; lb.ld_gates = (long long)T * 4 * H;
-        lb.c_prev = (s == 0) ? nullptr : p->C + (long long)tp * B * H; lb.ld_cprev = H;
-        lb.c = p->C + (long long)t * B * H; lb.ld_c = H;
-        lb.dc = p->dc; lb.ld_dc = H;
-        lb.dgates = p->DG + (long long)t * 4 * H; lb.ld_dgates = (long long)T * 4 * H;
-        lb.lens = p->lens; lb.t = t;
-        T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, stream));
-        if (s > 0) {
-            t2amd_skinny_gemm g = {};
-            g.nseg = 1;
-            g.x[0] = seg(p->DG + (long long)t * 4 * H, (long long)T * 4 * H, 4 * H);
-            g.W = p->WhhT; g.Ktot = 4 * H; g.N = H; g.B = B;
-            g.Y = p->dX; g.ldy = H; g.nsplit = 1; g.split_stride = 0;
-            T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
-        }
-    }
-    return T2AMD_OK;
+    return t2amd_lstm_seq_bwd2_f32(p, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------

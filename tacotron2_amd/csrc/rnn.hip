@@ -488,69 +488,101 @@ extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
 // ---------------------------------------------------------------------------------------
 struct LstmBwdParams { t2amd_lstm_bwd a[2]; int nblk0; };
 
-__device__ __forceinline__ float addend_sum(const t2amd_addend& ad, int row, int col) {
-    if (!ad.p) return 0.f;
-    float s = 0.f;
+__device__ __forceinline__ float4 addend_sum4(const t2amd_addend& ad, int row, int col) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ad.p) return s;
     const float* q = ad.p + (long long)row * ad.ld + col;
-    for (int k = 0; k < ad.nsplit; ++k) s += q[(long long)k * ad.split_stride];
+    for (int k = 0; k < ad.nsplit; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(q + (long long)k * ad.split_stride);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
     return s;
 }
 
-// one thread per (row, unit); blocks [0, nblk0) serve a[0], the rest a[1]
+// one thread per (row, 4 consecutive units): 16-byte loads/stores; blocks [0, nblk0) serve a[0], the rest a[1]
 __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p) {
     const bool second = (int)blockIdx.x >= p.nblk0;
     const t2amd_lstm_bwd& a = second ? p.a[1] : p.a[0];
     const int lb = (int)blockIdx.x - (second ? p.nblk0 : 0);
-    const int H = a.H;
-    const long long n = (long long)a.B * H;
+    const int H = a.H, H4 = H >> 2;
+    const long long n = (long long)a.B * H4;
     const long long idx = (long long)lb * 256 + threadIdx.x;
     if (idx >= n) return;
-    const int b = (int)(idx / H);
-    const int j = (int)(idx - (long long)b * H);
-    float* dg = a.dgates + (long long)b * a.ld_dgates;
+    const int b = (int)(idx / H4);
+    const int j = (int)(idx - (long long)b * H4) * 4;
+    float* dg = a.dgates + (long long)b * a.ld_dgates + j;
     float* dcp = a.dc + (long long)b * a.ld_dc + j;
+    unsigned short* d16 = a.dgates16 ? reinterpret_cast<unsigned short*>(a.dgates16) + (long long)b * a.ld_dgates16 + j : nullptr;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     bool valid = true;
     if (a.lens) valid = a.t < a.lens[b];
     if (!valid) {
-        dg[j] = 0.f; dg[H + j] = 0.f; dg[2 * H + j] = 0.f; dg[3 * H + j] = 0.f;
-        if (a.dgates16) {
-            unsigned short* d16 = reinterpret_cast<unsigned short*>(a.dgates16) + (long long)b * a.ld_dgates16;
-            d16[j] = 0; d16[H + j] = 0; d16[2 * H + j] = 0; d16[3 * H + j] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4*>(dg + q * H) = z4;
+            if (d16) *reinterpret_cast<uint2*>(d16 + q * H) = make_uint2(0u, 0u);
         }
-        *dcp = 0.f;
+        *reinterpret_cast<float4*>(dcp) = z4;
         return;
     }
     // issue every independent load before the first use
-    const float* g = a.gates + (long long)b * a.ld_gates;
-    const float gi = g[j], gf = g[H + j], gg = g[2 * H + j], go = g[3 * H + j];
-    const float c = a.c[(long long)b * a.ld_c + j];
-    const float cprev = a.c_prev ? a.c_prev[(long long)b * a.ld_cprev + j] : 0.f;
-    const float dc_in = *dcp;
-    const bool kp = a.keep ? a.keep[(long long)b * a.ld_keep + j] != 0 : true;
-    float dh = addend_sum(a.dh[0], b, j) + addend_sum(a.dh[1], b, j) + addend_sum(a.dh[2], b, j);
-    if (a.keep) dh = kp ? dh * a.keep_scale : 0.f;
-    const float tc = tanhf(c);
-    const float d_o = dh * tc;
-    const float dc = dc_in + dh * go * (1.f - tc * tc);
-    const float d0 = dc * gg * gi * (1.f - gi), d1 = dc * cprev * gf * (1.f - gf);
-    const float d2 = dc * gi * (1.f - gg * gg), d3 = d_o * go * (1.f - go);
-    dg[j] = d0;
-    dg[H + j] = d1;
-    dg[2 * H + j] = d2;
-    dg[3 * H + j] = d3;
-    if (a.dgates16) {       // bf16 copy: the dgrad GEMM's MFMA operand in bf16 mode
-        unsigned short* d16 = reinterpret_cast<unsigned short*>(a.dgates16) + (long long)b * a.ld_dgates16;
-        d16[j] = t2_f32_to_bf16(d0);
-        d16[H + j] = t2_f32_to_bf16(d1);
-        d16[2 * H + j] = t2_f32_to_bf16(d2);
-        d16[3 * H + j] = t2_f32_to_bf16(d3);
+    const float* g = a.gates + (long long)b * a.ld_gates + j;
+    const float4 gi = *reinterpret_cast<const float4*>(g), gf = *reinterpret_cast<const float4*>(g + H);
+    const float4 gg = *reinterpret_cast<const float4*>(g + 2 * H), go = *reinterpret_cast<const float4*>(g + 3 * H);
+    const float4 c = *reinterpret_cast<const float4*>(a.c + (long long)b * a.ld_c + j);
+    const float4 cprev = a.c_prev ? *reinterpret_cast<const float4*>(a.c_prev + (long long)b * a.ld_cprev + j) : z4;
+    const float4 dc_in = *reinterpret_cast<const float4*>(dcp);
+    unsigned kp = 0x01010101u;
+    if (a.keep) kp = *reinterpret_cast<const unsigned*>(a.keep + (long long)b * a.ld_keep + j);
+    const float4 d0 = addend_sum4(a.dh[0], b, j), d1 = addend_sum4(a.dh[1], b, j), d2 = addend_sum4(a.dh[2], b, j);
+    const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
+    const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
+    const float c_[4] = {c.x, c.y, c.z, c.w}, cp_[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
+    const float dci[4] = {dc_in.x, dc_in.y, dc_in.z, dc_in.w};
+    const float dh_[4] = {(d0.x + d1.x) + d2.x, (d0.y + d1.y) + d2.y, (d0.z + d1.z) + d2.z, (d0.w + d1.w) + d2.w};
+    float o0[4], o1[4], o2[4], o3[4], dcn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float dh = dh_[e];
+        if (a.keep) dh = ((kp >> (8 * e)) & 0xffu) ? dh * a.keep_scale : 0.f;
+        const float tc = tanhf(c_[e]);
+        const float d_o = dh * tc;
+        const float dc = dci[e] + dh * go_[e] * (1.f - tc * tc);
+        o0[e] = dc * gg_[e] * gi_[e] * (1.f - gi_[e]);
+        o1[e] = dc * cp_[e] * gf_[e] * (1.f - gf_[e]);
+        o2[e] = dc * gi_[e] * (1.f - gg_[e] * gg_[e]);
+        o3[e] = d_o * go_[e] * (1.f - go_[e]);
+        dcn[e] = dc * gf_[e];
     }
-    *dcp = dc * gf;
+    *reinterpret_cast<float4*>(dg) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+    *reinterpret_cast<float4*>(dg + H) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+    *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+    *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(o3[0], o3[1], o3[2], o3[3]);
+    if (d16) {       // bf16 copy: the dgrad GEMM's MFMA operand in bf16 mode
+#define T2_PK4(o) make_uint2((unsigned)t2_f32_to_bf16(o[0]) | ((unsigned)t2_f32_to_bf16(o[1]) << 16), \
+                             (unsigned)t2_f32_to_bf16(o[2]) | ((unsigned)t2_f32_to_bf16(o[3]) << 16))
+        *reinterpret_cast<uint2*>(d16) = T2_PK4(o0);
+        *reinterpret_cast<uint2*>(d16 + H) = T2_PK4(o1);
+        *reinterpret_cast<uint2*>(d16 + 2 * H) = T2_PK4(o2);
+        *reinterpret_cast<uint2*>(d16 + 3 * H) = T2_PK4(o3);
+#undef T2_PK4
+    }
+    *reinterpret_cast<float4*>(dcp) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
 }
 
 static int check_lstm_bwd(const t2amd_lstm_bwd* a) {
     T2_REQUIRE(a && a->gates && a->c && a->dc && a->dgates, "lstm_bwd: null args");
-    T2_REQUIRE(a->B > 0 && a->H > 0, "lstm_bwd: bad dims");
+    T2_REQUIRE(a->B > 0 && a->H > 0 && a->H % 4 == 0, "lstm_bwd: H must be a positive multiple of 4");
+    // 16-byte accesses: every row base and stride must keep 4-float alignment
+    T2_REQUIRE(t2_aligned16(a->gates) && t2_aligned16(a->c) && t2_aligned16(a->dc) && t2_aligned16(a->dgates) &&
+                   a->ld_gates % 4 == 0 && a->ld_c % 4 == 0 && a->ld_dc % 4 == 0 && a->ld_dgates % 4 == 0 &&
+                   (!a->c_prev || (t2_aligned16(a->c_prev) && a->ld_cprev % 4 == 0)) &&
+                   (!a->keep || ((reinterpret_cast<uintptr_t>(a->keep) & 3u) == 0 && a->ld_keep % 4 == 0)),
+               "lstm_bwd: operands must be 16-byte aligned with strides % 4 == 0");
+    for (int i = 0; i < 3; ++i)
+        if (a->dh[i].p)
+            T2_REQUIRE(t2_aligned16(a->dh[i].p) && a->dh[i].ld % 4 == 0 && a->dh[i].split_stride % 4 == 0,
+                       "lstm_bwd: dh addends must be 16-byte aligned with strides % 4 == 0");
     return T2AMD_OK;
 }
 
@@ -558,12 +590,12 @@ extern "C" int t2amd_lstm_pointwise_bwd2_f32(const t2amd_lstm_bwd* a, const t2am
     T2_PROPAGATE(check_lstm_bwd(a));
     LstmBwdParams p;
     p.a[0] = *a;
-    p.nblk0 = t2_cdiv((long long)a->B * a->H, 256);
+    p.nblk0 = t2_cdiv((long long)a->B * a->H / 4, 256);
     int total = p.nblk0;
     if (b) {
         T2_PROPAGATE(check_lstm_bwd(b));
         p.a[1] = *b;
-        total += t2_cdiv((long long)b->B * b->H, 256);
+        total += t2_cdiv((long long)b->B * b->H / 4, 256);
     } else {
         p.a[1] = *a;
     }

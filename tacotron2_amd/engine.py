@@ -319,8 +319,8 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         desc.out, desc.ld_out = nv.ptr(out_view), E
         desc.C = nv.ptr(Cst)
         desc.lens = nv.ptr(lens32, torch.int32)
-        nv.lstm_seq_fwd(desc)
-        c.enc_lstm.append(dict(GX=GX, C=Cst, Whh=Whh, Wih=Wih))
+        c.enc_lstm.append(dict(GX=GX, C=Cst, Whh=Whh, Wih=Wih, desc=desc))
+    nv.lstm_seq_fwd2(c.enc_lstm[0]['desc'], c.enc_lstm[1]['desc'])      # both directions, one launch per step
     c.x3, c.memory = x3, memory
 
     # ---- decoder: hoisted dense parts ------------------------------------------------------
@@ -598,6 +598,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         sync.bucket_ready('decoder', g)          # travels while the encoder backward runs
     # ---- encoder backward -----------------------------------------------------------------
     dx3 = run.empty(rowsE, E)
+    bdesc, DGs, keepalive = [], [], []
     for d, sfx in enumerate(('', '_reverse')):
         L = c.enc_lstm[d]
         WhhT = run.empty(He, 4 * He)
@@ -615,7 +616,12 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         dX = run.empty(B, He)
         dc = run.empty(B, He)
         desc.dX, desc.dc = nv.ptr(dX), nv.ptr(dc)
-        nv.lstm_seq_bwd(desc)
+        bdesc.append(desc)
+        DGs.append(DG)
+        keepalive.append((WhhT, dX, dc))
+    nv.lstm_seq_bwd2(bdesc[0], bdesc[1])                                 # both directions, paired launches
+    for d, sfx in enumerate(('', '_reverse')):
+        L, DG = c.enc_lstm[d], DGs[d]
         dWih = run.empty(4 * He, E)
         _rg(run, dWih, DG, c.x3, a_km=True, b_kn=True)
         # h_prev of row (b,t) is the output at (b, t-1) forward / (b, t+1) reverse, zero outside [0,T)
@@ -712,6 +718,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     x3, _ = _conv_stack_fwd(run, P, bufs, 'encoder.convolutions', hp.encoder_n_convolutions, x, Ti,
                             [1] * hp.encoder_n_convolutions, None, False, lens=lens32 if ragged else None)
     memory = run.empty(B, Ti, E)
+    idesc = []
     for d, sfx in enumerate(('', '_reverse')):
         Wih = P['encoder.lstm.weight_ih_l0' + sfx]
         Whh = P['encoder.lstm.weight_hh_l0' + sfx]
@@ -726,7 +733,8 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         desc.out, desc.ld_out = nv.ptr(out_view), E
         desc.C = nv.ptr(Cst)
         desc.lens = nv.ptr(lens32, torch.int32)
-        nv.lstm_seq_fwd(desc)
+        idesc.append((desc, GX, Cst))
+    nv.lstm_seq_fwd2(idesc[0][0], idesc[1][0])
 
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
     pm = run.empty(B, Ti, A)

@@ -213,6 +213,7 @@ SYMBOLS = [
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
+    "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
 ]
 
 _P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
@@ -255,6 +256,8 @@ def _argtypes():
         "t2amd_decoder_train_bwd_loop_f32": [pt(DecTrainBwd), _P],
         "t2amd_lstm_seq_fwd_f32": [pt(LstmSeq), _P],
         "t2amd_lstm_seq_bwd_f32": [pt(LstmSeq), _P],
+        "t2amd_lstm_seq_fwd2_f32": [pt(LstmSeq), pt(LstmSeq), _P],
+        "t2amd_lstm_seq_bwd2_f32": [pt(LstmSeq), pt(LstmSeq), _P],
         "t2amd_decoder_infer_steps_f32": [pt(DecInfer), _P],
         "t2amd_struct_sizes": [pt(C.c_int), _I],
         "t2amd_set_validate_only": [_I],
@@ -819,6 +822,16 @@ def decoder_train_bwd_loop(desc):
 def lstm_seq_fwd(desc):
     lib = load()
     _check(lib.t2amd_lstm_seq_fwd_f32(C.byref(desc), _stream()), "t2amd_lstm_seq_fwd_f32")
+
+
+def lstm_seq_fwd2(d0, d1):
+    lib = load()
+    _check(lib.t2amd_lstm_seq_fwd2_f32(C.byref(d0), C.byref(d1), _stream()), "t2amd_lstm_seq_fwd2_f32")
+
+
+def lstm_seq_bwd2(d0, d1):
+    lib = load()
+    _check(lib.t2amd_lstm_seq_bwd2_f32(C.byref(d0), C.byref(d1), _stream()), "t2amd_lstm_seq_bwd2_f32")
 
 
 def lstm_seq_bwd(desc):
