@@ -36,7 +36,9 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"),
+    ap.add_argument("--no-fp32-leg", action="store_true",
+                    help="skip the extra fp32-mode timing that is reported beside a bf16 run")
+    ap.add_argument("--precision", default="bf16", choices=("fp32", "bf16"),
                     help="fp32: exact-f32 MFMA forward, split-bf16 gradient GEMMs (parity mode); bf16: bf16 matrix "
                          "operands, f32 accumulation/state/master weights (BASELINE configs[1] names bf16)")
     ap.add_argument("--decoder-streams", type=int, default=1, choices=(1, 2),
@@ -166,19 +168,27 @@ def main():
         native.profile_enable(3 if fused else 2, To)  # role 3 = fused LSTM_d(t-1) || LSTM_a(t); role 2 = LSTM_d(t)
         step(batches[-1])
         torch.cuda.synchronize()
+        ev_ms = native.profile_event_overhead()
         ms, cnt = native.profile_read()
         B, Ha, Hd, E = args.batch_size, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.encoder_embedding_dim
 
+        es = 2.0 if args.precision == "bf16" else 4.0     # bytes per MFMA operand element
+
         def lstm_bytes(K, H, with_gin):
-            # weights once + activations in + (pre-activation addend) + bias + gates/c/h out + c_prev + keep mask
-            return 4.0 * (4 * H * K + B * K + (B * 4 * H if with_gin else 0) + 4 * H + B * 4 * H
-                          + 3 * B * H + 0.25 * B * H)
+            # weights once + activations in (operand precision) + f32: (pre-activation addend) + bias + gates/c/h
+            # out + c_prev + keep mask (+ the bf16 copy of h in bf16 mode)
+            return es * (4 * H * K + B * K) + 4.0 * ((B * 4 * H if with_gin else 0) + 4 * H + B * 4 * H
+                                                   + 3 * B * H + 0.25 * B * H) + (2.0 * B * H if es == 2.0 else 0.0)
         alg_bytes = lstm_bytes(Ha + E + Hd, Hd, False) + (lstm_bytes(E + Ha, Ha, True) if fused else 0.0)
         alg_flops = 2.0 * B * (4 * Hd * (Ha + E + Hd) + (4 * Ha * (E + Ha) if fused else 0))
-        avg_s = (ms / 1e3) / max(cnt, 1)
+        # A bracket = two hipEventRecords around ONE launch on its stream; an empty bracket costs ev_ms by itself
+        # (calibrated on the same stream right before the first launch), which is subtracted.
+        raw_s = (ms / 1e3) / max(cnt, 1)
+        avg_s = max(raw_s - ev_ms / 1e3, 1e-9)
         achieved = alg_bytes / avg_s / 1e9
-        kname = ("skinny_gemm_kernel<true,3> (one decoder time step: decoder LSTM of step t-1 (64x2560x4096) + attention "
-                 "LSTM of step t (64x1536x4096), exact-f32 MFMA + fused cells)") if fused else \
+        mm = "bf16 MFMA (f32 accumulate)" if es == 2.0 else "exact-f32 MFMA"
+        kname = ("skinny_gemm_kernel<true,3,%s> (one decoder time step: decoder LSTM of step t-1 (64x2560x4096) + attention "
+                 "LSTM of step t (64x1536x4096), %s + fused cells)" % ("true" if es == 2.0 else "false", mm)) if fused else \
                 ("skinny_gemm_kernel<true,2> (decoder LSTM step: 64x2560x4096 exact-f32 MFMA GEMM + fused cell; runs on the "
                  "side stream concurrently with the attention chain, so its duration includes sharing the CUs)")
         # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler
@@ -186,14 +196,43 @@ def main():
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_launch_fused" if fused else "hbm_bytes_per_launch"]
+                traffic = json.load(fh).get(("fused_" if fused else "single_") + args.precision)
         except Exception:
             traffic = None
         roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic,
-                    "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes,
-                    "mfma_f32": {"achieved_tflops": alg_flops / avg_s / 1e12, "peak_tflops": 157.3,
-                                 "frac": alg_flops / avg_s / 1e12 / 157.3}}
+                    "avg_launch_us": avg_s * 1e6, "avg_bracket_us": raw_s * 1e6, "empty_bracket_us": ev_ms * 1e3,
+                    "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes,
+                    "mfma": {"achieved_tflops": alg_flops / avg_s / 1e12,
+                             "peak_tflops": 2500.0 if es == 2.0 else 157.3,
+                             "frac": alg_flops / avg_s / 1e12 / (2500.0 if es == 2.0 else 157.3)}}
+    # ---- the same step in fp32 parity mode, reported beside a bf16 run (fewer steps, same batches) ----------
+    fp32_leg = None
+    if args.precision == "bf16" and not args.no_fp32_leg:
+        model.precision = "fp32"
+        k32 = max(2, args.steps // 2)
+        step(batches[0])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(k32):
+            step(batches[args.warmup + i % args.steps])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        fr = sum(frames[args.warmup + i % args.steps] for i in range(k32))
+        if world > 1:
+            t = torch.tensor([dt, float(fr)], dtype=torch.float64, device=dev)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dt, fr = tmax[0].item(), t[1].item()
+        fp32_leg = {"value": fr / dt, "unit": "valid mel-frames/s", "ms_per_step": 1e3 * dt / k32, "steps": k32,
+                    "note": "same workload with model.precision='fp32' (exact-f32 MFMA forward: the mode the 1e-4 / "
+                            "bit-exact-stop parity tests run in)"}
+        model.precision = args.precision
     if world > 1:
         dist.barrier()
 
@@ -217,6 +256,8 @@ def main():
             * args.gpus / elapsed if world == 1 else None
         if roofline:
             out["roofline"] = roofline
+        if fp32_leg:
+            out["fp32_mode"] = fp32_leg
         if args.gpus == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1234, args.cpu_threads)
         print(json.dumps(out), flush=True)

@@ -52,6 +52,9 @@ int t2amd_set_validate_only(int on);
  * t2amd_profile_read synchronises those events and returns the summed elapsed time and the count. */
 int t2amd_profile_enable(int tag, int max_launches);
 int t2amd_profile_read(float* total_ms, int* count);
+/* Elapsed time of an EMPTY bracket (two event records back to back on the launch stream), measured at the start
+ * of the profiling session: what a bracket costs besides the kernel.  Call before t2amd_profile_read. */
+int t2amd_profile_event_overhead(float* ms);
 
 /* ------------------------------------------------------------------------------------
  * Dense / implicit-convolution GEMM on exact-f32 MFMA (v_mfma_f32_32x32x2_f32).

@@ -31,11 +31,23 @@ extern "C" int t2amd_struct_sizes(int* out, int max_n) {
 // ---- live kernel timing (bench.py roofline) ---------------------------------------------------
 static int g_prof_tag = -1, g_prof_max = 0, g_prof_n = 0;
 static std::vector<hipEvent_t> g_prof_ev;
+// cost of an EMPTY event bracket on the launch stream (two hipEventRecords back to back), measured once per
+// profiling session just before the first real bracket: the part of a bracket that is not the kernel
+static hipEvent_t g_cal_ev[8];
+static int g_cal_have = 0, g_cal_done = 0;
 
 extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s) {
     if (g_prof_tag < 0 || tag != g_prof_tag || g_validate_only) return;
     if (!end) {
         if (g_prof_n >= g_prof_max) return;
+        if (!g_cal_done) {
+            if (!g_cal_have) {
+                for (int i = 0; i < 8; ++i) (void)hipEventCreate(&g_cal_ev[i]);
+                g_cal_have = 1;
+            }
+            for (int i = 0; i < 8; ++i) (void)hipEventRecord(g_cal_ev[i], s);
+            g_cal_done = 1;
+        }
         (void)hipEventRecord(g_prof_ev[2 * g_prof_n], s);
     } else {
         if (g_prof_n >= g_prof_max) return;
@@ -46,6 +58,7 @@ extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s) {
 
 extern "C" int t2amd_profile_enable(int tag, int max_launches) {
     g_prof_n = 0;
+    g_cal_done = 0;
     if (tag < 0 || max_launches <= 0) {
         g_prof_tag = -1;
         return T2AMD_OK;
@@ -57,6 +70,21 @@ extern "C" int t2amd_profile_enable(int tag, int max_launches) {
     }
     g_prof_max = max_launches;
     g_prof_tag = tag;
+    return T2AMD_OK;
+}
+
+// smallest elapsed time between two back-to-back event records of the calibration burst (ms), 0 if none
+extern "C" int t2amd_profile_event_overhead(float* ms) {
+    T2_REQUIRE(ms != nullptr, "profile_event_overhead: null arg");
+    *ms = 0.f;
+    if (!g_cal_done) return T2AMD_OK;
+    float best = -1.f;
+    if (hipEventSynchronize(g_cal_ev[7]) != hipSuccess) T2_FAIL("profile_event_overhead: event sync failed");
+    for (int i = 0; i + 1 < 8; ++i) {
+        float e = 0.f;
+        if (hipEventElapsedTime(&e, g_cal_ev[i], g_cal_ev[i + 1]) == hipSuccess && (best < 0.f || e < best)) best = e;
+    }
+    *ms = best < 0.f ? 0.f : best;
     return T2AMD_OK;
 }
 

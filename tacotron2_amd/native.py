@@ -198,7 +198,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
-    "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read",
+    "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
     "t2amd_gemm_f32", "t2amd_splitk_reduce_f32",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
@@ -266,6 +266,7 @@ def _argtypes():
         "t2amd_linear_small_f32": [pt(SmallLinear), _P],
         "t2amd_profile_enable": [_I, _I],
         "t2amd_profile_read": [pt(C.c_float), pt(C.c_int)],
+        "t2amd_profile_event_overhead": [pt(C.c_float)],
     }
 
 
@@ -341,6 +342,13 @@ def validate_only():
 def profile_enable(tag, max_launches):
     """Bracket every LSTM-step launch with role `tag` (1 attention LSTM, 2 decoder LSTM) by HIP events."""
     _check(load().t2amd_profile_enable(tag, max_launches), "t2amd_profile_enable")
+
+
+def profile_event_overhead():
+    """ms of an empty event bracket on the launch stream (call before profile_read)."""
+    ms = C.c_float(0)
+    _check(load().t2amd_profile_event_overhead(C.byref(ms)), "t2amd_profile_event_overhead")
+    return ms.value
 
 
 def profile_read():
