@@ -197,6 +197,10 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
     reference model.py:141-146 (Postnet.forward), :174-175 (Encoder.forward)."""
     saved = []
     rows = x.shape[0]
+    if training and rows == 1:
+        # same refusal, same exception type as torch.nn.functional.batch_norm under the reference
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                         % (torch.Size([1, x.shape[1], 1]),))
     for i in range(n_layers):
         W = P['%s.%d.0.conv.weight' % (prefix, i)]
         bias = P['%s.%d.0.conv.bias' % (prefix, i)]

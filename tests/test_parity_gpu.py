@@ -288,3 +288,58 @@ def test_bf16_compute_mode_train_step(native_lib):
     assert abs(float(loss.detach()) - float(oloss)) < 2e-2 * abs(float(oloss))
     assert cos > 0.999, cos
     assert worst < 0.25, worst
+
+
+@pytest.mark.parametrize("hpstr,in_lens,out_lens,gtol", [
+    # B = 1, two tokens, two frames: BatchNorm over TWO samples (1/sigma amplifies every rounding error, the
+    # embedding gradient reaches 22).  Ill-conditioned: against an fp64 run of the oracle the f32 oracle itself
+    # is off by 0.77 % of the gradient's max and the engine by 0.51 %, so the two f32 results are only held
+    # to 3e-2 of each other here
+    (gu.TINY_HP, [2], [2], 3e-2),
+    (gu.TINY_HP, [3, 3, 1], [2, 5, 1], 1e-3),     # shorter than the location kernel's halo; a length-1 utterance
+    (gu.TINY_HP, [40, 17, 16, 15, 2], [1, 33, 7, 64, 9], 1e-3),   # Ti across MFMA tile edges (15/16/17), To = 1 in the batch
+    ("", [19, 2], [3, 18], 1e-3),                 # default geometry, tiny ragged batch
+])
+def test_edge_shapes_match_oracle(native_lib, hpstr, in_lens, out_lens, gtol):
+    """Ragged / degenerate shapes against the live oracle with shared dropout masks (fp32 mode tolerances)."""
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    hp = gu.make_hparams(hpstr)
+    sd = gu.build_state_dict(hp, 99, perturb_bn=True)
+    order = sorted(range(len(in_lens)), key=lambda i: -in_lens[i])       # collate order: text length descending
+    il, ol = [in_lens[i] for i in order], [out_lens[i] for i in order]
+    batch = gu.make_train_batch(il, ol, hp.n_mel_channels, 99)
+    masks = orc.draw_masks_train(hp, len(il), max(il), max(ol), torch.Generator().manual_seed(5))
+    oloss, oout, ograds, obufs = orc.train_step_grads(sd, hp, batch, masks)
+    model = _model(hp, sd).train()
+    model.dropout_masks = gu.masks_to_engine(masks, DEV)
+    x, y = model.parse_batch(tuple(t.clone() for t in batch))
+    out = model(x)
+    loss = Tacotron2Loss()(out, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    for i in range(4):
+        mean, mx, refmax = _stats(out[i], oout[i])
+        assert mean < 1e-4 and mx < 5e-4 * max(1.0, refmax), (i, mean, mx)
+    assert abs(float(loss.detach()) - float(oloss)) < 1e-4 * max(1.0, abs(float(oloss)))
+    for k, p in model.named_parameters():
+        ref = ograds[k]
+        assert torch.isfinite(p.grad).all(), k
+        e = (p.grad.cpu() - ref).abs().max().item()
+        if k.endswith('.0.conv.bias'):
+            # a bias in front of a BatchNorm has an analytically zero gradient: both sides hold rounding noise,
+            # which must stay negligible next to the same layer's weight gradient
+            wmax = ograds[k.replace('.bias', '.weight')].abs().max().item()
+            assert p.grad.abs().max().item() < 1e-4 * wmax + 1e-5, (k, p.grad.abs().max().item(), wmax)
+            continue
+        assert e < gtol * ref.abs().max().item() + 2e-6, (k, e, ref.abs().max().item())
+
+
+def test_single_value_batchnorm_is_refused_like_the_reference(native_lib):
+    """B = 1, one token: torch's BatchNorm1d (reference model.py:174) raises ValueError in training mode."""
+    hp = gu.make_hparams(gu.TINY_HP)
+    sd = gu.build_state_dict(hp, 99)
+    batch = gu.make_train_batch([1], [3], hp.n_mel_channels, 99)
+    model = _model(hp, sd).train()
+    x, _ = model.parse_batch(tuple(t.clone() for t in batch))
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        model(x)
