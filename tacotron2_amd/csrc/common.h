@@ -74,5 +74,9 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     return v;
 }
 
+// internal entry points shared between translation units (not part of the C ABI)
+int t2amd_proj_finish_small_(const t2amd_small_linear* a, int* out_lengths, uint8_t* active, int* done_count, int t,
+                             int max_steps, float thr, int gate_row, void* stream);
+
 static inline bool t2_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int t2_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -31,6 +31,9 @@ struct SmallParams {
     // plain epilogue
     float* Y; long long ldy; int act;
     int xvec;            // 1: input rows are 16-byte aligned (float4 staging), 0: scalar staging
+    // optional stop test fused into the projection (plain epilogue): row `gate_row` is the gate logit
+    int* out_lengths; uint8_t* active; int* done_count;
+    int fin_t, fin_max_steps, gate_row; float fin_thr;
 };
 
 template <bool LSTM, int NB>
@@ -148,6 +151,16 @@ __global__ __launch_bounds__(256) void small_batch_kernel(SmallParams p) {
                 if (p.act == 1) v = fmaxf(v, 0.f);
                 if (p.keep) v = p.keep[(long long)b * p.ld_keep + n] ? v * p.keep_scale : 0.f;
                 p.Y[(long long)b * p.ldy + n] = v;
+                // stop test after the frame is emitted: sigmoid(gate) > threshold (strict); the stopping frame is
+                // part of the output (reference model.py:439-444)
+                if (p.out_lengths && n == p.gate_row && p.active[b]) {
+                    const float sg = 1.0f / (1.0f + expf(-v));
+                    if (sg > p.fin_thr || p.fin_t + 1 >= p.fin_max_steps) {
+                        p.out_lengths[b] = p.fin_t + 1;
+                        p.active[b] = 0;
+                        atomicAdd(p.done_count, 1);
+                    }
+                }
             }
         }
         return;
@@ -253,7 +266,22 @@ extern "C" int t2amd_lstm_step_small_f32(const t2amd_lstm_step* a, void* stream)
     return rc;
 }
 
+static int linear_small_impl(const t2amd_small_linear* a, int* out_lengths, uint8_t* active, int* done_count, int t,
+                             int max_steps, float thr, int gate_row, void* stream);
+
 extern "C" int t2amd_linear_small_f32(const t2amd_small_linear* a, void* stream) {
+    return linear_small_impl(a, nullptr, nullptr, nullptr, 0, 0, 0.f, -1, stream);
+}
+
+// internal (loops.hip): frame + gate projection with the per-utterance stop test fused in
+int t2amd_proj_finish_small_(const t2amd_small_linear* a, int* out_lengths, uint8_t* active, int* done_count, int t,
+                             int max_steps, float thr, int gate_row, void* stream) {
+    T2_REQUIRE(out_lengths && active && done_count, "proj_finish_small: null state");
+    return linear_small_impl(a, out_lengths, active, done_count, t, max_steps, thr, gate_row, stream);
+}
+
+static int linear_small_impl(const t2amd_small_linear* a, int* out_lengths, uint8_t* active, int* done_count, int t,
+                             int max_steps, float thr, int gate_row, void* stream) {
     T2_REQUIRE(a && a->X && a->W && a->Y, "linear_small: null args");
     T2_REQUIRE(a->B > 0 && a->B <= 8 && a->N > 0 && a->K > 0 && a->K % 4 == 0, "linear_small: 1 <= B <= 8, K % 4 == 0");
     T2_REQUIRE(t2_aligned16(a->W) && a->ldw % 4 == 0, "linear_small: W must be 16-byte aligned with ldw % 4 == 0");
@@ -266,5 +294,7 @@ extern "C" int t2amd_linear_small_f32(const t2amd_small_linear* a, void* stream)
     p.keep = a->keep; p.ld_keep = a->ldkeep; p.keep_scale = a->keep_scale;
     p.Y = a->Y; p.ldy = a->ldy;
     p.xvec = (t2_aligned16(a->X) && a->ldx % 4 == 0) ? 1 : 0;
+    p.out_lengths = out_lengths; p.active = active; p.done_count = done_count;
+    p.fin_t = t; p.fin_max_steps = max_steps; p.fin_thr = thr; p.gate_row = gate_row;
     return small_launch<false>(p, t2_cdiv(a->N, 16), stream);
 }

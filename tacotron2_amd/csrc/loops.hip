@@ -496,24 +496,23 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         g1.M = B; g1.N = P; g1.K = C; g1.a_kcontig = 1; g1.b_kcontig = 1; g1.batch = 1; g1.splitk = 1;
         g1.act = 1; g1.keep = p->keep_prenet + ((long long)t * 2 + 0) * sP; g1.ldkeep = P; g1.keep_scale = two;
         const bool small = B <= 8;        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
-        if (small) {
-            t2amd_small_linear l1 = {};
-            l1.X = g1.A; l1.ldx = g1.lda; l1.W = p->W1; l1.ldw = C; l1.Y = p->x_prenet; l1.ldy = P;
-            l1.B = B; l1.N = P; l1.K = C; l1.act = 1; l1.keep = g1.keep; l1.ldkeep = P; l1.keep_scale = two;
-            T2_PROPAGATE(t2amd_linear_small_f32(&l1, stream));
-        } else {
-            T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
-        }
         t2amd_gemm_desc g2 = {};
         g2.A = p->x_prenet; g2.lda = P; g2.B = p->W2; g2.ldb = P; g2.C = p->x_prenet + sP; g2.ldc = P;
         g2.M = B; g2.N = P; g2.K = P; g2.a_kcontig = 1; g2.b_kcontig = 1; g2.batch = 1; g2.splitk = 1;
         g2.act = 1; g2.keep = p->keep_prenet + ((long long)t * 2 + 1) * sP; g2.ldkeep = P; g2.keep_scale = two;
         if (small) {
+            // two launches of P/16 workgroups each: a single-workgroup fusion of both layers was measured 10x
+            // slower (one workgroup cannot keep 256 KB of weight loads in flight)
+            t2amd_small_linear l1 = {};
+            l1.X = g1.A; l1.ldx = g1.lda; l1.W = p->W1; l1.ldw = C; l1.Y = p->x_prenet; l1.ldy = P;
+            l1.B = B; l1.N = P; l1.K = C; l1.act = 1; l1.keep = g1.keep; l1.ldkeep = P; l1.keep_scale = two;
+            T2_PROPAGATE(t2amd_linear_small_f32(&l1, stream));
             t2amd_small_linear l2 = {};
             l2.X = p->x_prenet; l2.ldx = P; l2.W = p->W2; l2.ldw = P; l2.Y = p->x_prenet + sP; l2.ldy = P;
             l2.B = B; l2.N = P; l2.K = P; l2.act = 1; l2.keep = g2.keep; l2.ldkeep = P; l2.keep_scale = two;
             T2_PROPAGATE(t2amd_linear_small_f32(&l2, stream));
         } else {
+            T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
             T2_PROPAGATE(t2amd_gemm_f32(&g2, stream));
         }
 
@@ -568,7 +567,9 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             t2amd_small_linear lp = {};
             lp.X = gp.A; lp.ldx = gp.lda; lp.W = p->Wpg; lp.ldw = Hd + E; lp.bias = p->bias_pg;
             lp.Y = gp.C; lp.ldy = C + 1; lp.B = B; lp.N = C + 1; lp.K = Hd + E;
-            T2_PROPAGATE(t2amd_linear_small_f32(&lp, stream));
+            T2_PROPAGATE(t2amd_proj_finish_small_(&lp, p->out_lengths, p->active, p->done_count, t, p->max_steps,
+                                                  p->gate_threshold, C, stream));
+            continue;      // the stop test ran inside the projection kernel
         } else {
             T2_PROPAGATE(t2amd_gemm_f32(&gp, stream));
         }
