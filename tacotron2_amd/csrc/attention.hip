@@ -353,6 +353,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     int t1 = t0 + tsz;
     if (t1 > Ti) t1 = Ti;
 
+    // memory rows of the first trip (8 rows x 2 column groups per lane): they do not depend on dctx, so their
+    // latency overlaps the gradient sums and the carry gathers below
+    const int E4 = E >> 2;
+    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4;
+    const int grp = tid >> 5, l32 = tid & 31;      // 8 row groups of 32 lanes
+    float4 pm0[KB1_MAXP], pm1[KB1_MAXP];
+    {
+        const int c0 = l32, c1 = l32 + 32;
+        const bool two = c1 < E4;
+#pragma unroll
+        for (int i = 0; i < KB1_MAXP; ++i) {
+            const int ti = t0 + grp + 8 * i;
+            const int tc = (ti < t1 && ti < len) ? ti : 0;
+            pm0[i] = (c0 < E4) ? M4[(long long)tc * E4 + c0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pm1[i] = two ? M4[(long long)tc * E4 + c1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
     for (int c = tid; c < E; c += 256) {
         float s = 0.f;
 #pragma unroll
@@ -388,10 +406,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         }
     }
     __syncthreads();
-    const int E4 = E >> 2;
-    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4;
     float* __restrict__ dwo = a.ws + (long long)b * Ti;
-    const int grp = tid >> 5, l32 = tid & 31;      // 8 row groups of 32 lanes
     float psum = 0.f;
     for (int r0 = 0; r0 < tsz; r0 += 8 * KB1_MAXP) {
         float acc[KB1_MAXP];
@@ -401,12 +416,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
             const int c1 = c0 + 32;
             const bool two = c1 < E4;
             float4 m0[KB1_MAXP], m1[KB1_MAXP];
+            if (r0 == 0 && c0 == l32) {                 // the prefetched trip
 #pragma unroll
-            for (int i = 0; i < KB1_MAXP; ++i) {
-                const int ti = t0 + r0 + grp + 8 * i;
-                const int tc = (ti < t1 && ti < len) ? ti : 0;        // clamped: loaded, then ignored
-                m0[i] = M4[(long long)tc * E4 + c0];
-                m1[i] = M4[(long long)tc * E4 + (two ? c1 : c0)];
+                for (int i = 0; i < KB1_MAXP; ++i) { m0[i] = pm0[i]; m1[i] = pm1[i]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < KB1_MAXP; ++i) {
+                    const int ti = t0 + r0 + grp + 8 * i;
+                    const int tc = (ti < t1 && ti < len) ? ti : 0;        // clamped: loaded, then ignored
+                    m0[i] = M4[(long long)tc * E4 + c0];
+                    m1[i] = M4[(long long)tc * E4 + (two ? c1 : c0)];
+                }
             }
             const float4 g0 = *reinterpret_cast<const float4*>(&dctx_s[c0 * 4]);
             float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -469,6 +489,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
 
     const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + dbase + 4 * lg;
     float* __restrict__ dpmb = a.d_pm + (long long)b * Ti * AD + dbase + 4 * lg;
+    const float dv_old = tid < DSL ? a.dv_acc[(long long)b * AD + dbase + tid] : 0.f;   // read-modify-write operand, fetched early
     float4 pmA[2], pmB[2], opA[2], opB[2];      // issued now, consumed in the tile loop
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -598,7 +619,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dvs += red_s[(w * 2 + 0) * DSL + tid];
             dqs += red_s[(w * 2 + 1) * DSL + tid];
         }
-        a.dv_acc[(long long)b * AD + dbase + tid] += dvs;
+        a.dv_acc[(long long)b * AD + dbase + tid] = dv_old + dvs;
         dq_s[tid] = dqs;
         a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
     }
