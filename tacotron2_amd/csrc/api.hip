@@ -103,3 +103,10 @@ extern "C" int t2amd_profile_read(float* total_ms, int* count) {
     g_prof_tag = -1;
     return T2AMD_OK;
 }
+
+// tools only: n dependent launches of a trivial kernel on `stream` (per-launch floor measurement)
+__global__ void t2_nop_kernel(float* p) { if (threadIdx.x == 0 && blockIdx.x == 0 && p) p[0] += 1.0f; }
+extern "C" int t2amd_debug_launch_chain_(float* p, int n, int blocks, void* stream) {
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(t2_nop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return 0;
+}

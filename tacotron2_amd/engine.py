@@ -10,6 +10,8 @@ Data layout in HBM (fp32): activations are channel-last.  Encoder / postnet rows
 batch-major ``(b, t)``; decoder slabs are time-major ``[T][B][F]`` so that one step's slice is
 contiguous.  Reference call sites are cited next to each stage.
 """
+import os
+
 import torch
 
 from . import native as nv
@@ -490,7 +492,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     nv.transpose(Wa_recT, T['Wa_rec'])
     Wd_catT = run.empty(Ha + E + Hd, 4 * Hd)
     nv.transpose(Wd_catT, T['Wd_cat'])
-    ns = 2
+    ns = int(os.environ.get('T2AMD_DGRAD_SPLIT', '2'))      # split-K factor of the two BPTT dgrad GEMMs
     bw = nv.DecTrainBwd()
     bw.f = c.dec
     bw.Wa_recT, bw.Wd_catT = nv.ptr(Wa_recT), nv.ptr(Wd_catT)
