@@ -371,7 +371,7 @@ typedef struct t2amd_attn_bwd {
     float* dh_out;           /* [T2AMD_ATT_SLICES] partial slabs of Wq^T dq: slice s, row b at dh_out + s*dh_split_stride + b*ld_dh */
     long long ld_dh;
     long long dh_split_stride;
-    float* ws;               /* workspace, >= B*Ti + T2AMD_ATT_SLICES*B floats */
+    float* ws;               /* workspace, >= B*Ti + 8*B floats */
 } t2amd_attn_bwd;
 
 int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);

@@ -29,6 +29,8 @@
 #define HALO 15
 #define NSL T2AMD_ATT_SLICES   // 4 slices per utterance in every kernel
 #define DSL (AD / NSL)         // 32 attention dims per K_e / K_b2 workgroup
+#define NCS 4                  // context-channel slices (K_c workgroups per utterance)
+#define NTS 4                  // position slices (K_b1 workgroups per utterance)
 #define DCL 68                 // dcol_s row stride (floats)
 #define DPL 48                 // dpre_s row stride (floats): 48*lg mod 64 = {0,48,32,16}: conflict-free A reads
 
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
 
     // The context rows do not depend on the softmax: fetch this thread's share of memory[b] first so
     // that the HBM/L2 latency overlaps the three dependent reductions below.
-    const int EC = E / NSL, EC4 = EC >> 2, E4 = E >> 2;
+    const int EC = E / NCS, EC4 = EC >> 2, E4 = E >> 2;
     int parts = KC_NT / EC4;
     if (parts > 32) parts = 32;
     const int c4 = tid % EC4, part = tid / EC4;
@@ -306,7 +308,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     T2_REQUIRE(a && a->h && a->Wq && a->U && a->v && a->pm && a->memory && a->cum && a->w_out && a->ctx_out && a->ws,
                "attn_fwd: null pointer");
     T2_REQUIRE(a->B > 0 && a->Ti > 0 && a->Ti <= 8192, "attn_fwd: Ti out of range");
-    T2_REQUIRE(a->E % (4 * NSL) == 0 && a->E >= 4 * NSL && a->E <= 4096, "attn_fwd: E must be a multiple of 16, <= 4096");
+    T2_REQUIRE(a->E % (4 * NCS) == 0 && a->E >= 4 * NCS && a->E <= 4096, "attn_fwd: E must be a multiple of 32, <= 4096");
     T2_REQUIRE(a->Hq % 32 == 0 && a->Hq > 0, "attn_fwd: Hq must be a multiple of 32");
     T2_REQUIRE(t2_aligned16(a->Wq) && t2_aligned16(a->memory) && t2_aligned16(a->pm) && t2_aligned16(a->h) &&
                    a->ld_h % 4 == 0,
@@ -317,14 +319,14 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     p.dbg = attn_dbg_stage();
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP);
-    const int EC = a->E / NSL;
+    const int EC = a->E / NCS;
     int parts = KC_NT / (EC / 4);
     if (parts > 32) parts = 32;
     T2_REQUIRE(parts >= 1, "attn_fwd: E too large");
     const size_t lds_c = sizeof(float) * ((size_t)((a->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
     T2_REQUIRE(lds_e <= 64 * 1024 && lds_c <= 64 * 1024, "attn_fwd: Ti too large for the LDS windows");
     T2_LAUNCH(attn_energy_kernel, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
-    T2_LAUNCH(attn_context_kernel, dim3(NSL, a->B), dim3(KC_NT), lds_c, s, p);
+    T2_LAUNCH(attn_context_kernel, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     const int ts = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Ti = a.Ti, E = a.E, B = a.B;
-    const int tsz = (Ti + NSL - 1) / NSL;
+    const int tsz = (Ti + NTS - 1) / NTS;
     float* dctx_s = smem;            // [E]
     float* base_s = dctx_s + E;      // [tsz] carries + running dcum (+ extra) per position of the slice
     float* wl_s = base_s + tsz;      // [tsz] this step's weights
@@ -507,7 +509,9 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     }
     {
         const float* sd = a.ws + (long long)B * Ti;
-        const float sdot = ((sd[b] + sd[B + b]) + sd[2 * B + b]) + sd[3 * B + b];
+        float sdot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTS; ++k) sdot += sd[k * B + b];
         const float* __restrict__ wrow = a.w + (long long)b * a.ld_w;
         const float* __restrict__ dwi = a.ws + (long long)b * Ti;
         for (int ti = tid; ti < NP; ti += KB2_NT) de_s[ti] = (ti < len) ? wrow[ti] * (dwi[ti] - sdot) : 0.f;
@@ -718,7 +722,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     p.np = ((a->Ti + 15) / 16) * 16;
     p.dbg = attn_dbg_stage();
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds1 = sizeof(float) * ((size_t)a->E + 2 * (size_t)((a->Ti + NSL - 1) / NSL) + 8);
+    const size_t lds1 = sizeof(float) * ((size_t)a->E + 2 * (size_t)((a->Ti + NTS - 1) / NTS) + 8);
     const size_t lds2 = sizeof(float) * (2 * (size_t)p.tip + p.np + (size_t)p.np * (DCL + DPL) + KB2_NW * 2 * DSL + DSL +
                                          DSL * NTAP + (size_t)a->Hq);
     T2_REQUIRE(lds1 <= 64 * 1024, "attn_bwd: E too large");
@@ -727,7 +731,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         g_attn_bwd_lds = (int)lds2;
     }
-    T2_LAUNCH(attn_bwd_dw_kernel, dim3(NSL, a->B), dim3(256), lds1, s, p);
+    T2_LAUNCH(attn_bwd_dw_kernel, dim3(NTS, a->B), dim3(256), lds1, s, p);
     T2_LAUNCH(attn_bwd_main_kernel, dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;

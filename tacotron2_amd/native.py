@@ -757,7 +757,7 @@ def attn_fwd_ws_floats(B, Ti):
 
 
 def attn_bwd_ws_floats(B, Ti):
-    return B * Ti + ATT_SLICES * B
+    return B * Ti + 8 * B
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None):
