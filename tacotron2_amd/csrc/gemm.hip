@@ -426,9 +426,11 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 // X3 = false is the plain bf16 product (precision 2): only the hi halves are formed, stored and multiplied.
 template <bool AK, bool BKC, bool X3>
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
-    // [buf][hi/lo][row][HLD_]
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][2][HBM_][HLD_];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][2][HBN_][HLD_];
+    // [buf][hi/lo][row][HLD_]; the plain-bf16 variant has no lo image: 40 KB instead of 80 KB -> twice the
+    // workgroups per CU
+    constexpr int NH = X3 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][NH][HBM_][HLD_];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][NH][HBN_][HLD_];
 
     const t2amd_gemm_desc& d = p.d;
     const int tid = threadIdx.x;
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
     };
 
     auto store_one = [&](unsigned short (*S)[HBM_][HLD_], bool kc, const float4 (&r)[4]) {
-        // S = As[buf] or Bs[buf] : [hi/lo][row][HLD_]
+        // S = As[buf] or Bs[buf] : [hi/lo][row][HLD_]   (index 1 exists only when X3)
         if (kc) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
                 uint2 hi, lo;
                 split4(r[i].x, r[i].y, r[i].z, r[i].w, hi, lo);
                 *reinterpret_cast<uint2*>(&S[0][row][kq * 4]) = hi;
-                if (X3) *reinterpret_cast<uint2*>(&S[1][row][kq * 4]) = lo;
+                if (X3) *reinterpret_cast<uint2*>(&S[NH - 1][row][kq * 4]) = lo;
             }
         } else {
             // M-contiguous operand: "pair-interleaved" image P[k/2][m] (one dword = the bf16 pair (k, k+1) of
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
             // two 16-byte stores per half, consecutive lanes -> consecutive 16 B: conflict-free.
             const int m4 = tid & 31, kq = tid >> 5;
             unsigned* Ph = reinterpret_cast<unsigned*>(&S[0][0][0]);
-            unsigned* Pl = reinterpret_cast<unsigned*>(&S[1][0][0]);
+            unsigned* Pl = reinterpret_cast<unsigned*>(&S[NH - 1][0][0]);
             uint4 h0, h1, l0, l1;
             {
                 const float a0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};   // k = 4kq
@@ -669,8 +671,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
                 ah[t] = frag(As[cur][0], AK, wm * 64 + t * 32 + l31, ks, lhi);
                 bh[t] = frag(Bs[cur][0], BKC, wn * 64 + t * 32 + l31, ks, lhi);
                 if (X3) {
-                    al[t] = frag(As[cur][1], AK, wm * 64 + t * 32 + l31, ks, lhi);
-                    bl[t] = frag(Bs[cur][1], BKC, wn * 64 + t * 32 + l31, ks, lhi);
+                    al[t] = frag(As[cur][NH - 1], AK, wm * 64 + t * 32 + l31, ks, lhi);
+                    bl[t] = frag(Bs[cur][NH - 1], BKC, wn * 64 + t * 32 + l31, ks, lhi);
                 }
             }
 #pragma unroll
