@@ -87,13 +87,17 @@ def main():
         raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # T2AMD_DIST_BACKEND=gloo lets the N>1 control flow be exercised on a 1-GPU box (ranks share cuda:0); the
+    # driver's runs use RCCL with one rank per GPU.
+    backend = os.environ.get("T2AMD_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
 
     from tacotron2_amd import build, native
     if rank == 0 or not os.path.exists(native.LIB_PATH):
@@ -162,6 +166,9 @@ def main():
 
     # ---- roofline of the dominant kernel: one extra untimed step with HIP-event brackets ------
     roofline = None
+    if not args.no_roofline and rank != 0:
+        step(batches[-1])                 # the gradient exchange is collective: every rank runs the extra step
+        torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
         To = batches[-1][2].shape[2]
         fused = args.decoder_streams == 1
