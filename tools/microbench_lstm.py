@@ -60,3 +60,40 @@ print("fused d||d    %.2f us" % timeit(lambda: lib.t2amd_lstm_step_fwd2_f32(C.by
 flops = 2.0 * B * 4 * Hd * (Ha + E + Hd)
 t = timeit(lambda: lib.t2amd_lstm_step_fwd_f32(C.byref(d), s))
 print("LSTM_d alone: %.1f TFLOP/s f32 MFMA, %.2f TB/s weights" % (flops / t / 1e6, 4 * 4 * Hd * (Ha + E + Hd) / t / 1e6))
+
+
+# ---- bf16 operands (model.precision='bf16'): LSTM pair and the BPTT dgrad pair --------------------------------
+def mk16(K, H, nseg_w):
+    st, keep = mk(K, H, nseg_w)
+    xs16 = [torch.randn(B, w, device=dev).to(torch.bfloat16) for w in nseg_w]
+    W16 = (torch.randn(4 * H, K, device=dev) * 0.02).to(torch.bfloat16)
+    for i, x in enumerate(xs16):
+        st.x[i] = nv._seg(x, x.shape[1], torch.bfloat16)
+    st.W = nv.ptr(W16, torch.bfloat16)
+    st.bf16 = 1
+    return st, (keep, xs16, W16)
+
+
+def mkplain16(K, N, nsplit):
+    a = nv.SkinnyGemm()
+    x = torch.randn(B, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+    Y = torch.empty(nsplit, B, N, device=dev)
+    a.nseg = 1
+    a.x[0] = nv._seg(x, K, torch.bfloat16)
+    a.W = nv.ptr(W, torch.bfloat16)
+    a.bf16 = 1
+    a.Ktot, a.N, a.B = K, N, B
+    a.Y, a.ldy, a.nsplit, a.split_stride = nv.ptr(Y), N, nsplit, B * N
+    return a, (x, W, Y)
+
+
+d16, kd16 = mk16(Ha + E + Hd, Hd, [Ha, E, Hd])
+a16, ka16 = mk16(E + Ha, Ha, [E, Ha])
+print("bf16 LSTM_d alone  %.2f us" % timeit(lambda: lib.t2amd_lstm_step_fwd_f32(C.byref(d16), s)))
+print("bf16 LSTM_a alone  %.2f us" % timeit(lambda: lib.t2amd_lstm_step_fwd_f32(C.byref(a16), s)))
+print("bf16 fused d||a    %.2f us" % timeit(lambda: lib.t2amd_lstm_step_fwd2_f32(C.byref(d16), C.byref(a16), s)))
+for ns in (1, 2, 4):
+    gd, kgd = mkplain16(4 * Hd, Ha + E + Hd, ns)
+    ga, kga = mkplain16(4 * Ha, E + Ha, ns)
+    print("bf16 dgrad d||a nsplit=%d  %.2f us" % (ns, timeit(lambda: lib.t2amd_skinny_gemm2_f32(C.byref(gd), C.byref(ga), s))))
