@@ -23,6 +23,34 @@ struct GemmParams {
     int ktiles_per_split;
 };
 
+// XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest), and each
+// XCD has its own 4 MB L2: with the plain blockIdx -> tile map every XCD walks ALL row tiles and re-fetches the whole
+// A operand (measured on the 4096x2560x55k wgrad: L2 hit rate 60 %, 14 GB of fabric reads for 1.5 GB of operands).
+// Here XCD j takes a contiguous run of logical tile ids, and ids are laid out in groups of 8 row tiles x all
+// column tiles (column-major inside the group), so the ~96 workgroups an XCD runs at once form an ~8 x 12 block of
+// tiles that shares 8 A tiles and 12 B tiles per k step.
+struct TileId { int bx, by, bz; };
+__device__ __forceinline__ TileId xcd_tile_id() {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int total = nbx * nby * (int)gridDim.z;
+    const int L = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+    const int xcd = L & 7, q = L >> 3;
+    const int base = total >> 3, rem = total & 7;
+    const int id = xcd * base + (xcd < rem ? xcd : rem) + q;      // bijection for any total
+    const int per_z = nbx * nby;
+    TileId t;
+    t.bz = id / per_z;
+    const int r = id - t.bz * per_z;
+    const int G = 8;
+    const int group = r / (G * nbx);
+    const int first = group * G;
+    const int gsz = (nby - first) < G ? (nby - first) : G;
+    const int w = r - group * (G * nbx);
+    t.by = first + w % gsz;
+    t.bx = w / gsz;
+    return t;
+}
+
 template <bool AK, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float As[2][GBK][GLD];
@@ -34,15 +62,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int z = blockIdx.z;
+    const TileId tile = xcd_tile_id();
+    const int z = tile.bz;
     const int bidx = z / d.splitk;
     const int split = z - bidx * d.splitk;
     const float* __restrict__ A = d.A + (long long)bidx * d.strideA;
     const float* __restrict__ B = d.B + (long long)bidx * d.strideB;
     float* __restrict__ C = d.C + (long long)bidx * d.strideC + (long long)split * d.strideSplitC;
 
-    const int row0 = blockIdx.y * GBM;
-    const int col0 = blockIdx.x * GBN;
+    const int row0 = tile.by * GBM;
+    const int col0 = tile.bx * GBN;
     const int M = d.M, N = d.N;
     const int kbeg = split * p.ktiles_per_split * GBK;
     int kend = kbeg + p.ktiles_per_split * GBK;
@@ -268,8 +297,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     }
 }
 
-template <bool AK, bool BKC, bool X3>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p);
+template <bool AK, bool BKC, bool X3, int TB>
+__global__ __launch_bounds__(2 * TB) void gemm_bf16x3_kernel(GemmParams p);
+
+// Output tile edge the library will use for an (M, N) product at this precision when `nz` = batch * splitk slices
+// of it are launched: callers that split K size the split from it.  256 only for the plain-bf16 kernel, on outputs
+// at least two 256-tiles wide both ways, and only when the launch still has >= 192 workgroups (a 256-tile workgroup
+// owns a whole CU).  T2AMD_GEMM_TILE=128 forces the small tile (A/B measurements).
+extern "C" int t2amd_gemm_tile_size(int M, int N, int precision, int nz) {
+    static const bool force128 = [] { const char* e = getenv("T2AMD_GEMM_TILE"); return e && atoi(e) == 128; }();
+    if (force128 || precision != 2 || M < 512 || N < 512) return 128;
+    const long long wgs = (long long)t2_cdiv(M, 256) * t2_cdiv(N, 256) * (nz > 0 ? nz : 1);
+    return wgs >= 192 ? 256 : 128;
+}
 
 extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
     T2_REQUIRE(dp != nullptr, "gemm: null descriptor");
@@ -319,25 +359,38 @@ extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (fast && d.precision == 1) {
         if (d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, true, true>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<true, true, true, 128>), grid, dim3(256), 0, s, p);
         else if (d.a_kcontig && !d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, false, true>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<true, false, true, 128>), grid, dim3(256), 0, s, p);
         else if (!d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<false, true, true>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<false, true, true, 128>), grid, dim3(256), 0, s, p);
         else
-            T2_LAUNCH((gemm_bf16x3_kernel<false, false, true>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<false, false, true, 128>), grid, dim3(256), 0, s, p);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
+    if (fast && t2amd_gemm_tile_size(d.M, d.N, d.precision, d.batch * d.splitk) == 256) {
+        dim3 g2(t2_cdiv(d.N, 256), t2_cdiv(d.M, 256), d.batch * d.splitk);
+        if (d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, true, false, 256>), g2, dim3(512), 0, s, p);
+        else if (d.a_kcontig && !d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, false, false, 256>), g2, dim3(512), 0, s, p);
+        else if (!d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<false, true, false, 256>), g2, dim3(512), 0, s, p);
+        else
+            T2_LAUNCH((gemm_bf16x3_kernel<false, false, false, 256>), g2, dim3(512), 0, s, p);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
     if (fast) {
         if (d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, true, false>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<true, true, false, 128>), grid, dim3(256), 0, s, p);
         else if (d.a_kcontig && !d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, false, false>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<true, false, false, 128>), grid, dim3(256), 0, s, p);
         else if (!d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<false, true, false>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<false, true, false, 128>), grid, dim3(256), 0, s, p);
         else
-            T2_LAUNCH((gemm_bf16x3_kernel<false, false, false>), grid, dim3(256), 0, s, p);
+            T2_LAUNCH((gemm_bf16x3_kernel<false, false, false, 128>), grid, dim3(256), 0, s, p);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
@@ -424,29 +477,40 @@ __device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u
 }
 
 // X3 = false is the plain bf16 product (precision 2): only the hi halves are formed, stored and multiplied.
-template <bool AK, bool BKC, bool X3>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
+// TB = 128: 256 threads, waves 2 x 2, 64 x 64 per wave.  TB = 256: 512 threads, waves 2 (m) x 4 (n), 128 x 64 per
+// wave -- every operand byte fetched from L2 feeds twice the MFMA work (the 128-tile kernel saturates at ~300 TF on
+// the 55k-deep wgrads whatever its occupancy: it is bound by operand traffic, not by latency).
+template <bool AK, bool BKC, bool X3, int TB>
+__global__ __launch_bounds__(2 * TB) void gemm_bf16x3_kernel(GemmParams p) {
+    constexpr int NTHR = 2 * TB;
+    constexpr int WN = TB / 64;            // waves along n (2 or 4); 2 along m
+    constexpr int TM = TB / 64;            // 32-row MFMA tiles per wave along m (2 or 4); 2 along n
     // [buf][hi/lo][row][HLD_]; the plain-bf16 variant has no lo image: 40 KB instead of 80 KB -> twice the
     // workgroups per CU
+    // K-contiguous operands use padded rows (HLD_ shorts); the pair-interleaved image of an M-contiguous operand is
+    // exactly [16][128] dwords and needs no padding: 32 KB for a wgrad (both M-contiguous), five workgroups per CU.
     constexpr int NH = X3 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned short As[2][NH][HBM_][HLD_];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][NH][HBN_][HLD_];
+    constexpr int ALD = AK ? HLD_ : 32, BLD = BKC ? HLD_ : 32;
+    constexpr int AIMG = TB * ALD, BIMG = TB * BLD;       // shorts per image
+    __shared__ __attribute__((aligned(16))) unsigned short As[2][NH * AIMG];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2][NH * BIMG];
 
     const t2amd_gemm_desc& d = p.d;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
-    const int z = blockIdx.z;
+    const TileId tile = xcd_tile_id();
+    const int z = tile.bz;
     const int bidx = z / d.splitk;
     const int split = z - bidx * d.splitk;
     const float* __restrict__ A = d.A + (long long)bidx * d.strideA;
     const float* __restrict__ B = d.B + (long long)bidx * d.strideB;
     float* __restrict__ C = d.C + (long long)bidx * d.strideC + (long long)split * d.strideSplitC;
 
-    const int row0 = blockIdx.y * HBM_;
-    const int col0 = blockIdx.x * HBN_;
+    const int row0 = tile.by * TB;
+    const int col0 = tile.bx * TB;
     const int M = d.M, N = d.N;
     const int kbeg = split * p.ktiles_per_split * HBK_;
     int kend = kbeg + p.ktiles_per_split * HBK_;
@@ -458,11 +522,11 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
     int a_t[4] = {0, 0, 0, 0};
     if (AK && d.convA_T > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a_t[i] = (row0 + ((tid + 256 * i) >> 3)) % d.convA_T;
+        for (int i = 0; i < 4; ++i) a_t[i] = (row0 + ((tid + NTHR * i) >> 3)) % d.convA_T;
     }
     int b_tap = 0, b_ci = 0;
     if (!BKC && d.convB_T > 0) {
-        const int gn = col0 + (tid & 31) * 4;
+        const int gn = col0 + (tid & (TB / 4 - 1)) * 4;
         b_tap = gn / d.convB_C;
         b_ci = gn - b_tap * d.convB_C;
     }
@@ -474,7 +538,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (AK) {
-                const int f = tid + 256 * i;
+                const int f = tid + NTHR * i;
                 const int r = f >> 3, kq = f & 7;
                 const int gm = row0 + r;
                 const int gk = k0 + kq * 4;
@@ -503,7 +567,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
                     }
                 }
             } else {
-                const int m4 = tid & 31, kq = tid >> 5;
+                const int m4 = tid & (TB / 4 - 1), kq = tid / (TB / 4);
                 const int gk = k0 + kq * 4 + i;
                 const int gm = row0 + m4 * 4;
                 if (gk < kend && gm < M) {
@@ -527,7 +591,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (BKC) {
-                const int f = tid + 256 * i;
+                const int f = tid + NTHR * i;
                 const int r = f >> 3, kq = f & 7;
                 const int gn = col0 + r;
                 const int gk = k0 + kq * 4;
@@ -543,7 +607,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
                     }
                 }
             } else {
-                const int n4 = tid & 31, kq = tid >> 5;
+                const int n4 = tid & (TB / 4 - 1), kq = tid / (TB / 4);
                 const int gk = k0 + kq * 4 + i;
                 const int gn = col0 + n4 * 4;
                 if (gk < kend && gn < N) {
@@ -574,25 +638,25 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
         }
     };
 
-    auto store_one = [&](unsigned short (*S)[HBM_][HLD_], bool kc, const float4 (&r)[4]) {
-        // S = As[buf] or Bs[buf] : [hi/lo][row][HLD_]   (index 1 exists only when X3)
+    auto store_one = [&](unsigned short* S, int img, bool kc, const float4 (&r)[4]) {
+        // S = As[buf] or Bs[buf] : hi image, then (X3 only) the lo image `img` shorts further
         if (kc) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int f = tid + 256 * i;
+                const int f = tid + NTHR * i;
                 const int row = f >> 3, kq = f & 7;
                 uint2 hi, lo;
                 split4(r[i].x, r[i].y, r[i].z, r[i].w, hi, lo);
-                *reinterpret_cast<uint2*>(&S[0][row][kq * 4]) = hi;
-                if (X3) *reinterpret_cast<uint2*>(&S[NH - 1][row][kq * 4]) = lo;
+                *reinterpret_cast<uint2*>(&S[row * HLD_ + kq * 4]) = hi;
+                if (X3) *reinterpret_cast<uint2*>(&S[img + row * HLD_ + kq * 4]) = lo;
             }
         } else {
             // M-contiguous operand: "pair-interleaved" image P[k/2][m] (one dword = the bf16 pair (k, k+1) of
             // row m), aliased onto the same storage.  This thread holds k = 4kq..4kq+3 for m = 4m4..4m4+3:
             // two 16-byte stores per half, consecutive lanes -> consecutive 16 B: conflict-free.
-            const int m4 = tid & 31, kq = tid >> 5;
-            unsigned* Ph = reinterpret_cast<unsigned*>(&S[0][0][0]);
-            unsigned* Pl = reinterpret_cast<unsigned*>(&S[NH - 1][0][0]);
+            const int m4 = tid & (TB / 4 - 1), kq = tid / (TB / 4);
+            unsigned* Ph = reinterpret_cast<unsigned*>(S);
+            unsigned* Pl = reinterpret_cast<unsigned*>(S + (X3 ? img : 0));
             uint4 h0, h1, l0, l1;
             {
                 const float a0[4] = {r[0].x, r[0].y, r[0].z, r[0].w};   // k = 4kq
@@ -614,34 +678,34 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
                 l0 = make_uint4(ll0[0], ll0[1], ll0[2], ll0[3]);
                 l1 = make_uint4(ll1[0], ll1[1], ll1[2], ll1[3]);
             }
-            *reinterpret_cast<uint4*>(&Ph[(2 * kq + 0) * HBM_ + m4 * 4]) = h0;
-            *reinterpret_cast<uint4*>(&Ph[(2 * kq + 1) * HBM_ + m4 * 4]) = h1;
+            *reinterpret_cast<uint4*>(&Ph[(2 * kq + 0) * TB + m4 * 4]) = h0;
+            *reinterpret_cast<uint4*>(&Ph[(2 * kq + 1) * TB + m4 * 4]) = h1;
             if (X3) {
-                *reinterpret_cast<uint4*>(&Pl[(2 * kq + 0) * HBM_ + m4 * 4]) = l0;
-                *reinterpret_cast<uint4*>(&Pl[(2 * kq + 1) * HBM_ + m4 * 4]) = l1;
+                *reinterpret_cast<uint4*>(&Pl[(2 * kq + 0) * TB + m4 * 4]) = l0;
+                *reinterpret_cast<uint4*>(&Pl[(2 * kq + 1) * TB + m4 * 4]) = l1;
             }
         }
     };
 
     // fragment (8 consecutive k of one row) from either LDS image
-    auto frag = [&](const unsigned short (*S)[HLD_], bool kc, int row, int ks, int lhi_) -> bf16x8 {
+    auto frag = [&](const unsigned short* S, bool kc, int row, int ks, int lhi_) -> bf16x8 {
         if (kc) {
-            return *reinterpret_cast<const bf16x8*>(&S[row][ks * 16 + lhi_ * 8]);
+            return *reinterpret_cast<const bf16x8*>(&S[row * HLD_ + ks * 16 + lhi_ * 8]);
         } else {
-            const unsigned* P = reinterpret_cast<const unsigned*>(&S[0][0]);
+            const unsigned* P = reinterpret_cast<const unsigned*>(S);
             const int p0 = ks * 8 + lhi_ * 4;
             union { unsigned u[4]; bf16x8 v; } t;
-            t.u[0] = P[(p0 + 0) * HBM_ + row];
-            t.u[1] = P[(p0 + 1) * HBM_ + row];
-            t.u[2] = P[(p0 + 2) * HBM_ + row];
-            t.u[3] = P[(p0 + 3) * HBM_ + row];
+            t.u[0] = P[(p0 + 0) * TB + row];
+            t.u[1] = P[(p0 + 1) * TB + row];
+            t.u[2] = P[(p0 + 2) * TB + row];
+            t.u[3] = P[(p0 + 3) * TB + row];
             return t.v;
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -650,8 +714,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
     if (nk > 0) {
         load_a(kbeg);
         load_b(kbeg);
-        store_one(As[0], AK, ra);
-        store_one(Bs[0], BKC, rb);
+        store_one(As[0], AIMG, AK, ra);
+        store_one(Bs[0], BIMG, BKC, rb);
     }
     __syncthreads();
 
@@ -665,18 +729,19 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int ks = 0; ks < HBK_ / 16; ++ks) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            bf16x8 ah[TM], al[TM], bh[2], bl[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                ah[t] = frag(As[cur][0], AK, wm * 64 + t * 32 + l31, ks, lhi);
-                bh[t] = frag(Bs[cur][0], BKC, wn * 64 + t * 32 + l31, ks, lhi);
-                if (X3) {
-                    al[t] = frag(As[cur][NH - 1], AK, wm * 64 + t * 32 + l31, ks, lhi);
-                    bl[t] = frag(Bs[cur][NH - 1], BKC, wn * 64 + t * 32 + l31, ks, lhi);
-                }
+            for (int t = 0; t < TM; ++t) {
+                ah[t] = frag(As[cur], AK, wm * (32 * TM) + t * 32 + l31, ks, lhi);
+                if (X3) al[t] = frag(As[cur] + AIMG, AK, wm * (32 * TM) + t * 32 + l31, ks, lhi);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int t = 0; t < 2; ++t) {
+                bh[t] = frag(Bs[cur], BKC, wn * 64 + t * 32 + l31, ks, lhi);
+                if (X3) bl[t] = frag(Bs[cur] + BIMG, BKC, wn * 64 + t * 32 + l31, ks, lhi);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     if (X3) {
@@ -687,8 +752,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
                 }
         }
         if (more) {
-            store_one(As[cur ^ 1], AK, ra);
-            store_one(Bs[cur ^ 1], BKC, rb);
+            store_one(As[cur ^ 1], AIMG, AK, ra);
+            store_one(Bs[cur ^ 1], BIMG, BKC, rb);
         }
         __syncthreads();
         cur ^= 1;
@@ -696,14 +761,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmParams p) {
 
     // ---- epilogue (C/D layout of the 32x32 MFMA is dtype independent) -------------------
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
             const int gn = col0 + wn * 64 + tn * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                const int gm = row0 + wm * 64 + tm * 32 + row;
+                const int gm = row0 + wm * (32 * TM) + tm * 32 + row;
                 if (gm < M && gn < N) {
                     float val = acc[tm][tn][r];
                     float* cp = C + (long long)gm * d.ldc + gn;

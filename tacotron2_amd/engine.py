@@ -12,6 +12,7 @@ contiguous.  Reference call sites are cited next to each stage.
 """
 import os
 
+import math
 import torch
 
 from . import native as nv
@@ -78,7 +79,27 @@ class MaskSource(object):
 # ----------------------------------------------------------------------------
 # small helpers
 # ----------------------------------------------------------------------------
-def _choose_splitk(M, N, K, batch=1):
+def _choose_splitk(M, N, K, batch=1, precision=0):
+    """Split count for a plain-epilogue GEMM.  The library tiles 256 x 256 (one workgroup per CU) for plain-bf16
+    products when that still yields >= 192 workgroups, else 128 x 128 (three to five per CU); the split is chosen
+    against whichever applies (native.gemm_tile_size is the same rule the launch uses)."""
+    t256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
+    if precision == 2 and M >= 512 and N >= 512 and nv.gemm_tile_size(M, N, 2, 1 << 20) == 256:
+        if t256 >= 192:
+            return 1
+        # fill whole rounds of 256 workgroups: efficiency = rounds / ceil(rounds), mild preference for fewer slabs
+        best, best_score = 0, -1.0
+        for s in range(1, 33):
+            if s > 1 and K // s < 512:
+                break
+            if t256 * s < 192:
+                continue
+            w = t256 * s / 256.0
+            score = w / math.ceil(w) * min(1.0, w / 0.85) - 0.02 * (s - 1)
+            if score > best_score:
+                best, best_score = s, score
+        if best:
+            return best
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if tiles >= 512:        # >= 2 workgroups per CU already: one's loads hide behind the other's MFMAs
         return 1
@@ -151,7 +172,7 @@ class _Run(object):
         K = A.shape[0] if a_km else A.shape[1]
         plain = kw.get('bias') is None and kw.get('act', 0) == 0 and kw.get('keep') is None \
             and kw.get('convA') is None
-        sk = _choose_splitk(M, N, K, batch) if (plain and batch == 1) else 1
+        sk = _choose_splitk(M, N, K, batch, int(fast)) if (plain and batch == 1) else 1
         if perm is not None and sk == 1:
             sk = 2 if K >= 512 else 1
         if sk == 1 and perm is None:

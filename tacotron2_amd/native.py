@@ -199,7 +199,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
     "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
-    "t2amd_gemm_f32", "t2amd_splitk_reduce_f32",
+    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
@@ -223,6 +223,7 @@ def _argtypes():
     pt = C.POINTER
     return {
         "t2amd_gemm_f32": [pt(GemmDesc), _P],
+        "t2amd_gemm_tile_size": [_I, _I, _I, _I],
         "t2amd_splitk_reduce_f32": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
         "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
@@ -405,6 +406,11 @@ def scale_for(p):
 # ----------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------
+def gemm_tile_size(M, N, precision, nz=1):
+    """Tile edge (128/256) the library will use for this product launched as nz = batch*splitk slices."""
+    return int(load().t2amd_gemm_tile_size(int(M), int(N), int(precision), int(nz)))
+
+
 def gemm(Cm, A, B, a_km=False, b_kn=False, accumulate=False, bias=None, act=0, keep=None,
          keep_scale=1.0, convA=None, convB=None, batch=1, strides=(0, 0, 0), splitk=1, partials=None,
          fast=False):

@@ -53,6 +53,33 @@ def test_gemm_layouts(nv, M, N, K, a_km, b_kn):
     assert err(C, ref) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(3600, 3590, 100, 1), (1000, 900, 2100, 12), (2048, 1792, 96, 4), (300, 257, 96, 1)])
+@pytest.mark.parametrize("a_km,b_kn", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_plain_bf16_tiles(nv, M, N, K, sk, a_km, b_kn):
+    """precision=2 on both tile sizes (256 x 256 x 32 / 8 waves when the launch has >= 192 such tiles, else
+    128 x 128): equals the f32 product of the bf16-ROUNDED operands to summation-order accuracy; ragged M, N, K
+    edges, every layout, split-K partial slabs."""
+    A = rnd(M, K, seed=11) * (1.0 + torch.arange(M).float().unsqueeze(1) / M)
+    B = rnd(K, N, seed=12) * (0.5 + torch.arange(N).float().unsqueeze(0) / N)
+    Ar, Br = A.bfloat16().double(), B.bfloat16().double()
+    ref = Ar @ Br
+    scale = Ar.abs() @ Br.abs()
+    Ad = dv(A.t().contiguous()) if a_km else dv(A)
+    Bd = dv(B) if b_kn else dv(B.t().contiguous())
+    expect = 256 if (M >= 512 and N >= 512 and -(-M // 256) * -(-N // 256) * sk >= 192) else 128
+    assert nv.gemm_tile_size(M, N, 2, sk) == expect
+    if sk == 1:
+        C = torch.full((M, N), float('nan'), device=DEV)
+        nv.gemm(C, Ad, Bd, a_km=a_km, b_kn=b_kn, fast=2)
+        out = C.cpu().double()
+    else:
+        part = torch.full((sk, M * N), float('nan'), device=DEV)
+        nv.gemm(part[0].view(M, N), Ad, Bd, a_km=a_km, b_kn=b_kn, fast=2, splitk=sk, partials=part)
+        out = part.cpu().double().sum(0).view(M, N)
+    rel = ((out - ref).abs() / scale).max().item()
+    assert rel < 2e-6, rel
+
+
 @pytest.mark.parametrize("M,N,K", [(130, 81, 50), (300, 257, 96), (64, 4096, 256), (7, 5, 3), (256, 128, 1024), (512, 384, 4000)])
 @pytest.mark.parametrize("a_km,b_kn", [(False, False), (False, True), (True, False), (True, True)])
 def test_gemm_split_bf16(nv, M, N, K, a_km, b_kn):
@@ -511,6 +538,16 @@ def test_lstm_step_bf16_operands(nv, B, H, widths):
                      c_prev=dv(c_prev), bf16=True, h16_out=h16)
     assert err(gates, torch.cat((i, f, g, o), 1)) < 1e-5
     assert err(c_out, c) < 1e-5 and err(h_out, h) < 1e-5
+    assert torch.equal(h16.cpu(), h_out.cpu().bfloat16())
+    # dropout mask + finished rows (t >= len): the wide kernel has its own cell epilogue
+    keep = (torch.rand(B, H, generator=torch.Generator().manual_seed(129)) > 0.3).to(torch.uint8)
+    lens = torch.tensor([(5 if r % 3 else 2) for r in range(B)], dtype=torch.int32)
+    gates.fill_(float('nan'))
+    nv.lstm_step_fwd([x.to(DEV) for x in xs], list(widths), W.to(DEV), H, B, gates, c_out, h_out, gin=dv(gin), bias=dv(bias),
+                     c_prev=dv(c_prev), keep=keep.to(DEV), keep_scale=1.0 / 0.7, lens=lens.to(DEV), t=3, bf16=True, h16_out=h16)
+    live = (3 < lens).float().unsqueeze(1)
+    assert err(gates, torch.cat((i, f, g, o), 1) * live) < 1e-5
+    assert err(c_out, c * live) < 1e-5 and err(h_out, h * keep.float() / 0.7 * live) < 1e-5
     assert torch.equal(h16.cpu(), h_out.cpu().bfloat16())
     # plain (dgrad-shaped) product with split-K
     N = 200
