@@ -379,8 +379,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         for (int i = 0; i < 3; ++i) {
             const t2amd_addend& ad = a.dctx[i];
             if (ad.p) {
+                // up to four slabs by independent loads (a runtime loop waits for every slab in turn)
                 const float* q = ad.p + (long long)b * ad.ld + c;
-                for (int k = 0; k < ad.nsplit; ++k) s += q[(long long)k * ad.split_stride];
+                const int n = ad.nsplit;
+                const long long st = ad.split_stride;
+                const float v0 = q[0];
+                float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                if (n > 1) v1 = q[st];
+                if (n > 2) v2 = q[2 * st];
+                if (n > 3) v3 = q[3 * st];
+                s += v0;
+                if (n > 1) s += v1;
+                if (n > 2) s += v2;
+                if (n > 3) s += v3;
+                for (int k = 4; k < n; ++k) s += q[(long long)k * st];
             }
         }
         dctx_s[c] = s;

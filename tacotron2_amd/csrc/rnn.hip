@@ -822,13 +822,37 @@ extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
 // ---------------------------------------------------------------------------------------
 struct LstmBwdParams { t2amd_lstm_bwd a[2]; int nblk0; };
 
-__device__ __forceinline__ float4 addend_sum4(const t2amd_addend& ad, int row, int col) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!ad.p) return s;
+// An addend's partial slabs at (row, col..col+3) are added in index order.  Up to four slabs are fetched by
+// independent loads (addend_issue4) and only summed later (addend_finish4), after every other operand load of the
+// kernel has been issued: a runtime-trip-count loop made every slab a separate, fully waited L2 round trip (seven
+// in a row for the decoder cells).  More than four slabs fall back to a loop.
+struct Slab4 { float4 v0, v1, v2, v3; };
+__device__ __forceinline__ Slab4 addend_issue4(const t2amd_addend& ad, int row, int col) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    Slab4 r = {z, z, z, z};
+    if (!ad.p) return r;
     const float* q = ad.p + (long long)row * ad.ld + col;
-    for (int k = 0; k < ad.nsplit; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(q + (long long)k * ad.split_stride);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    const int n = ad.nsplit;
+    const long long st = ad.split_stride;
+    r.v0 = *reinterpret_cast<const float4*>(q);
+    if (n > 1) r.v1 = *reinterpret_cast<const float4*>(q + st);
+    if (n > 2) r.v2 = *reinterpret_cast<const float4*>(q + 2 * st);
+    if (n > 3) r.v3 = *reinterpret_cast<const float4*>(q + 3 * st);
+    return r;
+}
+__device__ __forceinline__ float4 addend_finish4(const Slab4& r, const t2amd_addend& ad, int row, int col) {
+    if (!ad.p) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = ad.nsplit;
+    float4 s = make_float4(0.f + r.v0.x, 0.f + r.v0.y, 0.f + r.v0.z, 0.f + r.v0.w);
+    if (n > 1) { s.x += r.v1.x; s.y += r.v1.y; s.z += r.v1.z; s.w += r.v1.w; }
+    if (n > 2) { s.x += r.v2.x; s.y += r.v2.y; s.z += r.v2.z; s.w += r.v2.w; }
+    if (n > 3) { s.x += r.v3.x; s.y += r.v3.y; s.z += r.v3.z; s.w += r.v3.w; }
+    if (n > 4) {
+        const float* q = ad.p + (long long)row * ad.ld + col;
+        for (int k = 4; k < n; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(q + (long long)k * ad.split_stride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
     return s;
 }
@@ -868,7 +892,8 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
     const float4 dc_in = *reinterpret_cast<const float4*>(dcp);
     unsigned kp = 0x01010101u;
     if (a.keep) kp = *reinterpret_cast<const unsigned*>(a.keep + (long long)b * a.ld_keep + j);
-    const float4 d0 = addend_sum4(a.dh[0], b, j), d1 = addend_sum4(a.dh[1], b, j), d2 = addend_sum4(a.dh[2], b, j);
+    const Slab4 s0 = addend_issue4(a.dh[0], b, j), s1 = addend_issue4(a.dh[1], b, j), s2 = addend_issue4(a.dh[2], b, j);
+    const float4 d0 = addend_finish4(s0, a.dh[0], b, j), d1 = addend_finish4(s1, a.dh[1], b, j), d2 = addend_finish4(s2, a.dh[2], b, j);
     const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
     const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
     const float c_[4] = {c.x, c.y, c.z, c.w}, cp_[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
