@@ -43,14 +43,40 @@ __device__ __forceinline__ int tap_offset(int tap, int TIP) {
     return tap < LK ? tap : TIP + tap - LK;
 }
 
-__device__ __forceinline__ void stage_windows(float* win_s, int TIP, int Ti, const float* wprev, const float* cum,
-                                              int tid, int nthreads) {
-    for (int i = tid; i < TIP; i += nthreads) {
+// The two halo windows go to LDS in two halves: the loads of the first pass (one element of each window per
+// thread) are issued with the rest of the prologue loads and only written after them (a conditional load inside the
+// staging loop is waited for on the spot); utterances longer than the block take the remaining passes in a loop.
+struct WinRegs { float wp, cm; };
+__device__ __forceinline__ WinRegs stage_windows_issue(int TIP, int Ti, const float* wprev, const float* cum, int tid) {
+    int ti = tid - HALO;
+    ti = ti < 0 ? 0 : (ti > Ti - 1 ? Ti - 1 : ti);       // clamped: always a valid element, selected below
+    WinRegs r;
+    r.cm = cum[ti];
+    r.wp = wprev ? wprev[ti] : 0.f;
+    return r;
+}
+__device__ __forceinline__ void stage_windows_finish(const WinRegs& r, float* win_s, int TIP, int Ti, const float* wprev,
+                                                     const float* cum, int tid, int nthreads) {
+    if (tid < TIP) {
+        const int ti = tid - HALO;
+        const bool in = (ti >= 0 && ti < Ti);
+        win_s[tid] = in ? r.wp : 0.f;
+        win_s[TIP + tid] = in ? r.cm : 0.f;
+    }
+    for (int i = tid + nthreads; i < TIP; i += nthreads) {
         const int ti = i - HALO;
         const bool in = (ti >= 0 && ti < Ti);
         win_s[i] = (in && wprev) ? wprev[ti] : 0.f;
         win_s[TIP + i] = in ? cum[ti] : 0.f;
     }
+}
+// the slice's 32 rows of U (1984 contiguous floats, 16-byte aligned): one float4 per thread
+__device__ __forceinline__ float4 stage_u_issue(const float* __restrict__ Uslice, int tid) {
+    const int i = tid < DSL * NTAP / 4 ? tid : 0;
+    return reinterpret_cast<const float4*>(Uslice)[i];
+}
+__device__ __forceinline__ void stage_u_finish(const float4& r, float* u_s, int tid) {
+    if (tid < DSL * NTAP / 4) reinterpret_cast<float4*>(u_s)[tid] = r;
 }
 
 // loc^T tile: acc[dt][r] = sum_tap U[dt*16 + 4*lg + r][tap] * win[c(tap)][pos + k(tap)],  pos = lane&15
@@ -100,52 +126,75 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     float* win_s = smem;             // [2][TIP]
     float* q_s = win_s + 2 * TIP;    // [32]
     float* u_s = q_s + DSL;          // [32][62] the slice's rows of U (contiguous in HBM)
-    const int len = a.lens ? a.lens[b] : Ti;
-
-    // processed-memory rows of this wave's first two position tiles: issued now, consumed after the q phase
-    const int nmt = (len + 15) >> 4;
+    float* h_s = u_s + DSL * NTAP;   // [Hq] this utterance's query input
+    // Every load of the prologue is issued before the first one is consumed, in consumption order (the wait
+    // counter is in-order): utterance length, processed-memory rows of this wave's first two position tiles,
+    // U slice, window elements, v, then the W_q / h stream of the q phase.  Nothing is selected or compared on
+    // a loaded value before the q phase has issued its loads (a select on a fresh load is waited for on the spot).
+    const int len_raw = a.lens ? a.lens[b] : Ti;
     const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + ds * DSL + 4 * lg;
     float4 pmA[2], pmB[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int pos = (wv + rr * (KE_NT / 64)) * 16 + l15;
-        pmA[rr] = pmB[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pos < Ti && wv + rr * (KE_NT / 64) < nmt) {
-            pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
-            pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
-        }
+        int pos = (wv + rr * (KE_NT / 64)) * 16 + l15;
+        pos = pos < Ti ? pos : Ti - 1;                  // clamped; rows past the utterance are never used
+        pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
+        pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
     }
-    // q[d] = W_q[d][:] . h for the slice's 32 dims: 16 threads per row, 256 contiguous bytes per group
-    // and instruction; all loads are issued before the first use.
+    const float* wprev_b = a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr;
+    const float* cum_b = a.cum + (long long)b * Ti;
+    const float4 ureg = stage_u_issue(a.U + (long long)ds * DSL * NTAP, tid);
+    const WinRegs wreg = stage_windows_issue(TIP, Ti, wprev_b, cum_b, tid);
+    float vv[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[dt][r] = a.v[ds * DSL + dt * 16 + 4 * lg + r];
+    // q[d] = W_q[d][:] . h for the slice's 32 dims: 16 threads per row, 256 contiguous bytes per group and
+    // instruction.  h goes through LDS (one float4 per thread), so a thread keeps only its 16 W_q float4 in flight
+    // and the whole 1024-wide row is one round trip.
     float qacc = 0.f;
     {
         const int d = tid >> 4, part = tid & 15;
         const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq + (long long)(ds * DSL + d) * Hq);
         const float4* __restrict__ h4 = reinterpret_cast<const float4*>(a.h + (long long)b * a.ld_h);
+        float4* h_s4 = reinterpret_cast<float4*>(h_s);
         const int n4 = Hq >> 2;
-        for (int i0 = part; i0 < n4; i0 += 16 * 8) {
-            float4 w[8], x[8];
+        // first 1024 columns straight-line (a loop header makes the compiler drain every pending load)
+        float4 w[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + 16 * u;
-                const int ic = i < n4 ? i : part;
-                w[u] = W4[ic];
-                x[u] = h4[ic];
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int i = part + 16 * u;
+            w[u] = W4[i < n4 ? i : part];
+        }
+        {
+            // h staged behind the W_q loads: its store is the first consumer of the whole prologue
+            const float4 hv = h4[tid < n4 ? tid : 0];
+            if (tid < n4) h_s4[tid] = hv;
+            for (int j = tid + KE_NT; j < n4; j += KE_NT) h_s4[j] = h4[j];
+        }
+        __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (i0 + 16 * u < n4) {
-                    qacc = fmaf(w[u].x, x[u].x, qacc);
-                    qacc = fmaf(w[u].y, x[u].y, qacc);
-                    qacc = fmaf(w[u].z, x[u].z, qacc);
-                    qacc = fmaf(w[u].w, x[u].w, qacc);
-                }
+        for (int u = 0; u < 16; ++u) {
+            const int i = part + 16 * u;
+            if (i < n4) {
+                const float4 x = h_s4[i];
+                qacc = fmaf(w[u].x, x.x, qacc);
+                qacc = fmaf(w[u].y, x.y, qacc);
+                qacc = fmaf(w[u].z, x.z, qacc);
+                qacc = fmaf(w[u].w, x.w, qacc);
             }
         }
+        for (int i = part + 256; i < n4; i += 16) {          // Hq > 1024
+            const float4 ww = W4[i], x = h_s4[i];
+            qacc = fmaf(ww.x, x.x, qacc);
+            qacc = fmaf(ww.y, x.y, qacc);
+            qacc = fmaf(ww.z, x.z, qacc);
+            qacc = fmaf(ww.w, x.w, qacc);
+        }
     }
-    stage_windows(win_s, TIP, Ti, a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr,
-                  a.cum + (long long)b * Ti, tid, KE_NT);
-    for (int i = tid; i < DSL * NTAP; i += KE_NT) u_s[i] = a.U[(long long)ds * DSL * NTAP + i];
+    stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
+    stage_u_finish(ureg, u_s, tid);
     {
         const int d = tid >> 4, part = tid & 15;
         qacc += __shfl_xor(qacc, 1, 64);
@@ -157,11 +206,8 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
             if (a.q_out) a.q_out[(long long)b * a.ld_q + ds * DSL + d] = qacc;
         }
     }
-    float vv[2][4];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vv[dt][r] = a.v[ds * DSL + dt * 16 + 4 * lg + r];
+    const int len = len_raw;
+    const int nmt = (len + 15) >> 4;
     __syncthreads();
     if (p.dbg == 1) return;
     float ua[2][16];
@@ -227,12 +273,18 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     const int c4 = tid % EC4, part = tid / EC4;
     const bool worker = part < parts;
     const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4 + cs * EC4 + c4;
+    // (rows are clamped to the padded length Ti, not to lens[b]: the prefetch must not wait for the length load;
+    // rows past the utterance get weight 0 below)
     float4 mrow[KC_MAXR];
 #pragma unroll
     for (int i = 0; i < KC_MAXR; ++i) {
         const int ti = part + i * parts;
-        mrow[i] = (worker && ti < len) ? M4[(long long)ti * E4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mrow[i] = worker ? M4[(long long)(ti < Ti ? ti : Ti - 1) * E4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // slice 0 also carries the cumulative weights forward: its read-modify-write operand is fetched now
+    float* const cum_b = a.cum + (long long)b * Ti;
+    float c_old0 = 0.f;
+    if (cs == 0) c_old0 = cum_b[tid < Ti ? tid : Ti - 1];
 
     const float* __restrict__ e0 = a.ws + (long long)b * Ti;
     const long long es = (long long)B * Ti;
@@ -264,14 +316,14 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     const float inv = 1.0f / gsum;
     {
         float* wout = a.w_out + (long long)b * a.ld_wout;
-        float* cum = a.cum + (long long)b * Ti;
+        float* cum = cum_b;
         float* csave = a.cum_save ? a.cum_save + (long long)b * Ti : nullptr;
         for (int ti = tid; ti < Ti; ti += KC_NT) {
             const float w = w_s[ti] * inv;
             w_s[ti] = w;
             if (cs == 0) {
                 wout[ti] = w;
-                const float c_old = cum[ti];
+                const float c_old = (ti == tid) ? c_old0 : cum[ti];
                 if (csave) csave[ti] = c_old;
                 cum[ti] = c_old + w;
             }
@@ -318,7 +370,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     p.tip = attn_tip(a->Ti);
     p.dbg = attn_dbg_stage();
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP);
+    const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP + (size_t)a->Hq);
     const int EC = a->E / NCS;
     int parts = KC_NT / (EC / 4);
     if (parts > 32) parts = 32;
@@ -337,8 +389,11 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; };
 
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
-// Half a wave (32 lanes) per memory row, 8 rows per pass, every load of a pass issued before its first use.
+// Half a wave (32 lanes) per memory row, 8 rows per pass.  One L2 round trip: the memory rows of the first 64
+// positions of the slice (all four column groups: 32 float4 per lane), the gradient slabs and the carry partials
+// are all issued before anything is consumed; nothing is compared or selected on a loaded value before that.
 #define KB1_MAXP 8      // passes kept in registers: 8 rows x 8 passes = 64 positions per slice (Ti <= 256)
+#define KB1_MAXC 4      // column groups kept in registers: 4 x 32 float4 = E <= 512
 __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const t2amd_attn_bwd& a = p.a;
@@ -350,75 +405,128 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     float* base_s = dctx_s + E;      // [tsz] carries + running dcum (+ extra) per position of the slice
     float* wl_s = base_s + tsz;      // [tsz] this step's weights
     float* red_s = wl_s + tsz;       // [8]
-    const int len = a.lens ? a.lens[b] : Ti;
+    const int len_raw = a.lens ? a.lens[b] : Ti;
     const int t0 = ts * tsz;
     int t1 = t0 + tsz;
     if (t1 > Ti) t1 = Ti;
 
-    // memory rows of the first trip (8 rows x 2 column groups per lane): they do not depend on dctx, so their
-    // latency overlaps the gradient sums and the carry gathers below
     const int E4 = E >> 2;
     const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4;
     const int grp = tid >> 5, l32 = tid & 31;      // 8 row groups of 32 lanes
-    float4 pm0[KB1_MAXP], pm1[KB1_MAXP];
-    {
-        const int c0 = l32, c1 = l32 + 32;
-        const bool two = c1 < E4;
+    const int npass = (tsz + 7) >> 3;              // passes that hold positions of this slice
+    float4 pm[KB1_MAXC][KB1_MAXP];
 #pragma unroll
-        for (int i = 0; i < KB1_MAXP; ++i) {
-            const int ti = t0 + grp + 8 * i;
-            const int tc = (ti < t1 && ti < len) ? ti : 0;
-            pm0[i] = (c0 < E4) ? M4[(long long)tc * E4 + c0] : make_float4(0.f, 0.f, 0.f, 0.f);
-            pm1[i] = two ? M4[(long long)tc * E4 + c1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < KB1_MAXP; ++i) {
+        const int ti = t0 + grp + 8 * i;
+        const long long tc = (i < npass && ti < t1) ? ti : t0;      // clamped: loaded, never used
+#pragma unroll
+        for (int g = 0; g < KB1_MAXC; ++g) {
+            const int c = l32 + 32 * g;
+            pm[g][i] = M4[tc * E4 + (c < E4 ? c : l32)];
         }
     }
+    // gradient of the context: up to three addends of up to four slabs each, two channels per thread at most
+    float gsl[2][3][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = tid + 256 * u;
+        const int cc = c < E ? c : 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const t2amd_addend& ad = a.dctx[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gsl[u][i][k] = 0.f;
+            if (ad.p) {
+                const int n = ad.nsplit;
+                const float* q0 = ad.p + (long long)b * ad.ld;       // wave-uniform slab bases (scalar adds only)
+                const float* q1 = q0 + ad.split_stride;
+                const float* q2 = q1 + ad.split_stride;
+                const float* q3 = q2 + ad.split_stride;
+                gsl[u][i][0] = q0[cc];
+                if (n > 1) gsl[u][i][1] = q1[cc];
+                if (n > 2) gsl[u][i][2] = q2[cc];
+                if (n > 3) gsl[u][i][3] = q3[cc];
+            }
+        }
+    }
+    // carries: one thread per position of the slice (first pass in registers)
+    const long long ps = (long long)B * 2 * Ti;                 // stride between dim-slice partials
+    const float* __restrict__ cw = a.dwin_part + ((long long)b * 2 + 0) * Ti;
+    const float* __restrict__ cc_ = a.dwin_part + ((long long)b * 2 + 1) * Ti;
+    float* __restrict__ dcum = a.dcum_acc + (long long)b * Ti;
+    float cwv[4], ccv[4], dcv, exv = 0.f, wv0;
+    {
+        const int ti = (t0 + tid < t1) ? t0 + tid : t0;         // clamped
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cwv[k] = cw[k * ps + ti]; ccv[k] = cc_[k * ps + ti]; }
+        dcv = dcum[ti];
+        if (a.d_w_extra) exv = a.d_w_extra[(long long)b * a.ld_dwextra + ti];
+        wv0 = a.w[(long long)b * a.ld_w + ti];
+    }
 
-    for (int c = tid; c < E; c += 256) {
+    // ---- consume --------------------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = tid + 256 * u;
+        if (c < E) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const t2amd_addend& ad = a.dctx[i];
+                if (ad.p) {
+                    const int n = ad.nsplit;
+                    s += gsl[u][i][0];
+                    if (n > 1) s += gsl[u][i][1];
+                    if (n > 2) s += gsl[u][i][2];
+                    if (n > 3) s += gsl[u][i][3];
+                    if (n > 4) {
+                        const float* q = ad.p + (long long)b * ad.ld + c;
+                        for (int k = 4; k < n; ++k) s += q[(long long)k * ad.split_stride];
+                    }
+                }
+            }
+            dctx_s[c] = s;
+            if (ts == 0) a.dctx_total[(long long)b * a.ld_dctx_total + c] = s;
+        }
+    }
+    for (int c = tid + 512; c < E; c += 256) {       // E > 512: remaining channels the plain way
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const t2amd_addend& ad = a.dctx[i];
             if (ad.p) {
-                // up to four slabs by independent loads (a runtime loop waits for every slab in turn)
                 const float* q = ad.p + (long long)b * ad.ld + c;
-                const int n = ad.nsplit;
-                const long long st = ad.split_stride;
-                const float v0 = q[0];
-                float v1 = 0.f, v2 = 0.f, v3 = 0.f;
-                if (n > 1) v1 = q[st];
-                if (n > 2) v2 = q[2 * st];
-                if (n > 3) v3 = q[3 * st];
-                s += v0;
-                if (n > 1) s += v1;
-                if (n > 2) s += v2;
-                if (n > 3) s += v3;
-                for (int k = 4; k < n; ++k) s += q[(long long)k * st];
+                for (int k = 0; k < ad.nsplit; ++k) s += q[(long long)k * ad.split_stride];
             }
         }
         dctx_s[c] = s;
         if (ts == 0) a.dctx_total[(long long)b * a.ld_dctx_total + c] = s;
     }
-    {   // carries: one thread per position of the slice
-        const long long ps = (long long)B * 2 * Ti;                 // stride between dim-slice partials
-        const float* __restrict__ cw = a.dwin_part + ((long long)b * 2 + 0) * Ti;
-        const float* __restrict__ cc = a.dwin_part + ((long long)b * 2 + 1) * Ti;
-        float* __restrict__ dcum = a.dcum_acc + (long long)b * Ti;
-        for (int i = tid; i < tsz; i += 256) {
-            const int ti = t0 + i;
-            float base = 0.f, w = 0.f;
-            if (ti < t1) {
-                const float carry_w = ((cw[ti] + cw[ps + ti]) + cw[2 * ps + ti]) + cw[3 * ps + ti];
-                const float carry_c = ((cc[ti] + cc[ps + ti]) + cc[2 * ps + ti]) + cc[3 * ps + ti];
-                const float dc = dcum[ti] + carry_c;
-                dcum[ti] = dc;
-                base = carry_w + dc;
-                if (a.d_w_extra) base += a.d_w_extra[(long long)b * a.ld_dwextra + ti];
+    for (int i = tid; i < tsz; i += 256) {
+        const int ti = t0 + i;
+        float base = 0.f, w = 0.f;
+        if (ti < t1) {
+            float carry_w, carry_c, dc0, ex = 0.f;
+            if (i == tid) {
+                carry_w = ((cwv[0] + cwv[1]) + cwv[2]) + cwv[3];
+                carry_c = ((ccv[0] + ccv[1]) + ccv[2]) + ccv[3];
+                dc0 = dcv; ex = exv; w = wv0;
+            } else {
+                carry_w = ((cw[ti] + cw[ps + ti]) + cw[2 * ps + ti]) + cw[3 * ps + ti];
+                carry_c = ((cc_[ti] + cc_[ps + ti]) + cc_[2 * ps + ti]) + cc_[3 * ps + ti];
+                dc0 = dcum[ti];
+                if (a.d_w_extra) ex = a.d_w_extra[(long long)b * a.ld_dwextra + ti];
                 w = a.w[(long long)b * a.ld_w + ti];
             }
-            base_s[i] = base;
-            wl_s[i] = w;
+            const float dc = dc0 + carry_c;
+            dcum[ti] = dc;
+            base = carry_w + dc;
+            if (a.d_w_extra) base += ex;
         }
+        base_s[i] = base;
+        wl_s[i] = w;
     }
+    const int len = len_raw;
     __syncthreads();
     float* __restrict__ dwo = a.ws + (long long)b * Ti;
     float psum = 0.f;
@@ -426,35 +534,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         float acc[KB1_MAXP];
 #pragma unroll
         for (int i = 0; i < KB1_MAXP; ++i) acc[i] = 0.f;
-        for (int c0 = l32; c0 < E4; c0 += 64) {          // two 32-float4 column groups per trip: 16 loads in flight
-            const int c1 = c0 + 32;
-            const bool two = c1 < E4;
-            float4 m0[KB1_MAXP], m1[KB1_MAXP];
-            if (r0 == 0 && c0 == l32) {                 // the prefetched trip
+        if (r0 == 0) {
 #pragma unroll
-                for (int i = 0; i < KB1_MAXP; ++i) { m0[i] = pm0[i]; m1[i] = pm1[i]; }
-            } else {
+            for (int g = 0; g < KB1_MAXC; ++g) {
+                const int c = l32 + 32 * g;
+                if (c < E4) {
+                    const float4 gq = *reinterpret_cast<const float4*>(&dctx_s[c * 4]);
 #pragma unroll
-                for (int i = 0; i < KB1_MAXP; ++i) {
-                    const int ti = t0 + r0 + grp + 8 * i;
-                    const int tc = (ti < t1 && ti < len) ? ti : 0;        // clamped: loaded, then ignored
-                    m0[i] = M4[(long long)tc * E4 + c0];
-                    m1[i] = M4[(long long)tc * E4 + (two ? c1 : c0)];
+                    for (int i = 0; i < KB1_MAXP; ++i) {
+                        acc[i] = fmaf(pm[g][i].x, gq.x, acc[i]);
+                        acc[i] = fmaf(pm[g][i].y, gq.y, acc[i]);
+                        acc[i] = fmaf(pm[g][i].z, gq.z, acc[i]);
+                        acc[i] = fmaf(pm[g][i].w, gq.w, acc[i]);
+                    }
                 }
             }
-            const float4 g0 = *reinterpret_cast<const float4*>(&dctx_s[c0 * 4]);
-            float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (two) g1 = *reinterpret_cast<const float4*>(&dctx_s[c1 * 4]);
+        }
+        // column groups / positions beyond the register-resident block (E > 512 or Ti > 256)
+        for (int c = l32 + (r0 == 0 ? 32 * KB1_MAXC : 0); c < E4; c += 32) {
+            const float4 gq = *reinterpret_cast<const float4*>(&dctx_s[c * 4]);
 #pragma unroll
             for (int i = 0; i < KB1_MAXP; ++i) {
-                acc[i] = fmaf(m0[i].x, g0.x, acc[i]);
-                acc[i] = fmaf(m0[i].y, g0.y, acc[i]);
-                acc[i] = fmaf(m0[i].z, g0.z, acc[i]);
-                acc[i] = fmaf(m0[i].w, g0.w, acc[i]);
-                acc[i] = fmaf(m1[i].x, g1.x, acc[i]);
-                acc[i] = fmaf(m1[i].y, g1.y, acc[i]);
-                acc[i] = fmaf(m1[i].z, g1.z, acc[i]);
-                acc[i] = fmaf(m1[i].w, g1.w, acc[i]);
+                const int ti = t0 + r0 + grp + 8 * i;
+                const float4 m = M4[(long long)(ti < t1 ? ti : t0) * E4 + c];
+                acc[i] = fmaf(m.x, gq.x, acc[i]);
+                acc[i] = fmaf(m.y, gq.y, acc[i]);
+                acc[i] = fmaf(m.z, gq.z, acc[i]);
+                acc[i] = fmaf(m.w, gq.w, acc[i]);
             }
         }
 #pragma unroll
@@ -496,41 +602,36 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     float* dq_s = red_s + KB2_NW * 2 * DSL;   // [32]
     float* u_s = dq_s + DSL;                  // [32][62]
     float* dh_s = u_s + DSL * NTAP;           // [Hq] second-half partial of dh
-    const int len = a.lens ? a.lens[b] : Ti;
-    const int nmt = (len + 15) >> 4;
-    const int npos = nmt * 16;                // positions covered by the MFMA tiles
+    // Prologue loads: all issued before the first is consumed, nothing selected on a fresh load (see K_e).
+    const int len_raw = a.lens ? a.lens[b] : Ti;
     const int dbase = ds * DSL;
 
     const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + dbase + 4 * lg;
     float* __restrict__ dpmb = a.d_pm + (long long)b * Ti * AD + dbase + 4 * lg;
-    const float dv_old = tid < DSL ? a.dv_acc[(long long)b * AD + dbase + tid] : 0.f;   // read-modify-write operand, fetched early
+    const float dv_old = a.dv_acc[(long long)b * AD + dbase + (tid < DSL ? tid : 0)];   // read-modify-write operand, fetched early
     float4 pmA[2], pmB[2], opA[2], opB[2];      // issued now, consumed in the tile loop
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int mt_ = wv + rr * KB2_NW;
-        const int pos = mt_ * 16 + l15;
-        pmA[rr] = pmB[rr] = opA[rr] = opB[rr] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mt_ < nmt && pos < Ti) {
-            pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
-            pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
-        }
-        if (mt_ < nmt && pos < len) {
-            opA[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD);
-            opB[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD + 16);
-        }
+        int pos = (wv + rr * KB2_NW) * 16 + l15;
+        pos = pos < Ti ? pos : Ti - 1;          // clamped; rows past the utterance are never used / stored
+        pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
+        pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+        opA[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD);
+        opB[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD + 16);
     }
+    float sdv[NTS], w_r, dw_r;
     {
         const float* sd = a.ws + (long long)B * Ti;
-        float sdot = 0.f;
 #pragma unroll
-        for (int k = 0; k < NTS; ++k) sdot += sd[k * B + b];
-        const float* __restrict__ wrow = a.w + (long long)b * a.ld_w;
-        const float* __restrict__ dwi = a.ws + (long long)b * Ti;
-        for (int ti = tid; ti < NP; ti += KB2_NT) de_s[ti] = (ti < len) ? wrow[ti] * (dwi[ti] - sdot) : 0.f;
+        for (int k = 0; k < NTS; ++k) sdv[k] = sd[k * B + b];
+        const int tc = tid < Ti ? tid : Ti - 1;
+        w_r = a.w[(long long)b * a.ld_w + tc];
+        dw_r = a.ws[(long long)b * Ti + tc];
     }
-    stage_windows(win_s, TIP, Ti, a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr,
-                  a.cum_before + (long long)b * Ti, tid, KB2_NT);
-    for (int i = tid; i < DSL * NTAP; i += KB2_NT) u_s[i] = a.U[(long long)dbase * NTAP + i];
+    const float* wprev_b = a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr;
+    const float* cumb_b = a.cum_before + (long long)b * Ti;
+    const WinRegs wreg = stage_windows_issue(TIP, Ti, wprev_b, cumb_b, tid);
+    const float4 ureg = stage_u_issue(a.U + (long long)dbase * NTAP, tid);
     float vv[2][4], qv[2][4], dva[2][4], dqa[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -542,6 +643,21 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dva[dt][r] = 0.f;
             dqa[dt][r] = 0.f;
         }
+    // ---- consume ----
+    const int len = len_raw;
+    const int nmt = (len + 15) >> 4;
+    const int npos = nmt * 16;                // positions covered by the MFMA tiles
+    {
+        float sdot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NTS; ++k) sdot += sdv[k];
+        const float* __restrict__ wrow = a.w + (long long)b * a.ld_w;
+        const float* __restrict__ dwi = a.ws + (long long)b * Ti;
+        if (tid < NP) de_s[tid] = (tid < len) ? w_r * (dw_r - sdot) : 0.f;
+        for (int ti = tid + KB2_NT; ti < NP; ti += KB2_NT) de_s[ti] = (ti < len) ? wrow[ti] * (dwi[ti] - sdot) : 0.f;
+    }
+    stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
+    stage_u_finish(ureg, u_s, tid);
     __syncthreads();
     if (p.dbg == 1) return;
     float ua[2][16];
