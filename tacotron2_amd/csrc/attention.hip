@@ -727,6 +727,16 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         }
     }
     if (p.dbg == 2) return;
+    // W_q rows of the closing dh product (first 1024 columns): independent of everything above, fetched now so
+    // that the round trip hides behind the reductions, the dU product and col2im
+    float4 wq_pre[16];
+    {
+        const int H4 = Hq >> 2;
+        const int half = tid >> 8, t8 = tid & 255;
+        const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(dbase + half * 16) * H4;
+#pragma unroll
+        for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (t8 < H4 ? t8 : 0)];
+    }
     // dv / dq: reduce over the positions held by the 16 lanes of a lane group
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -788,11 +798,19 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         for (int i = tid; i < 2 * Ti; i += KB2_NT) {
             const int c = i >= Ti;
             const int tip_ = i - c * Ti;
+            // 31 independent LDS reads (row clamped, contribution selected): a branch per tap serialises them
+            float v[LK];
+#pragma unroll
+            for (int k = 0; k < LK; ++k) {
+                int row = tip_ - k + HALO;
+                row = row < 0 ? 0 : (row > npos - 1 ? npos - 1 : row);
+                v[k] = dcol_s[(size_t)row * DCL + c * LK + k];
+            }
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < LK; ++k) {
                 const int row = tip_ - k + HALO;
-                if (row >= 0 && row < npos) s += dcol_s[(size_t)row * DCL + c * LK + k];
+                s += (row >= 0 && row < npos) ? v[k] : 0.f;
             }
             out[i] = s;
         }
@@ -809,8 +827,13 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             const int k4 = k0 + t8;
             const bool ok = k4 < H4;
             float4 w[16];
+            if (k0 == 0) {
 #pragma unroll
-            for (int dd = 0; dd < 16; ++dd) w[dd] = W4[(long long)dd * H4 + (ok ? k4 : 0)];
+                for (int dd = 0; dd < 16; ++dd) w[dd] = wq_pre[dd];
+            } else {
+#pragma unroll
+                for (int dd = 0; dd < 16; ++dd) w[dd] = W4[(long long)dd * H4 + (ok ? k4 : 0)];
+            }
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int dd = 0; dd < 16; ++dd) {
