@@ -273,13 +273,13 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     const int c4 = tid % EC4, part = tid / EC4;
     const bool worker = part < parts;
     const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4 + cs * EC4 + c4;
-    // (rows are clamped to the padded length Ti, not to lens[b]: the prefetch must not wait for the length load;
-    // rows past the utterance get weight 0 below)
+    // (rows past the utterance are clamped to row 0 -- an L1 hit -- and get weight 0 below: the kernel is bound by
+    // the memory rows it moves, so skipping the padding is worth waiting for the scalar length load)
     float4 mrow[KC_MAXR];
 #pragma unroll
     for (int i = 0; i < KC_MAXR; ++i) {
         const int ti = part + i * parts;
-        mrow[i] = worker ? M4[(long long)(ti < Ti ? ti : Ti - 1) * E4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mrow[i] = worker ? M4[(long long)(ti < len ? ti : 0) * E4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // slice 0 also carries the cumulative weights forward: its read-modify-write operand is fetched now
     float* const cum_b = a.cum + (long long)b * Ti;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
 #pragma unroll
     for (int i = 0; i < KB1_MAXP; ++i) {
         const int ti = t0 + grp + 8 * i;
-        const long long tc = (i < npass && ti < t1) ? ti : t0;      // clamped: loaded, never used
+        const long long tc = (i < npass && ti < t1 && ti < len_raw) ? ti : t0;      // clamped: loaded, never used
 #pragma unroll
         for (int g = 0; g < KB1_MAXC; ++g) {
             const int c = l32 + 32 * g;
