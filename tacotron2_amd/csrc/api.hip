@@ -110,3 +110,60 @@ extern "C" int t2amd_debug_launch_chain_(float* p, int n, int blocks, void* stre
     for (int i = 0; i < n; ++i) hipLaunchKernelGGL(t2_nop_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     return 0;
 }
+
+// tools/microbench_launch.py: the same chain captured once into a hipGraph and replayed `reps` times; returns the
+// average milliseconds per replay (HIP events on `stream`), or a negative HIP error code.
+extern "C" float t2amd_debug_graph_chain_(float* p, int n, int blocks, int reps, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) return -(float)e;
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(t2_nop_kernel, dim3(blocks), dim3(256), 0, s, p);
+    e = hipStreamEndCapture(s, &g);
+    if (e != hipSuccess) return -(float)e;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) return -(float)e;
+    hipGraphLaunch(ge, s);
+    hipStreamSynchronize(s);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, s);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    return ms / reps;
+}
+
+// tools only: capture whatever the caller launches on `stream` between begin and end into a hipGraph, then replay it
+// `reps` times and return the average milliseconds per replay (negative HIP error code on failure).
+extern "C" int t2amd_debug_capture_begin_(void* stream) {
+    return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);
+}
+extern "C" float t2amd_debug_capture_end_(void* stream, int reps) {
+    hipStream_t s = (hipStream_t)stream;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &g);
+    if (e != hipSuccess) return -(float)e;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) return -(float)e;
+    hipGraphLaunch(ge, s);
+    hipStreamSynchronize(s);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, s);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    return ms / reps;
+}
+

@@ -84,11 +84,15 @@ __device__ __forceinline__ void loc_tile(const float (&ua)[2][16], const float* 
                                          int pos, int lg, f32x4& acc0, f32x4& acc1) {
     acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // all 16 window operands first (left to itself the compiler pairs every LDS read with its MFMA and waits for it)
+    float bw[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) bw[kk] = win_s[tap_offset(kk * 4 + lg, TIP) + pos];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-        const float bw = win_s[tap_offset(kk * 4 + lg, TIP) + pos];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[0][kk], bw, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[1][kk], bw, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[0][kk], bw[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[1][kk], bw[kk], acc1, 0, 0, 0);
     }
 }
 
@@ -234,14 +238,14 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
         }
         f32x4 acc0, acc1;
         loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
-        float e = vv[0][0] * tanhf(acc0[0] + qv[0][0] + pm0.x);
-        e = fmaf(vv[0][1], tanhf(acc0[1] + qv[0][1] + pm0.y), e);
-        e = fmaf(vv[0][2], tanhf(acc0[2] + qv[0][2] + pm0.z), e);
-        e = fmaf(vv[0][3], tanhf(acc0[3] + qv[0][3] + pm0.w), e);
-        e = fmaf(vv[1][0], tanhf(acc1[0] + qv[1][0] + pm1.x), e);
-        e = fmaf(vv[1][1], tanhf(acc1[1] + qv[1][1] + pm1.y), e);
-        e = fmaf(vv[1][2], tanhf(acc1[2] + qv[1][2] + pm1.z), e);
-        e = fmaf(vv[1][3], tanhf(acc1[3] + qv[1][3] + pm1.w), e);
+        float e = vv[0][0] * t2_tanh(acc0[0] + qv[0][0] + pm0.x);
+        e = fmaf(vv[0][1], t2_tanh(acc0[1] + qv[0][1] + pm0.y), e);
+        e = fmaf(vv[0][2], t2_tanh(acc0[2] + qv[0][2] + pm0.z), e);
+        e = fmaf(vv[0][3], t2_tanh(acc0[3] + qv[0][3] + pm0.w), e);
+        e = fmaf(vv[1][0], t2_tanh(acc1[0] + qv[1][0] + pm1.x), e);
+        e = fmaf(vv[1][1], t2_tanh(acc1[1] + qv[1][1] + pm1.y), e);
+        e = fmaf(vv[1][2], t2_tanh(acc1[2] + qv[1][2] + pm1.z), e);
+        e = fmaf(vv[1][3], t2_tanh(acc1[3] + qv[1][3] + pm1.w), e);
         e += __shfl_xor(e, 16, 64);
         e += __shfl_xor(e, 32, 64);
         if (lg == 0 && pos < Ti) eout[pos] = e;
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = (dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r];
-                const float th = tanhf(x);
+                const float th = t2_tanh(x);
                 const float g = de * vv[dt][r] * (1.f - th * th);
                 dva[dt][r] = fmaf(de, th, dva[dt][r]);
                 dqa[dt][r] += g;

@@ -62,6 +62,21 @@ __device__ __forceinline__ unsigned short t2_f32_to_bf16(float x) {
 }
 
 __device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh without divergent paths (libm's tanhf is two exec-masked branches, both taken by a mixed wave).
+// |x| < 0.625: x + x*x2*P(x2), the minimax polynomial libm uses on that range; otherwise 1 - 2/(exp(2|x|) + 1) on
+// v_exp_f32 / v_rcp_f32 (absolute error < 5e-7).  Both are evaluated and one is selected.
+__device__ __forceinline__ float t2_tanh(float x) {
+    const float ax = fabsf(x);
+    const float x2 = ax * ax;
+    float p = fmaf(x2, __uint_as_float(0xbbbac73du), __uint_as_float(0x3ca908c9u));
+    p = fmaf(x2, p, __uint_as_float(0xbd5c1c4eu));
+    p = fmaf(x2, p, __uint_as_float(0x3e088382u));
+    p = fmaf(x2, p, __uint_as_float(0xbeaaaa99u));
+    const float small = fmaf(x2, ax * p, ax);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);      // exp(2|x|); inf for large |x| -> big = 1
+    const float big = fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+    return copysignf(ax < 0.625f ? small : big, x);
+}
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll

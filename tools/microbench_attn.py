@@ -40,3 +40,20 @@ def timeit(fn, n=200):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 print("stage", os.environ.get("T2AMD_ATTN_STAGE", "0"), "fwd (K_e+K_c) %.2f us   bwd (K_b1+K_b2) %.2f us" % (timeit(fwd), timeit(bwd)))
+
+# the same launches replayed from a hipGraph (what a captured decoder loop would pay per step)
+if os.environ.get("T2AMD_ATTN_STAGE", "0") == "0":
+    side = torch.cuda.Stream()
+    sp = C.c_void_p(side.cuda_stream)
+    lib.t2amd_debug_capture_end_.restype = C.c_float
+    lib.t2amd_debug_capture_end_.argtypes = [C.c_void_p, C.c_int]
+    lib.t2amd_debug_capture_begin_.argtypes = [C.c_void_p]
+    torch.cuda.synchronize()
+    for name, desc, fn in (("fwd", fa, _of), ("bwd", ba, _ob)):
+        n = 100
+        rc = lib.t2amd_debug_capture_begin_(sp)
+        assert rc == 0, rc
+        for _ in range(n):
+            fn(C.byref(desc), sp)
+        ms = lib.t2amd_debug_capture_end_(sp, 20)
+        print("graph replay %s: %.2f us per step" % (name, ms * 1e3 / n))

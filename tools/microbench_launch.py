@@ -10,3 +10,13 @@ for blocks in (1, 256, 512, 1024):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); f(x.data_ptr(), 2000, blocks, nv._stream()); e1.record(); torch.cuda.synchronize()
     print("blocks %4d: %.2f us per dependent trivial launch" % (blocks, e0.elapsed_time(e1) / 2000 * 1e3))
+
+g = lib.t2amd_debug_graph_chain_
+g.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+g.restype = C.c_float
+side = torch.cuda.Stream()          # capture is not allowed on the legacy default stream
+torch.cuda.synchronize()
+for blocks in (1, 256, 512):
+    for n in (7, 70, 700):
+        ms = g(x.data_ptr(), n, blocks, 200 if n < 100 else 20, C.c_void_p(side.cuda_stream))
+        print("graph of %3d nodes, blocks %4d: %.2f us per replay = %.2f us per node" % (n, blocks, ms * 1e3, ms * 1e3 / n))
