@@ -188,8 +188,9 @@ def main():
                                                    + 3 * B * H + 0.25 * B * H) + (2.0 * B * H if es == 2.0 else 0.0)
         alg_bytes = lstm_bytes(Ha + E + Hd, Hd, False) + (lstm_bytes(E + Ha, Ha, True) if fused else 0.0)
         alg_flops = 2.0 * B * (4 * Hd * (Ha + E + Hd) + (4 * Ha * (E + Ha) if fused else 0))
-        # A bracket = two hipEventRecords around ONE launch on its stream; an empty bracket costs ev_ms by itself
-        # (calibrated on the same stream right before the first launch), which is subtracted.
+        # Every launch of the role carries its own event pair, stamped by the dispatch itself (hipExtLaunchKernelGGL
+        # start/stop events = the kernel begin/end timestamps rocprofv3 --kernel-trace reports); ev_ms is 0 in this
+        # mode (it is the calibrated empty-bracket cost of the older hipEventRecord brackets).
         raw_s = (ms / 1e3) / max(cnt, 1)
         avg_s = max(raw_s - ev_ms / 1e3, 1e-9)
         achieved = alg_bytes / avg_s / 1e9

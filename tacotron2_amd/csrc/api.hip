@@ -56,6 +56,17 @@ extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s) {
     }
 }
 
+// Event pair for the next profiled launch of role `tag`, or false when that role is not being profiled.  The
+// launch site passes the pair to hipExtLaunchKernelGGL, which stamps them from the dispatch's own start / end
+// timestamps (the clock rocprofv3 --kernel-trace reads): no bracket overhead to calibrate away.
+extern "C" bool t2amd_profile_pair_(int tag, hipEvent_t* e0, hipEvent_t* e1) {
+    if (g_prof_tag < 0 || tag != g_prof_tag || g_validate_only || g_prof_n >= g_prof_max) return false;
+    *e0 = g_prof_ev[2 * g_prof_n];
+    *e1 = g_prof_ev[2 * g_prof_n + 1];
+    ++g_prof_n;
+    return true;
+}
+
 extern "C" int t2amd_profile_enable(int tag, int max_launches) {
     g_prof_n = 0;
     g_cal_done = 0;

@@ -17,6 +17,7 @@
 // Replaces torch.nn.LSTMCell + F.dropout (reference model.py:352-356, 366-371) and the
 // per-timestep work of nn.LSTM (model.py:181-188).
 #include "common.h"
+#include <hip/hip_ext.h>
 
 #define SK_BK 64      // k per LDS tile
 #define SK_ROWS 64    // batch rows per workgroup
@@ -728,29 +729,36 @@ extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_ls
         d.p[1] = d.p[0];
     }
     hipStream_t s = (hipStream_t)stream;
-    t2amd_profile_mark_(a->tag, 0, s);
+    // bench.py's roofline leg: this role's launches carry an event pair stamped by the dispatch itself
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    const bool prof = !t2amd_validate_only_flag_() && t2amd_profile_pair_(a->tag, &pe0, &pe1);
+#define LSTM_LAUNCH(K, G, BLK)                                                         \
+    do {                                                                               \
+        if (prof) hipExtLaunchKernelGGL(K, G, BLK, 0, s, pe0, pe1, 0, d);              \
+        else T2_LAUNCH(K, G, BLK, 0, s, d);                                            \
+    } while (0)
     T2_REQUIRE(!b || (a->bf16 != 0) == (b->bf16 != 0), "lstm_step: both problems of a launch must share the operand type");
     if (a->bf16 && skinny_wide_enabled() && a->H % 8 == 0 && (!b || b->H % 8 == 0)) {
         d.p[0].gx = a->H / 8;
         d.nblk0 = d.p[0].gx * d.p[0].gy;
         total = d.nblk0;
         if (b) { d.p[1].gx = b->H / 8; total += d.p[1].gx * d.p[1].gy; } else { d.p[1] = d.p[0]; }
-        if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<true, 1>), dim3(total), dim3(512), 0, s, d);
-        else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<true, 2>), dim3(total), dim3(512), 0, s, d);
-        else if (a->tag == 3) T2_LAUNCH((skinny_wide_kernel<true, 3>), dim3(total), dim3(512), 0, s, d);
-        else T2_LAUNCH((skinny_wide_kernel<true, 0>), dim3(total), dim3(512), 0, s, d);
+        if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1>), dim3(total), dim3(512));
+        else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2>), dim3(total), dim3(512));
+        else if (a->tag == 3) LSTM_LAUNCH((skinny_wide_kernel<true, 3>), dim3(total), dim3(512));
+        else LSTM_LAUNCH((skinny_wide_kernel<true, 0>), dim3(total), dim3(512));
     } else if (a->bf16) {
-        if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1, true>), dim3(total), dim3(256), 0, s, d);
-        else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2, true>), dim3(total), dim3(256), 0, s, d);
-        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<true, 3, true>), dim3(total), dim3(256), 0, s, d);
-        else T2_LAUNCH((skinny_gemm_kernel<true, 0, true>), dim3(total), dim3(256), 0, s, d);
+        if (a->tag == 1) LSTM_LAUNCH((skinny_gemm_kernel<true, 1, true>), dim3(total), dim3(256));
+        else if (a->tag == 2) LSTM_LAUNCH((skinny_gemm_kernel<true, 2, true>), dim3(total), dim3(256));
+        else if (a->tag == 3) LSTM_LAUNCH((skinny_gemm_kernel<true, 3, true>), dim3(total), dim3(256));
+        else LSTM_LAUNCH((skinny_gemm_kernel<true, 0, true>), dim3(total), dim3(256));
     } else {
-        if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<true, 1, false>), dim3(total), dim3(256), 0, s, d);
-        else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<true, 2, false>), dim3(total), dim3(256), 0, s, d);
-        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<true, 3, false>), dim3(total), dim3(256), 0, s, d);
-        else T2_LAUNCH((skinny_gemm_kernel<true, 0, false>), dim3(total), dim3(256), 0, s, d);
+        if (a->tag == 1) LSTM_LAUNCH((skinny_gemm_kernel<true, 1, false>), dim3(total), dim3(256));
+        else if (a->tag == 2) LSTM_LAUNCH((skinny_gemm_kernel<true, 2, false>), dim3(total), dim3(256));
+        else if (a->tag == 3) LSTM_LAUNCH((skinny_gemm_kernel<true, 3, false>), dim3(total), dim3(256));
+        else LSTM_LAUNCH((skinny_gemm_kernel<true, 0, false>), dim3(total), dim3(256));
     }
-    t2amd_profile_mark_(a->tag, 1, s);
+#undef LSTM_LAUNCH
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -97,3 +97,8 @@ for ns in (1, 2, 4):
     gd, kgd = mkplain16(4 * Hd, Ha + E + Hd, ns)
     ga, kga = mkplain16(4 * Ha, E + Ha, ns)
     print("bf16 dgrad d||a nsplit=%d  %.2f us" % (ns, timeit(lambda: lib.t2amd_skinny_gemm2_f32(C.byref(gd), C.byref(ga), s))))
+
+# K sweep of the wide bf16 kernel (one problem per launch): slope = time per 128-k tile, intercept = fixed cost
+for K in (256, 512, 1024, 2048, 4096):
+    st, keep_ = mk16(K, Hd, [K])
+    print("bf16 LSTM K=%4d (%2d tiles) alone  %.2f us" % (K, K // 128, timeit(lambda: lib.t2amd_lstm_step_fwd_f32(C.byref(st), s))))
