@@ -106,9 +106,32 @@ __device__ __forceinline__ void load_u_frag(float (&ua)[2][16], const float* __r
         }
 }
 
-struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; };
+struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; unsigned long long* ts; };
 
 // timing experiments only (tools/microbench_attn.py): T2AMD_ATTN_STAGE=n makes the kernels return after stage n
+// timing experiments only (tools/microbench_attn.py --phases): with T2AMD_ATTN_TS=1 the first thread of workgroup
+// (0,0) of every attention kernel stamps the 100 MHz wall clock at its phase boundaries into a 64-entry device buffer
+// (slots 0-15 K_e, 16-31 K_c, 32-47 K_b1, 48-63 K_b2), read back with t2amd_debug_attn_ts_.
+static unsigned long long* g_attn_ts = nullptr;
+static unsigned long long* attn_ts_buffer() {
+    static int init = 0;
+    if (!init) {
+        init = 1;
+        const char* e = getenv("T2AMD_ATTN_TS");
+        if (e && e[0] == '1' && hipMalloc((void**)&g_attn_ts, 64 * sizeof(unsigned long long)) != hipSuccess) g_attn_ts = nullptr;
+        if (g_attn_ts) (void)hipMemset(g_attn_ts, 0, 64 * sizeof(unsigned long long));
+    }
+    return g_attn_ts;
+}
+extern "C" int t2amd_debug_attn_ts_(unsigned long long* out64) {
+    if (!g_attn_ts) return -1;
+    return (int)hipMemcpy(out64, g_attn_ts, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#define T2_TS(slot)                                                                                      \
+    do {                                                                                                 \
+        if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.ts[slot] = wall_clock64(); \
+    } while (0)
+
 static int attn_dbg_stage() {
     static int v = -2;
     if (v == -2) { const char* e = getenv("T2AMD_ATTN_STAGE"); v = e ? atoi(e) : 0; }
@@ -127,6 +150,7 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int Ti = a.Ti, Hq = a.Hq, TIP = p.tip;
+    T2_TS(0);
     float* win_s = smem;             // [2][TIP]
     float* q_s = win_s + 2 * TIP;    // [32]
     float* u_s = q_s + DSL;          // [32][62] the slice's rows of U (contiguous in HBM)
@@ -201,10 +225,7 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     stage_u_finish(ureg, u_s, tid);
     {
         const int d = tid >> 4, part = tid & 15;
-        qacc += __shfl_xor(qacc, 1, 64);
-        qacc += __shfl_xor(qacc, 2, 64);
-        qacc += __shfl_xor(qacc, 4, 64);
-        qacc += __shfl_xor(qacc, 8, 64);
+        qacc = row16_sum(qacc);
         if (part == 0) {
             q_s[d] = qacc;
             if (a.q_out) a.q_out[(long long)b * a.ld_q + ds * DSL + d] = qacc;
@@ -213,6 +234,7 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     const int len = len_raw;
     const int nmt = (len + 15) >> 4;
     __syncthreads();
+    T2_TS(1);
     if (p.dbg == 1) return;
     float ua[2][16];
     load_u_frag(ua, u_s, 0, l15, lg);
@@ -250,6 +272,7 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
         e += __shfl_xor(e, 32, 64);
         if (lg == 0 && pos < Ti) eout[pos] = e;
     }
+    T2_TS(2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -265,35 +288,56 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Ti = a.Ti, E = a.E, B = a.B;
     float* w_s = smem;                    // [Ti rounded to 4]
+    T2_TS(16);
     float* red_s = w_s + ((Ti + 3) & ~3); // [16]
     float* part_s = red_s + 16;           // [parts][EC]
-    const int len = a.lens ? a.lens[b] : Ti;
+    // Length through the scalar path (s_load from the constant address space): a vector load would put it in the same
+    // in-order queue as the streams below.
+    const int len = a.lens ? *reinterpret_cast<const __attribute__((address_space(4))) int*>(
+                                 reinterpret_cast<uintptr_t>(a.lens + b)) : Ti;
 
-    // The context rows do not depend on the softmax: fetch this thread's share of memory[b] first so
-    // that the HBM/L2 latency overlaps the three dependent reductions below.
+    // Row offsets of this thread's share of memory[b], computed before any load is issued (address arithmetic placed
+    // between loads can falsely depend on a pending destination register and drain the queue).
     const int EC = E / NCS, EC4 = EC >> 2, E4 = E >> 2;
     int parts = KC_NT / EC4;
     if (parts > 32) parts = 32;
     const int c4 = tid % EC4, part = tid / EC4;
     const bool worker = part < parts;
     const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4 + cs * EC4 + c4;
-    // (rows past the utterance are clamped to row 0 -- an L1 hit -- and get weight 0 below: the kernel is bound by
-    // the memory rows it moves, so skipping the padding is worth waiting for the scalar length load)
+    long long roff[KC_MAXR];
+#pragma unroll
+    for (int i = 0; i < KC_MAXR; ++i) roff[i] = (long long)(part + i * parts) * E4;
+    const float* __restrict__ e0 = a.ws + (long long)b * Ti;
+    const long long es = (long long)B * Ti;
+    const int tc0 = tid < Ti ? tid : Ti - 1;
+    float* const cum_b = a.cum + (long long)b * Ti;
+    __builtin_amdgcn_sched_barrier(0);
+
+    // Partial energies of this thread's first position first: loads complete in order, so the softmax below waits
+    // for these four only, not for the 1 KB-per-row context stream issued behind them.
+    float e_first[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e_first[k] = e0[k * es + tc0];
+    // slice 0 also carries the cumulative weights forward: its read-modify-write operand is fetched now
+    float c_old0 = 0.f;
+    if (cs == 0) c_old0 = cum_b[tc0];
+    // The context rows do not depend on the softmax.  Rows past the utterance are clamped to row 0 (an L1 hit) and
+    // get weight 0 below: the kernel is bound by the rows it moves, skipping the padding is worth the scalar wait.
     float4 mrow[KC_MAXR];
 #pragma unroll
     for (int i = 0; i < KC_MAXR; ++i) {
         const int ti = part + i * parts;
-        mrow[i] = worker ? M4[(long long)(ti < len ? ti : 0) * E4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mrow[i] = M4[ti < len ? roff[i] : 0ll];
     }
-    // slice 0 also carries the cumulative weights forward: its read-modify-write operand is fetched now
-    float* const cum_b = a.cum + (long long)b * Ti;
-    float c_old0 = 0.f;
-    if (cs == 0) c_old0 = cum_b[tid < Ti ? tid : Ti - 1];
+    __builtin_amdgcn_sched_barrier(0);
 
-    const float* __restrict__ e0 = a.ws + (long long)b * Ti;
-    const long long es = (long long)B * Ti;
     float lmax = -INFINITY;
-    for (int ti = tid; ti < Ti; ti += KC_NT) {
+    if (tid < Ti) {
+        const float e = tid < len ? ((e_first[0] + e_first[1]) + e_first[2]) + e_first[3] : -INFINITY;
+        w_s[tid] = e;
+        lmax = e;
+    }
+    for (int ti = tid + KC_NT; ti < Ti; ti += KC_NT) {
         float e = -INFINITY;
         if (ti < len) e = ((e0[ti] + e0[es + ti]) + e0[2 * es + ti]) + e0[3 * es + ti];
         w_s[ti] = e;
@@ -302,6 +346,7 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     lmax = wave_reduce_max(lmax);
     if (lane == 0) red_s[wv] = lmax;
     __syncthreads();
+    T2_TS(17);
     float gmax = red_s[0];
 #pragma unroll
     for (int i = 1; i < KC_NT / 64; ++i) gmax = fmaxf(gmax, red_s[i]);
@@ -314,6 +359,7 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     lsum = wave_reduce_sum(lsum);
     if (lane == 0) red_s[8 + wv] = lsum;
     __syncthreads();
+    T2_TS(18);
     float gsum = red_s[8];
 #pragma unroll
     for (int i = 1; i < KC_NT / 64; ++i) gsum += red_s[8 + i];
@@ -334,6 +380,7 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
         }
     }
     __syncthreads();
+    T2_TS(19);
     // context channels [cs*EC, (cs+1)*EC)
     if (worker) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -352,12 +399,14 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
         *reinterpret_cast<float4*>(&part_s[part * EC + c4 * 4]) = acc;
     }
     __syncthreads();
+    T2_TS(20);
     for (int c = tid; c < EC; c += KC_NT) {
         float s = 0.f;
         for (int q = 0; q < parts; ++q) s += part_s[q * EC + c];
         a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c] = s;
         if (a.ctx16_out) reinterpret_cast<unsigned short*>(a.ctx16_out)[(long long)b * a.ld_ctx16 + cs * EC + c] = t2_f32_to_bf16(s);
     }
+    T2_TS(21);
 }
 
 extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream) {
@@ -373,6 +422,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     p.a = *a;
     p.tip = attn_tip(a->Ti);
     p.dbg = attn_dbg_stage();
+    p.ts = attn_ts_buffer();
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP + (size_t)a->Hq);
     const int EC = a->E / NCS;
@@ -390,7 +440,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // =========================================================================================
 // Backward of one attention step.
 // =========================================================================================
-struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; };
+struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; };
 
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
 // Half a wave (32 lanes) per memory row, 8 rows per pass.  One L2 round trip: the memory rows of the first 64
@@ -409,6 +459,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     float* base_s = dctx_s + E;      // [tsz] carries + running dcum (+ extra) per position of the slice
     float* wl_s = base_s + tsz;      // [tsz] this step's weights
     float* red_s = wl_s + tsz;       // [8]
+    T2_TS(32);
     const int len_raw = a.lens ? a.lens[b] : Ti;
     const int t0 = ts * tsz;
     int t1 = t0 + tsz;
@@ -533,6 +584,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     const int len = len_raw;
     __syncthreads();
     float* __restrict__ dwo = a.ws + (long long)b * Ti;
+    T2_TS(33);
     float psum = 0.f;
     for (int r0 = 0; r0 < tsz; r0 += 8 * KB1_MAXP) {
         float acc[KB1_MAXP];
@@ -569,9 +621,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         }
 #pragma unroll
         for (int i = 0; i < KB1_MAXP; ++i) {
-            float s = acc[i];
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) s += __shfl_xor(s, off, 64);
+            float s = row16_sum(acc[i]);
+            s += __shfl_xor(s, 16, 64);
             const int li = r0 + grp + 8 * i;
             const int ti = t0 + li;
             if (l32 == 0 && ti < t1) {
@@ -581,11 +632,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
             }
         }
     }
+    T2_TS(34);
     // psum lives in lanes 0 and 32 of every wave
     psum += __shfl_xor(psum, 32, 64);
     if (lane == 0) red_s[wv] = psum;
     __syncthreads();
     if (tid == 0) a.ws[(long long)B * Ti + (long long)ts * B + b] = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
+    T2_TS(35);
 }
 
 // K_b2: everything that lives in attention-dim space, for 32 dims (8 waves)
@@ -606,6 +659,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     float* dq_s = red_s + KB2_NW * 2 * DSL;   // [32]
     float* u_s = dq_s + DSL;                  // [32][62]
     float* dh_s = u_s + DSL * NTAP;           // [Hq] second-half partial of dh
+    T2_TS(48);
     // Prologue loads: all issued before the first is consumed, nothing selected on a fresh load (see K_e).
     const int len_raw = a.lens ? a.lens[b] : Ti;
     const int dbase = ds * DSL;
@@ -663,6 +717,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
     stage_u_finish(ureg, u_s, tid);
     __syncthreads();
+    T2_TS(49);
     if (p.dbg == 1) return;
     float ua[2][16];
     load_u_frag(ua, u_s, 0, l15, lg);
@@ -730,6 +785,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16) = o1;
         }
     }
+    T2_TS(50);
     if (p.dbg == 2) return;
     // W_q rows of the closing dh product (first 1024 columns): independent of everything above, fetched now so
     // that the round trip hides behind the reductions, the dU product and col2im
@@ -746,12 +802,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float x = dva[dt][r], y = dqa[dt][r];
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                x += __shfl_xor(x, off, 64);
-                y += __shfl_xor(y, off, 64);
-            }
+            const float x = row16_sum(dva[dt][r]), y = row16_sum(dqa[dt][r]);
             if (l15 == 0) {
                 red_s[(wv * 2 + 0) * DSL + dt * 16 + 4 * lg + r] = x;
                 red_s[(wv * 2 + 1) * DSL + dt * 16 + 4 * lg + r] = y;
@@ -769,6 +820,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         dq_s[tid] = dqs;
         a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
     }
+    T2_TS(51);
     if (p.dbg == 3) return;
     // dU[d][tap] += sum_pos dpre[pos][d] * win[c(tap)][pos + k(tap)]: wave w owns (tap tile w&3, dim tile w>>2)
     {
@@ -795,6 +847,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             for (int r = 0; r < 4; ++r) dUg[(long long)r * NTAP] = old[r] + (c0[r] + c1[r]);
         }
     }
+    T2_TS(52);
     if (p.dbg == 4) return;
     // col2im: partial carry dwin[c][ti'] = sum_k dcol[ti' - k + 15][c*31 + k] over this slice's dims
     {
@@ -819,6 +872,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             out[i] = s;
         }
     }
+    T2_TS(53);
     if (p.dbg == 5) return;
     __syncthreads();   // dq_s
     // partial dh = sum_{d in slice} dq[d] * W_q[d][:]; the two halves of the block take 16 dims each
@@ -856,6 +910,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             }
         }
     }
+    T2_TS(54);
 }
 
 static int g_attn_bwd_lds = 0;
@@ -876,6 +931,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     p.tip = attn_tip(a->Ti);
     p.np = ((a->Ti + 15) / 16) * 16;
     p.dbg = attn_dbg_stage();
+    p.ts = attn_ts_buffer();
     hipStream_t s = (hipStream_t)stream;
     const size_t lds1 = sizeof(float) * ((size_t)a->E + 2 * (size_t)((a->Ti + NTS - 1) / NTS) + 8);
     const size_t lds2 = sizeof(float) * (2 * (size_t)p.tip + p.np + (size_t)p.np * (DCL + DPL) + KB2_NW * 2 * DSL + DSL +

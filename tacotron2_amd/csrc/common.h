@@ -78,14 +78,37 @@ __device__ __forceinline__ float t2_tanh(float x) {
     return copysignf(ax < 0.625f ? small : big, x);
 }
 
+// DPP lane exchanges (VALU, no LDS crossbar: a __shfl_xor is a ds_bpermute the compiler waits for one at a time).
+// The four steps pair exactly the lanes the xor-1/2/4/8 butterfly pairs, so sums are bitwise the same.
+template <int CTRL>
+__device__ __forceinline__ float t2_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over each aligned group of 16 lanes, result in every lane of the group
+__device__ __forceinline__ float row16_sum(float v) {
+    v += t2_dpp<0xB1>(v);      // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += t2_dpp<0x4E>(v);      // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += t2_dpp<0x141>(v);     // row_half_mirror      (the other quad of the 8-lane half: same partner sums as lane ^ 4)
+    v += t2_dpp<0x140>(v);     // row_mirror           (the other half of the row: as lane ^ 8)
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, t2_dpp<0xB1>(v));
+    v = fmaxf(v, t2_dpp<0x4E>(v));
+    v = fmaxf(v, t2_dpp<0x141>(v));
+    v = fmaxf(v, t2_dpp<0x140>(v));
+    return v;
+}
 __device__ __forceinline__ float wave_reduce_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_reduce_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = row16_max(v);
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 

@@ -57,3 +57,15 @@ if os.environ.get("T2AMD_ATTN_STAGE", "0") == "0":
             fn(C.byref(desc), sp)
         ms = lib.t2amd_debug_capture_end_(sp, 20)
         print("graph replay %s: %.2f us per step" % (name, ms * 1e3 / n))
+
+# in-kernel phase timestamps (T2AMD_ATTN_TS=1): 100 MHz wall clock at the phase boundaries of workgroup (0,0)
+if os.environ.get("T2AMD_ATTN_TS") == "1":
+    fwd(); bwd(); torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 64)()
+    lib.t2amd_debug_attn_ts_.argtypes = [C.c_void_p]
+    rc = lib.t2amd_debug_attn_ts_(buf)
+    assert rc == 0, rc
+    names = {0: "K_e ", 16: "K_c ", 32: "K_b1", 48: "K_b2"}
+    for base, nm in names.items():
+        ts = [buf[base + i] for i in range(16) if buf[base + i]]
+        print(nm, "phase boundaries (us from kernel entry):", " ".join("%.2f" % ((t - ts[0]) / 100.0) for t in ts))
