@@ -376,6 +376,10 @@ typedef struct t2amd_attn_bwd {
     long long ld_dh;
     long long dh_split_stride;
     float* ws;               /* workspace, >= B*Ti + 8*B floats */
+    /* 1: the two gradient products of the location layer (dcol = U^T dpre, dU += dpre^T im2col) round their
+     * operands to bf16 and run on v_mfma_f32_16x16x32_bf16 (f32 accumulate) -- the engine's bf16 compute mode.
+     * 0: exact-f32 MFMA.  The forward-type recompute of the location conv stays f32 either way. */
+    int bf16;
 } t2amd_attn_bwd;
 
 int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);

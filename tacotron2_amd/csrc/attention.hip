@@ -23,6 +23,7 @@
 #include "common.h"
 #include <stdlib.h>
 
+typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 #define AD T2AMD_ATT_DIM       // 128
 #define NTAP T2AMD_LOC_TAPS    // 62
 #define LK T2AMD_LOC_KERNEL    // 31
@@ -732,6 +733,17 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 const int tap = tt * 16 + l15;
                 ut[tt][dt][r] = tap < NTAP ? u_s[(dt * 16 + 4 * lg + r) * NTAP + tap] : 0.f;
             }
+    // bf16 mode: the same operand as one v_mfma_f32_16x16x32_bf16 fragment per tap tile.  MFMA k index 8*lg + e stands
+    // for dim (e < 4 ? 4*lg + e : 16 + 4*lg + e - 4), so that the B fragment is exactly this lane's dpre registers.
+    const bool use16 = a.bf16 != 0;
+    uint4 utb[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        utb[tt].x = t2_cvt_pk_bf16(ut[tt][0][0], ut[tt][0][1]);
+        utb[tt].y = t2_cvt_pk_bf16(ut[tt][0][2], ut[tt][0][3]);
+        utb[tt].z = t2_cvt_pk_bf16(ut[tt][1][0], ut[tt][1][1]);
+        utb[tt].w = t2_cvt_pk_bf16(ut[tt][1][2], ut[tt][1][3]);
+    }
 
     int round = 0;
     for (int mt = wv; mt < nmt; mt += KB2_NW, ++round) {
@@ -767,14 +779,29 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 dp[dt][r] = g;
             }
         // dcol^T[tap][pos] = sum_d U[d][tap] dpre[d][pos]: B operand = this lane's own dpre registers
+        if (use16) {
+            uint4 dpb;
+            dpb.x = t2_cvt_pk_bf16(dp[0][0], dp[0][1]);
+            dpb.y = t2_cvt_pk_bf16(dp[0][2], dp[0][3]);
+            dpb.z = t2_cvt_pk_bf16(dp[1][0], dp[1][1]);
+            dpb.w = t2_cvt_pk_bf16(dp[1][2], dp[1][3]);
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf16x8, utb[tt]),
+                                                           __builtin_bit_cast(at_bf16x8, dpb), c, 0, 0, 0);
+                *reinterpret_cast<float4*>(&dcol_s[(size_t)pos * DCL + tt * 16 + 4 * lg]) = make_float4(c[0], c[1], c[2], c[3]);
+            }
+        } else {
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int tt = 0; tt < 4; ++tt) {
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ut[tt][dt][r], dp[dt][r], c, 0, 0, 0);
-            *reinterpret_cast<float4*>(&dcol_s[(size_t)pos * DCL + tt * 16 + 4 * lg]) = make_float4(c[0], c[1], c[2], c[3]);
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ut[tt][dt][r], dp[dt][r], c, 0, 0, 0);
+                *reinterpret_cast<float4*>(&dcol_s[(size_t)pos * DCL + tt * 16 + 4 * lg]) = make_float4(c[0], c[1], c[2], c[3]);
+            }
         }
         *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * DPL + 4 * lg]) = make_float4(dp[0][0], dp[0][1], dp[0][2], dp[0][3]);
         *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * DPL + 16 + 4 * lg]) = make_float4(dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
@@ -796,6 +823,14 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(dbase + half * 16) * H4;
 #pragma unroll
         for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (t8 < H4 ? t8 : 0)];
+    }
+    // ... and the read-modify-write operand of this wave's dU tile (wave w owns tap tile w&3, dim tile w>>2)
+    float dU_old[4];
+    {
+        const int tap = (wv & 3) * 16 + l15;
+        const float* dUg = a.dU_acc + ((long long)b * AD + dbase + (wv >> 2) * 16 + 4 * lg) * NTAP + (tap < NTAP ? tap : 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dU_old[r] = dUg[(long long)r * NTAP];
     }
     // dv / dq: reduce over the positions held by the 16 lanes of a lane group
 #pragma unroll
@@ -830,16 +865,49 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         float* dUg = a.dU_acc + ((long long)b * AD + dbase + dt * 16 + 4 * lg) * NTAP + (tap < NTAP ? tap : 0);
         float old[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) old[r] = dUg[(long long)r * NTAP];      // fetch early
+        for (int r = 0; r < 4; ++r) old[r] = dU_old[r];                    // fetched right after the tile loop
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
         const float* ap = dpre_s + (size_t)lg * DPL + dt * 16 + l15;
         const float* bp = win_s + toff + lg;
-        int s = 0;
-        for (; s + 8 <= npos; s += 8) {
-            const float a0 = ap[(size_t)s * DPL], a1 = ap[(size_t)(s + 4) * DPL];
-            const float b0 = bp[s], b1 = bp[s + 4];
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, c1, 0, 0, 0);
+        // npos is a multiple of 16: chunks of 16 positions (four k-steps), the next chunk's eight LDS operands are
+        // read while the current chunk's four MFMAs issue (an unpipelined loop pays the LDS latency per MFMA pair)
+        if (use16) {
+            // bf16: K = 32 positions per MFMA; lane (row/col l15, group lg) supplies positions s + 8*lg .. + 7
+            const float* ap16 = dpre_s + dt * 16 + l15;
+            const float* bp16 = win_s + toff;
+            for (int s = 0; s < npos; s += 32) {
+                float av[8], bv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int ps = s + 8 * lg + e;
+                    const int pc = ps < npos ? ps : 0;          // rows past npos were never written: read row 0, use 0
+                    av[e] = ap16[(size_t)pc * DPL];
+                    bv[e] = bp16[pc];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) av[e] = (s + 8 * lg + e < npos) ? av[e] : 0.f;
+                uint4 af, bf;
+                af.x = t2_cvt_pk_bf16(av[0], av[1]); af.y = t2_cvt_pk_bf16(av[2], av[3]);
+                af.z = t2_cvt_pk_bf16(av[4], av[5]); af.w = t2_cvt_pk_bf16(av[6], av[7]);
+                bf.x = t2_cvt_pk_bf16(bv[0], bv[1]); bf.y = t2_cvt_pk_bf16(bv[2], bv[3]);
+                bf.z = t2_cvt_pk_bf16(bv[4], bv[5]); bf.w = t2_cvt_pk_bf16(bv[6], bv[7]);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf16x8, af),
+                                                            __builtin_bit_cast(at_bf16x8, bf), c0, 0, 0, 0);
+            }
+        }
+        float a_cur[4], b_cur[4], a_nxt[4], b_nxt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a_cur[j] = ap[(size_t)(4 * j) * DPL]; b_cur[j] = bp[4 * j]; }
+        for (int s = 0; s < (use16 ? 0 : npos); s += 16) {
+            const int sn = (s + 16 < npos) ? s + 16 : s;        // clamped: the last prefetch re-reads this chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a_nxt[j] = ap[(size_t)(sn + 4 * j) * DPL]; b_nxt[j] = bp[sn + 4 * j]; }
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0], b_cur[0], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1], b_cur[1], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[2], b_cur[2], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[3], b_cur[3], c1, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a_cur[j] = a_nxt[j]; b_cur[j] = b_nxt[j]; }
         }
         // npos is a multiple of 16, so no tail
         if (tap < NTAP) {

@@ -61,6 +61,13 @@ __device__ __forceinline__ unsigned short t2_f32_to_bf16(float x) {
     return (unsigned short)(u >> 16);
 }
 
+// two f32 -> packed bf16 pair (a in the low half), round to nearest even, one VALU instruction
+__device__ __forceinline__ unsigned t2_cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // tanh without divergent paths (libm's tanhf is two exec-masked branches, both taken by a mixed wave).
 // |x| < 0.625: x + x*x2*P(x2), the minimax polynomial libm uses on that range; otherwise 1 - 2/(exp(2|x|) + 1) on

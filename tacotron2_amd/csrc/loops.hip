@@ -264,6 +264,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;
+        ab.bf16 = f.bf16 ? 1 : 0;
         return t2amd_attention_step_bwd_f32(&ab, st);
     };
     auto cell_a = [&](int t, t2amd_lstm_bwd& la) {

@@ -127,6 +127,7 @@ class AttnBwd(C.Structure):
         ("dq_out", _f32p), ("ld_dq", _i64),
         ("dh_out", _f32p), ("ld_dh", _i64), ("dh_split_stride", _i64),
         ("ws", _f32p),
+        ("bf16", C.c_int),
     ]
 
 
@@ -790,7 +791,7 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
 
 
 def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory, lens, w, w_prev, cum_before,
-                       dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws):
+                       dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws, bf16=False):
     """dwin_part: (ATT_SLICES, B, 2, Ti) in/out; dcum_acc: (B, Ti) in/out; dh_parts: (ATT_SLICES, B, Hq) out."""
     lib = load()
     a = AttnBwd()
@@ -817,6 +818,7 @@ def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory
     if ws.numel() < attn_bwd_ws_floats(B, Ti):
         raise NativeError("attention_step_bwd: workspace too small")
     a.ws = ptr(_fullc(ws))
+    a.bf16 = 1 if bf16 else 0
     _check(lib.t2amd_attention_step_bwd_f32(C.byref(a), _stream()), "t2amd_attention_step_bwd_f32")
 
 

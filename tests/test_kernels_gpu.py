@@ -394,8 +394,11 @@ def _attn_inputs(B, Ti, E, Hq, seed):
     return sd, h, mem, pm, lens, w_prev, cum
 
 
+@pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("B,Ti,E,Hq", [(3, 37, 128, 128), (4, 175, 512, 1024), (2, 70, 512, 1024)])
-def test_attention_forward_backward(nv, B, Ti, E, Hq):
+def test_attention_forward_backward(nv, B, Ti, E, Hq, bf16):
+    """bf16=True: the two gradient products of the location layer (dcol = U^T dpre -> the carries, dU) round their
+    operands to bf16 (t2amd_attn_bwd.bf16): bf16-class tolerance on exactly those outputs, f32-class on the rest."""
     sd, h, mem, pm, lens, w_prev, cum = _attn_inputs(B, Ti, E, Hq, 70)
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     hL, pmL, wpL, cumL = (t.clone().requires_grad_(True) for t in (h, pm, w_prev, cum))
@@ -441,17 +444,21 @@ def test_attention_forward_backward(nv, B, Ti, E, Hq):
     dq, dh = torch.empty(B, 128, device=DEV), torch.full((S, B, Hq), float('nan'), device=DEV)
     half = dv(d_ctx * 0.5)
     nv.attention_step_bwd([half, half], dctx_total, dv(d_w_extra), q_out, Wq, U, v, pmd, memd, lens32, w_out, wpd,
-                          cum_save, dwin_d, dcum_d, d_pm, dU_acc, dv_acc, dq, dh, ws)
+                          cum_save, dwin_d, dcum_d, d_pm, dU_acc, dv_acc, dq, dh, ws, bf16=bf16)
+    gt = 2e-2 if bf16 else 1.0          # tolerance scale of the bf16-rounded products (relative to the f32 limits)
     assert err(dctx_total, d_ctx) < 1e-6
     assert err(dh.sum(0), hL.grad) < 2e-5
     assert err(d_pm, pmL.grad) < 2e-5
     assert err(dcum_d, d_cum_carry) < 1e-6                      # running accumulator now holds the full carry
-    assert err(dwin_d[:, :, 0].sum(0), wpL.grad) < 2e-5
-    assert err(dcum_d + dwin_d[:, :, 1].sum(0), cumL.grad) < 2e-5
+    cl = lambda lim, ref: max(lim, gt * 0.5 * ref.abs().max().item()) if bf16 else lim
+    assert err(dwin_d[:, :, 0].sum(0), wpL.grad) < cl(2e-5, wpL.grad)
+    assert err(dcum_d + dwin_d[:, :, 1].sum(0), cumL.grad) < cl(2e-5, cumL.grad)
     dWd, dWc, dvv = torch.empty(128, 32, device=DEV), torch.empty(32, 2, 31, device=DEV), torch.empty(1, 128, device=DEV)
     nv.unfold_location_grads(dU_acc, dv_acc, B, Wd, Wc, dWd, dWc, dvv)
-    assert err(dWd, leaf['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'].grad) < 5e-5
-    assert err(dWc, leaf['decoder.attention_layer.location_layer.location_conv.conv.weight'].grad) < 5e-5
+    gWd = leaf['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'].grad
+    gWc = leaf['decoder.attention_layer.location_layer.location_conv.conv.weight'].grad
+    assert err(dWd, gWd) < cl(5e-5, gWd)
+    assert err(dWc, gWc) < cl(5e-5, gWc)
     assert err(dvv, leaf['decoder.attention_layer.v.linear_layer.weight'].grad) < 5e-5
     dWq_ref = leaf['decoder.attention_layer.query_layer.linear_layer.weight'].grad
     assert err(dq.cpu().t() @ h, dWq_ref) < 5e-5
