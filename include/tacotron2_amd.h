@@ -336,6 +336,10 @@ typedef struct t2amd_attn_fwd {
     float* ws;               /* workspace, >= T2AMD_ATT_SLICES*B*Ti floats (partial energies) */
     void* ctx16_out;         /* optional bf16 copy of the context [B][ld_ctx16] (bf16 operand mode) */
     long long ld_ctx16;
+    /* 1: the location convolution runs as a split-bf16 product (U = Uh + Ul, window = Wh + Wl in bf16;
+     * Uh.Wh + Uh.Wl + Ul.Wh on v_mfma_f32_16x16x32_bf16, f32 accumulate: ~2^-17 relative per product) -- the
+     * engine's bf16 compute mode.  0: exact-f32 MFMA (parity mode). */
+    int loc_split_bf16;
 } t2amd_attn_fwd;
 
 int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
@@ -378,7 +382,8 @@ typedef struct t2amd_attn_bwd {
     float* ws;               /* workspace, >= B*Ti + 8*B floats */
     /* 1: the two gradient products of the location layer (dcol = U^T dpre, dU += dpre^T im2col) round their
      * operands to bf16 and run on v_mfma_f32_16x16x32_bf16 (f32 accumulate) -- the engine's bf16 compute mode.
-     * 0: exact-f32 MFMA.  The forward-type recompute of the location conv stays f32 either way. */
+     * 0: exact-f32 MFMA.  The recompute of the location conv uses the forward's split-bf16 form (see
+     * t2amd_attn_fwd.loc_split_bf16) when this is 1, the exact-f32 MFMA otherwise. */
     int bf16;
 } t2amd_attn_bwd;
 

@@ -107,6 +107,58 @@ __device__ __forceinline__ void load_u_frag(float (&ua)[2][16], const float* __r
         }
 }
 
+// ---- split-bf16 form of the location product (bf16 compute mode) ------------------------------------------
+// One v_mfma_f32_16x16x32_bf16 per (dim tile, window channel c): K = 32 taps = the channel's 31 + one zero column.
+// A = U[d][c*31 + k] (lane: d = l15, k = 8*lg + e), B = win[c][pos + k] (lane: pos = l15, k = 8*lg + e: eight
+// consecutive floats of the halo window).  Both operands are split x = hi + lo (bf16 each) and the product is
+// Uh.Wh + Uh.Wl + Ul.Wh: ~2^-17 relative per product instead of bf16's 2^-9, at 12 MFMAs of 16 cycles per tile
+// instead of 32 of 32.
+struct UFrag16 { uint4 hi[2][2], lo[2][2]; };      // [dim tile][channel]
+__device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo) {
+    hi.x = t2_cvt_pk_bf16(f[0], f[1]); hi.y = t2_cvt_pk_bf16(f[2], f[3]);
+    hi.z = t2_cvt_pk_bf16(f[4], f[5]); hi.w = t2_cvt_pk_bf16(f[6], f[7]);
+    lo.x = t2_cvt_pk_bf16(f[0] - __uint_as_float(hi.x << 16), f[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = t2_cvt_pk_bf16(f[2] - __uint_as_float(hi.y << 16), f[3] - __uint_as_float(hi.y & 0xffff0000u));
+    lo.z = t2_cvt_pk_bf16(f[4] - __uint_as_float(hi.z << 16), f[5] - __uint_as_float(hi.z & 0xffff0000u));
+    lo.w = t2_cvt_pk_bf16(f[6] - __uint_as_float(hi.w << 16), f[7] - __uint_as_float(hi.w & 0xffff0000u));
+}
+__device__ __forceinline__ void load_u_frag16(UFrag16& uf, const float* __restrict__ u_s, int l15, int lg) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * lg + e;
+                f[e] = k < LK ? u_s[(dt * 16 + l15) * NTAP + c * LK + k] : 0.f;
+            }
+            split8(f, uf.hi[dt][c], uf.lo[dt][c]);
+        }
+}
+__device__ __forceinline__ void loc_tile16(const UFrag16& uf, const float* __restrict__ win_s, int TIP, int pos, int lg,
+                                           f32x4& acc0, f32x4& acc1) {
+    acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float f0[8], f1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        f0[e] = win_s[pos + 8 * lg + e];
+        f1[e] = win_s[TIP + pos + 8 * lg + e];
+    }
+    uint4 h0, l0, h1, l1;
+    split8(f0, h0, l0);
+    split8(f1, h1, l1);
+#define T2_M16(A, B, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf16x8, (A)), __builtin_bit_cast(at_bf16x8, (B)), C, 0, 0, 0)
+    T2_M16(uf.lo[0][0], h0, acc0); T2_M16(uf.lo[1][0], h0, acc1);
+    T2_M16(uf.hi[0][0], l0, acc0); T2_M16(uf.hi[1][0], l0, acc1);
+    T2_M16(uf.lo[0][1], h1, acc0); T2_M16(uf.lo[1][1], h1, acc1);
+    T2_M16(uf.hi[0][1], l1, acc0); T2_M16(uf.hi[1][1], l1, acc1);
+    T2_M16(uf.hi[0][0], h0, acc0); T2_M16(uf.hi[1][0], h0, acc1);
+    T2_M16(uf.hi[0][1], h1, acc0); T2_M16(uf.hi[1][1], h1, acc1);
+#undef T2_M16
+}
+
 struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; unsigned long long* ts; };
 
 // timing experiments only (tools/microbench_attn.py): T2AMD_ATTN_STAGE=n makes the kernels return after stage n
@@ -237,8 +289,11 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     __syncthreads();
     T2_TS(1);
     if (p.dbg == 1) return;
+    const bool split16 = a.loc_split_bf16 != 0;
     float ua[2][16];
-    load_u_frag(ua, u_s, 0, l15, lg);
+    UFrag16 uf;
+    if (split16) load_u_frag16(uf, u_s, l15, lg);
+    else load_u_frag(ua, u_s, 0, l15, lg);
     float qv[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -260,7 +315,8 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
             }
         }
         f32x4 acc0, acc1;
-        loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
+        if (split16) loc_tile16(uf, win_s, TIP, pos, lg, acc0, acc1);
+        else loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
         float e = vv[0][0] * t2_tanh(acc0[0] + qv[0][0] + pm0.x);
         e = fmaf(vv[0][1], t2_tanh(acc0[1] + qv[0][1] + pm0.y), e);
         e = fmaf(vv[0][2], t2_tanh(acc0[2] + qv[0][2] + pm0.z), e);
@@ -721,7 +777,9 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     T2_TS(49);
     if (p.dbg == 1) return;
     float ua[2][16];
-    load_u_frag(ua, u_s, 0, l15, lg);
+    UFrag16 uf;
+    if (a.bf16) load_u_frag16(uf, u_s, l15, lg);
+    else load_u_frag(ua, u_s, 0, l15, lg);
     // U^T as the A operand of dcol^T = U^T dpre: A[i = tap][k = lg], k-step (dt, r) <-> dim dt*16 + 4*lg + r
     float ut[4][2][4];
 #pragma unroll
@@ -763,7 +821,8 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             }
         }
         f32x4 acc0, acc1;
-        loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
+        if (a.bf16) loc_tile16(uf, win_s, TIP, pos, lg, acc0, acc1);
+        else loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
         const float de = de_s[pos];
         float dp[2][4];
         const float pmv[2][4] = {{pm0.x, pm0.y, pm0.z, pm0.w}, {pm1.x, pm1.y, pm1.z, pm1.w}};

@@ -107,6 +107,7 @@ class AttnFwd(C.Structure):
         ("active", C.c_void_p),
         ("ws", _f32p),
         ("ctx16_out", C.c_void_p), ("ld_ctx16", _i64),
+        ("loc_split_bf16", C.c_int),
     ]
 
 
@@ -767,7 +768,8 @@ def attn_bwd_ws_floats(B, Ti):
     return B * Ti + 8 * B
 
 
-def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None):
+def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,
+                       bf16=False):
     lib = load()
     a = AttnFwd()
     B, Ti, E = memory.shape
@@ -787,6 +789,7 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
     if ws.numel() < attn_fwd_ws_floats(B, Ti):
         raise NativeError("attention_step_fwd: workspace too small")
     a.ws = ptr(_fullc(ws))
+    a.loc_split_bf16 = 1 if bf16 else 0
     _check(lib.t2amd_attention_step_fwd_f32(C.byref(a), _stream()), "t2amd_attention_step_fwd_f32")
 
 

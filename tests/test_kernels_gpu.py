@@ -423,9 +423,10 @@ def test_attention_forward_backward(nv, B, Ti, E, Hq, bf16):
     w_out, ctx_out, q_out = torch.empty(B, Ti, device=DEV), torch.empty(B, E, device=DEV), torch.empty(B, 128, device=DEV)
     memd, pmd, hd, wpd = dv(mem), dv(pm), dv(h), dv(w_prev)
     ws = torch.full((nv.attn_fwd_ws_floats(B, Ti) + nv.attn_bwd_ws_floats(B, Ti),), float('nan'), device=DEV)
-    nv.attention_step_fwd(hd, Wq, U, v, pmd, memd, lens32, wpd, cum_d, cum_save, w_out, ctx_out, q_out, ws)
-    assert err(w_out, w) < 1e-5 and err(ctx_out, ctx) < 1e-5
-    assert err(cum_d, cum_new) < 1e-5 and torch.equal(cum_save.cpu(), cum)
+    nv.attention_step_fwd(hd, Wq, U, v, pmd, memd, lens32, wpd, cum_d, cum_save, w_out, ctx_out, q_out, ws, bf16=bf16)
+    ftol = 1e-4 if bf16 else 1e-5         # bf16=True: location conv as a split-bf16 product (~2^-17 per product)
+    assert err(w_out, w) < ftol and err(ctx_out, ctx) < ftol
+    assert err(cum_d, cum_new) < ftol and torch.equal(cum_save.cpu(), cum)
     assert err(q_out, h @ sd['decoder.attention_layer.query_layer.linear_layer.weight'].t()) < 1e-5
     assert (w_out.cpu()[mask] == 0).all()
 
@@ -447,8 +448,8 @@ def test_attention_forward_backward(nv, B, Ti, E, Hq, bf16):
                           cum_save, dwin_d, dcum_d, d_pm, dU_acc, dv_acc, dq, dh, ws, bf16=bf16)
     gt = 2e-2 if bf16 else 1.0          # tolerance scale of the bf16-rounded products (relative to the f32 limits)
     assert err(dctx_total, d_ctx) < 1e-6
-    assert err(dh.sum(0), hL.grad) < 2e-5
-    assert err(d_pm, pmL.grad) < 2e-5
+    assert err(dh.sum(0), hL.grad) < (2e-4 if bf16 else 2e-5)
+    assert err(d_pm, pmL.grad) < (2e-4 if bf16 else 2e-5)
     assert err(dcum_d, d_cum_carry) < 1e-6                      # running accumulator now holds the full carry
     cl = lambda lim, ref: max(lim, gt * 0.5 * ref.abs().max().item()) if bf16 else lim
     assert err(dwin_d[:, :, 0].sum(0), wpL.grad) < cl(2e-5, wpL.grad)
