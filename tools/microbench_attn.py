@@ -29,6 +29,8 @@ nv.attention_step_fwd(h, Wq, U, v, pm, mem, lens, wprev, cum, cum_save, w_out, c
 nv.attention_step_bwd([dctx], dctx_total, None, q, Wq, U, v, pm, mem, lens, w_out, wprev, cum_save, dwin, dcum, d_pm, dU, dv_, dq, dh, ws)
 lib.t2amd_attention_step_fwd_f32, lib.t2amd_attention_step_bwd_f32 = _of, _ob
 fa, fs = _cap['f']; ba, bs = _cap['b']
+if os.environ.get('T2AMD_MB_BF16') == '1':      # the engine's bf16 compute mode: split-bf16 location conv, bf16 gradient products
+    fa.loc_split_bf16 = 1; ba.bf16 = 1
 def fwd(): _of(C.byref(fa), fs)
 def bwd(): _ob(C.byref(ba), bs)
 def timeit(fn, n=200):
