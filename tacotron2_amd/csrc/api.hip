@@ -178,3 +178,22 @@ extern "C" float t2amd_debug_capture_end_(void* stream, int reps) {
     return ms / reps;
 }
 
+// tools only: device buffer of 128 wall-clock stamps (T2AMD_ATTN_TS=1), written by thread 0 of workgroup 0 of the
+// instrumented kernels at their phase boundaries (attention: slots 0-63, wide LSTM step kernel: 64-79, its plain
+// variant: 80-95); nullptr when the switch is off, so the kernels skip the stamps.
+static unsigned long long* g_dbg_ts = nullptr;
+extern "C" unsigned long long* t2amd_debug_ts_() {
+    static int init = 0;
+    if (!init) {
+        init = 1;
+        const char* e = getenv("T2AMD_ATTN_TS");
+        if (e && e[0] == '1' && hipMalloc((void**)&g_dbg_ts, 128 * sizeof(unsigned long long)) != hipSuccess) g_dbg_ts = nullptr;
+        if (g_dbg_ts) (void)hipMemset(g_dbg_ts, 0, 128 * sizeof(unsigned long long));
+    }
+    return g_dbg_ts;
+}
+extern "C" int t2amd_debug_attn_ts_(unsigned long long* out128) {
+    if (!g_dbg_ts) return -1;
+    return (int)hipMemcpy(out128, g_dbg_ts, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+

@@ -164,22 +164,8 @@ struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; unsigned long long* t
 // timing experiments only (tools/microbench_attn.py): T2AMD_ATTN_STAGE=n makes the kernels return after stage n
 // timing experiments only (tools/microbench_attn.py --phases): with T2AMD_ATTN_TS=1 the first thread of workgroup
 // (0,0) of every attention kernel stamps the 100 MHz wall clock at its phase boundaries into a 64-entry device buffer
-// (slots 0-15 K_e, 16-31 K_c, 32-47 K_b1, 48-63 K_b2), read back with t2amd_debug_attn_ts_.
-static unsigned long long* g_attn_ts = nullptr;
-static unsigned long long* attn_ts_buffer() {
-    static int init = 0;
-    if (!init) {
-        init = 1;
-        const char* e = getenv("T2AMD_ATTN_TS");
-        if (e && e[0] == '1' && hipMalloc((void**)&g_attn_ts, 64 * sizeof(unsigned long long)) != hipSuccess) g_attn_ts = nullptr;
-        if (g_attn_ts) (void)hipMemset(g_attn_ts, 0, 64 * sizeof(unsigned long long));
-    }
-    return g_attn_ts;
-}
-extern "C" int t2amd_debug_attn_ts_(unsigned long long* out64) {
-    if (!g_attn_ts) return -1;
-    return (int)hipMemcpy(out64, g_attn_ts, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-}
+// (slots 0-15 K_e, 16-31 K_c, 32-47 K_b1, 48-63 K_b2; api.hip owns the buffer), read back with t2amd_debug_attn_ts_.
+static unsigned long long* attn_ts_buffer() { return t2amd_debug_ts_(); }
 #define T2_TS(slot)                                                                                      \
     do {                                                                                                 \
         if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.ts[slot] = wall_clock64(); \

@@ -121,6 +121,7 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
 
 // internal entry points shared between translation units (not part of the C ABI)
 extern "C" bool t2amd_profile_pair_(int tag, hipEvent_t* e0, hipEvent_t* e1);
+extern "C" unsigned long long* t2amd_debug_ts_();
 int t2amd_proj_finish_small_(const t2amd_small_linear* a, int* out_lengths, uint8_t* active, int* done_count, int t,
                              int max_steps, float thr, int gate_row, void* stream);
 

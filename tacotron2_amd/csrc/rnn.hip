@@ -54,7 +54,28 @@ struct SkinnyParams {
 // Two independent problems in one launch (blocks [0, nblk0) -> p[0], the rest -> p[1]): the decoder
 // LSTM of step t-1 rides along with the attention LSTM of step t (and likewise their BPTT dgrads),
 // which puts two workgroups on every CU so that one's MFMAs cover the other's loads and barriers.
-struct SkinnyDual { SkinnyParams p[2]; int nblk0; };
+struct SkinnyDual { SkinnyParams p[2]; int nblk0; unsigned long long* ts; };
+
+// The workgroup's problem, selected FIELD BY FIELD from the two kernel-argument copies.  Taking a reference to
+// dp.p[second] makes every later field access a scalar load from a computed address, which the compiler issues one
+// at a time and waits for (1.7 us of serial s_load round trips before the first DMA); selecting per field keeps
+// every load at a constant kernarg offset, so they are batched into a few wide s_loads issued together.
+__device__ __forceinline__ SkinnyParams skinny_select(const SkinnyDual& dp, bool second) {
+    const SkinnyParams& a = dp.p[0];
+    const SkinnyParams& b = dp.p[1];
+    SkinnyParams p;
+#define SK_SEL(F) p.F = second ? b.F : a.F
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { SK_SEL(x[i].p); SK_SEL(x[i].ld); SK_SEL(x[i].width); }
+    SK_SEL(nseg); SK_SEL(W); SK_SEL(Ktot); SK_SEL(B); SK_SEL(H); SK_SEL(N);
+    SK_SEL(gin); SK_SEL(ld_gin); SK_SEL(bias); SK_SEL(c_prev); SK_SEL(ld_cprev);
+    SK_SEL(gates_out); SK_SEL(ld_gates); SK_SEL(c_out); SK_SEL(ld_c); SK_SEL(h_out); SK_SEL(ld_h);
+    SK_SEL(h16_out); SK_SEL(ld_h16); SK_SEL(keep); SK_SEL(ld_keep); SK_SEL(keep_scale); SK_SEL(lens); SK_SEL(t);
+    SK_SEL(Y); SK_SEL(ldy); SK_SEL(nsplit); SK_SEL(split_stride); SK_SEL(ktiles_per_split);
+    SK_SEL(gx); SK_SEL(gy); SK_SEL(gz);
+#undef SK_SEL
+    return p;
+}
 
 #define SK_DEPTH 4    // register ring: tiles kt+1 .. kt+3 are in flight from HBM/L2 while tile kt is multiplied
 
@@ -75,7 +96,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
     float* const Os = smem + SK_NBUF * (SK_XT + SK_WT);   // [64][17]
 
     const bool second = (int)blockIdx.x >= dp.nblk0;
-    const SkinnyParams& p = second ? dp.p[1] : dp.p[0];
+    const SkinnyParams p = skinny_select(dp, second);
     const int lb = (int)blockIdx.x - (second ? dp.nblk0 : 0);
     const int bx = lb % p.gx;
     const int by = (lb / p.gx) % p.gy;
@@ -392,16 +413,21 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
 #define SW_XB (64 * 256)    // bytes per activation tile
 #define SW_WB (32 * 256)    // bytes per weight tile
 
+#define SW_TS(slot)                                                                                              \
+    do {                                                                                                         \
+        if (dp.ts && blockIdx.x == 0 && threadIdx.x == 0) dp.ts[(LSTM ? 64 : 80) + (slot)] = wall_clock64();     \
+    } while (0)
 template <bool LSTM, int TAG>
 __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     constexpr int BK = 128;
+    SW_TS(0);
     __shared__ __attribute__((aligned(16))) char smem[SW_NBUF * (SW_XB + SW_WB)];
     char* const Xs = smem;                       // [NBUF][64][256 B]
     char* const Ws = smem + SW_NBUF * SW_XB;     // [NBUF][32][256 B]
     float* const Ps = reinterpret_cast<float*>(smem);   // epilogue: [4][64][33] partial sums (aliases the ring)
 
     const bool second = (int)blockIdx.x >= dp.nblk0;
-    const SkinnyParams& p = second ? dp.p[1] : dp.p[0];
+    const SkinnyParams p = skinny_select(dp, second);
     const int lb = (int)blockIdx.x - (second ? dp.nblk0 : 0);
     const int bx = lb % p.gx;
     const int by = (lb / p.gx) % p.gy;
@@ -589,6 +615,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     }
 
     if (kt_end > kt_beg) {
+        SW_TS(1);
         SW_ISSUE(0)
         SW_ISSUE(1)
         SW_ISSUE(2)
@@ -596,6 +623,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        SW_TS(2);
         SW_X(SW_READ, 0, SW_SETA)
         SW_X(SW_WAITR, SW_SETA)
         int kt = kt_beg;
@@ -623,6 +651,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
 #undef SW_X
 
     // k-quarter partial sums -> LDS (the ring is dead once every wave's DMA has drained)
+    SW_TS(3);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -630,6 +659,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
         Ps[(wk * 64 + row) * 33 + l31] = acc0[r] + acc1[r];
     }
     __syncthreads();
+    SW_TS(4);
 
     if (!LSTM) {
         // thread -> (row = tid>>3, 4 consecutive columns)
@@ -643,6 +673,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
             const float v = (Ps[erow * 33 + c] + Ps[(64 + erow) * 33 + c]) + (Ps[(128 + erow) * 33 + c] + Ps[(192 + erow) * 33 + c]);
             if (gn < p.N) Y[gn] = v;
         }
+        SW_TS(5);
         return;
     }
     if (egr >= B) return;
@@ -674,6 +705,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     p.c_out[(long long)egr * p.ld_c + ej] = cn;
     p.h_out[(long long)egr * p.ld_h + ej] = hn;
     if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
+    SW_TS(5);
 }
 
 // T2AMD_SKINNY_NARROW=1 keeps the 64x16 kernel for bf16 operands too (A/B measurements)
@@ -719,6 +751,7 @@ static int fill_lstm(const t2amd_lstm_step* a, SkinnyParams& p) {
 // role is a's tag.
 extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_lstm_step* b, void* stream) {
     SkinnyDual d;
+    d.ts = t2amd_debug_ts_();
     T2_PROPAGATE(fill_lstm(a, d.p[0]));
     d.nblk0 = d.p[0].gx * d.p[0].gy;
     int total = d.nblk0;
@@ -785,6 +818,7 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
 
 extern "C" int t2amd_skinny_gemm2_f32(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, void* stream) {
     SkinnyDual d;
+    d.ts = t2amd_debug_ts_();
     T2_PROPAGATE(fill_plain(a, d.p[0]));
     d.nblk0 = d.p[0].gx * d.p[0].gy * d.p[0].gz;
     int total = d.nblk0;

@@ -102,3 +102,16 @@ for ns in (1, 2, 4):
 for K in (256, 512, 1024, 2048, 4096):
     st, keep_ = mk16(K, Hd, [K])
     print("bf16 LSTM K=%4d (%2d tiles) alone  %.2f us" % (K, K // 128, timeit(lambda: lib.t2amd_lstm_step_fwd_f32(C.byref(st), s))))
+
+# in-kernel phase stamps of the wide kernel (T2AMD_ATTN_TS=1): entry, prologue done, first tile landed, k loop done,
+# partial sums exchanged, stores issued -- for workgroup 0 (a decoder-LSTM workgroup) of the fused launch
+if os.environ.get("T2AMD_ATTN_TS") == "1":
+    lib.t2amd_lstm_step_fwd2_f32(C.byref(d16), C.byref(a16), s); torch.cuda.synchronize()
+    gd, kgd = mkplain16(4 * Hd, Ha + E + Hd, 2); ga, kga = mkplain16(4 * Ha, E + Ha, 2)
+    lib.t2amd_skinny_gemm2_f32(C.byref(gd), C.byref(ga), s); torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 128)()
+    lib.t2amd_debug_attn_ts_.argtypes = [C.c_void_p]
+    assert lib.t2amd_debug_attn_ts_(buf) == 0
+    for base, nm in ((64, "LSTM pair "), (80, "dgrad pair")):
+        ts = [buf[base + i] for i in range(6)]
+        print(nm, "stamps (us from entry): " + " ".join("%.2f" % ((t - ts[0]) / 100.0) for t in ts))
