@@ -20,7 +20,20 @@ __global__ void colreduce_partial_kernel(const float* __restrict__ x, long long 
     __shared__ double s1[4][64], s2[4][64];
     double a = 0.0, q = 0.0;
     if (col < N) {
-        for (long long r = (long long)rb * 4 + rsub; r < M; r += (long long)RB * 4) {
+        // four rows per trip, loaded before the first is used: one load in flight per thread left the kernel
+        // latency-bound at ~1.5 TB/s
+        const long long step = (long long)RB * 4;
+        long long r = (long long)rb * 4 + rsub;
+        for (; r + 3 * step < M; r += 4 * step) {
+            const float v0 = x[r * ldx + col], v1 = x[(r + step) * ldx + col];
+            const float v2 = x[(r + 2 * step) * ldx + col], v3 = x[(r + 3 * step) * ldx + col];
+            a += (double)v0; a += (double)v1; a += (double)v2; a += (double)v3;
+            if (MODE == 0) {
+                q += (double)v0 * (double)v0; q += (double)v1 * (double)v1;
+                q += (double)v2 * (double)v2; q += (double)v3 * (double)v3;
+            }
+        }
+        for (; r < M; r += step) {
             const float v = x[r * ldx + col];
             a += (double)v;
             if (MODE == 0) q += (double)v * (double)v;
@@ -152,11 +165,9 @@ __global__ void bn_act_bwd_stage1_kernel(float* __restrict__ dy, long long lddy,
     double a = 0.0, q = 0.0;
     if (col < N) {
         const float mu = mean[col], is = invstd[col];
-        for (long long r = (long long)rb * 4 + rsub; r < M; r += (long long)RB * 4) {
-            float g = dy[r * lddy + col];
-            const float yv = y[r * ldy + col];
+        auto gate = [&](float g, float yv, unsigned kp) -> float {
             if (keep) {
-                if (keep[r * ldkeep + col]) {
+                if (kp) {
                     g *= keep_scale;
                     if (act == 1) g = (yv > 0.f) ? g : 0.f;
                     else if (act == 2) { const float th = yv / keep_scale; g *= (1.f - th * th); }
@@ -167,6 +178,29 @@ __global__ void bn_act_bwd_stage1_kernel(float* __restrict__ dy, long long lddy,
                 if (act == 1) g = (yv > 0.f) ? g : 0.f;
                 else if (act == 2) g *= (1.f - yv * yv);
             }
+            return g;
+        };
+        // two rows per trip, every load issued before the first use (see colreduce_partial_kernel)
+        const long long step = (long long)RB * 4;
+        long long r = (long long)rb * 4 + rsub;
+        for (; r + step < M; r += 2 * step) {
+            const long long r1 = r + step;
+            float g0 = dy[r * lddy + col], g1 = dy[r1 * lddy + col];
+            const float y0 = y[r * ldy + col], y1 = y[r1 * ldy + col];
+            const float x0 = x[r * ldx + col], x1 = x[r1 * ldx + col];
+            unsigned k0 = 1, k1 = 1;
+            if (keep) { k0 = keep[r * ldkeep + col]; k1 = keep[r1 * ldkeep + col]; }
+            g0 = gate(g0, y0, k0);
+            g1 = gate(g1, y1, k1);
+            dy[r * lddy + col] = g0;
+            dy[r1 * lddy + col] = g1;
+            a += (double)g0; q += (double)g0 * (double)((x0 - mu) * is);
+            a += (double)g1; q += (double)g1 * (double)((x1 - mu) * is);
+        }
+        for (; r < M; r += step) {
+            float g = dy[r * lddy + col];
+            const float yv = y[r * ldy + col];
+            g = gate(g, yv, keep ? keep[r * ldkeep + col] : 1u);
             dy[r * lddy + col] = g;
             const float xhat = (x[r * ldx + col] - mu) * is;
             a += (double)g;
