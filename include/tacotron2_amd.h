@@ -143,7 +143,8 @@ int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, double* ws, fl
  * ------------------------------------------------------------------------------------ */
 int t2amd_embedding_fwd_f32(const long long* ids, const float* table, float* out, long long rows,
                             int dim, int n_symbols, void* stream);
-/* ws: >= 8 * n_symbols * dim floats (row-chunk partials, summed in a fixed order) */
+/* dtable[s] = sum of the dout rows whose id is s, in ascending row order (no atomics).  ws is unused (may be
+ * NULL); it stays in the signature for callers built against the earlier partial-sum version. */
 int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, float* ws, long long rows,
                             int dim, int n_symbols, void* stream);
 /* Philox4x32-10 keep-mask: out[i] = uniform(seed, offset+i) >= p */

@@ -292,49 +292,61 @@ extern "C" int t2amd_embedding_fwd_f32(const long long* ids, const float* table,
     return T2AMD_OK;
 }
 
-// one workgroup per (symbol, 256-column slab, row chunk): deterministic row order, no atomics; the
-// EMB_SPLIT row-chunk partials of a (symbol, column) are summed in chunk order by the last-launched pass
-#define EMB_SPLIT 8
-__global__ void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout,
-                                     float* __restrict__ part, long long rows, int dim, int n_symbols) {
+// One workgroup per (symbol, 256-column slab): deterministic ascending row order, no atomics.  Rows are taken in
+// chunks of EMB_CHUNK: the workgroup first compacts the chunk's matching row numbers into LDS (ballot + prefix, so
+// the list is ascending), then sums those rows eight at a time with the loads issued first.  (The previous form
+// tested every row inside the accumulation loop: a conditional load per row, 390 us for 11 k rows.)
+#define EMB_CHUNK 4096
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout,
+                                                            float* __restrict__ dtable, long long rows, int dim) {
     const int sym = blockIdx.x;
     const int c = blockIdx.y * 256 + threadIdx.x;
-    const int chunk = blockIdx.z;
-    const long long per = (rows + EMB_SPLIT - 1) / EMB_SPLIT;
-    const long long rbeg = chunk * per;
-    long long rend = rbeg + per;
-    if (rend > rows) rend = rows;
-    __shared__ long long idbuf[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int list[EMB_CHUNK];
+    __shared__ int wcount[4];
+    __shared__ int total;
     float acc = 0.f;
-    for (long long r0 = rbeg; r0 < rend; r0 += 256) {
-        const long long r = r0 + threadIdx.x;
-        idbuf[threadIdx.x] = (r < rend) ? ids[r] : -1;
+    for (long long r0 = 0; r0 < rows; r0 += EMB_CHUNK) {
+        if (threadIdx.x == 0) total = 0;
         __syncthreads();
-        const int lim = (rend - r0 < 256) ? (int)(rend - r0) : 256;
-        if (c < dim)
-            for (int k = 0; k < lim; ++k)
-                if (idbuf[k] == sym) acc += dout[(r0 + k) * dim + c];
+        const int lim = (rows - r0 < EMB_CHUNK) ? (int)(rows - r0) : EMB_CHUNK;
+        for (int base = 0; base < lim; base += 256) {
+            const int k = base + threadIdx.x;
+            const bool hit = (k < lim) && (ids[r0 + k] == sym);
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wcount[wave] = __popcll(m);
+            __syncthreads();
+            int off = total;
+            for (int w = 0; w < wave; ++w) off += wcount[w];
+            if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            __syncthreads();
+            if (threadIdx.x == 0) total += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+            __syncthreads();
+        }
+        const int n = total;
+        if (c < dim) {
+            const float* __restrict__ src = dout + r0 * dim + c;
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = src[(long long)list[k + j] * dim];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += v[j];
+            }
+            for (; k < n; ++k) acc += src[(long long)list[k] * dim];
+        }
         __syncthreads();
     }
-    if (c < dim) part[((long long)chunk * n_symbols + sym) * dim + c] = acc;
-}
-
-__global__ void embedding_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dtable, long long n) {
-    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < EMB_SPLIT; ++k) s += part[(long long)k * n + i];
-    dtable[i] = s;
+    if (c < dim) dtable[(long long)sym * dim + c] = acc;
 }
 
 extern "C" int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, float* ws,
                                        long long rows, int dim, int n_symbols, void* stream) {
-    T2_REQUIRE(ids && dout && dtable && ws && rows > 0 && dim > 0 && n_symbols > 0, "embedding_bwd: bad args");
-    T2_LAUNCH(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256), EMB_SPLIT), dim3(256), 0, (hipStream_t)stream,
-              ids, dout, ws, rows, dim, n_symbols);
-    const long long n = (long long)n_symbols * dim;
-    T2_LAUNCH(embedding_bwd_reduce_kernel, dim3(t2_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, ws, dtable, n);
+    T2_REQUIRE(ids && dout && dtable && rows > 0 && dim > 0 && n_symbols > 0, "embedding_bwd: bad args");
+    (void)ws;      // kept in the signature: earlier versions needed a partial-sum workspace
+    T2_LAUNCH(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream,
+              ids, dout, dtable, rows, dim);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -547,12 +547,8 @@ def embedding_fwd(ids, table, out):
 def embedding_bwd(ids, dout, dtable, ws=None):
     lib = load()
     rows = ids.numel()
-    if ws is None:
-        ws = torch.empty(8 * dtable.numel(), dtype=torch.float32, device=dtable.device)
-    if ws.numel() < 8 * dtable.numel():
-        raise NativeError("embedding_bwd: workspace too small")
     _check(lib.t2amd_embedding_bwd_f32(ptr(_fullc(ids), torch.int64), ptr(_fullc(dout)), ptr(_fullc(dtable)),
-                                       ptr(_fullc(ws)), _i64(rows), dtable.shape[1], dtable.shape[0], _stream()),
+                                       None, _i64(rows), dtable.shape[1], dtable.shape[0], _stream()),
            "t2amd_embedding_bwd_f32")
 
 
