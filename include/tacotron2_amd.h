@@ -341,6 +341,9 @@ typedef struct t2amd_attn_fwd {
      * Uh.Wh + Uh.Wl + Ul.Wh on v_mfma_f32_16x16x32_bf16, f32 accumulate: ~2^-17 relative per product) -- the
      * engine's bf16 compute mode.  0: exact-f32 MFMA (parity mode). */
     int loc_split_bf16;
+    /* optional bf16 copy of `memory` ([B][Ti][E] bf16): the context product then streams it instead of the f32 rows
+     * (the kernel is bound by the bytes of those rows); weights, accumulation and the context stay f32. */
+    const void* memory16;
 } t2amd_attn_fwd;
 
 int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
@@ -386,6 +389,8 @@ typedef struct t2amd_attn_bwd {
      * 0: exact-f32 MFMA.  The recompute of the location conv uses the forward's split-bf16 form (see
      * t2amd_attn_fwd.loc_split_bf16) when this is 1, the exact-f32 MFMA otherwise. */
     int bf16;
+    /* optional bf16 copy of `memory`: dw = dctx . memory streams it instead of the f32 rows */
+    const void* memory16;
 } t2amd_attn_bwd;
 
 int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);
@@ -433,6 +438,7 @@ typedef struct t2amd_dec_train {
     void* HA16;            /* [To][B][Ha] bf16 */
     void* HD16;            /* [To][B][Hd] bf16 */
     void* CTX16;           /* [To][B][E] bf16 */
+    const void* memory16;  /* [B][Ti][E] bf16 copy of memory, or NULL: attention context / its backward stream it */
 } t2amd_dec_train;
 
 int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream);

@@ -322,8 +322,13 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
 // K_c: softmax over the utterance + one quarter of the context channels
 // ---------------------------------------------------------------------------------------
 #define KC_NT 512
-#define KC_MAXR 12      // memory rows a thread keeps in registers; longer utterances take extra passes
+// M16: the context rows come from a bf16 copy of the encoder memory (t2amd_attn_fwd.memory16, the engine's bf16
+// compute mode): a thread then owns 8 channels (one 16-byte load per row) of twice as many row groups, i.e. half
+// the bytes of the f32 stream this kernel is bound by; weights, accumulation and the context stay f32.
+template <bool M16>
 __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
+    constexpr int CPT = M16 ? 8 : 4;          // channels per thread
+    constexpr int KC_MAXR = M16 ? 6 : 12;     // memory rows a thread keeps in registers; longer utterances take extra passes
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const t2amd_attn_fwd& a = p.a;
     const int cs = blockIdx.x, b = blockIdx.y;
@@ -341,12 +346,14 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
 
     // Row offsets of this thread's share of memory[b], computed before any load is issued (address arithmetic placed
     // between loads can falsely depend on a pending destination register and drain the queue).
-    const int EC = E / NCS, EC4 = EC >> 2, E4 = E >> 2;
+    // (EC4 / E4 count 16-byte units: 4 floats, or 8 bf16 in the M16 form)
+    const int EC = E / NCS, EC4 = EC / CPT, E4 = E / CPT;
     int parts = KC_NT / EC4;
     if (parts > 32) parts = 32;
     const int c4 = tid % EC4, part = tid / EC4;
     const bool worker = part < parts;
-    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4 + cs * EC4 + c4;
+    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(M16 ? a.memory16 : (const void*)a.memory) +
+                                    (long long)b * Ti * E4 + cs * EC4 + c4;
     long long roff[KC_MAXR];
 #pragma unroll
     for (int i = 0; i < KC_MAXR; ++i) roff[i] = (long long)(part + i * parts) * E4;
@@ -426,20 +433,34 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     T2_TS(19);
     // context channels [cs*EC, (cs+1)*EC)
     if (worker) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float acc[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+        auto fma_row = [&](const float4& m, float w) {
+            if constexpr (M16) {
+                const unsigned u[4] = {__float_as_uint(m.x), __float_as_uint(m.y), __float_as_uint(m.z), __float_as_uint(m.w)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] = fmaf(w, __uint_as_float(u[j] << 16), acc[2 * j]);
+                    acc[2 * j + 1] = fmaf(w, __uint_as_float(u[j] & 0xffff0000u), acc[2 * j + 1]);
+                }
+            } else {
+                acc[0] = fmaf(w, m.x, acc[0]); acc[1] = fmaf(w, m.y, acc[1]);
+                acc[2] = fmaf(w, m.z, acc[2]); acc[3] = fmaf(w, m.w, acc[3]);
+            }
+        };
 #pragma unroll
         for (int i = 0; i < KC_MAXR; ++i) {
             const int ti = part + i * parts;
-            const float w = ti < len ? w_s[ti] : 0.f;
-            acc.x = fmaf(w, mrow[i].x, acc.x); acc.y = fmaf(w, mrow[i].y, acc.y);
-            acc.z = fmaf(w, mrow[i].z, acc.z); acc.w = fmaf(w, mrow[i].w, acc.w);
+            fma_row(mrow[i], ti < len ? w_s[ti] : 0.f);
         }
         for (int ti = part + KC_MAXR * parts; ti < len; ti += parts) {      // utterances longer than MAXR*parts
             const float4 m = M4[(long long)ti * E4];
-            const float w = w_s[ti];
-            acc.x = fmaf(w, m.x, acc.x); acc.y = fmaf(w, m.y, acc.y); acc.z = fmaf(w, m.z, acc.z); acc.w = fmaf(w, m.w, acc.w);
+            fma_row(m, w_s[ti]);
         }
-        *reinterpret_cast<float4*>(&part_s[part * EC + c4 * 4]) = acc;
+#pragma unroll
+        for (int j = 0; j < CPT; j += 4)
+            *reinterpret_cast<float4*>(&part_s[part * EC + c4 * CPT + j]) = make_float4(acc[j], acc[j + 1], acc[j + 2], acc[j + 3]);
     }
     __syncthreads();
     T2_TS(20);
@@ -469,13 +490,15 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP + (size_t)a->Hq);
     const int EC = a->E / NCS;
-    int parts = KC_NT / (EC / 4);
+    T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && EC % 8 == 0), "attn_fwd: memory16 must be 16-byte aligned, E a multiple of 32");
+    int parts = KC_NT / (EC / (a->memory16 ? 8 : 4));
     if (parts > 32) parts = 32;
     T2_REQUIRE(parts >= 1, "attn_fwd: E too large");
     const size_t lds_c = sizeof(float) * ((size_t)((a->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
     T2_REQUIRE(lds_e <= 64 * 1024 && lds_c <= 64 * 1024, "attn_fwd: Ti too large for the LDS windows");
     T2_LAUNCH(attn_energy_kernel, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
-    T2_LAUNCH(attn_context_kernel, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
+    if (a->memory16) T2_LAUNCH(attn_context_kernel<true>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
+    else T2_LAUNCH(attn_context_kernel<false>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
@@ -485,13 +508,31 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // =========================================================================================
 struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; };
 
+// acc + sum of 8 bf16 values (packed in the 16 bytes of m, ascending channel order) times 8 floats (g0, g1)
+__device__ __forceinline__ float dot8_bf16(const float4& m, const float4& g0, const float4& g1, float acc) {
+    const unsigned u0 = __float_as_uint(m.x), u1 = __float_as_uint(m.y), u2 = __float_as_uint(m.z), u3 = __float_as_uint(m.w);
+    acc = fmaf(__uint_as_float(u0 << 16), g0.x, acc);
+    acc = fmaf(__uint_as_float(u0 & 0xffff0000u), g0.y, acc);
+    acc = fmaf(__uint_as_float(u1 << 16), g0.z, acc);
+    acc = fmaf(__uint_as_float(u1 & 0xffff0000u), g0.w, acc);
+    acc = fmaf(__uint_as_float(u2 << 16), g1.x, acc);
+    acc = fmaf(__uint_as_float(u2 & 0xffff0000u), g1.y, acc);
+    acc = fmaf(__uint_as_float(u3 << 16), g1.z, acc);
+    acc = fmaf(__uint_as_float(u3 & 0xffff0000u), g1.w, acc);
+    return acc;
+}
+
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
 // Half a wave (32 lanes) per memory row, 8 rows per pass.  One L2 round trip: the memory rows of the first 64
 // positions of the slice (all four column groups: 32 float4 per lane), the gradient slabs and the carry partials
 // are all issued before anything is consumed; nothing is compared or selected on a loaded value before that.
 #define KB1_MAXP 8      // passes kept in registers: 8 rows x 8 passes = 64 positions per slice (Ti <= 256)
-#define KB1_MAXC 4      // column groups kept in registers: 4 x 32 float4 = E <= 512
+// M16: rows come from the bf16 copy of the encoder memory (t2amd_attn_bwd.memory16): one 16-byte load is 8 channels,
+// so two column groups cover E <= 512 and the kernel moves half the bytes it is bound by; dctx and the sums stay f32.
+template <bool M16>
 __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
+    constexpr int CPT = M16 ? 8 : 4;           // channels per 16-byte load
+    constexpr int KB1_MAXC = M16 ? 2 : 4;      // column groups kept in registers: KB1_MAXC x 32 loads = E <= 512
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const t2amd_attn_bwd& a = p.a;
     const int ts = blockIdx.x, b = blockIdx.y;
@@ -508,8 +549,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     int t1 = t0 + tsz;
     if (t1 > Ti) t1 = Ti;
 
-    const int E4 = E >> 2;
-    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(a.memory) + (long long)b * Ti * E4;
+    const int E4 = E / CPT;                        // 16-byte units per row
+    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(M16 ? a.memory16 : (const void*)a.memory) +
+                                    (long long)b * Ti * E4;
     const int grp = tid >> 5, l32 = tid & 31;      // 8 row groups of 32 lanes
     const int npass = (tsz + 7) >> 3;              // passes that hold positions of this slice
     float4 pm[KB1_MAXC][KB1_MAXP];
@@ -638,28 +680,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
             for (int g = 0; g < KB1_MAXC; ++g) {
                 const int c = l32 + 32 * g;
                 if (c < E4) {
-                    const float4 gq = *reinterpret_cast<const float4*>(&dctx_s[c * 4]);
+                    if constexpr (M16) {
+                        const float4 g0 = *reinterpret_cast<const float4*>(&dctx_s[c * 8]);
+                        const float4 g1 = *reinterpret_cast<const float4*>(&dctx_s[c * 8 + 4]);
 #pragma unroll
-                    for (int i = 0; i < KB1_MAXP; ++i) {
-                        acc[i] = fmaf(pm[g][i].x, gq.x, acc[i]);
-                        acc[i] = fmaf(pm[g][i].y, gq.y, acc[i]);
-                        acc[i] = fmaf(pm[g][i].z, gq.z, acc[i]);
-                        acc[i] = fmaf(pm[g][i].w, gq.w, acc[i]);
+                        for (int i = 0; i < KB1_MAXP; ++i) acc[i] = dot8_bf16(pm[g][i], g0, g1, acc[i]);
+                    } else {
+                        const float4 gq = *reinterpret_cast<const float4*>(&dctx_s[c * 4]);
+#pragma unroll
+                        for (int i = 0; i < KB1_MAXP; ++i) {
+                            acc[i] = fmaf(pm[g][i].x, gq.x, acc[i]);
+                            acc[i] = fmaf(pm[g][i].y, gq.y, acc[i]);
+                            acc[i] = fmaf(pm[g][i].z, gq.z, acc[i]);
+                            acc[i] = fmaf(pm[g][i].w, gq.w, acc[i]);
+                        }
                     }
                 }
             }
         }
         // column groups / positions beyond the register-resident block (E > 512 or Ti > 256)
         for (int c = l32 + (r0 == 0 ? 32 * KB1_MAXC : 0); c < E4; c += 32) {
-            const float4 gq = *reinterpret_cast<const float4*>(&dctx_s[c * 4]);
+            const float4 gq = *reinterpret_cast<const float4*>(&dctx_s[c * CPT]);
+            float4 gq1 = gq;
+            if constexpr (M16) gq1 = *reinterpret_cast<const float4*>(&dctx_s[c * CPT + 4]);
 #pragma unroll
             for (int i = 0; i < KB1_MAXP; ++i) {
                 const int ti = t0 + r0 + grp + 8 * i;
                 const float4 m = M4[(long long)(ti < t1 ? ti : t0) * E4 + c];
-                acc[i] = fmaf(m.x, gq.x, acc[i]);
-                acc[i] = fmaf(m.y, gq.y, acc[i]);
-                acc[i] = fmaf(m.z, gq.z, acc[i]);
-                acc[i] = fmaf(m.w, gq.w, acc[i]);
+                if constexpr (M16) {
+                    acc[i] = dot8_bf16(m, gq, gq1, acc[i]);
+                } else {
+                    acc[i] = fmaf(m.x, gq.x, acc[i]);
+                    acc[i] = fmaf(m.y, gq.y, acc[i]);
+                    acc[i] = fmaf(m.z, gq.z, acc[i]);
+                    acc[i] = fmaf(m.w, gq.w, acc[i]);
+                }
             }
         }
 #pragma unroll
@@ -1055,7 +1110,9 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         g_attn_bwd_lds = (int)lds2;
     }
-    T2_LAUNCH(attn_bwd_dw_kernel, dim3(NTS, a->B), dim3(256), lds1, s, p);
+    T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && a->E % 8 == 0), "attn_bwd: memory16 must be 16-byte aligned, E a multiple of 8");
+    if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(256), lds1, s, p);
+    else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(256), lds1, s, p);
     T2_LAUNCH(attn_bwd_main_kernel, dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -1089,8 +1146,17 @@ __global__ void unfold_location_kernel(const float* __restrict__ dU_acc, const f
     // single workgroup: first reduce dU over utterances, then the two small products
     const int tid = threadIdx.x;
     for (int i = tid; i < AD * NTAP; i += blockDim.x) {
+        // utterances eight at a time, loads first (a plain loop is one waited load per utterance); same add order
         float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += dU_acc[(long long)b * AD * NTAP + i];
+        int b = 0;
+        for (; b + 8 <= nb; b += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dU_acc[(long long)(b + j) * AD * NTAP + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; b < nb; ++b) s += dU_acc[(long long)b * AD * NTAP + i];
         dUsum[i] = s;
     }
     for (int i = tid; i < AD; i += blockDim.x) {

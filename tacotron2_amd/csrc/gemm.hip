@@ -412,8 +412,15 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int nsplit,
                                      int taps, int ci_dim) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
+        // slabs four at a time, loads first (same add order as the plain loop, which waits for every slab in turn)
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += part[(long long)k * stride + i];
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {
+            const float v0 = part[(long long)k * stride + i], v1 = part[(long long)(k + 1) * stride + i];
+            const float v2 = part[(long long)(k + 2) * stride + i], v3 = part[(long long)(k + 3) * stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < nsplit; ++k) s += part[(long long)k * stride + i];
         long long o = i;
         if (taps > 0) {
             const long long per_co = (long long)taps * ci_dim;

@@ -142,7 +142,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)To * Ti;
         at.ctx_out = p->CTX + t * sE; at.ld_ctx = E;
         at.q_out = p->Q + (long long)t * B * T2AMD_ATT_DIM; at.ld_q = T2AMD_ATT_DIM;
-        if (p->bf16) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; at.loc_split_bf16 = 1; }
+        if (p->bf16) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; at.loc_split_bf16 = 1; at.memory16 = p->memory16; }
         return t2amd_attention_step_fwd_f32(&at, st);
     };
 
@@ -265,6 +265,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;
         ab.bf16 = f.bf16 ? 1 : 0;
+        ab.memory16 = f.bf16 ? f.memory16 : nullptr;
         return t2amd_attention_step_bwd_f32(&ab, st);
     };
     auto cell_a = [&](int t, t2amd_lstm_bwd& la) {

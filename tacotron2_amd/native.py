@@ -108,6 +108,7 @@ class AttnFwd(C.Structure):
         ("ws", _f32p),
         ("ctx16_out", C.c_void_p), ("ld_ctx16", _i64),
         ("loc_split_bf16", C.c_int),
+        ("memory16", C.c_void_p),
     ]
 
 
@@ -129,6 +130,7 @@ class AttnBwd(C.Structure):
         ("dh_out", _f32p), ("ld_dh", _i64), ("dh_split_stride", _i64),
         ("ws", _f32p),
         ("bf16", C.c_int),
+        ("memory16", C.c_void_p),
     ]
 
 
@@ -143,6 +145,7 @@ class DecTrain(C.Structure):
         ("Q", _f32p), ("ALIGN", _f32p), ("CUM", _f32p), ("cum_work", _f32p), ("attn_ws", _f32p),
         ("bf16", C.c_int), ("Wa_rec16", C.c_void_p), ("Wd_cat16", C.c_void_p),
         ("HA16", C.c_void_p), ("HD16", C.c_void_p), ("CTX16", C.c_void_p),
+        ("memory16", C.c_void_p),
     ]
 
 
@@ -765,7 +768,7 @@ def attn_bwd_ws_floats(B, Ti):
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,
-                       bf16=False):
+                       bf16=False, memory16=None):
     lib = load()
     a = AttnFwd()
     B, Ti, E = memory.shape
@@ -786,11 +789,13 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
         raise NativeError("attention_step_fwd: workspace too small")
     a.ws = ptr(_fullc(ws))
     a.loc_split_bf16 = 1 if bf16 else 0
+    if memory16 is not None:
+        a.memory16 = ptr(_fullc(memory16), torch.bfloat16)
     _check(lib.t2amd_attention_step_fwd_f32(C.byref(a), _stream()), "t2amd_attention_step_fwd_f32")
 
 
 def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory, lens, w, w_prev, cum_before,
-                       dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws, bf16=False):
+                       dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws, bf16=False, memory16=None):
     """dwin_part: (ATT_SLICES, B, 2, Ti) in/out; dcum_acc: (B, Ti) in/out; dh_parts: (ATT_SLICES, B, Hq) out."""
     lib = load()
     a = AttnBwd()
@@ -818,6 +823,8 @@ def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory
         raise NativeError("attention_step_bwd: workspace too small")
     a.ws = ptr(_fullc(ws))
     a.bf16 = 1 if bf16 else 0
+    if memory16 is not None:
+        a.memory16 = ptr(_fullc(memory16), torch.bfloat16)
     _check(lib.t2amd_attention_step_bwd_f32(C.byref(a), _stream()), "t2amd_attention_step_bwd_f32")
 
 

@@ -11,6 +11,18 @@ for blocks in (1, 256, 512, 1024):
     e0.record(); f(x.data_ptr(), 2000, blocks, nv._stream()); e1.record(); torch.cuda.synchronize()
     print("blocks %4d: %.2f us per dependent trivial launch" % (blocks, e0.elapsed_time(e1) / 2000 * 1e3))
 
+# the same chain on a non-default stream (torch's current stream is the legacy default stream unless the caller
+# switches): does the null stream cost extra per launch?
+side0 = torch.cuda.Stream()
+sp0 = C.c_void_p(side0.cuda_stream)
+for blocks in (1, 256):
+    f(x.data_ptr(), 100, blocks, sp0); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side0):
+        e0.record(); f(x.data_ptr(), 2000, blocks, sp0); e1.record()
+    torch.cuda.synchronize()
+    print("side stream, blocks %4d: %.2f us per dependent trivial launch" % (blocks, e0.elapsed_time(e1) / 2000 * 1e3))
+
 g = lib.t2amd_debug_graph_chain_
 g.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
 g.restype = C.c_float
