@@ -143,7 +143,7 @@ int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, double* ws, fl
  * ------------------------------------------------------------------------------------ */
 int t2amd_embedding_fwd_f32(const long long* ids, const float* table, float* out, long long rows,
                             int dim, int n_symbols, void* stream);
-/* dtable[s] = sum of the dout rows whose id is s, in ascending row order (no atomics).  ws is unused (may be
+/* dtable[s] = sum of the dout rows whose id is s, in a fixed order (eight interleaved row lanes, no atomics).  ws is unused (may be
  * NULL); it stays in the signature for callers built against the earlier partial-sum version. */
 int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, float* ws, long long rows,
                             int dim, int n_symbols, void* stream);

@@ -292,19 +292,24 @@ extern "C" int t2amd_embedding_fwd_f32(const long long* ids, const float* table,
     return T2AMD_OK;
 }
 
-// One workgroup per (symbol, 256-column slab): deterministic ascending row order, no atomics.  Rows are taken in
-// chunks of EMB_CHUNK: the workgroup first compacts the chunk's matching row numbers into LDS (ballot + prefix, so
-// the list is ascending), then sums those rows eight at a time with the loads issued first.  (The previous form
-// tested every row inside the accumulation loop: a conditional load per row, 390 us for 11 k rows.)
+// One workgroup per (symbol, 32-column slab): no atomics, fixed summation order.  Rows are taken in chunks of
+// EMB_CHUNK: the workgroup first compacts the chunk's matching row numbers into LDS (ballot + prefix, ascending),
+// then eight row lanes x 32 columns sum them -- lane l takes list entries l, l+8, ... four at a time with the loads
+// issued first -- and the eight lane sums are added in lane order.  (The first version tested every row inside the
+// accumulation loop, 390 us for 11 k rows; a single accumulation chain per column still took 300 us because the
+// padding symbol owns ~40 % of the rows.)
 #define EMB_CHUNK 4096
+#define EMB_COLS 32
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const float* __restrict__ dout,
                                                             float* __restrict__ dtable, long long rows, int dim) {
     const int sym = blockIdx.x;
-    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int cl = threadIdx.x & (EMB_COLS - 1), rl = threadIdx.x / EMB_COLS;      // column in slab, row lane 0..7
+    const int c = blockIdx.y * EMB_COLS + cl;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ int list[EMB_CHUNK];
     __shared__ int wcount[4];
     __shared__ int total;
+    __shared__ float lsum[8][EMB_COLS];
     float acc = 0.f;
     for (long long r0 = 0; r0 < rows; r0 += EMB_CHUNK) {
         if (threadIdx.x == 0) total = 0;
@@ -326,26 +331,31 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __r
         const int n = total;
         if (c < dim) {
             const float* __restrict__ src = dout + r0 * dim + c;
-            int k = 0;
-            for (; k + 8 <= n; k += 8) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[(long long)list[k + j] * dim];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc += v[j];
+            int k = rl;
+            for (; k + 24 < n; k += 32) {
+                const float v0 = src[(long long)list[k] * dim], v1 = src[(long long)list[k + 8] * dim];
+                const float v2 = src[(long long)list[k + 16] * dim], v3 = src[(long long)list[k + 24] * dim];
+                acc += v0; acc += v1; acc += v2; acc += v3;
             }
-            for (; k < n; ++k) acc += src[(long long)list[k] * dim];
+            for (; k < n; k += 8) acc += src[(long long)list[k] * dim];
         }
         __syncthreads();
     }
-    if (c < dim) dtable[(long long)sym * dim + c] = acc;
+    lsum[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && c < dim) {
+        float s = lsum[0][cl];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) s += lsum[l][cl];
+        dtable[(long long)sym * dim + c] = s;
+    }
 }
 
 extern "C" int t2amd_embedding_bwd_f32(const long long* ids, const float* dout, float* dtable, float* ws,
                                        long long rows, int dim, int n_symbols, void* stream) {
     T2_REQUIRE(ids && dout && dtable && rows > 0 && dim > 0 && n_symbols > 0, "embedding_bwd: bad args");
     (void)ws;      // kept in the signature: earlier versions needed a partial-sum workspace
-    T2_LAUNCH(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, 256)), dim3(256), 0, (hipStream_t)stream,
+    T2_LAUNCH(embedding_bwd_kernel, dim3(n_symbols, t2_cdiv(dim, EMB_COLS)), dim3(256), 0, (hipStream_t)stream,
               ids, dout, dtable, rows, dim);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
