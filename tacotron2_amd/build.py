@@ -25,7 +25,19 @@ def up_to_date():
     return all(os.path.getmtime(f) <= t for f in DEPS if os.path.exists(f))
 
 
-def build(force=False, verbose=True):
+STAMPS_OUT = os.path.join(HERE, "lib", "libtacotron2_amd_stamps.so")
+
+
+def build(force=False, verbose=True, stamps=False):
+    """stamps=True builds the instrumented variant (in-kernel phase stamps, tools only) next to the product library;
+    select it with T2AMD_LIB=<path> T2AMD_ATTN_TS=1."""
+    if stamps:
+        os.makedirs(os.path.dirname(STAMPS_OUT), exist_ok=True)
+        cmd = [HIPCC] + FLAGS + ["-DT2AMD_PHASE_STAMPS", "-o", STAMPS_OUT] + SRC
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return STAMPS_OUT
     if not force and up_to_date():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
@@ -37,5 +49,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    if "--stamps" in sys.argv:
+        print(build(stamps=True))
+    else:
+        build(force="--force" in sys.argv)
+        print(OUT)

@@ -188,7 +188,12 @@ extern "C" unsigned long long* t2amd_debug_ts_() {
         init = 1;
         const char* e = getenv("T2AMD_ATTN_TS");
         if (e && e[0] == '1' && hipMalloc((void**)&g_dbg_ts, 128 * sizeof(unsigned long long)) != hipSuccess) g_dbg_ts = nullptr;
-        if (g_dbg_ts) (void)hipMemset(g_dbg_ts, 0, 128 * sizeof(unsigned long long));
+        if (g_dbg_ts) {
+            (void)hipMemset(g_dbg_ts, 0, 128 * sizeof(unsigned long long));
+            const char* pk = getenv("T2AMD_ATTN_TS_PICK");
+            const unsigned long long pick = pk ? strtoull(pk, nullptr, 10) : 1200ull;
+            (void)hipMemcpy(g_dbg_ts + 127, &pick, sizeof(pick), hipMemcpyHostToDevice);
+        }
     }
     return g_dbg_ts;
 }

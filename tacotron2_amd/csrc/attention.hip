@@ -166,10 +166,15 @@ struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; unsigned long long* t
 // (0,0) of every attention kernel stamps the 100 MHz wall clock at its phase boundaries into a 64-entry device buffer
 // (slots 0-15 K_e, 16-31 K_c, 32-47 K_b1, 48-63 K_b2; api.hip owns the buffer), read back with t2amd_debug_attn_ts_.
 static unsigned long long* attn_ts_buffer() { return t2amd_debug_ts_(); }
-#define T2_TS(slot)                                                                                      \
-    do {                                                                                                 \
-        if (p.ts && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.ts[slot] = wall_clock64(); \
+#ifdef T2AMD_PHASE_STAMPS
+#define T2_TS(slot)                                                                        \
+    do {                                                                                   \
+        if (((slot) & 15) == 0) ts_on = t2_ts_begin(p.ts, (slot));                         \
+        else t2_ts_mark(ts_on, p.ts, (slot));                                              \
     } while (0)
+#else
+#define T2_TS(slot) do { (void)ts_on; } while (0)
+#endif
 
 static int attn_dbg_stage() {
     static int v = -2;
@@ -183,6 +188,7 @@ static int attn_dbg_stage() {
 #define KE_NT 512
 __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool ts_on = false;
     const t2amd_attn_fwd& a = p.a;
     const int ds = blockIdx.x, b = blockIdx.y;
     if (a.active && !a.active[b]) return;
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     constexpr int CPT = M16 ? 8 : 4;          // channels per thread
     constexpr int KC_MAXR = M16 ? 6 : 12;     // memory rows a thread keeps in registers; longer utterances take extra passes
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool ts_on = false;
     const t2amd_attn_fwd& a = p.a;
     const int cs = blockIdx.x, b = blockIdx.y;
     if (a.active && !a.active[b]) return;
@@ -534,6 +541,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     constexpr int CPT = M16 ? 8 : 4;           // channels per 16-byte load
     constexpr int KB1_MAXC = M16 ? 2 : 4;      // column groups kept in registers: KB1_MAXC x 32 loads = E <= 512
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool ts_on = false;
     const t2amd_attn_bwd& a = p.a;
     const int ts = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -744,6 +752,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
 #define KB2_NW (KB2_NT / 64)
 __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool ts_on = false;
     const t2amd_attn_bwd& a = p.a;
     const int ds = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -69,6 +69,10 @@ __device__ __forceinline__ unsigned t2_cvt_pk_bf16(float a, float b) {
 }
 
 __device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on v_exp_f32 / v_rcp_f32 (|err| ~1e-7): the bf16-mode kernels' cell; the parity-mode kernels keep libm's
+__device__ __forceinline__ float t2_sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 // tanh without divergent paths (libm's tanhf is two exec-masked branches, both taken by a mixed wave).
 // |x| < 0.625: x + x*x2*P(x2), the minimax polynomial libm uses on that range; otherwise 1 - 2/(exp(2|x|) + 1) on
 // v_exp_f32 / v_rcp_f32 (absolute error < 5e-7).  Both are evaluated and one is selected.
@@ -117,6 +121,24 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
+}
+
+
+// tools only: phase stamps of ONE mid-loop launch per instrumented kernel.  Compiled in only with
+// -DT2AMD_PHASE_STAMPS (python -m tacotron2_amd.build --stamps -> lib/libtacotron2_amd_stamps.so, selected with
+// T2AMD_LIB) -- even a never-taken stamp branch in the chain kernels costs ~2 % of a training step.  With
+// T2AMD_ATTN_TS=1, thread 0 of workgroup 0 counts the launches of its kernel in slot base+15 and stamps only the launch
+// whose number is in slot 127 (T2AMD_ATTN_TS_PICK, default 1200 = second training step, mid sequence), so that
+// tools/phase_stamps_step.py sees a warm, regular step rather than the last (special) one.
+__device__ __forceinline__ bool t2_ts_begin(unsigned long long* ts, int base) {
+    if (!ts || blockIdx.x != 0 || blockIdx.y != 0 || threadIdx.x != 0) return false;
+    const unsigned long long n = atomicAdd(&ts[base + 15], 1ull);
+    if (n != ts[127]) return false;
+    ts[base] = wall_clock64();
+    return true;
+}
+__device__ __forceinline__ void t2_ts_mark(bool on, unsigned long long* ts, int slot) {
+    if (on) ts[slot] = wall_clock64();
 }
 
 // internal entry points shared between translation units (not part of the C ABI)

@@ -315,9 +315,19 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __r
         if (threadIdx.x == 0) total = 0;
         __syncthreads();
         const int lim = (rows - r0 < EMB_CHUNK) ? (int)(rows - r0) : EMB_CHUNK;
-        for (int base = 0; base < lim; base += 256) {
+        // this thread's 16 ids of the chunk, all loads issued before the compaction loop consumes them
+        long long myid[EMB_CHUNK / 256];
+#pragma unroll
+        for (int j = 0; j < EMB_CHUNK / 256; ++j) {
+            const int k = j * 256 + threadIdx.x;
+            myid[j] = ids[r0 + (k < lim ? k : 0)];
+        }
+#pragma unroll
+        for (int j = 0; j < EMB_CHUNK / 256; ++j) {
+            const int base = j * 256;
+            if (base >= lim) break;
             const int k = base + threadIdx.x;
-            const bool hit = (k < lim) && (ids[r0 + k] == sym);
+            const bool hit = (k < lim) && (myid[j] == sym);
             const unsigned long long m = __ballot(hit);
             if (lane == 0) wcount[wave] = __popcll(m);
             __syncthreads();

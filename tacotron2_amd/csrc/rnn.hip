@@ -413,13 +413,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
 #define SW_XB (64 * 256)    // bytes per activation tile
 #define SW_WB (32 * 256)    // bytes per weight tile
 
-#define SW_TS(slot)                                                                                              \
-    do {                                                                                                         \
-        if (dp.ts && blockIdx.x == 0 && threadIdx.x == 0) dp.ts[(LSTM ? 64 : 80) + (slot)] = wall_clock64();     \
+#ifdef T2AMD_PHASE_STAMPS
+#define SW_TS(slot)                                                                        \
+    do {                                                                                   \
+        if ((slot) == 0) ts_on = t2_ts_begin(dp.ts, LSTM ? 64 : 80);                       \
+        else t2_ts_mark(ts_on, dp.ts, (LSTM ? 64 : 80) + (slot));                          \
     } while (0)
+#else
+#define SW_TS(slot) do { (void)ts_on; } while (0)
+#endif
 template <bool LSTM, int TAG>
 __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     constexpr int BK = 128;
+    bool ts_on = false;
     SW_TS(0);
     __shared__ __attribute__((aligned(16))) char smem[SW_NBUF * (SW_XB + SW_WB)];
     char* const Xs = smem;                       // [NBUF][64][256 B]
@@ -689,12 +695,12 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
             pre[q] = ((Ps[erow * 33 + c] + Ps[(64 + erow) * 33 + c]) + (Ps[(128 + erow) * 33 + c] + Ps[(192 + erow) * 33 + c]))
                      + e_gin[q] + e_bias[q];
         }
-        gi = t2_sigmoid(pre[0]);
-        gf = t2_sigmoid(pre[1]);
-        gg = tanhf(pre[2]);
-        go = t2_sigmoid(pre[3]);
+        gi = t2_sigmoid_fast(pre[0]);
+        gf = t2_sigmoid_fast(pre[1]);
+        gg = t2_tanh(pre[2]);
+        go = t2_sigmoid_fast(pre[3]);
         cn = gf * e_cp + gi * gg;
-        hn = go * tanhf(cn);
+        hn = go * t2_tanh(cn);
         if (p.keep) hn = e_keep ? hn * p.keep_scale : 0.f;
     }
     float* go_ = p.gates_out + (long long)egr * p.ld_gates;
@@ -862,7 +868,7 @@ extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
 // LSTM cell backward (pointwise part): given dL/dh' (dropped-out hidden) and the carried
 // dL/dc, produce the gate pre-activation gradients and the new dL/dc carry.
 // ---------------------------------------------------------------------------------------
-struct LstmBwdParams { t2amd_lstm_bwd a[2]; int nblk0; };
+struct LstmBwdParams { t2amd_lstm_bwd a[2]; int nblk0; unsigned long long* ts; };
 
 // An addend's partial slabs at (row, col..col+3) are added in index order.  Up to four slabs are fetched by
 // independent loads (addend_issue4) and only summed later (addend_finish4), after every other operand load of the
@@ -900,7 +906,18 @@ __device__ __forceinline__ float4 addend_finish4(const Slab4& r, const t2amd_add
 }
 
 // one thread per (row, 4 consecutive units): 16-byte loads/stores; blocks [0, nblk0) serve a[0], the rest a[1]
+#ifdef T2AMD_PHASE_STAMPS
+#define PW_TS(slot)                                                                        \
+    do {                                                                                   \
+        if ((slot) == 0) ts_on = t2_ts_begin(p.ts, 96);                                    \
+        else t2_ts_mark(ts_on, p.ts, 96 + (slot));                                         \
+    } while (0)
+#else
+#define PW_TS(slot) do { (void)ts_on; } while (0)
+#endif
 __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p) {
+    bool ts_on = false;
+    PW_TS(0);
     const bool second = (int)blockIdx.x >= p.nblk0;
     const t2amd_lstm_bwd& a = second ? p.a[1] : p.a[0];
     const int lb = (int)blockIdx.x - (second ? p.nblk0 : 0);
@@ -936,6 +953,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
     if (a.keep) kp = *reinterpret_cast<const unsigned*>(a.keep + (long long)b * a.ld_keep + j);
     const Slab4 s0 = addend_issue4(a.dh[0], b, j), s1 = addend_issue4(a.dh[1], b, j), s2 = addend_issue4(a.dh[2], b, j);
     const float4 d0 = addend_finish4(s0, a.dh[0], b, j), d1 = addend_finish4(s1, a.dh[1], b, j), d2 = addend_finish4(s2, a.dh[2], b, j);
+    PW_TS(1);
     const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
     const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
     const float c_[4] = {c.x, c.y, c.z, c.w}, cp_[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
@@ -969,6 +987,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
 #undef T2_PK4
     }
     *reinterpret_cast<float4*>(dcp) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+    PW_TS(2);
 }
 
 static int check_lstm_bwd(const t2amd_lstm_bwd* a) {
@@ -990,6 +1009,7 @@ static int check_lstm_bwd(const t2amd_lstm_bwd* a) {
 extern "C" int t2amd_lstm_pointwise_bwd2_f32(const t2amd_lstm_bwd* a, const t2amd_lstm_bwd* b, void* stream) {
     T2_PROPAGATE(check_lstm_bwd(a));
     LstmBwdParams p;
+    p.ts = t2amd_debug_ts_();
     p.a[0] = *a;
     p.nblk0 = t2_cdiv((long long)a->B * a->H / 4, 256);
     int total = p.nblk0;

@@ -1,5 +1,8 @@
 """Timing of the attention step launches (tools only).  T2AMD_ATTN_STAGE=n truncates the kernels after stage n."""
 import os, sys, torch
+os.environ.setdefault('T2AMD_ATTN_TS_PICK', '100')
+if os.environ.get('T2AMD_ATTN_TS') == '1':      # stamps exist only in the instrumented build (python -m tacotron2_amd.build --stamps)
+    os.environ.setdefault('T2AMD_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tacotron2_amd', 'lib', 'libtacotron2_amd_stamps.so'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tacotron2_amd import native as nv
 dev = torch.device('cuda')
@@ -69,5 +72,5 @@ if os.environ.get("T2AMD_ATTN_TS") == "1":
     assert rc == 0, rc
     names = {0: "K_e ", 16: "K_c ", 32: "K_b1", 48: "K_b2"}
     for base, nm in names.items():
-        ts = [buf[base + i] for i in range(16) if buf[base + i]]
+        ts = [buf[base + i] for i in range(15) if buf[base + i]]
         print(nm, "phase boundaries (us from kernel entry):", " ".join("%.2f" % ((t - ts[0]) / 100.0) for t in ts))

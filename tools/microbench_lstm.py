@@ -3,6 +3,9 @@
 """
 import ctypes as C
 import os
+os.environ.setdefault('T2AMD_ATTN_TS_PICK', '100')
+if os.environ.get('T2AMD_ATTN_TS') == '1':      # stamps exist only in the instrumented build (python -m tacotron2_amd.build --stamps)
+    os.environ.setdefault('T2AMD_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tacotron2_amd', 'lib', 'libtacotron2_amd_stamps.so'))
 import sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
