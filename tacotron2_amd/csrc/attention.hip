@@ -166,6 +166,13 @@ struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; unsigned long long* t
 // (0,0) of every attention kernel stamps the 100 MHz wall clock at its phase boundaries into a 64-entry device buffer
 // (slots 0-15 K_e, 16-31 K_c, 32-47 K_b1, 48-63 K_b2; api.hip owns the buffer), read back with t2amd_debug_attn_ts_.
 static unsigned long long* attn_ts_buffer() { return t2amd_debug_ts_(); }
+// T2AMD_ATTN_STAGE=n (tools/microbench_attn.py stage ablation) makes the kernels return after stage n: like the phase
+// stamps, compiled in only in the instrumented build -- an early return is a barrier to the compiler's code motion.
+#ifdef T2AMD_PHASE_STAMPS
+#define T2_STAGE_RETURN(n) do { if (p.dbg == (n)) return; } while (0)
+#else
+#define T2_STAGE_RETURN(n) do { } while (0)
+#endif
 #ifdef T2AMD_PHASE_STAMPS
 #define T2_TS(slot)                                                                        \
     do {                                                                                   \
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
     const int nmt = (len + 15) >> 4;
     __syncthreads();
     T2_TS(1);
-    if (p.dbg == 1) return;
+    T2_STAGE_RETURN(1);
     const bool split16 = a.loc_split_bf16 != 0;
     float ua[2][16];
     UFrag16 uf;
@@ -825,7 +832,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     stage_u_finish(ureg, u_s, tid);
     __syncthreads();
     T2_TS(49);
-    if (p.dbg == 1) return;
+    T2_STAGE_RETURN(1);
     float ua[2][16];
     UFrag16 uf;
     if (a.bf16) load_u_frag16(uf, u_s, l15, lg);
@@ -922,7 +929,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         }
     }
     T2_TS(50);
-    if (p.dbg == 2) return;
+    T2_STAGE_RETURN(2);
     // W_q rows of the closing dh product (first 1024 columns): independent of everything above, fetched now so
     // that the round trip hides behind the reductions, the dU product and col2im
     float4 wq_pre[16];
@@ -965,7 +972,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
     }
     T2_TS(51);
-    if (p.dbg == 3) return;
+    T2_STAGE_RETURN(3);
     // dU[d][tap] += sum_pos dpre[pos][d] * win[c(tap)][pos + k(tap)]: wave w owns (tap tile w&3, dim tile w>>2)
     {
         const int tt = wv & 3, dt = wv >> 2;
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         }
     }
     T2_TS(52);
-    if (p.dbg == 4) return;
+    T2_STAGE_RETURN(4);
     // col2im: partial carry dwin[c][ti'] = sum_k dcol[ti' - k + 15][c*31 + k] over this slice's dims
     {
         float* __restrict__ out = a.dwin_part + (((long long)ds * B + b) * 2) * Ti;
@@ -1050,7 +1057,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         }
     }
     T2_TS(53);
-    if (p.dbg == 5) return;
+    T2_STAGE_RETURN(5);
     __syncthreads();   // dq_s
     // partial dh = sum_{d in slice} dq[d] * W_q[d][:]; the two halves of the block take 16 dims each
     {

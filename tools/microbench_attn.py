@@ -1,7 +1,7 @@
 """Timing of the attention step launches (tools only).  T2AMD_ATTN_STAGE=n truncates the kernels after stage n."""
 import os, sys, torch
 os.environ.setdefault('T2AMD_ATTN_TS_PICK', '100')
-if os.environ.get('T2AMD_ATTN_TS') == '1':      # stamps exist only in the instrumented build (python -m tacotron2_amd.build --stamps)
+if os.environ.get('T2AMD_ATTN_TS') == '1' or os.environ.get('T2AMD_ATTN_STAGE', '0') != '0':      # stamps / stage returns exist only in the instrumented build (python -m tacotron2_amd.build --stamps)
     os.environ.setdefault('T2AMD_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tacotron2_amd', 'lib', 'libtacotron2_amd_stamps.so'))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tacotron2_amd import native as nv
