@@ -261,6 +261,14 @@ typedef struct t2amd_skinny_gemm {
     long long split_stride;
     int tag;          /* kernel-symbol role, as in t2amd_lstm_step */
     int bf16;         /* 1: x[i].p and W are bf16 (see t2amd_lstm_step) */
+    /* optional epilogue (nsplit must be 1 when any of it is used): Y = keep ? act(Y + bias) * keep_scale : 0 --
+     * nn.Linear + F.relu + F.dropout of the per-step prenet / projection at decode batch sizes 9..
+     * (reference model.py:99, 373-378) */
+    const float* bias;        /* [N] or NULL */
+    int act;                  /* 0 none, 1 relu */
+    const uint8_t* keep;      /* [B][ld_keep] keep mask or NULL */
+    long long ld_keep;
+    float keep_scale;
 } t2amd_skinny_gemm;
 
 int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream);

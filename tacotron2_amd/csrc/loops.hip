@@ -514,8 +514,17 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             l2.B = B; l2.N = P; l2.K = P; l2.act = 1; l2.keep = g2.keep; l2.ldkeep = P; l2.keep_scale = two;
             T2_PROPAGATE(t2amd_linear_small_f32(&l2, stream));
         } else {
+            // layer 1 (K = n_mel = 80: five k-steps) on the tiled GEMM; layer 2 and the projection below are B x N
+            // outputs over a long K -- one or two 128-tiles for the tiled kernel (75-190 us at B = 256), a full
+            // LDS-DMA pipeline per 16 columns for the skinny kernel
             T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
-            T2_PROPAGATE(t2amd_gemm_f32(&g2, stream));
+            t2amd_skinny_gemm s2 = {};
+            s2.nseg = 1;
+            s2.x[0] = seg(p->x_prenet, P, P);
+            s2.W = p->W2; s2.Ktot = P; s2.N = P; s2.B = B;
+            s2.Y = p->x_prenet + sP; s2.ldy = P; s2.nsplit = 1;
+            s2.act = 1; s2.keep = g2.keep; s2.ld_keep = P; s2.keep_scale = two;
+            T2_PROPAGATE(t2amd_skinny_gemm_f32(&s2, stream));
         }
 
         // attention LSTM on [prenet | ctx_{t-1} | h_att_{t-1}]  (no dropout in eval)
@@ -573,7 +582,13 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
                                                   p->gate_threshold, C, stream));
             continue;      // the stop test ran inside the projection kernel
         } else {
-            T2_PROPAGATE(t2amd_gemm_f32(&gp, stream));
+            t2amd_skinny_gemm sp = {};
+            sp.nseg = 1;
+            sp.x[0] = seg(p->hc + wr * sHC, Hd + E, Hd + E);
+            sp.W = p->Wpg; sp.Ktot = Hd + E; sp.N = C + 1; sp.B = B;
+            sp.Y = p->PG + (long long)t * sPG; sp.ldy = C + 1; sp.nsplit = 1;
+            sp.bias = p->bias_pg;
+            T2_PROPAGATE(t2amd_skinny_gemm_f32(&sp, stream));
         }
 
         T2_LAUNCH(infer_finish_step_kernel, dim3(t2_cdiv(B, 64)), dim3(64), 0, s, p->PG + (long long)t * sPG, B,

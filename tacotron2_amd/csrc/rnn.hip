@@ -48,6 +48,7 @@ struct SkinnyParams {
     const int* lens; int t;
     // plain epilogue
     float* Y; long long ldy; int nsplit; long long split_stride; int ktiles_per_split;
+    int act;          // plain epilogue: 1 = relu (bias / keep / keep_scale above are shared with the LSTM epilogue)
     int gx, gy, gz;   // logical grid of this problem
 };
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ SkinnyParams skinny_select(const SkinnyDual& dp, bool
     SK_SEL(gin); SK_SEL(ld_gin); SK_SEL(bias); SK_SEL(c_prev); SK_SEL(ld_cprev);
     SK_SEL(gates_out); SK_SEL(ld_gates); SK_SEL(c_out); SK_SEL(ld_c); SK_SEL(h_out); SK_SEL(ld_h);
     SK_SEL(h16_out); SK_SEL(ld_h16); SK_SEL(keep); SK_SEL(ld_keep); SK_SEL(keep_scale); SK_SEL(lens); SK_SEL(t);
-    SK_SEL(Y); SK_SEL(ldy); SK_SEL(nsplit); SK_SEL(split_stride); SK_SEL(ktiles_per_split);
+    SK_SEL(Y); SK_SEL(ldy); SK_SEL(nsplit); SK_SEL(split_stride); SK_SEL(ktiles_per_split); SK_SEL(act);
     SK_SEL(gx); SK_SEL(gy); SK_SEL(gz);
 #undef SK_SEL
     return p;
@@ -360,7 +361,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gr = rowbase + wave * 16 + lg * 4 + r;
-            if (gr < B && gn < p.N) Y[(long long)gr * p.ldy + gn] = acc0[r] + acc1[r];
+            if (gr < B && gn < p.N) {
+                float v = acc0[r] + acc1[r];
+                if (p.bias) v += p.bias[gn];
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                if (p.keep) v = p.keep[(long long)gr * p.ld_keep + gn] ? v * p.keep_scale : 0.f;
+                Y[(long long)gr * p.ldy + gn] = v;
+            }
         }
         return;
     }
@@ -677,7 +684,13 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
             const int c = ejj * 4 + j;
             const int gn = bx * 32 + c;
             const float v = (Ps[erow * 33 + c] + Ps[(64 + erow) * 33 + c]) + (Ps[(128 + erow) * 33 + c] + Ps[(192 + erow) * 33 + c]);
-            if (gn < p.N) Y[gn] = v;
+            if (gn < p.N) {
+                float o = v;
+                if (p.bias) o += p.bias[gn];
+                if (p.act == 1) o = fmaxf(o, 0.f);
+                if (p.keep) o = p.keep[(long long)gr * p.ld_keep + gn] ? o * p.keep_scale : 0.f;
+                Y[gn] = o;
+            }
         }
         SW_TS(5);
         return;
@@ -816,6 +829,9 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     p.nseg = a->nseg;
     p.W = a->W; p.Ktot = a->Ktot; p.B = a->B; p.N = a->N; p.H = 0;
     p.Y = a->Y; p.ldy = a->ldy; p.nsplit = a->nsplit; p.split_stride = a->split_stride;
+    T2_REQUIRE((!a->bias && !a->act && !a->keep) || a->nsplit == 1, "skinny_gemm: the bias/act/keep epilogue needs nsplit == 1");
+    T2_REQUIRE(a->act == 0 || a->act == 1, "skinny_gemm: act must be 0 or 1");
+    p.bias = a->bias; p.act = a->act; p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     const int ktiles = a->Ktot / (a->bf16 ? 128 : 64);
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     p.gx = t2_cdiv(a->N, 16); p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = a->nsplit;

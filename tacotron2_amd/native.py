@@ -71,6 +71,7 @@ class SkinnyGemm(C.Structure):
         ("W", _f32p), ("Ktot", C.c_int), ("N", C.c_int), ("B", C.c_int),
         ("Y", _f32p), ("ldy", _i64), ("nsplit", C.c_int), ("split_stride", _i64), ("tag", C.c_int),
         ("bf16", C.c_int),
+        ("bias", _f32p), ("act", C.c_int), ("keep", C.c_void_p), ("ld_keep", _i64), ("keep_scale", C.c_float),
     ]
 
 
@@ -698,7 +699,7 @@ def linear_small(X, W, Y, bias=None, act=0, keep=None, keep_scale=1.0):
     _check(lib.t2amd_linear_small_f32(C.byref(a), _stream()), "t2amd_linear_small_f32")
 
 
-def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1, bf16=False):
+def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1, bf16=False, bias=None, act=0, keep=None, keep_scale=1.0):
     """Y[nsplit, B, N] = [xs...] . W[N, K]^T"""
     lib = load()
     a = SkinnyGemm()
@@ -711,6 +712,11 @@ def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1, bf16=False):
     a.Ktot, a.N, a.B = sum(widths), N, B
     _fullc(Y)
     a.Y, a.ldy, a.nsplit, a.split_stride = ptr(Y), N, nsplit, B * N
+    if bias is not None:
+        a.bias = ptr(_fullc(bias))
+    a.act = int(act)
+    if keep is not None:
+        a.keep, a.ld_keep, a.keep_scale = ptr(_fullc(keep), torch.uint8), keep.stride(0), keep_scale
     _check(lib.t2amd_skinny_gemm_f32(C.byref(a), _stream()), "t2amd_skinny_gemm_f32")
 
 

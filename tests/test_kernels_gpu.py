@@ -531,6 +531,23 @@ def test_small_batch_lstm_step_and_linear(nv, B):
     assert err(Y2, Xbig[:, :Kl] @ Wl.t()) < 1e-5
 
 
+@pytest.mark.parametrize("B,N,widths", [(16, 256, (256,)), (256, 81, (1024, 512)), (70, 33, (64, 128))])
+def test_skinny_gemm_epilogue(nv, B, N, widths):
+    """Plain skinny product with the nn.Linear + relu + dropout epilogue (the per-step prenet layer / mel+gate
+    projection of batched inference, reference model.py:99, 373-378): ragged N, several row blocks."""
+    K = sum(widths)
+    xs = [rnd(B, w, seed=140 + i) for i, w in enumerate(widths)]
+    W, bias = rnd(N, K, seed=144, scale=0.1), rnd(N, seed=145)
+    keep = (torch.rand(B, N, generator=torch.Generator().manual_seed(146)) > 0.5).to(torch.uint8)
+    X = torch.cat(xs, 1)
+    Y = torch.full((1, B, N), float('nan'), device=DEV)
+    nv.skinny_gemm([dv(x) for x in xs], list(widths), dv(W), N, B, Y, bias=dv(bias), act=1, keep=dv(keep), keep_scale=2.0)
+    assert err(Y[0], torch.relu(X @ W.t() + bias) * keep * 2.0) < 1e-5
+    Y2 = torch.full((1, B, N), float('nan'), device=DEV)
+    nv.skinny_gemm([dv(x) for x in xs], list(widths), dv(W), N, B, Y2, bias=dv(bias))
+    assert err(Y2[0], X @ W.t() + bias) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # bf16 operand mode of the recurrent kernels
 # ------------------------------------------------------------------------------------------------
