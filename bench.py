@@ -195,8 +195,9 @@ def main():
         avg_s = max(raw_s - ev_ms / 1e3, 1e-9)
         achieved = alg_bytes / avg_s / 1e9
         mm = "bf16 MFMA (f32 accumulate)" if es == 2.0 else "exact-f32 MFMA"
-        kname = ("skinny_gemm_kernel<true,3,%s> (one decoder time step: decoder LSTM of step t-1 (64x2560x4096) + attention "
-                 "LSTM of step t (64x1536x4096), %s + fused cells)" % ("true" if es == 2.0 else "false", mm)) if fused else \
+        kname = ("%s (one decoder time step: decoder LSTM of step t-1 (64x2560x4096) + attention "
+                 "LSTM of step t (64x1536x4096), %s + fused cells)"
+                 % ("skinny_wide_kernel<true,3>" if es == 2.0 else "skinny_gemm_kernel<true,3,false>", mm)) if fused else \
                 ("skinny_gemm_kernel<true,2> (decoder LSTM step: 64x2560x4096 exact-f32 MFMA GEMM + fused cell; runs on the "
                  "side stream concurrently with the attention chain, so its duration includes sharing the CUs)")
         # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler
