@@ -540,24 +540,25 @@ __device__ __forceinline__ float dot8_bf16(const float4& m, const float4& g0, co
 // Half a wave (32 lanes) per memory row, 8 rows per pass.  One L2 round trip: the memory rows of the first 64
 // positions of the slice (all four column groups: 32 float4 per lane), the gradient slabs and the carry partials
 // are all issued before anything is consumed; nothing is compared or selected on a loaded value before that.
-#define KB1_MAXP 8      // passes kept in registers: 8 rows x 8 passes = 64 positions per slice (Ti <= 256)
+#define KB1_NT 512      // threads: 16 row groups of 32 lanes
+#define KB1_NG (KB1_NT / 32)
+#define KB1_MAXP 4      // passes kept in registers: 16 rows x 4 passes = 64 positions per slice (Ti <= 256)
 // M16: rows come from the bf16 copy of the encoder memory (t2amd_attn_bwd.memory16): one 16-byte load is 8 channels,
 // so two column groups cover E <= 512 and the kernel moves half the bytes it is bound by; dctx and the sums stay f32.
+// The body is a device function so that the fused backward kernel (below) can run it as its first phase; `ts_on` is
+// the caller's phase-stamp switch.
 template <bool M16>
-__global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
+__device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, const int ts, const int b, bool& ts_on) {
     constexpr int CPT = M16 ? 8 : 4;           // channels per 16-byte load
     constexpr int KB1_MAXC = M16 ? 2 : 4;      // column groups kept in registers: KB1_MAXC x 32 loads = E <= 512
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    bool ts_on = false;
     const t2amd_attn_bwd& a = p.a;
-    const int ts = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Ti = a.Ti, E = a.E, B = a.B;
     const int tsz = (Ti + NTS - 1) / NTS;
     float* dctx_s = smem;            // [E]
     float* base_s = dctx_s + E;      // [tsz] carries + running dcum (+ extra) per position of the slice
     float* wl_s = base_s + tsz;      // [tsz] this step's weights
-    float* red_s = wl_s + tsz;       // [8]
+    float* red_s = wl_s + tsz;       // [KB1_NT / 64]
     T2_TS(32);
     const int len_raw = a.lens ? a.lens[b] : Ti;
     const int t0 = ts * tsz;
@@ -567,12 +568,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     const int E4 = E / CPT;                        // 16-byte units per row
     const float4* __restrict__ M4 = reinterpret_cast<const float4*>(M16 ? a.memory16 : (const void*)a.memory) +
                                     (long long)b * Ti * E4;
-    const int grp = tid >> 5, l32 = tid & 31;      // 8 row groups of 32 lanes
-    const int npass = (tsz + 7) >> 3;              // passes that hold positions of this slice
+    const int grp = tid >> 5, l32 = tid & 31;      // KB1_NG row groups of 32 lanes
+    const int npass = (tsz + KB1_NG - 1) / KB1_NG; // passes that hold positions of this slice
     float4 pm[KB1_MAXC][KB1_MAXP];
 #pragma unroll
     for (int i = 0; i < KB1_MAXP; ++i) {
-        const int ti = t0 + grp + 8 * i;
+        const int ti = t0 + grp + KB1_NG * i;
         const long long tc = (i < npass && ti < t1 && ti < len_raw) ? ti : t0;      // clamped: loaded, never used
 #pragma unroll
         for (int g = 0; g < KB1_MAXC; ++g) {
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     float gsl[2][3][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int c = tid + 256 * u;
+        const int c = tid + KB1_NT * u;
         const int cc = c < E ? c : 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     // ---- consume --------------------------------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int c = tid + 256 * u;
+        const int c = tid + KB1_NT * u;
         if (c < E) {
             float s = 0.f;
 #pragma unroll
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
             if (ts == 0) a.dctx_total[(long long)b * a.ld_dctx_total + c] = s;
         }
     }
-    for (int c = tid + 512; c < E; c += 256) {       // E > 512: remaining channels the plain way
+    for (int c = tid + 2 * KB1_NT; c < E; c += KB1_NT) {       // E > 1024: remaining channels the plain way
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -657,7 +658,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         dctx_s[c] = s;
         if (ts == 0) a.dctx_total[(long long)b * a.ld_dctx_total + c] = s;
     }
-    for (int i = tid; i < tsz; i += 256) {
+    for (int i = tid; i < tsz; i += KB1_NT) {
         const int ti = t0 + i;
         float base = 0.f, w = 0.f;
         if (ti < t1) {
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     float* __restrict__ dwo = a.ws + (long long)b * Ti;
     T2_TS(33);
     float psum = 0.f;
-    for (int r0 = 0; r0 < tsz; r0 += 8 * KB1_MAXP) {
+    for (int r0 = 0; r0 < tsz; r0 += KB1_NG * KB1_MAXP) {
         float acc[KB1_MAXP];
 #pragma unroll
         for (int i = 0; i < KB1_MAXP; ++i) acc[i] = 0.f;
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
             if constexpr (M16) gq1 = *reinterpret_cast<const float4*>(&dctx_s[c * CPT + 4]);
 #pragma unroll
             for (int i = 0; i < KB1_MAXP; ++i) {
-                const int ti = t0 + r0 + grp + 8 * i;
+                const int ti = t0 + r0 + grp + KB1_NG * i;
                 const float4 m = M4[(long long)(ti < t1 ? ti : t0) * E4 + c];
                 if constexpr (M16) {
                     acc[i] = dot8_bf16(m, gq, gq1, acc[i]);
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
         for (int i = 0; i < KB1_MAXP; ++i) {
             float s = row16_sum(acc[i]);
             s += __shfl_xor(s, 16, 64);
-            const int li = r0 + grp + 8 * i;
+            const int li = r0 + grp + KB1_NG * i;
             const int ti = t0 + li;
             if (l32 == 0 && ti < t1) {
                 const float dw = ((ti < len) ? s : 0.f) + base_s[li];
@@ -750,8 +751,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dw_kernel(AttnBwdParams p) {
     psum += __shfl_xor(psum, 32, 64);
     if (lane == 0) red_s[wv] = psum;
     __syncthreads();
-    if (tid == 0) a.ws[(long long)B * Ti + (long long)ts * B + b] = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
+    if (tid == 0) {
+        float s = red_s[0];
+#pragma unroll
+        for (int w = 1; w < KB1_NT / 64; ++w) s += red_s[w];
+        a.ws[(long long)B * Ti + (long long)ts * B + b] = s;
+    }
     T2_TS(35);
+}
+
+template <bool M16>
+__global__ __launch_bounds__(KB1_NT) void attn_bwd_dw_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool ts_on = false;
+    kb1_phase<M16>(p, smem, blockIdx.x, blockIdx.y, ts_on);
 }
 
 // K_b2: everything that lives in attention-dim space, for 32 dims (8 waves)
@@ -1127,8 +1140,8 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         g_attn_bwd_lds = (int)lds2;
     }
     T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && a->E % 8 == 0), "attn_bwd: memory16 must be 16-byte aligned, E a multiple of 8");
-    if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(256), lds1, s, p);
-    else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(256), lds1, s, p);
+    if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
+    else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
     T2_LAUNCH(attn_bwd_main_kernel, dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
