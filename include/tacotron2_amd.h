@@ -391,7 +391,9 @@ typedef struct t2amd_attn_bwd {
     float* dh_out;           /* [T2AMD_ATT_SLICES] partial slabs of Wq^T dq: slice s, row b at dh_out + s*dh_split_stride + b*ld_dh */
     long long ld_dh;
     long long dh_split_stride;
-    float* ws;               /* workspace, >= B*Ti + 8*B floats */
+    float* ws;               /* workspace, >= B*Ti + 8*B floats.  Its last 4*B words receive the hand-off tokens of the
+                              * fused kernel (a nonzero launch counter): zero them once before the first call and do
+                              * not let other kernels write there between calls. */
     /* 1: the two gradient products of the location layer (dcol = U^T dpre, dU += dpre^T im2col) round their
      * operands to bf16 and run on v_mfma_f32_16x16x32_bf16 (f32 accumulate) -- the engine's bf16 compute mode.
      * 0: exact-f32 MFMA.  The recompute of the location conv uses the forward's split-bf16 form (see
@@ -437,7 +439,8 @@ typedef struct t2amd_dec_train {
     float* ALIGN; /* [B][To][Ti] */
     float* CUM;   /* [To][B][Ti] cumulative weights before each step */
     float* cum_work; /* [B][Ti] scratch (zeroed by the call) */
-    float* attn_ws;  /* >= T2AMD_ATT_SLICES*B*Ti + B*Ti floats: attention workspace (forward and backward) */
+    float* attn_ws;  /* >= T2AMD_ATT_SLICES*B*Ti + B*Ti + 8*B floats: attention workspace (the backward loop uses the
+                      * part behind the forward's T2AMD_ATT_SLICES*B*Ti) */
     /* bf16 operand mode (all NULL / 0 for f32): bf16 copies of the packed weights and of the three recurrent
      * operand slabs; the LSTM products then run on the bf16 MFMA, state and slabs above stay f32. */
     int bf16;

@@ -217,6 +217,10 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     T2_PROPAGATE(t2amd_fill_f32(p->dc_d, sHd, 0.f, stream));
     T2_PROPAGATE(t2amd_fill_f32(p->dwin_part, (long long)T2AMD_ATT_SLICES * B * 2 * Ti, 0.f, stream));
     T2_PROPAGATE(t2amd_fill_f32(p->dcum_acc, (long long)B * Ti, 0.f, stream));
+    // the backward's attention workspace sits behind the forward's four partial-energy slabs; its 8*B tail holds the
+    // slice partials and the hand-off tokens of the fused backward kernel: zeroed once, tokens are never zero
+    float* const bwd_ws = f.attn_ws + (long long)T2AMD_ATT_SLICES * B * Ti;
+    T2_PROPAGATE(t2amd_fill_f32(bwd_ws + (long long)B * Ti, 8ll * B, 0.f, stream));
 
     // The decoder-LSTM BPTT chain (cell backward -> dgrad GEMM) depends only on itself and on the
     // projection gradient; the attention chain consumes its dX one step later.  So the loop is
@@ -260,7 +264,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.w = f.ALIGN + (long long)t * Ti; ab.ld_w = (long long)To * Ti;
         ab.w_prev = t ? f.ALIGN + (long long)(t - 1) * Ti : nullptr; ab.ld_wprev = (long long)To * Ti;
         ab.cum_before = f.CUM + (long long)t * B * Ti;
-        ab.dwin_part = p->dwin_part; ab.dcum_acc = p->dcum_acc; ab.ws = f.attn_ws;
+        ab.dwin_part = p->dwin_part; ab.dcum_acc = p->dcum_acc; ab.ws = bwd_ws;
         ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;

@@ -473,6 +473,46 @@ def test_attention_forward_backward(nv, B, Ti, E, Hq, bf16):
     assert err(dq.cpu().t() @ h, dWq_ref) < cl(5e-5, dWq_ref)
 
 
+def test_attention_backward_fused_matches_two_launch():
+    """T2AMD_ATTN_FUSED_BWD=1 (K_b1 + hand-off + K_b2 in one launch) must reproduce the two-launch backward bit for
+    bit: same per-thread arithmetic, only the transport of dw between the four workgroups of an utterance differs.
+    Runs in child processes because the switch is read once per process."""
+    import subprocess, sys, os, tempfile
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from tacotron2_amd import native as nv
+dev = torch.device('cuda')
+g = torch.Generator().manual_seed(5)
+rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+B, Ti, E, Hq = 5, 150, 512, 1024
+mem, pm = rnd(B, Ti, E), rnd(B, Ti, 128)
+Wq, U, v = rnd(128, Hq) * 0.05, rnd(128 * 62) * 0.1, rnd(128)
+lens = torch.tensor([150, 140, 97, 64, 33], dtype=torch.int32, device=dev)
+w = torch.softmax(rnd(B, Ti), 1); wprev = torch.softmax(rnd(B, Ti), 1); cum = torch.rand(B, Ti, generator=g).to(dev)
+q, dctx, dwx = rnd(B, 128), rnd(B, E), rnd(B, Ti)
+outs = []
+ws = torch.zeros(nv.attn_bwd_ws_floats(B, Ti), device=dev)
+dwin, dcum = rnd(4, B, 2, Ti), rnd(B, Ti)
+d_pm, dU, dv_ = torch.zeros(B, Ti, 128, device=dev), torch.zeros(B, 128, 62, device=dev), torch.zeros(B, 128, device=dev)
+dq, dh, tot = torch.empty(B, 128, device=dev), torch.empty(4, B, Hq, device=dev), torch.empty(B, E, device=dev)
+for step in range(3):
+    nv.attention_step_bwd([dctx], tot, dwx, q, Wq, U, v, pm, mem, lens, w, wprev, cum, dwin, dcum, d_pm, dU, dv_, dq, dh, ws)
+torch.cuda.synchronize()
+torch.save([t.cpu() for t in (tot, dwin, dcum, d_pm, dU, dv_, dq, dh)], sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for fused in ("0", "1"):
+        with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as fh:
+            path = fh.name
+        env = dict(os.environ, T2AMD_ATTN_FUSED_BWD=fused)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=120)
+        res.append(torch.load(path))
+        os.unlink(path)
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
 def test_attention_no_mask_and_first_step(nv):
     """Inference semantics: no length mask (reference model.py:432) and zero previous weights."""
     B, Ti, E, Hq = 1, 29, 512, 1024
