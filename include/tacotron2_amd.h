@@ -97,10 +97,10 @@ typedef struct t2amd_gemm_desc {
     int precision;
 } t2amd_gemm_desc;
 
-/* Output tile edge (128 or 256) t2amd_gemm_f32 will use for an M x N product at `precision` launched as
- * `nz` = batch*splitk slices: callers that split K pick the split count from the resulting workgroup count.
+/* Output tile edge (128 or 256) t2amd_gemm_f32 will use for an M x N product at `precision` with the given
+ * operand layouts, launched as `nz` = batch*splitk slices: callers that split K pick the split count from the resulting workgroup count.
  * (Host-side sizing helper; the reference has no counterpart, torch.mm hides its tiling.) */
-int t2amd_gemm_tile_size(int M, int N, int precision, int nz);
+int t2amd_gemm_tile_size(int M, int N, int precision, int nz, int a_kcontig, int b_kcontig);
 int t2amd_gemm_f32(const t2amd_gemm_desc* d, void* stream);
 
 /* out[i] (+)= sum_s partials[s*stride + i]; with `perm_taps`>0 the flat index i = (co, tap, ci)

@@ -300,13 +300,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 template <bool AK, bool BKC, bool X3, int TB>
 __global__ __launch_bounds__(2 * TB) void gemm_bf16x3_kernel(GemmParams p);
 
-// Output tile edge the library will use for an (M, N) product at this precision when `nz` = batch * splitk slices
-// of it are launched: callers that split K size the split from it.  256 only for the plain-bf16 kernel, on outputs
+// Output tile edge the library will use for an (M, N) product at this precision / operand layout when `nz` = batch *
+// splitk slices of it are launched: callers that split K size the split from it.  256 only for the bf16 kernels, on outputs
 // at least two 256-tiles wide both ways, and only when the launch still has >= 192 workgroups (a 256-tile workgroup
 // owns a whole CU).  T2AMD_GEMM_TILE=128 forces the small tile (A/B measurements).
-extern "C" int t2amd_gemm_tile_size(int M, int N, int precision, int nz) {
+extern "C" int t2amd_gemm_tile_size(int M, int N, int precision, int nz, int a_kcontig, int b_kcontig) {
     static const bool force128 = [] { const char* e = getenv("T2AMD_GEMM_TILE"); return e && atoi(e) == 128; }();
-    if (force128 || precision != 2 || M < 512 || N < 512) return 128;
+    if (force128 || precision < 1 || M < 512 || N < 512) return 128;
+    // split-bf16 (precision 1) keeps hi and lo images: 256-tiles fit the 160 KB of LDS only when both operands are
+    // M/N-contiguous (unpadded pair-interleaved images, 128 KB) -- the weight-gradient layout
+    if (precision == 1 && (a_kcontig || b_kcontig)) return 128;
     const long long wgs = (long long)t2_cdiv(M, 256) * t2_cdiv(N, 256) * (nz > 0 ? nz : 1);
     return wgs >= 192 ? 256 : 128;
 }
@@ -369,7 +372,19 @@ extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
-    if (fast && t2amd_gemm_tile_size(d.M, d.N, d.precision, d.batch * d.splitk) == 256) {
+    if (fast && d.precision == 1 && t2amd_gemm_tile_size(d.M, d.N, 1, d.batch * d.splitk, d.a_kcontig, d.b_kcontig) == 256) {
+        dim3 g2(t2_cdiv(d.N, 256), t2_cdiv(d.M, 256), d.batch * d.splitk);
+        static bool attr_set = false;
+        if (!attr_set && !t2amd_validate_only_flag_()) {      // 128 KB of static LDS is above the 64 KB default limit
+            (void)hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, false, true, 256>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+            attr_set = true;
+        }
+        T2_LAUNCH((gemm_bf16x3_kernel<false, false, true, 256>), g2, dim3(512), 0, s, p);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
+    if (fast && d.precision == 2 && t2amd_gemm_tile_size(d.M, d.N, 2, d.batch * d.splitk, d.a_kcontig, d.b_kcontig) == 256) {
         dim3 g2(t2_cdiv(d.N, 256), t2_cdiv(d.M, 256), d.batch * d.splitk);
         if (d.a_kcontig && d.b_kcontig)
             T2_LAUNCH((gemm_bf16x3_kernel<true, true, false, 256>), g2, dim3(512), 0, s, p);

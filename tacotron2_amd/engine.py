@@ -79,12 +79,12 @@ class MaskSource(object):
 # ----------------------------------------------------------------------------
 # small helpers
 # ----------------------------------------------------------------------------
-def _choose_splitk(M, N, K, batch=1, precision=0):
+def _choose_splitk(M, N, K, batch=1, precision=0, a_km=False, b_kn=False):
     """Split count for a plain-epilogue GEMM.  The library tiles 256 x 256 (one workgroup per CU) for plain-bf16
     products when that still yields >= 192 workgroups, else 128 x 128 (three to five per CU); the split is chosen
     against whichever applies (native.gemm_tile_size is the same rule the launch uses)."""
     t256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
-    if precision == 2 and M >= 512 and N >= 512 and nv.gemm_tile_size(M, N, 2, 1 << 20) == 256:
+    if precision >= 1 and M >= 512 and N >= 512 and nv.gemm_tile_size(M, N, precision, 1 << 20, a_km, b_kn) == 256:
         if t256 >= 192:
             return 1
         # fill whole rounds of 256 workgroups: efficiency = rounds / ceil(rounds), mild preference for fewer slabs
@@ -172,7 +172,7 @@ class _Run(object):
         K = A.shape[0] if a_km else A.shape[1]
         plain = kw.get('bias') is None and kw.get('act', 0) == 0 and kw.get('keep') is None \
             and kw.get('convA') is None
-        sk = _choose_splitk(M, N, K, batch, int(fast)) if (plain and batch == 1) else 1
+        sk = _choose_splitk(M, N, K, batch, int(fast), a_km, b_kn) if (plain and batch == 1) else 1
         if perm is not None and sk == 1:
             sk = 2 if K >= 512 else 1
         if sk == 1 and perm is None:

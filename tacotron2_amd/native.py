@@ -229,7 +229,7 @@ def _argtypes():
     pt = C.POINTER
     return {
         "t2amd_gemm_f32": [pt(GemmDesc), _P],
-        "t2amd_gemm_tile_size": [_I, _I, _I, _I],
+        "t2amd_gemm_tile_size": [_I, _I, _I, _I, _I, _I],
         "t2amd_splitk_reduce_f32": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
         "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
@@ -412,9 +412,9 @@ def scale_for(p):
 # ----------------------------------------------------------------------------
 # GEMM
 # ----------------------------------------------------------------------------
-def gemm_tile_size(M, N, precision, nz=1):
+def gemm_tile_size(M, N, precision, nz=1, a_km=False, b_kn=False):
     """Tile edge (128/256) the library will use for this product launched as nz = batch*splitk slices."""
-    return int(load().t2amd_gemm_tile_size(int(M), int(N), int(precision), int(nz)))
+    return int(load().t2amd_gemm_tile_size(int(M), int(N), int(precision), int(nz), 0 if a_km else 1, 0 if b_kn else 1))
 
 
 def gemm(Cm, A, B, a_km=False, b_kn=False, accumulate=False, bias=None, act=0, keep=None,

@@ -67,7 +67,7 @@ def test_gemm_plain_bf16_tiles(nv, M, N, K, sk, a_km, b_kn):
     Ad = dv(A.t().contiguous()) if a_km else dv(A)
     Bd = dv(B) if b_kn else dv(B.t().contiguous())
     expect = 256 if (M >= 512 and N >= 512 and -(-M // 256) * -(-N // 256) * sk >= 192) else 128
-    assert nv.gemm_tile_size(M, N, 2, sk) == expect
+    assert nv.gemm_tile_size(M, N, 2, sk, a_km, b_kn) == expect
     if sk == 1:
         C = torch.full((M, N), float('nan'), device=DEV)
         nv.gemm(C, Ad, Bd, a_km=a_km, b_kn=b_kn, fast=2)
@@ -78,6 +78,23 @@ def test_gemm_plain_bf16_tiles(nv, M, N, K, sk, a_km, b_kn):
         out = part.cpu().double().sum(0).view(M, N)
     rel = ((out - ref).abs() / scale).max().item()
     assert rel < 2e-6, rel
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(2048, 1792, 2100, 4), (1000, 900, 4100, 12)])
+def test_gemm_split_bf16_big_tile_wgrad(nv, M, N, K, sk):
+    """precision=1 on 256 x 256 tiles: only the weight-gradient layout (both operands M/N-contiguous: unpadded LDS
+    images, 128 KB) qualifies; split-K partial slabs, ragged edges."""
+    A = rnd(M, K, seed=21) * (1.0 + torch.arange(M).float().unsqueeze(1) / M)
+    B = rnd(K, N, seed=22) * (0.5 + torch.arange(N).float().unsqueeze(0) / N)
+    ref = A.double() @ B.double()
+    scale = A.abs().double() @ B.abs().double()
+    assert nv.gemm_tile_size(M, N, 1, sk, True, True) == 256
+    assert nv.gemm_tile_size(M, N, 1, sk, False, True) == 128
+    part = torch.full((sk, M * N), float('nan'), device=DEV)
+    nv.gemm(part[0].view(M, N), dv(A.t().contiguous()), dv(B), a_km=True, b_kn=True, fast=1, splitk=sk, partials=part)
+    out = part.cpu().double().sum(0).view(M, N)
+    rel = ((out - ref).abs() / scale).max().item()
+    assert rel < 2.5e-5, rel
 
 
 @pytest.mark.parametrize("M,N,K", [(130, 81, 50), (300, 257, 96), (64, 4096, 256), (7, 5, 3), (256, 128, 1024), (512, 384, 4000)])
