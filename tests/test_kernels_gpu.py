@@ -412,7 +412,7 @@ def _attn_inputs(B, Ti, E, Hq, seed):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("B,Ti,E,Hq", [(3, 37, 128, 128), (4, 175, 512, 1024), (2, 70, 512, 1024)])
+@pytest.mark.parametrize("B,Ti,E,Hq", [(3, 37, 128, 128), (4, 175, 512, 1024), (2, 70, 512, 1024), (2, 300, 512, 1024)])
 def test_attention_forward_backward(nv, B, Ti, E, Hq, bf16):
     """bf16=True: the two gradient products of the location layer (dcol = U^T dpre -> the carries, dU) round their
     operands to bf16 (t2amd_attn_bwd.bf16): bf16-class tolerance on exactly those outputs, f32-class on the rest."""
