@@ -352,6 +352,8 @@ typedef struct t2amd_attn_fwd {
     /* optional bf16 copy of `memory` ([B][Ti][E] bf16): the context product then streams it instead of the f32 rows
      * (the kernel is bound by the bytes of those rows); weights, accumulation and the context stay f32. */
     const void* memory16;
+    /* optional bf16 copy of Wq ([128][Hq] bf16): the query product q = Wq h streams it (h and the sums stay f32) */
+    const void* Wq16;
 } t2amd_attn_fwd;
 
 int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
@@ -450,6 +452,7 @@ typedef struct t2amd_dec_train {
     void* HD16;            /* [To][B][Hd] bf16 */
     void* CTX16;           /* [To][B][E] bf16 */
     const void* memory16;  /* [B][Ti][E] bf16 copy of memory, or NULL: attention context / its backward stream it */
+    const void* Wq16;      /* [128][Ha] bf16 copy of Wq, or NULL: the forward query product streams it */
 } t2amd_dec_train;
 
 int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream);

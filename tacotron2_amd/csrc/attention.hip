@@ -159,6 +159,20 @@ __device__ __forceinline__ void loc_tile16(const UFrag16& uf, const float* __res
 #undef T2_M16
 }
 
+// acc + sum of 8 bf16 values (packed in the 16 bytes of m, ascending channel order) times 8 floats (g0, g1)
+__device__ __forceinline__ float dot8_bf16(const float4& m, const float4& g0, const float4& g1, float acc) {
+    const unsigned u0 = __float_as_uint(m.x), u1 = __float_as_uint(m.y), u2 = __float_as_uint(m.z), u3 = __float_as_uint(m.w);
+    acc = fmaf(__uint_as_float(u0 << 16), g0.x, acc);
+    acc = fmaf(__uint_as_float(u0 & 0xffff0000u), g0.y, acc);
+    acc = fmaf(__uint_as_float(u1 << 16), g0.z, acc);
+    acc = fmaf(__uint_as_float(u1 & 0xffff0000u), g0.w, acc);
+    acc = fmaf(__uint_as_float(u2 << 16), g1.x, acc);
+    acc = fmaf(__uint_as_float(u2 & 0xffff0000u), g1.y, acc);
+    acc = fmaf(__uint_as_float(u3 << 16), g1.z, acc);
+    acc = fmaf(__uint_as_float(u3 & 0xffff0000u), g1.w, acc);
+    return acc;
+}
+
 struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; unsigned long long* ts; };
 
 // timing experiments only (tools/microbench_attn.py): T2AMD_ATTN_STAGE=n makes the kernels return after stage n
@@ -240,12 +254,25 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
         const float4* __restrict__ h4 = reinterpret_cast<const float4*>(a.h + (long long)b * a.ld_h);
         float4* h_s4 = reinterpret_cast<float4*>(h_s);
         const int n4 = Hq >> 2;
-        // first 1024 columns straight-line (a loop header makes the compiler drain every pending load)
+        // first 1024 columns straight-line (a loop header makes the compiler drain every pending load).
+        // bf16 mode (a.Wq16): the row is 128 sixteen-byte units of 8 bf16 -- half the bytes of the stream that bounds
+        // this prologue (128 KB of W_q per workgroup in f32); h and the sums stay f32.
+        const bool wq16 = a.Wq16 != nullptr;
+        const float4* __restrict__ W16 = reinterpret_cast<const float4*>(a.Wq16) + (long long)(ds * DSL + d) * (Hq >> 3);
+        const int n8 = Hq >> 3;
         float4 w[16];
+        if (wq16) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = part + 16 * u;
-            w[u] = W4[i < n4 ? i : part];
+            for (int u = 0; u < 8; ++u) {
+                const int i = part + 16 * u;
+                w[u] = W16[i < n8 ? i : part];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = part + 16 * u;
+                w[u] = W4[i < n4 ? i : part];
+            }
         }
         {
             // h staged behind the W_q loads: its store is the first consumer of the whole prologue
@@ -254,18 +281,27 @@ __global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
             for (int j = tid + KE_NT; j < n4; j += KE_NT) h_s4[j] = h4[j];
         }
         __syncthreads();
+        if (wq16) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = part + 16 * u;
-            if (i < n4) {
-                const float4 x = h_s4[i];
-                qacc = fmaf(w[u].x, x.x, qacc);
-                qacc = fmaf(w[u].y, x.y, qacc);
-                qacc = fmaf(w[u].z, x.z, qacc);
-                qacc = fmaf(w[u].w, x.w, qacc);
+            for (int u = 0; u < 8; ++u) {
+                const int i = part + 16 * u;
+                if (i < n8) qacc = dot8_bf16(w[u], h_s4[2 * i], h_s4[2 * i + 1], qacc);
+            }
+            for (int i = part + 128; i < n8; i += 16) qacc = dot8_bf16(W16[i], h_s4[2 * i], h_s4[2 * i + 1], qacc);   // Hq > 1024
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = part + 16 * u;
+                if (i < n4) {
+                    const float4 x = h_s4[i];
+                    qacc = fmaf(w[u].x, x.x, qacc);
+                    qacc = fmaf(w[u].y, x.y, qacc);
+                    qacc = fmaf(w[u].z, x.z, qacc);
+                    qacc = fmaf(w[u].w, x.w, qacc);
+                }
             }
         }
-        for (int i = part + 256; i < n4; i += 16) {          // Hq > 1024
+        for (int i = part + 256; i < (wq16 ? 0 : n4); i += 16) {          // Hq > 1024
             const float4 ww = W4[i], x = h_s4[i];
             qacc = fmaf(ww.x, x.x, qacc);
             qacc = fmaf(ww.y, x.y, qacc);
@@ -505,6 +541,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP + (size_t)a->Hq);
     const int EC = a->E / NCS;
     T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && EC % 8 == 0), "attn_fwd: memory16 must be 16-byte aligned, E a multiple of 32");
+    T2_REQUIRE(!a->Wq16 || (t2_aligned16(a->Wq16) && a->Hq % 128 == 0), "attn_fwd: Wq16 must be 16-byte aligned, Hq a multiple of 128");
     int parts = KC_NT / (EC / (a->memory16 ? 8 : 4));
     if (parts > 32) parts = 32;
     T2_REQUIRE(parts >= 1, "attn_fwd: E too large");
@@ -521,20 +558,6 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // Backward of one attention step.
 // =========================================================================================
 struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; unsigned token; int kb1_smem_off; };
-
-// acc + sum of 8 bf16 values (packed in the 16 bytes of m, ascending channel order) times 8 floats (g0, g1)
-__device__ __forceinline__ float dot8_bf16(const float4& m, const float4& g0, const float4& g1, float acc) {
-    const unsigned u0 = __float_as_uint(m.x), u1 = __float_as_uint(m.y), u2 = __float_as_uint(m.z), u3 = __float_as_uint(m.w);
-    acc = fmaf(__uint_as_float(u0 << 16), g0.x, acc);
-    acc = fmaf(__uint_as_float(u0 & 0xffff0000u), g0.y, acc);
-    acc = fmaf(__uint_as_float(u1 << 16), g0.z, acc);
-    acc = fmaf(__uint_as_float(u1 & 0xffff0000u), g0.w, acc);
-    acc = fmaf(__uint_as_float(u2 << 16), g1.x, acc);
-    acc = fmaf(__uint_as_float(u2 & 0xffff0000u), g1.y, acc);
-    acc = fmaf(__uint_as_float(u3 << 16), g1.z, acc);
-    acc = fmaf(__uint_as_float(u3 & 0xffff0000u), g1.w, acc);
-    return acc;
-}
 
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
 // Half a wave (32 lanes) per memory row, 8 rows per pass.  One L2 round trip: the memory rows of the first 64

@@ -142,7 +142,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)To * Ti;
         at.ctx_out = p->CTX + t * sE; at.ld_ctx = E;
         at.q_out = p->Q + (long long)t * B * T2AMD_ATT_DIM; at.ld_q = T2AMD_ATT_DIM;
-        if (p->bf16) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; at.loc_split_bf16 = 1; at.memory16 = p->memory16; }
+        if (p->bf16) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; at.loc_split_bf16 = 1; at.memory16 = p->memory16; at.Wq16 = p->Wq16; }
         return t2amd_attention_step_fwd_f32(&at, st);
     };
 

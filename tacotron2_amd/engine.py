@@ -410,7 +410,8 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         # bf16 compute mode: bf16 copies of the packed weights and of the recurrent operand slabs (the LSTM
         # products run on the bf16 MFMA; cell state, gates and every saved slab stay f32)
         c.bf16 = dict(Wa_rec16=run.cast16(Wa_rec), Wd_cat16=run.cast16(Wd_cat), HA16=run.empty16(To, B, Ha),
-                      HD16=run.empty16(To, B, Hd), CTX16=run.empty16(To, B, E), memory16=run.cast16(memory))
+                      HD16=run.empty16(To, B, Hd), CTX16=run.empty16(To, B, E), memory16=run.cast16(memory),
+                      Wq16=run.cast16(Wq))
         d.bf16 = 1
         for k_, v_ in c.bf16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))

@@ -110,6 +110,7 @@ class AttnFwd(C.Structure):
         ("ctx16_out", C.c_void_p), ("ld_ctx16", _i64),
         ("loc_split_bf16", C.c_int),
         ("memory16", C.c_void_p),
+        ("Wq16", C.c_void_p),
     ]
 
 
@@ -146,7 +147,7 @@ class DecTrain(C.Structure):
         ("Q", _f32p), ("ALIGN", _f32p), ("CUM", _f32p), ("cum_work", _f32p), ("attn_ws", _f32p),
         ("bf16", C.c_int), ("Wa_rec16", C.c_void_p), ("Wd_cat16", C.c_void_p),
         ("HA16", C.c_void_p), ("HD16", C.c_void_p), ("CTX16", C.c_void_p),
-        ("memory16", C.c_void_p),
+        ("memory16", C.c_void_p), ("Wq16", C.c_void_p),
     ]
 
 
@@ -774,7 +775,7 @@ def attn_bwd_ws_floats(B, Ti):
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,
-                       bf16=False, memory16=None):
+                       bf16=False, memory16=None, Wq16=None):
     lib = load()
     a = AttnFwd()
     B, Ti, E = memory.shape
@@ -797,6 +798,8 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
     a.loc_split_bf16 = 1 if bf16 else 0
     if memory16 is not None:
         a.memory16 = ptr(_fullc(memory16), torch.bfloat16)
+    if Wq16 is not None:
+        a.Wq16 = ptr(_fullc(Wq16), torch.bfloat16)
     _check(lib.t2amd_attention_step_fwd_f32(C.byref(a), _stream()), "t2amd_attention_step_fwd_f32")
 
 

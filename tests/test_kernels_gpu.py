@@ -445,6 +445,14 @@ def test_attention_forward_backward(nv, B, Ti, E, Hq, bf16):
                           memory16=mem16)
     ftol = 1e-4 if bf16 else 1e-5         # bf16=True: location conv as a split-bf16 product (~2^-17 per product)
     assert err(w_out, w) < ftol
+    if bf16 and Hq % 128 == 0:            # the query product from a bf16 copy of W_q: exact against the same rounding
+        q16 = torch.empty(B, 128, device=DEV)
+        cum2, w2, c2 = dv(cum.clone()), torch.empty(B, Ti, device=DEV), torch.empty(B, E, device=DEV)
+        nv.attention_step_fwd(hd, Wq, U, v, pmd, memd, lens32, wpd, cum2, torch.empty(B, Ti, device=DEV), w2, c2, q16, ws,
+                              bf16=True, memory16=mem16, Wq16=Wq.bfloat16())
+        Wq_r = sd['decoder.attention_layer.query_layer.linear_layer.weight'].bfloat16().float()
+        assert err(q16, h @ Wq_r.t()) < 1e-5
+        assert err(w2, w) < 2e-2
     if bf16:        # context from bf16-rounded rows: exact against the same rounding, bf16-class against f32 rows
         assert err(ctx_out, torch.bmm(w_out.cpu().unsqueeze(1), mem.bfloat16().float()).squeeze(1)) < 1e-5
         assert err(ctx_out, ctx) < 5e-3
