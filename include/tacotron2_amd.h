@@ -269,6 +269,8 @@ typedef struct t2amd_skinny_gemm {
     const uint8_t* keep;      /* [B][ld_keep] keep mask or NULL */
     long long ld_keep;
     float keep_scale;
+    void* Y16;                /* optional bf16 copy of Y (first split only), row stride ldy16 */
+    long long ldy16;
 } t2amd_skinny_gemm;
 
 int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream);
@@ -559,6 +561,15 @@ typedef struct t2amd_dec_infer {
     int* out_lengths;      /* [B] frames emitted incl. the stopping frame (0 while running) */
     uint8_t* active;       /* [B] 1 while the utterance is still decoding */
     int* done_count;       /* [1] number of finished utterances */
+    /* bf16 operand mode for the two LSTM products at B > 8 (all NULL / 0 for f32; ignored at B <= 8, whose
+     * matrix-vector kernels stay f32): bf16 copies of the packed weights and of the recurrent operands, written
+     * by their producers next to the f32 values; state, gates, attention and outputs stay f32. */
+    int bf16;
+    const void* Wa_cat16;  /* [4Ha][P+E+Ha] bf16 */
+    const void* Wd_cat16;  /* [4Hd][Ha+E+Hd] bf16 */
+    void* x_prenet16;      /* [B][P] bf16: prenet output of the current step */
+    void* h_a16;           /* [2][B][Ha] bf16 ping-pong (zeroed before t0 == 0) */
+    void* hc16;            /* [2][B][Hd+E] bf16 ping-pong (zeroed before t0 == 0) */
 } t2amd_dec_infer;
 
 int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);

@@ -485,6 +485,10 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
     T2_REQUIRE(p->W1 && p->W2 && p->Wa_cat && p->bias_a && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->attn_ws &&
                    p->Wpg && p->bias_pg && p->memory && p->pm && p->keep_prenet,
                "dec_infer: null weights/inputs");
+    if (p->bf16 && B > 8) {
+        T2_REQUIRE(p->Wa_cat16 && p->Wd_cat16 && p->x_prenet16 && p->h_a16 && p->hc16, "dec_infer: bf16 mode needs the bf16 buffers");
+        T2_REQUIRE(E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0 && P % 128 == 0, "dec_infer: bf16 mode needs E, Ha, Hd, P multiples of 128");
+    }
     T2_REQUIRE(p->h_a && p->c_a && p->c_d && p->hc && p->cum && p->x_prenet && p->gates && p->zero_frame && p->PG &&
                    p->ALIGN && p->out_lengths && p->active && p->done_count,
                "dec_infer: null state/outputs");
@@ -502,6 +506,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         g1.M = B; g1.N = P; g1.K = C; g1.a_kcontig = 1; g1.b_kcontig = 1; g1.batch = 1; g1.splitk = 1;
         g1.act = 1; g1.keep = p->keep_prenet + ((long long)t * 2 + 0) * sP; g1.ldkeep = P; g1.keep_scale = two;
         const bool small = B <= 8;        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
+        const bool use16 = !small && p->bf16 != 0;
         t2amd_gemm_desc g2 = {};
         g2.A = p->x_prenet; g2.lda = P; g2.B = p->W2; g2.ldb = P; g2.C = p->x_prenet + sP; g2.ldc = P;
         g2.M = B; g2.N = P; g2.K = P; g2.a_kcontig = 1; g2.b_kcontig = 1; g2.batch = 1; g2.splitk = 1;
@@ -528,6 +533,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             s2.W = p->W2; s2.Ktot = P; s2.N = P; s2.B = B;
             s2.Y = p->x_prenet + sP; s2.ldy = P; s2.nsplit = 1;
             s2.act = 1; s2.keep = g2.keep; s2.ld_keep = P; s2.keep_scale = two;
+            if (use16) { s2.Y16 = p->x_prenet16; s2.ldy16 = P; }
             T2_PROPAGATE(t2amd_skinny_gemm_f32(&s2, stream));
         }
 
@@ -544,6 +550,15 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         a.c_out = p->c_a + wr * sHa; a.ld_c = Ha;
         a.h_out = p->h_a + wr * sHa; a.ld_h = Ha;
         a.tag = 1;
+        if (use16) {
+            unsigned short* ha16 = (unsigned short*)p->h_a16;
+            unsigned short* hc16 = (unsigned short*)p->hc16;
+            a.x[0].p = (const float*)p->x_prenet16;
+            a.x[1].p = (const float*)(hc16 + rd * sHC + Hd);
+            a.x[2].p = (const float*)(ha16 + rd * sHa);
+            a.W = (const float*)p->Wa_cat16; a.bf16 = 1;
+            a.h16_out = (void*)(ha16 + wr * sHa); a.ld_h16 = Ha;
+        }
         T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&a, stream) : t2amd_lstm_step_fwd_f32(&a, stream));
 
         t2amd_attn_fwd at = {};
@@ -556,6 +571,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)p->max_steps * Ti;
         at.ctx_out = p->hc + wr * sHC + Hd; at.ld_ctx = Hd + E;
         at.q_out = nullptr;
+        if (use16) { at.ctx16_out = (void*)((unsigned short*)p->hc16 + wr * sHC + Hd); at.ld_ctx16 = Hd + E; }
         T2_PROPAGATE(t2amd_attention_step_fwd_f32(&at, stream));
 
         t2amd_lstm_step d = {};
@@ -570,6 +586,15 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         d.c_out = p->c_d + wr * sHd; d.ld_c = Hd;
         d.h_out = p->hc + wr * sHC; d.ld_h = Hd + E;
         d.tag = 2;
+        if (use16) {
+            unsigned short* ha16 = (unsigned short*)p->h_a16;
+            unsigned short* hc16 = (unsigned short*)p->hc16;
+            d.x[0].p = (const float*)(ha16 + wr * sHa);
+            d.x[1].p = (const float*)(hc16 + wr * sHC + Hd);
+            d.x[2].p = (const float*)(hc16 + rd * sHC);
+            d.W = (const float*)p->Wd_cat16; d.bf16 = 1;
+            d.h16_out = (void*)(hc16 + wr * sHC); d.ld_h16 = Hd + E;
+        }
         T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&d, stream) : t2amd_lstm_step_fwd_f32(&d, stream));
 
         // frame + gate: PG[t] = [h_dec | ctx] . Wpg^T + bias

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
                 if (p.act == 1) v = fmaxf(v, 0.f);
                 if (p.keep) v = p.keep[(long long)gr * p.ld_keep + gn] ? v * p.keep_scale : 0.f;
                 Y[(long long)gr * p.ldy + gn] = v;
+                if (p.h16_out) p.h16_out[(long long)gr * p.ld_h16 + gn] = t2_f32_to_bf16(v);
             }
         }
         return;
@@ -690,6 +691,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
                 if (p.act == 1) o = fmaxf(o, 0.f);
                 if (p.keep) o = p.keep[(long long)gr * p.ld_keep + gn] ? o * p.keep_scale : 0.f;
                 Y[gn] = o;
+                if (p.h16_out) p.h16_out[(long long)gr * p.ld_h16 + gn] = t2_f32_to_bf16(o);
             }
         }
         SW_TS(5);
@@ -832,6 +834,8 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     T2_REQUIRE((!a->bias && !a->act && !a->keep) || a->nsplit == 1, "skinny_gemm: the bias/act/keep epilogue needs nsplit == 1");
     T2_REQUIRE(a->act == 0 || a->act == 1, "skinny_gemm: act must be 0 or 1");
     p.bias = a->bias; p.act = a->act; p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
+    T2_REQUIRE(!a->Y16 || a->nsplit == 1, "skinny_gemm: the bf16 copy of Y needs nsplit == 1");
+    p.h16_out = (unsigned short*)a->Y16; p.ld_h16 = a->ldy16;       // plain epilogue: bf16 copy of Y
     const int ktiles = a->Ktot / (a->bf16 ? 128 : 64);
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     p.gx = t2_cdiv(a->N, 16); p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = a->nsplit;

@@ -715,7 +715,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     for n, p in P.items():
         if p.dtype != torch.float32:
             raise NativeError("parameter %s is %s: this build of the engine computes in fp32" % (n, p.dtype))
-    run = _Run(dev)
+    run = _Run(dev, getattr(model, 'precision', 'fp32'))
     ms = MaskSource(model.dropout_masks, dev)
     B, Ti = text.shape
     E = hp.encoder_embedding_dim
@@ -817,6 +817,14 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     d.active = nv.ptr(active, torch.uint8)
     d.done_count = nv.ptr(done, torch.int32)
 
+    if run.bf16 and B > 8:
+        # bf16 operand mode of the two LSTM products (the matrix-vector path of B <= 8 stays f32)
+        i16 = dict(Wa_cat16=run.cast16(Wa_cat), Wd_cat16=run.cast16(Wd_cat), x_prenet16=run.empty16(B, Pd),
+                   h_a16=torch.zeros(2, B, Ha, dtype=torch.bfloat16, device=dev),
+                   hc16=torch.zeros(2, B, Hd + E, dtype=torch.bfloat16, device=dev))
+        d.bf16 = 1
+        for k_, v_ in i16.items():
+            setattr(d, k_, nv.ptr(v_, torch.bfloat16))
     t = 0
     while t < max_steps:
         n = min(poll_steps, max_steps - t)

@@ -72,6 +72,7 @@ class SkinnyGemm(C.Structure):
         ("Y", _f32p), ("ldy", _i64), ("nsplit", C.c_int), ("split_stride", _i64), ("tag", C.c_int),
         ("bf16", C.c_int),
         ("bias", _f32p), ("act", C.c_int), ("keep", C.c_void_p), ("ld_keep", _i64), ("keep_scale", C.c_float),
+        ("Y16", C.c_void_p), ("ldy16", _i64),
     ]
 
 
@@ -197,6 +198,8 @@ class DecInfer(C.Structure):
         ("x_prenet", _f32p), ("gates", _f32p), ("zero_frame", _f32p), ("attn_ws", _f32p),
         ("PG", _f32p), ("ALIGN", _f32p), ("out_lengths", C.c_void_p), ("active", C.c_void_p),
         ("done_count", C.c_void_p),
+        ("bf16", C.c_int), ("Wa_cat16", C.c_void_p), ("Wd_cat16", C.c_void_p),
+        ("x_prenet16", C.c_void_p), ("h_a16", C.c_void_p), ("hc16", C.c_void_p),
     ]
 
 

@@ -343,3 +343,40 @@ def test_single_value_batchnorm_is_refused_like_the_reference(native_lib):
     x, _ = model.parse_batch(tuple(t.clone() for t in batch))
     with pytest.raises(ValueError, match="more than 1 value per channel"):
         model(x)
+
+
+def test_bf16_compute_mode_batched_inference():
+    """model.precision = 'bf16' in inference: dense GEMMs on the bf16 MFMA and, at B > 8, bf16 operands for the two
+    LSTM products (wide kernel).  Same weights, texts and prenet dropout stream as an fp32 run; forced 40 steps
+    (threshold above 1), so the outputs are compared frame by frame with a bf16-class tolerance."""
+    import torch
+    from tacotron2_amd.hparams import create_hparams
+    from tacotron2_amd.model import Tacotron2
+    dev = torch.device("cuda", 0)
+    hp = create_hparams()
+    hp.max_decoder_steps = 40
+    hp.gate_threshold = 2.0
+    torch.manual_seed(77)
+    m = Tacotron2(hp).to(dev).eval()
+    B, Ti = 12, 50
+    g = torch.Generator().manual_seed(78)
+    lens = torch.randint(20, Ti + 1, (B,), generator=g).sort(descending=True)[0]
+    lens[0] = Ti
+    text = torch.zeros(B, Ti, dtype=torch.long)
+    for b in range(B):
+        text[b, :lens[b]] = torch.randint(1, 148, (int(lens[b]),), generator=g)
+    outs = []
+    for prec in ("fp32", "bf16"):
+        m.precision = prec
+        torch.manual_seed(79)                 # same Philox stream for the always-on prenet dropout
+        with torch.no_grad():
+            o = m.inference(text.to(dev), lens.to(dev))
+        outs.append([t.float().cpu() for t in o[:4]])
+    m.precision = "fp32"
+    (mel32, post32, gate32, al32), (mel16, post16, gate16, al16) = outs
+    assert mel32.shape == mel16.shape == (B, hp.n_mel_channels, 40)
+    scale = mel32.abs().mean().item()
+    assert (mel16 - mel32).abs().mean().item() < 2e-2 * max(scale, 1e-3)
+    assert (al16 - al32).abs().max().item() < 2e-2
+    assert torch.isfinite(post16).all()
+

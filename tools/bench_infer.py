@@ -15,13 +15,15 @@ from tacotron2_amd.synth import synth_lengths
 
 dev = torch.device("cuda")
 native.load()
-out = {}
+PREC = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "fp32"
+out = {"precision": PREC}
 for name, B, steps in (("config4_B1", 1, 1000), ("B16", 16, 400), ("config5_B256", 256, 400)):
     hp = create_hparams()
     hp.max_decoder_steps = steps
     hp.gate_threshold = 2.0
     torch.manual_seed(1234)
     m = Tacotron2(hp).to(dev).eval()
+    m.precision = PREC
     if B == 1:
         text = torch.randint(1, 148, (1, 100), device=dev)
         lens = None
@@ -43,4 +45,4 @@ for name, B, steps in (("config4_B1", 1, 1000), ("B16", 16, 400), ("config5_B256
     out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt, "utterance_steps_per_s": B * T / dt}
     print(name, json.dumps(out[name]), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/bench_infer.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/bench_infer_%s.json" % PREC, "w"), indent=1)
