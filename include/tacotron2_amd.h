@@ -218,7 +218,8 @@ typedef struct t2amd_lstm_step {
     int tag;            /* kernel-symbol / profiling role: 0 generic, 1 attention LSTM, 2 decoder LSTM, 3 fused pair */
     /* bf16 operand mode: x[i].p and W point at bf16 (widths / ld / Ktot count ELEMENTS, widths multiples of 128);
      * the product runs on v_mfma_f32_16x16x32_bf16 with f32 accumulation; gin, bias, cell state and all f32
-     * outputs are unchanged.  h16_out (optional) receives a bf16 copy of h, the next step's operand. */
+     * outputs are unchanged.  h16_out (optional) receives a bf16 copy of h, the next step's operand.
+     * t2amd_lstm_step_small_f32 accepts 0 or 2: 2 = W alone is bf16, x[i].p stay f32 (matrix-vector path). */
     int bf16;
     void* h16_out;
     long long ld_h16;
@@ -561,9 +562,10 @@ typedef struct t2amd_dec_infer {
     int* out_lengths;      /* [B] frames emitted incl. the stopping frame (0 while running) */
     uint8_t* active;       /* [B] 1 while the utterance is still decoding */
     int* done_count;       /* [1] number of finished utterances */
-    /* bf16 operand mode for the two LSTM products at B > 8 (all NULL / 0 for f32; ignored at B <= 8, whose
-     * matrix-vector kernels stay f32): bf16 copies of the packed weights and of the recurrent operands, written
-     * by their producers next to the f32 values; state, gates, attention and outputs stay f32. */
+    /* bf16 operand mode for the two LSTM products (all NULL / 0 for f32): bf16 copies of the packed weights and,
+     * for B > 8 (MFMA path), of the recurrent operands, written by their producers next to the f32 values; the
+     * matrix-vector kernels of B <= 8 read the bf16 weight rows against f32 inputs.  State, gates, attention and
+     * outputs stay f32. */
     int bf16;
     const void* Wa_cat16;  /* [4Ha][P+E+Ha] bf16 */
     const void* Wd_cat16;  /* [4Hd][Ha+E+Hd] bf16 */

@@ -31,12 +31,15 @@ struct SmallParams {
     // plain epilogue
     float* Y; long long ldy; int act;
     int xvec;            // 1: input rows are 16-byte aligned (float4 staging), 0: scalar staging
+    int w16;             // 1: W holds bf16 (ldw in elements)
     // optional stop test fused into the projection (plain epilogue): row `gate_row` is the gate logit
     int* out_lengths; uint8_t* active; int* done_count;
     int fin_t, fin_max_steps, gate_row; float fin_thr;
 };
 
-template <bool LSTM, int NB>
+// W16: the weight rows are bf16 (t2amd_lstm_step.bf16 == 2: weights only -- the input vectors, sums, cell and outputs
+// stay f32): a 16-byte load is eight k, the stream this kernel is bound by halves.
+template <bool LSTM, int NB, bool W16>
 __global__ __launch_bounds__(256) void small_batch_kernel(SmallParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xs = smem;                                   // [NB][Ktot]
@@ -85,7 +88,8 @@ __global__ __launch_bounds__(256) void small_batch_kernel(SmallParams p) {
             row = (long long)blockIdx.x * 16 + wave * 4 + u;
             if (row > p.N - 1) row = p.N - 1;                          // ragged last block: never stored
         }
-        wr[u] = reinterpret_cast<const float4*>(p.W + row * p.ldw);
+        wr[u] = W16 ? reinterpret_cast<const float4*>(reinterpret_cast<const unsigned short*>(p.W) + row * p.ldw)
+                    : reinterpret_cast<const float4*>(p.W + row * p.ldw);
     }
     __syncthreads();
 
@@ -95,7 +99,43 @@ __global__ __launch_bounds__(256) void small_batch_kernel(SmallParams p) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[u][b] = 0.f;
 
-    int k4 = lane;
+    if constexpr (W16) {
+        // units of 8 k (16 bytes of bf16): same two-pieces-in-flight structure
+        const int K8 = K >> 3;
+        auto fma8 = [&](const float4& wv, int b, int k8, float sacc) -> float {
+            const float4 x0 = *reinterpret_cast<const float4*>(&xs[(size_t)b * K + k8 * 8]);
+            const float4 x1 = *reinterpret_cast<const float4*>(&xs[(size_t)b * K + k8 * 8 + 4]);
+            const unsigned u0 = __float_as_uint(wv.x), u1 = __float_as_uint(wv.y), u2 = __float_as_uint(wv.z), u3 = __float_as_uint(wv.w);
+            sacc = fmaf(__uint_as_float(u0 << 16), x0.x, sacc); sacc = fmaf(__uint_as_float(u0 & 0xffff0000u), x0.y, sacc);
+            sacc = fmaf(__uint_as_float(u1 << 16), x0.z, sacc); sacc = fmaf(__uint_as_float(u1 & 0xffff0000u), x0.w, sacc);
+            sacc = fmaf(__uint_as_float(u2 << 16), x1.x, sacc); sacc = fmaf(__uint_as_float(u2 & 0xffff0000u), x1.y, sacc);
+            sacc = fmaf(__uint_as_float(u3 << 16), x1.z, sacc); sacc = fmaf(__uint_as_float(u3 & 0xffff0000u), x1.w, sacc);
+            return sacc;
+        };
+        int k8 = lane;
+        for (; k8 + 64 < K8; k8 += 128) {
+            float4 w0[4], w1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w0[u] = wr[u][k8];
+                w1[u] = wr[u][k8 + 64];
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u][b] = fma8(w1[u], b, k8 + 64, fma8(w0[u], b, k8, acc[u][b]));
+        }
+        for (; k8 < K8; k8 += 64) {
+            float4 w0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w0[u] = wr[u][k8];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u][b] = fma8(w0[u], b, k8, acc[u][b]);
+        }
+    }
+    int k4 = W16 ? K4 : lane;
     for (; k4 + 64 < K4; k4 += 128) {          // two 1-KiB pieces per row in flight: 8 loads before the first use
         float4 w0[4], w1[4];
 #pragma unroll
@@ -226,10 +266,13 @@ static int small_launch(const SmallParams& p, int grid, void* stream) {
 #define T2_SMALL_CASE(NB)                                                                                       \
     case NB:                                                                                                    \
         if ((int)lds > 64 * 1024 && (int)lds > g_small_lds && !t2amd_validate_only_flag_()) {                   \
-            (void)hipFuncSetAttribute((const void*)small_batch_kernel<LSTM, NB>,                                \
+            (void)hipFuncSetAttribute((const void*)small_batch_kernel<LSTM, NB, false>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+            (void)hipFuncSetAttribute((const void*)small_batch_kernel<LSTM, NB, true>,                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
         }                                                                                                       \
-        T2_LAUNCH((small_batch_kernel<LSTM, NB>), dim3(grid), dim3(256), lds, s, p);                            \
+        if (p.w16) T2_LAUNCH((small_batch_kernel<LSTM, NB, true>), dim3(grid), dim3(256), lds, s, p);           \
+        else T2_LAUNCH((small_batch_kernel<LSTM, NB, false>), dim3(grid), dim3(256), lds, s, p);                \
         break;
     switch (nb) {
         T2_SMALL_CASE(1)
@@ -260,6 +303,9 @@ extern "C" int t2amd_lstm_step_small_f32(const t2amd_lstm_step* a, void* stream)
     p.c_out = a->c_out; p.ld_c = a->ld_c; p.h_out = a->h_out; p.ld_h = a->ld_h;
     p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     p.lens = a->lens; p.t = a->t; p.xvec = 1;
+    T2_REQUIRE(a->bf16 == 0 || a->bf16 == 2, "lstm_step_small: bf16 must be 0 or 2 (bf16 weights, f32 inputs)");
+    T2_REQUIRE(a->bf16 == 0 || a->Ktot % 8 == 0, "lstm_step_small: bf16 weights need K % 8 == 0");
+    p.w16 = a->bf16 == 2 ? 1 : 0;
     t2amd_profile_mark_(a->tag, 0, (hipStream_t)stream);
     const int rc = small_launch<true>(p, a->H / 4, stream);
     t2amd_profile_mark_(a->tag, 1, (hipStream_t)stream);

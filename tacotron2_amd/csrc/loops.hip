@@ -507,6 +507,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         g1.act = 1; g1.keep = p->keep_prenet + ((long long)t * 2 + 0) * sP; g1.ldkeep = P; g1.keep_scale = two;
         const bool small = B <= 8;        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
         const bool use16 = !small && p->bf16 != 0;
+        const bool small16 = small && p->bf16 != 0 && p->Wa_cat16 && p->Wd_cat16;     // bf16 weight rows, f32 inputs
         t2amd_gemm_desc g2 = {};
         g2.A = p->x_prenet; g2.lda = P; g2.B = p->W2; g2.ldb = P; g2.C = p->x_prenet + sP; g2.ldc = P;
         g2.M = B; g2.N = P; g2.K = P; g2.a_kcontig = 1; g2.b_kcontig = 1; g2.batch = 1; g2.splitk = 1;
@@ -559,6 +560,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             a.W = (const float*)p->Wa_cat16; a.bf16 = 1;
             a.h16_out = (void*)(ha16 + wr * sHa); a.ld_h16 = Ha;
         }
+        if (small16) { a.W = (const float*)p->Wa_cat16; a.bf16 = 2; }
         T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&a, stream) : t2amd_lstm_step_fwd_f32(&a, stream));
 
         t2amd_attn_fwd at = {};
@@ -595,6 +597,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             d.W = (const float*)p->Wd_cat16; d.bf16 = 1;
             d.h16_out = (void*)(hc16 + wr * sHC); d.ld_h16 = Hd + E;
         }
+        if (small16) { d.W = (const float*)p->Wd_cat16; d.bf16 = 2; }
         T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&d, stream) : t2amd_lstm_step_fwd_f32(&d, stream));
 
         // frame + gate: PG[t] = [h_dec | ctx] . Wpg^T + bias

@@ -817,8 +817,9 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     d.active = nv.ptr(active, torch.uint8)
     d.done_count = nv.ptr(done, torch.int32)
 
-    if run.bf16 and B > 8:
-        # bf16 operand mode of the two LSTM products (the matrix-vector path of B <= 8 stays f32)
+    if run.bf16:
+        # bf16 operand mode of the two LSTM products: B > 8 reads bf16 weights and bf16 copies of the recurrent
+        # operands (wide MFMA kernel); the matrix-vector path of B <= 8 reads bf16 weight rows against f32 inputs
         i16 = dict(Wa_cat16=run.cast16(Wa_cat), Wd_cat16=run.cast16(Wd_cat), x_prenet16=run.empty16(B, Pd),
                    h_a16=torch.zeros(2, B, Ha, dtype=torch.bfloat16, device=dev),
                    hc16=torch.zeros(2, B, Hd + E, dtype=torch.bfloat16, device=dev))

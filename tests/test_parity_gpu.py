@@ -380,3 +380,29 @@ def test_bf16_compute_mode_batched_inference():
     assert (al16 - al32).abs().max().item() < 2e-2
     assert torch.isfinite(post16).all()
 
+
+def test_bf16_compute_mode_single_utterance_inference():
+    """B = 1 in bf16 mode: the matrix-vector LSTM kernels read bf16 weight rows against f32 inputs
+    (t2amd_lstm_step.bf16 = 2); forced 30 steps, compared with the fp32 run."""
+    from tacotron2_amd.hparams import create_hparams
+    from tacotron2_amd.model import Tacotron2
+    dev = torch.device("cuda", 0)
+    hp = create_hparams()
+    hp.max_decoder_steps = 30
+    hp.gate_threshold = 2.0
+    torch.manual_seed(81)
+    m = Tacotron2(hp).to(dev).eval()
+    text = torch.randint(1, 148, (1, 60), generator=torch.Generator().manual_seed(82)).to(dev)
+    outs = []
+    for prec in ("fp32", "bf16"):
+        m.precision = prec
+        torch.manual_seed(83)
+        with torch.no_grad():
+            o = m.inference(text)
+        outs.append([t.float().cpu() for t in o[:4]])
+    m.precision = "fp32"
+    mel32, mel16 = outs[0][0], outs[1][0]
+    assert mel32.shape == mel16.shape == (1, hp.n_mel_channels, 30)
+    assert (mel16 - mel32).abs().mean().item() < 2e-2 * max(mel32.abs().mean().item(), 1e-3)
+    assert (outs[1][3] - outs[0][3]).abs().max().item() < 2e-2
+
