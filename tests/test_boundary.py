@@ -99,3 +99,29 @@ def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens):
         assert o[0].shape[0] == len(in_lens)
     finally:
         native.set_validate_only(False)
+
+
+def test_splitk_policy_matches_library_tile_rule():
+    """engine._choose_splitk sizes split-K against the tile edge the library reports (t2amd_gemm_tile_size): for the
+    hot weight-gradient shapes the launch must fill whole rounds of 256 workgroups when it runs 256-tiles, and the
+    query itself is pure host logic (no GPU)."""
+    import math
+    from tacotron2_amd import native as nv, engine
+    nv.load()
+    # (M, N, K, precision, a_km, b_kn): decoder / attention LSTM wgrads, a postnet conv wgrad, the gate projection
+    shapes = [(4096, 2560, 55000, 2, True, True), (4096, 1792, 55000, 2, True, True), (512, 2560, 55000, 2, True, True),
+              (4096, 2560, 55000, 1, True, True), (81, 1536, 55000, 2, True, True), (55000, 512, 2560, 2, False, False)]
+    for M, N, K, prec, a_km, b_kn in shapes:
+        sk = engine._choose_splitk(M, N, K, 1, prec, a_km, b_kn)
+        assert 1 <= sk <= 64 and (sk == 1 or K // sk >= 256)
+        tile = nv.gemm_tile_size(M, N, prec, sk, a_km, b_kn)
+        assert tile in (128, 256)
+        wgs = math.ceil(M / tile) * math.ceil(N / tile) * sk
+        if tile == 256:
+            assert wgs >= 192
+            rounds = wgs / 256.0
+            assert rounds / math.ceil(rounds) >= 0.8, (M, N, sk, wgs)
+    # split-bf16 keeps both hi and lo images: only the weight-gradient layout may use the large tile
+    assert nv.gemm_tile_size(4096, 2560, 1, 3, False, True) == 128
+    assert nv.gemm_tile_size(4096, 2560, 0, 3, True, True) == 128
+
