@@ -1,3 +1,4 @@
+// Build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/probe/xcc_map tools/probe/xcc_map.hip ; run on the GPU box.
 // Prints which XCD (XCC_ID) and CU each workgroup of a 3-D grid lands on: tools only.
 #include <hip/hip_runtime.h>
 #include <cstdio>
