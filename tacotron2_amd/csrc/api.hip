@@ -130,18 +130,21 @@ extern "C" float t2amd_debug_graph_chain_(float* p, int n, int blocks, int reps,
     hipGraphExec_t ge = nullptr;
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) return -(float)e;
-    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(t2_nop_kernel, dim3(blocks), dim3(256), 0, s, p);
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(t2_nop_kernel, dim3(blocks < 0 ? -blocks : blocks), dim3(256), 0, s, p);
     e = hipStreamEndCapture(s, &g);
     if (e != hipSuccess) return -(float)e;
     e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     if (e != hipSuccess) return -(float)e;
-    hipGraphLaunch(ge, s);
-    hipStreamSynchronize(s);
+    // replay on the LEGACY DEFAULT stream when `blocks` is negative (capture is not allowed there, launching is)
+    hipStream_t ls = blocks < 0 ? nullptr : s;
+    e = hipGraphLaunch(ge, ls);
+    if (e != hipSuccess) return -(float)e;
+    hipStreamSynchronize(ls);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, s);
-    for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, s);
-    hipEventRecord(e1, s);
+    hipEventRecord(e0, ls);
+    for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, ls);
+    hipEventRecord(e1, ls);
     hipEventSynchronize(e1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);

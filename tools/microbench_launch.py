@@ -32,3 +32,7 @@ for blocks in (1, 256, 512):
     for n in (7, 70, 700):
         ms = g(x.data_ptr(), n, blocks, 200 if n < 100 else 20, C.c_void_p(side.cuda_stream))
         print("graph of %3d nodes, blocks %4d: %.2f us per replay = %.2f us per node" % (n, blocks, ms * 1e3, ms * 1e3 / n))
+# captured on the side stream, replayed on the legacy default stream (what a library called on torch's current stream does)
+ms = g(x.data_ptr(), 70, -256, 200, C.c_void_p(side.cuda_stream))
+print("graph of  70 nodes replayed on the default stream: %.2f us per node" % (ms * 1e3 / 70) if ms > 0 else "default-stream replay failed: HIP error %d" % int(-ms))
+
