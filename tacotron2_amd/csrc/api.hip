@@ -139,17 +139,17 @@ extern "C" float t2amd_debug_graph_chain_(float* p, int n, int blocks, int reps,
     hipStream_t ls = blocks < 0 ? nullptr : s;
     e = hipGraphLaunch(ge, ls);
     if (e != hipSuccess) return -(float)e;
-    hipStreamSynchronize(ls);
+    (void)hipStreamSynchronize(ls);
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, ls);
-    for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, ls);
-    hipEventRecord(e1, ls);
-    hipEventSynchronize(e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, ls);
+    for (int r = 0; r < reps; ++r) (void)hipGraphLaunch(ge, ls);
+    (void)hipEventRecord(e1, ls);
+    (void)hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
     return ms / reps;
 }
 
@@ -166,18 +166,18 @@ extern "C" float t2amd_debug_capture_end_(void* stream, int reps) {
     if (e != hipSuccess) return -(float)e;
     e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     if (e != hipSuccess) return -(float)e;
-    hipGraphLaunch(ge, s);
-    hipStreamSynchronize(s);
+    (void)hipGraphLaunch(ge, s);
+    (void)hipStreamSynchronize(s);
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, s);
-    for (int r = 0; r < reps; ++r) hipGraphLaunch(ge, s);
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) (void)hipGraphLaunch(ge, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
     return ms / reps;
 }
 
