@@ -576,6 +576,28 @@ typedef struct t2amd_dec_infer {
 
 int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Mel front end: element passes around the two GEMMs of
+ * TacotronSTFT.mel_spectrogram (reference layers.py:63-80, stft.py:77-105,
+ * audio_processing.py:78-84).  The contractions themselves are t2amd_gemm_f32 calls:
+ *   spec[n][2F] = frames . basis^T with frames = the padded signal viewed as [n][L] with
+ *   row stride hop (lda = hop < K: overlapping rows, no frame matrix), then
+ *   mel[n][n_mel] = mag[n][Fpad] . mel_basis[n_mel][Fpad]^T.
+ * ------------------------------------------------------------------------------------ */
+/* out[b][i] = y[b][reflect(i - pad)] for i < T + 2*pad (torch 'reflect': the edge sample is not repeated;
+ * needs pad < T), 0 for T + 2*pad <= i < Tout (row slack so that ldo can be a multiple of 4). */
+int t2amd_reflect_pad_f32(const float* y, long long ldy, float* out, long long ldo, int B, int T, int pad,
+                          int Tout, void* stream);
+/* The index rule of the kernel above, callable on the host: position in y[0..T) of offset i in [-T+1, 2T-2]. */
+long long t2amd_reflect_index(long long i, long long T);
+/* mag[r][f] = sqrt(spec[r][f]^2 + spec[r][F+f]^2) for f < F, 0 for F <= f < Fpad; rows <= 65535 per call. */
+int t2amd_stft_magnitude_f32(const float* spec, long long lds, float* mag, long long ldm, long long rows,
+                             int F, int Fpad, void* stream);
+/* out[b][m][j] = log(max(mel[(b*n + j)*ld + m], clip)): dynamic range compression + (frame, channel) transpose
+ * into the (B, n_mel, n) layout TextMelCollate pads. */
+int t2amd_mel_log_compress_f32(const float* mel, long long ld, float* out, int B, int n, int n_mel,
+                               float clip, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,6 +224,7 @@ SYMBOLS = [
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
+    "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
 ]
 
 _P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
@@ -278,6 +279,9 @@ def _argtypes():
         "t2amd_profile_enable": [_I, _I],
         "t2amd_profile_read": [pt(C.c_float), pt(C.c_int)],
         "t2amd_profile_event_overhead": [pt(C.c_float)],
+        "t2amd_reflect_pad_f32": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
+        "t2amd_stft_magnitude_f32": [_P, _L, _P, _L, _L, _I, _I, _P],
+        "t2amd_mel_log_compress_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
     }
 
 
@@ -307,6 +311,8 @@ def load():
         fn.argtypes = at
         fn.restype = C.c_int
     lib.t2amd_last_error.restype = C.c_char_p
+    lib.t2amd_reflect_index.argtypes = [_L, _L]
+    lib.t2amd_reflect_index.restype = C.c_longlong
     lib.t2amd_abi_version.restype = C.c_int
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
@@ -876,3 +882,44 @@ def lstm_seq_bwd(desc):
 def decoder_infer_steps(desc):
     lib = load()
     _check(lib.t2amd_decoder_infer_steps_f32(C.byref(desc), _stream()), "t2amd_decoder_infer_steps_f32")
+
+
+# ----------------------------------------------------------------------------
+# mel front end (csrc/audio.hip)
+# ----------------------------------------------------------------------------
+def reflect_index(i, T):
+    """Host copy of the kernel's reflect rule (no GPU needed)."""
+    return int(load().t2amd_reflect_index(int(i), int(T)))
+
+
+def reflect_pad(y, out, pad):
+    """out[b][:T+2*pad] = reflect-padded y[b]; the rest of each out row is zeroed.  y (B,T), out (B,Tout)."""
+    py, ldy, B, T = _mat(y)
+    po, ldo, B1, Tout = _mat(out)
+    if B1 != B:
+        raise NativeError("reflect_pad: batch mismatch %s vs %s" % (tuple(y.shape), tuple(out.shape)))
+    _check(load().t2amd_reflect_pad_f32(py, _i64(ldy), po, _i64(ldo), B, T, int(pad), Tout, _stream()),
+           "t2amd_reflect_pad_f32")
+
+
+def stft_magnitude(spec, mag, F):
+    """mag[r][:F] = |spec[r][:F] + i spec[r][F:2F]|, mag[r][F:] = 0.  Chunked to the grid limit."""
+    ps, lds, R, C2 = _mat(spec)
+    pm, ldm, R1, Fpad = _mat(mag)
+    if R1 != R or C2 < 2 * F or Fpad < F:
+        raise NativeError("stft_magnitude: shape mismatch spec=%s mag=%s F=%d" % (tuple(spec.shape), tuple(mag.shape), F))
+    lib = load()
+    for r0 in range(0, R, 65535):
+        rows = min(65535, R - r0)
+        _check(lib.t2amd_stft_magnitude_f32(ptr(spec[r0:]), _i64(lds), ptr(mag[r0:]), _i64(ldm), _i64(rows), int(F),
+                                            Fpad, _stream()), "t2amd_stft_magnitude_f32")
+
+
+def mel_log_compress(mel, out, clip):
+    """out (B, n_mel, n) = log(max(mel (B*n, n_mel), clip)) transposed per utterance."""
+    pm, ld, R, n_mel = _mat(mel)
+    B, n_mel1, n = out.shape
+    if n_mel1 != n_mel or B * n != R:
+        raise NativeError("mel_log_compress: shape mismatch mel=%s out=%s" % (tuple(mel.shape), tuple(out.shape)))
+    _check(load().t2amd_mel_log_compress_f32(pm, _i64(ld), ptr(_fullc(out)), B, n, n_mel, C.c_float(clip), _stream()),
+           "t2amd_mel_log_compress_f32")

@@ -18,3 +18,22 @@ def to_gpu(x):
     if torch.cuda.is_available():
         x = x.cuda(non_blocking=True)
     return x
+
+
+def load_filepaths_and_text(filename, split="|"):
+    """One list of fields per filelist line, e.g. ``["DUMMY/LJ001-0001.wav", "transcript"]``
+    (reference utils.py:18-21; the reference's filelists are pipe-separated)."""
+    rows = []
+    with open(filename, encoding='utf-8') as fh:
+        for line in fh:
+            rows.append(line.strip().split(split))
+    return rows
+
+
+def load_wav_to_torch(full_path):
+    """``(samples as float32 tensor in the file's integer range, sampling_rate)`` — reference
+    utils.py:13-15 (scipy.io.wavfile.read, no resampling, no scaling)."""
+    import numpy as np
+    from scipy.io.wavfile import read
+    sampling_rate, data = read(full_path)
+    return torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)), sampling_rate

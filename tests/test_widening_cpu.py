@@ -1,0 +1,229 @@
+"""CPU coverage of the rows widened after the hot path: mel front end oracle + tables,
+batch collation / dataset, training driver (checkpoint, warm start, resume, validation) and launcher.
+
+No GPU arithmetic here: the oracle is checked against the fixtures made from the reference
+(tests/golden/make_golden_audio.py); product host code runs in the library's validate-only mode
+(every argument check and host loop runs, no kernel is launched, values are meaningless)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from tacotron2_amd import native
+from tacotron2_amd.hparams import create_hparams
+
+
+def _golden(name):
+    return torch.load(os.path.join(gu.GOLDEN_DIR, name), weights_only=False)
+
+
+# ---- mel front end ------------------------------------------------------------------------------
+def test_audio_oracle_matches_reference_fixture():
+    from oracle import audio_oracle as ao
+    g = _golden("audio_demo.pt")
+    assert torch.equal(ao.mel_spectrogram(g["y"]), g["mel"])                 # fixture = reference stft.py/layers.py
+    assert torch.equal(ao.mel_spectrogram(g["y_odd"]), g["mel_odd"])
+    assert g["mel"].shape == (2, 80, 9000 // 256 + 1) and g["mel_odd"].shape == (1, 80, 4321 // 256 + 1)
+    assert torch.equal(ao.stft_magnitude(g["y"]).sum(dim=1), g["mag_row_sums"])
+
+
+def test_product_tables_match_oracle_and_reference_digest():
+    from oracle import audio_oracle as ao
+    from tacotron2_amd import audio
+    g = _golden("audio_demo.pt")
+    fb = audio.fourier_basis(1024, 1024)
+    assert fb.shape == (1026, 1024) and fb.dtype == np.float32
+    assert np.abs(fb - ao.forward_basis(1024, 1024)[:, 0, :].numpy()).max() <= 2 ** -23
+    assert torch.allclose(torch.from_numpy(fb).double().sum(dim=1), g["basis_digest"], atol=1e-4)
+    # win_length < filter_length: window centred in the frame
+    fb2 = audio.fourier_basis(16, 8)
+    assert np.abs(fb2 - ao.forward_basis(16, 8)[:, 0, :].numpy()).max() <= 2 ** -23
+    assert np.all(fb2[:, :4] == 0) and np.all(fb2[:, 12:] == 0)
+    for args in [(22050, 1024, 80, 0.0, 8000.0), (16000, 512, 40, 50.0, None), (22050, 1024, 128, 0.0, None)]:
+        a, b = audio.mel_filterbank(*args), ao.librosa_mel(*args)
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-14
+
+
+def test_mel_filterbank_structure():
+    """The table has no reference artefact to be pinned to (librosa is absent): check what the published
+    definition implies — triangles on the Slaney scale, unit area in Hz, linear spacing below 1 kHz."""
+    from tacotron2_amd import audio
+    fb = audio.mel_filterbank(22050, 1024, 80, 0.0, 8000.0)
+    assert fb.shape == (80, 513) and (fb >= 0).all()
+    hz = np.linspace(0, 22050 / 2, 513)
+    assert fb[:, hz > 8000.0 + 22050 / 1024].max() == 0.0
+    peaks = hz[fb.argmax(axis=1)]
+    assert np.all(np.diff(peaks) > 0)
+    for row in fb:                                           # single-peaked
+        nz = np.nonzero(row)[0]
+        assert np.all(np.diff(nz) == 1)
+        k = row.argmax()
+        assert np.all(np.diff(row[nz[0]:k + 1]) >= 0) and np.all(np.diff(row[k:nz[-1] + 1]) <= 0)
+    edges = audio._mel_to_hz(np.linspace(audio._hz_to_mel(0.0), audio._hz_to_mel(8000.0), 82))
+    low = edges[edges < 1000.0]
+    assert np.allclose(np.diff(low), np.diff(low)[0])        # linear part
+    assert abs(audio._hz_to_mel(1000.0) - 15.0) < 1e-12 and abs(audio._mel_to_hz(15.0) - 1000.0) < 1e-9
+    # area normalisation: integral of each triangle over Hz is 1 (sampled on the FFT grid -> approximately)
+    area = fb.sum(axis=1) * (hz[1] - hz[0])
+    assert np.all(np.abs(area[20:] - 1.0) < 0.15)
+
+
+def test_reflect_index_rule(native_lib):
+    T, pad = 37, 9
+    ref = torch.nn.functional.pad(torch.arange(T, dtype=torch.float32).view(1, 1, T), (pad, pad), mode='reflect').view(-1)
+    got = [native.reflect_index(i - pad, T) for i in range(T + 2 * pad)]
+    assert got == [int(v) for v in ref.tolist()]
+
+
+def test_audio_host_plumbing_validate_only(native_lib):
+    from tacotron2_amd.audio import TacotronSTFT
+    native.set_validate_only(True)
+    try:
+        stft = TacotronSTFT().cpu()
+        assert set(dict(stft.named_buffers())) >= {"mel_basis", "stft_fn.forward_basis"}
+        assert stft.mel_basis.shape == (80, 513) and stft.stft_fn.forward_basis.shape == (1026, 1, 1024)
+        for T in (9000, 4321, 513):
+            out = stft.mel_spectrogram(torch.zeros(3, T))
+            assert out.shape == (3, 80, T // 256 + 1)
+        assert stft.stft_fn.transform_magnitude(torch.zeros(2, 2048)).shape == (2, 513, 9)
+        with pytest.raises(ValueError):
+            stft.mel_spectrogram(torch.zeros(1, 512))        # cannot reflect-pad by 512
+        with pytest.raises(ValueError):
+            stft.mel_spectrogram(torch.zeros(4000))
+    finally:
+        native.set_validate_only(False)
+    with pytest.raises(native.NativeError):                  # no CPU path
+        TacotronSTFT().cpu().mel_spectrogram(torch.zeros(1, 4096))
+
+
+def test_audio_argument_errors(native_lib):
+    rc = native_lib.t2amd_reflect_pad_f32(None, 0, None, 0, 1, 10, 2, 14, None)
+    assert rc == 1 and b"null operand" in native_lib.t2amd_last_error()
+
+
+# ---- data path ----------------------------------------------------------------------------------
+def test_collate_matches_reference_fixture():
+    from tacotron2_amd.data_utils import TextMelCollate
+    g = _golden("collate.pt")
+    for r, ref in g["collated"].items():
+        out = TextMelCollate(r)(g["items"])
+        assert len(out) == 5
+        for a, b in zip(out, ref):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        assert out[2].shape[2] % r == 0
+    text, il, mel, gate, ol = TextMelCollate(1)(g["items"])
+    assert il.tolist() == sorted(il.tolist(), reverse=True)
+    for b in range(len(ol)):
+        assert gate[b, :ol[b] - 1].sum() == 0 and gate[b, ol[b] - 1:].min() == 1
+        assert mel[b, :, ol[b]:].abs().sum() == 0 and text[b, il[b]:].sum() == 0
+
+
+def test_loader_filelist_shuffle_npy_and_synthetic(tmp_path):
+    from tacotron2_amd.data_utils import TextMelLoader, TextMelCollate
+    g = _golden("collate.pt")
+    lines = []
+    for i in range(50):
+        p = tmp_path / ("f%d.npy" % i)
+        np.save(p, np.full((80, 5 + i % 7), float(i), dtype=np.float32))
+        lines.append("%s|%s" % (p, " ".join(str(1 + (i + k) % 147) for k in range(3 + i % 5))))
+    fl = tmp_path / "list.txt"
+    fl.write_text("\n".join(lines) + "\n", encoding="utf-8")
+    hp = create_hparams("load_mel_from_disk=True")
+    ds = TextMelLoader(str(fl), hp)
+    order = [int(os.path.basename(r[0])[1:-4]) for r in ds.audiopaths_and_text]
+    assert order == g["shuffle_1234"]                        # reference: random.seed(1234); random.shuffle
+    text, mel = ds[0]
+    i = order[0]
+    assert text.dtype == torch.int32 and text.tolist() == [1 + (i + k) % 147 for k in range(3 + i % 5)]
+    assert mel.shape == (80, 5 + i % 7) and float(mel[0, 0]) == float(i)
+    np.save(tmp_path / "bad.npy", np.zeros((40, 5), dtype=np.float32))
+    with pytest.raises(AssertionError):
+        ds.get_mel(str(tmp_path / "bad.npy"))
+    with pytest.raises(RuntimeError):
+        ds.get_text("plain words need a text frontend")
+    ds2 = TextMelLoader(str(fl), hp, text_to_sequence=lambda t, cleaners: [len(t), len(cleaners)])
+    assert ds2.get_text("abc").tolist() == [3, 1]
+    syn = TextMelLoader("synthetic:6:7", create_hparams())
+    assert len(syn) == 6
+    a, b = syn[2], syn[2]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[1].shape[0] == 80
+    assert 15 <= a[0].numel() <= 187 and 90 <= a[1].shape[1] <= 870 and int(a[0].min()) >= 1
+    batch = TextMelCollate(1)([syn[i] for i in range(6)])
+    assert batch[0].shape[0] == 6 and batch[2].shape[1] == 80
+
+
+# ---- training driver ----------------------------------------------------------------------------
+class _FiniteLoss(torch.nn.Module):
+    """Validate-only outputs are uninitialised memory: a criterion that is finite whatever they hold."""
+
+    def forward(self, out, targets):
+        return sum(torch.nan_to_num(o, nan=0.0, posinf=0.0, neginf=0.0).sum() for o in out[:3]) * 0.0 + 1.0
+
+
+def _finite_clip(params, max_norm):
+    for p in params:
+        if p.grad is not None:
+            p.grad.zero_()
+    return torch.tensor(0.5)
+
+
+def test_train_driver_checkpoint_resume_warm_start(native_lib, tmp_path, monkeypatch, capsys):
+    from tacotron2_amd import train as tr
+    monkeypatch.setattr(tr, "Tacotron2Loss", _FiniteLoss)
+    monkeypatch.setattr(torch.nn.utils, "clip_grad_norm_", _finite_clip)
+    native.set_validate_only(True)
+    try:
+        hpstr = gu.TINY_HP + ",batch_size=2,iters_per_checkpoint=2,epochs=2,training_files=synthetic:6:3:60," \
+                             "validation_files=synthetic:3:4:60"
+        out = tmp_path / "run"
+        last = tr.train(str(out), "logs", None, False, 1, 0, "g", create_hparams(hpstr), max_iterations=3)
+        assert last == 2
+        assert sorted(os.listdir(out)) == ["checkpoint_0", "checkpoint_2", "logs"]
+        ck = torch.load(out / "checkpoint_2", weights_only=False)
+        assert set(ck) == {"iteration", "state_dict", "optimizer", "learning_rate"} and ck["iteration"] == 2
+        assert len(ck["state_dict"]) == 84 and ck["learning_rate"] == 1e-3
+        recs = [json.loads(l) for l in open(out / "logs" / "scalars.jsonl")]
+        assert [r["iteration"] for r in recs if "training.loss" in r] == [0, 1, 2]
+        assert [r["iteration"] for r in recs if "validation.loss" in r] == [0, 2]
+        assert any(k.startswith("param.rms/decoder.") for k in recs[1])
+        # resume: next iteration is saved + 1, epoch offset from the loader length (3 batches per epoch)
+        last = tr.main(["-o", str(out), "-l", "logs", "-c", str(out / "checkpoint_2"), "--hparams", hpstr,
+                        "--max_iterations", "5"])
+        assert last == 4 and os.path.exists(out / "checkpoint_4")
+        assert "Epoch: 1" in capsys.readouterr().out
+        # warm start: every tensor from the checkpoint except the ignored layer
+        hp = create_hparams(hpstr)
+        torch.manual_seed(77)
+        m = tr.load_model(hp)
+        before = m.embedding.weight.detach().clone()
+        tr.warm_start_model(str(out / "checkpoint_2"), m, hp.ignore_layers)
+        sd = m.state_dict()
+        assert torch.equal(sd["embedding.weight"], before)
+        assert all(torch.equal(sd[k], v) for k, v in ck["state_dict"].items() if k != "embedding.weight")
+        tr.warm_start_model(str(out / "checkpoint_2"), m, [])
+        assert torch.equal(m.state_dict()["embedding.weight"], ck["state_dict"]["embedding.weight"])
+        opt = torch.optim.Adam(m.parameters(), lr=0.5)
+        _, opt, lr, it = tr.load_checkpoint(str(out / "checkpoint_2"), m, opt)
+        assert (lr, it) == (1e-3, 2) and len(opt.state_dict()["state"]) == 60
+        with pytest.raises(AssertionError):
+            tr.load_checkpoint(str(out / "nope"), m, opt)
+        # fp16_run selects the engine's bf16 compute mode (no Apex)
+        m16 = tr.load_model(create_hparams(hpstr + ",fp16_run=True"))
+        assert m16.precision == "bf16" and m16.decoder.attention_layer.score_mask_value == -65504.0
+    finally:
+        native.set_validate_only(False)
+    with pytest.raises(native.NativeError):                  # without validate-only there is no CPU path
+        tr.load_model(create_hparams(gu.TINY_HP)) if not torch.cuda.is_available() else (_ for _ in ()).throw(
+            native.NativeError("gpu box"))
+
+
+def test_launcher_child_commands():
+    from tacotron2_amd.multiproc import child_commands
+    cmds = child_commands(["-m", "tacotron2_amd.train", "-o", "out"], 4, "S", python="py")
+    assert len(cmds) == 4
+    for i, c in enumerate(cmds):
+        assert c[:5] == ["py", "-m", "tacotron2_amd.train", "-o", "out"]
+        assert c[5:] == ["--n_gpus=4", "--group_name=group_S", "--rank=%d" % i]
