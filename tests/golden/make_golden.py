@@ -245,7 +245,10 @@ def main():
     ref_model, ref_loss = import_reference()
     real_dropout = torch.nn.functional.dropout
     try:
+        only = set(sys.argv[1:])                      # optional: regenerate just the named cases
         for name, case in gu.CASES.items():
+            if only and name not in only:
+                continue
             if case['kind'] == 'train':
                 run_train_case(name, case, ref_model, ref_loss)
             else:

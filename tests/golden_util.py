@@ -26,6 +26,10 @@ TINY_HP = ("encoder_embedding_dim=128,symbols_embedding_dim=128,attention_rnn_di
 CASES = OrderedDict([
     ("tiny_train", dict(kind="train", hp=TINY_HP, seed=1234, in_lens=[12, 9, 5], out_lens=[20, 16, 11])),
     ("default_train", dict(kind="train", hp="", seed=1234, in_lens=[17, 11], out_lens=[30, 23])),
+    # mask_padding=False (reference model.py:490, hparams.py:85): padded frames keep their decoded values and
+    # contribute to the loss and to every gradient
+    ("tiny_train_nomask", dict(kind="train", hp=TINY_HP + ",mask_padding=False", seed=77, in_lens=[10, 7, 4],
+                               out_lens=[9, 18, 13])),
     ("default_infer", dict(kind="infer", hp="max_decoder_steps=40", seed=1234, in_lens=[13], steps=40)),
     ("tiny_infer_batched", dict(kind="infer_batched", hp=TINY_HP + ",max_decoder_steps=24", seed=4321,
                                 in_lens=[11, 8, 4], steps=24)),

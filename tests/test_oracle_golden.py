@@ -18,7 +18,7 @@ def _rel(a, b):
     return (a.double() - b.double()).abs().max().item() / max(1.0, b.double().abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["tiny_train", "default_train"])
+@pytest.mark.parametrize("name", ["tiny_train", "default_train", "tiny_train_nomask"])
 def test_oracle_train_matches_reference(name):
     fx = gu.load_fixture(name)
     hp = gu.make_hparams(fx['hp'])

@@ -115,3 +115,11 @@ def test_train_driver_runs_on_the_engine(native_lib, tmp_path):
     m = tr.load_model(create_hparams(hpstr))
     tr.warm_start_model(str(out / "checkpoint_4"), m, [])
     assert all(torch.equal(v.cpu(), ck["state_dict"][k].cpu()) for k, v in m.state_dict().items())
+
+
+def test_train_step_without_padding_mask(native_lib):
+    """hparams.mask_padding=False (reference model.py:490): padded frames keep their decoded values, carry loss
+    and gradient.  Same checks as the masked fixtures, against tests/golden/tiny_train_nomask.pt (made by the
+    reference) and the live oracle."""
+    import test_parity_gpu as tp
+    tp.test_train_step_matches_reference_and_oracle(native_lib, "tiny_train_nomask")
