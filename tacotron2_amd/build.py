@@ -40,6 +40,10 @@ def build(force=False, verbose=True, stamps=False):
         return STAMPS_OUT
     if not force and up_to_date():
         return OUT
+    if not force and os.path.exists(OUT) and not os.path.exists(HIPCC):
+        # a box without the toolchain: the library shipped with the snapshot is the only one there can be
+        print("tacotron2_amd.build: %s not found, using the shipped %s" % (HIPCC, OUT), file=sys.stderr)
+        return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [HIPCC] + FLAGS + ["-o", OUT] + SRC
     if verbose:

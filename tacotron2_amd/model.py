@@ -136,6 +136,27 @@ class Tacotron2(nn.Module):
         # 'fp32': exact-f32 MFMA forward (parity mode).  'bf16': matrix operands rounded to bf16, f32
         # accumulation, f32 master weights / cell state / saved activations (throughput mode, training only).
         self.precision = 'fp32'
+        self._output_dtype = None
+
+    # -- inference.ipynb cell 7: ``model.cuda().eval().half()`` -----------------------------------
+    def half(self):
+        """Reduced-precision mode without reduced-precision *storage*: the parameters stay f32 master
+        weights (the engine refuses anything else), the matrix products switch to the bf16 compute mode
+        and ``inference`` returns float16 tensors, so that the notebook's half-precision WaveGlow takes
+        ``mel_outputs_postnet`` unchanged (inference.ipynb cells 7, 13, 15)."""
+        self.precision = 'bf16'
+        self._output_dtype = torch.float16
+        return self
+
+    def bfloat16(self):
+        self.precision = 'bf16'
+        self._output_dtype = torch.bfloat16
+        return self
+
+    def float(self):
+        self.precision = 'fp32'
+        self._output_dtype = None
+        return super().float()
 
     # -- reference model.py:473-485 ---------------------------------------------------------
     def parse_batch(self, batch):
@@ -186,4 +207,6 @@ class Tacotron2(nn.Module):
         self.last_inference_lengths = lengths
         if hit_max:
             print("Warning! Reached max decoder steps")
+        if self._output_dtype is not None:
+            outs = [o.to(self._output_dtype) for o in outs]
         return outs

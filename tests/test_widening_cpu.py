@@ -227,3 +227,22 @@ def test_launcher_child_commands():
     for i, c in enumerate(cmds):
         assert c[:5] == ["py", "-m", "tacotron2_amd.train", "-o", "out"]
         assert c[5:] == ["--n_gpus=4", "--group_name=group_S", "--rank=%d" % i]
+
+
+def test_notebook_half_call_keeps_master_weights(native_lib):
+    """inference.ipynb cell 7 runs ``model.cuda().eval().half()``: parameters stay f32 (the engine's master
+    weights), the compute mode becomes bf16 and inference hands back float16 tensors (cells 13/15 feed them
+    to a half-precision WaveGlow); ``.float()`` restores the parity mode."""
+    from tacotron2_amd.model import Tacotron2
+    m = Tacotron2(create_hparams(gu.TINY_HP + ",max_decoder_steps=5"))
+    assert m.eval().half() is m and m.precision == "bf16"
+    assert all(p.dtype == torch.float32 for p in m.parameters())
+    native.set_validate_only(True)
+    try:
+        out = m.inference(torch.randint(1, 148, (1, 9)))
+        assert len(out) == 4 and all(o.dtype == torch.float16 for o in out)
+        assert out[0].shape[:2] == (1, 80) and out[2].shape[2] == 1 and out[3].shape[2] == 9
+        assert m.float() is m and m.precision == "fp32"
+        assert all(o.dtype == torch.float32 for o in m.inference(torch.randint(1, 148, (1, 9))))
+    finally:
+        native.set_validate_only(False)
