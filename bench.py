@@ -14,6 +14,7 @@ Extra objects in the JSON line:
                 launch stream during one extra, untimed, step.
   cpu_baseline  the CPU oracle (oracle/tacotron2_oracle.py, a port of the reference) timed on this
                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  inference     BASELINE's second metric, decode steps/s (configs 4 and 5), N=1 only; see inference_leg().
 """
 import argparse
 import json
@@ -36,6 +37,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true",
+                    help="skip the decode-steps/s leg (BASELINE configs 4/5) reported beside the training metric at N=1")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the extra fp32-mode timing that is reported beside a bf16 run")
     ap.add_argument("--precision", default="bf16", choices=("fp32", "bf16"),
@@ -74,6 +77,52 @@ def cpu_baseline(sample_b, seed, threads=16):
             "sample": "1 fwd+bwd step (no optimiser) of oracle/tacotron2_oracle.py on %d of the 64 utterances "
                       "(every %dth, Ti_max=%d, To_max=%d, %d valid frames), fp32, %.1f s"
                       % (sample_b, 64 // sample_b, Ti, To, frames, dt)}
+
+
+def inference_leg(dev):
+    """BASELINE configs 4 and 5 beside the headline (decode steps/s): B=1, Ti=100, 1000 forced steps (gate threshold
+    above 1 so the stop never fires: timing independent of the random weights) in both precision modes, and 256
+    LJSpeech-length texts, 400 forced steps, bf16 mode.  Second of two runs; the whole of Tacotron2.inference
+    (encoder + loop + postnet) is inside the timed region.  Roofline: algorithmic bytes per decode step = step
+    weights (18,189,969 parameters) at the operand width + the encoder memory and its projection
+    (Ti x 640 f32 per utterance), against 8 TB/s."""
+    from tacotron2_amd.hparams import create_hparams
+    from tacotron2_amd.model import Tacotron2
+    from tacotron2_amd.synth import synth_lengths
+    out = {}
+    for name, B, steps, prec in (("config4_B1_fp32", 1, 1000, "fp32"), ("config4_B1_bf16", 1, 1000, "bf16"),
+                                 ("config5_B256_bf16", 256, 400, "bf16")):
+        hp = create_hparams()
+        hp.max_decoder_steps = steps
+        hp.gate_threshold = 2.0
+        torch.manual_seed(1234)
+        m = Tacotron2(hp).to(dev).eval()
+        m.precision = prec
+        if B == 1:
+            ti = [100]
+            text = torch.randint(1, 148, (1, 100), device=dev)
+            lens = None
+        else:
+            ti, _ = synth_lengths(B, 1234)
+            text = torch.zeros(B, int(ti.max()), dtype=torch.long, device=dev)
+            for b in range(B):
+                text[b, :ti[b]] = torch.randint(1, 148, (int(ti[b]),), device=dev)
+            lens = torch.from_numpy(ti.copy()).to(dev)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                o = m.inference(text, lens) if lens is not None else m.inference(text)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        T = int(o[0].shape[2])
+        step_bytes = 18189969 * (2.0 if prec == "bf16" else 4.0) + 4.0 * 640 * float(sum(int(v) for v in ti))
+        gbs = step_bytes * T / dt / 1e9
+        out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt,
+                     "utterance_steps_per_s": B * T / dt, "precision": prec,
+                     "hbm_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": gbs, "frac": gbs / 8000.0}}
+        del m
+    return out
 
 
 def main():
@@ -269,6 +318,11 @@ def main():
             out["fp32_mode"] = fp32_leg
         if args.gpus == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1234, args.cpu_threads)
+        if args.gpus == 1 and not args.no_inference:
+            try:                                   # never let the secondary metric take the headline line down
+                out["inference"] = inference_leg(dev)
+            except Exception as e:                 # noqa: BLE001
+                out["inference"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
