@@ -205,3 +205,49 @@ extern "C" int t2amd_debug_attn_ts_(unsigned long long* out128) {
     return (int)hipMemcpy(out128, g_dbg_ts, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 
+
+// tools/microbench_barrier.py: cost of a device-scope barrier across `blocks` co-resident workgroups — the number that
+// decides whether a weight-stationary persistent decode step (DESIGN.md section 8, "next") pays.  One counter per round
+// (no reset race); thread 0 of every workgroup arrives with a release add and polls with acquire loads at agent
+// scope.  Every spin is BOUNDED: past 2^22 polls the workgroup raises status[0] and leaves, so a mistake cannot hang
+// the GPU.  `lds_bytes` of dynamic LDS pin the residency (e.g. 145000 -> one workgroup per CU).  clk[0] = wall-clock
+// ticks (100 MHz) workgroup 0 spent in `rounds` barriers.
+__global__ void __launch_bounds__(256) t2_grid_barrier_kernel(unsigned* counters, int rounds, unsigned long long* clk,
+                                                              int* status) {
+    extern __shared__ float t2_barrier_lds[];
+    if (threadIdx.x == 0) t2_barrier_lds[0] = 0.0f;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    bool bad = false;
+    for (int r = 0; r < rounds && !bad; ++r) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&counters[r], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(&counters[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                if (++spins > (1 << 22)) {
+                    atomicExch(status, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            t2_barrier_lds[0] = spins > (1 << 22) ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        bad = t2_barrier_lds[0] != 0.0f;
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = wall_clock64() - t0;
+}
+
+// counters: >= rounds zeroed uint32; clk: 1 uint64; status: 1 zeroed int32 (all device memory owned by the caller).
+extern "C" int t2amd_debug_grid_barrier_(unsigned* counters, int rounds, int blocks, int lds_bytes,
+                                         unsigned long long* clk, int* status, void* stream) {
+    if (!counters || !clk || !status || rounds < 1 || blocks < 1 || blocks > 2048 || lds_bytes < 4) return -1;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)t2_grid_barrier_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds_bytes) != hipSuccess)
+        return -2;
+    hipLaunchKernelGGL(t2_grid_barrier_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, counters, rounds,
+                       clk, status);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
