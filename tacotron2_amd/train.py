@@ -53,10 +53,11 @@ def init_distributed(hparams, n_gpus, rank, group_name):
     """Bind this process to its GPU and join the process group (reference train.py:27-39).
     ``hparams.dist_backend`` "nccl" is RCCL on ROCm; ``group_name`` is accepted for signature
     compatibility (torch >= 1.x ignores it)."""
-    if not torch.cuda.is_available():
-        raise AssertionError("Distributed mode requires an MI355X (torch.cuda.is_available() is False).")
     world, rank, local_rank, from_env = _env_rank_world(n_gpus, rank)
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    elif not native.validate_only():                          # CPU tests drive the loop with kernels switched off
+        raise AssertionError("Distributed mode requires an MI355X (torch.cuda.is_available() is False).")
     if dist.is_initialized():
         return
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL needs it on this driver
