@@ -598,6 +598,45 @@ int t2amd_stft_magnitude_f32(const float* spec, long long lds, float* mag, long 
 int t2amd_mel_log_compress_f32(const float* mel, long long ld, float* out, int B, int n, int n_mel,
                                float clip, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Optimiser step: global-norm clipping + Adam over all parameter
+ * tensors in two launches.  Replaces reference train.py:233-236
+ *   grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), grad_clip_thresh)
+ *   optimizer.step()                      # torch.optim.Adam(lr, weight_decay), train.py:170-171
+ * with torch's arithmetic (L2 weight decay folded into the gradient, bias-corrected moments,
+ * no amsgrad).  The state tensors (exp_avg, exp_avg_sq) are the ones torch.optim.Adam keeps, so
+ * the reference's checkpoint format (train.py:112-118) is unchanged.
+ * ------------------------------------------------------------------------------------ */
+#define T2AMD_MAX_TENSORS 64
+typedef struct t2amd_tensor_list {
+    void* param[T2AMD_MAX_TENSORS];        /* f32, updated in place (unused by t2amd_grad_norm_f32) */
+    const void* grad[T2AMD_MAX_TENSORS];   /* f32, read only: the clip factor is applied on the fly, p.grad is NOT rescaled */
+    void* exp_avg[T2AMD_MAX_TENSORS];      /* f32 first moment */
+    void* exp_avg_sq[T2AMD_MAX_TENSORS];   /* f32 second moment */
+    long long numel[T2AMD_MAX_TENSORS];
+    int first_block[T2AMD_MAX_TENSORS];    /* running sum of ceil(numel / t2amd_optim_chunk()) */
+    int count;
+} t2amd_tensor_list;
+
+typedef struct t2amd_adam_hyper {
+    float step_size;        /* lr / (1 - beta1^step) */
+    float bc2_sqrt;         /* sqrt(1 - beta2^step) */
+    float one_minus_beta1;
+    float beta2;
+    float one_minus_beta2;
+    float eps;
+    float weight_decay;     /* L2: g += weight_decay * p */
+} t2amd_adam_hyper;
+
+/* elements one workgroup covers (4096): callers size first_block[] and the workspace with it */
+int t2amd_optim_chunk(void);
+/* norm_and_coef[0] = ||all gradients||_2, [1] = min(1, max_norm / (norm + 1e-6)) (1 when max_norm <= 0).
+ * ws: >= total blocks doubles.  Deterministic (fixed summation order). */
+int t2amd_grad_norm_f32(const t2amd_tensor_list* L, float max_norm, double* ws, float* norm_and_coef, void* stream);
+/* One Adam step on every tensor of the list; gradients are scaled by norm_and_coef[1] when the pointer is non-NULL. */
+int t2amd_adam_step_f32(const t2amd_tensor_list* L, const t2amd_adam_hyper* h, const float* norm_and_coef,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

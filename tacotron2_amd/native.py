@@ -203,8 +203,22 @@ class DecInfer(C.Structure):
     ]
 
 
+MAX_TENSORS = 64
+
+
+class TensorList(C.Structure):
+    _fields_ = [("param", C.c_void_p * MAX_TENSORS), ("grad", C.c_void_p * MAX_TENSORS),
+                ("exp_avg", C.c_void_p * MAX_TENSORS), ("exp_avg_sq", C.c_void_p * MAX_TENSORS),
+                ("numel", C.c_longlong * MAX_TENSORS), ("first_block", C.c_int * MAX_TENSORS), ("count", C.c_int)]
+
+
+class AdamHyper(C.Structure):
+    _fields_ = [("step_size", C.c_float), ("bc2_sqrt", C.c_float), ("one_minus_beta1", C.c_float),
+                ("beta2", C.c_float), ("one_minus_beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float)]
+
+
 _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnBwd, DecTrain,
-            DecTrainBwd, LstmSeq, DecInfer, SmallLinear]
+            DecTrainBwd, LstmSeq, DecInfer, SmallLinear, TensorList, AdamHyper]
 
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
@@ -225,6 +239,7 @@ SYMBOLS = [
     "t2amd_set_decoder_streams", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
+    "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
 ]
 
 _P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
@@ -282,6 +297,9 @@ def _argtypes():
         "t2amd_reflect_pad_f32": [_P, _L, _P, _L, _I, _I, _I, _I, _P],
         "t2amd_stft_magnitude_f32": [_P, _L, _P, _L, _L, _I, _I, _P],
         "t2amd_mel_log_compress_f32": [_P, _L, _P, _I, _I, _I, _F, _P],
+        "t2amd_optim_chunk": [],
+        "t2amd_grad_norm_f32": [pt(TensorList), _F, _P, _P, _P],
+        "t2amd_adam_step_f32": [pt(TensorList), pt(AdamHyper), _P, _P],
     }
 
 
@@ -923,3 +941,48 @@ def mel_log_compress(mel, out, clip):
         raise NativeError("mel_log_compress: shape mismatch mel=%s out=%s" % (tuple(mel.shape), tuple(out.shape)))
     _check(load().t2amd_mel_log_compress_f32(pm, _i64(ld), ptr(_fullc(out)), B, n, n_mel, C.c_float(clip), _stream()),
            "t2amd_mel_log_compress_f32")
+
+
+# ----------------------------------------------------------------------------
+# optimiser step (csrc/optim.hip)
+# ----------------------------------------------------------------------------
+def _raw(t):
+    v = ptr(t)
+    return None if v is None else v.value
+
+
+def tensor_list(grads, params=None, exp_avgs=None, exp_avg_sqs=None):
+    """-> (TensorList, total_blocks).  Every tensor must be contiguous f32 (views at any offset are fine)."""
+    n = len(grads)
+    if not 0 < n <= MAX_TENSORS:
+        raise NativeError("tensor_list: 1..%d tensors per call, got %d" % (MAX_TENSORS, n))
+    chunk = int(load().t2amd_optim_chunk())
+    L = TensorList()
+    blocks = 0
+    for i in range(n):
+        g = _fullc(grads[i])
+        L.grad[i] = _raw(g)
+        L.numel[i] = g.numel()
+        L.first_block[i] = blocks
+        blocks += (g.numel() + chunk - 1) // chunk
+        for field, seq in (("param", params), ("exp_avg", exp_avgs), ("exp_avg_sq", exp_avg_sqs)):
+            if seq is not None:
+                t = _fullc(seq[i])
+                if t.numel() != g.numel():
+                    raise NativeError("tensor_list: %s[%d] has %d elements, gradient %d" % (field, i, t.numel(), g.numel()))
+                getattr(L, field)[i] = _raw(t)
+    L.count = n
+    return L, blocks
+
+
+def grad_norm(L, blocks, max_norm, ws, out):
+    """out[0] = global L2 norm of the gradients of L, out[1] = clip coefficient.  ws: float64, >= blocks."""
+    if ws.dtype != torch.float64 or ws.numel() < blocks or out.numel() < 2:
+        raise NativeError("grad_norm: workspace too small")
+    _check(load().t2amd_grad_norm_f32(C.byref(L), C.c_float(max_norm), ptr(ws, torch.float64), ptr(out), _stream()),
+           "t2amd_grad_norm_f32")
+
+
+def adam_step(L, hyper, norm_and_coef=None):
+    _check(load().t2amd_adam_step_f32(C.byref(L), C.byref(hyper), ptr(norm_and_coef) if norm_and_coef is not None else None,
+                                      _stream()), "t2amd_adam_step_f32")

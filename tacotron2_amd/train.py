@@ -182,10 +182,12 @@ def validate(model, criterion, valset, iteration, batch_size, n_gpus, collate_fn
 
 
 def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, rank, group_name, hparams,
-          max_iterations=None):
+          max_iterations=None, fused_optimizer=False):
     """The reference's loop (train.py:149-255): Adam(lr, weight_decay), global-norm clipping, validation
     + checkpoint every ``iters_per_checkpoint`` iterations.  ``max_iterations`` (not in the
-    reference) bounds the run for smoke tests and benchmarks.  Returns the last iteration index."""
+    reference) bounds the run for smoke tests and benchmarks.  ``fused_optimizer`` runs clipping + Adam as
+    two HIP launches (``optim.FusedAdam``: same state, same checkpoint format) instead of torch's
+    ``clip_grad_norm_`` + ``Adam.step``.  Returns the last iteration index."""
     if hparams.distributed_run:
         init_distributed(hparams, n_gpus, rank, group_name)
         n_gpus, rank, _, _ = _env_rank_world(n_gpus, rank)
@@ -196,7 +198,11 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
 
     model = load_model(hparams)
     learning_rate = hparams.learning_rate
-    optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, weight_decay=hparams.weight_decay)
+    if fused_optimizer:
+        from .optim import FusedAdam
+        optimizer = FusedAdam(model.parameters(), lr=learning_rate, weight_decay=hparams.weight_decay)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=learning_rate, weight_decay=hparams.weight_decay)
     criterion = Tacotron2Loss()
     logger = prepare_directories_and_logger(output_directory, log_directory, rank)
     train_loader, valset, collate_fn = prepare_dataloaders(hparams)
@@ -229,8 +235,11 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
             loss = criterion(model(x), y)
             shown = reduce_tensor(loss, n_gpus) if hparams.distributed_run else loss.detach()
             loss.backward()
-            grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), hparams.grad_clip_thresh)
-            optimizer.step()
+            if fused_optimizer:
+                grad_norm = optimizer.step(clip_norm=hparams.grad_clip_thresh)
+            else:
+                grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), hparams.grad_clip_thresh)
+                optimizer.step()
             # the whole step is enqueued: one host read for both scalars
             reduced_loss, grad_norm = (float(v) for v in torch.stack([shown.float(), grad_norm.float()]).tolist())
             finite = not (math.isnan(grad_norm) or math.isinf(grad_norm))
@@ -268,12 +277,15 @@ def main(argv=None):
     ap.add_argument('--group_name', type=str, default='group_name', help='Distributed group name')
     ap.add_argument('--hparams', type=str, help='comma separated name=value pairs')
     ap.add_argument('--max_iterations', type=int, default=None, help='stop after this many iterations')
+    ap.add_argument('--fused_optimizer', action='store_true',
+                    help='clip + Adam as two HIP launches (tacotron2_amd.optim.FusedAdam) instead of the torch pair')
     args = ap.parse_args(argv)
     hparams = create_hparams(args.hparams)
     print("bf16 compute mode (fp16_run):", hparams.fp16_run)
     print("Distributed Run:", hparams.distributed_run)
     return train(args.output_directory, args.log_directory, args.checkpoint_path, args.warm_start, args.n_gpus,
-                 args.rank, args.group_name, hparams, max_iterations=args.max_iterations)
+                 args.rank, args.group_name, hparams, max_iterations=args.max_iterations,
+                 fused_optimizer=args.fused_optimizer)
 
 
 if __name__ == '__main__':

@@ -246,3 +246,80 @@ def test_notebook_half_call_keeps_master_weights(native_lib):
         assert all(o.dtype == torch.float32 for o in m.inference(torch.randint(1, 148, (1, 9))))
     finally:
         native.set_validate_only(False)
+
+
+# ---- optimiser step -----------------------------------------------------------------------------
+def test_fused_adam_is_a_torch_adam_on_the_host_side(native_lib):
+    """State layout, state_dict interchange with torch.optim.Adam, step counting and refusals — kernels off."""
+    from tacotron2_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    flat = torch.randn(5000)
+    params = [torch.nn.Parameter(flat[1:4097 + 1].clone()), torch.nn.Parameter(torch.randn(1)),
+              torch.nn.Parameter(torch.randn(7, 13))]
+    native.set_validate_only(True)
+    try:
+        opt = FusedAdam(params, lr=1e-3, weight_decay=1e-6)
+        assert isinstance(opt, torch.optim.Adam)
+        assert opt.step() is None                                # no gradients yet
+        for p in params:
+            p.grad = torch.randn_like(p)
+        n = opt.step(clip_norm=1.0)
+        assert n.shape == () and n.dtype == torch.float32
+        opt.step()
+        st = opt.state[params[0]]
+        assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 2.0
+        assert st["exp_avg"].shape == params[0].shape
+        ref = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-6)
+        ref.load_state_dict(opt.state_dict())                    # fused -> torch
+        assert float(ref.state[params[2]]["step"]) == 2.0
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        ref.step()
+        opt2 = FusedAdam(params, lr=1e-3, weight_decay=1e-6)
+        opt2.load_state_dict(ref.state_dict())                   # torch -> fused
+        opt2.step(clip_norm=1.0)
+        assert float(opt2.state[params[1]]["step"]) == 4.0
+        L, blocks = native.tensor_list([p.grad for p in params])
+        assert blocks == 2 + 1 + 1 and list(L.first_block[:3]) == [0, 2, 3] and L.count == 3
+        with pytest.raises(native.NativeError):
+            native.tensor_list([torch.zeros(3)] * 65)
+        bad = FusedAdam([torch.nn.Parameter(torch.zeros(3))])
+        bad.param_groups[0]["amsgrad"] = True
+        bad.param_groups[0]["params"][0].grad = torch.zeros(3)
+        with pytest.raises(native.NativeError):
+            bad.step()
+        half = FusedAdam([torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))])
+        half.param_groups[0]["params"][0].grad = torch.zeros(3, dtype=torch.float64)
+        with pytest.raises(native.NativeError):
+            half.step()
+    finally:
+        native.set_validate_only(False)
+    # argument validation of the C entry points
+    L = native.TensorList()
+    rc = native_lib.t2amd_grad_norm_f32(ctypes_byref(L), 1.0, None, None, None)
+    assert rc == 1 and b"tensor count" in native_lib.t2amd_last_error()
+
+
+def ctypes_byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
+
+def test_train_driver_with_fused_optimizer_validate_only(native_lib, tmp_path, monkeypatch):
+    from tacotron2_amd import train as tr
+    monkeypatch.setattr(tr, "Tacotron2Loss", _FiniteLoss)
+    native.set_validate_only(True)
+    try:
+        hpstr = gu.TINY_HP + ",batch_size=2,iters_per_checkpoint=1,epochs=1,training_files=synthetic:4:3:60," \
+                             "validation_files=synthetic:2:4:60"
+        out = tmp_path / "run"
+        # gradients are uninitialised memory in this mode: only the plumbing (60 tensors -> one list, state, checkpoint)
+        tr.train(str(out), "logs", None, False, 1, 0, "g", create_hparams(hpstr), max_iterations=2, fused_optimizer=True)
+        files = sorted(os.listdir(out))
+        assert "logs" in files
+        ck = [f for f in files if f.startswith("checkpoint_")]
+        if ck:                                                   # written only when the garbage norm happened to be finite
+            st = torch.load(out / ck[0], weights_only=False)["optimizer"]["state"]
+            assert len(st) == 60 and set(st[0]) == {"step", "exp_avg", "exp_avg_sq"}
+    finally:
+        native.set_validate_only(False)
