@@ -148,8 +148,9 @@ def test_fused_adam_matches_torch_clip_and_adam(native_lib):
     torch.optim.Adam(lr, weight_decay) (train.py:170-171, 233-236), run on the CPU in float32 on the same tensors:
     odd sizes, a 1-element tensor, views at odd offsets of a flat buffer (the data-parallel bucket layout), chunk
     edges (4095 / 4096 / 4097 elements), one step with the clip active and two without.
-    Tolerance: |dp| < 1e-7 (an update is ~1e-3; float32 rounding of the few operations that may be fused
-    differently is ~1e-10), moments 1e-5 relative, norm 1e-5 relative."""
+    Tolerance: |dp| < 3e-7 (an update is ~1e-3 and float32 rounding of the few operations that may be fused
+    differently is ~1e-10, but one flipped rounding of p + dp costs an ulp of p: 1.2e-7 for |p| in [1, 2)),
+    moments 1e-5 relative, norm 1e-5 relative."""
     from tacotron2_amd.optim import FusedAdam
     gen = torch.Generator().manual_seed(21)
     sizes = [(4095,), (4096,), (4097,), (1,), (7, 13), (129, 257), (3, 5, 31), (10000,)]
@@ -185,7 +186,7 @@ def test_fused_adam_matches_torch_clip_and_adam(native_lib):
         for pc, pg, b in zip(cpu_params, gpu_params, before):
             assert torch.equal(pg.grad, b)                       # gradients are read, never rescaled in place
             d = (pg.detach().cpu() - pc.detach()).abs().max().item()
-            assert d < 1e-7, (it, tuple(pc.shape), d)
+            assert d < 3e-7, (it, tuple(pc.shape), d)
             for key in ("exp_avg", "exp_avg_sq"):
                 a, r = opt.state[pg][key].cpu(), ref.state[pc][key]
                 assert ((a - r).abs() <= 1e-5 * r.abs() + 1e-12).all(), (it, key, tuple(pc.shape))
