@@ -1,0 +1,19 @@
+#!/bin/bash
+# One gpurun call that (re)establishes the GPU evidence of a round:
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/round_gpu_check.sh r02_a'
+# Writes everything under gpurun_out/<tag>_*; copy what should be judged into profiles/.
+# rocprofv3: kernel-trace/stats and --pmc passes are separate runs (never combined with other trace domains).
+tag=${1:-rXX}
+out=gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -x -q > $out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_pytest_gpu.log
+tail -5 $out/${tag}_pytest_gpu.log
+python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; tail -c 600 $out/${tag}_bench.json
+timeout 120 python tools/microbench_barrier.py > $out/${tag}_barrier.txt 2>&1; cat $out/${tag}_barrier.txt
+timeout 300 python tools/microbench_audio.py > $out/${tag}_audio.json 2> $out/${tag}_audio.err; cat $out/${tag}_audio.json
+( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-fp32-leg --no-inference > $GRAFT_REPO_ROOT/$out/${tag}_bench_under_rocprof.json 2>/dev/null )
+find /tmp/prof_bench -name '*kernel_stats.csv' -exec cp {} $out/${tag}_kernel_stats_bf16.csv \;
+( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_audio -o audio -- python $GRAFT_REPO_ROOT/tools/microbench_audio.py > /dev/null 2>&1 )
+find /tmp/prof_audio -name '*kernel_stats.csv' -exec cp {} $out/${tag}_kernel_stats_audio.csv \;
+ls -la $out | tail -12
