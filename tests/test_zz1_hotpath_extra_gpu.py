@@ -1,0 +1,38 @@
+"""Hot-path cases added after the main parity suite (file names sort these last, least risky first):
+mask_padding=False against the reference fixture, and the notebook's ``.half()`` inference call."""
+import json
+import os
+
+import pytest
+import torch
+
+import golden_util as gu
+from tacotron2_amd.hparams import create_hparams
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_step_without_padding_mask(native_lib):
+    """hparams.mask_padding=False (reference model.py:490): padded frames keep their decoded values, carry loss
+    and gradient.  Same checks as the masked fixtures, against tests/golden/tiny_train_nomask.pt (made by the
+    reference) and the live oracle."""
+    import test_parity_gpu as tp
+    tp.test_train_step_matches_reference_and_oracle(native_lib, "tiny_train_nomask")
+
+
+def test_notebook_half_inference(native_lib):
+    """inference.ipynb cells 7 + 13: ``model.cuda().eval().half()`` then ``model.inference(sequence)``."""
+    from tacotron2_amd.model import Tacotron2
+    hp = create_hparams("max_decoder_steps=30")
+    torch.manual_seed(11)
+    model = Tacotron2(hp)
+    _ = model.cuda().eval().half()
+    seq = torch.randint(1, 148, (1, 21)).cuda().long()
+    mel, mel_post, gate, align = model.inference(seq)
+    torch.cuda.synchronize()
+    assert all(t.dtype == torch.float16 and t.is_cuda for t in (mel, mel_post, gate, align))
+    T = mel.shape[2]
+    assert 1 <= T <= 30 and mel_post.shape == mel.shape and gate.shape == (1, T, 1) and align.shape == (1, T, 21)
+    assert torch.isfinite(mel.float()).all() and torch.isfinite(mel_post.float()).all()
+    assert (align.float().sum(2) - 1).abs().max().item() < 5e-3        # float16 rounding of 21 weights
+    assert all(p.dtype == torch.float32 for p in model.parameters())
