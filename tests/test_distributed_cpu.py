@@ -110,7 +110,7 @@ def _train_worker(rank, world, port, outdir, q):
 
         class FiniteLoss(torch.nn.Module):
             def forward(self, out, targets):
-                return sum(torch.nan_to_num(o, nan=0.0, posinf=0.0, neginf=0.0).sum() for o in out[:3]) * 0.0 + 1.0 + rank
+                return sum(torch.nan_to_num(o, nan=0.0, posinf=0.0, neginf=0.0).clamp(-1.0, 1.0).sum() for o in out[:3]) * 0.0 + 1.0 + rank
 
         def finite_clip(params, max_norm):
             for p in params:

@@ -160,7 +160,7 @@ class _FiniteLoss(torch.nn.Module):
     """Validate-only outputs are uninitialised memory: a criterion that is finite whatever they hold."""
 
     def forward(self, out, targets):
-        return sum(torch.nan_to_num(o, nan=0.0, posinf=0.0, neginf=0.0).sum() for o in out[:3]) * 0.0 + 1.0
+        return sum(torch.nan_to_num(o, nan=0.0, posinf=0.0, neginf=0.0).clamp(-1.0, 1.0).sum() for o in out[:3]) * 0.0 + 1.0
 
 
 def _finite_clip(params, max_norm):
