@@ -1,0 +1,62 @@
+// TEST INFRASTRUCTURE ONLY — a host stand-in for <hip/hip_runtime.h>, just large enough to compile the
+// *element-wise* kernels of tacotron2_amd/csrc (audio.hip, optim.hip) for the CPU and execute them thread by thread
+// (tests/hip_emu/emu_runtime.cpp).  It lets the CPU test-suite run the very kernel source the GPU runs — index
+// arithmetic, bounds, reductions, rounding — when no GPU is at hand.  It is never built into, linked with or imported
+// by the product; MFMA / LDS-DMA / DPP kernels cannot be emulated here (their builtins are stubs that abort).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static          /* one workgroup runs at a time: block-shared = one static instance */
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_idx { unsigned x, y, z; };
+extern thread_local emu_idx threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void emu_syncthreads();
+void emu_exchange(const void* mine, void* partner, size_t bytes, int mask);   // wave-level xor exchange
+
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) emu_launch((grid), (block), [=]() { kern(__VA_ARGS__); })
+#define __syncthreads() emu_syncthreads()
+
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    (void)width;
+    T out;
+    emu_exchange(&v, &out, sizeof(T), mask);
+    return out;
+}
+
+// correctly rounded single operations (compile this target with -ffp-contract=off)
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline unsigned __float_as_uint(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float x; memcpy(&x, &u, 4); return x; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __sync_fetch_and_add(p, v); }
+static inline unsigned long long wall_clock64() { return 0; }
+
+// device-only builtins referenced by inline helpers of common.h that the emulated kernels never call
+static inline float __builtin_amdgcn_rcpf(float) { abort(); }
+static inline float __builtin_amdgcn_exp2f(float) { abort(); }
+static inline int __builtin_amdgcn_update_dpp(int, int, int, int, int, bool) { abort(); }
