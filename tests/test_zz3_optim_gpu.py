@@ -57,8 +57,8 @@ def test_fused_adam_matches_torch_clip_and_adam(native_lib):
             assert d < 3e-7, (it, tuple(pc.shape), d)
             for key in ("exp_avg", "exp_avg_sq"):
                 a, r = opt.state[pg][key].cpu(), ref.state[pc][key]
-                    # relative to the tensor's scale: a moment that cancels to ~0 has no relative precision of its own
-                    assert ((a - r).abs() <= 1e-5 * r.abs() + 1e-6 * r.abs().max()).all(), (it, key, tuple(pc.shape))
+                # relative to the tensor's scale: a moment that cancels to ~0 has no relative precision of its own
+                assert ((a - r).abs() <= 1e-5 * r.abs() + 1e-6 * r.abs().max()).all(), (it, key, tuple(pc.shape))
             assert float(opt.state[pg]["step"]) == float(ref.state[pc]["step"]) == it + 1
     # the neighbours of every view in the flat buffer were not touched
     off = 1
