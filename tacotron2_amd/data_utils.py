@@ -66,8 +66,9 @@ class TextMelLoader(torch.utils.data.Dataset):
             ti, to = synth_lengths(n, seed)
             if len(parts) > 3:                              # synthetic:N:seed:max_frames -> short utterances
                 cap = int(parts[3])
-                to = np.minimum(to, cap)
-                ti = np.minimum(ti, max(2, cap // 5))
+                k = np.arange(n)                                # keep the capped set ragged
+                to = np.maximum(2, np.minimum(to, cap) - k % 7)
+                ti = np.maximum(2, np.minimum(ti, max(2, cap // 5)) - k % 3)
             self.synthetic = (seed, ti, to)
             self.audiopaths_and_text = [['synthetic/%d' % i, ''] for i in range(n)]
         else:
