@@ -84,8 +84,8 @@ def inference_leg(dev):
     above 1 so the stop never fires: timing independent of the random weights) in both precision modes, and 256
     LJSpeech-length texts, 400 forced steps, bf16 mode.  Second of two runs; the whole of Tacotron2.inference
     (encoder + loop + postnet) is inside the timed region.  Roofline: algorithmic bytes per decode step = step
-    weights (18,189,969 parameters) at the operand width + the encoder memory and its projection
-    (Ti x 640 f32 per utterance), against 8 TB/s."""
+    weights (18,189,969 parameters) + the encoder memory and its projection (Ti x 640 per utterance), at the
+    operand width of the mode (SURVEY 8d / BASELINE.md 3.5), against 8 TB/s."""
     from tacotron2_amd.hparams import create_hparams
     from tacotron2_amd.model import Tacotron2
     from tacotron2_amd.synth import synth_lengths
@@ -116,7 +116,8 @@ def inference_leg(dev):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         T = int(o[0].shape[2])
-        step_bytes = 18189969 * (2.0 if prec == "bf16" else 4.0) + 4.0 * 640 * float(sum(int(v) for v in ti))
+        es = 2.0 if prec == "bf16" else 4.0                    # (W_step + sum_b Ti_b * 640) * s
+        step_bytes = es * (18189969 + 640 * float(sum(int(v) for v in ti)))
         gbs = step_bytes * T / dt / 1e9
         out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt,
                      "utterance_steps_per_s": B * T / dt, "precision": prec,
