@@ -39,22 +39,18 @@ class Tacotron2Logger(object):
                                  'learning.rate': learning_rate, 'duration': duration})
 
     def log_validation(self, reduced_loss, model, y, y_pred, iteration):
+        """``y`` / ``y_pred`` are accepted for signature compatibility (the reference plots them)."""
+        import torch
         stats = {'validation.loss': reduced_loss}
-        try:
-            import torch
+        named = list(model.named_parameters()) if model is not None else []
+        if named:
             with torch.no_grad():
-                names, means, rms = [], [], []
-                for name, p in model.named_parameters():
-                    names.append(name)
-                    means.append(p.detach().float().mean())
-                    rms.append(p.detach().float().pow(2).mean().sqrt())
-                if names:
-                    packed = torch.stack(means + rms).cpu().tolist()
-                    for i, name in enumerate(names):
-                        stats['param.mean/' + name] = packed[i]
-                        stats['param.rms/' + name] = packed[len(names) + i]
-        except Exception:
-            pass
+                means = [p.detach().float().mean() for _, p in named]
+                rms = [p.detach().float().pow(2).mean().sqrt() for _, p in named]
+                packed = torch.stack(means + rms).cpu().tolist()       # one device-to-host copy
+            for i, (name, _) in enumerate(named):
+                stats['param.mean/' + name] = packed[i]
+                stats['param.rms/' + name] = packed[len(named) + i]
         self._emit(iteration, **stats)
 
     def close(self):
