@@ -1,0 +1,58 @@
+"""Drop-in claim, executed: the reference's UNMODIFIED ``train.py`` (loaded from /root/reference at test time, never
+copied) runs its ``train()`` against this repository's modules — ``model``, ``hparams``, ``distributed``,
+``loss_function``, ``data_utils``, ``logger`` are resolved to ``tacotron2_amd.*`` through ``sys.modules`` — for one
+iteration including validation and checkpointing, with the kernels switched off (validate-only; the build container
+has no GPU, so ``nn.Module.cuda`` is made a no-op for the duration of the test).  Values are meaningless; what is
+pinned is every call, attribute and return shape the reference's loop relies on.
+
+Only runs where /root/reference exists (the build container); skipped elsewhere.
+"""
+import importlib.util
+import os
+import sys
+
+import pytest
+import torch
+
+import golden_util as gu
+from tacotron2_amd import native
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "train.py")), reason="reference tree not present")
+
+
+def test_reference_train_py_drives_our_modules(native_lib, tmp_path, monkeypatch, capsys):
+    import tacotron2_amd.data_utils
+    import tacotron2_amd.distributed
+    import tacotron2_amd.hparams
+    import tacotron2_amd.logger
+    import tacotron2_amd.loss_function
+    import tacotron2_amd.model
+    for name in ("model", "hparams", "distributed", "loss_function", "data_utils", "logger"):
+        monkeypatch.setitem(sys.modules, name, getattr(tacotron2_amd, name))
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    spec = importlib.util.spec_from_file_location("reference_train", os.path.join(REF, "train.py"))
+    ref_train = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_train)                      # the reference's file, as it lies under /root/reference
+    assert ref_train.Tacotron2 is tacotron2_amd.model.Tacotron2
+    if not torch.cuda.is_available():
+        monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+        monkeypatch.setattr(torch.cuda, "manual_seed", lambda seed: None)
+    native.set_validate_only(True)
+    try:
+        hp = ref_train.create_hparams(gu.TINY_HP + ",batch_size=2,epochs=1,iters_per_checkpoint=1,"
+                                      "training_files=synthetic:2:3:40,validation_files=synthetic:2:4:40")
+        out = tmp_path / "out"
+        ref_train.train(str(out), "logs", None, False, 1, 0, "group", hp)
+    finally:
+        native.set_validate_only(False)
+    text = capsys.readouterr().out
+    assert "Epoch: 0" in text and "Validation loss 0" in text and "Saving model and optimizer state at iteration 0" in text
+    ck = torch.load(out / "checkpoint_0", weights_only=False)
+    assert set(ck) == {"iteration", "state_dict", "optimizer", "learning_rate"} and len(ck["state_dict"]) == 84
+    # and back: the reference's loader functions read what was written
+    m = ref_train.load_model(hp) if torch.cuda.is_available() else tacotron2_amd.model.Tacotron2(hp)
+    opt = torch.optim.Adam(m.parameters(), lr=1.0)
+    m, opt, lr, it = ref_train.load_checkpoint(str(out / "checkpoint_0"), m, opt)
+    assert (lr, it) == (hp.learning_rate, 0)
+    ref_train.warm_start_model(str(out / "checkpoint_0"), m, hp.ignore_layers)
