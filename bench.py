@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true",
                     help="skip the decode-steps/s leg (BASELINE configs 4/5) reported beside the training metric at N=1")
+    ap.add_argument("--fused-optimizer", action="store_true",
+                    help="clip + Adam as two HIP launches (tacotron2_amd.optim.FusedAdam) instead of torch's "
+                         "clip_grad_norm_ + Adam.step (default until the fused pair has been measured)")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the extra fp32-mode timing that is reported beside a bf16 run")
     ap.add_argument("--precision", default="bf16", choices=("fp32", "bf16"),
@@ -169,7 +172,11 @@ def main():
     model.precision = args.precision
     if world > 1:
         model = apply_gradient_allreduce(model)
-    optimizer = torch.optim.Adam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    if args.fused_optimizer:
+        from tacotron2_amd.optim import FusedAdam
+        optimizer = FusedAdam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    else:
+        optimizer = torch.optim.Adam(model.parameters(), lr=hp.learning_rate, weight_decay=hp.weight_decay)
     criterion = Tacotron2Loss()
     model.train()
 
@@ -187,8 +194,11 @@ def main():
         y_pred = model(x)
         loss = criterion(y_pred, y)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), hp.grad_clip_thresh)
-        optimizer.step()
+        if args.fused_optimizer:
+            optimizer.step(clip_norm=hp.grad_clip_thresh)
+        else:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), hp.grad_clip_thresh)
+            optimizer.step()
         return loss
 
     for i in range(args.warmup):
@@ -306,6 +316,7 @@ def main():
                                    "synthetic LJSpeech-shaped batches (Ti<=187, To<=870), full train step "
                                    "(fwd+loss+bwd+clip+Adam)" % args.batch_size,
                        "global_batch": args.batch_size * args.gpus, "parallelism": "dp%d" % args.gpus,
+                       "optimizer": "FusedAdam (csrc/optim.hip)" if args.fused_optimizer else "torch clip_grad_norm_ + Adam",
                        "compute": ("bf16 matrix operands (MFMA bf16), f32 accumulation, f32 cell state / saved activations / "
                                    "master weights / optimiser" if args.precision == "bf16" else
                                    "fp32 storage; forward on the exact-f32 MFMA, gradient GEMMs on split-bf16 (x3) MFMA")},
