@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q > $out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_pytest_gpu.log
 tail -5 $out/${tag}_pytest_gpu.log
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; tail -c 600 $out/${tag}_bench.json
+python bench.py --fused-optimizer --no-inference --no-fp32-leg --cpu-sample 0 --no-roofline > $out/${tag}_bench_fused_optimizer.json 2>> $out/${tag}_bench.err; tail -c 400 $out/${tag}_bench_fused_optimizer.json
 timeout 120 python tools/microbench_barrier.py > $out/${tag}_barrier.txt 2>&1; cat $out/${tag}_barrier.txt
 timeout 300 python tools/microbench_audio.py > $out/${tag}_audio.json 2> $out/${tag}_audio.err; cat $out/${tag}_audio.json
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-fp32-leg --no-inference > $GRAFT_REPO_ROOT/$out/${tag}_bench_under_rocprof.json 2>/dev/null )
