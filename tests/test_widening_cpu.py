@@ -323,3 +323,27 @@ def test_train_driver_with_fused_optimizer_validate_only(native_lib, tmp_path, m
             assert len(st) == 60 and set(st[0]) == {"step", "exp_avg", "exp_avg_sq"}
     finally:
         native.set_validate_only(False)
+
+
+def test_bench_inference_leg_plumbing(native_lib, monkeypatch):
+    """bench.py's decode-steps/s leg (BASELINE configs 4/5) with the kernels off: shapes, forced step counts and the
+    JSON fields; the numbers are meaningless here.  (In bench.py the leg sits inside a try/except so that it can never
+    take the headline line down — which is exactly why its plumbing is pinned by a test.)"""
+    import importlib
+    import sys as _sys
+    _sys.path.insert(0, gu.ROOT)
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    native.set_validate_only(True)
+    try:
+        out = bench.inference_leg(torch.device("cpu"))
+    finally:
+        native.set_validate_only(False)
+    assert set(out) == {"config4_B1_fp32", "config4_B1_bf16", "config5_B256_bf16"}
+    # (the stop bookkeeping lives in device memory the kernels never wrote here: the step count itself is not checked)
+    assert 1 <= out["config4_B1_fp32"]["steps"] <= 1000 and 1 <= out["config5_B256_bf16"]["steps"] <= 400
+    b1 = out["config4_B1_bf16"]["hbm_roofline"]["algorithmic_bytes_per_step"]
+    assert b1 == 2.0 * (18189969 + 640 * 100)                          # 36.5 MB: SURVEY 8d's figure
+    for v in out.values():
+        assert v["decode_steps_per_s"] > 0 and 0 < v["hbm_roofline"]["frac"]
+        assert v["utterance_steps_per_s"] == pytest.approx(v["B"] * v["decode_steps_per_s"])
