@@ -17,6 +17,7 @@ Extra objects in the JSON line:
   inference     BASELINE's second metric, decode steps/s (configs 4 and 5), N=1 only; see inference_leg().
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -114,7 +115,9 @@ def inference_leg(dev):
         for _ in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            with torch.no_grad():
+            # the forced runs end at max_decoder_steps: the model's "Warning! Reached max decoder steps" line (reference
+            # model.py:446 prints it) must not land on stdout next to the ONE JSON line the driver reads
+            with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
                 o = m.inference(text, lens) if lens is not None else m.inference(text)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
