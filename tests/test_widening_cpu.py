@@ -325,7 +325,7 @@ def test_train_driver_with_fused_optimizer_validate_only(native_lib, tmp_path, m
         native.set_validate_only(False)
 
 
-def test_bench_inference_leg_plumbing(native_lib, monkeypatch):
+def test_bench_inference_leg_plumbing(native_lib, monkeypatch, capsys):
     """bench.py's decode-steps/s leg (BASELINE configs 4/5) with the kernels off: shapes, forced step counts and the
     JSON fields; the numbers are meaningless here.  (In bench.py the leg sits inside a try/except so that it can never
     take the headline line down — which is exactly why its plumbing is pinned by a test.)"""
@@ -339,6 +339,7 @@ def test_bench_inference_leg_plumbing(native_lib, monkeypatch):
         out = bench.inference_leg(torch.device("cpu"))
     finally:
         native.set_validate_only(False)
+    assert capsys.readouterr().out == ""                              # stdout belongs to the one JSON line
     assert set(out) == {"config4_B1_fp32", "config4_B1_bf16", "config5_B256_bf16"}
     # (the stop bookkeeping lives in device memory the kernels never wrote here: the step count itself is not checked)
     assert 1 <= out["config4_B1_fp32"]["steps"] <= 1000 and 1 <= out["config5_B256_bf16"]["steps"] <= 400
