@@ -35,3 +35,12 @@ class ConvNorm(torch.nn.Module):
                                     bias=bias)
         torch.nn.init.xavier_uniform_(
             self.conv.weight, gain=torch.nn.init.calculate_gain(w_init_gain))
+
+
+def __getattr__(name):
+    """``from layers import TacotronSTFT, STFT`` (reference layers.py:42-80, inference.ipynb cell 2): the GPU mel
+    front end lives in ``tacotron2_amd.audio``; resolved lazily so that the model containers do not import it."""
+    if name in ('TacotronSTFT', 'STFT'):
+        from . import audio
+        return getattr(audio, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
