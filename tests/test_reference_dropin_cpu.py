@@ -56,3 +56,51 @@ def test_reference_train_py_drives_our_modules(native_lib, tmp_path, monkeypatch
     m, opt, lr, it = ref_train.load_checkpoint(str(out / "checkpoint_0"), m, opt)
     assert (lr, it) == (hp.learning_rate, 0)
     ref_train.warm_start_model(str(out / "checkpoint_0"), m, hp.ignore_layers)
+
+
+def test_reference_notebook_cells_run_on_our_modules(native_lib, tmp_path, monkeypatch):
+    """inference.ipynb cells 5, 7, 11 and 13 (checkpoint load, ``.cuda().eval().half()``, text -> ids with the
+    reference's own ``text`` package, ``model.inference``), source taken from the notebook file at test time and
+    executed unchanged against ``hparams`` / ``train`` / ``model`` resolved to tacotron2_amd.  WaveGlow cells
+    (9, 15, 17) need the un-vendored vocoder and are not run.  Kernels off; ``.cuda()`` is a no-op without a GPU."""
+    import json
+    import types
+    import tacotron2_amd.hparams
+    import tacotron2_amd.model
+    import tacotron2_amd.train
+    nb = json.load(open(os.path.join(REF, "inference.ipynb")))
+    cells = {i: "".join(c["source"]) for i, c in enumerate(nb["cells"]) if c["cell_type"] == "code"}
+    for name in ("hparams", "model", "train"):
+        monkeypatch.setitem(sys.modules, name, getattr(tacotron2_amd, name))
+    # the reference's text frontend (out of scope for the engine) with its two uninstalled dependencies stubbed
+    monkeypatch.setitem(sys.modules, "unidecode", types.SimpleNamespace(unidecode=lambda s: s))
+    monkeypatch.setitem(sys.modules, "inflect", types.SimpleNamespace(
+        engine=lambda: types.SimpleNamespace(number_to_words=lambda *a, **k: "number")))
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.syspath_prepend(REF)
+    for stale in [k for k in sys.modules if k == "text" or k.startswith("text.")]:
+        monkeypatch.delitem(sys.modules, stale)
+    if not torch.cuda.is_available():
+        monkeypatch.setattr(torch.nn.Module, "cuda", lambda self, *a, **k: self)
+        monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.chdir(tmp_path)
+    native.set_validate_only(True)
+    try:
+        ns = {}
+        exec("import numpy as np\nimport torch\nfrom hparams import create_hparams\nfrom model import Tacotron2\n"
+             "from train import load_model\nfrom text import text_to_sequence\n", ns)          # cell 2, minus plotting/WaveGlow
+        shown = []
+        ns["plot_data"] = lambda data, figsize=(16, 4): shown.append([d.shape for d in data])   # cell 3 without matplotlib
+        exec(cells[5], ns)                                                                       # hparams
+        torch.save({"state_dict": tacotron2_amd.model.Tacotron2(ns["hparams"]).state_dict()}, "tacotron2_statedict.pt")
+        exec(cells[7], ns)                                                                       # load + .cuda().eval().half()
+        exec(cells[11], ns)                                                                      # text -> ids
+        assert tuple(ns["sequence"].shape) == (1, 27) and ns["sequence"].dtype == torch.int64   # SURVEY: 27 symbols
+        exec(cells[13], ns)                                                                      # inference + plot
+    finally:
+        native.set_validate_only(False)
+    model = ns["model"]
+    assert model.precision == "bf16" and not model.training
+    assert all(p.dtype == torch.float32 for p in model.parameters())
+    assert ns["mel_outputs_postnet"].dtype == torch.float16 and ns["mel_outputs_postnet"].shape[:2] == (1, 80)
+    assert len(shown) == 1 and shown[0][0][0] == 80 and shown[0][2][0] == 27                     # mel (80,T), align.T (27,T)
