@@ -33,6 +33,16 @@ enum { hipSuccess = 0 };
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
+// just enough of the host API for tools/probe/gpu_selftest.cpp to be dry-run against the emulated kernels
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost };
+struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; };
+template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)malloc(n); return *p ? hipSuccess : 2; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcpy(p->gcnArchName, "host-emulation"); p->multiProcessorCount = 0; return hipSuccess; }
+
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void emu_syncthreads();
 void emu_exchange(const void* mine, void* partner, size_t bytes, int mask);   // wave-level xor exchange
