@@ -99,6 +99,8 @@ def test_reference_notebook_cells_run_on_our_modules(native_lib, tmp_path, monke
         exec(cells[13], ns)                                                                      # inference + plot
     finally:
         native.set_validate_only(False)
+        for loaded in [k for k in sys.modules if k == "text" or k.startswith("text.")]:
+            del sys.modules[loaded]                      # the reference's package must not outlive this test
     model = ns["model"]
     assert model.precision == "bf16" and not model.training
     assert all(p.dtype == torch.float32 for p in model.parameters())

@@ -6,6 +6,7 @@ No GPU arithmetic here: the oracle is checked against the fixtures made from the
 (every argument check and host loop runs, no kernel is launched, values are meaningless)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -121,7 +122,8 @@ def test_collate_matches_reference_fixture():
         assert mel[b, :, ol[b]:].abs().sum() == 0 and text[b, il[b]:].sum() == 0
 
 
-def test_loader_filelist_shuffle_npy_and_synthetic(tmp_path):
+def test_loader_filelist_shuffle_npy_and_synthetic(tmp_path, monkeypatch):
+    monkeypatch.setitem(sys.modules, "text", None)           # no text frontend importable, whatever ran before
     from tacotron2_amd.data_utils import TextMelLoader, TextMelCollate
     g = _golden("collate.pt")
     lines = []
