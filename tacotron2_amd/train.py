@@ -71,14 +71,14 @@ def init_distributed(hparams, n_gpus, rank, group_name):
 
 def prepare_dataloaders(hparams):
     """``(train_loader, valset, collate_fn)`` (reference train.py:42-60).  Items whose mel is
-    computed on the GPU inside the dataset (wav input) are loaded in-process; ``.npy`` mels and
-    synthetic utterances keep the reference's single worker."""
+    computed on the GPU inside the dataset (wav input) and synthetic utterances are produced in-process (a forked
+    worker must not touch the GPU, and generated items need none); ``.npy`` mels keep the reference's single worker."""
     trainset = TextMelLoader(hparams.training_files, hparams)
     valset = TextMelLoader(hparams.validation_files, hparams)
     collate_fn = TextMelCollate(hparams.n_frames_per_step)
-    gpu_mel = trainset.synthetic is None and not hparams.load_mel_from_disk
+    in_process = trainset.synthetic is not None or not hparams.load_mel_from_disk    # GPU mel / generated items
     sampler = DistributedSampler(trainset) if hparams.distributed_run else None
-    train_loader = DataLoader(trainset, num_workers=0 if gpu_mel else 1, shuffle=sampler is None,
+    train_loader = DataLoader(trainset, num_workers=0 if in_process else 1, shuffle=sampler is None,
                               sampler=sampler, batch_size=hparams.batch_size, pin_memory=False,
                               drop_last=True, collate_fn=collate_fn)
     return train_loader, valset, collate_fn
@@ -159,7 +159,7 @@ def validate(model, criterion, valset, iteration, batch_size, n_gpus, collate_fn
     running statistics, only the prenet dropout active.  One host read at the end, not one per batch."""
     model.eval()
     sampler = DistributedSampler(valset) if distributed_run else None
-    loader = DataLoader(valset, sampler=sampler, num_workers=0 if valset.synthetic is None and
+    loader = DataLoader(valset, sampler=sampler, num_workers=0 if valset.synthetic is not None or
                         not valset.load_mel_from_disk else 1, shuffle=False, batch_size=batch_size,
                         pin_memory=False, collate_fn=collate_fn)
     total, batches, y, y_pred = None, 0, None, None
