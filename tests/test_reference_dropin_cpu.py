@@ -106,3 +106,39 @@ def test_reference_notebook_cells_run_on_our_modules(native_lib, tmp_path, monke
     assert all(p.dtype == torch.float32 for p in model.parameters())
     assert ns["mel_outputs_postnet"].dtype == torch.float16 and ns["mel_outputs_postnet"].shape[:2] == (1, 80)
     assert len(shown) == 1 and shown[0][0][0] == 80 and shown[0][2][0] == 27                     # mel (80,T), align.T (27,T)
+
+
+def test_collate_equals_reference_on_random_ragged_batches(monkeypatch):
+    """TextMelCollate against the reference's, live, on 60 random ragged batches (ties in text length, 1-item batches,
+    n_frames_per_step 1..4): every tensor of the 5-tuple bit-identical, dtypes included."""
+    import types
+    for name, mod in (("librosa", types.ModuleType("librosa")), ("unidecode", types.SimpleNamespace(unidecode=lambda s: s)),
+                      ("inflect", types.SimpleNamespace(engine=lambda: None))):
+        monkeypatch.setitem(sys.modules, name, mod)
+    filt = types.ModuleType("librosa.filters"); filt.mel = lambda *a, **k: None
+    util = types.ModuleType("librosa.util"); util.pad_center = util.tiny = util.normalize = None
+    monkeypatch.setitem(sys.modules, "librosa.filters", filt)
+    monkeypatch.setitem(sys.modules, "librosa.util", util)
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    monkeypatch.syspath_prepend(REF)
+    before = set(sys.modules)
+    try:
+        spec = importlib.util.spec_from_file_location("reference_data_utils", os.path.join(REF, "data_utils.py"))
+        ref_data = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_data)
+        from tacotron2_amd.data_utils import TextMelCollate
+        g = torch.Generator().manual_seed(2024)
+        for case in range(60):
+            n = int(torch.randint(1, 9, (1,), generator=g))
+            r = int(torch.randint(1, 5, (1,), generator=g))
+            items = []
+            for _ in range(n):
+                ti = int(torch.randint(1, 12, (1,), generator=g))
+                to = int(torch.randint(1, 40, (1,), generator=g))
+                items.append((torch.randint(1, 148, (ti,), generator=g, dtype=torch.int32), torch.randn(80, to, generator=g)))
+            want, got = ref_data.TextMelCollate(r)(items), TextMelCollate(r)(items)
+            for a, b in zip(want, got):
+                assert a.dtype == b.dtype and torch.equal(a, b), (case, n, r)
+    finally:
+        for loaded in set(sys.modules) - before:            # layers / stft / text / utils ... of the reference
+            del sys.modules[loaded]
