@@ -142,3 +142,32 @@ def test_collate_equals_reference_on_random_ragged_batches(monkeypatch):
     finally:
         for loaded in set(sys.modules) - before:            # layers / stft / text / utils ... of the reference
             del sys.modules[loaded]
+
+
+@pytest.mark.parametrize("seed,in_lens,out_lens,extra", [
+    (101, [9, 9, 3], [14, 6, 21], ""),                       # tie in text length, longest mel not first
+    (202, [15, 2], [3, 17], ",mask_padding=False"),
+    (303, [6], [9], ",p_attention_dropout=0.3,p_decoder_dropout=0.2,gate_threshold=0.4"),
+])
+def test_oracle_equals_reference_live_on_more_cases(monkeypatch, seed, in_lens, out_lens, extra):
+    """The oracle's pin, widened beyond the committed fixtures: the reference's model.py is run here (through the
+    fixture generator's own shim and assertions: state_dict bit-identical under the seed; outputs, loss, all 60
+    gradients and the BatchNorm buffers equal to the oracle's) on further shapes and hyper-parameters.  Nothing is
+    written."""
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    before = set(sys.modules)
+    real_dropout = torch.nn.functional.dropout
+    spec = importlib.util.spec_from_file_location("make_golden_live", os.path.join(gu.GOLDEN_DIR, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    path_before = list(sys.path)
+    try:
+        spec.loader.exec_module(mg)
+        ref_model, ref_loss = mg.import_reference()
+        monkeypatch.setattr(torch, "save", lambda *a, **k: None)
+        case = dict(kind="train", hp=gu.TINY_HP + extra, seed=seed, in_lens=in_lens, out_lens=out_lens)
+        mg.run_train_case("live_%d" % seed, case, ref_model, ref_loss)          # raises on any mismatch
+    finally:
+        torch.nn.functional.dropout = real_dropout
+        sys.path[:] = path_before
+        for loaded in set(sys.modules) - before:
+            del sys.modules[loaded]
