@@ -36,3 +36,12 @@ def test_notebook_half_inference(native_lib):
     assert torch.isfinite(mel.float()).all() and torch.isfinite(mel_post.float()).all()
     assert (align.float().sum(2) - 1).abs().max().item() < 5e-3        # float16 rounding of 21 weights
     assert all(p.dtype == torch.float32 for p in model.parameters())
+
+
+def test_other_dropout_rates_match_oracle(native_lib):
+    """p_attention_dropout / p_decoder_dropout other than the default 0.1 (hparams.py:60-61): the keep scale 1/(1-p)
+    travels through the forward and the BPTT loops.  Oracle pinned for this configuration against the reference in
+    tests/test_reference_dropin_cpu.py; same tolerances as the other edge shapes."""
+    import test_parity_gpu as tp
+    tp.test_edge_shapes_match_oracle(native_lib, gu.TINY_HP + ",p_attention_dropout=0.3,p_decoder_dropout=0.2",
+                                     [9, 9, 3], [14, 6, 21], 1e-3)
