@@ -2,20 +2,25 @@
 
     python -m tacotron2_amd.build [--force]
 
-The library is built in-tree so that it travels with the repository snapshot to the GPU box.
+The library is built in-tree so that it travels with the repository snapshot to the GPU box.  Every ``csrc/*.hip`` is
+compiled to its own object (in parallel, rebuilt only when it or a header is newer) and the objects are linked into
+one shared library.
 """
 import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = sorted(glob.glob(os.path.join(HERE, "csrc", "*.hip")))
-DEPS = SRC + glob.glob(os.path.join(HERE, "csrc", "*.h")) + \
-    [os.path.join(HERE, "..", "include", "tacotron2_amd.h")]
+HDRS = glob.glob(os.path.join(HERE, "csrc", "*.h")) + [os.path.join(HERE, "..", "include", "tacotron2_amd.h")]
+DEPS = SRC + HDRS
 OUT = os.path.join(HERE, "lib", "libtacotron2_amd.so")
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+FLAGS = CFLAGS + ["-shared"]
 
 
 def up_to_date():
@@ -28,15 +33,39 @@ def up_to_date():
 STAMPS_OUT = os.path.join(HERE, "lib", "libtacotron2_amd_stamps.so")
 
 
+def _compile_objects(obj_dir, extra, verbose):
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in HDRS if os.path.exists(h))
+    jobs = []
+    for src in SRC:
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+            continue
+        jobs.append([HIPCC] + CFLAGS + extra + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
+        list(ex.map(run, jobs))
+    return [os.path.join(obj_dir, os.path.basename(s)[:-4] + ".o") for s in SRC]
+
+
+def _link(objs, out, verbose):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
 def build(force=False, verbose=True, stamps=False):
     """stamps=True builds the instrumented variant (in-kernel phase stamps, tools only) next to the product library;
     select it with T2AMD_LIB=<path> T2AMD_ATTN_TS=1."""
     if stamps:
         os.makedirs(os.path.dirname(STAMPS_OUT), exist_ok=True)
-        cmd = [HIPCC] + FLAGS + ["-DT2AMD_PHASE_STAMPS", "-o", STAMPS_OUT] + SRC
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        _link(_compile_objects(OBJ_DIR + "_stamps", ["-DT2AMD_PHASE_STAMPS"], verbose), STAMPS_OUT, verbose)
         return STAMPS_OUT
     if not force and up_to_date():
         return OUT
@@ -45,10 +74,10 @@ def build(force=False, verbose=True, stamps=False):
         print("tacotron2_amd.build: %s not found, using the shipped %s" % (HIPCC, OUT), file=sys.stderr)
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", OUT] + SRC
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    if force:
+        for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):
+            os.remove(o)
+    _link(_compile_objects(OBJ_DIR, [], verbose), OUT, verbose)
     return OUT
 
 

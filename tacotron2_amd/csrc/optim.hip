@@ -81,6 +81,9 @@ __global__ void __launch_bounds__(256) adam_step_kernel(t2amd_tensor_list L, t2a
     const long long n = L.numel[t];
     const long long base = (long long)(blk - L.first_block[t]) * OPT_CHUNK;
     const float coef = clip ? clip[1] : 1.0f;
+    // A non-finite global norm (overflow in the bf16 compute mode, a NaN batch) skips the whole update on the device:
+    // weights and moments keep their values, exactly what the reference's amp loss scaler does with such a step.
+    if (clip && !(fabsf(clip[0]) <= 3.0e38f)) return;
 #pragma unroll 4
     for (int k = 0; k < OPT_CHUNK / 256; ++k) {
         const long long i = base + k * 256 + threadIdx.x;

@@ -29,18 +29,26 @@ import torch.utils.data
 from .utils import load_filepaths_and_text, load_wav_to_torch
 
 
+PRETOKENISED = 'ids:'        # filelist marker: "path|ids: 12 7 33 ..." is a transcript that already is symbol ids
+
+
 def _ids_from_transcript(text, cleaner_names):
-    """Default tokeniser: a transcript that already is a list of symbol ids."""
-    fields = text.split()
-    if fields and all(f.lstrip('-').isdigit() for f in fields):
+    """Default tokeniser.  A transcript that starts with the marker ``ids:`` is a list of symbol ids (explicit
+    opt-in: a plain transcript such as "1984" is text, not id 1984); anything else goes to the reference's
+    ``text.text_to_sequence`` when that package is importable."""
+    if text.lstrip().startswith(PRETOKENISED):
+        fields = text.lstrip()[len(PRETOKENISED):].split()
+        if not fields or not all(f.isdigit() for f in fields):
+            raise ValueError("pre-tokenised transcript must be 'ids:' followed by non-negative integers, got %r" % (text,))
         return [int(f) for f in fields]
     try:                                                   # the reference's package, if importable
         from text import text_to_sequence                 # noqa: WPS433
     except Exception as e:
         raise RuntimeError(
             "TextMelLoader: no text frontend.  The cleaners/symbol table (reference text/*.py) are out "
-            "of scope for the engine: pass text_to_sequence=<callable(text, cleaner_names) -> ids> or use "
-            "a pre-tokenised filelist (space-separated ids).  (import text failed: %s)" % (e,))
+            "of scope for the engine: pass text_to_sequence=<callable(text, cleaner_names) -> ids>, put the "
+            "reference's `text` package on sys.path, or use a pre-tokenised filelist ('path|ids: 12 7 33').  "
+            "(import text failed: %s)" % (e,))
     return text_to_sequence(text, cleaner_names)
 
 
@@ -96,14 +104,17 @@ class TextMelLoader(torch.utils.data.Dataset):
             return melspec
         audio, sampling_rate = load_wav_to_torch(filename)
         if sampling_rate != self.sampling_rate:
-            raise ValueError("{} {} SR doesn't match target {} SR".format(
-                sampling_rate, self.sampling_rate, filename))
+            raise ValueError("{}: {} SR doesn't match target {} SR".format(
+                filename, sampling_rate, self.sampling_rate))
         audio_norm = (audio / self.max_wav_value).unsqueeze(0)
         return self.stft.mel_spectrogram(audio_norm).squeeze(0).cpu()
 
     # -- text ---------------------------------------------------------------------------------
     def get_text(self, text):
-        return torch.IntTensor(self._tokenise(text, self.text_cleaners))
+        ids = self._tokenise(text, self.text_cleaners)
+        if ids and not (0 <= min(ids) and max(ids) < self.n_symbols):
+            raise ValueError("symbol id out of range for the embedding (n_symbols=%d): %r" % (self.n_symbols, text[:60]))
+        return torch.IntTensor(ids)
 
     def get_mel_text_pair(self, audiopath_and_text):
         return self.get_text(audiopath_and_text[1]), self.get_mel(audiopath_and_text[0])

@@ -19,12 +19,14 @@ What is different (MI355X-first):
   * ``reduce_tensor`` returns the mean without forcing a host sync; the caller decides when
     to read it.
 
-Any other ``nn.Module`` (not driven by the engine) gets the generic path: one flat bucket,
-reduced from a post-backward callback — the reference's behaviour.
+  * the engine writes every gradient STRAIGHT into its bucket (``GradSync.out`` hands the kernels views of the
+    flat buffers, 256-byte aligned), so nothing is packed or copied before the all-reduce either.
+
+Only ``tacotron2_amd.model.Tacotron2`` is supported: its backward is the engine's, which knows when a bucket is
+complete.  Any other module raises (the reference's hook-based path is not restated here).
 """
 import torch
 import torch.distributed as dist
-from torch.autograd import Variable
 
 BUCKET_ORDER = ('postnet', 'decoder', 'encoder')      # order in which the engine finishes them
 
@@ -59,35 +61,62 @@ def _flat_broadcast(tensors, src=0):
             off += n
 
 
+ALIGN_ELEMS = 64           # every gradient starts on a 256-byte boundary of its bucket (vector stores in the kernels)
+
+
 class GradSync(object):
-    """Bucketed asynchronous gradient all-reduce driven by the engine's backward."""
+    """Bucketed asynchronous gradient all-reduce driven by the engine's backward.
+
+    Per backward: ``start(device)`` allocates the three flat buckets, the engine asks ``out(name, shape)`` for the
+    tensor each gradient kernel writes into (a view of the bucket), ``bucket_ready(bucket)`` launches that bucket's
+    all-reduce the moment its last gradient has been enqueued, ``finish()`` orders the compute stream behind all of
+    them and forms the mean."""
 
     def __init__(self, named_params, world_size=None, group=None):
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
         self.layout = {}                                  # bucket -> [(name, offset, numel)]
         self.sizes = {}
+        self.where = {}                                   # name -> (bucket, offset, numel)
         for name, p in named_params:
             b = bucket_of(name)
-            off = self.sizes.get(b, 0)
+            off = (self.sizes.get(b, 0) + ALIGN_ELEMS - 1) // ALIGN_ELEMS * ALIGN_ELEMS
             self.layout.setdefault(b, []).append((name, off, p.numel()))
+            self.where[name] = (b, off, p.numel())
             self.sizes[b] = off + p.numel()
+        self.flat = {}
         self.pending = []
 
-    def start(self):
+    def start(self, device=None, dtype=torch.float32):
         self.pending = []
+        self.flat = {}
+        if device is not None:
+            for b, n in self.sizes.items():
+                # zero-filled: the alignment gaps travel through the all-reduce too and must stay finite
+                self.flat[b] = torch.zeros(n, dtype=dtype, device=device)
 
-    def bucket_ready(self, bucket, grads):
-        """Pack this bucket's gradients into one flat buffer and launch its all-reduce on RCCL's
-        stream.  ``grads``: name -> tensor; entries are replaced by views into the flat buffer."""
+    def out(self, name, shape):
+        """The tensor the engine's kernels write gradient ``name`` into: a view of its bucket."""
+        b, off, n = self.where[name]
+        return self.flat[b][off:off + n].view(shape)
+
+    def bucket_ready(self, bucket, grads=None):
+        """Launch this bucket's all-reduce on RCCL's stream.  ``grads`` (name -> tensor) is only needed when the
+        producer did not write through ``out()``: those entries are copied in and replaced by bucket views."""
         entries = self.layout.get(bucket)
         if not entries:
             return
-        first = grads[entries[0][0]]
-        flat = torch.empty(self.sizes[bucket], dtype=first.dtype, device=first.device)
-        for name, off, n in entries:
-            flat[off:off + n].copy_(grads[name].reshape(-1))
-            grads[name] = flat[off:off + n].view(grads[name].shape)
+        if bucket not in self.flat:
+            first = grads[entries[0][0]]
+            self.flat[bucket] = torch.zeros(self.sizes[bucket], dtype=first.dtype, device=first.device)
+        flat = self.flat[bucket]
+        if grads is not None:
+            for name, off, n in entries:
+                g = grads[name]
+                view = flat[off:off + n].view(g.shape)
+                if g.data_ptr() != view.data_ptr():
+                    view.copy_(g)
+                    grads[name] = view
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self.pending.append((flat, work))
 
@@ -115,37 +144,5 @@ def apply_gradient_allreduce(module):
         module._grad_sync = GradSync(list(module.named_parameters()))
         return module
 
-    # generic module: one flat bucket reduced after the whole backward, like the reference
-    world = dist.get_world_size()
-
-    def allreduce_params():
-        if not module.needs_reduction:
-            return
-        module.needs_reduction = False
-        params = [p for p in module.parameters() if p.requires_grad and p.grad is not None]
-        by_dtype = {}
-        for p in params:
-            by_dtype.setdefault(p.grad.dtype, []).append(p)
-        for ps in by_dtype.values():
-            flat = torch.cat([p.grad.detach().reshape(-1) for p in ps])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat /= world
-            off = 0
-            for p in ps:
-                n = p.grad.numel()
-                p.grad.detach().copy_(flat[off:off + n].view_as(p.grad))
-                off += n
-
-    def allreduce_hook(*unused):
-        Variable._execution_engine.queue_callback(allreduce_params)
-
-    for p in list(module.parameters()):
-        if p.requires_grad:
-            p.register_hook(allreduce_hook)
-
-    def set_needs_reduction(mod, inputs, output):
-        mod.needs_reduction = True
-
-    module.needs_reduction = False
-    module.register_forward_hook(set_needs_reduction)
-    return module
+    raise TypeError("apply_gradient_allreduce: only tacotron2_amd.model.Tacotron2 is data-parallel here (its backward is "
+                    "the engine's and knows when a gradient bucket is complete); got %s" % type(module).__name__)

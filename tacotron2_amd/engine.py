@@ -112,10 +112,30 @@ class _Ctx(object):
     pass
 
 
+class _EvalCtx(object):
+    training = False
+
+
 # Gradient GEMMs (dgrad / wgrad, tolerance 1e-3 of the gradient's max in the parity tests) run on the
 # split-bf16 MFMA kernel (include/tacotron2_amd.h: t2amd_gemm_desc.precision = 1, ~2^-17 relative per
 # product).  Every forward GEMM stays on the exact-f32 MFMA.  Set to False for bit-faithful f32 gradients.
 FAST_GRAD_GEMM = True
+
+
+def _dgrad_split():
+    """Split-K factor of the two BPTT dgrad products (T2AMD_DGRAD_SPLIT, tuning knob): validated here because it
+    sizes the dXd / dXa slabs the kernels write."""
+    raw = os.environ.get('T2AMD_DGRAD_SPLIT', '2')
+    try:
+        ns = int(raw)
+    except ValueError:
+        ns = -1
+    if not 1 <= ns <= 8:
+        raise NativeError("T2AMD_DGRAD_SPLIT must be an integer in 1..8, got %r" % (raw,))
+    return ns
+
+
+DGRAD_SPLIT = _dgrad_split()
 
 
 def _rg(run, *a, **k):
@@ -130,18 +150,41 @@ def _fg(run, *a, **k):          # forward GEMM: exact f32, or plain bf16 in the 
     return nv.gemm(*a, fast=run.fwdp, **k)
 
 
+# Packed / transposed / bf16 weight images are rebuilt only when a weight changed: the key is the
+# parameters' storage addresses and torch version counters (every in-place optimiser update, copy_ and
+# load_state_dict bumps them) plus a generation counter that raw-pointer updates bump (optim.FusedAdam.step).
+# Writes through ``param.data`` bypass version counters by design of torch: call
+# ``engine.bump_weight_generation()`` after such an edit.
+_PACK_GEN = [0]
+
+
+def bump_weight_generation():
+    _PACK_GEN[0] += 1
+
+
 class _Run(object):
     """Allocation + kernel helpers bound to one device."""
 
-    def __init__(self, device, precision='fp32'):
+    def __init__(self, device, precision='fp32', cache=None):
         self.dev = device
         self._ws = None
+        self.cache = cache if cache is not None else {}
         if precision not in ('fp32', 'bf16'):
             raise NativeError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
         self.bf16 = precision == 'bf16'
         # t2amd_gemm_desc.precision: 0 exact f32 MFMA, 1 split-bf16 x3 (f32-class), 2 plain bf16
         self.fwdp = 2 if self.bf16 else 0
         self.gradp = 2 if self.bf16 else (1 if FAST_GRAD_GEMM else 0)
+
+    def cached(self, tag, deps, fn):
+        """fn() once per weight version: ``deps`` are the parameters the image is derived from."""
+        key = (_PACK_GEN[0], str(self.dev)) + tuple((d.data_ptr(), d._version) for d in deps)
+        hit = self.cache.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        val = fn()
+        self.cache[tag] = (key, val)
+        return val
 
     def empty16(self, *shape):
         return torch.empty(shape, dtype=torch.bfloat16, device=self.dev)
@@ -233,7 +276,7 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         rv = bufs['%s.%d.1.running_var' % (prefix, i)]
         Co, Ci, k = W.shape
         pad = (k - 1) // 2
-        Wp = run.pack_conv_fwd(W)
+        Wp = run.cached('convfwd.%s.%d' % (prefix, i), [W], lambda W=W: run.pack_conv_fwd(W))
         y = run.empty(rows, Co)
         _fg(run, y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
         invstd = run.empty(Co)
@@ -248,14 +291,17 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         keep = masks[i] if masks is not None else None
         nv.bn_act_fwd(y, z, mean, invstd, gamma, beta, acts[i],
                       keep.view(rows, Co) if keep is not None else None, 2.0, lens, T if lens is not None else 0)
-        saved.append(dict(x=x, y=y, z=z, mean=mean, invstd=invstd, keep=keep, W=W, act=acts[i]))
+        saved.append(dict(x=x, y=y, z=z, mean=mean, invstd=invstd, keep=keep, W=W, act=acts[i], layer=i))
         x = z
     return x, saved
 
 
-def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_accumulate=False):
+def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_accumulate=False, G=None):
     """g: grad wrt the last activation (rows, C_last), overwritten.  Returns grad wrt the stack input
-    (written to ``first_dx`` if given)."""
+    (written to ``first_dx`` if given).  ``G(name, *shape)`` allocates a parameter gradient (a view of its
+    data-parallel bucket when gradients are exchanged, distributed.GradSync.out)."""
+    if G is None:
+        G = lambda name, *shape: run.empty(*shape)                                   # noqa: E731
     for i in range(len(saved) - 1, -1, -1):
         s = saved[i]
         W = s['W']
@@ -263,23 +309,23 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
         pad = (k - 1) // 2
         rows = g.shape[0]
         gamma = P['%s.%d.1.weight' % (prefix, i)]
-        dgamma = run.empty(Co)
-        dbeta = run.empty(Co)
+        dgamma = G('%s.%d.1.weight' % (prefix, i), Co)
+        dbeta = G('%s.%d.1.bias' % (prefix, i), Co)
         keep = s['keep']
         nv.bn_act_bwd(g, s['z'], s['y'], s['mean'], s['invstd'], gamma, s['act'],
                       keep.view(rows, Co) if keep is not None else None, 2.0, run.ws(Co), dgamma, dbeta)
         grads['%s.%d.1.weight' % (prefix, i)] = dgamma
         grads['%s.%d.1.bias' % (prefix, i)] = dbeta
-        dbias = run.empty(Co)
+        dbias = G('%s.%d.0.conv.bias' % (prefix, i), Co)
         run.colsum(g, dbias)
         grads['%s.%d.0.conv.bias' % (prefix, i)] = dbias
         # weight gradient: dW[co][(tap,ci)] = sum_r g[r][co] * x[r + tap - pad][ci]
-        dW = run.empty(Co, Ci, k)
+        dW = G('%s.%d.0.conv.weight' % (prefix, i), Co, Ci, k)
         _rg(run, dW.view(Co, Ci * k), g, s['x'], a_km=True, b_kn=True, convB=(T, Ci, pad), perm=(k, Ci))
         grads['%s.%d.0.conv.weight' % (prefix, i)] = dW
         # data gradient
         if i > 0 or first_dx is not None:
-            Wd = run.pack_conv_dgrad(W)
+            Wd = run.cached('convdgrad.%s.%d' % (prefix, i), [W], lambda W=W: run.pack_conv_dgrad(W))
             if i == 0:
                 dx = first_dx
                 acc = first_dx_accumulate
@@ -289,6 +335,45 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
             _ng(run, dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
             g = dx
     return g
+
+
+def _weight_cache(model):
+    cache = getattr(model, '_weight_cache', None)
+    if cache is None:
+        cache = {}
+        try:
+            model._weight_cache = cache
+        except Exception:                 # a model object that refuses attributes: no caching
+            pass
+    return cache
+
+
+def _cached_bias_sum(run, tag, b1, b2):
+    return run.cached(tag, [b1, b2], lambda: _bias_sum(run, b1, b2))
+
+
+def _fold_U(run, Wdense, Wconv):
+    U = run.empty(nv.ATT_DIM * nv.LOC_TAPS)
+    nv.fold_location(Wdense, Wconv, U)
+    return U
+
+
+def _packed_projection(run, P, Cm, Hd, E):
+    """[linear_projection ; gate_layer] as one (Cm+1, Hd+E) matrix and one bias (reference model.py:373-378)."""
+    Wp = P['decoder.linear_projection.linear_layer.weight']      # (Cm, Hd+E)
+    Wg = P['decoder.gate_layer.linear_layer.weight']             # (1, Hd+E)
+    bp = P['decoder.linear_projection.linear_layer.bias']
+    bg = P['decoder.gate_layer.linear_layer.bias']
+
+    def pack():
+        Wpg = run.empty(Cm + 1, Hd + E)
+        nv.copy2d(Wpg[:Cm], Wp)
+        nv.copy2d(Wpg[Cm:], Wg)
+        bpg = run.empty(Cm + 1)
+        nv.copy2d(bpg[:Cm].view(1, Cm), bp.view(1, Cm))
+        nv.copy2d(bpg[Cm:].view(1, 1), bg.view(1, 1))
+        return Wpg, bpg
+    return run.cached('Wpg', [Wp, Wg, bp, bg], pack)
 
 
 # ----------------------------------------------------------------------------
@@ -301,7 +386,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         raise NativeError("tacotron2_amd: the engine runs on the MI355X only (got %s tensors). "
                           "There is no CPU path; the CPU oracle lives in oracle/ for tests." % dev)
     nv.load()
-    run = _Run(dev, getattr(model, 'precision', 'fp32'))
+    run = _Run(dev, getattr(model, 'precision', 'fp32'), _weight_cache(model))
     ms = MaskSource(model.dropout_masks, dev)
     c = _Ctx()
     B = text.shape[0]
@@ -334,7 +419,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     for d, sfx in enumerate(('', '_reverse')):                                           # model.py:181-188
         Wih = P['encoder.lstm.weight_ih_l0' + sfx]
         Whh = P['encoder.lstm.weight_hh_l0' + sfx]
-        bsum = _bias_sum(run, P['encoder.lstm.bias_ih_l0' + sfx], P['encoder.lstm.bias_hh_l0' + sfx])
+        bsum = _cached_bias_sum(run, 'enc_bias' + sfx, P['encoder.lstm.bias_ih_l0' + sfx], P['encoder.lstm.bias_hh_l0' + sfx])
         GX = run.empty(rowsE, 4 * He)
         _fg(run, GX, x3, Wih, bias=bsum)
         Cst = run.empty(Ti, B, He)
@@ -368,19 +453,27 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
 
     Wih_a, Whh_a = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
     Wih_d, Whh_d = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
-    bias_a = _bias_sum(run, P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
-    bias_d = _bias_sum(run, P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
-    Wa_rec = run.empty(4 * Ha, E + Ha)
-    nv.copy2d(Wa_rec[:, :E], Wih_a[:, Pd:Pd + E])
-    nv.copy2d(Wa_rec[:, E:], Whh_a)
-    Wd_cat = run.empty(4 * Hd, Ha + E + Hd)
-    nv.copy2d(Wd_cat[:, :Ha + E], Wih_d)
-    nv.copy2d(Wd_cat[:, Ha + E:], Whh_d)
+    bias_a = _cached_bias_sum(run, 'bias_a', P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
+    bias_d = _cached_bias_sum(run, 'bias_d', P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
+
+    def pack_a_rec():
+        W = run.empty(4 * Ha, E + Ha)
+        nv.copy2d(W[:, :E], Wih_a[:, Pd:Pd + E])
+        nv.copy2d(W[:, E:], Whh_a)
+        return W
+
+    def pack_d_cat():
+        W = run.empty(4 * Hd, Ha + E + Hd)
+        nv.copy2d(W[:, :Ha + E], Wih_d)
+        nv.copy2d(W[:, Ha + E:], Whh_d)
+        return W
+
+    Wa_rec = run.cached('Wa_rec', [Wih_a, Whh_a], pack_a_rec)
+    Wd_cat = run.cached('Wd_cat', [Wih_d, Whh_d], pack_d_cat)
     Wq = P['decoder.attention_layer.query_layer.linear_layer.weight'].contiguous()       # (A, Ha)
     Wdense = P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']
     Wconv = P['decoder.attention_layer.location_layer.location_conv.conv.weight']
-    U = run.empty(A * nv.LOC_TAPS)
-    nv.fold_location(Wdense, Wconv, U)
+    U = run.cached('U', [Wdense, Wconv], lambda: _fold_U(run, Wdense, Wconv))
     vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
 
     GA = run.empty(To, B, 4 * Ha)
@@ -409,23 +502,18 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     if run.bf16:
         # bf16 compute mode: bf16 copies of the packed weights and of the recurrent operand slabs (the LSTM
         # products run on the bf16 MFMA; cell state, gates and every saved slab stay f32)
-        c.bf16 = dict(Wa_rec16=run.cast16(Wa_rec), Wd_cat16=run.cast16(Wd_cat), HA16=run.empty16(To, B, Ha),
+        c.bf16 = dict(Wa_rec16=run.cached('Wa_rec16', [Wih_a, Whh_a], lambda: run.cast16(Wa_rec)),
+                      Wd_cat16=run.cached('Wd_cat16', [Wih_d, Whh_d], lambda: run.cast16(Wd_cat)),
+                      HA16=run.empty16(To, B, Ha),
                       HD16=run.empty16(To, B, Hd), CTX16=run.empty16(To, B, E), memory16=run.cast16(memory),
-                      Wq16=run.cast16(Wq))
+                      Wq16=run.cached('Wq16', [Wq], lambda: run.cast16(Wq)))
         d.bf16 = 1
         for k_, v_ in c.bf16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
     nv.decoder_train_fwd_loop(d)                                                         # model.py:405-411
 
     # mel + gate projection over all steps (model.py:373-378)
-    Wp = P['decoder.linear_projection.linear_layer.weight']      # (Cm, Hd+E)
-    Wg = P['decoder.gate_layer.linear_layer.weight']             # (1, Hd+E)
-    Wpg = run.empty(Cm + 1, Hd + E)
-    nv.copy2d(Wpg[:Cm], Wp)
-    nv.copy2d(Wpg[Cm:], Wg)
-    bpg = run.empty(Cm + 1)
-    nv.copy2d(bpg[:Cm].view(1, Cm), P['decoder.linear_projection.linear_layer.bias'].view(1, Cm))
-    nv.copy2d(bpg[Cm:].view(1, 1), P['decoder.gate_layer.linear_layer.bias'].view(1, 1))
+    Wpg, bpg = _packed_projection(run, P, Cm, Hd, E)             # rows: Cm mel channels, then the gate
     PG = run.empty(rowsD, Cm + 1)
     _fg(run, PG, slabs['HD'].view(rowsD, Hd), Wpg[:, :Hd])
     _fg(run, PG, slabs['CTX'].view(rowsD, E), Wpg[:, Hd:], accumulate=True, bias=bpg)
@@ -476,16 +564,21 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # data parallel: buckets are all-reduced over RCCL as soon as they are complete (distributed.py)
     sync = getattr(model, '_grad_sync', None)
     if sync is not None:
-        sync.start()
+        sync.start(run.dev)
+
+    def G(name, *shape):
+        """Where the kernels write the gradient of parameter ``name``: straight into its bucket when gradients
+        are exchanged (no packing pass before the all-reduce), a fresh buffer otherwise."""
+        return sync.out(name, shape) if sync is not None else run.empty(*shape)
 
     # ---- output boundary -> postnet backward ----------------------------------------------
     dmel_cl = run.empty(B, To, Cm)
     dpost_cl = run.empty(B, To, Cm)
     nv.grads_to_channel_last(cont(d_mel), cont(d_post), dmel_cl, dpost_cl)
     _conv_stack_bwd(run, P, g, 'postnet.convolutions', c.post_saved, dpost_cl.view(rowsP, Cm), To,
-                    first_dx=dmel_cl.view(rowsP, Cm), first_dx_accumulate=True)
+                    first_dx=dmel_cl.view(rowsP, Cm), first_dx_accumulate=True, G=G)
     if sync is not None:
-        sync.bucket_ready('postnet', g)          # travels while the decoder BPTT below runs
+        sync.bucket_ready('postnet')             # travels while the decoder BPTT below runs
     dout = run.empty(rowsD, Cm + 1)
     nv.gather_dout(dmel_cl, cont(d_gate), dout)
 
@@ -497,24 +590,34 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     dWpg_c = run.empty(Cm + 1, E)
     _rg(run, dWpg_h, dout, S['HD'].view(rowsD, Hd), a_km=True, b_kn=True)
     _rg(run, dWpg_c, dout, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
-    dWp = run.empty(Cm, Hd + E)
-    dWg = run.empty(1, Hd + E)
+    dWp = G('decoder.linear_projection.linear_layer.weight', Cm, Hd + E)
+    dWg = G('decoder.gate_layer.linear_layer.weight', 1, Hd + E)
     nv.copy2d(dWp[:, :Hd], dWpg_h[:Cm]); nv.copy2d(dWp[:, Hd:], dWpg_c[:Cm])
     nv.copy2d(dWg[:, :Hd], dWpg_h[Cm:]); nv.copy2d(dWg[:, Hd:], dWpg_c[Cm:])
     dbpg = run.empty(Cm + 1)
     run.colsum(dout, dbpg)
+    dbp = G('decoder.linear_projection.linear_layer.bias', Cm)
+    dbg = G('decoder.gate_layer.linear_layer.bias', 1)
+    nv.copy2d(dbp.view(1, Cm), dbpg[:Cm].view(1, Cm))
+    nv.copy2d(dbg.view(1, 1), dbpg[Cm:].view(1, 1))
     g['decoder.linear_projection.linear_layer.weight'] = dWp
     g['decoder.gate_layer.linear_layer.weight'] = dWg
-    g['decoder.linear_projection.linear_layer.bias'] = dbpg[:Cm].clone()
-    g['decoder.gate_layer.linear_layer.bias'] = dbpg[Cm:].clone()
+    g['decoder.linear_projection.linear_layer.bias'] = dbp
+    g['decoder.gate_layer.linear_layer.bias'] = dbg
 
     # ---- BPTT through the decoder loop ----------------------------------------------------
     Wq = P['decoder.attention_layer.query_layer.linear_layer.weight']
-    Wa_recT = run.empty(E + Ha, 4 * Ha)
-    nv.transpose(Wa_recT, T['Wa_rec'])
-    Wd_catT = run.empty(Ha + E + Hd, 4 * Hd)
-    nv.transpose(Wd_catT, T['Wd_cat'])
-    ns = int(os.environ.get('T2AMD_DGRAD_SPLIT', '2'))      # split-K factor of the two BPTT dgrad GEMMs
+    Wih_a, Whh_a = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
+    Wih_d, Whh_d = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
+
+    def transposed(src, rows, cols):
+        Wt = run.empty(rows, cols)
+        nv.transpose(Wt, src)
+        return Wt
+
+    Wa_recT = run.cached('Wa_recT', [Wih_a, Whh_a], lambda: transposed(T['Wa_rec'], E + Ha, 4 * Ha))
+    Wd_catT = run.cached('Wd_catT', [Wih_d, Whh_d], lambda: transposed(T['Wd_cat'], Ha + E + Hd, 4 * Hd))
+    ns = DGRAD_SPLIT                                        # split-K factor of the two BPTT dgrad GEMMs
     bw = nv.DecTrainBwd()
     bw.f = c.dec
     bw.Wa_recT, bw.Wd_catT = nv.ptr(Wa_recT), nv.ptr(Wd_catT)
@@ -529,7 +632,8 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     for k_, v_ in out.items():
         setattr(bw, k_, nv.ptr(v_))
     if run.bf16:
-        b16 = dict(Wa_recT16=run.cast16(Wa_recT), Wd_catT16=run.cast16(Wd_catT),
+        b16 = dict(Wa_recT16=run.cached('Wa_recT16', [Wih_a, Whh_a], lambda: run.cast16(Wa_recT)),
+                   Wd_catT16=run.cached('Wd_catT16', [Wih_d, Whh_d], lambda: run.cast16(Wd_catT)),
                    DGA16=run.empty16(B, 4 * Ha), DGD16=run.empty16(B, 4 * Hd))
         for k_, v_ in b16.items():
             setattr(bw, k_, nv.ptr(v_, torch.bfloat16))
@@ -540,21 +644,21 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # location layer + v
     Wdense = P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']
     Wconv = P['decoder.attention_layer.location_layer.location_conv.conv.weight']
-    dWdense = run.empty(A, nv.LOC_FILTERS)
-    dWconv = run.empty(nv.LOC_FILTERS, 2, nv.LOC_KERNEL)
-    dv = run.empty(1, A)
+    dWdense = G('decoder.attention_layer.location_layer.location_dense.linear_layer.weight', A, nv.LOC_FILTERS)
+    dWconv = G('decoder.attention_layer.location_layer.location_conv.conv.weight', nv.LOC_FILTERS, 2, nv.LOC_KERNEL)
+    dv = G('decoder.attention_layer.v.linear_layer.weight', 1, A)
     nv.unfold_location_grads(out['dU_acc'], out['dv_acc'], B, Wdense, Wconv, dWdense, dWconv, dv)
     g['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'] = dWdense
     g['decoder.attention_layer.location_layer.location_conv.conv.weight'] = dWconv
     g['decoder.attention_layer.v.linear_layer.weight'] = dv
     # query layer: dWq = DQ^T . HA
-    dWq = run.empty(A, Ha)
+    dWq = G('decoder.attention_layer.query_layer.linear_layer.weight', A, Ha)
     _rg(run, dWq, DQ.view(rowsD, A), S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
     g['decoder.attention_layer.query_layer.linear_layer.weight'] = dWq
 
     # attention LSTM weights: inputs [prenet_t | ctx_{t-1} | h_att_{t-1}]
-    dWih_a = run.empty(4 * Ha, Pd + E)
-    dWhh_a = run.empty(4 * Ha, Ha)
+    dWih_a = G('decoder.attention_rnn.weight_ih', 4 * Ha, Pd + E)
+    dWhh_a = G('decoder.attention_rnn.weight_hh', 4 * Ha, Ha)
     tmp = run.empty(4 * Ha, Pd)
     _rg(run, tmp, DGA2, T['p2'], a_km=True, b_kn=True)
     nv.copy2d(dWih_a[:, :Pd], tmp)
@@ -568,16 +672,18 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         nv.fill(dWhh_a, 0.0)
         z = run.zeros(4 * Ha, E)
         nv.copy2d(dWih_a[:, Pd:], z)
-    db_a = run.empty(4 * Ha)
+    db_a = G('decoder.attention_rnn.bias_ih', 4 * Ha)
     run.colsum(DGA2, db_a)
+    db_a2 = G('decoder.attention_rnn.bias_hh', 4 * Ha)
+    nv.copy2d(db_a2.view(1, -1), db_a.view(1, -1))
     g['decoder.attention_rnn.weight_ih'] = dWih_a
     g['decoder.attention_rnn.weight_hh'] = dWhh_a
     g['decoder.attention_rnn.bias_ih'] = db_a
-    g['decoder.attention_rnn.bias_hh'] = db_a.clone()
+    g['decoder.attention_rnn.bias_hh'] = db_a2
 
     # decoder LSTM weights: inputs [h_att_t | ctx_t | h_dec_{t-1}]
-    dWih_d = run.empty(4 * Hd, Ha + E)
-    dWhh_d = run.empty(4 * Hd, Hd)
+    dWih_d = G('decoder.decoder_rnn.weight_ih', 4 * Hd, Ha + E)
+    dWhh_d = G('decoder.decoder_rnn.weight_hh', 4 * Hd, Hd)
     tmp3 = run.empty(4 * Hd, Ha)
     _rg(run, tmp3, DGD2, S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
     nv.copy2d(dWih_d[:, :Ha], tmp3)
@@ -589,25 +695,26 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         _rg(run, dWhh_d, DGD2[B:], S['HD'].view(rowsD, Hd)[:sh], a_km=True, b_kn=True)
     else:
         nv.fill(dWhh_d, 0.0)
-    db_d = run.empty(4 * Hd)
+    db_d = G('decoder.decoder_rnn.bias_ih', 4 * Hd)
     run.colsum(DGD2, db_d)
+    db_d2 = G('decoder.decoder_rnn.bias_hh', 4 * Hd)
+    nv.copy2d(db_d2.view(1, -1), db_d.view(1, -1))
     g['decoder.decoder_rnn.weight_ih'] = dWih_d
     g['decoder.decoder_rnn.weight_hh'] = dWhh_d
     g['decoder.decoder_rnn.bias_ih'] = db_d
-    g['decoder.decoder_rnn.bias_hh'] = db_d.clone()
+    g['decoder.decoder_rnn.bias_hh'] = db_d2
 
     # prenet backward (model.py:99 under autograd)
-    Wih_a = P['decoder.attention_rnn.weight_ih']
     W2 = P['decoder.prenet.layers.1.linear_layer.weight']
     dp2 = run.empty(rowsD, Pd)
     _ng(run, dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
     nv.relu_dropout_bwd(dp2, T['p2'], 2.0)
-    dW2 = run.empty(Pd, Pd)
+    dW2 = G('decoder.prenet.layers.1.linear_layer.weight', Pd, Pd)
     _rg(run, dW2, dp2, T['p1'], a_km=True, b_kn=True)
     dp1 = run.empty(rowsD, Pd)
     _ng(run, dp1, dp2, W2, b_kn=True)
     nv.relu_dropout_bwd(dp1, T['p1'], 2.0)
-    dW1 = run.empty(Pd, Cm)
+    dW1 = G('decoder.prenet.layers.0.linear_layer.weight', Pd, Cm)
     _rg(run, dW1, dp1, T['x0'].view(rowsD, Cm), a_km=True, b_kn=True)
     g['decoder.prenet.layers.0.linear_layer.weight'] = dW1
     g['decoder.prenet.layers.1.linear_layer.weight'] = dW2
@@ -618,19 +725,18 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     _ng(run, dmem[0], S['ALIGN'][0], DCTX[:, 0, :], a_km=True, b_kn=True, batch=B,
             strides=(To * Ti, E, Ti * E))
     _ng(run, dmem.view(rowsE, E), d_pm.view(rowsE, A), Wmem, b_kn=True, accumulate=True)
-    dWmem = run.empty(A, E)
+    dWmem = G('decoder.attention_layer.memory_layer.linear_layer.weight', A, E)
     _rg(run, dWmem, d_pm.view(rowsE, A), c.memory.view(rowsE, E), a_km=True, b_kn=True)
     g['decoder.attention_layer.memory_layer.linear_layer.weight'] = dWmem
 
     if sync is not None:
-        sync.bucket_ready('decoder', g)          # travels while the encoder backward runs
+        sync.bucket_ready('decoder')             # travels while the encoder backward runs
     # ---- encoder backward -----------------------------------------------------------------
     dx3 = run.empty(rowsE, E)
     bdesc, DGs, keepalive = [], [], []
     for d, sfx in enumerate(('', '_reverse')):
         L = c.enc_lstm[d]
-        WhhT = run.empty(He, 4 * He)
-        nv.transpose(WhhT, L['Whh'])
+        WhhT = run.cached('enc_WhhT' + sfx, [L['Whh']], lambda L=L: transposed(L['Whh'], He, 4 * He))
         DG = run.empty(rowsE, 4 * He)
         desc = nv.LstmSeq()
         desc.B, desc.T, desc.H, desc.reverse = B, Ti, He, d
@@ -650,26 +756,28 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     nv.lstm_seq_bwd2(bdesc[0], bdesc[1])                                 # both directions, paired launches
     for d, sfx in enumerate(('', '_reverse')):
         L, DG = c.enc_lstm[d], DGs[d]
-        dWih = run.empty(4 * He, E)
+        dWih = G('encoder.lstm.weight_ih_l0' + sfx, 4 * He, E)
         _rg(run, dWih, DG, c.x3, a_km=True, b_kn=True)
         # h_prev of row (b,t) is the output at (b, t-1) forward / (b, t+1) reverse, zero outside [0,T)
-        dWhh = run.empty(4 * He, He)
+        dWhh = G('encoder.lstm.weight_hh_l0' + sfx, 4 * He, He)
         hview = c.memory.view(rowsE, E)[:, d * He:(d + 1) * He]
         _rg(run, dWhh, DG, hview, a_km=True, b_kn=True, convB=(Ti, He, 1 if d == 0 else -1))
-        db = run.empty(4 * He)
+        db = G('encoder.lstm.bias_ih_l0' + sfx, 4 * He)
         run.colsum(DG, db)
+        db2 = G('encoder.lstm.bias_hh_l0' + sfx, 4 * He)
+        nv.copy2d(db2.view(1, -1), db.view(1, -1))
         g['encoder.lstm.weight_ih_l0' + sfx] = dWih
         g['encoder.lstm.weight_hh_l0' + sfx] = dWhh
         g['encoder.lstm.bias_ih_l0' + sfx] = db
-        g['encoder.lstm.bias_hh_l0' + sfx] = db.clone()
+        g['encoder.lstm.bias_hh_l0' + sfx] = db2
         _ng(run, dx3, DG, L['Wih'], b_kn=True, accumulate=(d == 1))
     demb = run.empty(rowsE, E)
-    _conv_stack_bwd(run, P, g, 'encoder.convolutions', c.enc_saved, dx3, Ti, first_dx=demb)
-    dtable = run.empty(*P['embedding.weight'].shape)
+    _conv_stack_bwd(run, P, g, 'encoder.convolutions', c.enc_saved, dx3, Ti, first_dx=demb, G=G)
+    dtable = G('embedding.weight', *P['embedding.weight'].shape)
     nv.embedding_bwd(c.text, demb, dtable)
     g['embedding.weight'] = dtable
     if sync is not None:
-        sync.bucket_ready('encoder', g)
+        sync.bucket_ready('encoder')
         sync.finish()
     return g
 
@@ -684,12 +792,18 @@ class Tacotron2TrainFunction(torch.autograd.Function):
             if p.dtype != torch.float32:
                 raise NativeError("parameter %s is %s: this build of the engine computes in fp32" % (n, p.dtype))
         outs, c = _forward(model, P, buffers, text, in_lens, mels, max_len, out_lens, model.training)
-        ctx.model, ctx.names, ctx.c, ctx.P = model, names, c, P
+        # an eval-mode forward (validation, reference train.py:133) can never be differentiated: its activation
+        # slabs are released right here instead of living until the outputs die
+        ctx.model, ctx.names, ctx.P = model, names, P
+        ctx.c = c if model.training else _EvalCtx()
         ctx.set_materialize_grads(False)
         return outs
 
     @staticmethod
     def backward(ctx, d_mel, d_post, d_gate, d_align):
+        if ctx.c is None:
+            raise NativeError("the engine's saved activations were released by the first backward: "
+                              "retain_graph / a second backward through the same forward is not supported")
         if not ctx.c.training:
             raise NativeError("backward through an eval-mode forward is not supported")
         grads = _backward(ctx.model, ctx.P, ctx.c, d_mel, d_post, d_gate, d_align)
@@ -715,7 +829,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     for n, p in P.items():
         if p.dtype != torch.float32:
             raise NativeError("parameter %s is %s: this build of the engine computes in fp32" % (n, p.dtype))
-    run = _Run(dev, getattr(model, 'precision', 'fp32'))
+    run = _Run(dev, getattr(model, 'precision', 'fp32'), _weight_cache(model))
     ms = MaskSource(model.dropout_masks, dev)
     B, Ti = text.shape
     E = hp.encoder_embedding_dim
@@ -750,7 +864,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     for d, sfx in enumerate(('', '_reverse')):
         Wih = P['encoder.lstm.weight_ih_l0' + sfx]
         Whh = P['encoder.lstm.weight_hh_l0' + sfx]
-        bsum = _bias_sum(run, P['encoder.lstm.bias_ih_l0' + sfx], P['encoder.lstm.bias_hh_l0' + sfx])
+        bsum = _cached_bias_sum(run, 'enc_bias' + sfx, P['encoder.lstm.bias_ih_l0' + sfx], P['encoder.lstm.bias_hh_l0' + sfx])
         GX = run.empty(rowsE, 4 * He)
         nv.gemm(GX, x3, Wih, bias=bsum)
         Cst = run.empty(Ti, B, He)
@@ -770,25 +884,29 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
 
     Wih_a, Whh_a = P['decoder.attention_rnn.weight_ih'], P['decoder.attention_rnn.weight_hh']
     Wih_d, Whh_d = P['decoder.decoder_rnn.weight_ih'], P['decoder.decoder_rnn.weight_hh']
-    bias_a = _bias_sum(run, P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
-    bias_d = _bias_sum(run, P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
-    Wa_cat = run.empty(4 * Ha, Pd + E + Ha)
-    nv.copy2d(Wa_cat[:, :Pd + E], Wih_a)
-    nv.copy2d(Wa_cat[:, Pd + E:], Whh_a)
-    Wd_cat = run.empty(4 * Hd, Ha + E + Hd)
-    nv.copy2d(Wd_cat[:, :Ha + E], Wih_d)
-    nv.copy2d(Wd_cat[:, Ha + E:], Whh_d)
+    bias_a = _cached_bias_sum(run, 'bias_a', P['decoder.attention_rnn.bias_ih'], P['decoder.attention_rnn.bias_hh'])
+    bias_d = _cached_bias_sum(run, 'bias_d', P['decoder.decoder_rnn.bias_ih'], P['decoder.decoder_rnn.bias_hh'])
+
+    def pack_a_cat():
+        W = run.empty(4 * Ha, Pd + E + Ha)
+        nv.copy2d(W[:, :Pd + E], Wih_a)
+        nv.copy2d(W[:, Pd + E:], Whh_a)
+        return W
+
+    def pack_d_cat():
+        W = run.empty(4 * Hd, Ha + E + Hd)
+        nv.copy2d(W[:, :Ha + E], Wih_d)
+        nv.copy2d(W[:, Ha + E:], Whh_d)
+        return W
+
+    Wa_cat = run.cached('Wa_cat', [Wih_a, Whh_a], pack_a_cat)
+    Wd_cat = run.cached('Wd_cat', [Wih_d, Whh_d], pack_d_cat)
     Wq = P['decoder.attention_layer.query_layer.linear_layer.weight'].contiguous()
-    U = run.empty(A * nv.LOC_TAPS)
-    nv.fold_location(P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'],
-                     P['decoder.attention_layer.location_layer.location_conv.conv.weight'], U)
+    Wdense = P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']
+    Wconv = P['decoder.attention_layer.location_layer.location_conv.conv.weight']
+    U = run.cached('U', [Wdense, Wconv], lambda: _fold_U(run, Wdense, Wconv))
     vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
-    Wpg = run.empty(Cm + 1, Hd + E)
-    nv.copy2d(Wpg[:Cm], P['decoder.linear_projection.linear_layer.weight'])
-    nv.copy2d(Wpg[Cm:], P['decoder.gate_layer.linear_layer.weight'])
-    bpg = run.empty(Cm + 1)
-    nv.copy2d(bpg[:Cm].view(1, Cm), P['decoder.linear_projection.linear_layer.bias'].view(1, Cm))
-    nv.copy2d(bpg[Cm:].view(1, 1), P['decoder.gate_layer.linear_layer.bias'].view(1, 1))
+    Wpg, bpg = _packed_projection(run, P, Cm, Hd, E)
 
     keep = ms.get('prenet_infer', None, (max_steps, 2, B, Pd), 0.5)
 
@@ -820,7 +938,9 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     if run.bf16:
         # bf16 operand mode of the two LSTM products: B > 8 reads bf16 weights and bf16 copies of the recurrent
         # operands (wide MFMA kernel); the matrix-vector path of B <= 8 reads bf16 weight rows against f32 inputs
-        i16 = dict(Wa_cat16=run.cast16(Wa_cat), Wd_cat16=run.cast16(Wd_cat), x_prenet16=run.empty16(B, Pd),
+        i16 = dict(Wa_cat16=run.cached('Wa_cat16', [Wih_a, Whh_a], lambda: run.cast16(Wa_cat)),
+                   Wd_cat16=run.cached('Wd_cat16', [Wih_d, Whh_d], lambda: run.cast16(Wd_cat)),
+                   x_prenet16=run.empty16(B, Pd),
                    h_a16=torch.zeros(2, B, Ha, dtype=torch.bfloat16, device=dev),
                    hc16=torch.zeros(2, B, Hd + E, dtype=torch.bfloat16, device=dev))
         d.bf16 = 1

@@ -14,7 +14,10 @@ Differences from the torch pair, all deliberate:
   * the clip factor is applied while the gradient is read: ``p.grad`` itself is left unscaled (the
     reference's loop never looks at it again before ``zero_grad``);
   * ``step()`` without ``clip_norm`` is a plain Adam step; ``clip_norm`` returns the pre-clip global
-    norm as a 0-d device tensor, like ``clip_grad_norm_``.
+    norm as a 0-d device tensor, like ``clip_grad_norm_``;
+  * with ``clip_norm``, a non-finite global norm skips the update ON THE DEVICE (weights and moments untouched,
+    no host synchronisation); the caller that later reads the norm calls ``undo_step_count()`` so the bias
+    correction does not count the skipped step.
 Unsupported options raise (amsgrad, maximize, capturable, differentiable, decoupled weight decay,
 sparse or non-f32 gradients): there is no silent fallback to torch's implementation.
 """
@@ -102,4 +105,15 @@ class FusedAdam(torch.optim.Adam):
                 nv.adam_step(L, h, norm)
             for s in steps:
                 s += 1.0
+        # the kernels update the weights through raw pointers: torch's version counters do not see it
+        from . import engine
+        engine.bump_weight_generation()
         return norm[0] if norm is not None else None
+
+    def undo_step_count(self):
+        """The last ``step(clip_norm=...)`` was skipped on the device (non-finite norm): take it out of the counts."""
+        for group in self.param_groups:
+            for p in group['params']:
+                st = self.state.get(p)
+                if st and 'step' in st and float(st['step']) > 0:
+                    st['step'] -= 1.0

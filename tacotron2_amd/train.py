@@ -36,6 +36,8 @@ from .logger import Tacotron2Logger
 from .loss_function import Tacotron2Loss
 from .model import Tacotron2
 
+MAX_NONFINITE_STEPS = 10        # consecutive iterations with a non-finite gradient norm before the run is declared diverged
+
 __all__ = ['reduce_tensor', 'init_distributed', 'prepare_dataloaders', 'prepare_directories_and_logger',
            'load_model', 'warm_start_model', 'load_checkpoint', 'save_checkpoint', 'validate', 'train']
 
@@ -222,6 +224,7 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
 
     model.train()
     done = False
+    bad_steps = 0
     for epoch in range(first_epoch, hparams.epochs):
         print("Epoch: {}".format(epoch))
         if hparams.distributed_run and isinstance(train_loader.sampler, DistributedSampler):
@@ -236,13 +239,29 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
             shown = reduce_tensor(loss, n_gpus) if hparams.distributed_run else loss.detach()
             loss.backward()
             if fused_optimizer:
+                # a non-finite norm skips the update inside the kernel; the host learns about it below
                 grad_norm = optimizer.step(clip_norm=hparams.grad_clip_thresh)
+                reduced_loss, grad_norm = (float(v) for v in torch.stack([shown.float(), grad_norm.float()]).tolist())
+                finite = math.isfinite(grad_norm)
+                if not finite:
+                    optimizer.undo_step_count()
             else:
                 grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), hparams.grad_clip_thresh)
-                optimizer.step()
-            # the whole step is enqueued: one host read for both scalars
-            reduced_loss, grad_norm = (float(v) for v in torch.stack([shown.float(), grad_norm.float()]).tolist())
-            finite = not (math.isnan(grad_norm) or math.isinf(grad_norm))
+                # one host read per iteration either way; taken BEFORE the update so that an overflowed step
+                # (bf16 compute mode has no loss scaler) is skipped instead of poisoning weights and moments
+                reduced_loss, grad_norm = (float(v) for v in torch.stack([shown.float(), grad_norm.float()]).tolist())
+                finite = math.isfinite(grad_norm)
+                if finite:
+                    optimizer.step()
+            if not finite:
+                bad_steps += 1
+                print("Warning: non-finite gradient norm at iteration {} (loss {}): optimiser step skipped "
+                      "({} in a row)".format(iteration, reduced_loss, bad_steps), flush=True)
+                if bad_steps >= MAX_NONFINITE_STEPS:
+                    raise FloatingPointError("%d consecutive iterations with a non-finite gradient norm: the run "
+                                             "has diverged (last loss %r)" % (bad_steps, reduced_loss))
+            else:
+                bad_steps = 0
             if finite and rank == 0:
                 duration = time.perf_counter() - start
                 print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(

@@ -3,8 +3,9 @@
   * GradSync (the engine-driven bucketed all-reduce): after bucket_ready()+finish() every rank holds
     the world-mean gradient, bucketed postnet -> decoder -> encoder, and the tensors handed back
     are views into the flat bucket buffers;
-  * apply_gradient_allreduce on a generic module: state broadcast from rank 0, and
-    N ranks x B  ==  1 rank x N*B for the mean-loss gradient (the reference's DP contract).
+  * the same through GradSync.out(): the engine's kernels write into the buckets directly;
+  * apply_gradient_allreduce: state broadcast from rank 0; modules other than Tacotron2 are refused.
+  (N ranks x B == mean of the single-rank gradients with the REAL engine: tests/test_zz6_dp_gpu.py.)
 """
 import os
 import socket
@@ -61,21 +62,29 @@ def _worker(rank, world, port, q):
         names = [n for n, _ in model.named_parameters() if n.startswith('postnet.')]
         assert grads[names[0]].untyped_storage().data_ptr() == grads[names[1]].untyped_storage().data_ptr()
 
-        # ---- generic module: N ranks x B == 1 rank x N*B ----
-        torch.manual_seed(5 + rank)
+        # ---- the engine writes straight into the buckets: out() views, 256-byte aligned, no packing pass ----
+        sync.start(torch.device('cpu'))
+        mine2 = {}
+        for n, p in model.named_parameters():
+            o = sync.out(n, p.shape)
+            assert o.shape == p.shape and o.data_ptr() % 256 == sync.flat[bucket_of(n)].data_ptr() % 256
+            o.copy_(torch.randn(p.shape, generator=g))
+            mine2[n] = o.clone()
+        for b in ('postnet', 'decoder', 'encoder'):
+            sync.bucket_ready(b)
+        sync.finish()
+        for n, p in model.named_parameters():
+            other = torch.randn(p.shape, generator=g_other)
+            assert torch.allclose(sync.out(n, p.shape), (mine2[n] + other) / 2, atol=1e-6), n
+
+        # ---- any other module is refused (only the engine knows when a bucket is complete) ----
         net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
-        apply_gradient_allreduce(net)
-        apply_gradient_allreduce(net)                       # the reference wraps twice; must be harmless
-        xg = torch.Generator().manual_seed(11)
-        X, Y = torch.randn(8, 6, generator=xg), torch.randn(8, 2, generator=xg)
-        lo = rank * 4
-        loss = torch.nn.functional.mse_loss(net(X[lo:lo + 4]), Y[lo:lo + 4])
-        loss.backward()
-        single = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
-        single.load_state_dict(net.state_dict())
-        torch.nn.functional.mse_loss(single(X), Y).backward()
-        for a, b in zip(net.parameters(), single.parameters()):
-            assert torch.allclose(a.grad, b.grad, atol=1e-6)
+        try:
+            apply_gradient_allreduce(net)
+            raise AssertionError("generic module accepted")
+        except TypeError:
+            pass
+        apply_gradient_allreduce(model)                     # the reference wraps twice (train.py:79,179); harmless
         m = reduce_tensor(torch.tensor(float(rank + 1)), world)
         assert abs(m.item() - 1.5) < 1e-6
         q.put((rank, "ok"))

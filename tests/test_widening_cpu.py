@@ -130,7 +130,7 @@ def test_loader_filelist_shuffle_npy_and_synthetic(tmp_path, monkeypatch):
     for i in range(50):
         p = tmp_path / ("f%d.npy" % i)
         np.save(p, np.full((80, 5 + i % 7), float(i), dtype=np.float32))
-        lines.append("%s|%s" % (p, " ".join(str(1 + (i + k) % 147) for k in range(3 + i % 5))))
+        lines.append("%s|ids: %s" % (p, " ".join(str(1 + (i + k) % 147) for k in range(3 + i % 5))))
     fl = tmp_path / "list.txt"
     fl.write_text("\n".join(lines) + "\n", encoding="utf-8")
     hp = create_hparams("load_mel_from_disk=True")
@@ -146,6 +146,10 @@ def test_loader_filelist_shuffle_npy_and_synthetic(tmp_path, monkeypatch):
         ds.get_mel(str(tmp_path / "bad.npy"))
     with pytest.raises(RuntimeError):
         ds.get_text("plain words need a text frontend")
+    with pytest.raises(RuntimeError):
+        ds.get_text("1984")                                  # digits are text, not symbol id 1984 (explicit 'ids:' opt-in)
+    with pytest.raises(ValueError):
+        ds.get_text("ids: 5 1984")                           # out of range for the embedding
     ds2 = TextMelLoader(str(fl), hp, text_to_sequence=lambda t, cleaners: [len(t), len(cleaners)])
     assert ds2.get_text("abc").tolist() == [3, 1]
     syn = TextMelLoader("synthetic:6:7", create_hparams())

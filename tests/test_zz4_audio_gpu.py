@@ -76,7 +76,7 @@ def test_precompute_mels_and_loader_roundtrip(native_lib, tmp_path):
     wav = tmp_path / "utt0.wav"
     write(str(wav), 22050, pcm.numpy())
     fl = tmp_path / "list.txt"
-    fl.write_text("%s|5 6 7\n" % wav, encoding="utf-8")
+    fl.write_text("%s|ids: 5 6 7\n" % wav, encoding="utf-8")
     n = precompute_mels(str(fl), hp, str(tmp_path / "mels"), out_filelist=str(tmp_path / "mels.txt"))
     assert n == 1
     ref = ao.mel_spectrogram((pcm.float() / hp.max_wav_value).unsqueeze(0))[0]

@@ -1,0 +1,284 @@
+"""Parity at BASELINE scale against the LIVE oracle (shared dropout masks), both precision modes.
+
+  (i)   training: every 4th utterance of ``synth_batch(64, 1234)`` -- 16 utterances, Ti_max = 177, To = 870
+        (BASELINE configs[1] horizon: 870 dependent decoder steps forward and through BPTT), reference
+        model.py:405-411 under autograd;
+  (ii)  inference, B = 1, Ti = 100 (BASELINE configs[3]): greedy decode to a REAL gate stop beyond 300 steps,
+        stop index exact, once with a comfortable and once with a SMALL crossing margin, reference
+        model.py:435-449;
+  (iii) batched ragged inference with configs[4]'s length distribution (32 texts) against per-utterance oracle runs.
+
+Tolerances (stated here, measured values land in gpurun_out/parity_fullsize_*.json):
+  fp32 mode   outputs mean |diff| < 1e-4 (north star: mel L1 < 1e-4), max < 5e-4 * max(1, max|ref|);
+              loss 1e-4 relative; gradients max |diff| < 1e-3 * max|ref| + 2e-6 per tensor; stop index exact.
+  bf16 mode   decoder mel / gate mean |diff| < 4e-3, postnet mel < 6e-2, alignments < 2e-3, loss 2 % relative,
+              whole-gradient cosine > 0.995, per-tensor relative L2 < 0.35 (the reference's own bf16-autocast drift
+              at a 30-frame horizon is 6.7e-4 / 1.6e-2; 870 steps accumulate more of it).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import tacotron2_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OUT = os.path.join(gu.ROOT, "gpurun_out")
+
+
+def _stats(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    d = (a - b).abs()
+    return d.mean().item(), d.max().item(), b.abs().max().item()
+
+
+def _report(name, rows):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_fullsize_%s.json" % name), "w") as f:
+        json.dump(rows, f, indent=1)
+
+
+def _model(hp, sd):
+    from tacotron2_amd.model import Tacotron2
+    m = Tacotron2(hp)
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (i) training step at To = 870
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_train_case():
+    from tacotron2_amd.synth import synth_batch
+    hp = gu.make_hparams("")
+    sd = gu.build_state_dict(hp, 1234)
+    full = synth_batch(64, 1234)
+    idx = torch.arange(0, 64, 4)
+    text, il, mel, gate, ol = (t[idx] for t in full)
+    Ti, To = int(il.max()), int(ol.max())
+    assert To == 870 and Ti == 177
+    batch = (text[:, :Ti].contiguous(), il, mel[:, :, :To].contiguous(), gate[:, :To].contiguous(), ol)
+    masks = orc.draw_masks_train(hp, 16, Ti, To, torch.Generator().manual_seed(1234))
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    oloss, oout, ograds, obufs = orc.train_step_grads(sd, hp, batch, masks)
+    return dict(hp=hp, sd=sd, batch=batch, masks=masks, oloss=oloss, oout=oout, ograds=ograds, obufs=obufs)
+
+
+def _engine_step(case, precision):
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    model = _model(case['hp'], case['sd']).train()
+    model.precision = precision
+    model.dropout_masks = gu.masks_to_engine(case['masks'], DEV)
+    x, y = model.parse_batch(tuple(t.clone() for t in case['batch']))
+    out = model(x)
+    loss = Tacotron2Loss()(out, y)
+    loss.backward()
+    torch.cuda.synchronize()
+    return model, out, loss
+
+
+def test_train_step_To870_fp32(native_lib, full_train_case):
+    c = full_train_case
+    model, out, loss = _engine_step(c, 'fp32')
+    rows, bad = [], []
+    for i, nm in enumerate(('mel', 'mel_post', 'gate', 'align')):
+        mean, mx, rmax = _stats(out[i], c['oout'][i])
+        rows.append(dict(what=nm, mean=mean, max=mx, refmax=rmax))
+        if not (mean < 1e-4 and mx < 5e-4 * max(1.0, rmax)):
+            bad.append(rows[-1])
+    el, ol = float(loss.detach()), float(c['oloss'])
+    rows.append(dict(what='loss', engine=el, oracle=ol))
+    if not abs(el - ol) < 1e-4 * max(1.0, abs(ol)):
+        bad.append(rows[-1])
+    for k, p in model.named_parameters():
+        ref = c['ograds'][k]
+        mean, mx, rmax = _stats(p.grad, ref)
+        rows.append(dict(what='grad ' + k, mean=mean, max=mx, refmax=rmax))
+        if k.endswith('.0.conv.bias'):
+            # analytically zero (a bias in front of a BatchNorm): both sides hold rounding noise
+            wmax = c['ograds'][k.replace('.bias', '.weight')].abs().max().item()
+            if not p.grad.abs().max().item() < 1e-4 * wmax + 1e-5:
+                bad.append(rows[-1])
+            continue
+        if not mx < 1e-3 * rmax + 2e-6:
+            bad.append(rows[-1])
+    msd = model.state_dict()
+    for k, v in c['obufs'].items():
+        mean, mx, rmax = _stats(msd[k].float(), v.float())
+        if not mx < 1e-5 * max(1.0, rmax):
+            bad.append(dict(what='buffer ' + k, max=mx, refmax=rmax))
+    _report("train_fp32", dict(shape="B=16 (every 4th of synth_batch(64,1234)), Ti=177, To=870", rows=rows, bad=bad))
+    assert not bad, bad[:8]
+
+
+def test_train_step_To870_bf16(native_lib, full_train_case):
+    c = full_train_case
+    model, out, loss = _engine_step(c, 'bf16')
+    rows = []
+    lim = [4e-3, 6e-2, 4e-3, 2e-3]
+    fails = []
+    for i, nm in enumerate(("mel", "mel_post", "gate", "align")):
+        mean, mx, rmax = _stats(out[i], c['oout'][i])
+        rows.append(dict(what="bf16 " + nm, mean=mean, max=mx, refmax=rmax, limit=lim[i]))
+        if not mean < lim[i]:
+            fails.append(rows[-1])
+    worst, worst_k, dot, n1, n2 = 0.0, None, 0.0, 0.0, 0.0
+    for k, p in model.named_parameters():
+        ref = c['ograds'][k].double()
+        g = p.grad.cpu().double()
+        assert torch.isfinite(g).all(), k
+        if k.endswith('.0.conv.bias'):
+            continue
+        rel = ((g - ref).norm() / ref.norm().clamp_min(1e-30)).item()
+        rows.append(dict(what="bf16 grad " + k, rel_l2=rel))
+        if rel > worst:
+            worst, worst_k = rel, k
+        dot += float((g * ref).sum()); n1 += float((g * g).sum()); n2 += float((ref * ref).sum())
+    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
+    el, ol = float(loss.detach()), float(c['oloss'])
+    rows.append(dict(what="bf16 summary", engine_loss=el, oracle_loss=ol, grad_cosine=cos, worst_rel_l2=worst,
+                     worst_tensor=worst_k))
+    _report("train_bf16", dict(shape="B=16, Ti=177, To=870", rows=rows, fails=fails))
+    assert not fails, fails
+    assert abs(el - ol) < 2e-2 * abs(ol)
+    assert cos > 0.995, cos
+    assert worst < 0.35, (worst_k, worst)
+
+
+# ---------------------------------------------------------------------------------------------------
+# (ii) B = 1, Ti = 100, real gate stop beyond 300 steps
+# ---------------------------------------------------------------------------------------------------
+def _choose_thresholds(sig, lo_step):
+    """sig: sigmoid(gate) trajectory of ONE utterance decoded without stopping.  Returns a list of
+    (threshold, stop_length, margin) with the first crossing at index >= lo_step: one with the widest margin the
+    trajectory offers, one with a small margin (1e-4: two orders above the engine's f32 noise on the gate)."""
+    T = sig.numel()
+    best = None
+    for t in range(lo_step, T):
+        m = float(sig[:t].max())
+        if float(sig[t]) > m:                    # a first-crossing candidate for any thr in (m, sig[t])
+            margin = (float(sig[t]) - m) / 2
+            if best is None or margin > best[2]:
+                best = (m + margin, t + 1, margin)
+    assert best is not None, "no first-crossing candidate beyond step %d" % lo_step
+    out = [best]
+    t = best[1] - 1
+    m = float(sig[:t].max())
+    if float(sig[t]) - m > 4e-4:
+        out.append((float(sig[t]) - 1e-4, t + 1, 1e-4))
+    return out
+
+
+def test_inference_B1_Ti100_real_gate_stop(native_lib):
+    hp = gu.make_hparams("max_decoder_steps=520")
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    # Random weights give the gate an early transient and then a slow decay (its running maximum falls in the first
+    # ~100 steps whatever the seed).  Negating the CONTEXT half of the gate weight turns the attention drift into a
+    # slow rise with the decoder-LSTM noise on top: the first crossing of a threshold lands hundreds of steps in,
+    # the regime a trained model stops in.
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()
+    wg[:, hp.decoder_rnn_dim:] *= -1.0
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    text = gu.make_text([100], 4242)
+    keep = orc.draw_masks_infer(hp, 1, 520, torch.Generator().manual_seed(9))
+    # the oracle decoded without a stop: the whole gate trajectory
+    (mel_o, _, gate_o, al_o), _, _ = orc.tacotron2_inference(sd, hp, text, keep, 520, 2.0)
+    sig = torch.sigmoid(gate_o.reshape(-1))
+    cases = _choose_thresholds(sig, 300)
+    rows = []
+    for thr, L, margin in cases:
+        ohp = gu.make_hparams("max_decoder_steps=520")
+        ohp.gate_threshold = thr
+        oref, olen, _ = orc.tacotron2_inference(sd, ohp, text, keep)
+        assert olen.tolist() == [L]
+        model = _model(ohp, sd).eval()
+        model.dropout_masks = dict(prenet_infer=keep.to(DEV))
+        out = model.inference(text.to(DEV))
+        got = model.last_inference_lengths.tolist()
+        row = dict(threshold=thr, oracle_stop=L, engine_stop=got[0], margin=margin)
+        for i, nm in enumerate(('mel', 'mel_post', 'gate', 'align')):
+            if got == [L]:
+                mean, mx, rmax = _stats(out[i], oref[i])
+                row[nm] = dict(mean=mean, max=mx, refmax=rmax)
+        rows.append(row)
+        _report("infer_B1", rows)
+        assert got == [L], row                                             # bit-exact stop index, >= 300 steps
+        for nm in ('mel', 'mel_post', 'gate', 'align'):
+            assert row[nm]['mean'] < 1e-4 and row[nm]['max'] < 5e-4 * max(1.0, row[nm]['refmax']), (nm, row)
+    # bf16 mode on the same case: reported, with its own tolerance on the frames both runs produced
+    thr, L, margin = cases[0]
+    ohp = gu.make_hparams("max_decoder_steps=520")
+    ohp.gate_threshold = thr
+    model = _model(ohp, sd).eval()
+    model.precision = 'bf16'
+    model.dropout_masks = dict(prenet_infer=keep.to(DEV))
+    out = model.inference(text.to(DEV))
+    Lb = int(model.last_inference_lengths[0])
+    n = min(L, Lb)
+    mean, mx, rmax = _stats(out[0][:, :, :n], mel_o[:, :, :n])
+    rows.append(dict(what="bf16 mode", oracle_stop=L, engine_stop=Lb, mel_mean=mean, mel_max=mx, refmax=rmax))
+    _report("infer_B1", rows)
+    assert mean < 2e-2 * max(float(mel_o.abs().mean()), 1e-3), rows[-1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# (iii) ragged batch with configs[4] lengths against per-utterance oracle runs
+# ---------------------------------------------------------------------------------------------------
+def test_batched_inference_config5_lengths(native_lib):
+    from tacotron2_amd.synth import synth_lengths
+    B, steps = 32, 240
+    ti, _ = synth_lengths(256, 1234)
+    lens = [int(v) for v in ti[::8]]                       # 32 of the 256 config-5 lengths, descending (187 .. 15)
+    hp = gu.make_hparams("max_decoder_steps=%d" % steps)
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()      # slow rise of the gate, as in the B = 1 test above
+    wg[:, hp.decoder_rnn_dim:] *= -1.0
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    text = gu.make_text(lens, 777)
+    keep = orc.draw_masks_infer(hp, B, steps, torch.Generator().manual_seed(10))
+    il = torch.tensor(lens)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    (_, _, gate_o, _), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0, input_lengths=il)
+    sig = torch.sigmoid(gate_o.reshape(B, steps))
+    # threshold: at least a third of the utterances stop before max_decoder_steps, at most two of them inside the
+    # initial transient (< 30 steps), widest worst-case margin
+    best = None
+    for thr in torch.linspace(float(sig.min()), float(sig.max()), 800)[1:-1].tolist():
+        over = sig > thr
+        stop = torch.where(over.any(1), over.float().argmax(1) + 1, torch.full((B,), steps))
+        if int((stop < steps).sum()) < B // 3 or int((stop < 30).sum()) > 2:
+            continue
+        marg = min(float((sig[b, :int(stop[b])] - thr).abs().min()) for b in range(B))
+        if best is None or marg > best[1]:
+            best = (thr, marg, stop)
+    assert best is not None
+    thr, marg, stop = best
+    ohp = gu.make_hparams("max_decoder_steps=%d" % steps)
+    ohp.gate_threshold = thr
+    model = _model(ohp, sd).eval()
+    model.dropout_masks = dict(prenet_infer=keep.to(DEV))
+    out = model.inference(text.to(DEV), il.to(DEV))
+    got = model.last_inference_lengths.tolist()
+    rows = dict(threshold=thr, margin=marg, expected=stop.tolist(), engine=got, per_utterance=[])
+    _report("infer_config5", rows)
+    assert got == stop.tolist()
+    # per-utterance oracle runs (reference semantics: B == 1 on the unpadded text) on a spread of utterances
+    early = [b for b in range(B) if int(stop[b]) < steps]
+    for b in sorted(set([0, B - 1] + early[:8])):
+        L = int(stop[b])
+        oref, olen, _ = orc.tacotron2_inference(sd, ohp, text[b:b + 1, :lens[b]], keep[:, :, b:b + 1])
+        assert olen.tolist() == [L]
+        r = dict(b=b, Ti=lens[b], stop=L)
+        for nm, g_, w_ in (('mel', out[0][b, :, :L], oref[0][0]), ('mel_post', out[1][b, :, :L], oref[1][0]),
+                           ('align', out[3][b, :L, :lens[b]], oref[3][0])):
+            mean, mx, rmax = _stats(g_, w_)
+            r[nm] = dict(mean=mean, max=mx, refmax=rmax)
+        rows['per_utterance'].append(r)
+        _report("infer_config5", rows)
+        for nm in ('mel', 'mel_post', 'align'):
+            assert r[nm]['mean'] < 1e-4 and r[nm]['max'] < 5e-4 * max(1.0, r[nm]['refmax']), r
+        assert out[0][b, :, L:].abs().sum().item() == 0
