@@ -576,6 +576,46 @@ typedef struct t2amd_dec_infer {
 
 int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);
 
+/* Persistent, weight-stationary decode loop for ONE utterance (reference model.py:435-449 Decoder.inference's loop
+ * around Decoder.decode :340-379; Prenet :97-100; Attention :43-86; LocationLayer :22-26): ONE launch of H/4
+ * co-resident workgroups runs every step until the gate fires or max_steps is reached.  Each workgroup keeps its 16 rows
+ * of both LSTM matrices (bf16) in LDS for the whole utterance; the six per-step vectors (p2, h_att, partial energies,
+ * context, h_dec, p1 + stop flag) travel between workgroups as 8-byte {step + 1, f32} granules (agent-scope relaxed
+ * stores / polled loads, no fences).  Prenet layer 0 is folded through the frame projection (Wf below).  Requires
+ * attention_rnn_dim == decoder_rnn_dim = H, H/4 <= number of CUs, Ti <= 256 (t2amd_decoder_persist_supported).  Spins
+ * are bounded (30 ms): on a timeout *status = T2AMD_PERSIST_TIMEOUT, every workgroup leaves and the caller must use
+ * t2amd_decoder_infer_steps_f32 instead. */
+#define T2AMD_PERSIST_TIMEOUT 7
+typedef struct t2amd_dec_persist {
+    int Ti, E, H, P, C;
+    int max_steps;
+    float gate_threshold;
+    const void* Wa16;      /* [4H][P+E+H] bf16 = [W_ih_att | W_hh_att] */
+    const void* Wd16;      /* [4H][H+E+H] bf16 = [W_ih_dec | W_hh_dec] */
+    const float* bias_a;   /* [4H] b_ih + b_hh */
+    const float* bias_d;   /* [4H] */
+    const float* Wq;       /* [128][H] */
+    const float* U;        /* [128][62] folded location filter (t2amd_fold_location_f32) */
+    const float* v;        /* [128] */
+    const float* Wf;       /* [P + C + 1][H+E]: rows 0..P-1 = W_prenet0 . W_proj, rows P..P+C-1 = W_proj, row P+C = W_gate */
+    const float* bias_f;   /* [P + C + 1]: W_prenet0 . b_proj, b_proj, b_gate */
+    const float* W2;       /* [P][P] prenet layer 1 */
+    const float* memory;   /* [Ti][E] encoder outputs */
+    const float* pm;       /* [Ti][128] processed memory */
+    const uint8_t* keep_prenet; /* [max_steps][2][1][P] */
+    float* PG;             /* [max_steps][C+1] frame + gate logit per step */
+    float* ALIGN;          /* [max_steps][Ti] */
+    int* out_length;       /* [1] frames emitted incl. the stopping frame */
+    int* status;           /* [1] 0 = ok */
+    int* steps_done;       /* [1] */
+    unsigned long long* mailbox;  /* t2amd_decoder_persist_mailbox_bytes() bytes, zeroed by the call */
+    float* trace;          /* NULL, or [max_steps][H + E + H + P + P]: h_att, ctx, h_dec, p1(t+1), p2(t+1) per step (tests) */
+} t2amd_dec_persist;
+
+long long t2amd_decoder_persist_mailbox_bytes(int Ti, int E, int H, int P);
+int t2amd_decoder_persist_supported(const t2amd_dec_persist* p);
+int t2amd_decoder_infer_persistent_f32(const t2amd_dec_persist* p, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Mel front end: element passes around the two GEMMs of
  * TacotronSTFT.mel_spectrogram (reference layers.py:63-80, stft.py:77-105,

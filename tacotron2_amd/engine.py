@@ -819,6 +819,74 @@ class Tacotron2TrainFunction(torch.autograd.Function):
 # ----------------------------------------------------------------------------
 # inference (reference model.py:517-529)
 # ----------------------------------------------------------------------------
+# T2AMD_DECODE_PERSISTENT=0 keeps single-utterance bf16 decoding on the launch chain (A/B runs, shared GPUs)
+PERSISTENT_DECODE = os.environ.get('T2AMD_DECODE_PERSISTENT', '1') != '0'
+
+
+def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat, bias_a, bias_d, Wq, U,
+                       vvec, Wpg, bpg, i16, Ti):
+    """reference model.py:435-449 (Decoder.inference loop) for B == 1 as one persistent launch.  Returns False when the
+    kernel cannot run here (geometry, or a bounded-spin timeout): the caller then runs the launch chain from step 0."""
+    import sys
+    E, H, Pd, Cm = hp.encoder_embedding_dim, hp.attention_rnn_dim, hp.prenet_dim, hp.n_mel_channels
+    dev = run.dev
+    W1 = P['decoder.prenet.layers.0.linear_layer.weight']
+    W2 = P['decoder.prenet.layers.1.linear_layer.weight']
+    Wp = P['decoder.linear_projection.linear_layer.weight']
+    bp = P['decoder.linear_projection.linear_layer.bias']
+
+    def fold():
+        # prenet layer 0 folded through the frame projection: p1 = relu(W1 (Wp hc + bp)) = relu((W1 Wp) hc + W1 bp)
+        Wf = run.empty(Pd + Cm + 1, H + E)
+        nv.gemm(Wf[:Pd], W1, Wp, b_kn=True)
+        nv.copy2d(Wf[Pd:], Wpg)
+        bf = run.empty(Pd + Cm + 1)
+        nv.gemm(bf[:Pd].view(1, Pd), bp.view(1, Cm), W1)
+        nv.copy2d(bf[Pd:].view(1, Cm + 1), bpg.view(1, Cm + 1))
+        return Wf, bf
+    Wf, bf = run.cached('Wf_fold', [W1, Wp, bp, P['decoder.gate_layer.linear_layer.weight'],
+                                    P['decoder.gate_layer.linear_layer.bias']], fold)
+    d = nv.DecPersist()
+    d.Ti, d.E, d.H, d.P, d.C = Ti, E, H, Pd, Cm
+    d.max_steps = hp.max_decoder_steps
+    d.gate_threshold = float(hp.gate_threshold)
+    why = nv.decoder_persist_supported(d)
+    if why is not None:
+        model.last_decode_path = 'launch chain (%s)' % why
+        return False
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    steps_done = torch.zeros(1, dtype=torch.int32, device=dev)
+    mailbox = torch.empty(nv.decoder_persist_mailbox_bytes(Ti, E, H, Pd) // 8, dtype=torch.int64, device=dev)
+    trace = None
+    if getattr(model, 'persist_trace', False):
+        trace = run.zeros(hp.max_decoder_steps, 2 * H + E + 2 * Pd)
+        model.last_persist_trace = trace
+    d.Wa16, d.Wd16 = nv.ptr(i16['Wa_cat16'], torch.bfloat16), nv.ptr(i16['Wd_cat16'], torch.bfloat16)
+    d.bias_a, d.bias_d = nv.ptr(bias_a), nv.ptr(bias_d)
+    d.Wq, d.U, d.v, d.Wf, d.bias_f, d.W2 = nv.ptr(Wq), nv.ptr(U), nv.ptr(vvec), nv.ptr(Wf), nv.ptr(bf), nv.ptr(W2.contiguous())
+    d.memory, d.pm = nv.ptr(memory), nv.ptr(pm)
+    d.keep_prenet = nv.ptr(keep, torch.uint8)
+    d.PG, d.ALIGN = nv.ptr(st['PG']), nv.ptr(st['ALIGN'])
+    d.out_length = nv.ptr(out_lengths, torch.int32)
+    d.status, d.steps_done = nv.ptr(status, torch.int32), nv.ptr(steps_done, torch.int32)
+    d.mailbox = nv.ptr(mailbox, torch.int64)
+    d.trace = nv.ptr(trace) if trace is not None else None
+    nv.decoder_infer_persistent(d)
+    code = int(status.item())
+    if code != 0:
+        print("tacotron2_amd: the persistent decode kernel gave up (status %d: %d workgroups were not co-resident "
+              "within 30 ms -- is the GPU shared?); decoding again on the launch chain" % (code, H // 4),
+              file=sys.stderr, flush=True)
+        nv.fill(st['PG'], 0.0)
+        nv.fill(st['ALIGN'], 0.0)
+        out_lengths.zero_()
+        model.last_decode_path = 'launch chain (persistent kernel timed out)'
+        return False
+    model.last_decode_path = 'persistent'
+    return True
+
+
+
 def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     hp = model.hparams
     dev = text.device
@@ -946,8 +1014,16 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         d.bf16 = 1
         for k_, v_ in i16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
+    # One utterance in the bf16 mode: the whole loop as ONE persistent launch, LSTM weights resident in LDS
+    # (csrc/decode_persist.hip).  Anything it cannot take -- or a timeout because the GPU is shared and H/4 workgroups
+    # are not co-resident -- goes through the launch chain below.
+    ran_persistent = False
+    model.last_decode_path = 'launch chain'
+    if B == 1 and run.bf16 and not ragged and Ha == Hd and PERSISTENT_DECODE and not nv.validate_only():
+        ran_persistent = _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat,
+                                            bias_a, bias_d, Wq, U, vvec, Wpg, bpg, i16, Ti)
     t = 0
-    while t < max_steps:
+    while t < max_steps and not ran_persistent:
         n = min(poll_steps, max_steps - t)
         d.t0, d.n_steps = t, n
         nv.decoder_infer_steps(d)

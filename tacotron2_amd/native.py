@@ -203,6 +203,19 @@ class DecInfer(C.Structure):
     ]
 
 
+class DecPersist(C.Structure):
+    _fields_ = [
+        ("Ti", C.c_int), ("E", C.c_int), ("H", C.c_int), ("P", C.c_int), ("C", C.c_int),
+        ("max_steps", C.c_int), ("gate_threshold", C.c_float),
+        ("Wa16", C.c_void_p), ("Wd16", C.c_void_p), ("bias_a", _f32p), ("bias_d", _f32p),
+        ("Wq", _f32p), ("U", _f32p), ("v", _f32p), ("Wf", _f32p), ("bias_f", _f32p), ("W2", _f32p),
+        ("memory", _f32p), ("pm", _f32p), ("keep_prenet", C.c_void_p),
+        ("PG", _f32p), ("ALIGN", _f32p), ("out_length", C.c_void_p), ("status", C.c_void_p),
+        ("steps_done", C.c_void_p), ("mailbox", C.c_void_p), ("trace", _f32p),
+    ]
+
+
+PERSIST_TIMEOUT = 7
 MAX_TENSORS = 64
 
 
@@ -218,7 +231,7 @@ class AdamHyper(C.Structure):
 
 
 _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnBwd, DecTrain,
-            DecTrainBwd, LstmSeq, DecInfer, SmallLinear, TensorList, AdamHyper]
+            DecTrainBwd, LstmSeq, DecInfer, SmallLinear, TensorList, AdamHyper, DecPersist]
 
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
@@ -240,6 +253,7 @@ SYMBOLS = [
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
+    "t2amd_decoder_persist_mailbox_bytes", "t2amd_decoder_persist_supported", "t2amd_decoder_infer_persistent_f32",
 ]
 
 _P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
@@ -300,6 +314,9 @@ def _argtypes():
         "t2amd_optim_chunk": [],
         "t2amd_grad_norm_f32": [pt(TensorList), _F, _P, _P, _P],
         "t2amd_adam_step_f32": [pt(TensorList), pt(AdamHyper), _P, _P],
+        "t2amd_decoder_persist_mailbox_bytes": [_I, _I, _I, _I],
+        "t2amd_decoder_persist_supported": [pt(DecPersist)],
+        "t2amd_decoder_infer_persistent_f32": [pt(DecPersist), _P],
     }
 
 
@@ -332,6 +349,7 @@ def load():
     lib.t2amd_reflect_index.argtypes = [_L, _L]
     lib.t2amd_reflect_index.restype = C.c_longlong
     lib.t2amd_abi_version.restype = C.c_int
+    lib.t2amd_decoder_persist_mailbox_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
     sizes = (C.c_int * 32)()
@@ -355,6 +373,24 @@ def cast_bf16(src, dst):
     if src.numel() != dst.numel() or dst.dtype != torch.bfloat16:
         raise NativeError("cast_bf16: dst must be a bfloat16 tensor of the same size")
     _check(load().t2amd_cast_bf16_f32(ptr(src), ptr(dst, torch.bfloat16), src.numel(), _stream()), "t2amd_cast_bf16_f32")
+
+
+def decoder_persist_mailbox_bytes(Ti, E, H, P):
+    return int(load().t2amd_decoder_persist_mailbox_bytes(int(Ti), int(E), int(H), int(P)))
+
+
+def decoder_persist_supported(desc):
+    """None when the persistent single-utterance decode kernel can run this geometry, else the reason."""
+    lib = load()
+    if lib.t2amd_decoder_persist_supported(C.byref(desc)) == 0:
+        return None
+    msg = lib.t2amd_last_error()
+    return msg.decode() if msg else "unsupported"
+
+
+def decoder_infer_persistent(desc):
+    """The whole free-running decode loop of ONE utterance as one persistent launch (csrc/decode_persist.hip)."""
+    _check(load().t2amd_decoder_infer_persistent_f32(C.byref(desc), _stream()), "t2amd_decoder_infer_persistent_f32")
 
 
 def set_decoder_streams(n):

@@ -1,0 +1,110 @@
+"""The persistent, weight-stationary single-utterance decode kernel (csrc/decode_persist.hip, BASELINE configs[3]).
+
+It runs the whole of Decoder.inference's loop (reference model.py:435-449) as ONE launch; its arithmetic is the
+launch chain's bf16 mode for B <= 8 (bf16 LSTM weight rows against f32 inputs, everything else f32) with different
+summation orders and prenet layer 0 folded through the frame projection.  Checked here:
+  * against the launch chain on the same weights / text / prenet dropout stream (tight: same operand precision);
+  * against the f32 oracle with the bf16-mode tolerance;
+  * a real gate stop hundreds of steps in lands on the same frame as the launch chain;
+  * the engine reports which path ran (a silent fall back to the chain would otherwise pass every check).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import tacotron2_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+OUT = os.path.join(gu.ROOT, "gpurun_out")
+
+
+def _model(hp, sd):
+    from tacotron2_amd.model import Tacotron2
+    m = Tacotron2(hp)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.precision = 'bf16'
+    return m
+
+
+def _run(model, text, keep, persistent):
+    from tacotron2_amd import engine
+    old = engine.PERSISTENT_DECODE
+    engine.PERSISTENT_DECODE = persistent
+    try:
+        model.dropout_masks = dict(prenet_infer=keep.to(DEV))
+        with torch.no_grad():
+            out = model.inference(text.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        engine.PERSISTENT_DECODE = old
+    return [o.float().cpu() for o in out], int(model.last_inference_lengths[0]), model.last_decode_path
+
+
+@pytest.mark.parametrize("hpstr,Ti,steps", [(gu.TINY_HP, 23, 48), ("", 100, 160), ("", 187, 64), ("", 7, 40)])
+def test_persistent_matches_launch_chain_and_oracle(native_lib, hpstr, Ti, steps):
+    hp = gu.make_hparams((hpstr + "," if hpstr else "") + "max_decoder_steps=%d" % steps)
+    hp.gate_threshold = 2.0                                     # forced length: compare every frame
+    sd = gu.build_state_dict(hp, 321, perturb_bn=True)
+    text = gu.make_text([Ti], 55)
+    keep = orc.draw_masks_infer(hp, 1, steps, torch.Generator().manual_seed(4))
+    model = _model(hp, sd)
+    model.persist_trace = True
+    pout, plen, ppath = _run(model, text, keep, True)
+    cout, clen, cpath = _run(model, text, keep, False)
+    assert ppath == 'persistent', ppath
+    assert cpath.startswith('launch chain'), cpath
+    assert plen == clen == steps
+    (omel, opost, ogate, oalign), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0)
+    rows = dict(shape="H=%d Ti=%d steps=%d" % (hp.attention_rnn_dim, Ti, steps))
+    scale = max(float(omel.abs().mean()), 1e-3)
+    for i, nm in enumerate(("mel", "mel_post", "gate", "align")):
+        d = (pout[i] - cout[i]).abs()
+        rows[nm + " persistent vs chain"] = dict(mean=float(d.mean()), max=float(d.max()))
+    dm = (pout[0] - omel).abs()
+    rows["mel persistent vs oracle"] = dict(mean=float(dm.mean()), max=float(dm.max()), oracle_mean_abs=scale)
+    dc = (cout[0] - omel).abs()
+    rows["mel chain vs oracle"] = dict(mean=float(dc.mean()), max=float(dc.max()))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_persistent_H%d_Ti%d.json" % (hp.attention_rnn_dim, Ti)), "w") as f:
+        json.dump(rows, f, indent=1)
+    # same operand precision, different summation order: agreement far inside the bf16-vs-f32 error
+    assert rows["mel persistent vs chain"]["mean"] < 2e-2 * rows["mel chain vs oracle"]["mean"] + 2e-6, rows
+    assert rows["align persistent vs chain"]["max"] < 1e-4, rows
+    assert rows["mel persistent vs oracle"]["mean"] < 2e-2 * scale, rows
+    assert torch.isfinite(pout[1]).all()
+
+
+def test_persistent_real_gate_stop(native_lib):
+    """Greedy decode to the gate stop (threshold chosen on the f32 oracle's trajectory, first crossing beyond 300 steps):
+    the persistent kernel, the launch chain and the oracle stop on the same frame."""
+    hp = gu.make_hparams("max_decoder_steps=520")
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()
+    wg[:, hp.decoder_rnn_dim:] *= -1.0                        # slow rise of the gate (see test_zz5)
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    text = gu.make_text([100], 4242)
+    keep = orc.draw_masks_infer(hp, 1, 520, torch.Generator().manual_seed(9))
+    (_, _, gate_o, _), _, _ = orc.tacotron2_inference(sd, hp, text, keep, 520, 2.0)
+    sig = torch.sigmoid(gate_o.reshape(-1))
+    best = None
+    for t in range(300, 520):
+        m = float(sig[:t].max())
+        if float(sig[t]) > m and (best is None or (float(sig[t]) - m) / 2 > best[2]):
+            best = (m + (float(sig[t]) - m) / 2, t + 1, (float(sig[t]) - m) / 2)
+    assert best is not None
+    hp.gate_threshold = best[0]
+    model = _model(hp, sd)
+    pout, plen, ppath = _run(model, text, keep, True)
+    cout, clen, cpath = _run(model, text, keep, False)
+    with open(os.path.join(OUT, "parity_persistent_gate_stop.json"), "w") as f:
+        json.dump(dict(threshold=best[0], margin=best[2], oracle_stop=best[1], persistent_stop=plen, chain_stop=clen,
+                       path=ppath), f)
+    assert ppath == 'persistent'
+    assert plen == clen == best[1], (plen, clen, best)
+    assert pout[0].shape == cout[0].shape
+    assert (pout[0] - cout[0]).abs().mean().item() < 1e-4

@@ -15,8 +15,8 @@ python bench.py --fused-optimizer --no-inference --no-fp32-leg --cpu-sample 0 --
 timeout 600 python bench.py --batch-size 256 --steps 3 --warmup 1 --no-inference --no-fp32-leg --cpu-sample 0 --no-roofline > $out/${tag}_bench_B256.json 2>> $out/${tag}_bench.err; tail -c 400 $out/${tag}_bench_B256.json
 timeout 120 python tools/microbench_barrier.py > $out/${tag}_barrier.txt 2>&1; cat $out/${tag}_barrier.txt
 timeout 300 python tools/microbench_audio.py > $out/${tag}_audio.json 2> $out/${tag}_audio.err; cat $out/${tag}_audio.json
-( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-fp32-leg --no-inference > $GRAFT_REPO_ROOT/$out/${tag}_bench_under_rocprof.json 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-fp32-leg --no-inference > $GRAFT_REPO_ROOT/$out/${tag}_bench_under_rocprof.json 2>/dev/null )
 find /tmp/prof_bench -name '*kernel_stats.csv' -exec cp {} $out/${tag}_kernel_stats_bf16.csv \;
-( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_audio -o audio -- python $GRAFT_REPO_ROOT/tools/microbench_audio.py > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_audio -o audio -- python $GRAFT_REPO_ROOT/tools/microbench_audio.py > /dev/null 2>&1 )
 find /tmp/prof_audio -name '*kernel_stats.csv' -exec cp {} $out/${tag}_kernel_stats_audio.csv \;
 ls -la $out | tail -12
