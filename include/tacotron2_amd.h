@@ -610,6 +610,8 @@ typedef struct t2amd_dec_persist {
     int* steps_done;       /* [1] */
     unsigned long long* mailbox;  /* t2amd_decoder_persist_mailbox_bytes() bytes, zeroed by the call */
     float* trace;          /* NULL, or [max_steps][H + E + H + P + P]: h_att, ctx, h_dec, p1(t+1), p2(t+1) per step (tests) */
+    unsigned long long* timing; /* NULL, or [32] zeroed by the caller: 100 MHz ticks per phase, summed over the steps, of
+                                 * thread 0 of the first ([0..15]) and of the last ([16..31]) workgroup (tools) */
 } t2amd_dec_persist;
 
 long long t2amd_decoder_persist_mailbox_bytes(int Ti, int E, int H, int P);

@@ -8,7 +8,7 @@
 // rows of BOTH LSTMs they own (16 x 1792 + 16 x 2560 bf16 = 136 KB) in LDS for the whole utterance, their slice of
 // the small matrices in registers, and their slice of the recurrent state in registers.  Nothing is streamed from
 // HBM inside the loop; what remains per step is six all-to-all hand-offs of small vectors:
-//     p2 -> [LSTM_a] -> h_a -> [energies, 8 team CUs] -> partial energies -> [softmax + context slice, every CU]
+//     p2 -> [LSTM_a] -> h_a -> [energies: 8 dim teams x H/32 position groups] -> partial energies -> [softmax + context slice, every CU]
 //        -> ctx -> [LSTM_d] -> h_d -> [frame/gate rows + prenet layer 1 (folded through the frame projection)]
 //        -> p1 (+ stop flag) -> [prenet layer 2] -> p2 ...
 // Every hand-off is the guide's R2 form (cdna_hip_programming.md Guideline 16): 8-byte {tag = step + 1, f32 value}
@@ -25,11 +25,15 @@
 // p1 = relu(W1 (Wp hc + bp)) = relu((W1 Wp) hc + W1 bp), which removes one hand-off (frame -> p1) from the chain:
 // the rows of [W1 Wp ; Wp ; Wg] are one distributed matrix-vector product.
 #include "common.h"
+#include <stdlib.h>
 
 #define PB_NT 256
+#define PB_POLLERS 256                   // every thread polls
+#define PB_COMM 0                        // first thread of the wave that publishes (cells, context, projection rows): wave 0
+                                         // (wave 3 measured 17.9 vs 16.4 us per step)
 #define PB_TEAMS 8                       // attention teams: 16 of the 128 attention dims each
 #define PB_TDIM (T2AMD_ATT_DIM / PB_TEAMS)
-#define PB_MAXR 16                       // position rounds of an energy thread: Ti <= 16 * 16
+#define PB_PPW 8                         // positions per workgroup in the energy phase: Ti <= 8 * (workgroups / 8)
 #define PB_MAXFR 6                       // rows of the folded projection per workgroup
 #define PB_MAXKPT 6                      // (H + E) / 256 elements of such a row per thread
 #define PB_MAXP2R 2                      // prenet layer-2 rows per workgroup
@@ -43,6 +47,10 @@ typedef unsigned long long pb_u64;
 struct PersistParams {
     t2amd_dec_persist a;
     int nwg, tip;
+    // s_sleep units (64 clocks) before the first poll of each mailbox (p2, h_a, energies, ctx, h_d, p1) and between the
+    // polls of the singly-polled ones: the 256 CUs would otherwise hammer a mailbox's few cache lines while the stores
+    // into them are still on their way (measured: 16 units before the p2 sweep alone took 17.3 -> 15.2 us off a step)
+    int delay[6], poll_sleep;
 };
 
 // element k of a vector staged for the LSTM dot products: units of 8 consecutive k are split into two float4 halves
@@ -64,28 +72,60 @@ __device__ __forceinline__ bool pb_give_up(long long t0, int* status) {
     return true;
 }
 
-// Every thread polls its own granules (tid, tid + 256, ...) until all of a wave's carry `tag`; values go to LDS.
-// Returns true on failure (timeout or another workgroup already failed).  Wave-uniform control flow.
-template <bool SPLIT>
+// Every thread polls its own granules (tid, tid + 256, ...: NPT of them, all loads of a poll in flight together) until
+// all of a wave's carry `tag`; values go to LDS.  Returns true on failure (timeout or another workgroup already failed).
+// Wave-uniform control flow.
+// (Measured and dropped: a communicator wave that issues every global store while only the other three waves poll --
+// the idea being that a poll queued behind a write-through store is retired only after the store's acknowledgement --
+// was slower, 18.0 vs 16.4 us per step: six granules per polling thread instead of four cost more than the stores did.)
+template <bool SPLIT, int NPT, bool DBL>
 __device__ __forceinline__ bool pb_sweep(const pb_u64* __restrict__ g, int n, unsigned tag, float* __restrict__ dst, int len,
-                                         int* status, int tid) {
-    bool fail = false;
-    for (int base = 0; base < n; base += PB_NT) {
-        const int i = base + tid;
-        const bool mine = i < n;
-        pb_u64 x = 0;
-        const long long t0 = wall_clock64();
-        unsigned spins = 0;
-        for (;;) {
-            x = mine ? __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((pb_u64)tag << 32);
-            if (__all((unsigned)(x >> 32) == tag)) break;
-            if ((++spins & 63u) == 0 && pb_give_up(t0, status)) { fail = true; break; }
-            __builtin_amdgcn_s_sleep(1);
+                                         int* status, int tid, int poll_sleep) {
+    // DBL: two polls in flight -- while poll A's loads are checked, poll B's are already on their way, so a publication is
+    // seen half a round trip earlier.  Measured: pays for the 256-granule edges (p1: 2.4 -> 1.0 us), costs on the 1024-
+    // granule ones (h_a, h_d, ctx: the doubled poll traffic of 256 CUs slows every round trip), so those poll singly.
+    // (granules past n: the index is clamped -- an unconditional load of a valid word, no branch -- and ignored)
+    pb_u64 xa[NPT], xb[NPT];
+    const pb_u64* gp[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) gp[j] = g + ((tid + PB_POLLERS * j < n) ? tid + PB_POLLERS * j : n - 1);
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
+#define PB_POLL(X)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NPT; ++j) X[j] = __hip_atomic_load(gp[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define PB_READY(X, OK)                                                                                         \
+    OK = true;                                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < NPT; ++j) OK = OK && ((unsigned)(X[j] >> 32) == tag);
+    PB_POLL(xa)
+    for (;;) {
+        bool ok;
+        if constexpr (DBL) {
+            PB_POLL(xb)
+            PB_READY(xa, ok)
+            if (__all(ok)) break;
+            PB_POLL(xa)
+            PB_READY(xb, ok)
+            if (__all(ok)) {
+#pragma unroll
+                for (int j = 0; j < NPT; ++j) xa[j] = xb[j];
+                break;
+            }
+        } else {
+            PB_READY(xa, ok)
+            if (__all(ok)) break;
+            for (int d_ = 0; d_ < poll_sleep; ++d_) __builtin_amdgcn_s_sleep(1);
+            PB_POLL(xa)
         }
-        if (fail) break;
-        if (mine) dst[SPLIT ? pb_xoff(i, len) : i] = __uint_as_float((unsigned)x);
+        if ((++spins & 31u) == 0 && pb_give_up(t0, status)) return true;
     }
-    return fail;
+#undef PB_POLL
+#undef PB_READY
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = tid + PB_POLLERS * j;
+        if (i < n) dst[SPLIT ? pb_xoff(i, len) : i] = __uint_as_float((unsigned)xa[j]);
+    }
+    return false;
 }
 
 // acc[u] += W_s[row u of this wave][seg_off + k] * x[k], k < seg_len (multiple of 8): bf16 rows in LDS, f32 x in LDS
@@ -117,7 +157,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     const int Ka = P + E + H, Kd = H + E + H, KF = H + E;
     const int NF = P + C + 1;                       // rows of the folded projection: p1 rows, frame rows, gate row
     const int EPW = E / NWG;
-    const bool team = k < PB_TEAMS;
+    const int team = k % PB_TEAMS, NPG = NWG / PB_TEAMS, pgx = k / PB_TEAMS;    // attention dim team, position group
 
     // ---- LDS carve (all offsets multiples of 16 bytes) -------------------------------------------------------
     unsigned short* Wa_s = reinterpret_cast<unsigned short*>(smem_raw);            // [16][Ka] bf16
@@ -129,11 +169,11 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     float* xp1_s = xhd_s + H;                                                      // [P + 4] linear (+ stop flag)
     float* w_s = xp1_s + P + 4;                                                    // [TiP4] attention weights of the step
     const int TiP4 = (Ti + 3) & ~3;
-    float* win_s = w_s + TiP4;                                                     // [2][TIP] halo windows (teams)
-    float* os_s = win_s + 2 * TIP;                                                 // [16] gate pre-activations
-    float* red_s = os_s + 16;                                                      // [64] block-reduction scratch
-    float* qpart_s = red_s + 64;                                                   // [16][16] (teams)
-    float* q_s = qpart_s + 256;                                                    // [16] (teams)
+    float* win_s = w_s + TiP4;                                                     // [2][TIP] halo windows
+    float* os_s = win_s + 2 * TIP;                                                 // [16][4] gate pre-activation partials (row, 16-lane group)
+    float* red_s = os_s + 64;                                                      // [256] block-reduction scratch
+    float* qpart_s = red_s + 256;                                                  // [16][16]
+    float* q_s = qpart_s + 256;                                                    // [16]
 
     pb_u64* const G_p2 = a.mailbox;
     pb_u64* const G_ha = G_p2 + P;
@@ -186,30 +226,30 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     float memr[PB_MAXEPW];
 #pragma unroll
     for (int c = 0; c < PB_MAXEPW; ++c) memr[c] = (tid < Ti && c < EPW) ? a.memory[(long long)tid * E + k * EPW + c] : 0.f;
-    // teams: W_q slice (thread (d = tid & 15, part = tid >> 4) keeps H/16 elements of row k*16 + d), the 62 taps of
-    // U row d, v[d], processed-memory entries of its positions
-    float wq[PB_MAXQ], ureg[T2AMD_LOC_TAPS], pmr[PB_MAXR], vd = 0.f;
-    const int td = tid & 15, tpg = tid >> 4, HQ = H >> 4;
-    if (team) {
-        const int drow = k * PB_TDIM + td;
+    // attention slice of this workgroup: dims team*16 .. +15, positions pgx + NPG*pl (pl < 8).  Thread (td = tid & 15,
+    // slot = tid >> 4) keeps H/16 elements of W_q row team*16 + td (part `slot` of the row) for the q phase, and for the
+    // energy phase -- where slot = 2*pl + c -- the 31 taps of window channel c of U row td, v[td] and pm[position][td]
+    float wq[PB_MAXQ], ureg[T2AMD_LOC_KERNEL], pm1 = 0.f, vd;
+    const int td = tid & 15, slot = tid >> 4, HQ = H >> 4;
+    const int epl = slot >> 1, ech = slot & 1, epos = pgx + NPG * epl;
+    {
+        const int drow = team * PB_TDIM + td;
 #pragma unroll
-        for (int j = 0; j < PB_MAXQ; ++j) wq[j] = (j < HQ) ? a.Wq[(long long)drow * H + tpg * HQ + j] : 0.f;
+        for (int j = 0; j < PB_MAXQ; ++j) wq[j] = (j < HQ) ? a.Wq[(long long)drow * H + slot * HQ + j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < T2AMD_LOC_TAPS; ++j) ureg[j] = a.U[(long long)drow * T2AMD_LOC_TAPS + j];
-#pragma unroll
-        for (int r = 0; r < PB_MAXR; ++r) {
-            const int i = tpg + 16 * r;
-            pmr[r] = (i < Ti) ? a.pm[(long long)i * T2AMD_ATT_DIM + drow] : 0.f;
-        }
+        for (int j = 0; j < T2AMD_LOC_KERNEL; ++j) ureg[j] = a.U[(long long)drow * T2AMD_LOC_TAPS + ech * T2AMD_LOC_KERNEL + j];
+        if (epos < Ti) pm1 = a.pm[(long long)epos * T2AMD_ATT_DIM + drow];
         vd = a.v[drow];
     }
     // cell state of unit 4k + tid (threads 0..3), biases of its four gates
+    // (publishing lanes: ct = tid - PB_COMM owns unit 4k + ct, projection row k + ct*NWG, prenet row k + ct*NWG ...)
+    const int ct = tid - PB_COMM;
     float c_a = 0.f, c_d = 0.f, ba[4] = {0.f, 0.f, 0.f, 0.f}, bd[4] = {0.f, 0.f, 0.f, 0.f};
-    if (tid < 4) {
+    if (ct >= 0 && ct < 4) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            ba[g] = a.bias_a[g * H + 4 * k + tid];
-            bd[g] = a.bias_d[g * H + 4 * k + tid];
+            ba[g] = a.bias_a[g * H + 4 * k + ct];
+            bd[g] = a.bias_d[g * H + 4 * k + ct];
         }
     }
     float accA[4] = {0.f, 0.f, 0.f, 0.f}, accD[4] = {0.f, 0.f, 0.f, 0.f};
@@ -220,43 +260,90 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     const int TRW = H + E + H + P + P;
     __syncthreads();
 
+    // optional phase clock (a.timing != NULL): thread 0 of the first (a team) and of the last workgroup accumulate the
+    // 100 MHz wall clock between phase boundaries: slot 16*w + phase, w = 0 first / 1 last workgroup
+    unsigned long long* const tim = (a.timing && tid == 0 && (k == 0 || k == NWG - 1)) ? a.timing + (k == 0 ? 0 : 16) : nullptr;
+    unsigned long long tprev = tim ? wall_clock64() : 0ull, tacc[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) tacc[i] = 0ull;
+#define PB_T(slot)                                                  \
+    do {                                                            \
+        if (tim) {                                                  \
+            const unsigned long long now_ = wall_clock64();         \
+            tacc[slot] += now_ - tprev;     /* registers: a global read-modify-write per stamp would cost ~1 us each */ \
+            tprev = now_;                                           \
+        }                                                           \
+    } while (0)
+
+#define PB_DELAY(i) do { for (int d_ = 0; d_ < p.delay[i]; ++d_) __builtin_amdgcn_s_sleep(1); } while (0)
     int t = 0;
     for (; t < a.max_steps; ++t) {
         const unsigned tag = (unsigned)t + 1u;
         bool fail = false;
+        unsigned char keep1 = 1, keep2 = 1;
         // (1) p2(t): the prenet output for this step (published with tag t by step t-1; zeros at t = 0)
-        if (t > 0) fail = pb_sweep<true>(G_p2, P, (unsigned)t, xp2_s, P, a.status, tid);
+        if (t > 0) PB_DELAY(0);
+        if (t > 0) fail = pb_sweep<true, 1, true>(G_p2, P, (unsigned)t, xp2_s, P, a.status, tid, p.poll_sleep);
         if (__syncthreads_or(fail)) break;
+        PB_T(0);
 
         // (2) attention LSTM: accA already holds the ctx(t-1) and h_a(t-1) parts
         pb_dot_seg(WaW, Ka, 0, P, xp2_s, accA, lane);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float s = wave_reduce_sum(accA[u]);
-            if (lane == 0) os_s[wave * 4 + u] = s;
+            const float s = row16_sum(accA[u]);                       // 16-lane partials; the cell thread adds the four
+            if ((lane & 15) == 0) os_s[(wave * 4 + u) * 4 + (lane >> 4)] = s;
             accA[u] = 0.f;
         }
         __syncthreads();
-        if (tid < 4) {
-            const float gi = t2_sigmoid(os_s[0 * 4 + tid] + ba[0]), gf = t2_sigmoid(os_s[1 * 4 + tid] + ba[1]);
-            const float gg = tanhf(os_s[2 * 4 + tid] + ba[2]), go = t2_sigmoid(os_s[3 * 4 + tid] + ba[3]);
+        if (ct >= 0 && ct < 4) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 q4 = *reinterpret_cast<const float4*>(&os_s[(g * 4 + ct) * 4]);
+                pre[g] = ((q4.x + q4.y) + (q4.z + q4.w)) + ba[g];
+            }
+            const float gi = t2_sigmoid_fast(pre[0]), gf = t2_sigmoid_fast(pre[1]), gg = t2_tanh(pre[2]), go = t2_sigmoid_fast(pre[3]);
             c_a = gf * c_a + gi * gg;
-            const float h = go * tanhf(c_a);
-            pb_publish(G_ha + 4 * k + tid, tag, h);
-            if (trace) trace[(long long)t * TRW + 4 * k + tid] = h;
+            const float h = go * t2_tanh(c_a);
+            pb_publish(G_ha + 4 * k + ct, tag, h);
+            if (trace) trace[(long long)t * TRW + 4 * k + ct] = h;
         }
 
+        PB_T(1);
         // (3) h_a(t) from every workgroup
-        fail = pb_sweep<true>(G_ha, H, tag, xha_s, H, a.status, tid);
+        PB_DELAY(1);
+        fail = pb_sweep<true, 4, false>(G_ha, H, tag, xha_s, H, a.status, tid, p.poll_sleep);
         if (__syncthreads_or(fail)) break;
+        PB_T(2);
+        // keep-masks of the prenet outputs this workgroup will publish for step t + 1: fetched here (first use ~8 us away;
+        // issued in front of a sweep they would hold that wave's polls back: returns are in order)
+        if (t + 1 < a.max_steps) {
+            if (ct >= 0 && ct < PB_MAXFR && k + ct * NWG < P) keep1 = a.keep_prenet[((long long)(t + 1) * 2 + 0) * P + k + ct * NWG];
+            if (ct >= 0 && ct < PB_MAXP2R && k + ct * NWG < P) keep2 = a.keep_prenet[((long long)(t + 1) * 2 + 1) * P + k + ct * NWG];
+        }
 
-        // (4) teams: q for 16 attention dims, partial energies of all positions over those dims
-        if (team) {
-            float qp = 0.f;
+        // (4) q for this workgroup's 16 attention dims, then the partial energy over those dims of its (up to) 8 positions
+        {
+            float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+            const float* xq = xha_s;
 #pragma unroll
-            for (int j = 0; j < PB_MAXQ; ++j)
-                if (j < HQ) qp = fmaf(wq[j], xha_s[pb_xoff(tpg * HQ + j, H)], qp);
-            qpart_s[tpg * 16 + td] = qp;
+            for (int j = 0; j < PB_MAXQ; j += 8) {
+                if (j < HQ) {
+                    // elements slot*HQ + j .. + 7 are one 8-unit of the split layout: two float4 reads (HQ is a multiple of 8)
+                    const int kk = (slot * HQ + j) >> 3;
+                    const float4 xa = *reinterpret_cast<const float4*>(xq + kk * 4);
+                    const float4 xb = *reinterpret_cast<const float4*>(xq + (H >> 1) + kk * 4);
+                    q0 = fmaf(wq[j], xa.x, q0); q1 = fmaf(wq[j + 1], xa.y, q1); q2 = fmaf(wq[j + 2], xa.z, q2); q3 = fmaf(wq[j + 3], xa.w, q3);
+                    q0 = fmaf(wq[j + 4], xb.x, q0); q1 = fmaf(wq[j + 5], xb.y, q1); q2 = fmaf(wq[j + 6], xb.z, q2); q3 = fmaf(wq[j + 7], xb.w, q3);
+                }
+            }
+            qpart_s[slot * 16 + td] = (q0 + q1) + (q2 + q3);
+            // this thread's window operands: 31 consecutive halo-window elements of channel ech, all reads in flight
+            const int ic = epos < Ti ? epos : Ti - 1;
+            float wv[T2AMD_LOC_KERNEL];
+#pragma unroll
+            for (int j = 0; j < T2AMD_LOC_KERNEL; ++j) wv[j] = win_s[ech * TIP + ic + j];
             __syncthreads();
             if (tid < 16) {
                 float q = 0.f;
@@ -264,108 +351,142 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
                 for (int pp = 0; pp < 16; ++pp) q += qpart_s[pp * 16 + tid];
                 q_s[tid] = q;
             }
-            __syncthreads();
-            const float qd = q_s[td];
+            float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
 #pragma unroll
-            for (int r = 0; r < PB_MAXR; ++r) {
-                const int i = tpg + 16 * r;
-                if (16 * r < Ti) {                                   // wave-uniform round guard
-                    const int ic = i < Ti ? i : Ti - 1;
-                    float loc = 0.f;
-#pragma unroll
-                    for (int j = 0; j < T2AMD_LOC_KERNEL; ++j) loc = fmaf(ureg[j], win_s[ic + j], loc);
-#pragma unroll
-                    for (int j = 0; j < T2AMD_LOC_KERNEL; ++j) loc = fmaf(ureg[T2AMD_LOC_KERNEL + j], win_s[TIP + ic + j], loc);
-                    float e = vd * t2_tanh(qd + loc + pmr[r]);
-                    e = row16_sum(e);                                // over the team's 16 dims (lanes td = 0..15)
-                    if (td == 0 && i < Ti) pb_publish(G_pe + (size_t)k * TiP4 + i, tag, e);
-                }
+            for (int j = 0; j + 3 < T2AMD_LOC_KERNEL; j += 4) {
+                l0 = fmaf(ureg[j], wv[j], l0); l1 = fmaf(ureg[j + 1], wv[j + 1], l1);
+                l2 = fmaf(ureg[j + 2], wv[j + 2], l2); l3 = fmaf(ureg[j + 3], wv[j + 3], l3);
             }
+            l0 = fmaf(ureg[28], wv[28], l0); l1 = fmaf(ureg[29], wv[29], l1); l2 = fmaf(ureg[30], wv[30], l2);
+            float loc = (l0 + l1) + (l2 + l3);
+            loc += __shfl_xor(loc, 16, 64);                          // the other window channel (slot ^ 1)
+            __syncthreads();
+            float e = vd * t2_tanh(q_s[td] + loc + pm1);
+            e = row16_sum(e);                                        // over the 16 dims (lanes td = 0..15)
+            if (td == 0 && ech == 0 && epos < Ti) pb_publish(G_pe + (size_t)team * TiP4 + epos, tag, e);
         }
 
-        // (5) the h_a(t) parts of the decoder LSTM of this step and of the attention LSTM of the next one
+        // (5) the h_a(t) parts of the decoder LSTM of this step and of the attention LSTM of the next one (the partial
+        // energies are on their way meanwhile)
         pb_dot_seg(WdW, Kd, 0, H, xha_s, accD, lane);
         pb_dot_seg(WaW, Ka, P + E, H, xha_s, accA, lane);
+        PB_T(3);
 
         // (6) energies = fixed-order sum of the 8 team partials; softmax; this workgroup's context channels
         {
             float e = -INFINITY;
+            PB_DELAY(2);
             {
                 const bool mine = tid < Ti;
+                const pb_u64* gq = G_pe + (mine ? tid : Ti - 1);
                 const long long t0 = wall_clock64();
                 unsigned spins = 0;
+                pb_u64 xa[PB_TEAMS];
+#define PB_POLL8(X) _Pragma("unroll") for (int q = 0; q < PB_TEAMS; ++q) X[q] = __hip_atomic_load(gq + (size_t)q * TiP4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#define PB_READY8(X, OK) OK = true; _Pragma("unroll") for (int q = 0; q < PB_TEAMS; ++q) OK = OK && ((unsigned)(X[q] >> 32) == tag);
+                PB_POLL8(xa)
                 for (;;) {
-                    bool ok = true;
+                    bool ok;
+                    PB_READY8(xa, ok)
+                    if (__all(ok)) break;
+                    if ((++spins & 31u) == 0 && pb_give_up(t0, a.status)) { fail = true; break; }
+                    for (int d_ = 0; d_ < p.poll_sleep; ++d_) __builtin_amdgcn_s_sleep(1);
+                    PB_POLL8(xa)
+                }
+#undef PB_POLL8
+#undef PB_READY8
+                if (mine && !fail) {
                     float s = 0.f;
 #pragma unroll
-                    for (int q = 0; q < PB_TEAMS; ++q) {
-                        const pb_u64 x = mine ? __hip_atomic_load(G_pe + (size_t)q * TiP4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                              : ((pb_u64)tag << 32);
-                        ok = ok && ((unsigned)(x >> 32) == tag);
-                        s += __uint_as_float((unsigned)x);
-                    }
-                    if (__all(ok)) { if (mine) e = s; break; }
-                    if ((++spins & 63u) == 0 && pb_give_up(t0, a.status)) { fail = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    for (int q = 0; q < PB_TEAMS; ++q) s += __uint_as_float((unsigned)xa[q]);       // fixed order
+                    e = s;
                 }
             }
-            float m = wave_reduce_max(e);
-            if (lane == 0) red_s[wave] = m;
+            float m = row16_max(e);
+            if ((lane & 15) == 0) red_s[tid >> 4] = m;
             if (__syncthreads_or(fail)) break;
-            m = fmaxf(fmaxf(red_s[0], red_s[1]), fmaxf(red_s[2], red_s[3]));
+            PB_T(4);
+            {
+                const float4 m0 = *reinterpret_cast<const float4*>(&red_s[0]), m1 = *reinterpret_cast<const float4*>(&red_s[4]);
+                const float4 m2 = *reinterpret_cast<const float4*>(&red_s[8]), m3 = *reinterpret_cast<const float4*>(&red_s[12]);
+                m = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
+                          fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(fmaxf(m3.x, m3.y), fmaxf(m3.z, m3.w))));
+            }
             const float ex = (tid < Ti) ? expf(e - m) : 0.f;
-            const float ls = wave_reduce_sum(ex);
-            if (lane == 0) red_s[4 + wave] = ls;
-            __syncthreads();
-            const float inv = 1.0f / (((red_s[4] + red_s[5]) + red_s[6]) + red_s[7]);
-            const float w = ex * inv;
-            // context partials: wave sums of w[i] * memory[i][c]
+            const float ls = row16_sum(ex);
+            if ((lane & 15) == 0) red_s[16 + (tid >> 4)] = ls;
+            // context partials: 16-lane sums of ex[i] * memory[i][c] (normalised below)
 #pragma unroll
             for (int c = 0; c < PB_MAXEPW; ++c) {
-                const float s = wave_reduce_sum(w * memr[c]);
-                if (lane == 0) red_s[8 + c * 4 + wave] = s;
-            }
-            if (tid < Ti) {
-                if (k == 0) a.ALIGN[(long long)t * Ti + tid] = w;
-                if (team) {                                          // windows of the next step: w(t), cum(t) = cum(t-1) + w(t)
-                    win_s[PB_HALO + tid] = w;
-                    win_s[TIP + PB_HALO + tid] += w;
+                if (c < EPW) {
+                    const float s = row16_sum(ex * memr[c]);
+                    if ((lane & 15) == 0) red_s[32 + c * 16 + (tid >> 4)] = s;
                 }
             }
             __syncthreads();
-            if (tid < EPW) {
-                const float cx = ((red_s[8 + tid * 4] + red_s[8 + tid * 4 + 1]) + red_s[8 + tid * 4 + 2]) + red_s[8 + tid * 4 + 3];
-                pb_publish(G_ctx + k * EPW + tid, tag, cx);
-                if (trace) trace[(long long)t * TRW + H + k * EPW + tid] = cx;
+            float gsum;
+            {
+                const float4 s0 = *reinterpret_cast<const float4*>(&red_s[16]), s1 = *reinterpret_cast<const float4*>(&red_s[20]);
+                const float4 s2 = *reinterpret_cast<const float4*>(&red_s[24]), s3 = *reinterpret_cast<const float4*>(&red_s[28]);
+                gsum = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                       (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+            }
+            const float inv = 1.0f / gsum;
+            const float w = ex * inv;
+            if (tid < Ti) {
+                win_s[PB_HALO + tid] = w;                            // windows of the next step: w(t), cum(t) = cum(t-1) + w(t)
+                win_s[TIP + PB_HALO + tid] += w;
+                if (k == 0) a.ALIGN[(long long)t * Ti + tid] = w;    // alignment row of this step (reference model.py:447)
+            }
+            if (ct >= 0 && ct < EPW) {
+                const float* r = &red_s[32 + ct * 16];
+                const float4 s0 = *reinterpret_cast<const float4*>(r), s1 = *reinterpret_cast<const float4*>(r + 4);
+                const float4 s2 = *reinterpret_cast<const float4*>(r + 8), s3 = *reinterpret_cast<const float4*>(r + 12);
+                const float cx = ((((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                                  (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)))) * inv;
+                pb_publish(G_ctx + k * EPW + ct, tag, cx);
+                if (trace) trace[(long long)t * TRW + H + k * EPW + ct] = cx;
             }
         }
-
+        PB_T(5);
+        PB_T(6);
         // (7) ctx(t)
-        fail = pb_sweep<true>(G_ctx, E, tag, xctx_s, E, a.status, tid);
+        PB_DELAY(3);
+        fail = pb_sweep<true, 2, false>(G_ctx, E, tag, xctx_s, E, a.status, tid, p.poll_sleep);
         if (__syncthreads_or(fail)) break;
+        PB_T(7);
 
         // (8) decoder LSTM: accD holds the h_a(t) and h_d(t-1) parts
         pb_dot_seg(WdW, Kd, H, E, xctx_s, accD, lane);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float s = wave_reduce_sum(accD[u]);
-            if (lane == 0) os_s[wave * 4 + u] = s;
+            const float s = row16_sum(accD[u]);
+            if ((lane & 15) == 0) os_s[(wave * 4 + u) * 4 + (lane >> 4)] = s;
             accD[u] = 0.f;
         }
         __syncthreads();
-        if (tid < 4) {
-            const float gi = t2_sigmoid(os_s[0 * 4 + tid] + bd[0]), gf = t2_sigmoid(os_s[1 * 4 + tid] + bd[1]);
-            const float gg = tanhf(os_s[2 * 4 + tid] + bd[2]), go = t2_sigmoid(os_s[3 * 4 + tid] + bd[3]);
+        if (ct >= 0 && ct < 4) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 q4 = *reinterpret_cast<const float4*>(&os_s[(g * 4 + ct) * 4]);
+                pre[g] = ((q4.x + q4.y) + (q4.z + q4.w)) + bd[g];
+            }
+            const float gi = t2_sigmoid_fast(pre[0]), gf = t2_sigmoid_fast(pre[1]), gg = t2_tanh(pre[2]), go = t2_sigmoid_fast(pre[3]);
             c_d = gf * c_d + gi * gg;
-            const float h = go * tanhf(c_d);
-            pb_publish(G_hd + 4 * k + tid, tag, h);
-            if (trace) trace[(long long)t * TRW + H + E + 4 * k + tid] = h;
+            const float h = go * t2_tanh(c_d);
+            pb_publish(G_hd + 4 * k + ct, tag, h);
+            if (trace) trace[(long long)t * TRW + H + E + 4 * k + ct] = h;
         }
+        PB_T(8);
         pb_dot_seg(WaW, Ka, P, E, xctx_s, accA, lane);                // ctx(t) part of the next attention LSTM
+        PB_T(9);
 
         // (9) h_d(t)
-        fail = pb_sweep<true>(G_hd, H, tag, xhd_s, H, a.status, tid);
+        PB_DELAY(4);
+        fail = pb_sweep<true, 4, false>(G_hd, H, tag, xhd_s, H, a.status, tid, p.poll_sleep);
         if (__syncthreads_or(fail)) break;
+        PB_T(10);
 
         // (10) rows of [W1 Wp ; Wp ; Wg] . [h_d ; ctx]: p1(t+1) rows, frame rows, gate row (with the stop test)
         {
@@ -377,25 +498,34 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
             }
 #pragma unroll
             for (int j = 0; j < PB_MAXFR; ++j) {
-                float s = 0.f;
+                if (k + j * NWG < NF) {                               // workgroup-uniform: rows this workgroup owns
+                    float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < PB_MAXKPT; ++i) s = fmaf(wf[j][i], xr[i], s);
-                s = wave_reduce_sum(s);
-                if (lane == 0) red_s[32 + j * 4 + wave] = s;
+                    for (int i = 0; i < PB_MAXKPT; ++i) s = fmaf(wf[j][i], xr[i], s);
+                    s = row16_sum(s);
+                    if ((lane & 15) == 0) red_s[96 + j * 16 + (tid >> 4)] = s;
+                }
             }
             __syncthreads();
-            if (tid < PB_MAXFR) {
-                const int r = k + tid * NWG;
+            if (ct >= 0 && ct < PB_MAXFR) {
+                const int r = k + ct * NWG;
                 if (r < NF) {
-                    float y = ((red_s[32 + tid * 4] + red_s[32 + tid * 4 + 1]) + red_s[32 + tid * 4 + 2]) + red_s[32 + tid * 4 + 3];
+                    float y;
+                    {
+                        const float* rr = &red_s[96 + ct * 16];
+                        const float4 s0 = *reinterpret_cast<const float4*>(rr), s1 = *reinterpret_cast<const float4*>(rr + 4);
+                        const float4 s2 = *reinterpret_cast<const float4*>(rr + 8), s3 = *reinterpret_cast<const float4*>(rr + 12);
+                        y = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                            (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+                    }
                     // bias of row tid lives in register bf_[tid] of every thread: select without dynamic indexing
                     float b = bf_[0];
 #pragma unroll
-                    for (int j = 1; j < PB_MAXFR; ++j) b = (tid == j) ? bf_[j] : b;
+                    for (int j = 1; j < PB_MAXFR; ++j) b = (ct == j) ? bf_[j] : b;
                     y += b;
                     if (r < P) {
                         float v = fmaxf(y, 0.f);
-                        if (t + 1 < a.max_steps) v = a.keep_prenet[((long long)(t + 1) * 2 + 0) * P + r] ? v * 2.0f : 0.f;
+                        if (t + 1 < a.max_steps) v = keep1 ? v * 2.0f : 0.f;
                         pb_publish(G_p1 + r, tag, v);
                         if (trace) trace[(long long)t * TRW + H + E + H + r] = v;
                     } else {
@@ -412,46 +542,71 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
                 }
             }
         }
+        PB_T(11);
         pb_dot_seg(WdW, Kd, H + E, H, xhd_s, accD, lane);             // h_d(t) part of the next decoder LSTM
+        PB_T(12);
 
         // (11) p1(t+1) and the stop flag; prenet layer 2
+        PB_DELAY(5);
         {
             const bool mine = tid < P;
+            const pb_u64* gx = G_p1 + (mine ? tid : P - 1);
+            const pb_u64* gy = G_p1 + P;                              // the stop granule: every thread polls it (one address)
             const long long t0 = wall_clock64();
             unsigned spins = 0;
+            pb_u64 xa, ya, xb, yb;
+            xa = __hip_atomic_load(gx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ya = __hip_atomic_load(gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {
-                const pb_u64 x = mine ? __hip_atomic_load(G_p1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((pb_u64)tag << 32);
-                const pb_u64 y = tid == 0 ? __hip_atomic_load(G_p1 + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((pb_u64)tag << 32);
-                if (__all((unsigned)(x >> 32) == tag && (unsigned)(y >> 32) == tag)) {
-                    if (mine) xp1_s[tid] = __uint_as_float((unsigned)x);
-                    if (tid == 0) xp1_s[P] = __uint_as_float((unsigned)y);
-                    break;
-                }
-                if ((++spins & 63u) == 0 && pb_give_up(t0, a.status)) { fail = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                xb = __hip_atomic_load(gx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                yb = __hip_atomic_load(gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(xa >> 32) == tag && (unsigned)(ya >> 32) == tag)) break;
+                xa = __hip_atomic_load(gx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ya = __hip_atomic_load(gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(xb >> 32) == tag && (unsigned)(yb >> 32) == tag)) { xa = xb; ya = yb; break; }
+                if ((++spins & 31u) == 0 && pb_give_up(t0, a.status)) { fail = true; break; }
+            }
+            if (!fail) {
+                if (mine) xp1_s[tid] = __uint_as_float((unsigned)xa);
+                if (tid == 0) xp1_s[P] = __uint_as_float((unsigned)ya);
             }
         }
         if (__syncthreads_or(fail)) break;
+        PB_T(13);
         if (xp1_s[P] != 0.f) { ++t; break; }                           // every workgroup reads the same flag
         {
             const float x = tid < P ? xp1_s[tid] : 0.f;
 #pragma unroll
             for (int j = 0; j < PB_MAXP2R; ++j) {
-                const float s = wave_reduce_sum(w2[j] * x);
-                if (lane == 0) red_s[56 + j * 4 + wave] = s;
+                if (k + j * NWG < P) {
+                    const float s = row16_sum(w2[j] * x);
+                    if ((lane & 15) == 0) red_s[192 + j * 16 + (tid >> 4)] = s;
+                }
             }
             __syncthreads();
-            if (tid < PB_MAXP2R) {
-                const int r = k + tid * NWG;
+            if (ct >= 0 && ct < PB_MAXP2R) {
+                const int r = k + ct * NWG;
                 if (r < P) {
-                    float y = ((red_s[56 + tid * 4] + red_s[56 + tid * 4 + 1]) + red_s[56 + tid * 4 + 2]) + red_s[56 + tid * 4 + 3];
+                    float y;
+                    {
+                        const float* rr = &red_s[192 + ct * 16];
+                        const float4 s0 = *reinterpret_cast<const float4*>(rr), s1 = *reinterpret_cast<const float4*>(rr + 4);
+                        const float4 s2 = *reinterpret_cast<const float4*>(rr + 8), s3 = *reinterpret_cast<const float4*>(rr + 12);
+                        y = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                            (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+                    }
                     y = fmaxf(y, 0.f);
-                    y = a.keep_prenet[((long long)(t + 1) * 2 + 1) * P + r] ? y * 2.0f : 0.f;
+                    y = keep2 ? y * 2.0f : 0.f;
                     pb_publish(G_p2 + r, tag, y);
                     if (trace) trace[(long long)t * TRW + H + E + H + P + r] = y;
                 }
             }
         }
+        PB_T(14);
+    }
+    if (tim) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) tim[i] = tacc[i];
     }
     if (k == 0 && tid == 0) a.steps_done[0] = t;
 }
@@ -466,7 +621,7 @@ extern "C" long long t2amd_decoder_persist_mailbox_bytes(int Ti, int E, int H, i
 static long long persist_lds_bytes(const t2amd_dec_persist* a, int tip) {
     const long long Ka = a->P + a->E + a->H, Kd = 2ll * a->H + a->E;
     const long long TiP4 = (a->Ti + 3) & ~3;
-    return 2 * 16 * (Ka + Kd) + 4 * (a->P + a->E + 2ll * a->H + a->P + 4 + TiP4 + 2ll * tip + 16 + 64 + 256 + 16);
+    return 2 * 16 * (Ka + Kd) + 4 * (a->P + a->E + 2ll * a->H + a->P + 4 + TiP4 + 2ll * tip + 64 + 256 + 256 + 16);
 }
 
 // 0 = this geometry can run on the persistent kernel; otherwise the reason is left in t2amd_last_error()
@@ -476,14 +631,16 @@ extern "C" int t2amd_decoder_persist_supported(const t2amd_dec_persist* a) {
     const int nwg = a->H / 4;
     T2_REQUIRE(a->E % 8 == 0 && a->P % 8 == 0 && a->P <= PB_NT, "dec_persist: E, P multiples of 8, P <= 256");
     T2_REQUIRE(a->E % nwg == 0 && a->E / nwg <= PB_MAXEPW, "dec_persist: E must split into <= 4 channels per workgroup");
-    T2_REQUIRE(nwg >= PB_TEAMS, "dec_persist: fewer workgroups than attention teams");
-    T2_REQUIRE(a->Ti > 0 && a->Ti <= 16 * PB_MAXR, "dec_persist: Ti must be <= 256");
+    T2_REQUIRE(nwg % PB_TEAMS == 0, "dec_persist: the workgroups must split into 8 attention teams (H a multiple of 32)");
+    T2_REQUIRE(a->Ti > 0 && a->Ti <= PB_PPW * (nwg / PB_TEAMS) && a->Ti <= PB_NT, "dec_persist: Ti must be <= H/4 (<= 256)");
+    T2_REQUIRE((a->H / 16) % 8 == 0, "dec_persist: H must be a multiple of 128");
+    T2_REQUIRE(a->E <= 2 * PB_POLLERS && a->H <= 4 * PB_POLLERS && a->P <= PB_POLLERS, "dec_persist: E <= 512, H <= 1024 (granules per polling thread)");
     T2_REQUIRE((a->P + a->C + 1 + nwg - 1) / nwg <= PB_MAXFR, "dec_persist: too many projection rows per workgroup");
     T2_REQUIRE((a->P + nwg - 1) / nwg <= PB_MAXP2R, "dec_persist: too many prenet rows per workgroup");
     T2_REQUIRE((a->H + a->E + PB_NT - 1) / PB_NT <= PB_MAXKPT, "dec_persist: H + E too wide");
     T2_REQUIRE(a->H / 16 <= PB_MAXQ, "dec_persist: H too wide for the query slice");
     const int tip = ((a->Ti + 2 * PB_HALO + 2) + 3) & ~3;
-    T2_REQUIRE(persist_lds_bytes(a, tip) <= 160 * 1024, "dec_persist: the LSTM rows of one workgroup do not fit in 160 KB of LDS");
+    T2_REQUIRE(persist_lds_bytes(a, tip) <= 160 * 1024 - 1024, "dec_persist: the LSTM rows of one workgroup do not fit in 160 KB of LDS");
     return T2AMD_OK;
 }
 
@@ -500,11 +657,28 @@ extern "C" int t2amd_decoder_infer_persistent_f32(const t2amd_dec_persist* a, vo
     p.a = *a;
     p.nwg = a->H / 4;
     p.tip = ((a->Ti + 2 * PB_HALO + 2) + 3) & ~3;
+    {
+        // defaults from the round-2 sweep (profiles/r02_d_decode_b1_delays.txt: 16.6 us per step without, 12.3 with); T2AMD_PB_DELAYS="p2,ha,pe,ctx,hd,p1,poll"
+        // overrides them (tools only)
+        static int cfg[7] = {16, 16, 0, 16, 8, 8, 1};
+        static bool parsed = false;
+        if (!parsed) {
+            parsed = true;
+            if (const char* e = getenv("T2AMD_PB_DELAYS")) {
+                int v[7], n = sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+                for (int i = 0; i < n && i < 7; ++i) cfg[i] = v[i] < 0 ? 0 : (v[i] > 400 ? 400 : v[i]);
+            }
+        }
+        for (int i = 0; i < 6; ++i) p.delay[i] = cfg[i];
+        p.poll_sleep = cfg[6];
+    }
     const long long lds = persist_lds_bytes(a, p.tip);
     hipStream_t s = (hipStream_t)stream;
     if (t2amd_validate_only_flag_()) return T2AMD_OK;
     if (lds > 64 * 1024 && lds > g_persist_lds) {
-        if (hipFuncSetAttribute((const void*)decode_persistent_b1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        // exactly what is needed: the kernel also owns a few hundred bytes of static LDS (the compiler's scratch for
+        // __syncthreads_or), so asking for all 160 KB of dynamic LDS is refused
+        if (hipFuncSetAttribute((const void*)decode_persistent_b1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             T2_FAIL("dec_persist: cannot raise the dynamic LDS limit");
         g_persist_lds = (int)lds;
     }

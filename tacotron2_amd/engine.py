@@ -871,6 +871,11 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
     d.status, d.steps_done = nv.ptr(status, torch.int32), nv.ptr(steps_done, torch.int32)
     d.mailbox = nv.ptr(mailbox, torch.int64)
     d.trace = nv.ptr(trace) if trace is not None else None
+    timing = None
+    if getattr(model, 'persist_timing', False):                 # tools/bench_decode_b1.py: per-phase clock
+        timing = torch.zeros(32, dtype=torch.int64, device=dev)
+        model.last_persist_timing = timing
+        d.timing = nv.ptr(timing, torch.int64)
     nv.decoder_infer_persistent(d)
     code = int(status.item())
     if code != 0:

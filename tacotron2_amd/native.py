@@ -211,7 +211,7 @@ class DecPersist(C.Structure):
         ("Wq", _f32p), ("U", _f32p), ("v", _f32p), ("Wf", _f32p), ("bias_f", _f32p), ("W2", _f32p),
         ("memory", _f32p), ("pm", _f32p), ("keep_prenet", C.c_void_p),
         ("PG", _f32p), ("ALIGN", _f32p), ("out_length", C.c_void_p), ("status", C.c_void_p),
-        ("steps_done", C.c_void_p), ("mailbox", C.c_void_p), ("trace", _f32p),
+        ("steps_done", C.c_void_p), ("mailbox", C.c_void_p), ("trace", _f32p), ("timing", C.c_void_p),
     ]
 
 

@@ -20,7 +20,7 @@ dev = torch.device("cuda")
 native.load()
 
 
-def timed(prec, persistent, steps):
+def timed(prec, persistent, steps, phases=False):
     hp = create_hparams()
     hp.max_decoder_steps = steps
     hp.gate_threshold = 2.0
@@ -29,6 +29,7 @@ def timed(prec, persistent, steps):
     m.precision = prec
     text = torch.randint(1, 148, (1, 100), device=dev)
     engine.PERSISTENT_DECODE = persistent
+    m.persist_timing = phases
     best = None
     for _ in range(3):
         torch.cuda.synchronize()
@@ -39,7 +40,19 @@ def timed(prec, persistent, steps):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     assert o[0].shape[2] == steps
+    global PHASES
+    if m.persist_timing and getattr(m, 'last_persist_timing', None) is not None:
+        tk = m.last_persist_timing.cpu().tolist()
+        names = ["wait p2", "lstm_a tail + publish h_a", "wait h_a", "energies (team) / h_a parts (others)", "wait energies",
+                 "softmax + ctx publish", "h_a parts (team, deferred)", "wait ctx", "lstm_d tail + publish h_d", "ctx part of next lstm_a",
+                 "wait h_d", "projection rows + publish p1", "h_d part of next lstm_d", "wait p1", "prenet layer 2 + publish p2"]
+        PHASES = {"unit": "us per step (100 MHz wall clock, thread 0)",
+                  "first workgroup (attention team)": {n: tk[i] / steps / 100.0 for i, n in enumerate(names)},
+                  "last workgroup": {n: tk[16 + i] / steps / 100.0 for i, n in enumerate(names)}}
     return best, m.last_decode_path
+
+
+PHASES = None
 
 
 out = {"steps": STEPS, "Ti": 100}
@@ -49,6 +62,8 @@ with contextlib.redirect_stdout(sys.stderr):
                              ("launch_chain_fp32", "fp32", False)):
         full, path = timed(prec, pers, STEPS)
         one, _ = timed(prec, pers, 1)
+        if pers:
+            timed(prec, pers, STEPS, phases=True)             # separate run: the phase clock is not in the timed numbers
         es = 2.0 if prec == "bf16" else 4.0
         step_bytes = es * (18189969 + 640 * 100.0)
         loop = max(full - one, 1e-9)
@@ -56,4 +71,6 @@ with contextlib.redirect_stdout(sys.stderr):
                      "decode_steps_per_s_whole_call": STEPS / full, "us_per_step_loop_only": 1e6 * loop / (STEPS - 1),
                      "hbm_roofline_frac_whole_call": step_bytes * STEPS / full / 8e12}
 engine.PERSISTENT_DECODE = True
+if PHASES:
+    out["persistent_phases"] = PHASES
 print(json.dumps(out))
