@@ -9,11 +9,17 @@ synthetic LJSpeech-shaped batch per GPU: parse_batch -> forward -> Tacotron2Loss
 in HBM before the timed region.  Metric: VALID mel frames per second, whole job.
 
 Extra objects in the JSON line:
-  roofline      fused LSTM step launch (skinny_gemm_kernel<true,3>): algorithmic bytes per launch
+  roofline      fused LSTM step launch (skinny_wide_kernel<true,3>): algorithmic bytes per launch
                  / average launch duration measured live with HIP events on the
-                launch stream during one extra, untimed, step.
+                launch stream during one extra, untimed, step; beside it the attention-backward pair of one
+                time step (same method, second extra step) and the whole training step against SURVEY 8d's
+                92 MB-per-padded-time-step bound.
   cpu_baseline  the CPU oracle (oracle/tacotron2_oracle.py, a port of the reference) timed on this
-                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only): 1 warm-up + 2 timed
+                forward+backward steps, and the same with clip + Adam (reference train.py:229-236).
+  parity_check  the engine's loss on that very sub-batch with the oracle's dropout masks, both precision modes, against
+                the oracle's loss: the bench line verifies the thing it measures (non-zero exit code on a mismatch).
+  optimizer_ab  the same training step with torch's clip_grad_norm_ + Adam and with the fused HIP pair.
   inference     BASELINE's second metric, decode steps/s (configs 4 and 5), N=1 only; see inference_leg().
 """
 import argparse
@@ -35,14 +41,17 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip; 64 = SURVEY 8d's full batch, ~2 min)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true",
                     help="skip the decode-steps/s leg (BASELINE configs 4/5) reported beside the training metric at N=1")
-    ap.add_argument("--fused-optimizer", action="store_true",
-                    help="clip + Adam as two HIP launches (tacotron2_amd.optim.FusedAdam) instead of torch's "
-                         "clip_grad_norm_ + Adam.step (default until the fused pair has been measured)")
+    ap.add_argument("--fused-optimizer", dest="fused_optimizer", action="store_true", default=True,
+                    help="clip + Adam as two HIP launches (tacotron2_amd.optim.FusedAdam): the default since round 2 "
+                         "(measured faster than the torch pair, optimizer_ab in the JSON line)")
+    ap.add_argument("--torch-optimizer", dest="fused_optimizer", action="store_false",
+                    help="torch's clip_grad_norm_ + Adam.step in the timed region")
+    ap.add_argument("--no-optimizer-ab", action="store_true", help="skip the torch / fused optimiser A/B leg")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the extra fp32-mode timing that is reported beside a bf16 run")
     ap.add_argument("--precision", default="bf16", choices=("fp32", "bf16"),
@@ -53,8 +62,28 @@ def parse_args():
     return ap.parse_args()
 
 
+def kernel_source_sha1():
+    """Hash of the sources of the dominant kernel (csrc/rnn.hip + csrc/common.h): stamps profiles/pmc_traffic.json."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("rnn.hip", "common.h"):
+        with open(os.path.join(ROOT, "tacotron2_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def masks_to_engine(masks, device):
+    """Oracle/reference-layout keep-masks -> the engine's channel-last layout (engine.MaskSource)."""
+    return dict(enc=[m.permute(0, 2, 1).contiguous().to(device) for m in masks['enc']],
+                prenet=[m[:-1].contiguous().to(device) for m in masks['prenet']],
+                att=masks['att'].contiguous().to(device), dec=masks['dec'].contiguous().to(device),
+                post=[m.permute(0, 2, 1).contiguous().to(device) for m in masks['post']])
+
+
 def cpu_baseline(sample_b, seed, threads=16):
-    """Time the oracle (CPU port of the reference hot path) on a strided sub-batch of the bench batch."""
+    """Time the oracle (CPU port of the reference hot path) on a strided sub-batch of the bench batch: 1 warm-up +
+    2 timed forward+backward steps, then the optimiser part of a step (clip_grad_norm_ + Adam over the 28.2 M
+    parameters, reference train.py:229-236).  Returns the JSON object and what the parity check needs."""
     from oracle import tacotron2_oracle as orc
     from tacotron2_amd.hparams import create_hparams
     from tacotron2_amd.model import Tacotron2
@@ -73,29 +102,100 @@ def cpu_baseline(sample_b, seed, threads=16):
     # (128 threads measured 4x SLOWER than 8), so the baseline pins the pool and states the count.
     threads = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
+    orc.train_step_grads(sd, hp, batch, masks)                     # warm-up (allocator, thread pool, code paths)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        oloss, _, ograds, _ = orc.train_step_grads(sd, hp, batch, masks)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    # the optimiser part of the reference step on the host
+    params = [torch.nn.Parameter(sd[k].clone()) for k in ograds]
+    for p_, k in zip(params, ograds):
+        p_.grad = ograds[k].clone()
+    opt = torch.optim.Adam(params, lr=hp.learning_rate, weight_decay=hp.weight_decay)
+    torch.nn.utils.clip_grad_norm_(params, hp.grad_clip_thresh)
+    opt.step()                                                     # warm-up (state allocation)
     t0 = time.perf_counter()
-    orc.train_step_grads(sd, hp, batch, masks)
-    dt = time.perf_counter() - t0
+    torch.nn.utils.clip_grad_norm_(params, hp.grad_clip_thresh)
+    opt.step()
+    dopt = time.perf_counter() - t0
     frames = int(ol.sum())
-    return {"value": frames / dt, "unit": "valid mel-frames/s", "cores": threads, "kind": "port",
-            "sample": "1 fwd+bwd step (no optimiser) of oracle/tacotron2_oracle.py on %d of the 64 utterances "
-                      "(every %dth, Ti_max=%d, To_max=%d, %d valid frames), fp32, %.1f s"
-                      % (sample_b, 64 // sample_b, Ti, To, frames, dt)}
+    obj = {"value": frames / dt, "unit": "valid mel-frames/s", "cores": threads, "kind": "port",
+           "with_optimizer": frames / (dt + dopt),
+           "sample": "oracle/tacotron2_oracle.py on %d of the 64 utterances (every %dth, Ti_max=%d, To_max=%d, %d valid "
+                     "frames), fp32: 1 warm-up + 2 timed fwd+bwd steps of %.1f s each; clip_grad_norm_ + Adam add %.2f s "
+                     "per step (with_optimizer)" % (sample_b, 64 // sample_b, Ti, To, frames, dt, dopt)}
+    return obj, dict(hp=hp, sd=sd, batch=batch, masks=masks, oloss=float(oloss))
+
+
+def parity_check(ctx, dev):
+    """The engine on the cpu_baseline sub-batch with the oracle's dropout masks: loss against the oracle's, both modes."""
+    from tacotron2_amd.model import Tacotron2
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    out = {"oracle_loss": ctx['oloss'], "tolerance": {"fp32": 1e-4, "bf16": 2e-2}}
+    ok = True
+    for prec in ("fp32", "bf16"):
+        m = Tacotron2(ctx['hp'])
+        m.load_state_dict(ctx['sd'])
+        m = m.to(dev).train()
+        m.precision = prec
+        m.dropout_masks = masks_to_engine(ctx['masks'], dev)
+        x, y = m.parse_batch(tuple(t.clone() for t in ctx['batch']))
+        loss = float(Tacotron2Loss()(m(x), y).detach())
+        rel = abs(loss - ctx['oloss']) / max(abs(ctx['oloss']), 1e-12)
+        out["engine_loss_" + prec] = loss
+        out["rel_diff_" + prec] = rel
+        ok = ok and rel < out["tolerance"][prec]
+        del m
+    out["ok"] = ok
+    return out
+
+
+def _timed_inference(m, text, lens, reps=2):
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # forced runs end at max_decoder_steps: the model's "Warning! Reached max decoder steps" line (reference
+        # model.py:446 prints it) must not land on stdout next to the ONE JSON line the driver reads
+        with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+            o = m.inference(text, lens) if lens is not None else m.inference(text)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return o, dt
 
 
 def inference_leg(dev):
-    """BASELINE configs 4 and 5 beside the headline (decode steps/s): B=1, Ti=100, 1000 forced steps (gate threshold
-    above 1 so the stop never fires: timing independent of the random weights) in both precision modes, and 256
-    LJSpeech-length texts, 400 forced steps, bf16 mode.  Second of two runs; the whole of Tacotron2.inference
-    (encoder + loop + postnet) is inside the timed region.  Roofline: algorithmic bytes per decode step = step
-    weights (18,189,969 parameters) + the encoder memory and its projection (Ti x 640 per utterance), at the
-    operand width of the mode (SURVEY 8d / BASELINE.md 3.5), against 8 TB/s."""
+    """BASELINE configs 4 and 5 beside the headline (decode steps/s).  The whole of Tacotron2.inference (encoder + loop
+    + postnet) is inside the timed region; second of two runs.
+      config4_B1_*            B=1, Ti=100, 1000 forced steps (gate threshold above 1: timing independent of the random
+                              weights); bf16 runs on the persistent weight-stationary kernel (csrc/decode_persist.hip),
+                              fp32 and `config4_B1_bf16_launch_chain` on the launch chain (loops.hip)
+      config4_B1_bf16_gate_stop   the same utterance decoded greedily to a REAL gate stop: the threshold is put on the
+                              forced run's own gate trajectory where its first crossing lies beyond 300 steps
+      config5_B256_bf16       256 LJSpeech-length texts, 400 forced steps; config5_B256_bf16_2000: max_decoder_steps=2000
+                              (BASELINE configs[4]'s cap; with random weights every utterance runs to the cap)
+    Roofline: algorithmic bytes per decode step = step weights (18,189,969 parameters) + the encoder memory and its
+    projection (Ti x 640 per utterance), at the operand width of the mode (SURVEY 8d / BASELINE.md 3.5), against 8 TB/s."""
+    from tacotron2_amd import engine
     from tacotron2_amd.hparams import create_hparams
     from tacotron2_amd.model import Tacotron2
     from tacotron2_amd.synth import synth_lengths
     out = {}
-    for name, B, steps, prec in (("config4_B1_fp32", 1, 1000, "fp32"), ("config4_B1_bf16", 1, 1000, "bf16"),
-                                 ("config5_B256_bf16", 256, 400, "bf16")):
+
+    def record(name, B, ti, prec, o, dt, path):
+        T = int(o[0].shape[2])
+        es = 2.0 if prec == "bf16" else 4.0                    # SURVEY 8d: (W_step + sum_b Ti_b * 640) * s
+        step_bytes = es * (18189969 + 640 * float(sum(int(v) for v in ti)))
+        gbs = step_bytes * T / dt / 1e9
+        out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt,
+                     "utterance_steps_per_s": B * T / dt, "precision": prec, "decode_path": path,
+                     "hbm_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": gbs, "frac": gbs / 8000.0}}
+
+    for name, B, steps, prec, persistent in (("config4_B1_fp32", 1, 1000, "fp32", True), ("config4_B1_bf16", 1, 1000, "bf16", True),
+                                             ("config4_B1_bf16_launch_chain", 1, 1000, "bf16", False),
+                                             ("config5_B256_bf16", 256, 400, "bf16", True),
+                                             ("config5_B256_bf16_2000", 256, 2000, "bf16", True)):
         hp = create_hparams()
         hp.max_decoder_steps = steps
         hp.gate_threshold = 2.0
@@ -112,22 +212,38 @@ def inference_leg(dev):
             for b in range(B):
                 text[b, :ti[b]] = torch.randint(1, 148, (int(ti[b]),), device=dev)
             lens = torch.from_numpy(ti.copy()).to(dev)
-        for _ in range(2):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            # the forced runs end at max_decoder_steps: the model's "Warning! Reached max decoder steps" line (reference
-            # model.py:446 prints it) must not land on stdout next to the ONE JSON line the driver reads
-            with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
-                o = m.inference(text, lens) if lens is not None else m.inference(text)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        T = int(o[0].shape[2])
-        es = 2.0 if prec == "bf16" else 4.0                    # (W_step + sum_b Ti_b * 640) * s
-        step_bytes = es * (18189969 + 640 * float(sum(int(v) for v in ti)))
-        gbs = step_bytes * T / dt / 1e9
-        out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt,
-                     "utterance_steps_per_s": B * T / dt, "precision": prec,
-                     "hbm_roofline": {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": gbs, "frac": gbs / 8000.0}}
+        engine.PERSISTENT_DECODE, keep_flag = persistent, engine.PERSISTENT_DECODE
+        try:
+            o, dt = _timed_inference(m, text, lens)
+            record(name, B, ti, prec, o, dt, getattr(m, "last_decode_path", "launch chain"))
+            if name == "config4_B1_bf16":
+                # greedy decode to a real gate stop: random weights give a flat gate, so the context half of the gate
+                # weight is negated (the attention drift then raises the gate slowly, tests/test_zz5) and the threshold is
+                # put where the trajectory of a forced run first crosses it beyond 300 steps
+                with torch.no_grad():
+                    m.decoder.gate_layer.linear_layer.weight[:, hp.decoder_rnn_dim:] *= -60.0
+                    m.decoder.gate_layer.linear_layer.weight[:, :hp.decoder_rnn_dim] *= 60.0
+                torch.manual_seed(77)
+                with torch.no_grad(), contextlib.redirect_stdout(sys.stderr):
+                    sig = torch.sigmoid(m.inference(text)[2].float().reshape(-1)).cpu()
+                stop = None
+                for t in range(300, sig.numel()):
+                    top = float(sig[:t].max())
+                    if float(sig[t]) > top + 2e-3:
+                        stop, m.hparams.gate_threshold = t + 1, (float(sig[t]) + top) / 2
+                        break
+                if stop is not None:
+                    torch.manual_seed(77)                      # same prenet dropout stream as the probing run
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    with torch.no_grad():
+                        o2 = m.inference(text)
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t0
+                    record("config4_B1_bf16_gate_stop", 1, ti, prec, o2, dt2, getattr(m, "last_decode_path", "launch chain"))
+                    out["config4_B1_bf16_gate_stop"]["expected_stop"] = stop
+        finally:
+            engine.PERSISTENT_DECODE = keep_flag
         del m
     return out
 
@@ -230,7 +346,8 @@ def main():
     # ---- roofline of the dominant kernel: one extra untimed step with HIP-event brackets ------
     roofline = None
     if not args.no_roofline and rank != 0:
-        step(batches[-1])                 # the gradient exchange is collective: every rank runs the extra step
+        step(batches[-1])                 # the gradient exchange is collective: every rank runs the two extra steps
+        step(batches[-1])
         torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
         To = batches[-1][2].shape[2]
@@ -265,10 +382,13 @@ def main():
                  "side stream concurrently with the attention chain, so its duration includes sharing the CUs)")
         # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler
         # around itself); null if the file is absent.
+        # (the file records the hash of the kernel's source it was measured on: a stale measurement reads as null)
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-                traffic = json.load(fh).get(("fused_" if fused else "single_") + args.precision)
+                rec = json.load(fh)
+            if rec.get("source_sha1") == kernel_source_sha1():
+                traffic = rec.get(("fused_" if fused else "single_") + args.precision)
         except Exception:
             traffic = None
         roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -278,6 +398,31 @@ def main():
                     "mfma": {"achieved_tflops": alg_flops / avg_s / 1e12,
                              "peak_tflops": 2500.0 if es == 2.0 else 157.3,
                              "frac": alg_flops / avg_s / 1e12 / (2500.0 if es == 2.0 else 157.3)}}
+        # ---- the attention-backward pair (K_b1 + K_b2) of one time step, same method, one more untimed step ---------
+        native.profile_enable(4, To)
+        step(batches[-1])
+        torch.cuda.synchronize()
+        ev4 = native.profile_event_overhead()
+        ms4, cnt4 = native.profile_read()
+        if cnt4 > 0:
+            ti_sum = float(batches[-1][1].sum().item())
+            ab_bytes = es * 640.0 * ti_sum                    # the encoder memory + its projection, once per step
+            ab_s = max((ms4 / 1e3) / cnt4 - ev4 / 1e3, 1e-9)
+            roofline["attention_backward"] = {
+                "kernels": "attn_bwd_dw_kernel + attn_bwd_main_kernel (one decoder time step, hipEventRecord bracket minus "
+                           "the calibrated empty bracket)",
+                "algorithmic_bytes_per_step": ab_bytes, "avg_pair_us": ab_s * 1e6, "empty_bracket_us": ev4 * 1e3,
+                "achieved": ab_bytes / ab_s / 1e9, "unit": "GB/s", "frac": ab_bytes / ab_s / 1e9 / 8000.0, "launches": cnt4}
+        # ---- the whole training step against SURVEY 8d's per-padded-time-step bound ---------------------------------
+        ti_sum = float(batches[-1][1].sum().item())
+        per_step = 2.0 * (18189969 * es + 640.0 * ti_sum * es) + 2.0 * B * 12300 * es
+        ms_step = 1e3 * elapsed / args.steps
+        roofline["whole_step"] = {
+            "algorithmic_bytes_per_padded_time_step": per_step, "time_steps": To, "ms_per_step": ms_step,
+            "achieved": per_step * To / (ms_step / 1e3) / 1e9, "unit": "GB/s",
+            "frac": per_step * To / (ms_step / 1e3) / 1e9 / 8000.0,
+            "note": "SURVEY 8d: 2 x (step weights + encoder memory) + saved activations per padded time step; encoder, "
+                    "postnet, dense weight-gradient GEMMs and the optimiser are inside ms_per_step but not in the bytes"}
     # ---- the same step in fp32 parity mode, reported beside a bf16 run (fewer steps, same batches) ----------
     fp32_leg = None
     if args.precision == "bf16" and not args.no_fp32_leg:
@@ -305,9 +450,38 @@ def main():
                     "note": "same workload with model.precision='fp32' (exact-f32 MFMA forward: the mode the 1e-4 / "
                             "bit-exact-stop parity tests run in)"}
         model.precision = args.precision
+    # ---- optimiser A/B: the same step with the other clip + Adam implementation (fresh optimiser state) ----------
+    optimizer_ab = None
+    if world == 1 and not args.no_optimizer_ab:
+        from tacotron2_amd.optim import FusedAdam
+        res = {}
+        for which in ("torch", "fused"):
+            opt = (FusedAdam if which == "fused" else torch.optim.Adam)(model.parameters(), lr=hp.learning_rate,
+                                                                          weight_decay=hp.weight_decay)
+
+            def ab_step(batch, opt=opt, which=which):
+                model.zero_grad()
+                x, y = model.parse_batch(batch)
+                criterion(model(x), y).backward()
+                if which == "fused":
+                    opt.step(clip_norm=hp.grad_clip_thresh)
+                else:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), hp.grad_clip_thresh)
+                    opt.step()
+            ab_step(batches[0])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kab = max(2, args.steps // 2)
+            for i in range(kab):
+                ab_step(batches[args.warmup + i % args.steps])
+            torch.cuda.synchronize()
+            res[which] = 1e3 * (time.perf_counter() - t0) / kab
+        optimizer_ab = {"ms_per_step_torch_clip_adam": res["torch"], "ms_per_step_fused_clip_adam": res["fused"],
+                        "steps": kab}
     if world > 1:
         dist.barrier()
 
+    parity = None
     if rank == 0:
         out = {
             "metric": "mel-frames/sec (train fwd+bwd) LJSpeech hparams",
@@ -331,8 +505,15 @@ def main():
             out["roofline"] = roofline
         if fp32_leg:
             out["fp32_mode"] = fp32_leg
+        if optimizer_ab:
+            out["optimizer_ab"] = optimizer_ab
         if args.gpus == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1234, args.cpu_threads)
+            out["cpu_baseline"], ctx = cpu_baseline(args.cpu_sample, 1234, args.cpu_threads)
+            try:
+                parity = parity_check(ctx, dev)
+            except Exception as e:                 # noqa: BLE001
+                parity = {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
+            out["parity_check"] = parity
         if args.gpus == 1 and not args.no_inference:
             try:                                   # never let the secondary metric take the headline line down
                 out["inference"] = inference_leg(dev)
@@ -341,6 +522,10 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if parity is not None and not parity.get("ok", False):
+        print("bench.py: the engine's loss does not match the oracle's on the cpu_baseline sub-batch: %r" % (parity,),
+              file=sys.stderr, flush=True)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

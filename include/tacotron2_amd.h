@@ -649,6 +649,18 @@ int t2amd_mel_log_compress_f32(const float* mel, long long ld, float* out, int B
  * no amsgrad).  The state tensors (exp_avg, exp_avg_sq) are the ones torch.optim.Adam keeps, so
  * the reference's checkpoint format (train.py:112-118) is unchanged.
  * ------------------------------------------------------------------------------------ */
+/* Tacotron2Loss (reference loss_function.py:8-19): loss = mean((mel - y)^2) + mean((mel_post - y)^2) +
+ * mean(bce_with_logits(gate, g)) over the padded tensors, one reduction pass (fixed summation order, double partial sums:
+ * bit-reproducible) and one gradient pass.  out4 = {total, mel term, postnet term, gate term}; ws holds
+ * t2amd_loss_workspace_doubles() doubles; `upstream` is the device scalar d(total)/d(loss) (no host read). */
+int t2amd_loss_workspace_doubles(void);
+int t2amd_tacotron2_loss_fwd_f32(const float* mel, const float* mel_post, const float* mel_target, long long n_mel,
+                                 const float* gate, const float* gate_target, long long n_gate, double* ws, float* out4,
+                                 void* stream);
+int t2amd_tacotron2_loss_bwd_f32(const float* mel, const float* mel_post, const float* mel_target, long long n_mel,
+                                 const float* gate, const float* gate_target, long long n_gate, const float* upstream,
+                                 float* d_mel, float* d_mel_post, float* d_gate, void* stream);
+
 #define T2AMD_MAX_TENSORS 64
 typedef struct t2amd_tensor_list {
     void* param[T2AMD_MAX_TENSORS];        /* f32, updated in place (unused by t2amd_grad_norm_f32) */

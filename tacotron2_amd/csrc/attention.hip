@@ -1216,9 +1216,11 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
+    t2amd_profile_mark_(4, 0, s);          // role 4: the attention backward pair of one time step (bench.py roofline)
     if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
     else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
     T2_LAUNCH((attn_bwd_main_kernel<false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
+    t2amd_profile_mark_(4, 1, s);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -629,3 +629,41 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
     }
     return T2AMD_OK;
 }
+
+// tools/microbench_decode_graph.py (not part of the C ABI): the SAME launch chain of `p->n_steps` decode steps timed
+// two ways on `stream` (which must not be the legacy default stream) -- enqueued eagerly `reps` times, and captured
+// once into a hipGraph and replayed `reps` times.  Replays recompute the same step range (pointers are baked into the
+// graph), which is all a timing needs.  out_ms[0] = eager milliseconds per pass, out_ms[1] = graph replay.
+extern "C" int t2amd_debug_graph_decode_(const t2amd_dec_infer* p, int reps, float* out_ms, void* stream) {
+    T2_REQUIRE(p && out_ms && reps > 0 && stream, "debug_graph_decode: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) T2_FAIL("debug_graph_decode: hipEventCreate");
+    T2_PROPAGATE(t2amd_decoder_infer_steps_f32(p, s));          // warm-up: one-time function attributes are set eagerly
+    if (hipStreamSynchronize(s) != hipSuccess) T2_FAIL("debug_graph_decode: sync");
+    (void)hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) T2_PROPAGATE(t2amd_decoder_infer_steps_f32(p, s));
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) T2_FAIL("debug_graph_decode: event sync");
+    (void)hipEventElapsedTime(&out_ms[0], e0, e1);
+    out_ms[0] /= reps;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) T2_FAIL("debug_graph_decode: begin capture");
+    const int rc = t2amd_decoder_infer_steps_f32(p, s);
+    if (hipStreamEndCapture(s, &g) != hipSuccess || rc != T2AMD_OK) T2_FAIL("debug_graph_decode: capture failed");
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) T2_FAIL("debug_graph_decode: instantiate");
+    (void)hipGraphLaunch(ge, s);
+    if (hipStreamSynchronize(s) != hipSuccess) T2_FAIL("debug_graph_decode: sync after first replay");
+    (void)hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) (void)hipGraphLaunch(ge, s);
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) T2_FAIL("debug_graph_decode: event sync (graph)");
+    (void)hipEventElapsedTime(&out_ms[1], e0, e1);
+    out_ms[1] /= reps;
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return T2AMD_OK;
+}

@@ -254,6 +254,7 @@ SYMBOLS = [
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
     "t2amd_decoder_persist_mailbox_bytes", "t2amd_decoder_persist_supported", "t2amd_decoder_infer_persistent_f32",
+    "t2amd_loss_workspace_doubles", "t2amd_tacotron2_loss_fwd_f32", "t2amd_tacotron2_loss_bwd_f32",
 ]
 
 _P, _I, _L, _F, _UL = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_ulonglong
@@ -317,6 +318,9 @@ def _argtypes():
         "t2amd_decoder_persist_mailbox_bytes": [_I, _I, _I, _I],
         "t2amd_decoder_persist_supported": [pt(DecPersist)],
         "t2amd_decoder_infer_persistent_f32": [pt(DecPersist), _P],
+        "t2amd_loss_workspace_doubles": [],
+        "t2amd_tacotron2_loss_fwd_f32": [_P, _P, _P, _L, _P, _P, _L, _P, _P, _P],
+        "t2amd_tacotron2_loss_bwd_f32": [_P, _P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _P],
     }
 
 
@@ -391,6 +395,28 @@ def decoder_persist_supported(desc):
 def decoder_infer_persistent(desc):
     """The whole free-running decode loop of ONE utterance as one persistent launch (csrc/decode_persist.hip)."""
     _check(load().t2amd_decoder_infer_persistent_f32(C.byref(desc), _stream()), "t2amd_decoder_infer_persistent_f32")
+
+
+def tacotron2_loss_fwd(mel, post, tgt, gate, gate_tgt, ws, out4):
+    for t in (mel, post, tgt, gate, gate_tgt, out4):
+        _fullc(t)
+    if mel.numel() != post.numel() or mel.numel() != tgt.numel() or gate.numel() != gate_tgt.numel():
+        raise NativeError("tacotron2_loss: shape mismatch between outputs and targets")
+    _check(load().t2amd_tacotron2_loss_fwd_f32(ptr(mel), ptr(post), ptr(tgt), mel.numel(), ptr(gate), ptr(gate_tgt),
+                                               gate.numel(), ptr(ws, torch.float64), ptr(out4), _stream()),
+           "t2amd_tacotron2_loss_fwd_f32")
+
+
+def tacotron2_loss_bwd(mel, post, tgt, gate, gate_tgt, upstream, d_mel, d_post, d_gate):
+    for t in (mel, post, tgt, gate, gate_tgt, upstream, d_mel, d_post, d_gate):
+        _fullc(t)
+    _check(load().t2amd_tacotron2_loss_bwd_f32(ptr(mel), ptr(post), ptr(tgt), mel.numel(), ptr(gate), ptr(gate_tgt),
+                                               gate.numel(), ptr(upstream), ptr(d_mel), ptr(d_post), ptr(d_gate), _stream()),
+           "t2amd_tacotron2_loss_bwd_f32")
+
+
+def loss_workspace_doubles():
+    return int(load().t2amd_loss_workspace_doubles())
 
 
 def set_decoder_streams(n):

@@ -346,11 +346,13 @@ def test_bench_inference_leg_plumbing(native_lib, monkeypatch, capsys):
     finally:
         native.set_validate_only(False)
     assert capsys.readouterr().out == ""                              # stdout belongs to the one JSON line
-    assert set(out) == {"config4_B1_fp32", "config4_B1_bf16", "config5_B256_bf16"}
+    assert {"config4_B1_fp32", "config4_B1_bf16", "config4_B1_bf16_launch_chain", "config5_B256_bf16",
+            "config5_B256_bf16_2000"} <= set(out)
     # (the stop bookkeeping lives in device memory the kernels never wrote here: the step count itself is not checked)
     assert 1 <= out["config4_B1_fp32"]["steps"] <= 1000 and 1 <= out["config5_B256_bf16"]["steps"] <= 400
     b1 = out["config4_B1_bf16"]["hbm_roofline"]["algorithmic_bytes_per_step"]
     assert b1 == 2.0 * (18189969 + 640 * 100)                          # 36.5 MB: SURVEY 8d's figure
+    assert all(v["decode_path"].startswith("launch chain") for v in out.values())   # kernels off: never the persistent path
     for v in out.values():
         assert v["decode_steps_per_s"] > 0 and 0 < v["hbm_roofline"]["frac"]
         assert v["utterance_steps_per_s"] == pytest.approx(v["B"] * v["decode_steps_per_s"])
