@@ -572,6 +572,11 @@ typedef struct t2amd_dec_infer {
     void* x_prenet16;      /* [B][P] bf16: prenet output of the current step */
     void* h_a16;           /* [2][B][Ha] bf16 ping-pong (zeroed before t0 == 0) */
     void* hc16;            /* [2][B][Hd+E] bf16 ping-pong (zeroed before t0 == 0) */
+    /* B > 8, optional: prenet layer 0 folded through the frame projection, Wf = W1 . Wp [P][Hd+E], bias_f = W1 . bp [P]
+     * (p1 = relu(W1 (Wp hc + bp)) = relu(Wf hc + bias_f)): layer 0 of step t+1 then rides in step t's projection launch
+     * instead of being a B x 256 x 80 tiled GEMM of its own.  NULL: the unfolded form. */
+    const float* Wf;
+    const float* bias_f;
 } t2amd_dec_infer;
 
 int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);

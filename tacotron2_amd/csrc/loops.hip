@@ -524,10 +524,13 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             l2.B = B; l2.N = P; l2.K = P; l2.act = 1; l2.keep = g2.keep; l2.ldkeep = P; l2.keep_scale = two;
             T2_PROPAGATE(t2amd_linear_small_f32(&l2, stream));
         } else {
-            // layer 1 (K = n_mel = 80: five k-steps) on the tiled GEMM; layer 2 and the projection below are B x N
-            // outputs over a long K -- one or two 128-tiles for the tiled kernel (75-190 us at B = 256), a full
-            // LDS-DMA pipeline per 16 columns for the skinny kernel
-            T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
+            // Layer 1: with the folded matrix Wf = W1 . Wp (t2amd_dec_infer.Wf) it was produced by the PREVIOUS step's
+            // projection launch (p1 = relu(W1 (Wp hc + bp)) = relu(Wf hc + W1 bp): second problem of that launch) and is
+            // exactly zero at t = 0 (go frame).  Without Wf: K = n_mel = 80 on the tiled GEMM (one or two 128-tiles for
+            // a B x 256 output: 25 us at B = 256).  Layer 2 and the projection below are B x N outputs over a long K: a
+            // full LDS-DMA pipeline per 16 columns on the skinny kernel.
+            if (!p->Wf) T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
+            else if (t == 0) T2_PROPAGATE(t2amd_fill_f32(p->x_prenet, sP, 0.f, stream));
             t2amd_skinny_gemm s2 = {};
             s2.nseg = 1;
             s2.x[0] = seg(p->x_prenet, P, P);
@@ -620,7 +623,19 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             sp.W = p->Wpg; sp.Ktot = Hd + E; sp.N = C + 1; sp.B = B;
             sp.Y = p->PG + (long long)t * sPG; sp.ldy = C + 1; sp.nsplit = 1;
             sp.bias = p->bias_pg;
-            T2_PROPAGATE(t2amd_skinny_gemm_f32(&sp, stream));
+            if (p->Wf && t + 1 < p->max_steps) {
+                // second problem of the same launch: prenet layer 1 of step t + 1 through the folded matrix
+                t2amd_skinny_gemm s1 = {};
+                s1.nseg = 1;
+                s1.x[0] = seg(p->hc + wr * sHC, Hd + E, Hd + E);
+                s1.W = p->Wf; s1.Ktot = Hd + E; s1.N = P; s1.B = B;
+                s1.Y = p->x_prenet; s1.ldy = P; s1.nsplit = 1;
+                s1.bias = p->bias_f; s1.act = 1;
+                s1.keep = p->keep_prenet + ((long long)(t + 1) * 2 + 0) * sP; s1.ld_keep = P; s1.keep_scale = two;
+                T2_PROPAGATE(t2amd_skinny_gemm2_f32(&sp, &s1, stream));
+            } else {
+                T2_PROPAGATE(t2amd_skinny_gemm_f32(&sp, stream));
+            }
         }
 
         T2_LAUNCH(infer_finish_step_kernel, dim3(t2_cdiv(B, 64)), dim3(64), 0, s, p->PG + (long long)t * sPG, B,

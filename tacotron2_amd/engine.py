@@ -823,20 +823,15 @@ class Tacotron2TrainFunction(torch.autograd.Function):
 PERSISTENT_DECODE = os.environ.get('T2AMD_DECODE_PERSISTENT', '1') != '0'
 
 
-def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat, bias_a, bias_d, Wq, U,
-                       vvec, Wpg, bpg, i16, Ti):
-    """reference model.py:435-449 (Decoder.inference loop) for B == 1 as one persistent launch.  Returns False when the
-    kernel cannot run here (geometry, or a bounded-spin timeout): the caller then runs the launch chain from step 0."""
-    import sys
-    E, H, Pd, Cm = hp.encoder_embedding_dim, hp.attention_rnn_dim, hp.prenet_dim, hp.n_mel_channels
-    dev = run.dev
+def _folded_projection(run, P, hp, Wpg, bpg):
+    """[W1 . Wp ; Wp ; Wg] (P + C + 1 rows over Hd + E) and the matching bias: prenet layer 0 folded through the frame
+    projection, p1 = relu(W1 (Wp hc + bp)) = relu((W1 Wp) hc + W1 bp) (reference model.py:99 after :373-375)."""
+    E, H, Pd, Cm = hp.encoder_embedding_dim, hp.decoder_rnn_dim, hp.prenet_dim, hp.n_mel_channels
     W1 = P['decoder.prenet.layers.0.linear_layer.weight']
-    W2 = P['decoder.prenet.layers.1.linear_layer.weight']
     Wp = P['decoder.linear_projection.linear_layer.weight']
     bp = P['decoder.linear_projection.linear_layer.bias']
 
     def fold():
-        # prenet layer 0 folded through the frame projection: p1 = relu(W1 (Wp hc + bp)) = relu((W1 Wp) hc + W1 bp)
         Wf = run.empty(Pd + Cm + 1, H + E)
         nv.gemm(Wf[:Pd], W1, Wp, b_kn=True)
         nv.copy2d(Wf[Pd:], Wpg)
@@ -844,8 +839,19 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
         nv.gemm(bf[:Pd].view(1, Pd), bp.view(1, Cm), W1)
         nv.copy2d(bf[Pd:].view(1, Cm + 1), bpg.view(1, Cm + 1))
         return Wf, bf
-    Wf, bf = run.cached('Wf_fold', [W1, Wp, bp, P['decoder.gate_layer.linear_layer.weight'],
-                                    P['decoder.gate_layer.linear_layer.bias']], fold)
+    return run.cached('Wf_fold', [W1, Wp, bp, P['decoder.gate_layer.linear_layer.weight'],
+                                  P['decoder.gate_layer.linear_layer.bias']], fold)
+
+
+def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat, bias_a, bias_d, Wq, U,
+                       vvec, Wpg, bpg, i16, Ti):
+    """reference model.py:435-449 (Decoder.inference loop) for B == 1 as one persistent launch.  Returns False when the
+    kernel cannot run here (geometry, or a bounded-spin timeout): the caller then runs the launch chain from step 0."""
+    import sys
+    E, H, Pd, Cm = hp.encoder_embedding_dim, hp.attention_rnn_dim, hp.prenet_dim, hp.n_mel_channels
+    dev = run.dev
+    W2 = P['decoder.prenet.layers.1.linear_layer.weight']
+    Wf, bf = _folded_projection(run, P, hp, Wpg, bpg)
     d = nv.DecPersist()
     d.Ti, d.E, d.H, d.P, d.C = Ti, E, H, Pd, Cm
     d.max_steps = hp.max_decoder_steps
@@ -1007,6 +1013,9 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     d.out_lengths = nv.ptr(out_lengths, torch.int32)
     d.active = nv.ptr(active, torch.uint8)
     d.done_count = nv.ptr(done, torch.int32)
+    if B > 8:
+        Wf_, bf_ = _folded_projection(run, P, hp, Wpg, bpg)     # prenet layer 0 rides in the projection launch
+        d.Wf, d.bias_f = nv.ptr(Wf_), nv.ptr(bf_)
 
     if run.bf16:
         # bf16 operand mode of the two LSTM products: B > 8 reads bf16 weights and bf16 copies of the recurrent
