@@ -86,6 +86,10 @@ class GradSync(object):
             self.sizes[b] = off + p.numel()
         self.flat = {}
         self.pending = []
+        # gloo (host-staged; only ever used with GPU tensors to exercise this path on a single-GPU box) completes each
+        # bucket before the next is launched: three host-staged all-reduces in flight at once buy nothing and share
+        # torch's pinned staging buffers.  RCCL -- the production backend -- stays fully asynchronous.
+        self.serial = dist.is_initialized() and dist.get_backend(group) == 'gloo'
 
     def start(self, device=None, dtype=torch.float32):
         self.pending = []
@@ -118,6 +122,8 @@ class GradSync(object):
                     view.copy_(g)
                     grads[name] = view
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.serial:
+            work.wait()
         self.pending.append((flat, work))
 
     def finish(self):

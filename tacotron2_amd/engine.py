@@ -790,7 +790,9 @@ class Tacotron2TrainFunction(torch.autograd.Function):
         P = dict(zip(names, [p.detach() for p in params]))
         for n, p in P.items():
             if p.dtype != torch.float32:
-                raise NativeError("parameter %s is %s: this build of the engine computes in fp32" % (n, p.dtype))
+                raise NativeError("parameter %s is %s: training keeps f32 master weights (select the bf16 compute mode "
+                                  "with model.half() / hparams.fp16_run; reduced-precision parameter storage is accepted "
+                                  "by inference only)" % (n, p.dtype))
         outs, c = _forward(model, P, buffers, text, in_lens, mels, max_len, out_lens, model.training)
         # an eval-mode forward (validation, reference train.py:133) can never be differentiated: its activation
         # slabs are released right here instead of living until the outputs die
@@ -905,10 +907,24 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         raise NativeError("tacotron2_amd: the engine runs on the MI355X only (got %s tensors)" % dev)
     nv.load()
     P = {k: v.detach() for k, v in P.items()}
+    precision = getattr(model, 'precision', 'fp32')
+    run = _Run(dev, precision, _weight_cache(model))
+    low = [n for n, p in P.items() if p.dtype in (torch.float16, torch.bfloat16)]
+    if low:
+        # Reduced-precision parameter STORAGE (the reference notebook's ``model.half()`` on a stock nn.Module, or
+        # ``model.to(torch.bfloat16)``, inference.ipynb cell 7): accepted for inference.  The stored values are widened
+        # once per weight version to the f32 images the kernels read (exact: every fp16 / bf16 value is an f32 value)
+        # and the matrix products run in the bf16 compute mode -- there is no more precision in such weights to keep.
+        if len(low) != len(P):
+            raise NativeError("parameters mix reduced-precision and f32 storage (%s is %s): cast the whole model"
+                              % (low[0], P[low[0]].dtype))
+        P = {n: run.cached('widen.' + n, [p], lambda p=p: p.float()) for n, p in P.items()}
+        bufs = {k: (v.float() if v.is_floating_point() and v.dtype != torch.float32 else v) for k, v in bufs.items()}
+        if precision != 'bf16':
+            run = _Run(dev, 'bf16', _weight_cache(model))
     for n, p in P.items():
         if p.dtype != torch.float32:
-            raise NativeError("parameter %s is %s: this build of the engine computes in fp32" % (n, p.dtype))
-    run = _Run(dev, getattr(model, 'precision', 'fp32'), _weight_cache(model))
+            raise NativeError("parameter %s is %s: the engine reads f32, fp16 or bf16 parameters" % (n, p.dtype))
     ms = MaskSource(model.dropout_masks, dev)
     B, Ti = text.shape
     E = hp.encoder_embedding_dim

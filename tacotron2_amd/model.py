@@ -207,6 +207,9 @@ class Tacotron2(nn.Module):
         self.last_inference_lengths = lengths
         if hit_max:
             print("Warning! Reached max decoder steps")
-        if self._output_dtype is not None:
-            outs = [o.to(self._output_dtype) for o in outs]
+        out_dtype = self._output_dtype
+        if out_dtype is None and self.embedding.weight.dtype in (torch.float16, torch.bfloat16):
+            out_dtype = self.embedding.weight.dtype      # parameters stored in reduced precision (model.to(dtype))
+        if out_dtype is not None:
+            outs = [o.to(out_dtype) for o in outs]
         return outs

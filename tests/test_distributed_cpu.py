@@ -5,7 +5,7 @@
     are views into the flat bucket buffers;
   * the same through GradSync.out(): the engine's kernels write into the buckets directly;
   * apply_gradient_allreduce: state broadcast from rank 0; modules other than Tacotron2 are refused.
-  (N ranks x B == mean of the single-rank gradients with the REAL engine: tests/test_zz6_dp_gpu.py.)
+  (N ranks x B == mean of the single-rank gradients with the REAL engine: tests/test_zz9_dp_gpu.py.)
 """
 import os
 import socket

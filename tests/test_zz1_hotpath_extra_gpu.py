@@ -45,3 +45,48 @@ def test_other_dropout_rates_match_oracle(native_lib):
     import test_parity_gpu as tp
     tp.test_edge_shapes_match_oracle(native_lib, gu.TINY_HP + ",p_attention_dropout=0.3,p_decoder_dropout=0.2",
                                      [9, 9, 3], [14, 6, 21], 1e-3)
+
+
+def test_reduced_precision_parameter_storage_in_inference(native_lib):
+    """``model.to(torch.bfloat16)`` / ``.to(torch.float16)`` (what the reference notebook's ``.half()`` does to a stock
+    nn.Module, inference.ipynb cell 7): inference accepts the stored values (widened exactly to f32 once per weight
+    version), computes in the bf16 mode and returns tensors of the storage dtype.  Against the same weights held as f32
+    (after the same rounding) in the bf16 compute mode the outputs agree to the rounding of the output cast."""
+    import torch
+    from tacotron2_amd.hparams import create_hparams
+    from tacotron2_amd.model import Tacotron2
+    dev = torch.device("cuda", 0)
+    hp = create_hparams("max_decoder_steps=24")
+    hp.gate_threshold = 2.0
+    text = torch.randint(1, 148, (1, 40), generator=torch.Generator().manual_seed(3)).to(dev)
+    for dt in (torch.bfloat16, torch.float16):
+        torch.manual_seed(11)
+        ref = Tacotron2(hp).to(dev).eval()
+        with torch.no_grad():
+            for p in ref.parameters():
+                p.copy_(p.to(dt).float())                        # the values the reduced-precision model stores
+            for b_ in ref.buffers():
+                if b_.is_floating_point():
+                    b_.copy_(b_.to(dt).float())
+        ref.precision = 'bf16'
+        torch.manual_seed(12)
+        with torch.no_grad():
+            want = ref.inference(text)
+        torch.manual_seed(11)
+        low = Tacotron2(hp).to(dev).eval().to(dt)
+        assert low.embedding.weight.dtype == dt
+        torch.manual_seed(12)
+        with torch.no_grad():
+            got = low.inference(text)
+        assert all(t.dtype == dt for t in got)
+        assert got[0].shape == want[0].shape
+        assert (got[0].float() - want[0].to(dt).float()).abs().max().item() == 0.0
+    # training keeps f32 master weights: reduced-precision storage is refused there
+    low.train()
+    import pytest as _pytest
+    from tacotron2_amd.native import NativeError
+    import golden_util as gu
+    batch = gu.make_train_batch([9, 5], [12, 8], 80, 1)
+    x, _ = low.parse_batch(batch)
+    with _pytest.raises(NativeError, match="master weights"):
+        low(x)

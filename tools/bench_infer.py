@@ -17,7 +17,10 @@ dev = torch.device("cuda")
 native.load()
 PREC = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "fp32"
 out = {"precision": PREC}
-for name, B, steps in (("config4_B1", 1, 1000), ("B16", 16, 400), ("config5_B256", 256, 400)):
+ONLY = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None      # e.g. --only config5_B256
+for name, B, steps in (("config4_B1", 1, 1000), ("B16", 16, 400), ("B64", 64, 400), ("config5_B256", 256, 400)):
+    if ONLY and name not in ONLY:
+        continue
     hp = create_hparams()
     hp.max_decoder_steps = steps
     hp.gate_threshold = 2.0
@@ -45,4 +48,4 @@ for name, B, steps in (("config4_B1", 1, 1000), ("B16", 16, 400), ("config5_B256
     out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt, "utterance_steps_per_s": B * T / dt}
     print(name, json.dumps(out[name]), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/bench_infer_%s.json" % PREC, "w"), indent=1)
+json.dump(out, open("gpurun_out/bench_infer_%s%s.json" % (PREC, "_" + "_".join(ONLY) if ONLY else ""), "w"), indent=1)
