@@ -577,6 +577,10 @@ typedef struct t2amd_dec_infer {
      * instead of being a B x 256 x 80 tiled GEMM of its own.  NULL: the unfolded form. */
     const float* Wf;
     const float* bias_f;
+    /* bf16 mode, B > 8, optional: bf16 copies of the encoder memory [B][Ti][E] and of W_q [128][Ha] for the attention
+     * kernels (they are bound by those streams); NULL: the f32 arrays are read. */
+    const void* memory16;
+    const void* Wq16;
 } t2amd_dec_infer;
 
 int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);

@@ -577,6 +577,11 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         at.ctx_out = p->hc + wr * sHC + Hd; at.ld_ctx = Hd + E;
         at.q_out = nullptr;
         if (use16) { at.ctx16_out = (void*)((unsigned short*)p->hc16 + wr * sHC + Hd); at.ld_ctx16 = Hd + E; }
+        if (use16 && p->memory16 && p->Wq16) {
+            // bf16 compute mode, B > 8: the attention kernels stream bf16 copies of the encoder memory and of W_q and use
+            // the split-bf16 location product, as the training loop does (loops.hip above)
+            at.memory16 = p->memory16; at.Wq16 = p->Wq16; at.loc_split_bf16 = 1;
+        }
         T2_PROPAGATE(t2amd_attention_step_fwd_f32(&at, stream));
 
         t2amd_lstm_step d = {};

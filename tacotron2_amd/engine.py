@@ -821,6 +821,8 @@ class Tacotron2TrainFunction(torch.autograd.Function):
 # ----------------------------------------------------------------------------
 # inference (reference model.py:517-529)
 # ----------------------------------------------------------------------------
+# T2AMD_COMPACT_BATCH=0 keeps finished utterances in the batch until the slowest one stops (A/B runs)
+COMPACT_BATCH = os.environ.get('T2AMD_COMPACT_BATCH', '1') != '0'
 # T2AMD_DECODE_PERSISTENT=0 keeps single-utterance bf16 decoding on the launch chain (A/B runs, shared GPUs)
 PERSISTENT_DECODE = os.environ.get('T2AMD_DECODE_PERSISTENT', '1') != '0'
 
@@ -1041,6 +1043,9 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
                    x_prenet16=run.empty16(B, Pd),
                    h_a16=torch.zeros(2, B, Ha, dtype=torch.bfloat16, device=dev),
                    hc16=torch.zeros(2, B, Hd + E, dtype=torch.bfloat16, device=dev))
+        if B > 8:
+            i16['memory16'] = run.cast16(memory)
+            i16['Wq16'] = run.cached('Wq16', [Wq], lambda: run.cast16(Wq))
         d.bf16 = 1
         for k_, v_ in i16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
@@ -1052,14 +1057,84 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     if B == 1 and run.bf16 and not ragged and Ha == Hd and PERSISTENT_DECODE and not nv.validate_only():
         ran_persistent = _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat,
                                             bias_a, bias_d, Wq, U, vvec, Wpg, bpg, i16, Ti)
+    # ---- the launch chain, with early-exit compaction of the batch -----------------------------------
+    # Finished utterances keep occupying every launch until the slowest one stops.  At a poll, once enough of them
+    # have finished to free a 64-row tile of the LSTM kernels (or to reach the matrix-vector kernels of B <= 8), the
+    # rows still decoding are gathered into a smaller batch -- state, encoder memory, masks -- and the loop goes on with
+    # B' rows; what a segment produced is scattered back to the utterances' own rows of the output arrays.
     t = 0
+    Bc = B                                      # rows of the current segment
+    cur = None                                  # original utterance of each row (None: identity)
+    seg_t0 = 0
+    full_PG, full_ALIGN = st['PG'], st['ALIGN']
+    final_len = torch.zeros(B, dtype=torch.int32, device=dev)
+    min_rows = getattr(model, 'compact_min_rows', None)
+
+    def close_segment(t_end):
+        """Lengths and outputs of the current segment -> the utterances' own rows."""
+        if cur is None:
+            final_len.copy_(out_lengths)
+            return
+        fin = out_lengths > 0
+        final_len[cur[fin]] = out_lengths[fin]
+        full_PG[seg_t0:t_end, cur] = st['PG'][seg_t0:t_end]
+        full_ALIGN[cur, seg_t0:t_end] = st['ALIGN'][:, seg_t0:t_end]
+
     while t < max_steps and not ran_persistent:
         n = min(poll_steps, max_steps - t)
         d.t0, d.n_steps = t, n
         nv.decoder_infer_steps(d)
         t += n
-        if int(done.item()) >= B:       # one device->host sync per poll_steps steps
+        ndone = int(done.item())                # one device->host sync per poll_steps steps
+        if ndone >= Bc:
             break
+        left = Bc - ndone
+        if min_rows is not None:
+            shrink = ndone >= min_rows
+        else:
+            shrink = (left + 63) // 64 < (Bc + 63) // 64 or (Bc > 8 and left <= 8)
+        if not (COMPACT_BATCH and ragged and t < max_steps and ndone > 0 and shrink) or nv.validate_only():
+            continue
+        close_segment(t)
+        rows = torch.nonzero(active, as_tuple=False).view(-1)              # rows still decoding
+        cur = rows if cur is None else cur[rows]
+        oldPG, oldALIGN = st['PG'], st['ALIGN']
+        for k_ in ('h_a', 'c_a', 'c_d', 'hc', 'x_prenet'):
+            st[k_] = st[k_][:, rows].contiguous()
+        st['cum'] = st['cum'][rows].contiguous()
+        st['zero_frame'] = st['zero_frame'][:left].contiguous()
+        st['gates'] = run.empty(left, 4 * max(Ha, Hd))
+        st['attn_ws'] = run.empty(nv.attn_fwd_ws_floats(left, Ti))
+        st['PG'] = run.zeros(max_steps, left, Cm + 1)
+        st['PG'][t - 1] = oldPG[t - 1][rows]                               # the frame the next prenet input comes from
+        st['ALIGN'] = run.zeros(left, max_steps, Ti)
+        st['ALIGN'][:, t - 1] = oldALIGN[rows, t - 1]                      # the previous attention weights
+        memory, pm, lens32 = memory[rows].contiguous(), pm[rows].contiguous(), lens32[rows].contiguous()
+        keep = keep[:, :, rows].contiguous()
+        out_lengths = torch.zeros(left, dtype=torch.int32, device=dev)
+        active = torch.ones(left, dtype=torch.uint8, device=dev)
+        done.zero_()
+        d.B = left
+        d.memory, d.pm, d.lens = nv.ptr(memory), nv.ptr(pm), nv.ptr(lens32, torch.int32)
+        d.keep_prenet = nv.ptr(keep, torch.uint8)
+        for k_, v_ in st.items():
+            setattr(d, k_, nv.ptr(v_))
+        d.out_lengths, d.active = nv.ptr(out_lengths, torch.int32), nv.ptr(active, torch.uint8)
+        if run.bf16:
+            i16['x_prenet16'] = i16['x_prenet16'][rows].contiguous()
+            i16['h_a16'] = i16['h_a16'][:, rows].contiguous()
+            i16['hc16'] = i16['hc16'][:, rows].contiguous()
+            if 'memory16' in i16:
+                i16['memory16'] = i16['memory16'][rows].contiguous()
+            for k_ in ('x_prenet16', 'h_a16', 'hc16', 'memory16'):
+                if k_ in i16:
+                    setattr(d, k_, nv.ptr(i16[k_], torch.bfloat16))
+        Bc, seg_t0 = left, t
+        model.last_decode_path = 'launch chain (batch compacted to %d rows at step %d)' % (left, t)
+    if not ran_persistent:
+        close_segment(min(t, max_steps))
+        out_lengths = final_len
+    st['PG'], st['ALIGN'] = full_PG, full_ALIGN
     lengths = out_lengths.to(torch.long)
     Tout = int(lengths.max().item())
     hit_max = bool((lengths >= max_steps).any().item()) and Tout >= max_steps

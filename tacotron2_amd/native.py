@@ -200,7 +200,7 @@ class DecInfer(C.Structure):
         ("done_count", C.c_void_p),
         ("bf16", C.c_int), ("Wa_cat16", C.c_void_p), ("Wd_cat16", C.c_void_p),
         ("x_prenet16", C.c_void_p), ("h_a16", C.c_void_p), ("hc16", C.c_void_p),
-        ("Wf", _f32p), ("bias_f", _f32p),
+        ("Wf", _f32p), ("bias_f", _f32p), ("memory16", C.c_void_p), ("Wq16", C.c_void_p),
     ]
 
 

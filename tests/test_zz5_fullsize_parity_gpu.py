@@ -282,3 +282,23 @@ def test_batched_inference_config5_lengths(native_lib):
         for nm in ('mel', 'mel_post', 'align'):
             assert r[nm]['mean'] < 1e-4 and r[nm]['max'] < 5e-4 * max(1.0, r[nm]['refmax']), r
         assert out[0][b, :, L:].abs().sum().item() == 0
+    # Early-exit compaction: the run above kept all 32 rows to the end (fewer than 64 finished rows never
+    # free a tile).  Forcing a compaction at every poll that saw >= 3 finished utterances must change nothing but the
+    # batch the kernels see: same stop frames, same outputs (rows are computed independently of their neighbours).
+    assert 'compacted' not in model.last_decode_path
+    for prec in ('fp32', 'bf16'):
+        model.precision = prec
+        model.compact_min_rows = None
+        ref = [o.clone() for o in model.inference(text.to(DEV), il.to(DEV))]
+        ref_len = model.last_inference_lengths.tolist()
+        model.compact_min_rows = 3
+        got2 = model.inference(text.to(DEV), il.to(DEV))
+        assert 'compacted' in model.last_decode_path, model.last_decode_path
+        assert model.last_inference_lengths.tolist() == ref_len
+        rows['compaction_' + prec] = dict(path=model.last_decode_path,
+                                          mel_max_diff=float((got2[0] - ref[0]).abs().max()),
+                                          align_max_diff=float((got2[3] - ref[3]).abs().max()))
+        _report("infer_config5", rows)
+        assert rows['compaction_' + prec]['mel_max_diff'] < 1e-5 and rows['compaction_' + prec]['align_max_diff'] < 1e-6
+    model.compact_min_rows = None
+    model.precision = 'fp32'
