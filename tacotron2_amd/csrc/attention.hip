@@ -557,7 +557,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // =========================================================================================
 // Backward of one attention step.
 // =========================================================================================
-struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; unsigned token; int kb1_smem_off; };
+struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; unsigned token; int kb1_smem_off; int fused_delay; };
 
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
 // Half a wave (32 lanes) per memory row, 8 rows per pass.  One L2 round trip: the memory rows of the first 64
@@ -860,18 +860,35 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dva[dt][r] = 0.f;
             dqa[dt][r] = 0.f;
         }
+    bool poison = false;
     if constexpr (FUSED) {
         kb1_phase<M16>(p, smem + p.kb1_smem_off, ds, b, ts_on);
-        // hand-off (write-through form): K_b1's outputs were stored with device-scope (sc1, write-through) stores; the
-        // barrier's s_waitcnt vmcnt(0) means every wave's stores have been acknowledged, then thread 0 publishes the
+        // hand-off (write-through form): K_b1's outputs were stored with device-scope (sc1, write-through) stores; every
+        // wave waits for their acknowledgement (explicit s_waitcnt vmcnt(0) below), then thread 0 publishes the
         // launch token; consumers poll it and read the payload with device-scope loads -- no L2 write-back /
         // invalidate (an acquire/release pair at agent scope cost ~7 us per hand-off here)
+        // EVERY storing wave drains its write-through stores before the barrier (cdna_hip_programming.md Guideline 16 R1,
+        // pitfall 14): __syncthreads() on gfx950 waits for LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier), so without
+        // this the token below could overtake another wave's dw stores -- found in round 2 as a rare run-to-run difference
+        // of the B = 64 gradients (tests/test_parity_gpu.py::test_full_size_properties), never at the B = 5 of the unit test
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* flags = reinterpret_cast<unsigned*>(a.ws + (long long)B * Ti + (long long)NTS * B) + b * NTS;
         if (tid == 0) __hip_atomic_store(flags + ds, p.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < NTS) {
-            while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.token)
+            // a short pause before the first poll: polls issued while the partners' write-through stores are still on
+            // their way only delay them (round-2 finding on the persistent decode kernel, csrc/decode_persist.hip)
+            for (int d_ = 0; d_ < p.fused_delay; ++d_) __builtin_amdgcn_s_sleep(1);
+            // Bounded: the four workgroups of an utterance are consecutive in dispatch order, so a partner is always
+            // resident or next in line -- but HIP promises no dispatch order.  After 50 ms of the 100 MHz wall clock the
+            // wait is abandoned and this workgroup's dq is poisoned with NaN: every gradient of the step turns non-finite,
+            // which the training loop's finite-norm check reports and skips (train.py), instead of a hung GPU.
+            const long long t0_ = wall_clock64();
+            unsigned spins_ = 0;
+            while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.token) {
                 __builtin_amdgcn_s_sleep(1);
+                if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { poison = true; break; }
+            }
         }
         __syncthreads();
         const float* sd = a.ws + (long long)B * Ti;
@@ -1036,6 +1053,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dqs += red_s[(w * 2 + 1) * DSL + tid];
         }
         a.dv_acc[(long long)b * AD + dbase + tid] = dv_old + dvs;
+        if (FUSED && __any(poison)) dqs = __builtin_nanf("");       // abandoned hand-off (see above): poison the step
         dq_s[tid] = dqs;
         a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
     }
@@ -1195,10 +1213,15 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         g_attn_bwd_lds = (int)lds2;
     }
     T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && a->E % 8 == 0), "attn_bwd: memory16 must be 16-byte aligned, E a multiple of 8");
-    // Opt-in (T2AMD_ATTN_FUSED_BWD=1): measured 71.6 vs 72.1 ms per training step (0.7 %) -- the hand-off (write-through
-    // stores, token, device-scope polls and payload loads across XCDs) costs almost what the second launch did, so the
-    // default stays two launches and no workgroup ever waits for another.
-    static const bool fused = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return e && e[0] == '1'; }();
+    // One launch (default since round 2; T2AMD_ATTN_FUSED_BWD=0 restores the two launches): K_b1 runs as the first phase
+    // of K_b2's launch and the four workgroups of an utterance hand their dw slices to each other through memory
+    // (write-through stores drained by every wave, a per-launch token, a short pause (T2AMD_ATTN_FUSED_DELAY, s_sleep
+    // units, default 16), then polls).  Round 1 measured 71.6 vs 72.1 ms per training step -- with a hand-off that did not
+    // drain the stores before the token and was therefore racy; with the drain round 2 measures 71.5 vs 72.1 ms over 16
+    // steps, twice (profiles/r02_i_fused_bwd_after_fix.txt).  Bit-identical to the two-launch path (tests).
+    static const bool fused = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+    static const int fused_delay = [] { const char* e = getenv("T2AMD_ATTN_FUSED_DELAY"); const int v = e ? atoi(e) : 16; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
+    p.fused_delay = fused_delay;
     if (fused && lds1 + lds2 <= 160 * 1024) {
         static unsigned token = 0;
         if (++token == 0) ++token;
@@ -1211,8 +1234,10 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
             (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             g_attn_bwd_lds_fused = (int)ldsf;
         }
+        t2amd_profile_mark_(4, 0, s);
         if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
         else T2_LAUNCH((attn_bwd_main_kernel<true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
