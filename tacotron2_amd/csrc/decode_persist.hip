@@ -40,7 +40,7 @@
 #define PB_MAXEPW 4                      // context channels per workgroup
 #define PB_MAXQ 64                       // H / 16 W_q elements per energy thread
 #define PB_HALO 15
-#define PB_TIMEOUT_TICKS 3000000ll       // 30 ms of the 100 MHz wall clock per wait
+#define PB_TIMEOUT_TICKS 3000000ll       // 30 ms of the 100 MHz wall clock per wait (default; PersistParams.timeout_ticks)
 
 typedef unsigned long long pb_u64;
 
@@ -51,6 +51,7 @@ struct PersistParams {
     // polls of the singly-polled ones: the 256 CUs would otherwise hammer a mailbox's few cache lines while the stores
     // into them are still on their way (measured: 16 units before the p2 sweep alone took 17.3 -> 15.2 us off a step)
     int delay[6], poll_sleep;
+    long long timeout_ticks;      // bounded spins: ticks of the 100 MHz wall clock per wait
 };
 
 // element k of a vector staged for the LSTM dot products: units of 8 consecutive k are split into two float4 halves
@@ -64,8 +65,8 @@ __device__ __forceinline__ void pb_publish(pb_u64* g, unsigned tag, float v) {
 
 // Bounded spins: true when this wave must stop waiting -- its own 30 ms ran out (it then records the timeout) or any
 // workgroup has already given up.  The decision is wave-uniform.
-__device__ __forceinline__ bool pb_give_up(long long t0, int* status) {
-    const bool late = wall_clock64() - t0 > PB_TIMEOUT_TICKS;
+__device__ __forceinline__ bool pb_give_up(long long t0, int* status, long long limit) {
+    const bool late = (long long)wall_clock64() - t0 > limit;
     const bool other = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (!__any(late || other)) return false;
     if (late && !other && (threadIdx.x & 63) == 0) atomicCAS(status, 0, T2AMD_PERSIST_TIMEOUT);
@@ -80,7 +81,7 @@ __device__ __forceinline__ bool pb_give_up(long long t0, int* status) {
 // was slower, 18.0 vs 16.4 us per step: six granules per polling thread instead of four cost more than the stores did.)
 template <bool SPLIT, int NPT, bool DBL>
 __device__ __forceinline__ bool pb_sweep(const pb_u64* __restrict__ g, int n, unsigned tag, float* __restrict__ dst, int len,
-                                         int* status, int tid, int poll_sleep) {
+                                         int* status, int tid, int poll_sleep, long long timeout) {
     // DBL: two polls in flight -- while poll A's loads are checked, poll B's are already on their way, so a publication is
     // seen half a round trip earlier.  Measured: pays for the 256-granule edges (p1: 2.4 -> 1.0 us), costs on the 1024-
     // granule ones (h_a, h_d, ctx: the doubled poll traffic of 256 CUs slows every round trip), so those poll singly.
@@ -116,7 +117,7 @@ __device__ __forceinline__ bool pb_sweep(const pb_u64* __restrict__ g, int n, un
             for (int d_ = 0; d_ < poll_sleep; ++d_) __builtin_amdgcn_s_sleep(1);
             PB_POLL(xa)
         }
-        if ((++spins & 31u) == 0 && pb_give_up(t0, status)) return true;
+        if ((++spins & 31u) == 0 && pb_give_up(t0, status, timeout)) return true;
     }
 #undef PB_POLL
 #undef PB_READY
@@ -158,6 +159,12 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     const int NF = P + C + 1;                       // rows of the folded projection: p1 rows, frame rows, gate row
     const int EPW = E / NWG;
     const int team = k % PB_TEAMS, NPG = NWG / PB_TEAMS, pgx = k / PB_TEAMS;    // attention dim team, position group
+    if (p.timeout_ticks == 1 && k == 0) {
+        // test hook (T2AMD_PB_TIMEOUT_TICKS=1): workgroup 0 behaves like a workgroup that never became resident -- it
+        // records the timeout and leaves; every other workgroup finds `status` set in its first long wait and leaves too
+        if (tid == 0) atomicCAS(a.status, 0, T2AMD_PERSIST_TIMEOUT);
+        return;
+    }
 
     // ---- LDS carve (all offsets multiples of 16 bytes) -------------------------------------------------------
     unsigned short* Wa_s = reinterpret_cast<unsigned short*>(smem_raw);            // [16][Ka] bf16
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         unsigned char keep1 = 1, keep2 = 1;
         // (1) p2(t): the prenet output for this step (published with tag t by step t-1; zeros at t = 0)
         if (t > 0) PB_DELAY(0);
-        if (t > 0) fail = pb_sweep<true, 1, true>(G_p2, P, (unsigned)t, xp2_s, P, a.status, tid, p.poll_sleep);
+        if (t > 0) fail = pb_sweep<true, 1, true>(G_p2, P, (unsigned)t, xp2_s, P, a.status, tid, p.poll_sleep, p.timeout_ticks);
         if (__syncthreads_or(fail)) break;
         PB_T(0);
 
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         PB_T(1);
         // (3) h_a(t) from every workgroup
         PB_DELAY(1);
-        fail = pb_sweep<true, 4, false>(G_ha, H, tag, xha_s, H, a.status, tid, p.poll_sleep);
+        fail = pb_sweep<true, 4, false>(G_ha, H, tag, xha_s, H, a.status, tid, p.poll_sleep, p.timeout_ticks);
         if (__syncthreads_or(fail)) break;
         PB_T(2);
         // keep-masks of the prenet outputs this workgroup will publish for step t + 1: fetched here (first use ~8 us away;
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
                     bool ok;
                     PB_READY8(xa, ok)
                     if (__all(ok)) break;
-                    if ((++spins & 31u) == 0 && pb_give_up(t0, a.status)) { fail = true; break; }
+                    if ((++spins & 31u) == 0 && pb_give_up(t0, a.status, p.timeout_ticks)) { fail = true; break; }
                     for (int d_ = 0; d_ < p.poll_sleep; ++d_) __builtin_amdgcn_s_sleep(1);
                     PB_POLL8(xa)
                 }
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         PB_T(6);
         // (7) ctx(t)
         PB_DELAY(3);
-        fail = pb_sweep<true, 2, false>(G_ctx, E, tag, xctx_s, E, a.status, tid, p.poll_sleep);
+        fail = pb_sweep<true, 2, false>(G_ctx, E, tag, xctx_s, E, a.status, tid, p.poll_sleep, p.timeout_ticks);
         if (__syncthreads_or(fail)) break;
         PB_T(7);
 
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
 
         // (9) h_d(t)
         PB_DELAY(4);
-        fail = pb_sweep<true, 4, false>(G_hd, H, tag, xhd_s, H, a.status, tid, p.poll_sleep);
+        fail = pb_sweep<true, 4, false>(G_hd, H, tag, xhd_s, H, a.status, tid, p.poll_sleep, p.timeout_ticks);
         if (__syncthreads_or(fail)) break;
         PB_T(10);
 
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
                 xa = __hip_atomic_load(gx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ya = __hip_atomic_load(gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((unsigned)(xb >> 32) == tag && (unsigned)(yb >> 32) == tag)) { xa = xb; ya = yb; break; }
-                if ((++spins & 31u) == 0 && pb_give_up(t0, a.status)) { fail = true; break; }
+                if ((++spins & 31u) == 0 && pb_give_up(t0, a.status, p.timeout_ticks)) { fail = true; break; }
             }
             if (!fail) {
                 if (mine) xp1_s[tid] = __uint_as_float((unsigned)xa);
@@ -671,6 +678,10 @@ extern "C" int t2amd_decoder_infer_persistent_f32(const t2amd_dec_persist* a, vo
         }
         for (int i = 0; i < 6; ++i) p.delay[i] = cfg[i];
         p.poll_sleep = cfg[6];
+        // T2AMD_PB_TIMEOUT_TICKS (tests of the give-up path only): e.g. 1 makes the first wait that has to spin give up
+        const char* te = getenv("T2AMD_PB_TIMEOUT_TICKS");
+        p.timeout_ticks = te ? atoll(te) : PB_TIMEOUT_TICKS;
+        if (p.timeout_ticks < 1) p.timeout_ticks = 1;
     }
     const long long lds = persist_lds_bytes(a, p.tip);
     hipStream_t s = (hipStream_t)stream;

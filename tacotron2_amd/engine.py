@@ -278,14 +278,29 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         pad = (k - 1) // 2
         Wp = run.cached('convfwd.%s.%d' % (prefix, i), [W], lambda W=W: run.pack_conv_fwd(W))
         y = run.empty(rows, Co)
-        _fg(run, y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
         invstd = run.empty(Co)
+        K = Ci * k
+        small = (not training) and ((rows + 127) // 128) * ((Co + 127) // 128) < 128 and K >= 1024
+        if small:
+            # Inference on a few hundred rows (one utterance): a rows x Co output is a few dozen 128-tiles on 256 CUs
+            # (120 us per layer).  The bias moves into the BatchNorm shift -- (conv + b - mean) = conv - (mean - b), exact
+            # in eval mode where mean is the running mean -- so the product has a plain epilogue and can be split along K.
+            sk = max(1, min(10, K // 256))
+            part = run.empty(sk, rows * Co)
+            nv.gemm(part[0].view(rows, Co), x, Wp, convA=(T, Ci, pad, 1), splitk=sk, partials=part, fast=run.fwdp)
+            nv.splitk_reduce(part, sk, y)
+        else:
+            _fg(run, y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
         if training:
             mean = run.empty(Co)
             nv.bn_stats(y, run.ws(Co), mean, invstd, rm, rv, BN_MOMENTUM, BN_EPS)
             bufs['%s.%d.1.num_batches_tracked' % (prefix, i)].add_(1)
         else:
             mean = rm
+            if small:
+                negb = run.cached('negbias.%s.%d' % (prefix, i), [bias], lambda bias=bias: bias.neg())
+                mean = run.empty(Co)
+                nv.copy2d(mean.view(1, Co), rm.view(1, Co), negb.view(1, Co))       # running mean - conv bias
             nv.bn_eval_invstd(rv, invstd, BN_EPS)
         z = run.empty(rows, Co)
         keep = masks[i] if masks is not None else None

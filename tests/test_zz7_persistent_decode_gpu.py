@@ -108,3 +108,26 @@ def test_persistent_real_gate_stop(native_lib):
     assert plen == clen == best[1], (plen, clen, best)
     assert pout[0].shape == cout[0].shape
     assert (pout[0] - cout[0]).abs().mean().item() < 1e-4
+
+
+def test_persistent_gives_up_and_the_launch_chain_takes_over(native_lib, capsys, monkeypatch):
+    """A workgroup that never arrives (shared GPU, fewer than H/4 free CUs): every spin is bounded, the kernel reports
+    T2AMD_PERSIST_TIMEOUT, and Tacotron2.inference decodes the utterance on the launch chain -- same result as asking for
+    the chain directly, with a line on stderr; nothing hangs."""
+    hp = gu.make_hparams("max_decoder_steps=32")
+    hp.gate_threshold = 2.0
+    sd = gu.build_state_dict(hp, 321, perturb_bn=True)
+    text = gu.make_text([40], 56)
+    keep = orc.draw_masks_infer(hp, 1, 32, torch.Generator().manual_seed(5))
+    model = _model(hp, sd)
+    cout, clen, cpath = _run(model, text, keep, False)
+    monkeypatch.setenv("T2AMD_PB_TIMEOUT_TICKS", "1")
+    pout, plen, ppath = _run(model, text, keep, True)
+    monkeypatch.delenv("T2AMD_PB_TIMEOUT_TICKS")
+    assert ppath == 'launch chain (persistent kernel timed out)', ppath
+    assert "gave up" in capsys.readouterr().err
+    assert plen == clen
+    for a, b in zip(pout, cout):
+        assert torch.equal(a, b)
+    gout, glen, gpath = _run(model, text, keep, True)              # and the next call runs persistently again
+    assert gpath == 'persistent' and glen == clen
