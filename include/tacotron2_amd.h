@@ -272,6 +272,15 @@ typedef struct t2amd_skinny_gemm {
     float keep_scale;
     void* Y16;                /* optional bf16 copy of Y (first split only), row stride ldy16 */
     long long ldy16;
+    /* optional stop test of free-running decoding (reference model.py:439-444; nsplit must be 1), run by the thread that
+     * holds the final value of column stop_col (the gate logit) of a row with stop_active[row] != 0:
+     * sigmoid(Y) > stop_threshold (strict) or stop_t + 1 >= stop_max_steps  ->  stop_lengths[row] = stop_t + 1,
+     * stop_active[row] = 0, ++*stop_done.  stop_active == NULL: no test. */
+    uint8_t* stop_active;
+    int* stop_lengths;
+    int* stop_done;
+    int stop_col, stop_t, stop_max_steps;
+    float stop_threshold;
 } t2amd_skinny_gemm;
 
 int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream);
@@ -581,6 +590,14 @@ typedef struct t2amd_dec_infer {
      * kernels (they are bound by those streams); NULL: the f32 arrays are read. */
     const void* memory16;
     const void* Wq16;
+    /* bf16 mode, B > 8, optional (all four or none): bf16 copies of Wf [P][Hd+E], Wpg [C+1][Hd+E] and W2 [P][P] and a
+     * [B][P] bf16 buffer for prenet layer 0's output -- the per-step prenet and frame/gate projection then run on the
+     * bf16 MFMA path from the bf16 state copies the LSTM / attention kernels already write (f32 accumulation, f32
+     * outputs; as the training loop's bf16 mode computes them) */
+    const void* Wf16;
+    const void* Wpg16;
+    const void* W2_16;
+    void* x_prenet1_16;
 } t2amd_dec_infer;
 
 int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);

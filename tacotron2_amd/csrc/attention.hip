@@ -207,7 +207,11 @@ static int attn_dbg_stage() {
 // K_e: partial energies over 32 attention dims
 // ---------------------------------------------------------------------------------------
 #define KE_NT 512
-__global__ __launch_bounds__(KE_NT) void attn_energy_kernel(AttnFwdParams p) {
+// MINW = waves per SIMD the register allocation must leave room for: 2 (one workgroup per CU, every load of the prologue
+// in flight at once -- the latency-bound training / small-batch shape, <= 256 workgroups in a launch) or 4 (two resident
+// workgroups per CU for launches of several rounds of workgroups: batched inference at B = 256 is 1024 of them).
+template <int MINW>
+__global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     const t2amd_attn_fwd& a = p.a;
@@ -547,7 +551,10 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     T2_REQUIRE(parts >= 1, "attn_fwd: E too large");
     const size_t lds_c = sizeof(float) * ((size_t)((a->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
     T2_REQUIRE(lds_e <= 64 * 1024 && lds_c <= 64 * 1024, "attn_fwd: Ti too large for the LDS windows");
-    T2_LAUNCH(attn_energy_kernel, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    static const int ke_occ = [] { const char* e = getenv("T2AMD_KE_OCC"); return e ? atoi(e) : -1; }();   // A/B runs only
+    const bool dense = ke_occ < 0 ? (long long)NSL * a->B > 512 : ke_occ != 0;
+    if (dense) T2_LAUNCH(attn_energy_kernel<4>, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    else T2_LAUNCH(attn_energy_kernel<2>, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
     if (a->memory16) T2_LAUNCH(attn_context_kernel<true>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     else T2_LAUNCH(attn_context_kernel<false>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     T2_LAUNCH_CHECK();

@@ -460,22 +460,9 @@ extern "C" int t2amd_lstm_seq_bwd_f32(const t2amd_lstm_seq* p, void* stream) {
 // ---------------------------------------------------------------------------------------
 // Free-running decoder (reference model.py:418-454)
 // ---------------------------------------------------------------------------------------
-// stop test after the frame is emitted: sigmoid(gate) > threshold (strict); the stopping frame
-// is part of the output (reference model.py:439-444).  One thread per utterance.
-__global__ void infer_finish_step_kernel(const float* __restrict__ pg_t, int B, int C, int t, int max_steps,
-                                         float thr, int* __restrict__ out_lengths, uint8_t* __restrict__ active,
-                                         int* __restrict__ done_count) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B || !active[b]) return;
-    const float g = pg_t[(long long)b * (C + 1) + C];
-    const float sg = 1.0f / (1.0f + expf(-g));
-    if (sg > thr || t + 1 >= max_steps) {
-        out_lengths[b] = t + 1;
-        active[b] = 0;
-        atomicAdd(done_count, 1);
-    }
-}
-
+// Stop test after the frame is emitted -- sigmoid(gate) > threshold (strict), the stopping frame is part of the output
+// (reference model.py:439-444) -- runs inside the projection launch: t2amd_proj_finish_small_ (gemv.hip) at B <= 8, the
+// stop-test epilogue of the skinny GEMM (rnn.hip, t2amd_skinny_gemm.stop_*) above that.
 extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream) {
     T2_REQUIRE(p != nullptr, "dec_infer: null args");
     const int B = p->B, Ti = p->Ti, E = p->E, Ha = p->Ha, Hd = p->Hd, P = p->P, C = p->C;
@@ -508,6 +495,8 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         const bool small = B <= 8;        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
         const bool use16 = !small && p->bf16 != 0;
         const bool small16 = small && p->bf16 != 0 && p->Wa_cat16 && p->Wd_cat16;     // bf16 weight rows, f32 inputs
+        // bf16 mode, B > 8: prenet and frame/gate projection on the bf16 MFMA path too (t2amd_dec_infer.Wf16 ...)
+        const bool lin16 = use16 && p->Wf && p->Wf16 && p->Wpg16 && p->W2_16 && p->x_prenet1_16;
         t2amd_gemm_desc g2 = {};
         g2.A = p->x_prenet; g2.lda = P; g2.B = p->W2; g2.ldb = P; g2.C = p->x_prenet + sP; g2.ldc = P;
         g2.M = B; g2.N = P; g2.K = P; g2.a_kcontig = 1; g2.b_kcontig = 1; g2.batch = 1; g2.splitk = 1;
@@ -530,7 +519,10 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             // a B x 256 output: 25 us at B = 256).  Layer 2 and the projection below are B x N outputs over a long K: a
             // full LDS-DMA pipeline per 16 columns on the skinny kernel.
             if (!p->Wf) T2_PROPAGATE(t2amd_gemm_f32(&g1, stream));
-            else if (t == 0) T2_PROPAGATE(t2amd_fill_f32(p->x_prenet, sP, 0.f, stream));
+            else if (t == 0) {
+                T2_PROPAGATE(t2amd_fill_f32(p->x_prenet, sP, 0.f, stream));
+                if (lin16) T2_PROPAGATE(t2amd_fill_f32((float*)p->x_prenet1_16, sP / 2, 0.f, stream));   // bf16 zeros (P is even)
+            }
             t2amd_skinny_gemm s2 = {};
             s2.nseg = 1;
             s2.x[0] = seg(p->x_prenet, P, P);
@@ -538,6 +530,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             s2.Y = p->x_prenet + sP; s2.ldy = P; s2.nsplit = 1;
             s2.act = 1; s2.keep = g2.keep; s2.ld_keep = P; s2.keep_scale = two;
             if (use16) { s2.Y16 = p->x_prenet16; s2.ldy16 = P; }
+            if (lin16) { s2.x[0].p = (const float*)p->x_prenet1_16; s2.W = (const float*)p->W2_16; s2.bf16 = 1; }
             T2_PROPAGATE(t2amd_skinny_gemm_f32(&s2, stream));
         }
 
@@ -628,6 +621,11 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             sp.W = p->Wpg; sp.Ktot = Hd + E; sp.N = C + 1; sp.B = B;
             sp.Y = p->PG + (long long)t * sPG; sp.ldy = C + 1; sp.nsplit = 1;
             sp.bias = p->bias_pg;
+            // the stop test runs in this launch: the thread that finishes a row's gate logit applies it
+            sp.stop_active = p->active; sp.stop_lengths = p->out_lengths; sp.stop_done = p->done_count;
+            sp.stop_col = C; sp.stop_t = t; sp.stop_max_steps = p->max_steps; sp.stop_threshold = p->gate_threshold;
+            const unsigned short* hc16_wr = (const unsigned short*)p->hc16 + wr * sHC;
+            if (lin16) { sp.x[0].p = (const float*)hc16_wr; sp.W = (const float*)p->Wpg16; sp.bf16 = 1; }
             if (p->Wf && t + 1 < p->max_steps) {
                 // second problem of the same launch: prenet layer 1 of step t + 1 through the folded matrix
                 t2amd_skinny_gemm s1 = {};
@@ -637,15 +635,15 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
                 s1.Y = p->x_prenet; s1.ldy = P; s1.nsplit = 1;
                 s1.bias = p->bias_f; s1.act = 1;
                 s1.keep = p->keep_prenet + ((long long)(t + 1) * 2 + 0) * sP; s1.ld_keep = P; s1.keep_scale = two;
+                if (lin16) {
+                    s1.x[0].p = (const float*)hc16_wr; s1.W = (const float*)p->Wf16; s1.bf16 = 1;
+                    s1.Y16 = p->x_prenet1_16; s1.ldy16 = P;
+                }
                 T2_PROPAGATE(t2amd_skinny_gemm2_f32(&sp, &s1, stream));
             } else {
                 T2_PROPAGATE(t2amd_skinny_gemm_f32(&sp, stream));
             }
         }
-
-        T2_LAUNCH(infer_finish_step_kernel, dim3(t2_cdiv(B, 64)), dim3(64), 0, s, p->PG + (long long)t * sPG, B,
-                           C, t, p->max_steps, p->gate_threshold, p->out_lengths, p->active, p->done_count);
-        T2_LAUNCH_CHECK();
     }
     return T2AMD_OK;
 }

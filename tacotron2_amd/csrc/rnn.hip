@@ -49,6 +49,8 @@ struct SkinnyParams {
     // plain epilogue
     float* Y; long long ldy; int nsplit; long long split_stride; int ktiles_per_split;
     int act;          // plain epilogue: 1 = relu (bias / keep / keep_scale above are shared with the LSTM epilogue)
+    uint8_t* stop_active; int* stop_lengths; int* stop_done;     // plain epilogue: decode stop test (t2amd_skinny_gemm)
+    int stop_col, stop_max_steps; float stop_thr;                // (the step is `t` above)
     int gx, gy, gz;   // logical grid of this problem
 };
 
@@ -73,9 +75,22 @@ __device__ __forceinline__ SkinnyParams skinny_select(const SkinnyDual& dp, bool
     SK_SEL(gates_out); SK_SEL(ld_gates); SK_SEL(c_out); SK_SEL(ld_c); SK_SEL(h_out); SK_SEL(ld_h);
     SK_SEL(h16_out); SK_SEL(ld_h16); SK_SEL(keep); SK_SEL(ld_keep); SK_SEL(keep_scale); SK_SEL(lens); SK_SEL(t);
     SK_SEL(Y); SK_SEL(ldy); SK_SEL(nsplit); SK_SEL(split_stride); SK_SEL(ktiles_per_split); SK_SEL(act);
+    SK_SEL(stop_active); SK_SEL(stop_lengths); SK_SEL(stop_done); SK_SEL(stop_col); SK_SEL(stop_max_steps); SK_SEL(stop_thr);
     SK_SEL(gx); SK_SEL(gy); SK_SEL(gz);
 #undef SK_SEL
     return p;
+}
+
+// Stop test of free-running decoding on a finished gate logit (reference model.py:439-444: strict >, the stopping frame is
+// part of the output).  Same arithmetic as infer_finish_step_kernel (loops.hip), which it replaces at B > 8.
+__device__ __forceinline__ void skinny_stop_test(const SkinnyParams& p, int row, float logit) {
+    if (!p.stop_active[row]) return;
+    const float sg = 1.0f / (1.0f + expf(-logit));
+    if (sg > p.stop_thr || p.t + 1 >= p.stop_max_steps) {
+        p.stop_lengths[row] = p.t + 1;
+        p.stop_active[row] = 0;
+        atomicAdd(p.stop_done, 1);
+    }
 }
 
 #define SK_DEPTH 4    // register ring: tiles kt+1 .. kt+3 are in flight from HBM/L2 while tile kt is multiplied
@@ -368,6 +383,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
                 if (p.keep) v = p.keep[(long long)gr * p.ld_keep + gn] ? v * p.keep_scale : 0.f;
                 Y[(long long)gr * p.ldy + gn] = v;
                 if (p.h16_out) p.h16_out[(long long)gr * p.ld_h16 + gn] = t2_f32_to_bf16(v);
+                if (p.stop_active && gn == p.stop_col) skinny_stop_test(p, gr, v);
             }
         }
         return;
@@ -692,6 +708,7 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
                 if (p.keep) o = p.keep[(long long)gr * p.ld_keep + gn] ? o * p.keep_scale : 0.f;
                 Y[gn] = o;
                 if (p.h16_out) p.h16_out[(long long)gr * p.ld_h16 + gn] = t2_f32_to_bf16(o);
+                if (p.stop_active && gn == p.stop_col) skinny_stop_test(p, gr, o);
             }
         }
         SW_TS(5);
@@ -836,6 +853,10 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     p.bias = a->bias; p.act = a->act; p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     T2_REQUIRE(!a->Y16 || a->nsplit == 1, "skinny_gemm: the bf16 copy of Y needs nsplit == 1");
     p.h16_out = (unsigned short*)a->Y16; p.ld_h16 = a->ldy16;       // plain epilogue: bf16 copy of Y
+    T2_REQUIRE(!a->stop_active || (a->nsplit == 1 && a->stop_lengths && a->stop_done && a->stop_col >= 0 && a->stop_col < a->N),
+               "skinny_gemm: the stop test needs nsplit == 1, its three arrays and a column of Y");
+    p.stop_active = a->stop_active; p.stop_lengths = a->stop_lengths; p.stop_done = a->stop_done;
+    p.stop_col = a->stop_col; p.stop_max_steps = a->stop_max_steps; p.stop_thr = a->stop_threshold; p.t = a->stop_t;
     const int ktiles = a->Ktot / (a->bf16 ? 128 : 64);
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     p.gx = t2_cdiv(a->N, 16); p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = a->nsplit;

@@ -26,10 +26,13 @@ def check_hparams(hp):
     """Geometry the kernels are compiled / tiled for.  Anything else fails loudly."""
     if hp.n_frames_per_step != 1:
         raise ValueError("n_frames_per_step != 1 is not supported (nor by the reference, hparams.py:56)")
-    if hp.attention_dim != nv.ATT_DIM or hp.attention_location_n_filters != nv.LOC_FILTERS \
-            or hp.attention_location_kernel_size != nv.LOC_KERNEL:
-        raise ValueError("the attention kernels are built for attention_dim=128, 32 location filters, "
-                         "kernel 31 (reference defaults)")
+    K = hp.attention_location_kernel_size
+    if not (1 <= hp.attention_dim <= nv.ATT_DIM and 1 <= hp.attention_location_n_filters <= nv.LOC_FILTERS
+            and 1 <= K <= nv.LOC_KERNEL and K % 2 == 1):
+        raise ValueError("the attention kernels hold attention_dim <= %d, <= %d location filters and an odd location "
+                         "kernel <= %d (smaller geometries run zero-embedded in the compiled one; an even kernel size "
+                         "does not run in the reference either: ConvNorm pads (k-1)//2, model.py:18-20)"
+                         % (nv.ATT_DIM, nv.LOC_FILTERS, nv.LOC_KERNEL))
     for name in ('encoder_embedding_dim', 'attention_rnn_dim', 'decoder_rnn_dim', 'prenet_dim'):
         if getattr(hp, name) % 64 != 0:
             raise ValueError("%s must be a multiple of 64 for the MFMA recurrent kernels" % name)
@@ -367,6 +370,48 @@ def _cached_bias_sum(run, tag, b1, b2):
     return run.cached(tag, [b1, b2], lambda: _bias_sum(run, b1, b2))
 
 
+_ATT_Q = 'decoder.attention_layer.query_layer.linear_layer.weight'
+_ATT_M = 'decoder.attention_layer.memory_layer.linear_layer.weight'
+_ATT_V = 'decoder.attention_layer.v.linear_layer.weight'
+_ATT_D = 'decoder.attention_layer.location_layer.location_dense.linear_layer.weight'
+_ATT_C = 'decoder.attention_layer.location_layer.location_conv.conv.weight'
+
+
+def _embed_attention(run, P):
+    """The attention kernels are compiled for attention_dim 128, 32 location filters, 31 taps (hparams.py:65-70
+    defaults).  A smaller geometry is the same arithmetic with zeros in the missing rows / filters / outer taps --
+    a zero row of the query, memory and location weights gives tanh(0) = 0 under a zero entry of v, a zero tap
+    multiplies the same zero padding the shorter kernel would never have read -- so its five weights are embedded
+    once per weight version into compiled-geometry images.  Returns (P with those five entries replaced, their names)
+    or (P, ()) for the default geometry."""
+    Wq, Wm, Wv, Wd, Wc = (P[n] for n in (_ATT_Q, _ATT_M, _ATT_V, _ATT_D, _ATT_C))
+    A, F, K = Wq.shape[0], Wc.shape[0], Wc.shape[2]
+    AD, FD, KD = nv.ATT_DIM, nv.LOC_FILTERS, nv.LOC_KERNEL
+    if (A, F, K) == (AD, FD, KD):
+        return P, ()
+
+    def embed():
+        o = (KD - K) // 2
+        q = run.zeros(AD, Wq.shape[1]); q[:A] = Wq
+        m = run.zeros(AD, Wm.shape[1]); m[:A] = Wm
+        v = run.zeros(1, AD); v[:, :A] = Wv
+        d = run.zeros(AD, FD); d[:A, :F] = Wd
+        c = run.zeros(FD, 2, KD); c[:F, :, o:o + K] = Wc
+        return q, m, v, d, c
+    emb = run.cached('attention.embedded', [Wq, Wm, Wv, Wd, Wc], embed)
+    P = dict(P)
+    P.update(zip((_ATT_Q, _ATT_M, _ATT_V, _ATT_D, _ATT_C), emb))
+    return P, (_ATT_Q, _ATT_M, _ATT_V, _ATT_D, _ATT_C)
+
+
+def _crop_attention_grad(name, grad, shape):
+    """The block of a compiled-geometry gradient that belongs to the model's own (smaller) weight."""
+    if name == _ATT_C:
+        o = (nv.LOC_KERNEL - shape[2]) // 2
+        return grad[:shape[0], :, o:o + shape[2]]
+    return grad[:shape[0], :shape[1]]
+
+
 def _fold_U(run, Wdense, Wconv):
     U = run.empty(nv.ATT_DIM * nv.LOC_TAPS)
     nv.fold_location(Wdense, Wconv, U)
@@ -402,6 +447,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
                           "There is no CPU path; the CPU oracle lives in oracle/ for tests." % dev)
     nv.load()
     run = _Run(dev, getattr(model, 'precision', 'fp32'), _weight_cache(model))
+    P, _ = _embed_attention(run, P)
     ms = MaskSource(model.dropout_masks, dev)
     c = _Ctx()
     B = text.shape[0]
@@ -586,6 +632,18 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         are exchanged (no packing pass before the all-reduce), a fresh buffer otherwise."""
         return sync.out(name, shape) if sync is not None else run.empty(*shape)
 
+    # a smaller attention geometry: the kernels produce compiled-geometry gradients, cropped into place further down
+    own_shape = {n: tuple(P[n].shape) for n in (_ATT_Q, _ATT_M, _ATT_V, _ATT_D, _ATT_C)}
+    P, embedded = _embed_attention(run, P)
+    if embedded:
+        G_own, staged = G, {}
+
+        def G(name, *shape):
+            if name in embedded:
+                staged[name] = run.empty(*shape)
+                return staged[name]
+            return G_own(name, *shape)
+
     # ---- output boundary -> postnet backward ----------------------------------------------
     dmel_cl = run.empty(B, To, Cm)
     dpost_cl = run.empty(B, To, Cm)
@@ -744,6 +802,10 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     _rg(run, dWmem, d_pm.view(rowsE, A), c.memory.view(rowsE, E), a_km=True, b_kn=True)
     g['decoder.attention_layer.memory_layer.linear_layer.weight'] = dWmem
 
+    if embedded:
+        for name, big in staged.items():
+            g[name] = G_own(name, *own_shape[name])
+            g[name].copy_(_crop_attention_grad(name, big, own_shape[name]))
     if sync is not None:
         sync.bucket_ready('decoder')             # travels while the encoder backward runs
     # ---- encoder backward -----------------------------------------------------------------
@@ -942,6 +1004,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     for n, p in P.items():
         if p.dtype != torch.float32:
             raise NativeError("parameter %s is %s: the engine reads f32, fp16 or bf16 parameters" % (n, p.dtype))
+    P, _ = _embed_attention(run, P)
     ms = MaskSource(model.dropout_masks, dev)
     B, Ti = text.shape
     E = hp.encoder_embedding_dim
@@ -1061,6 +1124,17 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         if B > 8:
             i16['memory16'] = run.cast16(memory)
             i16['Wq16'] = run.cached('Wq16', [Wq], lambda: run.cast16(Wq))
+            # prenet + frame/gate projection on the bf16 MFMA path as well: bf16 images of [W1.Wp ; Wp ; Wg] and of W2
+            W2_ = P['decoder.prenet.layers.1.linear_layer.weight']
+            fold_deps = [P[n_] for n_ in ('decoder.prenet.layers.0.linear_layer.weight',
+                                          'decoder.linear_projection.linear_layer.weight',
+                                          'decoder.linear_projection.linear_layer.bias',
+                                          'decoder.gate_layer.linear_layer.weight',
+                                          'decoder.gate_layer.linear_layer.bias')]
+            i16['Wf16'] = run.cached('Wf16', fold_deps, lambda: run.cast16(Wf_))
+            i16['Wpg16'] = i16['Wf16'][Pd:]
+            i16['W2_16'] = run.cached('W2_16', [W2_], lambda: run.cast16(W2_))
+            i16['x_prenet1_16'] = torch.zeros(B, Pd, dtype=torch.bfloat16, device=dev)
         d.bf16 = 1
         for k_, v_ in i16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
@@ -1137,11 +1211,13 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         d.out_lengths, d.active = nv.ptr(out_lengths, torch.int32), nv.ptr(active, torch.uint8)
         if run.bf16:
             i16['x_prenet16'] = i16['x_prenet16'][rows].contiguous()
+            if 'x_prenet1_16' in i16:
+                i16['x_prenet1_16'] = i16['x_prenet1_16'][rows].contiguous()
             i16['h_a16'] = i16['h_a16'][:, rows].contiguous()
             i16['hc16'] = i16['hc16'][:, rows].contiguous()
             if 'memory16' in i16:
                 i16['memory16'] = i16['memory16'][rows].contiguous()
-            for k_ in ('x_prenet16', 'h_a16', 'hc16', 'memory16'):
+            for k_ in ('x_prenet16', 'x_prenet1_16', 'h_a16', 'hc16', 'memory16'):
                 if k_ in i16:
                     setattr(d, k_, nv.ptr(i16[k_], torch.bfloat16))
         Bc, seg_t0 = left, t

@@ -73,6 +73,8 @@ class SkinnyGemm(C.Structure):
         ("bf16", C.c_int),
         ("bias", _f32p), ("act", C.c_int), ("keep", C.c_void_p), ("ld_keep", _i64), ("keep_scale", C.c_float),
         ("Y16", C.c_void_p), ("ldy16", _i64),
+        ("stop_active", C.c_void_p), ("stop_lengths", C.c_void_p), ("stop_done", C.c_void_p),
+        ("stop_col", C.c_int), ("stop_t", C.c_int), ("stop_max_steps", C.c_int), ("stop_threshold", C.c_float),
     ]
 
 
@@ -201,6 +203,7 @@ class DecInfer(C.Structure):
         ("bf16", C.c_int), ("Wa_cat16", C.c_void_p), ("Wd_cat16", C.c_void_p),
         ("x_prenet16", C.c_void_p), ("h_a16", C.c_void_p), ("hc16", C.c_void_p),
         ("Wf", _f32p), ("bias_f", _f32p), ("memory16", C.c_void_p), ("Wq16", C.c_void_p),
+        ("Wf16", C.c_void_p), ("Wpg16", C.c_void_p), ("W2_16", C.c_void_p), ("x_prenet1_16", C.c_void_p),
     ]
 
 

@@ -42,7 +42,10 @@ def test_state_dict_surface():
 
 def test_unsupported_geometry_fails_loudly():
     with pytest.raises(ValueError):
-        Tacotron2(create_hparams("attention_dim=64"))
+        Tacotron2(create_hparams("attention_dim=256"))                     # larger than the compiled geometry
+    with pytest.raises(ValueError):
+        Tacotron2(create_hparams("attention_location_kernel_size=30"))     # even: the reference's own padding breaks
+    Tacotron2(create_hparams("attention_dim=64,attention_location_n_filters=8,attention_location_kernel_size=3"))
     with pytest.raises(ValueError):
         Tacotron2(create_hparams("n_frames_per_step=2"))
 

@@ -148,6 +148,8 @@ def test_collate_equals_reference_on_random_ragged_batches(monkeypatch):
     (101, [9, 9, 3], [14, 6, 21], ""),                       # tie in text length, longest mel not first
     (202, [15, 2], [3, 17], ",mask_padding=False"),
     (303, [6], [9], ",p_attention_dropout=0.3,p_decoder_dropout=0.2,gate_threshold=0.4"),
+    # a smaller attention geometry (hparams.py:65-70): the engine runs it zero-embedded, tests/test_zz1 holds it to this oracle
+    (404, [11, 8, 3], [9, 16, 5], ",attention_dim=96,attention_location_n_filters=16,attention_location_kernel_size=17"),
 ])
 def test_oracle_equals_reference_live_on_more_cases(monkeypatch, seed, in_lens, out_lens, extra):
     """The oracle's pin, widened beyond the committed fixtures: the reference's model.py is run here (through the

@@ -47,6 +47,59 @@ def test_other_dropout_rates_match_oracle(native_lib):
                                      [9, 9, 3], [14, 6, 21], 1e-3)
 
 
+SMALL_ATTENTION = ",attention_dim=96,attention_location_n_filters=16,attention_location_kernel_size=17"
+
+
+def test_smaller_attention_geometry_trains_like_the_oracle(native_lib):
+    """attention_dim / attention_location_n_filters / attention_location_kernel_size below the defaults the kernels are
+    compiled for (hparams.py:65-70): the five attention weights run zero-embedded (engine._embed_attention), gradients are
+    cropped back.  Outputs, loss and all 60 gradients against the oracle (pinned for this geometry against the reference
+    in tests/test_reference_dropin_cpu.py), fp32-mode tolerances of the other edge shapes."""
+    import test_parity_gpu as tp
+    tp.test_edge_shapes_match_oracle(native_lib, gu.TINY_HP + SMALL_ATTENTION, [11, 8, 3], [9, 16, 5], 1e-3)
+    tp.test_edge_shapes_match_oracle(native_lib, SMALL_ATTENTION.lstrip(",") + ",attention_location_kernel_size=5",
+                                     [19, 2], [3, 18], 1e-3)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_smaller_attention_geometry_decodes_like_the_oracle(native_lib, precision):
+    """Same geometry through Tacotron2.inference at the default widths: B = 1 (the persistent kernel in bf16 mode, the
+    launch chain in fp32 mode) and a ragged batch of three, forced length, against the f32 oracle."""
+    from oracle import tacotron2_oracle as orc
+    from tacotron2_amd.model import Tacotron2
+    steps = 36
+    hp = gu.make_hparams(SMALL_ATTENTION.lstrip(",") + ",max_decoder_steps=%d" % steps)
+    hp.gate_threshold = 2.0
+    sd = gu.build_state_dict(hp, 77, perturb_bn=True)
+    model = Tacotron2(hp)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    model.precision = precision
+    for lens, seed in (([37], 3), ([30, 21, 13], 4)):
+        text = gu.make_text(lens, 50 + seed)
+        keep = orc.draw_masks_infer(hp, len(lens), steps, torch.Generator().manual_seed(seed))
+        model.dropout_masks = dict(prenet_infer=keep.cuda())
+        il = torch.tensor(lens) if len(lens) > 1 else None
+        with torch.no_grad():
+            out = model.inference(text.cuda(), il.cuda() if il is not None else None)
+        torch.cuda.synchronize()
+        if len(lens) == 1:
+            assert model.last_decode_path == ('persistent' if precision == 'bf16' else 'launch chain'), model.last_decode_path
+            (omel, opost, ogate, oalign), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0)
+            refs = [(omel, out[0].float().cpu()), (oalign, out[3].float().cpu())]
+        else:
+            refs = []
+            for b, n in enumerate(lens):
+                (omel, _, _, oalign), _, _ = orc.tacotron2_inference(sd, hp, text[b:b + 1, :n], keep[:, :, b:b + 1], steps, 2.0)
+                refs.append((omel[0], out[0][b].float().cpu()))
+                refs.append((oalign[0], out[3][b, :, :n].float().cpu()))
+        for ref, got in refs:
+            assert got.shape == ref.shape, (got.shape, ref.shape)
+            scale = max(float(ref.abs().mean()), 1e-3)
+            err = float((got - ref).abs().mean())
+            assert err < (2e-2 if precision == 'bf16' else 2e-5) * scale, (lens, precision, err, scale)
+
+
 def test_reduced_precision_parameter_storage_in_inference(native_lib):
     """``model.to(torch.bfloat16)`` / ``.to(torch.float16)`` (what the reference notebook's ``.half()`` does to a stock
     nn.Module, inference.ipynb cell 7): inference accepts the stored values (widened exactly to f32 once per weight
