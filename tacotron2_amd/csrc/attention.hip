@@ -372,6 +372,180 @@ __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams 
 }
 
 // ---------------------------------------------------------------------------------------
+// K_e for decode batches of more than 128 utterances (bf16 mode): FOUR utterances per workgroup, side by side.
+//
+// With one utterance per workgroup a launch at B = 256 is four workgroups per CU, each fetching the slice's 64 KB of
+// bf16 W_q rows again (64 MB of the ~100 MB a step moves L2 -> CU) and each paying its own load -> dot -> barrier ->
+// tiles latency chain.  Here the W_q rows are fetched once per four utterances and stay in registers for four dot
+// products, the four query vectors / window pairs / lengths sit side by side in LDS, and the 8 waves share the
+// 4 x ceil(Ti/16) position tiles: one latency chain, one round of B/4 x 4 workgroups.  (Walking the four utterances one
+// after the other inside a workgroup measured slower than the one-utterance form: four chains in sequence.)
+// Per-thread arithmetic of q and of every energy is that of attn_energy_kernel: results are bit-identical.
+// ---------------------------------------------------------------------------------------
+#define KE4_U 4
+// PF = tiles per wave whose processed-memory rows are prefetched with the prologue, ahead of the W_q / h stream; the rest
+// are fetched on demand.  Measured at B = 256, Ti = 187 (6 tiles per wave): PF = 2 15.4 us, PF = 2 issued after the W_q / h
+// stream 15.8 us, PF = 6 17.9 us -- more rows in flight only delay the q phase (the wait counter is in-order).
+#define KE4_PF 2
+__global__ __launch_bounds__(KE_NT) void attn_energy4_kernel(AttnFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const t2amd_attn_fwd& a = p.a;
+    const int ds = blockIdx.x, b0 = blockIdx.y * KE4_U;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int Ti = a.Ti, Hq = a.Hq, TIP = p.tip, B = a.B;
+    float* win_s = smem;                         // [U][2][TIP]
+    float* q_s = win_s + KE4_U * 2 * TIP;        // [U][32]
+    float* u_s = q_s + KE4_U * DSL;              // [32][62]
+    float* h_s = u_s + DSL * NTAP;               // [U][Hq]
+    int* len_s = reinterpret_cast<int*>(h_s + KE4_U * Hq);   // [U] (0: absent or finished utterance)
+    const int NMT = (Ti + 15) >> 4;              // position tiles per utterance (padded length)
+
+    // ---- prologue: every load issued before the first one is consumed; nothing is compared on a loaded value before
+    // the last load has been issued (a comparison on a fresh load is waited for on the spot) ----
+    int bc[KE4_U], len_raw[KE4_U], act_raw[KE4_U];
+#pragma unroll
+    for (int u = 0; u < KE4_U; ++u) {
+        const int bu = b0 + u;
+        bc[u] = bu < B ? bu : B - 1;             // clamped: loads stay in bounds, results of absent rows are dropped
+        act_raw[u] = a.active ? a.active[bc[u]] : 1;
+        len_raw[u] = a.lens ? a.lens[bc[u]] : Ti;
+    }
+    constexpr int PF = KE4_PF;
+    float4 pmA[PF], pmB[PF];                     // processed-memory rows of this wave's first PF tiles
+    auto issue_pm = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < PF; ++rr) {
+            int g = wv + rr * (KE_NT / 64);
+            g = g < KE4_U * NMT ? g : KE4_U * NMT - 1;
+            const int u = g / NMT, mt = g - u * NMT;
+            int pos = mt * 16 + l15;
+            pos = pos < Ti ? pos : Ti - 1;
+            const int bb = b0 + u < B ? b0 + u : B - 1;
+            const float* pr = a.pm + ((long long)bb * Ti + pos) * AD + ds * DSL + 4 * lg;
+            pmA[rr] = *reinterpret_cast<const float4*>(pr);
+            pmB[rr] = *reinterpret_cast<const float4*>(pr + 16);
+        }
+    };
+    issue_pm();
+    const float4 ureg = stage_u_issue(a.U + (long long)ds * DSL * NTAP, tid);
+    WinRegs wreg[KE4_U];
+#pragma unroll
+    for (int u = 0; u < KE4_U; ++u)
+        wreg[u] = stage_windows_issue(TIP, Ti, a.w_prev ? a.w_prev + (long long)bc[u] * a.ld_wprev : nullptr,
+                                      a.cum + (long long)bc[u] * Ti, tid);
+    float vv[2][4];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vv[dt][r] = a.v[ds * DSL + dt * 16 + 4 * lg + r];
+    // q[u][d] = W_q[d][:] . h_u: 16 threads per row, the row's bf16 units stay in registers for the four utterances
+    const int d = tid >> 4, part = tid & 15;
+    const float4* __restrict__ W16 = reinterpret_cast<const float4*>(a.Wq16) + (long long)(ds * DSL + d) * (Hq >> 3);
+    const int n8 = Hq >> 3, n4 = Hq >> 2;
+    float4 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = part + 16 * k;
+        w[k] = W16[i < n8 ? i : part];
+    }
+    float4* h_s4 = reinterpret_cast<float4*>(h_s);
+    auto h_src = [&](int j) {
+        const int u = j / n4, k = j - u * n4;
+        const int bb = b0 + u < B ? b0 + u : B - 1;
+        return reinterpret_cast<const float4*>(a.h + (long long)bb * a.ld_h) + k;
+    };
+    // the four query inputs, staged behind the W_q loads; the first two float4 per thread straight-line (a loop header
+    // makes the compiler drain every pending load), which is all of them at Hq = 1024
+    const int tot = KE4_U * n4;
+    const float4 hv0 = *h_src(tid < tot ? tid : 0);
+    const float4 hv1 = *h_src(tid + KE_NT < tot ? tid + KE_NT : 0);
+    if (tid < tot) h_s4[tid] = hv0;
+    if (tid + KE_NT < tot) h_s4[tid + KE_NT] = hv1;
+    for (int j = tid + 2 * KE_NT; j < tot; j += KE_NT) h_s4[j] = *h_src(j);
+    bool live[KE4_U];
+#pragma unroll
+    for (int u = 0; u < KE4_U; ++u) live[u] = b0 + u < B && act_raw[u] != 0;
+    if (tid < KE4_U) {
+        int lv = 0;
+#pragma unroll
+        for (int u = 0; u < KE4_U; ++u) lv = tid == u ? (live[u] ? len_raw[u] : 0) : lv;
+        len_s[tid] = lv;
+    }
+    __syncthreads();
+    float qacc[KE4_U];
+#pragma unroll
+    for (int u = 0; u < KE4_U; ++u) {
+        const float4* hu = reinterpret_cast<const float4*>(h_s + u * Hq);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = part + 16 * k;
+            if (i < n8) acc = dot8_bf16(w[k], hu[2 * i], hu[2 * i + 1], acc);
+        }
+        for (int i = part + 128; i < n8; i += 16) acc = dot8_bf16(W16[i], hu[2 * i], hu[2 * i + 1], acc);   // Hq > 1024
+        qacc[u] = acc;
+    }
+#pragma unroll
+    for (int u = 0; u < KE4_U; ++u)
+        stage_windows_finish(wreg[u], win_s + u * 2 * TIP, TIP, Ti, a.w_prev ? a.w_prev + (long long)bc[u] * a.ld_wprev : nullptr,
+                             a.cum + (long long)bc[u] * Ti, tid, KE_NT);
+    stage_u_finish(ureg, u_s, tid);
+#pragma unroll
+    for (int u = 0; u < KE4_U; ++u) {
+        const float qs = row16_sum(qacc[u]);
+        if (part == 0) {
+            q_s[u * DSL + d] = qs;
+            if (a.q_out && live[u]) a.q_out[(long long)(b0 + u) * a.ld_q + ds * DSL + d] = qs;
+        }
+    }
+    __syncthreads();
+
+    // ---- energies: the 8 waves share the U x NMT position tiles ----
+    UFrag16 uf;
+    load_u_frag16(uf, u_s, l15, lg);
+    auto tile = [&](int g, float4 pm0, float4 pm1, bool fetched) {
+        const int u = g / NMT, mt = g - u * NMT;
+        const int len = len_s[u];
+        if (mt * 16 >= len) return;                    // past the utterance (or the utterance is absent / finished)
+        const int pos = mt * 16 + l15;
+        if (!fetched) {
+            pm0 = pm1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pos < Ti) {
+                const float* pr = a.pm + ((long long)(b0 + u) * Ti + pos) * AD + ds * DSL + 4 * lg;
+                pm0 = *reinterpret_cast<const float4*>(pr);
+                pm1 = *reinterpret_cast<const float4*>(pr + 16);
+            }
+        }
+        float qv[2][4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) qv[dt][r] = q_s[u * DSL + dt * 16 + 4 * lg + r];
+        f32x4 acc0, acc1;
+        loc_tile16(uf, win_s + u * 2 * TIP, TIP, pos, lg, acc0, acc1);
+        float e = vv[0][0] * t2_tanh(acc0[0] + qv[0][0] + pm0.x);
+        e = fmaf(vv[0][1], t2_tanh(acc0[1] + qv[0][1] + pm0.y), e);
+        e = fmaf(vv[0][2], t2_tanh(acc0[2] + qv[0][2] + pm0.z), e);
+        e = fmaf(vv[0][3], t2_tanh(acc0[3] + qv[0][3] + pm0.w), e);
+        e = fmaf(vv[1][0], t2_tanh(acc1[0] + qv[1][0] + pm1.x), e);
+        e = fmaf(vv[1][1], t2_tanh(acc1[1] + qv[1][1] + pm1.y), e);
+        e = fmaf(vv[1][2], t2_tanh(acc1[2] + qv[1][2] + pm1.z), e);
+        e = fmaf(vv[1][3], t2_tanh(acc1[3] + qv[1][3] + pm1.w), e);
+        e += __shfl_xor(e, 16, 64);
+        e += __shfl_xor(e, 32, 64);
+        if (lg == 0 && pos < Ti) a.ws[((long long)ds * B + (b0 + u)) * Ti + pos] = e;
+    };
+#pragma unroll
+    for (int rr = 0; rr < PF; ++rr) {
+        const int g = wv + rr * (KE_NT / 64);
+        if (g < KE4_U * NMT) tile(g, pmA[rr], pmB[rr], true);
+    }
+    for (int g = wv + PF * (KE_NT / 64); g < KE4_U * NMT; g += KE_NT / 64)          // rows fetched on demand
+        tile(g, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), false);
+}
+
+// ---------------------------------------------------------------------------------------
 // K_c: softmax over the utterance + one quarter of the context channels
 // ---------------------------------------------------------------------------------------
 #define KC_NT 512
@@ -551,10 +725,16 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     T2_REQUIRE(parts >= 1, "attn_fwd: E too large");
     const size_t lds_c = sizeof(float) * ((size_t)((a->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
     T2_REQUIRE(lds_e <= 64 * 1024 && lds_c <= 64 * 1024, "attn_fwd: Ti too large for the LDS windows");
-    static const int ke_occ = [] { const char* e = getenv("T2AMD_KE_OCC"); return e ? atoi(e) : -1; }();   // A/B runs only
-    const bool dense = ke_occ < 0 ? (long long)NSL * a->B > 512 : ke_occ != 0;
-    if (dense) T2_LAUNCH(attn_energy_kernel<4>, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
-    else T2_LAUNCH(attn_energy_kernel<2>, dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    // T2AMD_KE_FORM (A/B runs only): 0 one utterance per workgroup, 1 the two-workgroups-per-CU register allocation of
+    // it, 2 four utterances side by side in a workgroup.  Default: 2 for B > 128 (more than two rounds of one-utterance
+    // workgroups) in the bf16 mode, 1 for B > 128 otherwise, else 0.
+    static const int ke_form = [] { const char* e = getenv("T2AMD_KE_FORM"); return e ? atoi(e) : -1; }();
+    int form = ke_form >= 0 ? ke_form : ((long long)NSL * a->B > 512 ? 2 : 0);
+    const size_t lds_e4 = sizeof(float) * (KE4_U * (2 * (size_t)p.tip + DSL + (size_t)a->Hq) + DSL * NTAP + KE4_U);
+    if (form == 2 && !(a->Wq16 && a->loc_split_bf16 && lds_e4 <= 64 * 1024)) form = 1;      // the four-utterance form is bf16-mode only
+    if (form == 2) T2_LAUNCH(attn_energy4_kernel, dim3(NSL, t2_cdiv(a->B, KE4_U)), dim3(KE_NT), lds_e4, s, p);
+    else if (form == 1) T2_LAUNCH((attn_energy_kernel<4>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    else T2_LAUNCH((attn_energy_kernel<2>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
     if (a->memory16) T2_LAUNCH(attn_context_kernel<true>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     else T2_LAUNCH(attn_context_kernel<false>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     T2_LAUNCH_CHECK();

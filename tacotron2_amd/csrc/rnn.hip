@@ -746,6 +746,289 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     SW_TS(5);
 }
 
+// ---------------------------------------------------------------------------------------
+// 64 x 64 bf16 variant of the wide kernel, LSTM form only: 64 batch rows x 16 hidden units (x 4 gates) per workgroup.
+//
+// At decode batch sizes of 256 and more the 64 x 32 kernel above is two or more rounds of workgroups (B/64 row tiles x
+// H/8 column tiles), and every round pays the fixed cost of a workgroup again (first DMA, first tile, partial-sum
+// exchange, cell: about 5 us around a 3.6 us k loop); per output it also moves a 16 KB activation tile for every 8 KB of
+// weights through the L2 -> LDS path.  Here a tile step feeds 64 gate columns: 16 KB of activations + 16 KB of weights
+// (-33 % bytes per output), four v_mfma_f32_32x32x16_bf16 per wave (same (row half) x (k quarter) wave layout, the two
+// activation fragments are multiplied by both column halves), and B = 256, H = 1024 is one round of 256 workgroups.
+// 128 KB of LDS (4-tile ring), every wave issues exactly 4 DMA instructions per tile.  Same swizzle, counted vmcnt
+// and inline-asm fragment reads as above.
+// ---------------------------------------------------------------------------------------
+#define S6_WB (64 * 256)    // bytes per weight tile
+template <int TAG>
+__global__ __launch_bounds__(512) void skinny_wide64_kernel(SkinnyDual dp) {
+    constexpr int BK = 128;
+    __shared__ __attribute__((aligned(16))) char smem6[SW_NBUF * (SW_XB + S6_WB)];
+    char* const Xs = smem6;                      // [NBUF][64][256 B]
+    char* const Ws = smem6 + SW_NBUF * SW_XB;    // [NBUF][64][256 B]
+    float* const Ps = reinterpret_cast<float*>(smem6);   // epilogue: [4][64][65] partial sums (aliases the ring)
+
+    const bool second = (int)blockIdx.x >= dp.nblk0;
+    const SkinnyParams p = skinny_select(dp, second);
+    const int lb = (int)blockIdx.x - (second ? dp.nblk0 : 0);
+    const int bx = lb % p.gx;
+    const int by = lb / p.gx;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int wi = wave & 1, wk = wave >> 1;
+    const int rowbase = by * SK_ROWS;
+    const int B = p.B;
+
+    const int n0 = p.x[0].p ? p.x[0].width / BK : 0;
+    const int n1 = (p.nseg > 1 && p.x[1].p) ? p.x[1].width / BK : 0;
+    const int n2 = (p.nseg > 2 && p.x[2].p) ? p.x[2].width / BK : 0;
+    const int wo1 = p.x[0].width, wo2 = p.x[0].width + (p.nseg > 1 ? p.x[1].width : 0);
+    const int nvt = n0 + n1 + n2;
+    const int kt_beg = 0, kt_end = nvt;
+
+    // cell operands, fetched up front: thread -> (row = tid>>3, units ejj and ejj + 8 of the workgroup's 16)
+    const int erow = tid >> 3, ejj = tid & 7;
+    const int egr = rowbase + erow;
+    float e_gin[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, e_bias[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float e_cp[2] = {0.f, 0.f};
+    int e_keep_raw[2] = {1, 1};
+    int e_len = 0x7fffffff;
+    if (egr < B) {
+        const int H = p.H;
+        const int* lens_ = p.lens;
+        const float* gin_ = p.gin;
+        const float* bias_ = p.bias;
+        const float* cprev_ = p.c_prev;
+        const uint8_t* keep_ = p.keep;
+        const long long ld_gin_ = p.ld_gin, ld_cprev_ = p.ld_cprev, ld_keep_ = p.ld_keep;
+        if (lens_) e_len = lens_[egr];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int ej = bx * 16 + ejj + 8 * u;
+            if (gin_) {
+                const float* g = gin_ + (long long)egr * ld_gin_;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e_gin[u][q] = g[q * H + ej];
+            }
+            if (bias_) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) e_bias[u][q] = bias_[q * H + ej];
+            }
+            if (cprev_) e_cp[u] = cprev_[(long long)egr * ld_cprev_ + ej];
+            if (keep_) e_keep_raw[u] = keep_[(long long)egr * ld_keep_ + ej];
+        }
+    }
+
+    // DMA sources.  X: instruction q of this wave fills tile rows 8*wave + 4q + lg, LDS chunk l15 <- global chunk
+    // l15 ^ (row & 15).  W: instruction q fills weight-tile rows (= gate columns) 32q + 4*wave + lg; tile column c is
+    // gate c >> 4 of unit bx*16 + (c & 15).
+    long long xo0[2], xo1[2], xo2[2], wo[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = 8 * wave + 4 * q + lg;
+        int gr = rowbase + r;
+        if (gr > B - 1) gr = B - 1;
+        const int c8 = 8 * (l15 ^ (r & 15));
+        xo0[q] = ((long long)gr * p.x[0].ld + c8) * 2;
+        xo1[q] = ((long long)gr * p.x[1].ld + c8) * 2;
+        xo2[q] = ((long long)gr * p.x[2].ld + c8) * 2;
+        const int c = 32 * q + 4 * wave + lg;
+        const long long wrow = (long long)(c >> 4) * p.H + bx * 16 + (c & 15);
+        wo[q] = (wrow * p.Ktot + 8 * (l15 ^ (c & 15))) * 2;
+    }
+    const char* const Wp0 = reinterpret_cast<const char*>(p.W) + wo[0];
+    const long long wdelta = wo[1] - wo[0];
+    const char* const xp0 = reinterpret_cast<const char*>(p.x[0].p);
+    const char* const xp1 = reinterpret_cast<const char*>(p.x[1].p);
+    const char* const xp2 = reinterpret_cast<const char*>(p.x[2].p);
+    const int kt_last = kt_end - 1;
+
+    const char* xq0; const char* xq1; const char* wq;
+    int iss_kt = kt_beg, iss_seg = 0, iss_rem = 0;
+#define S6_SEEK(SEG, LOCAL)                                                                            \
+    {                                                                                                  \
+        const int seg_ = (SEG), loc_ = (LOCAL);                                                        \
+        if (seg_ == 0) {                                                                               \
+            const char* sp_ = xp0 + loc_ * 256;                                                        \
+            xq0 = sp_ + xo0[0]; xq1 = sp_ + xo0[1];                                                    \
+            wq = Wp0 + loc_ * 256; iss_rem = n0 - loc_;                                                \
+        } else if (seg_ == 1) {                                                                        \
+            const char* sp_ = xp1 + loc_ * 256;                                                        \
+            xq0 = sp_ + xo1[0]; xq1 = sp_ + xo1[1];                                                    \
+            wq = Wp0 + wo1 * 2 + loc_ * 256; iss_rem = n1 - loc_;                                      \
+        } else {                                                                                       \
+            const char* sp_ = xp2 + loc_ * 256;                                                        \
+            xq0 = sp_ + xo2[0]; xq1 = sp_ + xo2[1];                                                    \
+            wq = Wp0 + wo2 * 2 + loc_ * 256; iss_rem = n2 - loc_;                                      \
+        }                                                                                              \
+        iss_seg = seg_;                                                                                \
+    }
+    xq0 = xq1 = wq = reinterpret_cast<const char*>(p.W);
+    if (kt_end > kt_beg) {
+        if (n0 > 0) S6_SEEK(0, 0)
+        else if (n1 > 0) S6_SEEK(1, 0)
+        else S6_SEEK(2, 0)
+    }
+
+#define S6_ISSUE(BUF)                                                                                  \
+    {                                                                                                  \
+        char* xd_ = Xs + (BUF) * SW_XB + wave * (8 * 256);                                             \
+        char* wd_ = Ws + (BUF) * S6_WB + wave * 1024;                                                  \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq0), (t2_lptr)(xd_), 16, 0, 0);                    \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq1), (t2_lptr)(xd_ + 1024), 16, 0, 0);             \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(wq), (t2_lptr)(wd_), 16, 0, 0);                     \
+        __builtin_amdgcn_global_load_lds((t2_gptr)(wq + wdelta), (t2_lptr)(wd_ + 32 * 256), 16, 0, 0); \
+        if (iss_kt < kt_last) {                                                                        \
+            ++iss_kt;                                                                                  \
+            if (--iss_rem > 0) {                                                                       \
+                xq0 += 256; xq1 += 256; wq += 256;                                                     \
+            } else if (iss_seg == 0 && n1 > 0) {                                                       \
+                S6_SEEK(1, 0)                                                                          \
+            } else {                                                                                   \
+                S6_SEEK(2, 0)                                                                          \
+            }                                                                                          \
+        }                                                                                              \
+    }
+
+    f32x16 acc0, acc1, acc2, acc3;      // (k chunk pair m = 0, 1) x (column half 0, 1): acc0/acc1 half 0, acc2/acc3 half 1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
+
+    // fragment addresses: MFMA m of this wave uses k chunk 4*wk + 2m + lhi of activation row 32*wi + l31 and of weight
+    // rows l31 (column half 0) and 32 + l31 (half 1: same chunk swizzle, (32 + l31) & 15 == l31 & 15)
+    unsigned ax[2], aw[2];
+    {
+        const unsigned xbase = (unsigned)reinterpret_cast<size_t>((t2_lptr)(Xs));
+        const unsigned wbase = (unsigned)reinterpret_cast<size_t>((t2_lptr)(Ws));
+        const int rx = 32 * wi + l31;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c = 4 * wk + 2 * m + lhi;
+            ax[m] = xbase + (unsigned)(rx * 256 + ((c ^ (rx & 15)) << 4));
+            aw[m] = wbase + (unsigned)(l31 * 256 + ((c ^ (l31 & 15)) << 4));
+        }
+    }
+    f32x4 xa0, xa1, wa0, wa1, wa2, wa3, xb0, xb1, wb0, wb1, wb2, wb3;
+
+#define S6_READ(BUF, X0, X1, W0, W1, W2, W3)                                                           \
+    asm volatile(                                                                                      \
+        "ds_read_b128 %0, %6 offset:%10\n\t"                                                           \
+        "ds_read_b128 %2, %8 offset:%11\n\t"                                                           \
+        "ds_read_b128 %4, %8 offset:%12\n\t"                                                           \
+        "ds_read_b128 %1, %7 offset:%10\n\t"                                                           \
+        "ds_read_b128 %3, %9 offset:%11\n\t"                                                           \
+        "ds_read_b128 %5, %9 offset:%12"                                                               \
+        : "=&v"(X0), "=&v"(X1), "=&v"(W0), "=&v"(W1), "=&v"(W2), "=&v"(W3)                             \
+        : "v"(ax[0]), "v"(ax[1]), "v"(aw[0]), "v"(aw[1]), "i"((BUF) * SW_XB), "i"((BUF) * S6_WB),      \
+          "i"((BUF) * S6_WB + 32 * 256)                                                                \
+        : "memory");
+#define S6_WAITR(X0, X1, W0, W1, W2, W3)                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(X1), "+v"(W0), "+v"(W1), "+v"(W2), "+v"(W3) : : "memory");
+#define S6_M(ACC, X, W)                                                                                \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X)), __builtin_bit_cast(sk_bf16x8, (W)), ACC, 0, 0, 0);
+#define S6_FMA(X0, X1, W0, W1, W2, W3)                                                                 \
+    S6_M(acc0, X0, W0) S6_M(acc2, X0, W2) S6_M(acc1, X1, W1) S6_M(acc3, X1, W3)
+#define S6_SETA xa0, xa1, wa0, wa1, wa2, wa3
+#define S6_SETB xb0, xb1, wb0, wb1, wb2, wb3
+#define S6_X(M, ...) M(__VA_ARGS__)
+    // every wave issues exactly 4 DMA instructions per tile: "tile KT+1 landed" is vmcnt(8) (tiles KT+2, KT+3 may be
+    // pending); the barrier publishes it and frees tile KT's buffer for the DMA of tile KT+4
+#define S6_STEP(BUF, CUR, NXT)                                               \
+    {                                                                        \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                     \
+        __builtin_amdgcn_s_barrier();                                        \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        S6_X(S6_READ, ((BUF) + 1) % SW_NBUF, NXT)                            \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        S6_ISSUE(BUF)                                                        \
+        S6_X(S6_FMA, CUR)                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        S6_X(S6_WAITR, NXT)                                                  \
+    }
+
+    if (kt_end > kt_beg) {
+        S6_ISSUE(0)
+        S6_ISSUE(1)
+        S6_ISSUE(2)
+        S6_ISSUE(3)
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        S6_X(S6_READ, 0, S6_SETA)
+        S6_X(S6_WAITR, S6_SETA)
+        int kt = kt_beg;
+        for (; kt + 4 <= kt_end; kt += 4) {
+            S6_STEP(0, S6_SETA, S6_SETB)
+            S6_STEP(1, S6_SETB, S6_SETA)
+            S6_STEP(2, S6_SETA, S6_SETB)
+            S6_STEP(3, S6_SETB, S6_SETA)
+        }
+        if (kt < kt_end) {
+            S6_STEP(0, S6_SETA, S6_SETB)
+            if (kt + 1 < kt_end) {
+                S6_STEP(1, S6_SETB, S6_SETA)
+                if (kt + 2 < kt_end) S6_STEP(2, S6_SETA, S6_SETB)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped duplicate tiles
+    }
+#undef S6_ISSUE
+#undef S6_SEEK
+#undef S6_READ
+#undef S6_WAITR
+#undef S6_FMA
+#undef S6_M
+#undef S6_STEP
+#undef S6_X
+
+    // k-quarter partial sums -> LDS (the ring is dead once every wave's DMA has drained)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wi + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        Ps[(wk * 64 + row) * 65 + l31] = acc0[r] + acc1[r];
+        Ps[(wk * 64 + row) * 65 + 32 + l31] = acc2[r] + acc3[r];
+    }
+    __syncthreads();
+
+    if (egr >= B) return;
+    const int H = p.H;
+    asm volatile("" : "+v"(e_keep_raw[0]), "+v"(e_keep_raw[1]), "+v"(e_len));   // keeps the comparisons down here
+    const bool e_valid = p.t < e_len;
+    float* go_ = p.gates_out + (long long)egr * p.ld_gates;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int ej = bx * 16 + ejj + 8 * u;
+        float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, cn = 0.f, hn = 0.f;
+        if (e_valid) {
+            float pre[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * 16 + ejj + 8 * u;
+                pre[q] = ((Ps[erow * 65 + c] + Ps[(64 + erow) * 65 + c]) + (Ps[(128 + erow) * 65 + c] + Ps[(192 + erow) * 65 + c]))
+                         + e_gin[u][q] + e_bias[u][q];
+            }
+            gi = t2_sigmoid_fast(pre[0]);
+            gf = t2_sigmoid_fast(pre[1]);
+            gg = t2_tanh(pre[2]);
+            go = t2_sigmoid_fast(pre[3]);
+            cn = gf * e_cp[u] + gi * gg;
+            hn = go * t2_tanh(cn);
+            if (p.keep) hn = e_keep_raw[u] != 0 ? hn * p.keep_scale : 0.f;
+        }
+        go_[ej] = gi;
+        go_[H + ej] = gf;
+        go_[2 * H + ej] = gg;
+        go_[3 * H + ej] = go;
+        p.c_out[(long long)egr * p.ld_c + ej] = cn;
+        p.h_out[(long long)egr * p.ld_h + ej] = hn;
+        if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
+    }
+}
+
 // T2AMD_SKINNY_NARROW=1 keeps the 64x16 kernel for bf16 operands too (A/B measurements)
 static bool skinny_wide_enabled() {
     static const bool on = [] { const char* e = getenv("T2AMD_SKINNY_NARROW"); return !(e && e[0] == '1'); }();
@@ -809,7 +1092,17 @@ extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_ls
         else T2_LAUNCH(K, G, BLK, 0, s, d);                                            \
     } while (0)
     T2_REQUIRE(!b || (a->bf16 != 0) == (b->bf16 != 0), "lstm_step: both problems of a launch must share the operand type");
-    if (a->bf16 && skinny_wide_enabled() && a->H % 8 == 0 && (!b || b->H % 8 == 0)) {
+    // several rounds of 64 x 32 workgroups (decode batches of 256 and more): one round of 64 x 64 ones instead
+    static const int wide64 = [] { const char* e = getenv("T2AMD_LSTM_WIDE64"); return e ? atoi(e) : -1; }();   // A/B runs only
+    if (a->bf16 && skinny_wide_enabled() && !b && a->H % 16 == 0 &&
+        (wide64 < 0 ? (long long)d.p[0].gy * (a->H / 8) >= 512 : wide64 != 0)) {
+        d.p[0].gx = a->H / 16;
+        d.nblk0 = total = d.p[0].gx * d.p[0].gy;
+        d.p[1] = d.p[0];
+        if (a->tag == 1) LSTM_LAUNCH((skinny_wide64_kernel<1>), dim3(total), dim3(512));
+        else if (a->tag == 2) LSTM_LAUNCH((skinny_wide64_kernel<2>), dim3(total), dim3(512));
+        else LSTM_LAUNCH((skinny_wide64_kernel<0>), dim3(total), dim3(512));
+    } else if (a->bf16 && skinny_wide_enabled() && a->H % 8 == 0 && (!b || b->H % 8 == 0)) {
         d.p[0].gx = a->H / 8;
         d.nblk0 = d.p[0].gx * d.p[0].gy;
         total = d.nblk0;

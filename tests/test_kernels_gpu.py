@@ -538,6 +538,47 @@ torch.save([t.cpu() for t in (tot, dwin, dcum, d_pm, dU, dv_, dq, dh)], sys.argv
         assert torch.equal(x, y)
 
 
+def test_attention_energy_kernel_forms_agree():
+    """K_e has three forms (attention.hip): one utterance per workgroup in the latency-shaped register allocation, the
+    same with room for two workgroups per CU, and four utterances per workgroup with the W_q slice kept in registers
+    (batched inference, B > 128).  Per-thread arithmetic is identical, so weights, context and the saved query must
+    agree bit for bit -- with a ragged batch whose size is not a multiple of four and inactive utterances in it.
+    Child processes: the A/B switch is read once per process."""
+    import subprocess, sys, os, tempfile
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from tacotron2_amd import native as nv
+dev = torch.device('cuda')
+g = torch.Generator().manual_seed(15)
+rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+B, Ti, E, Hq = 11, 150, 512, 1024
+mem, pm, h = rnd(B, Ti, E), rnd(B, Ti, 128), rnd(B, Hq)
+Wq, U, v = rnd(128, Hq) * 0.05, rnd(128 * 62) * 0.1, rnd(128)
+lens = torch.tensor([150, 150, 140, 120, 97, 64, 33, 20, 16, 15, 2], dtype=torch.int32, device=dev)
+active = torch.tensor([1, 1, 0, 1, 1, 1, 1, 0, 1, 0, 1], dtype=torch.uint8, device=dev)
+wprev = torch.softmax(rnd(B, Ti), 1); cum = torch.rand(B, Ti, generator=g).to(dev)
+w_out, ctx_out, q_out = torch.zeros(B, Ti, device=dev), torch.zeros(B, E, device=dev), torch.zeros(B, 128, device=dev)
+ws = torch.zeros(nv.attn_fwd_ws_floats(B, Ti), device=dev)
+nv.attention_step_fwd(h, Wq, U, v, pm, mem, lens, wprev, cum, None, w_out, ctx_out, q_out, ws, active=active, bf16=True,
+                      memory16=mem.bfloat16(), Wq16=Wq.bfloat16())
+torch.cuda.synchronize()
+torch.save([t.cpu() for t in (w_out, ctx_out, q_out, cum)], sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for form in ("0", "1", "2"):
+        with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as fh:
+            path = fh.name
+        env = dict(os.environ, T2AMD_KE_FORM=form)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=300)
+        res.append(torch.load(path))
+        os.unlink(path)
+    assert float(res[0][0].sum()) > 5.0                       # eight active utterances, weights sum to one each
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert torch.equal(x, y)
+
+
 def test_attention_no_mask_and_first_step(nv):
     """Inference semantics: no length mask (reference model.py:432) and zero previous weights."""
     B, Ti, E, Hq = 1, 29, 512, 1024
@@ -616,7 +657,9 @@ def test_skinny_gemm_epilogue(nv, B, N, widths):
 # ------------------------------------------------------------------------------------------------
 # bf16 operand mode of the recurrent kernels
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,widths", [(64, 256, (256, 128, 256)), (37, 128, (128,)), (3, 64, (128, 256))])
+@pytest.mark.parametrize("B,H,widths", [(64, 256, (256, 128, 256)), (37, 128, (128,)), (3, 64, (128, 256)),
+                                        # two or more rounds of 64 x 32 workgroups: the 64 x 64 kernel (skinny_wide64_kernel)
+                                        (256, 1024, (128, 256, 128)), (200, 1024, (640,)), (520, 512, (128, 128))])
 def test_lstm_step_bf16_operands(nv, B, H, widths):
     """bf16 X and W on v_mfma_f32_16x16x32_bf16, f32 accumulate / cell: must equal an f32 product of the
     bf16-ROUNDED operands to f32 summation-order accuracy (products of bf16 values are exact in f32)."""
