@@ -19,3 +19,6 @@ head -12 $out/${tag}_kernel_stats_bf16.csv | cut -c1-150
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b1 -o b1 -- python $GRAFT_REPO_ROOT/tools/bench_infer.py --precision bf16 --only config4_B1 > /dev/null 2>&1 )
 find /tmp/prof_b1 -name '*kernel_stats.csv' -exec cp {} $out/${tag}_infer_config4_B1_kernel_stats_bf16.csv \;
 head -14 $out/${tag}_infer_config4_B1_kernel_stats_bf16.csv | cut -c1-150
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c5 -o c5 -- python $GRAFT_REPO_ROOT/tools/bench_infer.py --precision bf16 --only config5_B256 > /dev/null 2>&1 )
+find /tmp/prof_c5 -name '*kernel_stats.csv' -exec cp {} $out/${tag}_infer_config5_B256_kernel_stats_bf16.csv \;
+head -10 $out/${tag}_infer_config5_B256_kernel_stats_bf16.csv | cut -c1-150
