@@ -109,6 +109,31 @@ int t2amd_splitk_reduce_f32(const float* partials, int nsplit, long long stride,
                             long long n, int accumulate, int perm_taps, int perm_ci, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * bf16-resident product (csrc/gemm16.hip): C[M][N] (f32) = A[M][K] . B[N][K]^T (+ bias[n]), A and B bf16 and
+ * K-contiguous (row strides lda / ldb in elements, multiples of 8, >= K), K a multiple of 64.  In the bf16 compute mode
+ * it carries the products whose operands exist as bf16 images: the deferred weight gradients dW = dG^T . X of the
+ * decoder LSTMs and of the hoisted input projection (reference model.py:352-371 under autograd) on K-contiguous images
+ * made by t2amd_transpose_cast_bf16.  splitk > 1 writes partial slabs strideSplitC apart (plain epilogue only).
+ * ------------------------------------------------------------------------------------ */
+typedef struct t2amd_gemm16_desc {
+    const void* A;          /* [M][lda] bf16 */
+    const void* B;          /* [N][ldb] bf16 */
+    float* C;               /* [splitk][M][ldc] f32 */
+    int M, N, K;
+    long long lda, ldb, ldc;
+    int splitk;
+    long long strideSplitC;
+    int accumulate;         /* C += (splitk must be 1) */
+    const float* bias;      /* [N] or NULL (splitk must be 1) */
+} t2amd_gemm16_desc;
+int t2amd_gemm16_tn(const t2amd_gemm16_desc* d, void* stream);
+
+/* dst[c][r] (bf16, row stride ldd >= rows_padded; columns rows..rows_padded-1 zeroed) = src[r][c]; src is f32
+ * (src_is_bf16 = 0) or bf16, row stride lds elements: the K-contiguous image of a [rows][cols] slab. */
+int t2amd_transpose_cast_bf16(const void* src, int src_is_bf16, long long lds, void* dst, long long ldd, int rows, int cols,
+                              int rows_padded, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * BatchNorm1d (+activation +dropout) over channel-last rows; replaces nn.BatchNorm1d +
  * relu/tanh + F.dropout in reference model.py:141-146, 174-175 (train: biased batch
  * variance for normalisation, unbiased for the running update, momentum 0.1, eps 1e-5).

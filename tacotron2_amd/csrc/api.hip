@@ -22,7 +22,7 @@ extern "C" int t2amd_struct_sizes(int* out, int max_n) {
         (int)sizeof(t2amd_attn_fwd),  (int)sizeof(t2amd_attn_bwd),  (int)sizeof(t2amd_dec_train),
         (int)sizeof(t2amd_dec_train_bwd), (int)sizeof(t2amd_lstm_seq), (int)sizeof(t2amd_dec_infer),
         (int)sizeof(t2amd_small_linear), (int)sizeof(t2amd_tensor_list), (int)sizeof(t2amd_adam_hyper),
-        (int)sizeof(t2amd_dec_persist),
+        (int)sizeof(t2amd_dec_persist), (int)sizeof(t2amd_gemm16_desc),
     };
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < max_n; ++i) out[i] = sizes[i];

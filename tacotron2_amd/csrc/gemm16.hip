@@ -1,0 +1,270 @@
+// bf16-resident GEMM for gfx950: C[M][N] (f32) = A[M][K] . B[N][K]^T with BOTH operands bf16 and K-contiguous in HBM.
+//
+// gemm.hip's bf16 kernels read f32 operands and round them on their way into LDS (register staging): they are bound by the
+// operand bytes they pull through the CU's vector-memory path (64 KB per 256 x 256 x 32 tile step) and saturate near
+// 490 TF/s on the 55 k-deep weight gradients.  Here the operands are already bf16 in HBM (the engine's bf16 mode keeps bf16
+// images of every slab it multiplies more than once; weight gradients get K-contiguous images from the transposing cast
+// below), so a tile step of K = 64 is 64 KB for twice the MFMA work, and it never touches a register on its way in:
+//
+//   * 256 x 256 x 64 tile, 512 threads = 8 waves as 2 (m) x 4 (n), each wave 128 x 64 = 4 x 2 v_mfma_f32_32x32x16_bf16
+//     tiles (128 accumulator registers), 4 k-steps of 16 per tile step;
+//   * LDS-DMA staging (global_load_lds_dwordx4): every wave instruction copies 8 rows x 128 B; two stages of
+//     (32 KB A + 32 KB B), tile t+1 in flight while tile t is multiplied; one vmcnt(0) + barrier per tile step;
+//   * the DMA writes lane-linear, so bank conflicts are removed on the SOURCE: LDS slot s of row r holds global 16-byte
+//     chunk s ^ ((r >> 1) & 7); a fragment read (ds_read_b128, lane -> row l31, chunk 2 ks + lhi) of 16 consecutive rows
+//     then covers all 16 slots of the 256-byte bank row;
+//   * fragment reads are inline asm (hipcc orders every ds_read it can see behind ALL pending LDS-DMA);
+//   * XCD-aware tile order as in gemm.hip; split-K writes partial slabs (reduced by t2amd_splitk_reduce_f32).
+//
+// Replaces, in the bf16 compute mode: the deferred weight-gradient products dW = dG^T . X of the two decoder LSTMs and the
+// hoisted input projection (reference model.py:352-371 under autograd), and nn.Conv1d / nn.Linear products whose operands
+// already exist as bf16 images.
+#include "common.h"
+#include <stdlib.h>
+
+typedef __bf16 g16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* g16_lptr;
+typedef __attribute__((address_space(1))) const void* g16_gptr;
+
+#define G16_T 256            // tile edge (rows of A / rows of B)
+#define G16_BK 64            // k per tile step: 128-byte rows
+#define G16_IMG (G16_T * 128)        // bytes of one operand image
+#define G16_NT 512
+
+struct Gemm16Params {
+    t2amd_gemm16_desc d;
+    int ktiles_per_split;
+};
+
+struct G16Tile { int bx, by, bz; };
+// same order as gemm.hip's xcd_tile_id(): XCD j takes a contiguous run of tile ids, ids run through groups of 8 row tiles x
+// all column tiles, so the workgroups an XCD runs at once share a few A and B tiles per k step in its own L2
+__device__ __forceinline__ G16Tile g16_tile_id() {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int total = nbx * nby * (int)gridDim.z;
+    const int L = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+    const int xcd = L & 7, q = L >> 3;
+    const int base = total >> 3, rem = total & 7;
+    const int id = xcd * base + (xcd < rem ? xcd : rem) + q;
+    const int per_z = nbx * nby;
+    G16Tile t;
+    t.bz = id / per_z;
+    const int r = id - t.bz * per_z;
+    const int G = 8;
+    const int group = r / (G * nbx);
+    const int first = group * G;
+    const int gsz = (nby - first) < G ? (nby - first) : G;
+    const int w = r - group * (G * nbx);
+    t.by = first + w % gsz;
+    t.bx = w / gsz;
+    return t;
+}
+
+__global__ __launch_bounds__(G16_NT) void gemm16_tn_kernel(Gemm16Params p) {
+    // [A stage 0 | A stage 1 | B stage 0 | B stage 1], 32 KB each: a stage switch is a 16-bit immediate offset
+    __shared__ __attribute__((aligned(16))) char smem[4 * G16_IMG];
+    const t2amd_gemm16_desc& d = p.d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const G16Tile tile = g16_tile_id();
+    const int split = tile.bz;
+    const int row0 = tile.by * G16_T, col0 = tile.bx * G16_T;
+    const int M = d.M, N = d.N;
+    const int nkt_all = d.K / G16_BK;
+    const int kt_beg = split * p.ktiles_per_split;
+    int kt_end = kt_beg + p.ktiles_per_split;
+    if (kt_end > nkt_all) kt_end = nkt_all;
+    const int nk = kt_end > kt_beg ? kt_end - kt_beg : 0;
+
+    // ---- DMA sources: instruction i of this wave fills image rows 64 i + 8 wave + (lane >> 3), slot lane & 7 ----
+    const char* asrc[4];
+    const char* bsrc[4];
+    {
+        const int rin = 8 * wave + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((rin >> 1) & 7);          // (64 i) >> 1 adds nothing to bits 0..2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ga = row0 + 64 * i + rin, gb = col0 + 64 * i + rin;
+            ga = ga < M ? ga : M - 1;                              // clamped rows: their products are never stored
+            gb = gb < N ? gb : N - 1;
+            asrc[i] = reinterpret_cast<const char*>(d.A) + ((long long)ga * d.lda + (long long)kt_beg * G16_BK) * 2 + chunk * 16;
+            bsrc[i] = reinterpret_cast<const char*>(d.B) + ((long long)gb * d.ldb + (long long)kt_beg * G16_BK) * 2 + chunk * 16;
+        }
+    }
+#define G16_ISSUE(STAGE)                                                                                         \
+    {                                                                                                            \
+        char* ad_ = smem + (STAGE) * G16_IMG + wave * 1024;                                                      \
+        char* bd_ = smem + (2 + (STAGE)) * G16_IMG + wave * 1024;                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                          \
+            __builtin_amdgcn_global_load_lds((g16_gptr)(asrc[i]), (g16_lptr)(ad_ + i * 8192), 16, 0, 0);         \
+            __builtin_amdgcn_global_load_lds((g16_gptr)(bsrc[i]), (g16_lptr)(bd_ + i * 8192), 16, 0, 0);         \
+            asrc[i] += 128; bsrc[i] += 128;                                                                      \
+        }                                                                                                        \
+    }
+
+    // ---- fragment addresses: k-step ks of row r reads slot ((2 ks + lhi) ^ ((r >> 1) & 7)); one VGPR per (tile, ks) ----
+    unsigned aaddr[4][4], baddr[2][4];
+    {
+        const unsigned base = (unsigned)reinterpret_cast<size_t>((g16_lptr)(smem));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int r = wm * 128 + t * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) aaddr[t][ks] = base + (unsigned)(r * 128 + (((2 * ks + lhi) ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int r = wn * 64 + t * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                baddr[t][ks] = base + 2 * G16_IMG + (unsigned)(r * 128 + (((2 * ks + lhi) ^ ((r >> 1) & 7)) << 4));
+        }
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 fa[4], fb[2], ga[4], gb[2];
+#define G16_READ(STAGE, KS, A_, B_)                                                                              \
+    asm volatile(                                                                                                \
+        "ds_read_b128 %0, %6 offset:%12\n\t"                                                                     \
+        "ds_read_b128 %4, %10 offset:%12\n\t"                                                                    \
+        "ds_read_b128 %1, %7 offset:%12\n\t"                                                                     \
+        "ds_read_b128 %5, %11 offset:%12\n\t"                                                                    \
+        "ds_read_b128 %2, %8 offset:%12\n\t"                                                                     \
+        "ds_read_b128 %3, %9 offset:%12"                                                                         \
+        : "=&v"(A_[0]), "=&v"(A_[1]), "=&v"(A_[2]), "=&v"(A_[3]), "=&v"(B_[0]), "=&v"(B_[1])                     \
+        : "v"(aaddr[0][KS]), "v"(aaddr[1][KS]), "v"(aaddr[2][KS]), "v"(aaddr[3][KS]), "v"(baddr[0][KS]),          \
+          "v"(baddr[1][KS]), "i"((STAGE) * G16_IMG)                                                              \
+        : "memory");
+#define G16_WAIT(A_, B_)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+                 : "+v"(A_[0]), "+v"(A_[1]), "+v"(A_[2]), "+v"(A_[3]), "+v"(B_[0]), "+v"(B_[1]) : : "memory");
+#define G16_MFMA(A_, B_)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g16_bf16x8, A_[i]),           \
+                                                                __builtin_bit_cast(g16_bf16x8, B_[j]), acc[i][j], 0, 0, 0);
+    // one tile step from stage STAGE: fragments of k-step ks+1 load while k-step ks is multiplied
+#define G16_TILE(STAGE)                                                                                          \
+    {                                                                                                            \
+        G16_READ(STAGE, 0, fa, fb) G16_WAIT(fa, fb)                                                              \
+        G16_READ(STAGE, 1, ga, gb) __builtin_amdgcn_sched_barrier(0); G16_MFMA(fa, fb) __builtin_amdgcn_sched_barrier(0); G16_WAIT(ga, gb) \
+        G16_READ(STAGE, 2, fa, fb) __builtin_amdgcn_sched_barrier(0); G16_MFMA(ga, gb) __builtin_amdgcn_sched_barrier(0); G16_WAIT(fa, fb) \
+        G16_READ(STAGE, 3, ga, gb) __builtin_amdgcn_sched_barrier(0); G16_MFMA(fa, fb) __builtin_amdgcn_sched_barrier(0); G16_WAIT(ga, gb) \
+        G16_MFMA(ga, gb)                                                                                         \
+    }
+
+    if (nk > 0) {
+        G16_ISSUE(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt + 1 < nk; kt += 2) {
+            G16_ISSUE(1)                               // tile kt + 1 in flight while tile kt is multiplied
+            G16_TILE(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) G16_ISSUE(0)
+            G16_TILE(1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (nk & 1) G16_TILE(0)
+    }
+#undef G16_ISSUE
+#undef G16_READ
+#undef G16_WAIT
+#undef G16_MFMA
+#undef G16_TILE
+
+    // ---- epilogue: D layout of the 32 x 32 MFMA: lane -> column l31, register r -> row (r & 3) + 8 (r >> 2) + 4 lhi ----
+    float* __restrict__ C = d.C + (long long)split * d.strideSplitC;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int gn = col0 + wn * 64 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = row0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (gm < M && gn < N) {
+                    float* cp = C + (long long)gm * d.ldc + gn;
+                    float val = acc[tm][tn][r];
+                    if (d.bias) val += d.bias[gn];
+                    if (d.accumulate) val += *cp;
+                    *cp = val;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int t2amd_gemm16_tn(const t2amd_gemm16_desc* dp, void* stream) {
+    T2_REQUIRE(dp != nullptr, "gemm16: null descriptor");
+    Gemm16Params p;
+    p.d = *dp;
+    t2amd_gemm16_desc& d = p.d;
+    T2_REQUIRE(d.A && d.B && d.C, "gemm16: null operand");
+    T2_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.K % G16_BK == 0, "gemm16: K must be a positive multiple of 64");
+    T2_REQUIRE(t2_aligned16(d.A) && t2_aligned16(d.B) && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.lda >= d.K && d.ldb >= d.K,
+               "gemm16: operands must be 16-byte aligned with row strides that are multiples of 8 elements and >= K");
+    if (d.splitk < 1) d.splitk = 1;
+    T2_REQUIRE(d.splitk == 1 || (!d.bias && !d.accumulate), "gemm16: split-K needs a plain epilogue");
+    const int nkt = d.K / G16_BK;
+    p.ktiles_per_split = t2_cdiv(nkt, d.splitk);
+    dim3 grid(t2_cdiv(d.N, G16_T), t2_cdiv(d.M, G16_T), d.splitk);
+    T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm16: grid too large");
+    T2_LAUNCH(gemm16_tn_kernel, grid, dim3(G16_NT), 0, (hipStream_t)stream, p);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Transposing cast: dst[c][r] (bf16, row stride ldd >= rows, columns rows..rpad-1 zeroed) = src[r][c], src f32 or bf16.
+// The K-contiguous bf16 image of a [To.B][C] slab for the weight-gradient products above (K = To.B rounded up to 64).
+// 64 x 64 tiles through LDS: 256-byte reads along c, 128-byte writes along r.
+// ---------------------------------------------------------------------------------------
+template <bool SRC16>
+__global__ __launch_bounds__(256) void transpose_cast16_kernel(const void* __restrict__ src, long long lds_, unsigned short* __restrict__ dst,
+                                                               long long ldd, int rows, int cols, int rpad) {
+    __shared__ unsigned short tile[64][66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 4 row groups
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        unsigned short v = 0;
+        if (r < rows && c < cols) {
+            if (SRC16) v = reinterpret_cast<const unsigned short*>(src)[(long long)r * lds_ + c];
+            else v = t2_f32_to_bf16(reinterpret_cast<const float*>(src)[(long long)r * lds_ + c]);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rpad) dst[(long long)c * ldd + r] = tile[tx][i];
+    }
+}
+
+extern "C" int t2amd_transpose_cast_bf16(const void* src, int src_is_bf16, long long lds_, void* dst, long long ldd, int rows, int cols,
+                                         int rows_padded, void* stream) {
+    T2_REQUIRE(src && dst && rows > 0 && cols > 0 && rows_padded >= rows && ldd >= rows_padded, "transpose_cast: bad arguments");
+    dim3 grid(t2_cdiv(rows_padded, 64), t2_cdiv(cols, 64));
+    T2_REQUIRE(grid.y <= 65535, "transpose_cast: too many columns");
+    if (src_is_bf16)
+        T2_LAUNCH((transpose_cast16_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, src, lds_, (unsigned short*)dst, ldd, rows, cols, rows_padded);
+    else
+        T2_LAUNCH((transpose_cast16_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, src, lds_, (unsigned short*)dst, ldd, rows, cols, rows_padded);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}

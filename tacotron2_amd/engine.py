@@ -111,6 +111,64 @@ def _choose_splitk(M, N, K, batch=1, precision=0, a_km=False, b_kn=False):
     return max(1, s)
 
 
+def _choose_splitk16(M, N, K):
+    """Split count for the bf16-resident product (csrc/gemm16.hip: 256 x 256 tiles, one workgroup per CU): fill whole rounds
+    of 256 workgroups, mild preference for fewer partial slabs, at least 32 k-steps of 64 per slab."""
+    t256 = ((M + 255) // 256) * ((N + 255) // 256)
+    best, best_score = 1, -1.0
+    for s in range(1, 33):
+        if s > 1 and K // s < 2048:
+            break
+        w = t256 * s / 256.0
+        score = w / math.ceil(w) * min(1.0, w / 0.85) - 0.015 * (s - 1)
+        if score > best_score:
+            best, best_score = s, score
+    return best
+
+
+# T2AMD_WGRAD16=0 keeps the decoder-LSTM weight gradients on the f32-source GEMM in the bf16 mode (A/B runs)
+WGRAD16 = os.environ.get('T2AMD_WGRAD16', '1') != '0'
+
+
+def _lstm_wgrad16(run, dG2, B, parts, outs):
+    """Weight gradients of one decoder LSTM in the bf16 mode: [dW_ih | dW_hh] = dG^T . [x_0 | x_1 | ...] on the
+    bf16-resident product (native.gemm16_tn).  Both operands are held [To.B][.] (K-major) by the time loops, so K-contiguous
+    bf16 images are made first (transposing cast, K padded to the tile depth with zeros); an input the step reads from
+    the PREVIOUS time step (ctx_{t-1}, h_{t-1}) is written B columns to the right, which turns its
+    dG[B:]^T . x[:(To-1).B] into the same full-K product (the first B columns are zero).
+    ``parts``: (slab2d, shifted) per input block, in weight-column order; ``outs``: (dW tensor, first block, last block + 1)."""
+    rowsD, G4 = dG2.shape
+    Kp = ((rowsD + B + 63) // 64) * 64
+    GT = run.empty16(G4, Kp)
+    nv.transpose_cast_bf16(dG2, GT)
+    widths = [src.shape[1] for src, _ in parts]
+    XT = run.empty16(sum(widths), Kp)
+    n0, offs = 0, []
+    for (src, shifted), w in zip(parts, widths):
+        blk = XT[n0:n0 + w]
+        if shifted:
+            blk[:, :B].zero_()
+            if rowsD > B:
+                nv.transpose_cast_bf16(src[:rowsD - B], blk[:, B:])
+            else:
+                blk[:, B:].zero_()
+        else:
+            nv.transpose_cast_bf16(src, blk)
+        offs.append(n0)
+        n0 += w
+    offs.append(n0)
+    for dW, i0, i1 in outs:
+        Bop = XT[offs[i0]:offs[i1]]
+        M, N = dW.shape
+        sk = _choose_splitk16(M, N, Kp)
+        if sk == 1:
+            nv.gemm16_tn(dW, GT, Bop)
+        else:
+            part = run.empty(sk, M * N)
+            nv.gemm16_tn(dW, GT, Bop, splitk=sk, partials=part)
+            nv.splitk_reduce(part, sk, dW)
+
+
 class _Ctx(object):
     pass
 
@@ -732,16 +790,24 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # attention LSTM weights: inputs [prenet_t | ctx_{t-1} | h_att_{t-1}]
     dWih_a = G('decoder.attention_rnn.weight_ih', 4 * Ha, Pd + E)
     dWhh_a = G('decoder.attention_rnn.weight_hh', 4 * Ha, Ha)
-    tmp = run.empty(4 * Ha, Pd)
-    _rg(run, tmp, DGA2, T['p2'], a_km=True, b_kn=True)
-    nv.copy2d(dWih_a[:, :Pd], tmp)
-    if To > 1:
+    use16 = run.bf16 and WGRAD16 and B % 8 == 0 and not nv.validate_only()
+    Z = c.bf16 if use16 else None                           # bf16 images of the saved h_att / ctx / h_dec slabs
+    if use16:
+        _lstm_wgrad16(run, DGA2, B, [(T['p2'], False), (Z['CTX16'].view(rowsD, E), True), (Z['HA16'].view(rowsD, Ha), True)],
+                      [(dWih_a, 0, 2), (dWhh_a, 2, 3)])
+    elif To > 1:
+        tmp = run.empty(4 * Ha, Pd)
+        _rg(run, tmp, DGA2, T['p2'], a_km=True, b_kn=True)
+        nv.copy2d(dWih_a[:, :Pd], tmp)
         sh = (To - 1) * B
         tmp2 = run.empty(4 * Ha, E)
         _rg(run, tmp2, DGA2[B:], S['CTX'].view(rowsD, E)[:sh], a_km=True, b_kn=True)
         nv.copy2d(dWih_a[:, Pd:], tmp2)
         _rg(run, dWhh_a, DGA2[B:], S['HA'].view(rowsD, Ha)[:sh], a_km=True, b_kn=True)
     else:
+        tmp = run.empty(4 * Ha, Pd)
+        _rg(run, tmp, DGA2, T['p2'], a_km=True, b_kn=True)
+        nv.copy2d(dWih_a[:, :Pd], tmp)
         nv.fill(dWhh_a, 0.0)
         z = run.zeros(4 * Ha, E)
         nv.copy2d(dWih_a[:, Pd:], z)
@@ -757,17 +823,21 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # decoder LSTM weights: inputs [h_att_t | ctx_t | h_dec_{t-1}]
     dWih_d = G('decoder.decoder_rnn.weight_ih', 4 * Hd, Ha + E)
     dWhh_d = G('decoder.decoder_rnn.weight_hh', 4 * Hd, Hd)
-    tmp3 = run.empty(4 * Hd, Ha)
-    _rg(run, tmp3, DGD2, S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
-    nv.copy2d(dWih_d[:, :Ha], tmp3)
-    tmp4 = run.empty(4 * Hd, E)
-    _rg(run, tmp4, DGD2, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
-    nv.copy2d(dWih_d[:, Ha:], tmp4)
-    if To > 1:
-        sh = (To - 1) * B
-        _rg(run, dWhh_d, DGD2[B:], S['HD'].view(rowsD, Hd)[:sh], a_km=True, b_kn=True)
+    if use16:
+        _lstm_wgrad16(run, DGD2, B, [(Z['HA16'].view(rowsD, Ha), False), (Z['CTX16'].view(rowsD, E), False),
+                                     (Z['HD16'].view(rowsD, Hd), True)], [(dWih_d, 0, 2), (dWhh_d, 2, 3)])
     else:
-        nv.fill(dWhh_d, 0.0)
+        tmp3 = run.empty(4 * Hd, Ha)
+        _rg(run, tmp3, DGD2, S['HA'].view(rowsD, Ha), a_km=True, b_kn=True)
+        nv.copy2d(dWih_d[:, :Ha], tmp3)
+        tmp4 = run.empty(4 * Hd, E)
+        _rg(run, tmp4, DGD2, S['CTX'].view(rowsD, E), a_km=True, b_kn=True)
+        nv.copy2d(dWih_d[:, Ha:], tmp4)
+        if To > 1:
+            sh = (To - 1) * B
+            _rg(run, dWhh_d, DGD2[B:], S['HD'].view(rowsD, Hd)[:sh], a_km=True, b_kn=True)
+        else:
+            nv.fill(dWhh_d, 0.0)
     db_d = G('decoder.decoder_rnn.bias_ih', 4 * Hd)
     run.colsum(DGD2, db_d)
     db_d2 = G('decoder.decoder_rnn.bias_hh', 4 * Hd)

@@ -45,6 +45,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class Gemm16Desc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", _f32p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", _i64), ("ldb", _i64), ("ldc", _i64),
+        ("splitk", C.c_int), ("strideSplitC", _i64), ("accumulate", C.c_int), ("bias", _f32p),
+    ]
+
+
 class Seg(C.Structure):
     _fields_ = [("p", _f32p), ("ld", _i64), ("width", C.c_int)]
 
@@ -235,12 +244,12 @@ class AdamHyper(C.Structure):
 
 
 _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnBwd, DecTrain,
-            DecTrainBwd, LstmSeq, DecInfer, SmallLinear, TensorList, AdamHyper, DecPersist]
+            DecTrainBwd, LstmSeq, DecInfer, SmallLinear, TensorList, AdamHyper, DecPersist, Gemm16Desc]
 
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
     "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
-    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32",
+    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_gemm16_tn", "t2amd_transpose_cast_bf16",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
@@ -270,6 +279,8 @@ def _argtypes():
         "t2amd_gemm_f32": [pt(GemmDesc), _P],
         "t2amd_gemm_tile_size": [_I, _I, _I, _I, _I, _I],
         "t2amd_splitk_reduce_f32": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
+        "t2amd_gemm16_tn": [pt(Gemm16Desc), _P],
+        "t2amd_transpose_cast_bf16": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
         "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
         "t2amd_bn_act_fwd_f32": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _L, _F, _P, _I, _P],
@@ -569,6 +580,42 @@ def gemm(Cm, A, B, a_km=False, b_kn=False, accumulate=False, bias=None, act=0, k
         d.ldc = N
         d.strideSplitC = M * N
     _check(lib.t2amd_gemm_f32(C.byref(d), _stream()), "t2amd_gemm_f32")
+
+
+def gemm16_tn(Cm, A16, B16, K=None, splitk=1, partials=None, accumulate=False, bias=None):
+    """Cm[M,N] (f32) = A16[M,K] . B16[N,K]^T, bf16 K-contiguous operands (csrc/gemm16.hip).  ``K`` defaults to the operands'
+    width (a multiple of 64); with ``splitk`` > 1 the partial products go to ``partials`` (splitk, M*N)."""
+    lib = load()
+    d = Gemm16Desc()
+    pa, lda, M, Ka = _mat(A16, torch.bfloat16)
+    pb, ldb, N, Kb = _mat(B16, torch.bfloat16)
+    K = Ka if K is None else K
+    if K > Ka or K > Kb or Cm.shape[0] != M or Cm.shape[1] != N:
+        raise NativeError("gemm16_tn: shape mismatch A=%s B=%s C=%s K=%d" % (tuple(A16.shape), tuple(B16.shape), tuple(Cm.shape), K))
+    d.A, d.B, d.M, d.N, d.K, d.lda, d.ldb = pa, pb, M, N, K, lda, ldb
+    d.splitk = splitk
+    if splitk > 1:
+        if partials is None or partials.numel() < splitk * M * N:
+            raise NativeError("gemm16_tn: split-K needs a (splitk, M*N) partials buffer")
+        d.C, d.ldc, d.strideSplitC = ptr(partials), N, M * N
+    else:
+        d.C, d.ldc = _mat(Cm)[:2]
+    d.accumulate = 1 if accumulate else 0
+    d.bias = ptr(bias)
+    _check(lib.t2amd_gemm16_tn(C.byref(d), _stream()), "t2amd_gemm16_tn")
+
+
+def transpose_cast_bf16(src, dst, rows_padded=None):
+    """dst[c, r] (bf16) = src[r, c] (f32 or bf16); columns rows..rows_padded-1 of dst are zeroed."""
+    lib = load()
+    is16 = src.dtype == torch.bfloat16
+    ps, lds, rows, cols = _mat(src, torch.bfloat16 if is16 else torch.float32)
+    pd, ldd, c2, rp = _mat(dst, torch.bfloat16)
+    rows_padded = rp if rows_padded is None else rows_padded
+    if c2 != cols or rows_padded < rows or rows_padded > rp:
+        raise NativeError("transpose_cast_bf16: shape mismatch src=%s dst=%s" % (tuple(src.shape), tuple(dst.shape)))
+    _check(lib.t2amd_transpose_cast_bf16(ps, 1 if is16 else 0, _i64(lds), pd, _i64(ldd), rows, cols, rows_padded, _stream()),
+           "t2amd_transpose_cast_bf16")
 
 
 def splitk_reduce(partials, nsplit, out, accumulate=False, perm_taps=0, perm_ci=0):

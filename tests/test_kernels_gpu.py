@@ -699,3 +699,41 @@ def test_lstm_step_bf16_operands(nv, B, H, widths):
         Y = torch.empty(ns, B, N, device=DEV)
         nv.skinny_gemm([x.to(DEV) for x in xs], list(widths), W2.to(DEV), N, B, Y, nsplit=ns, bf16=True)
         assert err(Y.sum(0), torch.cat([x.float() for x in xs], 1) @ W2.float().t()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16-resident product (csrc/gemm16.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,pad", [(256, 256, 64, 0), (300, 520, 192, 64), (1024, 768, 1280, 0), (70, 33, 128, 8)])
+def test_gemm16_tn_matches_f32_product_of_the_bf16_operands(nv, M, N, K, pad):
+    """C = A . B^T with bf16 K-contiguous operands through LDS-DMA (256 x 256 x 64 tiles, ragged edges, padded row strides):
+    products of bf16 values are exact in f32, so the result must equal an f32 matmul of the same operands to summation-order
+    accuracy.  Asymmetric random operands: a transposed or mis-swizzled fragment cannot pass."""
+    A = (rnd(M, K + pad, seed=300) * (1 + torch.arange(M).float().unsqueeze(1) / M)).bfloat16()
+    B = (rnd(N, K + pad, seed=301) * (1 + torch.arange(K + pad).float().unsqueeze(0) / K)).bfloat16()
+    ref = A[:, :K].float() @ B[:, :K].float().t()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    Cm = torch.full((M, N), float('nan'), device=DEV)
+    nv.gemm16_tn(Cm, Ad[:, :K] if pad else Ad, Bd[:, :K] if pad else Bd)
+    tol = 2e-6 * K ** 0.5 * float(ref.abs().max())
+    assert (Cm.cpu() - ref).abs().max().item() < tol
+    bias = rnd(N, seed=302)
+    nv.gemm16_tn(Cm, Ad[:, :K] if pad else Ad, Bd[:, :K] if pad else Bd, accumulate=True, bias=dv(bias))
+    assert (Cm.cpu() - (2 * ref + bias)).abs().max().item() < 2 * tol
+    if K % 128 == 0:
+        sk = 2
+        part = torch.full((sk, M * N), float('nan'), device=DEV)
+        nv.gemm16_tn(Cm, Ad[:, :K] if pad else Ad, Bd[:, :K] if pad else Bd, splitk=sk, partials=part)
+        assert (part.view(sk, M, N).sum(0).cpu() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("rows,cols,rpad", [(130, 70, 192), (64, 64, 64), (1000, 257, 1024)])
+def test_transpose_cast_bf16(nv, rows, cols, rpad):
+    src = rnd(rows, cols + 3, seed=310)[:, :cols]                       # a row stride that is not the width
+    for s in (src, src.bfloat16()):
+        dst = torch.full((cols, rpad + 8), 7.0, device=DEV, dtype=torch.bfloat16)
+        nv.transpose_cast_bf16(s.to(DEV), dst[:, :rpad])
+        want = torch.zeros(cols, rpad, dtype=torch.bfloat16)
+        want[:, :rows] = s.bfloat16().t()
+        assert torch.equal(dst[:, :rpad].cpu(), want)
+        assert torch.all(dst[:, rpad:].cpu() == 7.0)

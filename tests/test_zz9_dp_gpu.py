@@ -33,8 +33,15 @@ def _worker(rank, world, port, precision, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # a rank that stops making progress says where: after 240 s every thread's stack goes to its log and the rank exits
+    import faulthandler
+    logdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(logdir, exist_ok=True)
+    log = open(os.path.join(logdir, "dp_rank%d_%s.log" % (rank, precision)), "w")
+    faulthandler.enable(log)
+    faulthandler.dump_traceback_later(240, exit=True, file=log)
     try:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=200))
         import golden_util as gu
         from tacotron2_amd import native
         from tacotron2_amd.distributed import apply_gradient_allreduce, reduce_tensor
@@ -127,21 +134,40 @@ def _worker(rank, world, port, precision, q):
         import traceback
         q.put((rank, traceback.format_exc(), None, None))
     finally:
+        faulthandler.cancel_dump_traceback_later()
+        log.close()
         if dist.is_initialized():
             dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_two_ranks_share_the_gpu_real_engine(native_lib, precision):
+    import queue
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
+    attempts = []
+    for attempt in range(2):
+        # Two processes sharing one GPU is a configuration of this TEST (the product runs one rank per GPU).  A rank that
+        # never reports -- seen once in a dozen runs, nothing in either rank's log -- is retried once and recorded; a rank
+        # that reports a mismatch or an exception fails the test at once.
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, precision, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = []
+        try:
+            for _ in procs:
+                res.append(q.get(timeout=300))
+        except queue.Empty:
+            res.append((-1, "no report within 300 s (exit codes %s): see gpurun_out/dp_rank*_%s.log"
+                        % ([p.exitcode for p in procs], precision), None, None))
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+        attempts.append([r[1] for r in res])
+        if all(r[0] >= 0 for r in res):
+            break
     assert all(r[1] == "ok" for r in res), res
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
@@ -149,4 +175,4 @@ def test_two_ranks_share_the_gpu_real_engine(native_lib, precision):
         import json
         json.dump(dict(world=2, backend="gloo, both ranks on cuda:0", precision=precision,
                        worst_relative_error_vs_mean_of_single_rank_grads=max(r[2] for r in res),
-                       p_grad_is_a_view_of_its_bucket=all(r[3] for r in res)), f)
+                       p_grad_is_a_view_of_its_bucket=all(r[3] for r in res), attempts=attempts), f)
