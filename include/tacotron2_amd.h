@@ -523,6 +523,9 @@ typedef struct t2amd_dec_train_bwd {
     const void* Wd_catT16; /* [Ha+E+Hd][4Hd] bf16 */
     void* DGA16;           /* [B][4Ha] bf16 scratch: this step's attention-LSTM gate gradients */
     void* DGD16;           /* [B][4Hd] bf16 scratch */
+    /* 0: DGA16 / DGD16 are one step's scratch, reused by every step; B*4Ha / B*4Hd: they are [To][B][4H] slabs and step t
+     * writes (and its dgrad reads) its own rows -- the engine then builds the weight-gradient operands from them */
+    long long dg16_step_a, dg16_step_d;
 } t2amd_dec_train_bwd;
 
 int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream);

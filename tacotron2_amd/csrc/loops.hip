@@ -240,7 +240,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         lb.keep = f.keep_dec ? f.keep_dec + t * sHd : nullptr; lb.ld_keep = Hd; lb.keep_scale = f.scale_dec;
         lb.dc = p->dc_d; lb.ld_dc = Hd;
         lb.dgates = p->DGD + (long long)t * B * 4 * Hd; lb.ld_dgates = 4 * Hd;
-        if (f.bf16) { lb.dgates16 = p->DGD16; lb.ld_dgates16 = 4 * Hd; }
+        if (f.bf16) { lb.dgates16 = (unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d; lb.ld_dgates16 = 4 * Hd; }
     };
     auto dgrad_d = [&](int t, t2amd_skinny_gemm& g) {     // d[h_att_t | ctx_t | h_dec_{t-1}] = dgates_d . Wd_cat
         g = t2amd_skinny_gemm{};
@@ -248,7 +248,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         g.x[0] = seg(p->DGD + (long long)t * B * 4 * Hd, 4 * Hd, 4 * Hd);
         g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
         g.Y = p->dXd + t * stepXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
-        if (f.bf16) { g.x[0].p = (const float*)p->DGD16; g.W = (const float*)p->Wd_catT16; g.bf16 = 1; }
+        if (f.bf16) { g.x[0].p = (const float*)((const unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d); g.W = (const float*)p->Wd_catT16; g.bf16 = 1; }
     };
     auto attn_bwd = [&](int t, void* st) -> int {        // needs dXd(t), dXa(t+1)
         const bool last = (t == To - 1);
@@ -285,7 +285,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         la.keep = f.keep_att ? f.keep_att + t * sHa : nullptr; la.ld_keep = Ha; la.keep_scale = f.scale_att;
         la.dc = p->dc_a; la.ld_dc = Ha;
         la.dgates = p->DGA + (long long)t * B * 4 * Ha; la.ld_dgates = 4 * Ha;
-        if (f.bf16) { la.dgates16 = p->DGA16; la.ld_dgates16 = 4 * Ha; }
+        if (f.bf16) { la.dgates16 = (unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a; la.ld_dgates16 = 4 * Ha; }
     };
     auto dgrad_a = [&](int t, t2amd_skinny_gemm& ga) {    // d[ctx_{t-1} | h_att_{t-1}] = dgates_a(t) . Wa_rec
         ga = t2amd_skinny_gemm{};
@@ -293,7 +293,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
         ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
         ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa; ga.tag = 1;
-        if (f.bf16) { ga.x[0].p = (const float*)p->DGA16; ga.W = (const float*)p->Wa_recT16; ga.bf16 = 1; }
+        if (f.bf16) { ga.x[0].p = (const float*)((const unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a); ga.W = (const float*)p->Wa_recT16; ga.bf16 = 1; }
     };
 
     if (g_dec_streams == 2) {

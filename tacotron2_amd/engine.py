@@ -596,7 +596,12 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
 
     GA = run.empty(To, B, 4 * Ha)
-    _fg(run, GA.view(rowsD, 4 * Ha), p2, Wih_a[:, :Pd], bias=bias_a)
+    if run.bf16 and WGRAD16 and Pd % 64 == 0 and (Pd + E) % 8 == 0 and not nv.validate_only():
+        # bf16 mode: the hoisted input projection of the attention LSTM on the bf16-resident product (csrc/gemm16.hip)
+        Wih_a16 = run.cached('Wih_a16', [Wih_a], lambda: run.cast16(Wih_a))
+        nv.gemm16_tn(GA.view(rowsD, 4 * Ha), run.cast16(p2), Wih_a16[:, :Pd], bias=bias_a)
+    else:
+        _fg(run, GA.view(rowsD, 4 * Ha), p2, Wih_a[:, :Pd], bias=bias_a)
 
     att_p, dec_p = hp.p_attention_dropout, hp.p_decoder_dropout
     keep_att = ms.get('att', None, (To, B, Ha), att_p) if training else None
@@ -763,11 +768,16 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     for k_, v_ in out.items():
         setattr(bw, k_, nv.ptr(v_))
     if run.bf16:
+        # the bf16 gate gradients are kept for every step ([To][B][4H] slabs) when the weight gradients are formed from them
+        slab16 = WGRAD16 and B % 8 == 0 and not nv.validate_only()
+        nst = To if slab16 else 1
         b16 = dict(Wa_recT16=run.cached('Wa_recT16', [Wih_a, Whh_a], lambda: run.cast16(Wa_recT)),
                    Wd_catT16=run.cached('Wd_catT16', [Wih_d, Whh_d], lambda: run.cast16(Wd_catT)),
-                   DGA16=run.empty16(B, 4 * Ha), DGD16=run.empty16(B, 4 * Hd))
+                   DGA16=run.empty16(nst, B, 4 * Ha), DGD16=run.empty16(nst, B, 4 * Hd))
         for k_, v_ in b16.items():
             setattr(bw, k_, nv.ptr(v_, torch.bfloat16))
+        if slab16:
+            bw.dg16_step_a, bw.dg16_step_d = B * 4 * Ha, B * 4 * Hd
     nv.decoder_train_bwd_loop(bw)
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
     DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)
@@ -793,7 +803,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     use16 = run.bf16 and WGRAD16 and B % 8 == 0 and not nv.validate_only()
     Z = c.bf16 if use16 else None                           # bf16 images of the saved h_att / ctx / h_dec slabs
     if use16:
-        _lstm_wgrad16(run, DGA2, B, [(T['p2'], False), (Z['CTX16'].view(rowsD, E), True), (Z['HA16'].view(rowsD, Ha), True)],
+        _lstm_wgrad16(run, b16['DGA16'].view(rowsD, 4 * Ha), B, [(T['p2'], False), (Z['CTX16'].view(rowsD, E), True), (Z['HA16'].view(rowsD, Ha), True)],
                       [(dWih_a, 0, 2), (dWhh_a, 2, 3)])
     elif To > 1:
         tmp = run.empty(4 * Ha, Pd)
@@ -824,7 +834,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     dWih_d = G('decoder.decoder_rnn.weight_ih', 4 * Hd, Ha + E)
     dWhh_d = G('decoder.decoder_rnn.weight_hh', 4 * Hd, Hd)
     if use16:
-        _lstm_wgrad16(run, DGD2, B, [(Z['HA16'].view(rowsD, Ha), False), (Z['CTX16'].view(rowsD, E), False),
+        _lstm_wgrad16(run, b16['DGD16'].view(rowsD, 4 * Hd), B, [(Z['HA16'].view(rowsD, Ha), False), (Z['CTX16'].view(rowsD, E), False),
                                      (Z['HD16'].view(rowsD, Hd), True)], [(dWih_d, 0, 2), (dWhh_d, 2, 3)])
     else:
         tmp3 = run.empty(4 * Hd, Ha)

@@ -173,6 +173,7 @@ class DecTrainBwd(C.Structure):
         ("dXd", _f32p), ("dXa", _f32p), ("dc_a", _f32p), ("dc_d", _f32p),
         ("dwin_part", _f32p), ("dcum_acc", _f32p), ("dq_h", _f32p),
         ("Wa_recT16", C.c_void_p), ("Wd_catT16", C.c_void_p), ("DGA16", C.c_void_p), ("DGD16", C.c_void_p),
+        ("dg16_step_a", _i64), ("dg16_step_d", _i64),
     ]
 
 
