@@ -125,8 +125,17 @@ typedef struct t2amd_gemm16_desc {
     long long strideSplitC;
     int accumulate;         /* C += (splitk must be 1) */
     const float* bias;      /* [N] or NULL (splitk must be 1) */
+    /* window mode (win_Tp > 0; nn.Conv1d over channel-last rows, reference layers.py:37-39 / model.py:141-146, 174-175):
+     * A is a bf16 image [B][Tp = T + 2 pad][Ci] with zero halo rows (t2amd_cast_halo_bf16), lda = Ci, K = k Ci -- row
+     * m = b Tp + t of A is the k-tap window of output (b, t), overlapping its neighbours; M = B Tp window rows are
+     * multiplied and those with t < win_T are stored to the compact rows b win_T + t of C.  splitk must be 1. */
+    int win_T, win_Tp;
 } t2amd_gemm16_desc;
 int t2amd_gemm16_tn(const t2amd_gemm16_desc* d, void* stream);
+
+/* dst[(b (T + 2 pad) + pad + t)][c] (bf16) = src[(b T + t)][c]; dst ([B (T + 2 pad) + 2 pad][C], zeroed by the caller: halo rows
+ * are not written) is the image the window mode reads. */
+int t2amd_cast_halo_bf16(const float* src, long long lds, void* dst, long long rows, int C, int T, int pad, void* stream);
 
 /* dst[c][r] (bf16, row stride ldd >= rows_padded; columns rows..rows_padded-1 zeroed) = src[r][c]; src is f32
  * (src_is_bf16 = 0) or bf16, row stride lds elements: the K-contiguous image of a [rows][cols] slab. */

@@ -195,8 +195,15 @@ __global__ __launch_bounds__(G16_NT) void gemm16_tn_kernel(Gemm16Params p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gm = row0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (gm < M && gn < N) {
-                    float* cp = C + (long long)gm * d.ldc + gn;
+                long long crow = gm;
+                bool live = gm < M;
+                if (d.win_Tp > 0) {              // window rows (b, t) of pitch Tp -> compact output rows b T + t, t < T
+                    const int b_ = gm / d.win_Tp, t_ = gm - b_ * d.win_Tp;
+                    live = live && t_ < d.win_T;
+                    crow = (long long)b_ * d.win_T + t_;
+                }
+                if (live && gn < N) {
+                    float* cp = C + crow * d.ldc + gn;
                     float val = acc[tm][tn][r];
                     if (d.bias) val += d.bias[gn];
                     if (d.accumulate) val += *cp;
@@ -214,8 +221,11 @@ extern "C" int t2amd_gemm16_tn(const t2amd_gemm16_desc* dp, void* stream) {
     t2amd_gemm16_desc& d = p.d;
     T2_REQUIRE(d.A && d.B && d.C, "gemm16: null operand");
     T2_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0 && d.K % G16_BK == 0, "gemm16: K must be a positive multiple of 64");
-    T2_REQUIRE(t2_aligned16(d.A) && t2_aligned16(d.B) && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.lda >= d.K && d.ldb >= d.K,
-               "gemm16: operands must be 16-byte aligned with row strides that are multiples of 8 elements and >= K");
+    T2_REQUIRE(t2_aligned16(d.A) && t2_aligned16(d.B) && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.ldb >= d.K,
+               "gemm16: operands must be 16-byte aligned with row strides that are multiples of 8 elements (B's >= K)");
+    // A's rows may overlap (lda < K): the sliding windows of a 1-d convolution over a channel-last image with zero halos
+    T2_REQUIRE(d.win_Tp == 0 || (d.win_T > 0 && d.win_T <= d.win_Tp && d.splitk == 1), "gemm16: bad window geometry");
+    T2_REQUIRE(d.win_Tp > 0 || d.lda >= d.K, "gemm16: lda must be >= K unless the rows are windows");
     if (d.splitk < 1) d.splitk = 1;
     T2_REQUIRE(d.splitk == 1 || (!d.bias && !d.accumulate), "gemm16: split-K needs a plain epilogue");
     const int nkt = d.K / G16_BK;
@@ -254,6 +264,35 @@ __global__ __launch_bounds__(256) void transpose_cast16_kernel(const void* __res
         const int c = c0 + i, r = r0 + tx;
         if (c < cols && r < rpad) dst[(long long)c * ldd + r] = tile[tx][i];
     }
+}
+
+// dst[(b Tp + pad + t)][c] (bf16) = src[(b T + t)][c] (f32): the channel-last image with `pad` zero rows around every utterance
+// that the window mode above reads; dst must have been zeroed once (the halo rows are never written).
+__global__ __launch_bounds__(256) void cast_halo16_kernel(const float* __restrict__ src, long long lds_, unsigned short* __restrict__ dst,
+                                                          long long rows, int C4, int T, int Tp, int pad) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C4) return;
+    const long long r = i / C4;
+    const int c4 = (int)(i - r * C4);
+    const long long b = r / T;
+    const int t = (int)(r - b * T);
+    const float4 v = *reinterpret_cast<const float4*>(src + r * lds_ + c4 * 4);
+    uint2 o;
+    o.x = (unsigned)t2_f32_to_bf16(v.x) | ((unsigned)t2_f32_to_bf16(v.y) << 16);
+    o.y = (unsigned)t2_f32_to_bf16(v.z) | ((unsigned)t2_f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(dst + ((b * Tp + pad + t) * (long long)(C4 * 4)) + c4 * 4) = o;
+}
+
+extern "C" int t2amd_cast_halo_bf16(const float* src, long long lds_, void* dst, long long rows, int C, int T, int pad, void* stream) {
+    T2_REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && T > 0 && rows % T == 0 && pad >= 0 && lds_ % 4 == 0 &&
+                   t2_aligned16(src) && t2_aligned16(dst),
+               "cast_halo: rows must be whole utterances of T, C a multiple of 4, 16-byte aligned operands");
+    const long long n = rows * (C / 4);
+    T2_REQUIRE((n + 255) / 256 < (1ll << 31), "cast_halo: too large");
+    T2_LAUNCH(cast_halo16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, lds_, (unsigned short*)dst, rows,
+              C / 4, T, T + 2 * pad, pad);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
 }
 
 extern "C" int t2amd_transpose_cast_bf16(const void* src, int src_is_bf16, long long lds_, void* dst, long long ldd, int rows, int cols,

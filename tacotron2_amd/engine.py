@@ -319,6 +319,23 @@ def _bias_sum(run, b1, b2):
 # ----------------------------------------------------------------------------
 # conv + BN (+act +dropout) stack, shared by encoder and postnet
 # ----------------------------------------------------------------------------
+# T2AMD_CONV16=0 keeps the convolutions of the bf16 mode on the f32-source GEMM (A/B runs)
+CONV16 = os.environ.get('T2AMD_CONV16', '1') != '0'
+
+
+def _conv16_ok(run, rows, T, C):
+    """The window form needs whole utterances of T rows, a channel count the 64-deep k-steps divide (a k-step never
+    straddles two taps) and enough rows for 256-row tiles to fill the chip."""
+    return run.bf16 and CONV16 and C % 64 == 0 and T > 0 and rows % T == 0 and rows >= 4096 and not nv.validate_only()
+
+
+def _halo_image(run, x, T, pad):
+    """bf16 image of the channel-last rows x (rows = B T) with `pad` zero rows around every utterance."""
+    rows, C = x.shape
+    img = torch.zeros((rows // T) * (T + 2 * pad) + 2 * pad, C, dtype=torch.bfloat16, device=x.device)
+    nv.cast_halo_bf16(x, img, T, pad)
+    return img
+
 def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training, lens=None):
     """x: (rows, C0) channel-last rows (b, t).  Returns the last activation and the saved slabs.
     reference model.py:141-146 (Postnet.forward), :174-175 (Encoder.forward)."""
@@ -350,6 +367,10 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
             part = run.empty(sk, rows * Co)
             nv.gemm(part[0].view(rows, Co), x, Wp, convA=(T, Ci, pad, 1), splitk=sk, partials=part, fast=run.fwdp)
             nv.splitk_reduce(part, sk, y)
+        elif _conv16_ok(run, rows, T, Ci):
+            # bf16 mode: the convolution as a product of sliding windows of a bf16 image with zero halo rows (csrc/gemm16.hip)
+            W16 = run.cached('convfwd16.%s.%d' % (prefix, i), [W], lambda Wp=Wp: run.cast16(Wp))
+            nv.conv16(y, _halo_image(run, x, T, pad), W16, rows // T, T, pad, bias=bias)
         else:
             _fg(run, y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
         if training:
@@ -408,7 +429,14 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
             else:
                 dx = run.empty(rows, Ci)
                 acc = False
-            _ng(run, dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
+            if _conv16_ok(run, rows, T, Co):
+                # dx[r][ci] = sum_{tap, co} g[r + pad - tap][co] W[co][ci][tap]: windows of g's halo image against the
+                # tap-reversed weights [Ci][k Co]
+                Wd16 = run.cached('convdgrad16.%s.%d' % (prefix, i), [W], lambda W=W: W.flip(2).permute(1, 2, 0).reshape(
+                    W.shape[1], W.shape[2] * W.shape[0]).contiguous().to(torch.bfloat16))
+                nv.conv16(dx, _halo_image(run, g, T, pad), Wd16, rows // T, T, pad, accumulate=acc)
+            else:
+                _ng(run, dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
             g = dx
     return g
 

@@ -51,6 +51,7 @@ class Gemm16Desc(C.Structure):
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("lda", _i64), ("ldb", _i64), ("ldc", _i64),
         ("splitk", C.c_int), ("strideSplitC", _i64), ("accumulate", C.c_int), ("bias", _f32p),
+        ("win_T", C.c_int), ("win_Tp", C.c_int),
     ]
 
 
@@ -250,7 +251,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
     "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
-    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_gemm16_tn", "t2amd_transpose_cast_bf16",
+    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_gemm16_tn", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
@@ -282,6 +283,7 @@ def _argtypes():
         "t2amd_splitk_reduce_f32": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_gemm16_tn": [pt(Gemm16Desc), _P],
         "t2amd_transpose_cast_bf16": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
+        "t2amd_cast_halo_bf16": [_P, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
         "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
         "t2amd_bn_act_fwd_f32": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _L, _F, _P, _I, _P],
@@ -604,6 +606,35 @@ def gemm16_tn(Cm, A16, B16, K=None, splitk=1, partials=None, accumulate=False, b
     d.accumulate = 1 if accumulate else 0
     d.bias = ptr(bias)
     _check(lib.t2amd_gemm16_tn(C.byref(d), _stream()), "t2amd_gemm16_tn")
+
+
+def conv16(Cm, img16, W16, B, T, pad, bias=None, accumulate=False):
+    """1-d convolution over channel-last rows on the bf16-resident product: Cm[(b T + t), co] (+)= sum_{tap, ci}
+    img16[b (T + 2 pad) + t + tap][ci] * W16[co][tap Ci + ci] (+ bias).  ``img16`` is cast_halo_bf16's image
+    ((B (T + 2 pad) + 2 pad) rows of Ci), ``W16`` the bf16 weights packed [Co][k Ci]."""
+    lib = load()
+    d = Gemm16Desc()
+    Ci = img16.shape[1]
+    Tp = T + 2 * pad
+    pw, ldw, Co, K = _mat(W16, torch.bfloat16)
+    if img16.shape[0] < B * Tp + 2 * pad or K != (2 * pad + 1) * Ci or Cm.shape[0] != B * T or Cm.shape[1] != Co:
+        raise NativeError("conv16: shape mismatch img=%s W=%s C=%s" % (tuple(img16.shape), tuple(W16.shape), tuple(Cm.shape)))
+    d.A, d.lda = ptr(_fullc(img16), torch.bfloat16), Ci
+    d.B, d.ldb = pw, ldw
+    d.C, d.ldc = _mat(Cm)[:2]
+    d.M, d.N, d.K = B * Tp, Co, K
+    d.splitk, d.accumulate, d.bias = 1, 1 if accumulate else 0, ptr(bias)
+    d.win_T, d.win_Tp = T, Tp
+    _check(lib.t2amd_gemm16_tn(C.byref(d), _stream()), "t2amd_gemm16_tn")
+
+
+def cast_halo_bf16(src, dst, T, pad):
+    """dst[(b (T + 2 pad) + pad + t), c] (bf16) = src[(b T + t), c]; dst must be zeroed (halo rows are not written)."""
+    ps, lds, rows, Cc = _mat(src)
+    if dst.dtype != torch.bfloat16 or dst.shape[1] != Cc or dst.shape[0] < (rows // T) * (T + 2 * pad) + 2 * pad:
+        raise NativeError("cast_halo_bf16: shape mismatch src=%s dst=%s" % (tuple(src.shape), tuple(dst.shape)))
+    _check(load().t2amd_cast_halo_bf16(ps, _i64(lds), ptr(_fullc(dst), torch.bfloat16), _i64(rows), Cc, T, pad, _stream()),
+           "t2amd_cast_halo_bf16")
 
 
 def transpose_cast_bf16(src, dst, rows_padded=None):

@@ -737,3 +737,37 @@ def test_transpose_cast_bf16(nv, rows, cols, rpad):
         want[:, :rows] = s.bfloat16().t()
         assert torch.equal(dst[:, :rpad].cpu(), want)
         assert torch.all(dst[:, rpad:].cpu() == 7.0)
+
+
+@pytest.mark.parametrize("B,T,Ci,Co,k", [(3, 37, 64, 96, 5), (5, 200, 128, 300, 5), (2, 9, 64, 64, 3)])
+def test_conv16_window_product_matches_conv1d(nv, B, T, Ci, Co, k):
+    """nn.Conv1d over channel-last rows as a product of sliding windows of a bf16 image with zero halo rows (gemm16 window
+    mode): equals F.conv1d on the bf16-rounded operands, utterance by utterance (nothing leaks across the halos), with
+    bias and accumulation; and the tap-reversed weights give the data gradient."""
+    import torch.nn.functional as F
+    pad = (k - 1) // 2
+    x = rnd(B * T, Ci, seed=320)
+    W = rnd(Co, Ci, k, seed=321, scale=0.2)
+    bias = rnd(Co, seed=322)
+    xb, Wb = x.bfloat16().float(), W.bfloat16().float()
+    ref = F.conv1d(xb.view(B, T, Ci).transpose(1, 2), Wb, bias, padding=pad).transpose(1, 2).reshape(B * T, Co)
+    img = torch.zeros(B * (T + 2 * pad) + 2 * pad, Ci, dtype=torch.bfloat16, device=DEV)
+    nv.cast_halo_bf16(dv(x), img, T, pad)
+    Wp16 = W.permute(0, 2, 1).reshape(Co, k * Ci).contiguous().bfloat16().to(DEV)          # [co][tap Ci + ci]
+    y = torch.full((B * T, Co), float('nan'), device=DEV)
+    nv.conv16(y, img, Wp16, B, T, pad, bias=dv(bias))
+    tol = 3e-6 * (k * Ci) ** 0.5 * float(ref.abs().max())
+    assert (y.cpu() - ref).abs().max().item() < tol
+    nv.conv16(y, img, Wp16, B, T, pad, accumulate=True)
+    assert (y.cpu() - (2 * ref - bias)).abs().max().item() < 2 * tol
+    # data gradient of the same convolution: g (rows, Co) -> dx (rows, Ci)
+    g = rnd(B * T, Co, seed=323)
+    gb = g.bfloat16().float()
+    dref = F.conv_transpose1d(gb.view(B, T, Co).transpose(1, 2), Wb, padding=pad).transpose(1, 2).reshape(B * T, Ci)
+    if Co % 64 == 0:
+        gimg = torch.zeros(B * (T + 2 * pad) + 2 * pad, Co, dtype=torch.bfloat16, device=DEV)
+        nv.cast_halo_bf16(dv(g), gimg, T, pad)
+        Wd16 = W.flip(2).permute(1, 2, 0).reshape(Ci, k * Co).contiguous().bfloat16().to(DEV)
+        dx = torch.full((B * T, Ci), float('nan'), device=DEV)
+        nv.conv16(dx, gimg, Wd16, B, T, pad)
+        assert (dx.cpu() - dref).abs().max().item() < 3e-6 * (k * Co) ** 0.5 * float(dref.abs().max())
