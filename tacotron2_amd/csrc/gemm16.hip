@@ -245,24 +245,58 @@ extern "C" int t2amd_gemm16_tn(const t2amd_gemm16_desc* dp, void* stream) {
 template <bool SRC16>
 __global__ __launch_bounds__(256) void transpose_cast16_kernel(const void* __restrict__ src, long long lds_, unsigned short* __restrict__ dst,
                                                                long long ldd, int rows, int cols, int rpad) {
+    // tile[r][c], row stride 66 shorts = 33 dwords: the column reads of the write pass fall on distinct banks
     __shared__ unsigned short tile[64][66];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 4 row groups
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        unsigned short v = 0;
-        if (r < rows && c < cols) {
-            if (SRC16) v = reinterpret_cast<const unsigned short*>(src)[(long long)r * lds_ + c];
-            else v = t2_f32_to_bf16(reinterpret_cast<const float*>(src)[(long long)r * lds_ + c]);
+    const int tid = threadIdx.x;
+    // read pass: thread -> (row i = tid >> 4 (+16 per pass), 4 consecutive columns 4 (tid & 15)): 8 bytes of a bf16 source,
+    // 16 of an f32 one; a row of the tile is one 128 / 256-byte segment
+    const bool vec_in = SRC16 ? (lds_ % 4 == 0 && (reinterpret_cast<size_t>(src) & 7) == 0) : (lds_ % 4 == 0 && (reinterpret_cast<size_t>(src) & 15) == 0);
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int i = pass * 16 + (tid >> 4), j = 4 * (tid & 15);
+        const int r = r0 + i, c = c0 + j;
+        unsigned short v[4] = {0, 0, 0, 0};
+        if (r < rows) {
+            if (vec_in && c + 3 < cols) {
+                if (SRC16) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(src) + (long long)r * lds_ + c);
+                    v[0] = (unsigned short)(u.x & 0xffffu); v[1] = (unsigned short)(u.x >> 16);
+                    v[2] = (unsigned short)(u.y & 0xffffu); v[3] = (unsigned short)(u.y >> 16);
+                } else {
+                    const float4 f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (long long)r * lds_ + c);
+                    v[0] = t2_f32_to_bf16(f.x); v[1] = t2_f32_to_bf16(f.y); v[2] = t2_f32_to_bf16(f.z); v[3] = t2_f32_to_bf16(f.w);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < cols)
+                        v[e] = SRC16 ? reinterpret_cast<const unsigned short*>(src)[(long long)r * lds_ + c + e]
+                                     : t2_f32_to_bf16(reinterpret_cast<const float*>(src)[(long long)r * lds_ + c + e]);
+            }
         }
-        tile[i][tx] = v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[i][j + e] = v[e];
     }
     __syncthreads();
-#pragma unroll 4
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;
-        if (c < cols && r < rpad) dst[(long long)c * ldd + r] = tile[tx][i];
+    // write pass: thread -> (column i of the tile = row of dst, 4 consecutive r): one 8-byte store, 128 bytes per dst row
+    const bool vec_out = ldd % 4 == 0 && (reinterpret_cast<size_t>(dst) & 7) == 0;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int i = pass * 16 + (tid >> 4), j = 4 * (tid & 15);
+        const int c = c0 + i, r = r0 + j;
+        if (c >= cols || r >= rpad) continue;
+        unsigned short* o = dst + (long long)c * ldd + r;
+        if (vec_out && r + 3 < rpad) {
+            uint2 u;
+            u.x = (unsigned)tile[j][i] | ((unsigned)tile[j + 1][i] << 16);
+            u.y = (unsigned)tile[j + 2][i] | ((unsigned)tile[j + 3][i] << 16);
+            *reinterpret_cast<uint2*>(o) = u;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (r + e < rpad) o[e] = tile[j + e][i];
+        }
     }
 }
 

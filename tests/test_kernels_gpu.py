@@ -727,10 +727,11 @@ def test_gemm16_tn_matches_f32_product_of_the_bf16_operands(nv, M, N, K, pad):
         assert (part.view(sk, M, N).sum(0).cpu() - ref).abs().max().item() < tol
 
 
-@pytest.mark.parametrize("rows,cols,rpad", [(130, 70, 192), (64, 64, 64), (1000, 257, 1024)])
+@pytest.mark.parametrize("rows,cols,rpad", [(130, 70, 192), (64, 64, 64), (1000, 257, 1024), (512, 256, 576)])
 def test_transpose_cast_bf16(nv, rows, cols, rpad):
-    src = rnd(rows, cols + 3, seed=310)[:, :cols]                       # a row stride that is not the width
-    for s in (src, src.bfloat16()):
+    src = rnd(rows, cols + 3, seed=310)[:, :cols]                       # a row stride that is not the width: scalar paths
+    src4 = rnd(rows, ((cols + 3) // 4) * 4, seed=311)[:, :cols]         # 16-byte-aligned rows: the vector paths
+    for s in (src, src.bfloat16(), src4, src4.bfloat16()):
         dst = torch.full((cols, rpad + 8), 7.0, device=DEV, dtype=torch.bfloat16)
         nv.transpose_cast_bf16(s.to(DEV), dst[:, :rpad])
         want = torch.zeros(cols, rpad, dtype=torch.bfloat16)
