@@ -269,6 +269,8 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "gloo":
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")            # single-node test runs: no host-name lookup
         dist.init_process_group(backend, rank=rank, world_size=world)     # "nccl" is RCCL on ROCm
 
     from tacotron2_amd import build, native

@@ -27,6 +27,7 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # no host-name lookup (it may not resolve here)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from tacotron2_amd.distributed import GradSync, apply_gradient_allreduce, bucket_of, reduce_tensor

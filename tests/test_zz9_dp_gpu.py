@@ -33,6 +33,9 @@ def _worker(rank, world, port, precision, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # gloo picks its interface by resolving the host name, which may not resolve in the test containers (a lookup that times
+    # out costs a minute or more per rank, seen as a 76 s -- once > 600 s -- run of this test): bind to loopback
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     # a rank that stops making progress says where: after 240 s every thread's stack goes to its log and the rank exits
     import faulthandler
     logdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
