@@ -439,9 +439,10 @@ typedef struct t2amd_attn_bwd {
     float* dh_out;           /* [T2AMD_ATT_SLICES] partial slabs of Wq^T dq: slice s, row b at dh_out + s*dh_split_stride + b*ld_dh */
     long long ld_dh;
     long long dh_split_stride;
-    float* ws;               /* workspace, >= B*Ti + 8*B floats.  Its last 4*B words receive the hand-off tokens of the
-                              * fused kernel (a nonzero launch counter): zero them once before the first call and do
-                              * not let other kernels write there between calls. */
+    float* ws;               /* workspace, >= B*Ti + 8*B floats (12*B with cell_q).  Words [B*Ti + 4*B, B*Ti + 8*B) (and
+                              * the next 4*B with cell_q) receive the hand-off tokens of the fused kernel (a nonzero
+                              * launch counter): zero them once before the first call and do not let other kernels
+                              * write there between calls. */
     /* 1: the two gradient products of the location layer (dcol = U^T dpre, dU += dpre^T im2col) round their
      * operands to bf16 and run on v_mfma_f32_16x16x32_bf16 (f32 accumulate) -- the engine's bf16 compute mode.
      * 0: exact-f32 MFMA.  The recompute of the location conv uses the forward's split-bf16 form (see
@@ -449,6 +450,20 @@ typedef struct t2amd_attn_bwd {
     int bf16;
     /* optional bf16 copy of `memory`: dw = dctx . memory streams it instead of the f32 rows */
     const void* memory16;
+    /* Optional (both NULL = off): the LSTM cell backwards of a BPTT step (reference: nn.LSTMCell under autograd,
+     * model.py:351-352, 366-370), run as the closing phase of THIS launch instead of a t2amd_lstm_pointwise_bwd2_f32
+     * launch of their own.
+     *   cell_q: the cell whose dL/dh contains this step's W_q^T dq -- the attention LSTM of the step.  Its dh[1] must
+     *           describe dh_out's T2AMD_ATT_SLICES slabs (what a separate launch would read); H = Hq, same B.
+     *   cell_x: a cell that does not depend on this launch (the decoder LSTM of step t-1), or NULL.
+     * In the folded form the four workgroups of an utterance exchange their dq slices through dq_out behind a second
+     * token block (ws must then hold B*Ti + 12*B floats, the last 8*B zeroed once), each forms W_q^T dq for a quarter
+     * of the columns in the summation order of the dh_out slabs, and runs both cells for those units: results are
+     * bit-identical to the separate launch; dh_out is not written.  Geometries the folded form does not cover
+     * (Hq % 16 != 0, H > 1024, the two-launch form of this step) run the cells as a separate launch from inside the
+     * call. */
+    const t2amd_lstm_bwd* cell_q;
+    const t2amd_lstm_bwd* cell_x;
 } t2amd_attn_bwd;
 
 int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);
@@ -543,6 +558,12 @@ int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream)
  * training loops runs on an internal side stream, ordered against the caller's stream with one hipEvent per
  * 8 steps. */
 int t2amd_set_decoder_streams(int n);
+/* 1: the two LSTM cell backwards of a decoder BPTT step (attention LSTM of step t, decoder LSTM of step t-1) run as the
+ * closing phase of the step's attention-backward launch (t2amd_attn_bwd.cell_q / cell_x): 5 dependent launches per
+ * decoder time step instead of 6.  0: a launch of their own.  Gradients are bit-identical either way.  Start-up value:
+ * environment T2AMD_CELL_FOLD, else the library default.  Single-stream loop only (t2amd_set_decoder_streams(1)). */
+int t2amd_set_bptt_cell_fold(int on);
+int t2amd_get_bptt_cell_fold(void);   /* the current value (0 / 1) */
 
 /* Encoder bi-LSTM over [B][T][.] with packed-sequence semantics (reference model.py:180-188).
  * GX [B][T][4H] holds x.W_ih^T + b_ih + b_hh (hoisted dense GEMM) and is overwritten with the

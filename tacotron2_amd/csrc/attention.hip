@@ -21,7 +21,9 @@
 // Every cross-workgroup reduction is a small slab of partials summed in a fixed order by the next
 // kernel: results are bit-reproducible run to run.
 #include "common.h"
+#include "cell_bwd.h"
 #include <stdlib.h>
+#include <stddef.h>
 
 typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 #define AD T2AMD_ATT_DIM       // 128
@@ -744,7 +746,11 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // =========================================================================================
 // Backward of one attention step.
 // =========================================================================================
-struct AttnBwdParams { t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; unsigned token; int kb1_smem_off; int fused_delay; };
+struct AttnBwdParams {
+    t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; unsigned token; int kb1_smem_off; int fused_delay;
+    t2amd_lstm_bwd cq, cx;      // CELL form: the folded cells by value (cq: takes W_q^T dq; cx: the independent one)
+    int cx_q4;                  // cx.H / 16 = float4 unit groups of cx per workgroup; 0 = no cx
+};
 
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
 // Half a wave (32 lanes) per memory row, 8 rows per pass.  One L2 round trip: the memory rows of the first 64
@@ -978,6 +984,17 @@ __global__ __launch_bounds__(KB1_NT) void attn_bwd_dw_kernel(AttnBwdParams p) {
     kb1_phase<M16>(p, smem, blockIdx.x, blockIdx.y, ts_on);
 }
 
+// The folded cells' descriptors (AttnBwdParams.cq / .cx, ~100 scalar fields) are read from the kernel-argument segment
+// where they are used: as ordinary by-value arguments the compiler loads every field at kernel entry and carries it in
+// SGPRs (spilled to VGPR lanes, then to scratch) through the whole kernel.  The empty asm makes the segment pointer
+// opaque at the point of the call, so the scalar loads cannot be hoisted above it.
+__device__ __forceinline__ const t2amd_lstm_bwd& kernarg_cell_late(size_t offset) {
+    typedef const char __attribute__((address_space(4))) * kptr_t;
+    kptr_t k = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *reinterpret_cast<const t2amd_lstm_bwd*>((const char*)(k + offset));
+}
+
 // K_b2: everything that lives in attention-dim space, for 32 dims (8 waves)
 #define KB2_NT 512
 #define KB2_NW (KB2_NT / 64)
@@ -986,8 +1003,16 @@ __global__ __launch_bounds__(KB1_NT) void attn_bwd_dw_kernel(AttnBwdParams p) {
 // token into ws, acquire spin on the four tokens -- and carries on as K_b2.  One launch instead of two, and K_b2's
 // prologue loads (issued before the K_b1 phase) land behind it.  The four workgroups of an utterance are consecutive
 // in dispatch order, so a waiting workgroup's partners are always resident or next to be dispatched.
-template <bool FUSED, bool M16>
+// CELL (needs FUSED): the closing phase also runs the LSTM cell backwards of the BPTT step (t2amd_attn_bwd.cell_q /
+// cell_x) -- one launch less per time step.  The cell of the attention LSTM needs the full W_q^T dq of its utterance,
+// which the four dim-slice workgroups hold as four partial sums; instead of exchanging those (4 x Hq floats each) they
+// exchange dq (32 floats each, through dq_out, behind a second token published before col2im and polled after it), and
+// workgroup ds forms the product for columns [ds Hq/4, (ds+1) Hq/4) over all 128 dims: eight 64-thread groups take 16
+// dims each -- exactly the 16-dim partial sums the dh_out slabs are made of -- and the closing reduction adds them in
+// the order a separate cell launch adds the slabs, so every bit of the result is the same.
+template <bool FUSED, bool M16, bool CELL>
 __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) {
+    static_assert(FUSED || !CELL, "the folded cells need the one-launch form");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     const t2amd_attn_bwd& a = p.a;
@@ -1002,7 +1027,8 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     float* red_s = dpre_s + (size_t)NP * DPL;   // [NW][2][32]
     float* dq_s = red_s + KB2_NW * 2 * DSL;   // [32]
     float* u_s = dq_s + DSL;                  // [32][62]
-    float* dh_s = u_s + DSL * NTAP;           // [Hq] second-half partial of dh
+    float* dh_s = u_s + DSL * NTAP;           // [Hq] second-half partial of dh; CELL: [8][Hq/4] 16-dim partials
+    float* dqall_s = dh_s + 2 * (size_t)Hq;   // CELL only: [128] the utterance's dq
     T2_TS(48);
     // Prologue loads: all issued before the first is consumed, nothing selected on a fresh load (see K_e).
     const int len_raw = a.lens ? a.lens[b] : Ti;
@@ -1204,8 +1230,31 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     T2_STAGE_RETURN(2);
     // W_q rows of the closing dh product (first 1024 columns): independent of everything above, fetched now so
     // that the round trip hides behind the reductions, the dU product and col2im
+    // CELL: the attention LSTM's cell belongs to wave 1.  Its operands that do not depend on dq are issued here, BEFORE
+    // the W_q prefetch: loads return in order, so whatever is issued after the W_q rows would have to land before the
+    // wave may touch them -- issued first, these are simply there by then.
+    const int cq_q4 = Hq >> 4;                   // float4 columns (= 4-unit groups) per workgroup, <= 64
+    const bool cq_on = CELL && wv == 1 && lane < cq_q4;
+    const int cq_j = (ds * cq_q4 + lane) * 4;
+    CellOperands cq_r;          // (only touched under cq_on)
+    Slab4 cq_s0, cq_s2;
+    if constexpr (CELL) {
+        if (cq_on) {
+            const t2amd_lstm_bwd& cq = kernarg_cell_late(offsetof(AttnBwdParams, cq));
+            cq_r = cell_bwd_issue(cq, b, cq_j);
+            cq_s0 = addend_issue4(cq.dh[0], b, cq_j);
+            cq_s2 = addend_issue4(cq.dh[2], b, cq_j);
+        }
+    }
     float4 wq_pre[16];
-    {
+    if constexpr (CELL) {
+        // group g = tid >> 6 takes dims 16g .. 16g+15 of ALL 128, lane c4 the float4 column ds*Hq/16 + c4
+        const int H4 = Hq >> 2, QC = Hq >> 4;
+        const int g = tid >> 6, c4 = tid & 63;
+        const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(g * 16) * H4 + ds * QC;
+#pragma unroll
+        for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (c4 < QC ? c4 : 0)];
+    } else {
         const int H4 = Hq >> 2;
         const int half = tid >> 8, t8 = tid & 255;
         const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(dbase + half * 16) * H4;
@@ -1242,7 +1291,25 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         a.dv_acc[(long long)b * AD + dbase + tid] = dv_old + dvs;
         if (FUSED && __any(poison)) dqs = __builtin_nanf("");       // abandoned hand-off (see above): poison the step
         dq_s[tid] = dqs;
-        a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
+        // CELL: the partners read this slice (device-scope store, drained before the token in the dU phase below)
+        if constexpr (CELL) __hip_atomic_store(&a.dq_out[(long long)b * a.ld_dq + dbase + tid], dqs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.dq_out[(long long)b * a.ld_dq + dbase + tid] = dqs;
+    }
+    // CELL: the independent cell (decoder LSTM of step t-1) belongs to the last wave: operands issued here, consumed
+    // after the wave's dU tile -- its HBM round trip hides behind the MFMAs, its arithmetic behind col2im, where the last
+    // waves have little or nothing to do (2 Ti outputs over 512 threads)
+    CellOperands cx_r;          // (only touched under cx_on)
+    Slab4 cx_s0, cx_s1, cx_s2;
+    const int cx_j = CELL ? (ds * p.cx_q4 + lane) * 4 : 0;
+    const bool cx_on = CELL && wv == KB2_NW - 1 && lane < p.cx_q4;
+    if constexpr (CELL) {
+        if (cx_on) {
+            const t2amd_lstm_bwd& cx = kernarg_cell_late(offsetof(AttnBwdParams, cx));
+            cx_r = cell_bwd_issue(cx, b, cx_j);
+            cx_s0 = addend_issue4(cx.dh[0], b, cx_j);
+            cx_s1 = addend_issue4(cx.dh[1], b, cx_j);
+            cx_s2 = addend_issue4(cx.dh[2], b, cx_j);
+        }
     }
     T2_TS(51);
     T2_STAGE_RETURN(3);
@@ -1299,6 +1366,16 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             for (int j = 0; j < 4; ++j) { a_cur[j] = a_nxt[j]; b_cur[j] = b_nxt[j]; }
         }
         // npos is a multiple of 16, so no tail
+        if constexpr (CELL) {
+            // second hand-off: wave 0 stored the slice's dq above; its outstanding vector-memory operations at this point
+            // are that store, the W_q prefetch and dU_old, which the stores below wait for anyway -- so draining them
+            // here costs nothing, and the token travels while col2im runs
+            if (wv == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                unsigned* flags2 = reinterpret_cast<unsigned*>(a.ws + (long long)B * Ti + 2ll * NTS * B) + b * NTS;
+                if (tid == 0) __hip_atomic_store(flags2 + ds, p.token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         if (tap < NTAP) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dUg[(long long)r * NTAP] = old[r] + (c0[r] + c1[r]);
@@ -1306,6 +1383,14 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     }
     T2_TS(52);
     T2_STAGE_RETURN(4);
+    if constexpr (CELL) {
+        if (cx_on) {
+            const t2amd_lstm_bwd& cx = kernarg_cell_late(offsetof(AttnBwdParams, cx));
+            const float4 d0 = addend_finish4(cx_s0, cx.dh[0], b, cx_j), d1 = addend_finish4(cx_s1, cx.dh[1], b, cx_j);
+            const float4 d2 = addend_finish4(cx_s2, cx.dh[2], b, cx_j);
+            cell_bwd_finish(cx, cx_r, d0, d1, d2, b, cx_j);
+        }
+    }
     // col2im: partial carry dwin[c][ti'] = sum_k dcol[ti' - k + 15][c*31 + k] over this slice's dims
     {
         float* __restrict__ out = a.dwin_part + (((long long)ds * B + b) * 2) * Ti;
@@ -1331,6 +1416,65 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     }
     T2_TS(53);
     T2_STAGE_RETURN(5);
+    if constexpr (CELL) {
+        // ---- the attention LSTM's cell: W_q^T dq for this workgroup's quarter of the columns, then the cell ----
+        const int QC = cq_q4;
+        const int g = tid >> 6, c4 = tid & 63;
+        // Wave 6 collects the utterance's dq: it has no col2im outputs for Ti <= 192 and so no stores in flight that a
+        // poll would have to queue behind (vector-memory operations complete in order).  The partners published their
+        // tokens before col2im, one phase ago: normally the first poll succeeds.  Bounded like the first hand-off; an
+        // abandoned wait turns the cell's gradients into NaN.  The same wave reads dq right behind the polls (program
+        // order within a wave), so no barrier separates the two.
+        if (wv == 6) {
+            bool bad = false;
+            if (lane < NTS) {
+                const unsigned* flags2 = reinterpret_cast<const unsigned*>(a.ws + (long long)B * Ti + 2ll * NTS * B) + b * NTS;
+                const long long t0_ = wall_clock64();
+                unsigned spins_ = 0;
+                while (__hip_atomic_load(flags2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.token) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; break; }
+                }
+            }
+            bad = __any(bad);
+            const float* dqg = a.dq_out + (long long)b * a.ld_dq;
+            const float q0 = __hip_atomic_load(dqg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float q1 = __hip_atomic_load(dqg + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dqall_s[lane] = bad ? __builtin_nanf("") : q0;
+            dqall_s[64 + lane] = bad ? __builtin_nanf("") : q1;
+        }
+        __syncthreads();
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dd = 0; dd < 16; ++dd) {
+            const float gq = dqall_s[g * 16 + dd];
+            acc.x = fmaf(gq, wq_pre[dd].x, acc.x);
+            acc.y = fmaf(gq, wq_pre[dd].y, acc.y);
+            acc.z = fmaf(gq, wq_pre[dd].z, acc.z);
+            acc.w = fmaf(gq, wq_pre[dd].w, acc.w);
+        }
+        float4* part_s = reinterpret_cast<float4*>(dh_s);      // [8 groups][QC]
+        if (c4 < QC) part_s[g * QC + c4] = acc;
+        __syncthreads();
+        if (cq_on) {
+            // slab k of a separate launch = (dims 32k .. 32k+15) + (dims 32k+16 .. 32k+31); slabs are added in index order
+            float4 d1;
+            {
+                const float4 p0 = part_s[0 * QC + c4], p1 = part_s[1 * QC + c4];
+                d1 = make_float4(0.f + (p0.x + p1.x), 0.f + (p0.y + p1.y), 0.f + (p0.z + p1.z), 0.f + (p0.w + p1.w));
+            }
+#pragma unroll
+            for (int k = 1; k < NSL; ++k) {
+                const float4 p0 = part_s[(2 * k) * QC + c4], p1 = part_s[(2 * k + 1) * QC + c4];
+                d1.x += p0.x + p1.x; d1.y += p0.y + p1.y; d1.z += p0.z + p1.z; d1.w += p0.w + p1.w;
+            }
+            const t2amd_lstm_bwd& cq = kernarg_cell_late(offsetof(AttnBwdParams, cq));
+            const float4 d0 = addend_finish4(cq_s0, cq.dh[0], b, cq_j), d2 = addend_finish4(cq_s2, cq.dh[2], b, cq_j);
+            cell_bwd_finish(cq, cq_r, d0, d1, d2, b, cq_j);
+        }
+        T2_TS(54);
+        return;
+    }
     __syncthreads();   // dq_s
     // partial dh = sum_{d in slice} dq[d] * W_q[d][:]; the two halves of the block take 16 dims each
     {
@@ -1370,7 +1514,8 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     T2_TS(54);
 }
 
-static int g_attn_bwd_lds = 0, g_attn_bwd_lds_fused = 0;
+static int g_attn_bwd_lds = 0, g_attn_bwd_lds_fused = 0, g_attn_bwd_lds_cell = 0;
+static unsigned g_attn_bwd_token = 0;      // one launch counter for both one-launch forms: a token never repeats in ws (never zero)
 
 extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream) {
     T2_REQUIRE(a && a->dctx_total && a->q && a->Wq && a->U && a->v && a->pm && a->memory && a->w &&
@@ -1395,8 +1540,27 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
                                          DSL * NTAP + (size_t)a->Hq);
     T2_REQUIRE(lds1 <= 64 * 1024, "attn_bwd: E too large");
     T2_REQUIRE(lds2 <= 160 * 1024, "attn_bwd: Ti needs more than 160 KiB of LDS");
+    // the folded cells (t2amd_attn_bwd.cell_q / cell_x)
+    T2_REQUIRE(a->cell_q || !a->cell_x, "attn_bwd: cell_x needs cell_q");
+    bool fold = false;
+    if (a->cell_q) {
+        const t2amd_lstm_bwd* cq = a->cell_q;
+        T2_PROPAGATE(t2amd_check_lstm_bwd_(cq));
+        T2_REQUIRE(cq->H == a->Hq && cq->B == a->B && !cq->lens, "attn_bwd: cell_q must be the [B][Hq] cell of this step, without lens");
+        T2_REQUIRE(cq->dh[1].p == a->dh_out && cq->dh[1].ld == a->ld_dh && cq->dh[1].nsplit == NSL &&
+                       cq->dh[1].split_stride == a->dh_split_stride,
+                   "attn_bwd: cell_q->dh[1] must describe the dh_out slabs");
+        fold = a->Hq % 16 == 0 && a->Hq <= 1024;
+        if (a->cell_x) {
+            T2_PROPAGATE(t2amd_check_lstm_bwd_(a->cell_x));
+            T2_REQUIRE(a->cell_x->B == a->B && !a->cell_x->lens, "attn_bwd: cell_x must have this step's batch, without lens");
+            fold = fold && a->cell_x->H % 16 == 0 && a->cell_x->H <= 1024;
+        }
+    }
+    // CELL form: dh_s grows from [Hq] to [2 Hq] (eight 16-dim partials per column), + the utterance's dq + a flag
+    const size_t lds2c = lds2 + sizeof(float) * ((size_t)a->Hq + AD + 4);
     if ((int)lds2 > 64 * 1024 && (int)lds2 > g_attn_bwd_lds && !t2amd_validate_only_flag_()) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         g_attn_bwd_lds = (int)lds2;
     }
     T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && a->E % 8 == 0), "attn_bwd: memory16 must be 16-byte aligned, E a multiple of 8");
@@ -1409,31 +1573,60 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     static const bool fused = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
     static const int fused_delay = [] { const char* e = getenv("T2AMD_ATTN_FUSED_DELAY"); const int v = e ? atoi(e) : 16; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
     p.fused_delay = fused_delay;
-    if (fused && lds1 + lds2 <= 160 * 1024) {
-        static unsigned token = 0;
-        if (++token == 0) ++token;
-        p.token = token;
-        const size_t l2a = (lds2 + 15) / 16 * 16;
+    p.cx_q4 = 0;
+    p.cq = t2amd_lstm_bwd{};
+    p.cx = t2amd_lstm_bwd{};
+    if (fused && fold && lds1 + lds2c <= 160 * 1024) {
+        // one launch for the attention backward AND the step's two LSTM cell backwards
+        if (++g_attn_bwd_token == 0) ++g_attn_bwd_token;
+        p.token = g_attn_bwd_token;
+        p.cq = *a->cell_q;
+        if (a->cell_x) { p.cx = *a->cell_x; p.cx_q4 = a->cell_x->H >> 4; }
+        for (int i = 0; i < 3; ++i) {
+            if (p.cq.dh[i].p && p.cq.dh[i].nsplit < 1) p.cq.dh[i].nsplit = 1;
+            if (p.cx.dh[i].p && p.cx.dh[i].nsplit < 1) p.cx.dh[i].nsplit = 1;
+        }
+        const size_t l2a = (lds2c + 15) / 16 * 16;
         p.kb1_smem_off = (int)(l2a / sizeof(float));
         const size_t ldsf = l2a + lds1;
-        if ((int)ldsf > 64 * 1024 && (int)ldsf > g_attn_bwd_lds_fused && !t2amd_validate_only_flag_()) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
-            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
-            g_attn_bwd_lds_fused = (int)ldsf;
+        if ((int)ldsf > 64 * 1024 && (int)ldsf > g_attn_bwd_lds_cell && !t2amd_validate_only_flag_()) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            g_attn_bwd_lds_cell = (int)ldsf;
         }
         t2amd_profile_mark_(4, 0, s);
-        if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
-        else T2_LAUNCH((attn_bwd_main_kernel<true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        else T2_LAUNCH((attn_bwd_main_kernel<true, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
         t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
-    t2amd_profile_mark_(4, 0, s);          // role 4: the attention backward pair of one time step (bench.py roofline)
-    if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
-    else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
-    T2_LAUNCH((attn_bwd_main_kernel<false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
-    t2amd_profile_mark_(4, 1, s);
-    T2_LAUNCH_CHECK();
+    if (fused && lds1 + lds2 <= 160 * 1024) {
+        if (++g_attn_bwd_token == 0) ++g_attn_bwd_token;
+        p.token = g_attn_bwd_token;
+        const size_t l2a = (lds2 + 15) / 16 * 16;
+        p.kb1_smem_off = (int)(l2a / sizeof(float));
+        const size_t ldsf = l2a + lds1;
+        if ((int)ldsf > 64 * 1024 && (int)ldsf > g_attn_bwd_lds_fused && !t2amd_validate_only_flag_()) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            g_attn_bwd_lds_fused = (int)ldsf;
+        }
+        t2amd_profile_mark_(4, 0, s);
+        if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        else T2_LAUNCH((attn_bwd_main_kernel<true, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        t2amd_profile_mark_(4, 1, s);
+        T2_LAUNCH_CHECK();
+    } else {
+        t2amd_profile_mark_(4, 0, s);          // role 4: the attention backward pair of one time step (bench.py roofline)
+        if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
+        else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
+        T2_LAUNCH((attn_bwd_main_kernel<false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
+        t2amd_profile_mark_(4, 1, s);
+        T2_LAUNCH_CHECK();
+    }
+    // cells that were asked for but not folded (geometry, or the two-launch form): the separate launch, from here
+    if (a->cell_q) return t2amd_lstm_pointwise_bwd2_f32(a->cell_q, a->cell_x, stream);
     return T2AMD_OK;
 }
 

@@ -147,5 +147,7 @@ extern "C" unsigned long long* t2amd_debug_ts_();
 int t2amd_proj_finish_small_(const t2amd_small_linear* a, int* out_lengths, uint8_t* active, int* done_count, int t,
                              int max_steps, float thr, int gate_row, void* stream);
 
+int t2amd_check_lstm_bwd_(const t2amd_lstm_bwd* a);      // rnn.hip: argument checks of one cell-backward descriptor
+
 static inline bool t2_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int t2_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

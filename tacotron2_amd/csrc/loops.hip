@@ -14,6 +14,7 @@
 // chunk of T2_CHUNK steps.  Default is 1 (single stream, the two chains share fused launches): on this chip
 // the two queues did not overlap any better than the fused launches do (round-1 A/B).
 #define T2_CHUNK 8
+#define T2_CELL_FOLD_DEFAULT 0      // (until the folded form has run the GPU suite: see DESIGN.md section 5)
 static int g_dec_streams = 1;   // measured on MI355X: 2 streams 134.3 ms/step vs 131.5 ms fused single stream
 static hipStream_t g_side = nullptr;
 static std::vector<hipEvent_t> g_events;
@@ -23,6 +24,19 @@ extern "C" int t2amd_set_decoder_streams(int n) {
     g_dec_streams = n;
     return T2AMD_OK;
 }
+// ---- BPTT cell fold -------------------------------------------------------------------------------------
+// 1: the two LSTM cell backwards of a decoder BPTT step run as the closing phase of the step's attention-backward launch
+// (t2amd_attn_bwd.cell_q / cell_x) instead of a launch of their own: 5 dependent launches per decoder time step instead of
+// 6 (3 forward + attention/cells + dgrad pair).  Bit-identical gradients either way (tests).  T2AMD_CELL_FOLD=0/1 sets
+// the start-up value, t2amd_set_bptt_cell_fold() changes it at run time.
+#include <stdlib.h>
+static int g_cell_fold = [] { const char* e = getenv("T2AMD_CELL_FOLD"); return e ? (e[0] != '0') : T2_CELL_FOLD_DEFAULT; }();
+extern "C" int t2amd_set_bptt_cell_fold(int on) {
+    T2_REQUIRE(on == 0 || on == 1, "set_bptt_cell_fold: 0 or 1");
+    g_cell_fold = on;
+    return T2AMD_OK;
+}
+extern "C" int t2amd_get_bptt_cell_fold(void) { return g_cell_fold; }
 static int side_stream(hipStream_t* out) {
     if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess)
         T2_FAIL("decoder loop: cannot create the side stream");
@@ -220,7 +234,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     // the backward's attention workspace sits behind the forward's four partial-energy slabs; its 8*B tail holds the
     // slice partials and the hand-off tokens of the fused backward kernel: zeroed once, tokens are never zero
     float* const bwd_ws = f.attn_ws + (long long)T2AMD_ATT_SLICES * B * Ti;
-    T2_PROPAGATE(t2amd_fill_f32(bwd_ws + (long long)B * Ti, 8ll * B, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(bwd_ws + (long long)B * Ti, 12ll * B, 0.f, stream));
 
     // The decoder-LSTM BPTT chain (cell backward -> dgrad GEMM) depends only on itself and on the
     // projection gradient; the attention chain consumes its dX one step later.  So the loop is
@@ -250,9 +264,10 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         g.Y = p->dXd + t * stepXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
         if (f.bf16) { g.x[0].p = (const float*)((const unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d); g.W = (const float*)p->Wd_catT16; g.bf16 = 1; }
     };
-    auto attn_bwd = [&](int t, void* st) -> int {        // needs dXd(t), dXa(t+1)
+    auto attn_bwd = [&](int t, void* st, const t2amd_lstm_bwd* cq = nullptr, const t2amd_lstm_bwd* cx = nullptr) -> int {   // needs dXd(t), dXa(t+1)
         const bool last = (t == To - 1);
         t2amd_attn_bwd ab = {};
+        ab.cell_q = cq; ab.cell_x = cx;
         ab.B = B; ab.Ti = Ti; ab.E = E; ab.Hq = Ha;
         ab.dctx[0] = addend(p->DHC + (long long)t * B * (Hd + E) + Hd, Hd + E, 1, 0);
         ab.dctx[1] = addend(p->dXd + t * stepXd + Ha, Kd, ns, strXd);
@@ -339,20 +354,20 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
     }
     for (int t = To - 1; t >= 0; --t) {
-        T2_PROPAGATE(attn_bwd(t, stream));
-        t2amd_lstm_bwd la;
+        t2amd_lstm_bwd la, lb;
         cell_a(t, la);
+        if (t > 0) cell_d(t - 1, lb);
+        if (g_cell_fold) T2_PROPAGATE(attn_bwd(t, stream, &la, t > 0 ? &lb : nullptr));     // attention + both cells
+        else T2_PROPAGATE(attn_bwd(t, stream));
         if (t > 0) {
-            t2amd_lstm_bwd lb;
-            cell_d(t - 1, lb);
-            T2_PROPAGATE(t2amd_lstm_pointwise_bwd2_f32(&la, &lb, stream));
+            if (!g_cell_fold) T2_PROPAGATE(t2amd_lstm_pointwise_bwd2_f32(&la, &lb, stream));
             t2amd_skinny_gemm ga, gd;
             dgrad_a(t, ga);
             dgrad_d(t - 1, gd);
             ga.tag = 3;
             gd.tag = 3;
             T2_PROPAGATE(t2amd_skinny_gemm2_f32(&gd, &ga, stream));
-        } else {
+        } else if (!g_cell_fold) {
             T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&la, stream));
         }
     }

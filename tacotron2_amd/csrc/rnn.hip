@@ -17,6 +17,7 @@
 // Replaces torch.nn.LSTMCell + F.dropout (reference model.py:352-356, 366-371) and the
 // per-timestep work of nn.LSTM (model.py:181-188).
 #include "common.h"
+#include "cell_bwd.h"
 #include <hip/hip_ext.h>
 
 #define SK_BK 64      // k per LDS tile
@@ -1204,41 +1205,6 @@ extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
 // ---------------------------------------------------------------------------------------
 struct LstmBwdParams { t2amd_lstm_bwd a[2]; int nblk0; unsigned long long* ts; };
 
-// An addend's partial slabs at (row, col..col+3) are added in index order.  Up to four slabs are fetched by
-// independent loads (addend_issue4) and only summed later (addend_finish4), after every other operand load of the
-// kernel has been issued: a runtime-trip-count loop made every slab a separate, fully waited L2 round trip (seven
-// in a row for the decoder cells).  More than four slabs fall back to a loop.
-struct Slab4 { float4 v0, v1, v2, v3; };
-__device__ __forceinline__ Slab4 addend_issue4(const t2amd_addend& ad, int row, int col) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    Slab4 r = {z, z, z, z};
-    if (!ad.p) return r;
-    const float* q = ad.p + (long long)row * ad.ld + col;
-    const int n = ad.nsplit;
-    const long long st = ad.split_stride;
-    r.v0 = *reinterpret_cast<const float4*>(q);
-    if (n > 1) r.v1 = *reinterpret_cast<const float4*>(q + st);
-    if (n > 2) r.v2 = *reinterpret_cast<const float4*>(q + 2 * st);
-    if (n > 3) r.v3 = *reinterpret_cast<const float4*>(q + 3 * st);
-    return r;
-}
-__device__ __forceinline__ float4 addend_finish4(const Slab4& r, const t2amd_addend& ad, int row, int col) {
-    if (!ad.p) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const int n = ad.nsplit;
-    float4 s = make_float4(0.f + r.v0.x, 0.f + r.v0.y, 0.f + r.v0.z, 0.f + r.v0.w);
-    if (n > 1) { s.x += r.v1.x; s.y += r.v1.y; s.z += r.v1.z; s.w += r.v1.w; }
-    if (n > 2) { s.x += r.v2.x; s.y += r.v2.y; s.z += r.v2.z; s.w += r.v2.w; }
-    if (n > 3) { s.x += r.v3.x; s.y += r.v3.y; s.z += r.v3.z; s.w += r.v3.w; }
-    if (n > 4) {
-        const float* q = ad.p + (long long)row * ad.ld + col;
-        for (int k = 4; k < n; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(q + (long long)k * ad.split_stride);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    }
-    return s;
-}
-
 // one thread per (row, 4 consecutive units): 16-byte loads/stores; blocks [0, nblk0) serve a[0], the rest a[1]
 #ifdef T2AMD_PHASE_STAMPS
 #define PW_TS(slot)                                                                        \
@@ -1277,54 +1243,15 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
         return;
     }
     // issue every independent load before the first use
-    const float* g = a.gates + (long long)b * a.ld_gates + j;
-    const float4 gi = *reinterpret_cast<const float4*>(g), gf = *reinterpret_cast<const float4*>(g + H);
-    const float4 gg = *reinterpret_cast<const float4*>(g + 2 * H), go = *reinterpret_cast<const float4*>(g + 3 * H);
-    const float4 c = *reinterpret_cast<const float4*>(a.c + (long long)b * a.ld_c + j);
-    const float4 cprev = a.c_prev ? *reinterpret_cast<const float4*>(a.c_prev + (long long)b * a.ld_cprev + j) : z4;
-    const float4 dc_in = *reinterpret_cast<const float4*>(dcp);
-    unsigned kp = 0x01010101u;
-    if (a.keep) kp = *reinterpret_cast<const unsigned*>(a.keep + (long long)b * a.ld_keep + j);
+    const CellOperands r = cell_bwd_issue(a, b, j);
     const Slab4 s0 = addend_issue4(a.dh[0], b, j), s1 = addend_issue4(a.dh[1], b, j), s2 = addend_issue4(a.dh[2], b, j);
     const float4 d0 = addend_finish4(s0, a.dh[0], b, j), d1 = addend_finish4(s1, a.dh[1], b, j), d2 = addend_finish4(s2, a.dh[2], b, j);
     PW_TS(1);
-    const float gi_[4] = {gi.x, gi.y, gi.z, gi.w}, gf_[4] = {gf.x, gf.y, gf.z, gf.w};
-    const float gg_[4] = {gg.x, gg.y, gg.z, gg.w}, go_[4] = {go.x, go.y, go.z, go.w};
-    const float c_[4] = {c.x, c.y, c.z, c.w}, cp_[4] = {cprev.x, cprev.y, cprev.z, cprev.w};
-    const float dci[4] = {dc_in.x, dc_in.y, dc_in.z, dc_in.w};
-    const float dh_[4] = {(d0.x + d1.x) + d2.x, (d0.y + d1.y) + d2.y, (d0.z + d1.z) + d2.z, (d0.w + d1.w) + d2.w};
-    float o0[4], o1[4], o2[4], o3[4], dcn[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float dh = dh_[e];
-        if (a.keep) dh = ((kp >> (8 * e)) & 0xffu) ? dh * a.keep_scale : 0.f;
-        const float tc = tanhf(c_[e]);
-        const float d_o = dh * tc;
-        const float dc = dci[e] + dh * go_[e] * (1.f - tc * tc);
-        o0[e] = dc * gg_[e] * gi_[e] * (1.f - gi_[e]);
-        o1[e] = dc * cp_[e] * gf_[e] * (1.f - gf_[e]);
-        o2[e] = dc * gi_[e] * (1.f - gg_[e] * gg_[e]);
-        o3[e] = d_o * go_[e] * (1.f - go_[e]);
-        dcn[e] = dc * gf_[e];
-    }
-    *reinterpret_cast<float4*>(dg) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-    *reinterpret_cast<float4*>(dg + H) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-    *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(o2[0], o2[1], o2[2], o2[3]);
-    *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(o3[0], o3[1], o3[2], o3[3]);
-    if (d16) {       // bf16 copy: the dgrad GEMM's MFMA operand in bf16 mode
-#define T2_PK4(o) make_uint2((unsigned)t2_f32_to_bf16(o[0]) | ((unsigned)t2_f32_to_bf16(o[1]) << 16), \
-                             (unsigned)t2_f32_to_bf16(o[2]) | ((unsigned)t2_f32_to_bf16(o[3]) << 16))
-        *reinterpret_cast<uint2*>(d16) = T2_PK4(o0);
-        *reinterpret_cast<uint2*>(d16 + H) = T2_PK4(o1);
-        *reinterpret_cast<uint2*>(d16 + 2 * H) = T2_PK4(o2);
-        *reinterpret_cast<uint2*>(d16 + 3 * H) = T2_PK4(o3);
-#undef T2_PK4
-    }
-    *reinterpret_cast<float4*>(dcp) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+    cell_bwd_finish(a, r, d0, d1, d2, b, j);
     PW_TS(2);
 }
 
-static int check_lstm_bwd(const t2amd_lstm_bwd* a) {
+int t2amd_check_lstm_bwd_(const t2amd_lstm_bwd* a) {
     T2_REQUIRE(a && a->gates && a->c && a->dc && a->dgates, "lstm_bwd: null args");
     T2_REQUIRE(a->B > 0 && a->H > 0 && a->H % 4 == 0, "lstm_bwd: H must be a positive multiple of 4");
     // 16-byte accesses: every row base and stride must keep 4-float alignment
@@ -1341,14 +1268,14 @@ static int check_lstm_bwd(const t2amd_lstm_bwd* a) {
 }
 
 extern "C" int t2amd_lstm_pointwise_bwd2_f32(const t2amd_lstm_bwd* a, const t2amd_lstm_bwd* b, void* stream) {
-    T2_PROPAGATE(check_lstm_bwd(a));
+    T2_PROPAGATE(t2amd_check_lstm_bwd_(a));
     LstmBwdParams p;
     p.ts = t2amd_debug_ts_();
     p.a[0] = *a;
     p.nblk0 = t2_cdiv((long long)a->B * a->H / 4, 256);
     int total = p.nblk0;
     if (b) {
-        T2_PROPAGATE(check_lstm_bwd(b));
+        T2_PROPAGATE(t2amd_check_lstm_bwd_(b));
         p.a[1] = *b;
         total += t2_cdiv((long long)b->B * b->H / 4, 256);
     } else {

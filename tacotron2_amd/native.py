@@ -146,6 +146,7 @@ class AttnBwd(C.Structure):
         ("ws", _f32p),
         ("bf16", C.c_int),
         ("memory16", C.c_void_p),
+        ("cell_q", C.POINTER(LstmBwd)), ("cell_x", C.POINTER(LstmBwd)),
     ]
 
 
@@ -264,7 +265,7 @@ SYMBOLS = [
     "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
-    "t2amd_set_decoder_streams", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
+    "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
@@ -322,6 +323,8 @@ def _argtypes():
         "t2amd_struct_sizes": [pt(C.c_int), _I],
         "t2amd_set_validate_only": [_I],
         "t2amd_set_decoder_streams": [_I],
+        "t2amd_set_bptt_cell_fold": [_I],
+        "t2amd_get_bptt_cell_fold": [],
         "t2amd_lstm_step_small_f32": [pt(LstmStep), _P],
         "t2amd_linear_small_f32": [pt(SmallLinear), _P],
         "t2amd_profile_enable": [_I, _I],
@@ -440,6 +443,16 @@ def loss_workspace_doubles():
 def set_decoder_streams(n):
     """1 (default): single stream, fused launches; 2: decoder-LSTM chain of the training loops on a side stream."""
     _check(load().t2amd_set_decoder_streams(int(n)), "t2amd_set_decoder_streams")
+
+
+def set_bptt_cell_fold(on):
+    """1: the LSTM cell backwards of a decoder BPTT step run inside the step's attention-backward launch (5 dependent
+    launches per time step instead of 6); 0: as a launch of their own.  Bit-identical gradients either way."""
+    _check(load().t2amd_set_bptt_cell_fold(1 if on else 0), "t2amd_set_bptt_cell_fold")
+
+
+def get_bptt_cell_fold():
+    return int(load().t2amd_get_bptt_cell_fold())
 
 
 def set_validate_only(on):
@@ -903,6 +916,35 @@ def _addend(t, nsplit=1, split_stride=0):
     return a
 
 
+def lstm_bwd_desc(B, H, dh_list, gates, c_prev, c, keep, keep_scale, dc, dgates, lens=None, t=0, dgates16=None):
+    """One cell-backward descriptor.  dh_list entries: a tensor, None, or (tensor, nsplit, split_stride) for an addend
+    made of partial slabs."""
+    a = LstmBwd()
+    a.B, a.H = B, H
+    for i in range(3):
+        d = dh_list[i] if i < len(dh_list) else None
+        a.dh[i] = _addend(*d) if isinstance(d, tuple) else _addend(d)
+    a.gates, a.ld_gates = _mat(gates)[:2]
+    if c_prev is not None:
+        a.c_prev, a.ld_cprev = _mat(c_prev)[:2]
+    a.c, a.ld_c = _mat(c)[:2]
+    if keep is not None:
+        a.keep, a.ld_keep, a.keep_scale = ptr(keep, torch.uint8), keep.stride(0), keep_scale
+    a.dc, a.ld_dc = _mat(dc)[:2]
+    a.dgates, a.ld_dgates = _mat(dgates)[:2]
+    a.lens = ptr(lens, torch.int32)
+    a.t = t
+    if dgates16 is not None:
+        a.dgates16, a.ld_dgates16 = ptr(dgates16, torch.bfloat16), dgates16.stride(0)
+    return a
+
+
+def lstm_pointwise_bwd2(a, b=None):
+    """The stand-alone launch for one or two descriptors of lstm_bwd_desc()."""
+    _check(load().t2amd_lstm_pointwise_bwd2_f32(C.byref(a), C.byref(b) if b is not None else None, _stream()),
+           "t2amd_lstm_pointwise_bwd2_f32")
+
+
 def lstm_pointwise_bwd(B, H, dh_list, gates, c_prev, c, keep, keep_scale, dc, dgates, lens=None, t=0):
     lib = load()
     a = LstmBwd()
@@ -943,7 +985,8 @@ def attn_fwd_ws_floats(B, Ti):
 
 
 def attn_bwd_ws_floats(B, Ti):
-    return B * Ti + 8 * B
+    """dw slab + slice partials + the token blocks of the two hand-offs (the second one: folded cells only)."""
+    return B * Ti + 12 * B
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,
@@ -976,8 +1019,10 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
 
 
 def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory, lens, w, w_prev, cum_before,
-                       dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws, bf16=False, memory16=None):
-    """dwin_part: (ATT_SLICES, B, 2, Ti) in/out; dcum_acc: (B, Ti) in/out; dh_parts: (ATT_SLICES, B, Hq) out."""
+                       dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws, bf16=False, memory16=None,
+                       cell_q=None, cell_x=None):
+    """dwin_part: (ATT_SLICES, B, 2, Ti) in/out; dcum_acc: (B, Ti) in/out; dh_parts: (ATT_SLICES, B, Hq) out.
+    cell_q / cell_x: descriptors of lstm_bwd_desc() to run inside this launch (t2amd_attn_bwd.cell_q / cell_x)."""
     lib = load()
     a = AttnBwd()
     B, Ti, E = memory.shape
@@ -1006,6 +1051,10 @@ def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory
     a.bf16 = 1 if bf16 else 0
     if memory16 is not None:
         a.memory16 = ptr(_fullc(memory16), torch.bfloat16)
+    if cell_q is not None:
+        a.cell_q = C.pointer(cell_q)
+    if cell_x is not None:
+        a.cell_x = C.pointer(cell_x)
     _check(lib.t2amd_attention_step_bwd_f32(C.byref(a), _stream()), "t2amd_attention_step_bwd_f32")
 
 

@@ -80,11 +80,16 @@ def test_argument_validation_errors_are_reported(native_lib):
     assert rc == 1 and b"null operand" in native_lib.t2amd_last_error()
 
 
+@pytest.mark.parametrize("fold", [0, 1])
 @pytest.mark.parametrize("hpstr,in_lens,out_lens", [(gu.TINY_HP, [12, 9, 5], [20, 16, 11]), ("", [17, 11], [30, 23])])
-def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens):
+def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens, fold):
     """Every host-side check / loop of forward, backward and inference runs (kernels skipped):
-    catches shape, stride, alignment and pointer-plumbing errors without a GPU."""
+    catches shape, stride, alignment and pointer-plumbing errors without a GPU.  fold = 1: the BPTT loop hands the
+    step's LSTM cell backwards to the attention-backward call (t2amd_attn_bwd.cell_q / cell_x), whose descriptor checks
+    run here."""
     native.set_validate_only(True)
+    start = native.get_bptt_cell_fold()
+    native.set_bptt_cell_fold(fold)
     try:
         hp = create_hparams((hpstr + "," if hpstr else "") + "max_decoder_steps=6")
         m = Tacotron2(hp)
@@ -102,6 +107,7 @@ def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens):
         assert o[0].shape[0] == len(in_lens)
     finally:
         native.set_validate_only(False)
+        native.set_bptt_cell_fold(start)
 
 
 def test_splitk_policy_matches_library_tile_rule():

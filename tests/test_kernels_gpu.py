@@ -538,6 +538,86 @@ torch.save([t.cpu() for t in (tot, dwin, dcum, d_pm, dU, dv_, dq, dh)], sys.argv
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("B,Ti,E,Hq,Hx,first", [(3, 37, 128, 128, 128, False), (5, 150, 512, 1024, 1024, False),
+                                                (64, 187, 512, 1024, 1024, False), (2, 300, 512, 1024, 512, False),
+                                                (4, 21, 256, 256, 0, True), (3, 60, 128, 136, 128, False)])
+def test_attention_backward_folded_cells_bitwise(nv, B, Ti, E, Hq, Hx, first, bf16):
+    """t2amd_attn_bwd.cell_q / cell_x: the LSTM cell backwards of a BPTT step run as the closing phase of the
+    attention-backward launch.  Against the separate t2amd_lstm_pointwise_bwd2_f32 launch fed by the dh_out slabs, every
+    output of the attention step and of both cells (gate gradients f32 + bf16, dc carry) must be bit-identical: the
+    folded kernel forms W_q^T dq from the same 16-dim partial sums in the same order.  Three chained calls per variant
+    (carries, accumulators and the dc carries feed the next call; the hand-off tokens change per launch).  B = 64 fills
+    the chip like the training step; Ti = 300 gives the polling wave col2im stores of its own; Hx = 0: no second cell
+    (time step 0 of the loop); first: no previous cell state; Hq = 136 is a geometry the folded kernel does not cover
+    (the call then launches the cells itself)."""
+    S = nv.ATT_SLICES
+    g = G(900 + B + Ti)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
+    mem, pm = r(B, Ti, E), r(B, Ti, 128)
+    Wq, U, v = r(128, Hq, scale=0.05), r(128 * 62, scale=0.1), r(128)
+    lens = torch.randint(max(1, Ti // 3), Ti + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = Ti
+    lens = lens.to(DEV)
+    w, wprev = torch.softmax(r(B, Ti), 1), torch.softmax(r(B, Ti), 1)
+    cum = torch.rand(B, Ti, generator=g).to(DEV)
+    q, dctx, dwx = r(B, 128), r(B, E), r(B, Ti)
+    mem16 = mem.bfloat16() if bf16 else None
+    # cell operands: activated gates in (0,1) / (-1,1), cell states, dropout masks, upstream gradient slabs
+    def cell_inputs(H, seed):
+        gg = G(seed)
+        rr = lambda *s: torch.randn(*s, generator=gg).to(DEV)
+        gates = torch.cat([torch.sigmoid(rr(B, H)), torch.sigmoid(rr(B, H)), torch.tanh(rr(B, H)), torch.sigmoid(rr(B, H))], 1)
+        return dict(gates=gates.contiguous(), c=rr(B, H), c_prev=None if first else rr(B, H),
+                    keep=(torch.rand(B, H, generator=gg) > 0.1).to(torch.uint8).to(DEV),
+                    up2=rr(2, B, H + 64), up1=rr(B, H + 32), dc0=rr(B, H))
+    cqi = cell_inputs(Hq, 31)
+    cxi = cell_inputs(Hx, 32) if Hx else None
+
+    def run(fold):
+        ws = torch.zeros(nv.attn_bwd_ws_floats(B, Ti), device=DEV)
+        gg = G(77)
+        dwin, dcum = (torch.randn(S, B, 2, Ti, generator=gg) * 0.1).to(DEV), (torch.randn(B, Ti, generator=gg) * 0.1).to(DEV)
+        d_pm, dU, dv_ = torch.zeros(B, Ti, 128, device=DEV), torch.zeros(B, 128, 62, device=DEV), torch.zeros(B, 128, device=DEV)
+        dq, dh = torch.empty(B, 128, device=DEV), torch.zeros(S, B, Hq, device=DEV)
+        tot = torch.empty(B, E, device=DEV)
+        st = {}
+        for name, ci, H in (("q", cqi, Hq), ("x", cxi, Hx)):
+            if ci is None:
+                continue
+            st[name] = dict(dc=ci['dc0'].clone(), dg=torch.full((B, 4 * H), float('nan'), device=DEV),
+                            dg16=torch.zeros(B, 4 * H, dtype=torch.bfloat16, device=DEV) if bf16 else None)
+        outs = []
+        for step in range(3):
+            descs = {}
+            for name, ci, H in (("q", cqi, Hq), ("x", cxi, Hx)):
+                if ci is None:
+                    continue
+                # dh[0]: two partial slabs (a split-K dgrad output, column offset 64), dh[1]: the dh_out slabs (cell_q) or
+                # a plain addend (cell_x), dh[2]: absent for cell_x, a one-slab addend at column offset 32 for cell_q
+                d0 = (ci['up2'][0, :, 64:], 2, ci['up2'].stride(0))
+                d1 = (dh[0], S, dh.stride(0)) if name == "q" else ci['up1'][:, 32:]
+                d2 = ci['up1'][:, 32:] if name == "q" else None
+                descs[name] = nv.lstm_bwd_desc(B, H, [d0, d1, d2], ci['gates'], ci['c_prev'], ci['c'], ci['keep'], 1.0 / 0.9,
+                                               st[name]['dc'], st[name]['dg'], dgates16=st[name]['dg16'])
+            args = ([dctx], tot, dwx, q, Wq, U, v, pm, mem, lens, w, wprev, cum, dwin, dcum, d_pm, dU, dv_, dq, dh, ws)
+            if fold:
+                nv.attention_step_bwd(*args, bf16=bf16, memory16=mem16, cell_q=descs["q"], cell_x=descs.get("x"))
+            else:
+                nv.attention_step_bwd(*args, bf16=bf16, memory16=mem16)
+                nv.lstm_pointwise_bwd2(descs["q"], descs.get("x"))
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (tot, dwin, dcum, d_pm, dU, dv_, dq)] +
+                        [t.clone() for n in sorted(st) for t in (st[n]['dc'], st[n]['dg'], st[n]['dg16']) if t is not None])
+        return outs
+
+    ref, got = run(False), run(True)
+    assert all(torch.isfinite(t.float()).all() for t in ref[-1])
+    for step, (a_, b_) in enumerate(zip(ref, got)):
+        for i, (x, y) in enumerate(zip(a_, b_)):
+            assert torch.equal(x, y), (step, i, (x.float() - y.float()).abs().max().item())
+
+
 def test_attention_energy_kernel_forms_agree():
     """K_e has three forms (attention.hip): one utterance per workgroup in the latency-shaped register allocation, the
     same with room for two workgroups per CU, and four utterances per workgroup with the W_q slice kept in registers

@@ -238,6 +238,41 @@ def test_two_stream_loops_are_bitwise_identical(native_lib):
             assert torch.equal(res[0][1][k], other[1][k]), k
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["tiny_train", "default_train"])
+def test_bptt_cell_fold_is_bitwise_identical(native_lib, name, precision):
+    """t2amd_set_bptt_cell_fold(1): the LSTM cell backwards of every decoder BPTT step run inside the step's
+    attention-backward launch (5 dependent launches per time step instead of 6).  The folded kernel adds the same partial
+    sums in the same order and shares the cell arithmetic with the stand-alone kernel (csrc/cell_bwd.h), so every gradient
+    must equal the unfolded run bit for bit, in both compute modes."""
+    from tacotron2_amd import native
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    fx = gu.load_fixture(name)
+    hp = gu.make_hparams(fx['hp'])
+    sd = gu.build_state_dict(hp, fx['seed'])
+    batch = gu.make_train_batch(fx['in_lens'], fx['out_lens'], hp.n_mel_channels, fx['seed'])
+    masks = gu.unpack_masks(fx['masks'])
+    res = []
+    start = native.get_bptt_cell_fold()
+    try:
+        for fold in (0, 1, 1):
+            native.set_bptt_cell_fold(fold)
+            model = _model(hp, sd).train()
+            model.precision = precision
+            model.dropout_masks = gu.masks_to_engine(masks, DEV)
+            x, y = model.parse_batch(tuple(t.clone() for t in batch))
+            out = model(x)
+            Tacotron2Loss()(out, y).backward()
+            torch.cuda.synchronize()
+            res.append({k: p.grad.cpu() for k, p in model.named_parameters()})
+    finally:
+        native.set_bptt_cell_fold(start)
+    assert all(torch.isfinite(g).all() for g in res[0].values())
+    for other in res[1:]:
+        for k in res[0]:
+            assert torch.equal(res[0][k], other[k]), (k, (res[0][k] - other[k]).abs().max().item())
+
+
 def test_bf16_compute_mode_train_step(native_lib):
     """precision='bf16' (throughput mode): matrix operands rounded to bf16, f32 accumulation / state / master
     weights.  Its own, stated tolerance (the reference under bf16 autocast already drifts from
