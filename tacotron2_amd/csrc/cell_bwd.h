@@ -70,6 +70,9 @@ __device__ __forceinline__ CellOperands cell_bwd_issue(const t2amd_lstm_bwd& a, 
 // dh = (d0 + d1) + d2 in that order (the three addends of t2amd_lstm_bwd.dh, each already summed over its slabs)
 __device__ __forceinline__ void cell_bwd_finish(const t2amd_lstm_bwd& a, const CellOperands& r, const float4& d0,
                                                 const float4& d1, const float4& d2, int b, int j) {
+    // no mul+add contraction in here: which products the compiler fuses depends on the surrounding kernel, and the two
+    // kernels that share this function must agree bit for bit (tests/test_kernels_gpu.py, folded cells)
+#pragma clang fp contract(off)
     const int H = a.H;
     float* dg = a.dgates + (long long)b * a.ld_dgates + j;
     float* dcp = a.dc + (long long)b * a.ld_dc + j;

@@ -14,7 +14,7 @@
 // chunk of T2_CHUNK steps.  Default is 1 (single stream, the two chains share fused launches): on this chip
 // the two queues did not overlap any better than the fused launches do (round-1 A/B).
 #define T2_CHUNK 8
-#define T2_CELL_FOLD_DEFAULT 0      // (until the folded form has run the GPU suite: see DESIGN.md section 5)
+#define T2_CELL_FOLD_DEFAULT 1      // measured on MI355X: 64.9 vs 68.0 ms per training step, bit-identical gradients (profiles/r02_w_ab_cell_fold.json)
 static int g_dec_streams = 1;   // measured on MI355X: 2 streams 134.3 ms/step vs 131.5 ms fused single stream
 static hipStream_t g_side = nullptr;
 static std::vector<hipEvent_t> g_events;
