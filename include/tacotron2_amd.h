@@ -464,9 +464,19 @@ typedef struct t2amd_attn_bwd {
      * call. */
     const t2amd_lstm_bwd* cell_q;
     const t2amd_lstm_bwd* cell_x;
+    /* Size of ws in floats, or 0 = "the minimum".  With at least t2amd_attn_bwd_ws_floats(B, Ti) floats (zeroed once from
+     * word B*Ti on) the first hand-off of the one-launch form may travel as 8-byte {launch token, value} granules in the
+     * block behind the token words (t2amd_set_attn_bwd_granules). */
+    long long ws_floats;
 } t2amd_attn_bwd;
 
 int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);
+/* floats of ws that every form of the call can use: dw slab, slice partials, two token blocks, granule block */
+long long t2amd_attn_bwd_ws_floats(int B, int Ti);
+/* First hand-off of the one-launch form (dw slices between the four workgroups of an utterance): 1 = 8-byte
+ * {token, value} granules polled by their consumers, 0 = write-through stores + drain + token + payload loads,
+ * -1 = library default / environment T2AMD_ATTN_GRANULES.  Bit-identical results. */
+int t2amd_set_attn_bwd_granules(int on);
 
 /* ------------------------------------------------------------------------------------
  * Device-resident time loops.  One host call enqueues every step's kernels.

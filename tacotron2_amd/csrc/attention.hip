@@ -750,6 +750,7 @@ struct AttnBwdParams {
     t2amd_attn_bwd a; int tip; int np; int dbg; unsigned long long* ts; unsigned token; int kb1_smem_off; int fused_delay;
     t2amd_lstm_bwd cq, cx;      // CELL form: the folded cells by value (cq: takes W_q^T dq; cx: the independent one)
     int cx_q4;                  // cx.H / 16 = float4 unit groups of cx per workgroup; 0 = no cx
+    long long gran_off;         // GRAN: float offset of the granule block in a.ws (8-byte aligned address)
 };
 
 // K_b1: dctx, dw[ti] = dctx . memory[ti] + carries, partial sum_ti w dw over a quarter of the positions.
@@ -763,7 +764,15 @@ struct AttnBwdParams {
 // so two column groups cover E <= 512 and the kernel moves half the bytes it is bound by; dctx and the sums stay f32.
 // The body is a device function so that the fused backward kernel (below) can run it as its first phase; `ts_on` is
 // the caller's phase-stamp switch.
-template <bool M16>
+// GRAN (one-launch form only): dw and the partial sum leave as 8-byte {launch token, f32} granules -- one write-through
+// store each, the data is the flag (Guideline 16 R2, as in csrc/decode_persist.hip) -- into the granule block of ws:
+// one row of Ti + NTS granules per utterance, dw[0 .. Ti) then the NTS partial sums (so that a consumer thread polls
+// exactly one granule: thread i < Ti + NTS the i-th of its utterance's row).
+typedef unsigned long long at_u64;
+__device__ __forceinline__ void gran_publish(at_u64* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((at_u64)tag << 32) | (at_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool M16, bool GRAN>
 __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, const int ts, const int b, bool& ts_on) {
     constexpr int CPT = M16 ? 8 : 4;           // channels per 16-byte load
     constexpr int KB1_MAXC = M16 ? 2 : 4;      // column groups kept in registers: KB1_MAXC x 32 loads = E <= 512
@@ -901,6 +910,7 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
     const int len = len_raw;
     __syncthreads();
     float* __restrict__ dwo = a.ws + (long long)b * Ti;
+    at_u64* __restrict__ gdw = reinterpret_cast<at_u64*>(a.ws + p.gran_off) + (long long)b * (Ti + NTS);
     T2_TS(33);
     float psum = 0.f;
     for (int r0 = 0; r0 < tsz; r0 += KB1_NG * KB1_MAXP) {
@@ -958,7 +968,8 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
             if (l32 == 0 && ti < t1) {
                 const float dw = ((ti < len) ? s : 0.f) + base_s[li];
                 // device-scope (write-through) stores: what the fused kernel's hand-off publishes
-                __hip_atomic_store(&dwo[ti], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (GRAN) gran_publish(gdw + ti, p.token, dw);
+                else __hip_atomic_store(&dwo[ti], dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 psum = fmaf(wl_s[li], dw, psum);
             }
         }
@@ -972,7 +983,8 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
         float s = red_s[0];
 #pragma unroll
         for (int w = 1; w < KB1_NT / 64; ++w) s += red_s[w];
-        __hip_atomic_store(&a.ws[(long long)B * Ti + (long long)ts * B + b], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (GRAN) gran_publish(reinterpret_cast<at_u64*>(a.ws + p.gran_off) + (long long)b * (Ti + NTS) + Ti + ts, p.token, s);
+        else __hip_atomic_store(&a.ws[(long long)B * Ti + (long long)ts * B + b], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     T2_TS(35);
 }
@@ -981,7 +993,7 @@ template <bool M16>
 __global__ __launch_bounds__(KB1_NT) void attn_bwd_dw_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
-    kb1_phase<M16>(p, smem, blockIdx.x, blockIdx.y, ts_on);
+    kb1_phase<M16, false>(p, smem, blockIdx.x, blockIdx.y, ts_on);
 }
 
 // The folded cells' descriptors (AttnBwdParams.cq / .cx, ~100 scalar fields) are read from the kernel-argument segment
@@ -1010,9 +1022,10 @@ __device__ __forceinline__ const t2amd_lstm_bwd& kernarg_cell_late(size_t offset
 // workgroup ds forms the product for columns [ds Hq/4, (ds+1) Hq/4) over all 128 dims: eight 64-thread groups take 16
 // dims each -- exactly the 16-dim partial sums the dh_out slabs are made of -- and the closing reduction adds them in
 // the order a separate cell launch adds the slabs, so every bit of the result is the same.
-template <bool FUSED, bool M16, bool CELL>
+template <bool FUSED, bool M16, bool CELL, bool GRAN>
 __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) {
     static_assert(FUSED || !CELL, "the folded cells need the one-launch form");
+    static_assert(FUSED || !GRAN, "granules are the one-launch form's first hand-off");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     const t2amd_attn_bwd& a = p.a;
@@ -1074,8 +1087,40 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dqa[dt][r] = 0.f;
         }
     bool poison = false;
-    if constexpr (FUSED) {
-        kb1_phase<M16>(p, smem + p.kb1_smem_off, ds, b, ts_on);
+    if constexpr (FUSED && GRAN) {
+        // First hand-off, granule form: no drain, no token, no second round trip -- every thread polls the granule of its
+        // own position (threads Ti .. Ti+3 the four partial sums) until it carries this launch's token.  The poll sits
+        // behind the wave's own K_b1 stores in the memory queue (operations complete in order), which is about when the
+        // partners' granules land as well.  The slice sums travel through dq_s[0..3], the give-up flag through dq_s[4]
+        // (dq_s proper is written after the tile loop).
+        int* const gflag_s = reinterpret_cast<int*>(dq_s + 4);
+        if (tid == 0) gflag_s[0] = 0;                  // published by the barriers inside kb1_phase
+        kb1_phase<M16, true>(p, smem + p.kb1_smem_off, ds, b, ts_on);
+        const at_u64* grow = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + (long long)b * (Ti + NTS);   // (uniform)
+        const int gi = tid < Ti + NTS ? tid : Ti + NTS - 1;          // Ti + NTS <= 512 (host check)
+        for (int d_ = 0; d_ < p.fused_delay; ++d_) __builtin_amdgcn_s_sleep(1);
+        at_u64 xd = __hip_atomic_load(grow + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            // bounded like every spin here: 50 ms of the 100 MHz wall clock, then NaN instead of a hung GPU
+            const long long t0_ = wall_clock64();
+            unsigned spins_ = 0;
+            bool bad = false;
+            for (;;) {
+                if (__all((unsigned)(xd >> 32) == p.token)) break;
+                __builtin_amdgcn_s_sleep(1);
+                xd = __hip_atomic_load(grow + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; break; }
+            }
+            if (bad && lane == 0) gflag_s[0] = 1;
+        }
+        dw_r = __uint_as_float((unsigned)xd);
+        if (tid >= Ti && tid < Ti + NTS) dq_s[tid - Ti] = dw_r;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NTS; ++k) sdv[k] = dq_s[k];
+        poison = gflag_s[0] != 0;
+    } else if constexpr (FUSED) {
+        kb1_phase<M16, false>(p, smem + p.kb1_smem_off, ds, b, ts_on);
         // hand-off (write-through form): K_b1's outputs were stored with device-scope (sc1, write-through) stores; every
         // wave waits for their acknowledgement (explicit s_waitcnt vmcnt(0) below), then thread 0 publishes the
         // launch token; consumers poll it and read the payload with device-scope loads -- no L2 write-back /
@@ -1444,6 +1489,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dqall_s[64 + lane] = bad ? __builtin_nanf("") : q1;
         }
         __syncthreads();
+        T2_TS(54);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int dd = 0; dd < 16; ++dd) {
@@ -1472,7 +1518,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             const float4 d0 = addend_finish4(cq_s0, cq.dh[0], b, cq_j), d2 = addend_finish4(cq_s2, cq.dh[2], b, cq_j);
             cell_bwd_finish(cq, cq_r, d0, d1, d2, b, cq_j);
         }
-        T2_TS(54);
+        T2_TS(55);
         return;
     }
     __syncthreads();   // dq_s
@@ -1515,7 +1561,19 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
 }
 
 static int g_attn_bwd_lds = 0, g_attn_bwd_lds_fused = 0, g_attn_bwd_lds_cell = 0;
+#define T2_ATTN_GRANULES_DEFAULT 0
+static int g_attn_gran = -1;               // -1: environment / default; 0 / 1: t2amd_set_attn_bwd_granules
+extern "C" int t2amd_set_attn_bwd_granules(int on) {
+    T2_REQUIRE(on == 0 || on == 1 || on == -1, "set_attn_bwd_granules: -1 (default), 0 or 1");
+    g_attn_gran = on;
+    return T2AMD_OK;
+}
 static unsigned g_attn_bwd_token = 0;      // one launch counter for both one-launch forms: a token never repeats in ws (never zero)
+
+extern "C" long long t2amd_attn_bwd_ws_floats(int B, int Ti) {
+    const long long goff = ((long long)B * Ti + 12ll * B + 1) / 2 * 2;
+    return goff + 2ll * B * Ti + 2ll * NTS * B;
+}
 
 extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream) {
     T2_REQUIRE(a && a->dctx_total && a->q && a->Wq && a->U && a->v && a->pm && a->memory && a->w &&
@@ -1560,7 +1618,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     // CELL form: dh_s grows from [Hq] to [2 Hq] (eight 16-dim partials per column), + the utterance's dq + a flag
     const size_t lds2c = lds2 + sizeof(float) * ((size_t)a->Hq + AD + 4);
     if ((int)lds2 > 64 * 1024 && (int)lds2 > g_attn_bwd_lds && !t2amd_validate_only_flag_()) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         g_attn_bwd_lds = (int)lds2;
     }
     T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && a->E % 8 == 0), "attn_bwd: memory16 must be 16-byte aligned, E a multiple of 8");
@@ -1573,6 +1631,13 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     static const bool fused = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
     static const int fused_delay = [] { const char* e = getenv("T2AMD_ATTN_FUSED_DELAY"); const int v = e ? atoi(e) : 16; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
     p.fused_delay = fused_delay;
+    // First hand-off as granules (T2AMD_ATTN_GRANULES=0/1): needs the granule block of ws (t2amd_attn_bwd.ws_floats),
+    // 8-byte aligned, and one granule per thread (Ti <= 512: always true within the LDS limit above)
+    static const bool gran_env = [] { const char* e = getenv("T2AMD_ATTN_GRANULES"); return e ? e[0] != '0' : T2_ATTN_GRANULES_DEFAULT != 0; }();
+    p.gran_off = ((long long)a->B * a->Ti + 12ll * a->B + 1) / 2 * 2;
+    const bool gran = (g_attn_gran < 0 ? gran_env : g_attn_gran != 0) && a->Ti + NTS <= KB2_NT &&
+                      a->ws_floats >= p.gran_off + 2ll * a->B * a->Ti + 2ll * NTS * a->B &&
+                      (reinterpret_cast<uintptr_t>(a->ws + p.gran_off) & 7u) == 0;
     p.cx_q4 = 0;
     p.cq = t2amd_lstm_bwd{};
     p.cx = t2amd_lstm_bwd{};
@@ -1590,13 +1655,20 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         p.kb1_smem_off = (int)(l2a / sizeof(float));
         const size_t ldsf = l2a + lds1;
         if ((int)ldsf > 64 * 1024 && (int)ldsf > g_attn_bwd_lds_cell && !t2amd_validate_only_flag_()) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
-            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             g_attn_bwd_lds_cell = (int)ldsf;
         }
         t2amd_profile_mark_(4, 0, s);
-        if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
-        else T2_LAUNCH((attn_bwd_main_kernel<true, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        if (gran) {
+            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH((attn_bwd_main_kernel<true, false, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        } else {
+            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH((attn_bwd_main_kernel<true, false, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        }
         t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
@@ -1608,20 +1680,27 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         p.kb1_smem_off = (int)(l2a / sizeof(float));
         const size_t ldsf = l2a + lds1;
         if ((int)ldsf > 64 * 1024 && (int)ldsf > g_attn_bwd_lds_fused && !t2amd_validate_only_flag_()) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
-            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
+            (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             g_attn_bwd_lds_fused = (int)ldsf;
         }
         t2amd_profile_mark_(4, 0, s);
-        if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
-        else T2_LAUNCH((attn_bwd_main_kernel<true, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        if (gran) {
+            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH((attn_bwd_main_kernel<true, false, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        } else {
+            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH((attn_bwd_main_kernel<true, false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+        }
         t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
     } else {
         t2amd_profile_mark_(4, 0, s);          // role 4: the attention backward pair of one time step (bench.py roofline)
         if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
         else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
-        T2_LAUNCH((attn_bwd_main_kernel<false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
+        T2_LAUNCH((attn_bwd_main_kernel<false, false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
         t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
     }

@@ -234,7 +234,8 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     // the backward's attention workspace sits behind the forward's four partial-energy slabs; its 8*B tail holds the
     // slice partials and the hand-off tokens of the fused backward kernel: zeroed once, tokens are never zero
     float* const bwd_ws = f.attn_ws + (long long)T2AMD_ATT_SLICES * B * Ti;
-    T2_PROPAGATE(t2amd_fill_f32(bwd_ws + (long long)B * Ti, 12ll * B, 0.f, stream));
+    const long long bwd_ws_floats = t2amd_attn_bwd_ws_floats(B, Ti);
+    T2_PROPAGATE(t2amd_fill_f32(bwd_ws + (long long)B * Ti, bwd_ws_floats - (long long)B * Ti, 0.f, stream));
 
     // The decoder-LSTM BPTT chain (cell backward -> dgrad GEMM) depends only on itself and on the
     // projection gradient; the attention chain consumes its dX one step later.  So the loop is
@@ -279,7 +280,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.w = f.ALIGN + (long long)t * Ti; ab.ld_w = (long long)To * Ti;
         ab.w_prev = t ? f.ALIGN + (long long)(t - 1) * Ti : nullptr; ab.ld_wprev = (long long)To * Ti;
         ab.cum_before = f.CUM + (long long)t * B * Ti;
-        ab.dwin_part = p->dwin_part; ab.dcum_acc = p->dcum_acc; ab.ws = bwd_ws;
+        ab.dwin_part = p->dwin_part; ab.dcum_acc = p->dcum_acc; ab.ws = bwd_ws; ab.ws_floats = bwd_ws_floats;
         ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;

@@ -147,6 +147,7 @@ class AttnBwd(C.Structure):
         ("bf16", C.c_int),
         ("memory16", C.c_void_p),
         ("cell_q", C.POINTER(LstmBwd)), ("cell_x", C.POINTER(LstmBwd)),
+        ("ws_floats", _i64),
     ]
 
 
@@ -265,7 +266,8 @@ SYMBOLS = [
     "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
-    "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
+    "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
+    "t2amd_set_attn_bwd_granules", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
@@ -325,6 +327,8 @@ def _argtypes():
         "t2amd_set_decoder_streams": [_I],
         "t2amd_set_bptt_cell_fold": [_I],
         "t2amd_get_bptt_cell_fold": [],
+        "t2amd_attn_bwd_ws_floats": [_I, _I],
+        "t2amd_set_attn_bwd_granules": [_I],
         "t2amd_lstm_step_small_f32": [pt(LstmStep), _P],
         "t2amd_linear_small_f32": [pt(SmallLinear), _P],
         "t2amd_profile_enable": [_I, _I],
@@ -374,6 +378,7 @@ def load():
     lib.t2amd_reflect_index.argtypes = [_L, _L]
     lib.t2amd_reflect_index.restype = C.c_longlong
     lib.t2amd_abi_version.restype = C.c_int
+    lib.t2amd_attn_bwd_ws_floats.restype = C.c_longlong
     lib.t2amd_decoder_persist_mailbox_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
@@ -985,8 +990,13 @@ def attn_fwd_ws_floats(B, Ti):
 
 
 def attn_bwd_ws_floats(B, Ti):
-    """dw slab + slice partials + the token blocks of the two hand-offs (the second one: folded cells only)."""
-    return B * Ti + 12 * B
+    """dw slab + slice partials + the token blocks of the two hand-offs + the granule block (t2amd_attn_bwd_ws_floats)."""
+    return int(load().t2amd_attn_bwd_ws_floats(int(B), int(Ti)))
+
+
+def set_attn_bwd_granules(on):
+    """First hand-off of the one-launch attention backward: 1 granules, 0 drained stores + token, -1 library default."""
+    _check(load().t2amd_set_attn_bwd_granules(int(on)), "t2amd_set_attn_bwd_granules")
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,
@@ -1048,6 +1058,7 @@ def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory
     if ws.numel() < attn_bwd_ws_floats(B, Ti):
         raise NativeError("attention_step_bwd: workspace too small")
     a.ws = ptr(_fullc(ws))
+    a.ws_floats = ws.numel()
     a.bf16 = 1 if bf16 else 0
     if memory16 is not None:
         a.memory16 = ptr(_fullc(memory16), torch.bfloat16)

@@ -527,22 +527,25 @@ torch.cuda.synchronize()
 torch.save([t.cpu() for t in (tot, dwin, dcum, d_pm, dU, dv_, dq, dh)], sys.argv[1])
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for fused in ("0", "1"):
+    # third run: the one-launch form with the first hand-off as {token, value} granules (T2AMD_ATTN_GRANULES=1)
+    for fused, gran in (("0", "0"), ("1", "0"), ("1", "1")):
         with tempfile.NamedTemporaryFile(suffix=".pt", delete=False) as fh:
             path = fh.name
-        env = dict(os.environ, T2AMD_ATTN_FUSED_BWD=fused)
+        env = dict(os.environ, T2AMD_ATTN_FUSED_BWD=fused, T2AMD_ATTN_GRANULES=gran)
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=120)
         res.append(torch.load(path))
         os.unlink(path)
-    for x, y in zip(*res):
-        assert torch.equal(x, y)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("gran", [0, 1])
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("B,Ti,E,Hq,Hx,first", [(3, 37, 128, 128, 128, False), (5, 150, 512, 1024, 1024, False),
                                                 (64, 187, 512, 1024, 1024, False), (2, 300, 512, 1024, 512, False),
                                                 (4, 21, 256, 256, 0, True), (3, 60, 128, 136, 128, False)])
-def test_attention_backward_folded_cells_bitwise(nv, B, Ti, E, Hq, Hx, first, bf16):
+def test_attention_backward_folded_cells_bitwise(nv, B, Ti, E, Hq, Hx, first, bf16, gran):
     """t2amd_attn_bwd.cell_q / cell_x: the LSTM cell backwards of a BPTT step run as the closing phase of the
     attention-backward launch.  Against the separate t2amd_lstm_pointwise_bwd2_f32 launch fed by the dh_out slabs, every
     output of the attention step and of both cells (gate gradients f32 + bf16, dc carry) must be bit-identical: the
@@ -550,7 +553,8 @@ def test_attention_backward_folded_cells_bitwise(nv, B, Ti, E, Hq, Hx, first, bf
     (carries, accumulators and the dc carries feed the next call; the hand-off tokens change per launch).  B = 64 fills
     the chip like the training step; Ti = 300 gives the polling wave col2im stores of its own; Hx = 0: no second cell
     (time step 0 of the loop); first: no previous cell state; Hq = 136 is a geometry the folded kernel does not cover
-    (the call then launches the cells itself)."""
+    (the call then launches the cells itself).  gran = 1: the folded run also takes the granule form of the first hand-off
+    (t2amd_set_attn_bwd_granules), the reference run the drained-stores-and-token form."""
     S = nv.ATT_SLICES
     g = G(900 + B + Ti)
     r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
@@ -611,7 +615,13 @@ def test_attention_backward_folded_cells_bitwise(nv, B, Ti, E, Hq, Hx, first, bf
                         [t.clone() for n in sorted(st) for t in (st[n]['dc'], st[n]['dg'], st[n]['dg16']) if t is not None])
         return outs
 
-    ref, got = run(False), run(True)
+    try:
+        nv.set_attn_bwd_granules(0)
+        ref = run(False)
+        nv.set_attn_bwd_granules(gran)
+        got = run(True)
+    finally:
+        nv.set_attn_bwd_granules(-1)
     assert all(torch.isfinite(t.float()).all() for t in ref[-1])
     for step, (a_, b_) in enumerate(zip(ref, got)):
         for i, (x, y) in enumerate(zip(a_, b_)):

@@ -14,7 +14,7 @@ Wq, U, v = rnd(128, Hq) * 0.05, rnd(128 * 62) * 0.1, rnd(128)
 lens = torch.randint(60, Ti + 1, (B,), generator=g).sort(descending=True)[0].to(torch.int32).to(dev)
 wprev = torch.softmax(rnd(B, Ti), 1); cum = torch.rand(B, Ti, device=dev)
 cum_save, w_out, ctx, q = torch.empty(B, Ti, device=dev), torch.empty(B, Ti, device=dev), torch.empty(B, E, device=dev), torch.empty(B, 128, device=dev)
-ws = torch.empty(nv.attn_fwd_ws_floats(B, Ti) + nv.attn_bwd_ws_floats(B, Ti), device=dev)
+ws = torch.zeros(nv.attn_fwd_ws_floats(B, Ti) + nv.attn_bwd_ws_floats(B, Ti), device=dev)     # token and granule words must start at zero
 dctx, dctx_total = rnd(B, E), torch.empty(B, E, device=dev)
 dwin, dcum = torch.zeros(4, B, 2, Ti, device=dev), torch.zeros(B, Ti, device=dev)
 d_pm, dU, dv_, dq, dh = torch.zeros(B, Ti, 128, device=dev), torch.zeros(B, 128, 62, device=dev), torch.zeros(B, 128, device=dev), torch.empty(B, 128, device=dev), torch.empty(4, B, Hq, device=dev)

@@ -37,7 +37,7 @@ assert lib.t2amd_debug_attn_ts_(buf) == 0, "stamps are off: set T2AMD_ATTN_TS=1"
 names = [(0, "K_e   (entry, prologue done, tiles done)"),
          (16, "K_c   (entry, max, sum, weights, context partials, end)"),
          (32, "K_b1  (entry, operands staged, dw done, end)"),
-         (48, "K_b2  (entry, prologue, tiles, reduce, dU, col2im, dh)"),
+         (48, "K_b2  (entry, prologue, tiles, reduce, dU, col2im, dh | folded cells: dq collected, end)"),
          (64, "LSTM pair  (entry, first DMA, tile 0 landed, k loop, partial sums, end)"),
          (80, "dgrad pair (entry, first DMA, tile 0 landed, k loop, partial sums, end)"),
          (96, "cell bwd   (entry, operands landed, end)")]
