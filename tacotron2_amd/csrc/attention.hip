@@ -1306,6 +1306,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
 #pragma unroll
         for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (t8 < H4 ? t8 : 0)];
     }
+    T2_TS(56);
     // ... and the read-modify-write operand of this wave's dU tile (wave w owns tap tile w&3, dim tile w>>2)
     float dU_old[4];
     {
@@ -1325,7 +1326,9 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 red_s[(wv * 2 + 1) * DSL + dt * 16 + 4 * lg + r] = y;
             }
         }
+    T2_TS(57);
     __syncthreads();
+    T2_TS(58);
     if (tid < DSL) {
         float dvs = 0.f, dqs = 0.f;
 #pragma unroll
@@ -1561,7 +1564,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
 }
 
 static int g_attn_bwd_lds = 0, g_attn_bwd_lds_fused = 0, g_attn_bwd_lds_cell = 0;
-#define T2_ATTN_GRANULES_DEFAULT 0
+#define T2_ATTN_GRANULES_DEFAULT 1      // measured on MI355X: 64.1 vs 65.3 ms per training step (profiles/r02_y_ab_fold_granules.json)
 static int g_attn_gran = -1;               // -1: environment / default; 0 / 1: t2amd_set_attn_bwd_granules
 extern "C" int t2amd_set_attn_bwd_granules(int on) {
     T2_REQUIRE(on == 0 || on == 1 || on == -1, "set_attn_bwd_granules: -1 (default), 0 or 1");
@@ -1629,8 +1632,9 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     // drain the stores before the token and was therefore racy; with the drain round 2 measures 71.5 vs 72.1 ms over 16
     // steps, twice (profiles/r02_i_fused_bwd_after_fix.txt).  Bit-identical to the two-launch path (tests).
     static const bool fused = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
-    static const int fused_delay = [] { const char* e = getenv("T2AMD_ATTN_FUSED_DELAY"); const int v = e ? atoi(e) : 16; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
-    p.fused_delay = fused_delay;
+    // pre-poll pause in s_sleep units: 16 for the token form; the granule form is flat from 4 to 16 (63.7 / 63.55 / 63.8 ms
+    // per training step at 4 / 8 / 16; 64.2 at 0, 64.9 at 64: profiles/r02_y_granule_delay_sweep.txt)
+    static const int fused_delay_env = [] { const char* e = getenv("T2AMD_ATTN_FUSED_DELAY"); const int v = e ? atoi(e) : -1; return v > 100 ? 100 : v; }();
     // First hand-off as granules (T2AMD_ATTN_GRANULES=0/1): needs the granule block of ws (t2amd_attn_bwd.ws_floats),
     // 8-byte aligned, and one granule per thread (Ti <= 512: always true within the LDS limit above)
     static const bool gran_env = [] { const char* e = getenv("T2AMD_ATTN_GRANULES"); return e ? e[0] != '0' : T2_ATTN_GRANULES_DEFAULT != 0; }();
@@ -1638,6 +1642,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     const bool gran = (g_attn_gran < 0 ? gran_env : g_attn_gran != 0) && a->Ti + NTS <= KB2_NT &&
                       a->ws_floats >= p.gran_off + 2ll * a->B * a->Ti + 2ll * NTS * a->B &&
                       (reinterpret_cast<uintptr_t>(a->ws + p.gran_off) & 7u) == 0;
+    p.fused_delay = fused_delay_env >= 0 ? fused_delay_env : (gran ? 8 : 16);
     p.cx_q4 = 0;
     p.cq = t2amd_lstm_bwd{};
     p.cx = t2amd_lstm_bwd{};

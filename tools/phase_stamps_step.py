@@ -45,3 +45,7 @@ for base, nm in names:
     ts = [buf[base + i] for i in range(15) if buf[base + i]]
     if ts:
         print("%-78s %s" % (nm, " ".join("%.2f" % ((t - ts[0]) / 100.0) for t in ts)))
+# K_b2's reduce phase in detail (slots 56-58: W_q / cell prefetch issued, lane-group sums written, barrier passed)
+if buf[48] and buf[56]:
+    print("K_b2 detail: tiles done %.2f | prefetch issued %.2f | sums in LDS %.2f | barrier passed %.2f | dq stored %.2f" %
+          tuple((buf[i] - buf[48]) / 100.0 for i in (50, 56, 57, 58, 51)))
