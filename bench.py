@@ -410,11 +410,20 @@ def main():
             ti_sum = float(batches[-1][1].sum().item())
             ab_bytes = es * 640.0 * ti_sum                    # the encoder memory + its projection, once per step
             ab_s = max((ms4 / 1e3) / cnt4 - ev4 / 1e3, 1e-9)
+            folded = bool(native.get_bptt_cell_fold())
+            # with the cells folded in, the launch also moves both LSTMs' saved gates, cell states, masks and carries
+            # and writes the gate gradients (f32 + the bf16 operand copy of the dgrad GEMM in bf16 mode): per hidden
+            # unit 4 gates + c + c_prev + dc in/out + 4 gate gradients = 12 floats, 1 mask byte, 4 bf16
+            hd = hp.attention_rnn_dim + hp.decoder_rnn_dim
+            cell_bytes = B * hd * (12 * 4.0 + 1.0 + (8.0 if es == 2.0 else 0.0)) if folded else 0.0
             roofline["attention_backward"] = {
-                "kernels": "attn_bwd_dw_kernel + attn_bwd_main_kernel (one decoder time step, hipEventRecord bracket minus "
-                           "the calibrated empty bracket)",
-                "algorithmic_bytes_per_step": ab_bytes, "avg_pair_us": ab_s * 1e6, "empty_bracket_us": ev4 * 1e3,
-                "achieved": ab_bytes / ab_s / 1e9, "unit": "GB/s", "frac": ab_bytes / ab_s / 1e9 / 8000.0, "launches": cnt4}
+                "kernels": ("attn_bwd_main_kernel, one launch per decoder time step: K_b1 phase, granule hand-off, K_b2 "
+                            "phase" + (", the step's two LSTM cell backwards" if folded else "") +
+                            " (hipEventRecord bracket minus the calibrated empty bracket)"),
+                "algorithmic_bytes_per_step": ab_bytes + cell_bytes, "attention_bytes": ab_bytes, "cell_bytes": cell_bytes,
+                "avg_pair_us": ab_s * 1e6, "empty_bracket_us": ev4 * 1e3,
+                "achieved": (ab_bytes + cell_bytes) / ab_s / 1e9, "unit": "GB/s",
+                "frac": (ab_bytes + cell_bytes) / ab_s / 1e9 / 8000.0, "launches": cnt4}
         # ---- the whole training step against SURVEY 8d's per-padded-time-step bound ---------------------------------
         ti_sum = float(batches[-1][1].sum().item())
         per_step = 2.0 * (18189969 * es + 640.0 * ti_sum * es) + 2.0 * B * 12300 * es

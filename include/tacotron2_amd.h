@@ -400,9 +400,19 @@ typedef struct t2amd_attn_fwd {
     const void* memory16;
     /* optional bf16 copy of Wq ([128][Hq] bf16): the query product q = Wq h streams it (h and the sums stay f32) */
     const void* Wq16;
+    /* Size of ws in floats, or 0 = "the minimum".  With at least t2amd_attn_fwd_ws_floats(B, Ti) floats -- the block
+     * behind the partial energies zeroed once -- the step may run as ONE launch whose four workgroups per utterance hand
+     * the partial energies to each other as 8-byte {launch token, value} granules (t2amd_set_attn_fwd_fused). */
+    long long ws_floats;
 } t2amd_attn_fwd;
 
 int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
+/* floats of ws that every form of the call can use (a multiple of 4) */
+long long t2amd_attn_fwd_ws_floats(int B, int Ti);
+/* 1: K_e and K_c of a step run as one launch (energy granules between the four workgroups of an utterance), 0: two
+ * launches, -1: library default / environment T2AMD_ATTN_FWD_FUSED.  Bit-identical results.  The one-launch form serves
+ * launches of at most 512 workgroups (B <= 128) with Ti <= 512. */
+int t2amd_set_attn_fwd_fused(int on);
 
 typedef struct t2amd_attn_bwd {
     int B, Ti, E, Hq;

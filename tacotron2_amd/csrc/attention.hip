@@ -175,7 +175,15 @@ __device__ __forceinline__ float dot8_bf16(const float4& m, const float4& g0, co
     return acc;
 }
 
-struct AttnFwdParams { t2amd_attn_fwd a; int tip; int dbg; unsigned long long* ts; };
+struct AttnFwdParams {
+    t2amd_attn_fwd a; int tip; int dbg; unsigned long long* ts;
+    // one-launch form (attn_fwd_fused_kernel): launch token, float offset of the granule block in a.ws, K_c's LDS offset
+    unsigned token; long long gran_off; int kc_smem_off; int delay;
+};
+typedef unsigned long long at_u64;
+__device__ __forceinline__ void gran_publish(at_u64* g, unsigned tag, float v) {
+    __hip_atomic_store(g, ((at_u64)tag << 32) | (at_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // timing experiments only (tools/microbench_attn.py): T2AMD_ATTN_STAGE=n makes the kernels return after stage n
 // timing experiments only (tools/microbench_attn.py --phases): with T2AMD_ATTN_TS=1 the first thread of workgroup
@@ -212,13 +220,14 @@ static int attn_dbg_stage() {
 // MINW = waves per SIMD the register allocation must leave room for: 2 (one workgroup per CU, every load of the prologue
 // in flight at once -- the latency-bound training / small-batch shape, <= 256 workgroups in a launch) or 4 (two resident
 // workgroups per CU for launches of several rounds of workgroups: batched inference at B = 256 is 1024 of them).
-template <int MINW>
-__global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    bool ts_on = false;
+// The body is a device function so that the one-launch forward (attn_fwd_fused_kernel below) can run it as its first
+// phase.  GRAN: the partial energies leave as 8-byte {launch token, f32} granules, [B][Ti][4 slices], instead of floats.
+// `after_prologue` runs once every prologue load has been issued and h has been staged (i.e. landed): what it issues
+// flies behind the q phase and the tiles without holding up anything of this phase (loads complete in order).
+template <bool GRAN, class Hook>
+__device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, const int ds, const int b, bool& ts_on,
+                                         Hook&& after_prologue) {
     const t2amd_attn_fwd& a = p.a;
-    const int ds = blockIdx.x, b = blockIdx.y;
-    if (a.active && !a.active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int Ti = a.Ti, Hq = a.Hq, TIP = p.tip;
@@ -286,6 +295,7 @@ __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams 
             if (tid < n4) h_s4[tid] = hv;
             for (int j = tid + KE_NT; j < n4; j += KE_NT) h_s4[j] = h4[j];
         }
+        after_prologue();
         __syncthreads();
         if (wq16) {
 #pragma unroll
@@ -342,6 +352,7 @@ __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams 
         for (int r = 0; r < 4; ++r) qv[dt][r] = q_s[dt * 16 + 4 * lg + r];
 
     float* __restrict__ eout = a.ws + ((long long)ds * a.B + b) * Ti;
+    at_u64* __restrict__ gout = reinterpret_cast<at_u64*>(a.ws + p.gran_off) + (long long)b * Ti * NSL + ds;
     int round = 0;
     for (int mt = wv; mt < nmt; mt += KE_NT / 64, ++round) {
         const int pos = mt * 16 + l15;
@@ -368,9 +379,20 @@ __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams 
         e = fmaf(vv[1][3], t2_tanh(acc1[3] + qv[1][3] + pm1.w), e);
         e += __shfl_xor(e, 16, 64);
         e += __shfl_xor(e, 32, 64);
-        if (lg == 0 && pos < Ti) eout[pos] = e;
+        if (lg == 0 && pos < Ti) {
+            if constexpr (GRAN) gran_publish(gout + (long long)pos * NSL, p.token, e);
+            else eout[pos] = e;
+        }
     }
     T2_TS(2);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool ts_on = false;
+    if (p.a.active && !p.a.active[blockIdx.y]) return;
+    ke_phase<false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -554,21 +576,41 @@ __global__ __launch_bounds__(KE_NT) void attn_energy4_kernel(AttnFwdParams p) {
 // M16: the context rows come from a bf16 copy of the encoder memory (t2amd_attn_fwd.memory16, the engine's bf16
 // compute mode): a thread then owns 8 channels (one 16-byte load per row) of twice as many row groups, i.e. half
 // the bytes of the f32 stream this kernel is bound by; weights, accumulation and the context stay f32.
+// The body is split so that the one-launch forward (attn_fwd_fused_kernel) can issue the context rows at its very
+// start (KcPre: everything that does not depend on the energies) and run the rest behind the energy hand-off.
+template <bool M16>
+struct KcPre {
+    static constexpr int MAXR = M16 ? 6 : 12;     // memory rows a thread keeps in registers; longer utterances take extra passes
+    float4 mrow[MAXR];
+    float c_old0;
+    int len;
+};
+template <bool M16, bool LOAD_E> __device__ __forceinline__ void kc_issue(const AttnFwdParams& p, int cs, int b, KcPre<M16>& r, float (&e_first)[4]);
+template <bool M16, bool FUSED> __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, int cs, int b, bool& ts_on,
+                                                                         const KcPre<M16>& r, const float (&e_first)[4]);
+
 template <bool M16>
 __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
-    constexpr int CPT = M16 ? 8 : 4;          // channels per thread
-    constexpr int KC_MAXR = M16 ? 6 : 12;     // memory rows a thread keeps in registers; longer utterances take extra passes
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     const t2amd_attn_fwd& a = p.a;
     const int cs = blockIdx.x, b = blockIdx.y;
     if (a.active && !a.active[b]) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int Ti = a.Ti, E = a.E, B = a.B;
-    float* w_s = smem;                    // [Ti rounded to 4]
     T2_TS(16);
-    float* red_s = w_s + ((Ti + 3) & ~3); // [16]
-    float* part_s = red_s + 16;           // [parts][EC]
+    float e_first[4];
+    KcPre<M16> r;
+    kc_issue<M16, true>(p, cs, b, r, e_first);
+    kc_finish<M16, false>(p, smem, cs, b, ts_on, r, e_first);
+}
+
+// LOAD_E: the four partial energies of this thread's first position are loaded here (two-launch form), first
+template <bool M16, bool LOAD_E>
+__device__ __forceinline__ void kc_issue(const AttnFwdParams& p, const int cs, const int b, KcPre<M16>& r, float (&e_first)[4]) {
+    constexpr int CPT = M16 ? 8 : 4;          // channels per thread
+    constexpr int KC_MAXR = KcPre<M16>::MAXR;
+    const t2amd_attn_fwd& a = p.a;
+    const int tid = threadIdx.x;
+    const int Ti = a.Ti, E = a.E;
     // Length through the scalar path (s_load from the constant address space): a vector load would put it in the same
     // in-order queue as the streams below.
     const int len = a.lens ? *reinterpret_cast<const __attribute__((address_space(4))) int*>(
@@ -587,29 +629,57 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     long long roff[KC_MAXR];
 #pragma unroll
     for (int i = 0; i < KC_MAXR; ++i) roff[i] = (long long)(part + i * parts) * E4;
-    const float* __restrict__ e0 = a.ws + (long long)b * Ti;
-    const long long es = (long long)B * Ti;
     const int tc0 = tid < Ti ? tid : Ti - 1;
-    float* const cum_b = a.cum + (long long)b * Ti;
+    const float* const cum_b = a.cum + (long long)b * Ti;
+    const float* __restrict__ e0 = a.ws + (long long)b * Ti;
+    const long long es = (long long)a.B * Ti;
     __builtin_amdgcn_sched_barrier(0);
 
     // Partial energies of this thread's first position first: loads complete in order, so the softmax below waits
     // for these four only, not for the 1 KB-per-row context stream issued behind them.
-    float e_first[4];
+    if constexpr (LOAD_E) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) e_first[k] = e0[k * es + tc0];
+        for (int k = 0; k < 4; ++k) e_first[k] = e0[k * es + tc0];
+    }
     // slice 0 also carries the cumulative weights forward: its read-modify-write operand is fetched now
-    float c_old0 = 0.f;
-    if (cs == 0) c_old0 = cum_b[tc0];
+    r.c_old0 = 0.f;
+    if (cs == 0) r.c_old0 = cum_b[tc0];
     // The context rows do not depend on the softmax.  Rows past the utterance are clamped to row 0 (an L1 hit) and
     // get weight 0 below: the kernel is bound by the rows it moves, skipping the padding is worth the scalar wait.
-    float4 mrow[KC_MAXR];
 #pragma unroll
     for (int i = 0; i < KC_MAXR; ++i) {
         const int ti = part + i * parts;
-        mrow[i] = M4[ti < len ? roff[i] : 0ll];
+        r.mrow[i] = M4[ti < len ? roff[i] : 0ll];
     }
+    r.len = len;
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// FUSED: Ti <= KC_NT (one position per thread; the host checks), e_first came through the granules
+template <bool M16, bool FUSED>
+__device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, const int cs, const int b, bool& ts_on,
+                                          const KcPre<M16>& r, const float (&e_first)[4]) {
+    constexpr int CPT = M16 ? 8 : 4;
+    constexpr int KC_MAXR = KcPre<M16>::MAXR;
+    const t2amd_attn_fwd& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int Ti = a.Ti, E = a.E, B = a.B;
+    float* w_s = smem;                    // [Ti rounded to 4]
+    float* red_s = w_s + ((Ti + 3) & ~3); // [16]
+    float* part_s = red_s + 16;           // [parts][EC]
+    const int len = r.len;
+    const int EC = E / NCS, EC4 = EC / CPT, E4 = E / CPT;
+    int parts = KC_NT / EC4;
+    if (parts > 32) parts = 32;
+    const int c4 = tid % EC4, part = tid / EC4;
+    const bool worker = part < parts;
+    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(M16 ? a.memory16 : (const void*)a.memory) +
+                                    (long long)b * Ti * E4 + cs * EC4 + c4;
+    const float* __restrict__ e0 = a.ws + (long long)b * Ti;
+    const long long es = (long long)B * Ti;
+    float* const cum_b = a.cum + (long long)b * Ti;
+    const float c_old0 = r.c_old0;
+    const float4 (&mrow)[KC_MAXR] = r.mrow;
 
     float lmax = -INFINITY;
     if (tid < Ti) {
@@ -703,6 +773,72 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
     T2_TS(21);
 }
 
+// ---------------------------------------------------------------------------------------
+// One-launch forward: K_e's phase, energy hand-off, K_c's phase (t2amd_set_attn_fwd_fused).
+//
+// K_e -> K_c is the one boundary of a decoder time step that lies inside an utterance: workgroup (s, b) computes the
+// partial energies of dim slice s, the four workgroups of utterance b exchange them as 8-byte {launch token, f32}
+// granules ([B][Ti][4], one write-through store per position and slice, polled by thread ti of every consumer: the data
+// is the flag), and workgroup (s, b) carries on as K_c for context-channel slice s.  K_c's context rows -- its only
+// long-latency operand -- are issued behind K_e's prologue and land during the q phase and the tiles.  Same per-thread
+// arithmetic and summation order as the two launches: bit-identical weights, context and cumulative weights.
+// ---------------------------------------------------------------------------------------
+template <bool M16>
+__global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams p) {
+    static_assert(KE_NT == KC_NT, "one thread mapping for both phases");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    bool ts_on = false;
+    const t2amd_attn_fwd& a = p.a;
+    const int sl = blockIdx.x, b = blockIdx.y;
+    if (a.active && !a.active[b]) return;
+    const int tid = threadIdx.x;
+    KcPre<M16> r;
+    float e_first[4] = {0.f, 0.f, 0.f, 0.f};
+    ke_phase<true>(p, smem, sl, b, ts_on, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
+    T2_TS(16);
+    {
+        // thread ti < len polls the four granules of position ti (32 contiguous bytes).  Bounded like every spin here:
+        // 50 ms of the 100 MHz wall clock, then NaN energies (-> NaN weights and context) instead of a hung GPU.
+        const int Ti = a.Ti;
+        const at_u64* g = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + ((long long)b * Ti + (tid < Ti ? tid : Ti - 1)) * NSL;
+        const bool need = tid < r.len;
+        for (int d_ = 0; d_ < p.delay; ++d_) __builtin_amdgcn_s_sleep(1);
+        at_u64 x[NSL];
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0_ = wall_clock64();
+        unsigned spins_ = 0;
+        bool bad = false;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) ok = ok && (unsigned)(x[k] >> 32) == p.token;
+            if (__all(ok || !need)) break;
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; break; }
+        }
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) e_first[k] = bad ? __builtin_nanf("") : __uint_as_float((unsigned)x[k]);
+    }
+    kc_finish<M16, true>(p, smem + p.kc_smem_off, sl, b, ts_on, r, e_first);
+}
+
+static int g_attn_fwd_fused = -1;          // -1: environment / default; 0 / 1: t2amd_set_attn_fwd_fused
+static unsigned g_attn_fwd_token = 0;
+#define T2_ATTN_FWD_FUSED_DEFAULT 0
+extern "C" int t2amd_set_attn_fwd_fused(int on) {
+    T2_REQUIRE(on == 0 || on == 1 || on == -1, "set_attn_fwd_fused: -1 (default), 0 or 1");
+    g_attn_fwd_fused = on;
+    return T2AMD_OK;
+}
+extern "C" long long t2amd_attn_fwd_ws_floats(int B, int Ti) {
+    // [4][B][Ti] partial energies (two-launch form), then the granule block [B][Ti][4] x 8 bytes; a multiple of 4 floats
+    const long long e = ((long long)NSL * B * Ti + 3) / 4 * 4;
+    return e + 2ll * NSL * B * Ti;
+}
+
 extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream) {
     T2_REQUIRE(a && a->h && a->Wq && a->U && a->v && a->pm && a->memory && a->cum && a->w_out && a->ctx_out && a->ws,
                "attn_fwd: null pointer");
@@ -717,6 +853,7 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     p.tip = attn_tip(a->Ti);
     p.dbg = attn_dbg_stage();
     p.ts = attn_ts_buffer();
+    p.token = 0; p.gran_off = 0; p.kc_smem_off = 0; p.delay = 0;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds_e = sizeof(float) * (2 * (size_t)p.tip + DSL + DSL * NTAP + (size_t)a->Hq);
     const int EC = a->E / NCS;
@@ -734,6 +871,24 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     int form = ke_form >= 0 ? ke_form : ((long long)NSL * a->B > 512 ? 2 : 0);
     const size_t lds_e4 = sizeof(float) * (KE4_U * (2 * (size_t)p.tip + DSL + (size_t)a->Hq) + DSL * NTAP + KE4_U);
     if (form == 2 && !(a->Wq16 && a->loc_split_bf16 && lds_e4 <= 64 * 1024)) form = 1;      // the four-utterance form is bf16-mode only
+    // one launch (T2AMD_ATTN_FWD_FUSED=0/1, t2amd_set_attn_fwd_fused): the one-utterance form of K_e only, one position
+    // per thread, and the granule block of ws present and 8-byte aligned
+    static const bool fused_env = [] { const char* e = getenv("T2AMD_ATTN_FWD_FUSED"); return e ? e[0] != '0' : T2_ATTN_FWD_FUSED_DEFAULT != 0; }();
+    static const int fwd_delay = [] { const char* e = getenv("T2AMD_ATTN_FWD_DELAY"); const int v = e ? atoi(e) : 8; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
+    p.gran_off = ((long long)NSL * a->B * a->Ti + 3) / 4 * 4;
+    const size_t lds_ea = (lds_e + 15) / 16 * 16;
+    if ((g_attn_fwd_fused < 0 ? fused_env : g_attn_fwd_fused != 0) && form == 0 && a->Ti <= KC_NT &&
+        a->ws_floats >= p.gran_off + 2ll * NSL * a->B * a->Ti && (reinterpret_cast<uintptr_t>(a->ws + p.gran_off) & 7u) == 0 &&
+        lds_ea + lds_c <= 64 * 1024) {
+        if (++g_attn_fwd_token == 0) ++g_attn_fwd_token;
+        p.token = g_attn_fwd_token;
+        p.kc_smem_off = (int)(lds_ea / sizeof(float));
+        p.delay = fwd_delay;
+        if (a->memory16) T2_LAUNCH(attn_fwd_fused_kernel<true>, dim3(NSL, a->B), dim3(KE_NT), lds_ea + lds_c, s, p);
+        else T2_LAUNCH(attn_fwd_fused_kernel<false>, dim3(NSL, a->B), dim3(KE_NT), lds_ea + lds_c, s, p);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
     if (form == 2) T2_LAUNCH(attn_energy4_kernel, dim3(NSL, t2_cdiv(a->B, KE4_U)), dim3(KE_NT), lds_e4, s, p);
     else if (form == 1) T2_LAUNCH((attn_energy_kernel<4>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
     else T2_LAUNCH((attn_energy_kernel<2>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
@@ -768,10 +923,6 @@ struct AttnBwdParams {
 // store each, the data is the flag (Guideline 16 R2, as in csrc/decode_persist.hip) -- into the granule block of ws:
 // one row of Ti + NTS granules per utterance, dw[0 .. Ti) then the NTS partial sums (so that a consumer thread polls
 // exactly one granule: thread i < Ti + NTS the i-th of its utterance's row).
-typedef unsigned long long at_u64;
-__device__ __forceinline__ void gran_publish(at_u64* g, unsigned tag, float v) {
-    __hip_atomic_store(g, ((at_u64)tag << 32) | (at_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 template <bool M16, bool GRAN>
 __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, const int ts, const int b, bool& ts_on) {
     constexpr int CPT = M16 ? 8 : 4;           // channels per 16-byte load

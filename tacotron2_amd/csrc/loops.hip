@@ -91,6 +91,12 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         T2_REQUIRE(E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0, "dec_train_fwd: bf16 mode needs E, Ha, Hd multiples of 128");
     }
     T2_PROPAGATE(t2amd_fill_f32(p->cum_work, (long long)B * Ti, 0.f, stream));
+    // the granule block of the attention workspace (one-launch form of the step): zero once, tokens are never zero
+    const long long fwd_ws_floats = t2amd_attn_fwd_ws_floats(B, Ti);
+    {
+        const long long e = ((long long)T2AMD_ATT_SLICES * B * Ti + 3) / 4 * 4;
+        T2_PROPAGATE(t2amd_fill_f32(p->attn_ws + e, fwd_ws_floats - e, 0.f, stream));
+    }
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
     auto fill_a = [&](int t, t2amd_lstm_step& a) {
         // attention LSTM: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T
@@ -149,7 +155,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
         at.h = p->HA + t * sHa; at.ld_h = Ha;
         at.Wq = p->Wq; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
-        at.ws = p->attn_ws;
+        at.ws = p->attn_ws; at.ws_floats = fwd_ws_floats;
         at.w_prev = t ? p->ALIGN + (long long)(t - 1) * Ti : nullptr; at.ld_wprev = (long long)To * Ti;
         at.cum = p->cum_work;
         at.cum_save = p->CUM + (long long)t * B * Ti;
@@ -233,7 +239,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     T2_PROPAGATE(t2amd_fill_f32(p->dcum_acc, (long long)B * Ti, 0.f, stream));
     // the backward's attention workspace sits behind the forward's four partial-energy slabs; its 8*B tail holds the
     // slice partials and the hand-off tokens of the fused backward kernel: zeroed once, tokens are never zero
-    float* const bwd_ws = f.attn_ws + (long long)T2AMD_ATT_SLICES * B * Ti;
+    float* const bwd_ws = f.attn_ws + t2amd_attn_fwd_ws_floats(B, Ti);
     const long long bwd_ws_floats = t2amd_attn_bwd_ws_floats(B, Ti);
     T2_PROPAGATE(t2amd_fill_f32(bwd_ws + (long long)B * Ti, bwd_ws_floats - (long long)B * Ti, 0.f, stream));
 

@@ -124,6 +124,7 @@ class AttnFwd(C.Structure):
         ("loc_split_bf16", C.c_int),
         ("memory16", C.c_void_p),
         ("Wq16", C.c_void_p),
+        ("ws_floats", _i64),
     ]
 
 
@@ -267,7 +268,7 @@ SYMBOLS = [
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
-    "t2amd_set_attn_bwd_granules", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
+    "t2amd_set_attn_bwd_granules", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
@@ -329,6 +330,8 @@ def _argtypes():
         "t2amd_get_bptt_cell_fold": [],
         "t2amd_attn_bwd_ws_floats": [_I, _I],
         "t2amd_set_attn_bwd_granules": [_I],
+        "t2amd_attn_fwd_ws_floats": [_I, _I],
+        "t2amd_set_attn_fwd_fused": [_I],
         "t2amd_lstm_step_small_f32": [pt(LstmStep), _P],
         "t2amd_linear_small_f32": [pt(SmallLinear), _P],
         "t2amd_profile_enable": [_I, _I],
@@ -379,6 +382,7 @@ def load():
     lib.t2amd_reflect_index.restype = C.c_longlong
     lib.t2amd_abi_version.restype = C.c_int
     lib.t2amd_attn_bwd_ws_floats.restype = C.c_longlong
+    lib.t2amd_attn_fwd_ws_floats.restype = C.c_longlong
     lib.t2amd_decoder_persist_mailbox_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
@@ -986,7 +990,13 @@ def unfold_location_grads(dU_acc, dv_acc, nb, wdense, wconv, dwdense, dwconv, dv
 
 
 def attn_fwd_ws_floats(B, Ti):
-    return ATT_SLICES * B * Ti
+    """partial energies + the granule block of the one-launch form (t2amd_attn_fwd_ws_floats; a multiple of 4)."""
+    return int(load().t2amd_attn_fwd_ws_floats(int(B), int(Ti)))
+
+
+def set_attn_fwd_fused(on):
+    """K_e and K_c of an attention step as one launch (1), two launches (0), or the library default (-1)."""
+    _check(load().t2amd_set_attn_fwd_fused(int(on)), "t2amd_set_attn_fwd_fused")
 
 
 def attn_bwd_ws_floats(B, Ti):
@@ -1020,6 +1030,7 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
     if ws.numel() < attn_fwd_ws_floats(B, Ti):
         raise NativeError("attention_step_fwd: workspace too small")
     a.ws = ptr(_fullc(ws))
+    a.ws_floats = ws.numel()
     a.loc_split_bf16 = 1 if bf16 else 0
     if memory16 is not None:
         a.memory16 = ptr(_fullc(memory16), torch.bfloat16)

@@ -628,6 +628,57 @@ def test_attention_backward_folded_cells_bitwise(nv, B, Ti, E, Hq, Hx, first, bf
             assert torch.equal(x, y), (step, i, (x.float() - y.float()).abs().max().item())
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("B,Ti,E,Hq,inactive", [(3, 37, 128, 128, False), (5, 150, 512, 1024, True), (64, 187, 512, 1024, False),
+                                                (2, 300, 512, 1024, False), (1, 5, 512, 1024, False)])
+def test_attention_forward_fused_matches_two_launch(nv, B, Ti, E, Hq, inactive, bf16):
+    """t2amd_set_attn_fwd_fused(1): K_e and K_c of a step as ONE launch whose four workgroups per utterance exchange the
+    partial energies as {token, value} granules.  Same per-thread arithmetic and summation order: weights, context (f32 and
+    the bf16 copy), cumulative weights and the saved query must equal the two-launch form bit for bit, over three chained
+    steps (the cumulative weights and the previous weights feed the next step; the launch token changes), with ragged
+    lengths, an utterance of full length, and utterances switched off (batched inference's `active` mask)."""
+    g = G(400 + B + Ti)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale).to(DEV)
+    mem, pm = r(B, Ti, E), r(B, Ti, 128)
+    Wq, U, v = r(128, Hq, scale=0.05), r(128 * 62, scale=0.1), r(128)
+    lens = torch.randint(max(1, Ti // 3), Ti + 1, (B,), generator=g).to(torch.int32)
+    lens[0] = Ti
+    lens = lens.to(DEV)
+    hs = [r(B, Hq) for _ in range(3)]
+    active = None
+    if inactive:
+        active = torch.ones(B, dtype=torch.uint8)
+        active[1] = 0
+        active = active.to(DEV)
+    mem16 = mem.bfloat16() if bf16 else None
+    Wq16 = Wq.bfloat16() if bf16 and Hq % 128 == 0 else None
+
+    def run(fused):
+        nv.set_attn_fwd_fused(fused)
+        ws = torch.zeros(nv.attn_fwd_ws_floats(B, Ti), device=DEV)
+        cum = torch.zeros(B, Ti, device=DEV)
+        w_prev, outs = None, []
+        for step in range(3):
+            cum_save, w_out = torch.zeros(B, Ti, device=DEV), torch.zeros(B, Ti, device=DEV)
+            ctx, q = torch.zeros(B, E, device=DEV), torch.zeros(B, 128, device=DEV)
+            nv.attention_step_fwd(hs[step], Wq, U, v, pm, mem, lens, w_prev, cum, cum_save, w_out, ctx, q, ws, active=active,
+                                  bf16=bf16, memory16=mem16, Wq16=Wq16)
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in (w_out, ctx, q, cum, cum_save)])
+            w_prev = w_out
+        return outs
+
+    try:
+        ref, got = run(0), run(1)
+    finally:
+        nv.set_attn_fwd_fused(-1)
+    assert all(torch.isfinite(t).all() for t in ref[-1])
+    assert (ref[-1][0].sum(1)[active.bool() if inactive else slice(None)] - 1).abs().max().item() < 1e-4
+    for step, (a_, b_) in enumerate(zip(ref, got)):
+        for i, (x, y) in enumerate(zip(a_, b_)):
+            assert torch.equal(x, y), (step, i, (x - y).abs().max().item())
+
+
 def test_attention_energy_kernel_forms_agree():
     """K_e has three forms (attention.hip): one utterance per workgroup in the latency-shaped register allocation, the
     same with room for two workgroups per CU, and four utterances per workgroup with the W_q slice kept in registers

@@ -255,10 +255,11 @@ def test_bptt_cell_fold_is_bitwise_identical(native_lib, name, precision):
     res = []
     start = native.get_bptt_cell_fold()
     try:
-        # (cells folded, first hand-off of the attention backward as granules): every combination, one of them twice
-        for fold, gran in ((0, 0), (1, 0), (1, 1), (0, 1), (1, 1)):
+        # (cells folded, first hand-off of the attention backward as granules, attention forward as one launch)
+        for fold, gran, fwd in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 1), (1, 1, 1), (1, 1, 1)):
             native.set_bptt_cell_fold(fold)
             native.set_attn_bwd_granules(gran)
+            native.set_attn_fwd_fused(fwd)
             model = _model(hp, sd).train()
             model.precision = precision
             model.dropout_masks = gu.masks_to_engine(masks, DEV)
@@ -270,6 +271,7 @@ def test_bptt_cell_fold_is_bitwise_identical(native_lib, name, precision):
     finally:
         native.set_bptt_cell_fold(start)
         native.set_attn_bwd_granules(-1)
+        native.set_attn_fwd_fused(-1)
     assert all(torch.isfinite(g).all() for g in res[0].values())
     for other in res[1:]:
         for k in res[0]:

@@ -1,7 +1,8 @@
 """A/B of the forms of the decoder BPTT step on the BASELINE configs[1] training step, in ONE process: the same model,
-batches and dropout seeds run under each configuration "fold,gran" -- fold: the LSTM cell backwards as a launch of their
+batches and dropout seeds run under each configuration "fold,gran[,fwd]" -- fold: the LSTM cell backwards as a launch of their
 own (0) or inside the attention-backward launch (1, t2amd_set_bptt_cell_fold); gran: the first hand-off of that launch as
-drained stores + token (0) or as {token, value} granules (1, t2amd_set_attn_bwd_granules) -- alternating, and the
+drained stores + token (0) or as {token, value} granules (1, t2amd_set_attn_bwd_granules); fwd: the attention forward
+of a step as two launches (0) or one (1, t2amd_set_attn_fwd_fused) -- alternating, and the
 gradients of every form are compared bit for bit with the first one at full size (B = 64, To <= 870).
 
     python tools/ab_cell_fold.py [--configs "0,0;1,0;1,1"] [--steps 6] [--rounds 3] [--precision bf16]
@@ -30,6 +31,7 @@ def main():
     ap.add_argument("--configs", default="0,0;1,0;1,1", help='";"-separated "fold,gran" pairs; the first is the reference')
     args = ap.parse_args()
     configs = [tuple(int(v) for v in c.split(",")) for c in args.configs.split(";")]
+    configs = [c if len(c) == 3 else c + (0,) for c in configs]
     from tacotron2_amd import native
     native.load()
     from tacotron2_amd.hparams import create_hparams
@@ -51,6 +53,7 @@ def main():
     def select(cfg):
         native.set_bptt_cell_fold(cfg[0])
         native.set_attn_bwd_granules(cfg[1])
+        native.set_attn_fwd_fused(cfg[2])
 
     def grads_of(cfg, seed):
         select(cfg)
@@ -95,10 +98,11 @@ def main():
     finally:
         native.set_bptt_cell_fold(start)
         native.set_attn_bwd_granules(-1)
+        native.set_attn_fwd_fused(-1)
     frames = sum(int(b[4].sum()) for b in batches) / len(batches)
     out = {"workload": "BASELINE configs[1] training step, B=%d, %s" % (args.batch_size, args.precision),
            "steps_per_round": args.steps,
-           "forms": {"fold=%d,granules=%d" % cfg: {"ms_per_step": v, "median_ms": statistics.median(v),
+           "forms": {"fold=%d,granules=%d,fwd_fused=%d" % cfg: {"ms_per_step": v, "median_ms": statistics.median(v),
                                                    "frames_per_s": frames / statistics.median(v) * 1e3}
                      for cfg, v in ms.items()},
            "bitwise_equal": bool(equal), "finite": finite, "worst_abs_diff": worst, "loss": losses}
