@@ -827,7 +827,7 @@ __global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams 
 
 static int g_attn_fwd_fused = -1;          // -1: environment / default; 0 / 1: t2amd_set_attn_fwd_fused
 static unsigned g_attn_fwd_token = 0;
-#define T2_ATTN_FWD_FUSED_DEFAULT 0
+#define T2_ATTN_FWD_FUSED_DEFAULT 1      // measured on MI355X: 63.0 vs 64.0 ms per training step (profiles/r02_aa_ab_fwd_fused.json)
 extern "C" int t2amd_set_attn_fwd_fused(int on) {
     T2_REQUIRE(on == 0 || on == 1 || on == -1, "set_attn_fwd_fused: -1 (default), 0 or 1");
     g_attn_fwd_fused = on;
@@ -1430,7 +1430,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     // the W_q prefetch: loads return in order, so whatever is issued after the W_q rows would have to land before the
     // wave may touch them -- issued first, these are simply there by then.
     const int cq_q4 = Hq >> 4;                   // float4 columns (= 4-unit groups) per workgroup, <= 64
-    const bool cq_on = CELL && wv == 1 && lane < cq_q4;
+    const bool cq_on = CELL && wv == 1 && lane < cq_q4;      // (waves 4 / 5, which have one position tile fewer: no gain)
     const int cq_j = (ds * cq_q4 + lane) * 4;
     CellOperands cq_r;          // (only touched under cq_on)
     Slab4 cq_s0, cq_s2;
