@@ -676,6 +676,9 @@ typedef struct t2amd_dec_infer {
     const void* Wpg16;
     const void* W2_16;
     void* x_prenet1_16;
+    /* floats in attn_ws, or 0 = "the minimum".  With t2amd_attn_fwd_ws_floats(B, Ti) floats, zeroed by the caller before the
+     * first call, the attention step of launches of at most 512 workgroups runs as ONE launch (t2amd_attn_fwd.ws_floats). */
+    long long attn_ws_floats;
 } t2amd_dec_infer;
 
 int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);

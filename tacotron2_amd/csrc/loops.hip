@@ -585,7 +585,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         at.B = B; at.Ti = Ti; at.E = E; at.Hq = Ha;
         at.h = p->h_a + wr * sHa; at.ld_h = Ha;
         at.Wq = p->Wq; at.U = p->U; at.v = p->v; at.pm = p->pm; at.memory = p->memory; at.lens = p->lens;
-        at.ws = p->attn_ws; at.active = p->active;
+        at.ws = p->attn_ws; at.ws_floats = p->attn_ws_floats; at.active = p->active;
         at.w_prev = t ? p->ALIGN + (long long)(t - 1) * Ti : nullptr; at.ld_wprev = (long long)p->max_steps * Ti;
         at.cum = p->cum; at.cum_save = nullptr;
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)p->max_steps * Ti;

@@ -1200,7 +1200,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     st = dict(h_a=run.zeros(2, B, Ha), c_a=run.zeros(2, B, Ha), c_d=run.zeros(2, B, Hd),
               hc=run.zeros(2, B, Hd + E), cum=run.zeros(B, Ti), x_prenet=run.empty(2, B, Pd),
               gates=run.empty(B, 4 * max(Ha, Hd)), zero_frame=run.zeros(B, Cm),
-              attn_ws=run.empty(nv.attn_fwd_ws_floats(B, Ti)),
+              attn_ws=run.zeros(nv.attn_fwd_ws_floats(B, Ti)),      # zeroed: the granule block of the one-launch step
               PG=run.zeros(max_steps, B, Cm + 1), ALIGN=run.zeros(B, max_steps, Ti))
     out_lengths = torch.zeros(B, dtype=torch.int32, device=dev)
     active = torch.ones(B, dtype=torch.uint8, device=dev)
@@ -1214,6 +1214,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     d.keep_prenet = nv.ptr(keep, torch.uint8)
     for k_, v_ in st.items():
         setattr(d, k_, nv.ptr(v_))
+    d.attn_ws_floats = st['attn_ws'].numel()
     d.out_lengths = nv.ptr(out_lengths, torch.int32)
     d.active = nv.ptr(active, torch.uint8)
     d.done_count = nv.ptr(done, torch.int32)
@@ -1301,7 +1302,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         st['cum'] = st['cum'][rows].contiguous()
         st['zero_frame'] = st['zero_frame'][:left].contiguous()
         st['gates'] = run.empty(left, 4 * max(Ha, Hd))
-        st['attn_ws'] = run.empty(nv.attn_fwd_ws_floats(left, Ti))
+        st['attn_ws'] = run.zeros(nv.attn_fwd_ws_floats(left, Ti))
         st['PG'] = run.zeros(max_steps, left, Cm + 1)
         st['PG'][t - 1] = oldPG[t - 1][rows]                               # the frame the next prenet input comes from
         st['ALIGN'] = run.zeros(left, max_steps, Ti)
@@ -1316,6 +1317,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         d.keep_prenet = nv.ptr(keep, torch.uint8)
         for k_, v_ in st.items():
             setattr(d, k_, nv.ptr(v_))
+        d.attn_ws_floats = st['attn_ws'].numel()
         d.out_lengths, d.active = nv.ptr(out_lengths, torch.int32), nv.ptr(active, torch.uint8)
         if run.bf16:
             i16['x_prenet16'] = i16['x_prenet16'][rows].contiguous()

@@ -218,6 +218,7 @@ class DecInfer(C.Structure):
         ("x_prenet16", C.c_void_p), ("h_a16", C.c_void_p), ("hc16", C.c_void_p),
         ("Wf", _f32p), ("bias_f", _f32p), ("memory16", C.c_void_p), ("Wq16", C.c_void_p),
         ("Wf16", C.c_void_p), ("Wpg16", C.c_void_p), ("W2_16", C.c_void_p), ("x_prenet1_16", C.c_void_p),
+        ("attn_ws_floats", _i64),
     ]
 
 
