@@ -432,6 +432,7 @@ def main():
             "algorithmic_bytes_per_padded_time_step": per_step, "time_steps": To, "ms_per_step": ms_step,
             "achieved": per_step * To / (ms_step / 1e3) / 1e9, "unit": "GB/s",
             "frac": per_step * To / (ms_step / 1e3) / 1e9 / 8000.0,
+            "dependent_launches_per_time_step": 2 + (2 if native.get_bptt_cell_fold() else 3),
             "note": "SURVEY 8d: 2 x (step weights + encoder memory) + saved activations per padded time step; encoder, "
                     "postnet, dense weight-gradient GEMMs and the optimiser are inside ms_per_step but not in the bytes"}
     # ---- the same step in fp32 parity mode, reported beside a bf16 run (fewer steps, same batches) ----------
