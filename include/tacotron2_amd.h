@@ -601,8 +601,13 @@ typedef struct t2amd_lstm_seq {
     const float* dout;  /* grad wrt out, same indexing with ld_dout */
     long long ld_dout;
     float* DG;          /* [B][T][4H] out: gate pre-activation grads */
-    float* dX;          /* [B][H] workspace */
+    float* dX;          /* [max(dx_splits, 1)][B][H] workspace */
     float* dc;          /* [B][H] workspace */
+    /* backward: 2..4 = the recurrent data-gradient product dh_prev = dgates . Whh of every step splits its K = 4H over
+     * that many groups of workgroups, which write partial slabs of dX that the next step's cell backward adds in index
+     * order (H/16 column tiles alone are 16 workgroups per direction at H = 256: a 16-tile dependent k loop on a
+     * handful of CUs).  0 / 1: one slab. */
+    int dx_splits;
 } t2amd_lstm_seq;
 
 int t2amd_lstm_seq_fwd_f32(const t2amd_lstm_seq* p, void* stream);

@@ -431,6 +431,8 @@ static int check_seq_bwd(const t2amd_lstm_seq* p) {
     T2_REQUIRE(p && p->WhhT && p->GX && p->C && p->lens && p->dout && p->DG && p->dX && p->dc,
                "lstm_seq_bwd: null pointer");
     T2_REQUIRE(p->B > 0 && p->T > 0 && p->H % 64 == 0, "lstm_seq_bwd: H must be a multiple of 64");
+    T2_REQUIRE(p->dx_splits >= 0 && p->dx_splits <= 4 && (p->dx_splits < 2 || (4 * p->H / 64) % p->dx_splits == 0),
+               "lstm_seq_bwd: dx_splits must be 0..4 and divide the 4H/64 k tiles");
     return T2AMD_OK;
 }
 static void seq_bwd_step(const t2amd_lstm_seq* p, int s, t2amd_lstm_bwd& lb, t2amd_skinny_gemm& g) {
@@ -441,7 +443,8 @@ static void seq_bwd_step(const t2amd_lstm_seq* p, int s, t2amd_lstm_bwd& lb, t2a
     lb = t2amd_lstm_bwd{};
     lb.B = B; lb.H = H;
     lb.dh[0] = addend(p->dout + (long long)t * p->ld_dout, (long long)T * p->ld_dout, 1, 0);
-    lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dX, H, 1, 0);
+    const int ns = p->dx_splits < 1 ? 1 : p->dx_splits;
+    lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dX, H, ns, (long long)B * H);
     lb.dh[2] = addend(nullptr, 0, 1, 0);
     lb.gates = p->GX + (long long)t * 4 * H; lb.ld_gates = (long long)T * 4 * H;
     lb.c_prev = (s == 0) ? nullptr : p->C + (long long)tp * B * H; lb.ld_cprev = H;
@@ -453,7 +456,7 @@ static void seq_bwd_step(const t2amd_lstm_seq* p, int s, t2amd_lstm_bwd& lb, t2a
     g.nseg = 1;
     g.x[0] = seg(p->DG + (long long)t * 4 * H, (long long)T * 4 * H, 4 * H);
     g.W = p->WhhT; g.Ktot = 4 * H; g.N = H; g.B = B;
-    g.Y = p->dX; g.ldy = H; g.nsplit = 1; g.split_stride = 0;
+    g.Y = p->dX; g.ldy = H; g.nsplit = ns; g.split_stride = (long long)B * H;
 }
 
 extern "C" int t2amd_lstm_seq_bwd2_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, void* stream) {

@@ -199,6 +199,18 @@ def _dgrad_split():
 DGRAD_SPLIT = _dgrad_split()
 
 
+def _enc_dgrad_split():
+    """Split-K factor of the encoder bi-LSTM's recurrent dgrad product (T2AMD_ENC_DGRAD_SPLIT, tuning knob; 1, 2 or 4 --
+    it must divide the 4H/64 k tiles).  At H = 256 the unsplit product is 16 workgroups per direction walking 16 k tiles."""
+    raw = os.environ.get('T2AMD_ENC_DGRAD_SPLIT', '1')
+    if raw not in ('1', '2', '4'):
+        raise NativeError("T2AMD_ENC_DGRAD_SPLIT must be 1, 2 or 4, got %r" % (raw,))
+    return int(raw)
+
+
+ENC_DGRAD_SPLIT = _enc_dgrad_split()
+
+
 def _rg(run, *a, **k):
     return run.gemm(*a, fast=run.gradp, **k)
 
@@ -932,9 +944,9 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         dout_view = dmem.view(rowsE, E)[:, d * He:(d + 1) * He]
         desc.dout, desc.ld_dout = nv.ptr(dout_view), E
         desc.DG = nv.ptr(DG)
-        dX = run.empty(B, He)
+        dX = run.empty(ENC_DGRAD_SPLIT, B, He)
         dc = run.empty(B, He)
-        desc.dX, desc.dc = nv.ptr(dX), nv.ptr(dc)
+        desc.dX, desc.dc, desc.dx_splits = nv.ptr(dX), nv.ptr(dc), ENC_DGRAD_SPLIT
         bdesc.append(desc)
         DGs.append(DG)
         keepalive.append((WhhT, dX, dc))

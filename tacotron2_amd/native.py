@@ -189,6 +189,7 @@ class LstmSeq(C.Structure):
         ("C", _f32p), ("lens", C.c_void_p),
         ("dout", _f32p), ("ld_dout", _i64),
         ("DG", _f32p), ("dX", _f32p), ("dc", _f32p),
+        ("dx_splits", C.c_int),
     ]
 
 
