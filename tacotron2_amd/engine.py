@@ -201,8 +201,9 @@ DGRAD_SPLIT = _dgrad_split()
 
 def _enc_dgrad_split():
     """Split-K factor of the encoder bi-LSTM's recurrent dgrad product (T2AMD_ENC_DGRAD_SPLIT, tuning knob; 1, 2 or 4 --
-    it must divide the 4H/64 k tiles).  At H = 256 the unsplit product is 16 workgroups per direction walking 16 k tiles."""
-    raw = os.environ.get('T2AMD_ENC_DGRAD_SPLIT', '1')
+    it must divide the 4H/64 k tiles).  At H = 256 the unsplit product is 16 workgroups per direction walking 16 k tiles;
+    measured on MI355X (profiles/r02_ad_enc_split.txt): 63.2 / 63.1 / 62.3 ms per training step at 1 / 2 / 4."""
+    raw = os.environ.get('T2AMD_ENC_DGRAD_SPLIT', '4')
     if raw not in ('1', '2', '4'):
         raise NativeError("T2AMD_ENC_DGRAD_SPLIT must be 1, 2 or 4, got %r" % (raw,))
     return int(raw)
