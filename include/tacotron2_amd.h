@@ -411,7 +411,9 @@ int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);
 long long t2amd_attn_fwd_ws_floats(int B, int Ti);
 /* 1: K_e and K_c of a step run as one launch (energy granules between the four workgroups of an utterance), 0: two
  * launches, -1: library default / environment T2AMD_ATTN_FWD_FUSED.  Bit-identical results.  The one-launch form serves
- * launches of at most 512 workgroups (B <= 128) with Ti <= 512. */
+ * launches of at most 512 workgroups (B <= 128) with Ti <= 512.  Its launch token is a kernel argument drawn from a
+ * process-wide counter at enqueue time: do not capture these launches into a hipGraph (a replay would present the same
+ * token again and accept the previous replay's granules); the same holds for the one-launch forms of the backward. */
 int t2amd_set_attn_fwd_fused(int on);
 
 typedef struct t2amd_attn_bwd {

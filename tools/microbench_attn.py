@@ -46,7 +46,9 @@ def timeit(fn, n=200):
     return e0.elapsed_time(e1) / n * 1e3
 print("stage", os.environ.get("T2AMD_ATTN_STAGE", "0"), "fwd (K_e+K_c) %.2f us   bwd (K_b1+K_b2) %.2f us" % (timeit(fwd), timeit(bwd)))
 
-# the same launches replayed from a hipGraph (what a captured decoder loop would pay per step)
+# the same launches replayed from a hipGraph (what a captured decoder loop would pay per step).  Timing only: the
+# in-launch hand-offs carry their launch token as a kernel argument, so a replay presents the tokens of the capture again
+# and its polls pass on the previous replay's granules (same inputs, same values here) -- never capture them in a product.
 if os.environ.get("T2AMD_ATTN_STAGE", "0") == "0":
     side = torch.cuda.Stream()
     sp = C.c_void_p(side.cuda_stream)

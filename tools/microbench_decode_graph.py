@@ -16,6 +16,9 @@ from tacotron2_amd.hparams import create_hparams               # noqa: E402
 from tacotron2_amd.model import Tacotron2                      # noqa: E402
 
 lib = nv.load()
+# the one-launch attention step carries its launch token as a kernel argument: a replayed graph would present the same
+# token again and read the previous replay's granules, so the captured chain uses the two-launch form
+nv.set_attn_fwd_fused(0)
 fn = lib.t2amd_debug_graph_decode_
 fn.argtypes = [C.POINTER(nv.DecInfer), C.c_int, C.POINTER(C.c_float), C.c_void_p]
 fn.restype = C.c_int
