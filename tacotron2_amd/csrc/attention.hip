@@ -623,7 +623,6 @@ __device__ __forceinline__ void kc_issue(const AttnFwdParams& p, const int cs, c
     int parts = KC_NT / EC4;
     if (parts > 32) parts = 32;
     const int c4 = tid % EC4, part = tid / EC4;
-    const bool worker = part < parts;
     const float4* __restrict__ M4 = reinterpret_cast<const float4*>(M16 ? a.memory16 : (const void*)a.memory) +
                                     (long long)b * Ti * E4 + cs * EC4 + c4;
     long long roff[KC_MAXR];

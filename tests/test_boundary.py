@@ -110,6 +110,39 @@ def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens, fold)
         native.set_bptt_cell_fold(start)
 
 
+def test_attention_workspace_sizes_and_cell_descriptor_checks(native_lib):
+    """t2amd_attn_{fwd,bwd}_ws_floats cover every form of the attention step (partial energies / dw slab, token blocks,
+    granule blocks at 8-byte-aligned offsets), and the folded-cell descriptors of t2amd_attn_bwd are validated on the
+    host: cell_q must be THIS step's [B][Hq] cell and its dh[1] must describe the dh_out slabs (validate-only: no GPU)."""
+    import torch
+    S = native.ATT_SLICES
+    for B, Ti in ((1, 1), (3, 37), (64, 187), (256, 203), (5, 511)):
+        f, w = native.attn_fwd_ws_floats(B, Ti), native.attn_bwd_ws_floats(B, Ti)
+        assert f % 4 == 0 and f >= S * B * Ti + 2 * S * B * Ti
+        goff = (B * Ti + 12 * B + 1) // 2 * 2
+        assert w == goff + 2 * B * (Ti + S)
+    native.set_validate_only(True)
+    try:
+        B, Ti, E, Hq = 3, 20, 64, 64
+        z = lambda *s: torch.zeros(*s)
+        dh = z(S, B, Hq)
+        args = ([z(B, E)], z(B, E), None, z(B, 128), z(128, Hq), z(128 * 62), z(128), z(B, Ti, 128), z(B, Ti, E),
+                torch.full((B,), Ti, dtype=torch.int32), z(B, Ti), None, z(B, Ti), z(S, B, 2, Ti), z(B, Ti), z(B, Ti, 128),
+                z(B, 128, 62), z(B, 128), z(B, 128), dh, z(native.attn_bwd_ws_floats(B, Ti)))
+        cell = lambda H, d1: native.lstm_bwd_desc(B, H, [z(B, H), d1, None], z(B, 4 * H), None, z(B, H), None, 1.0, z(B, H),
+                                                  z(B, 4 * H))
+        good = cell(Hq, (dh[0], S, dh.stride(0)))
+        native.attention_step_bwd(*args, cell_q=good, cell_x=cell(128, None))            # accepted
+        with pytest.raises(native.NativeError):                                          # dh[1] is not the dh_out slabs
+            native.attention_step_bwd(*args, cell_q=cell(Hq, z(B, Hq)))
+        with pytest.raises(native.NativeError):                                          # not this step's [B][Hq] cell
+            native.attention_step_bwd(*args, cell_q=cell(128, (z(S, B, 128)[0], S, B * 128)))
+        with pytest.raises(native.NativeError):                                          # cell_x without cell_q
+            native.attention_step_bwd(*args, cell_x=good)
+    finally:
+        native.set_validate_only(False)
+
+
 def test_splitk_policy_matches_library_tile_rule():
     """engine._choose_splitk sizes split-K against the tile edge the library reports (t2amd_gemm_tile_size): for the
     hot weight-gradient shapes the launch must fill whole rounds of 256 workgroups when it runs 256-tiles, and the
