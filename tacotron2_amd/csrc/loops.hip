@@ -4,6 +4,7 @@
 // stream and the decoder LSTM, which never feeds back into it, on a side stream (see below).
 #include "common.h"
 
+#include <stdlib.h>
 #include <vector>
 
 // ---- second HIP stream for the chain that is off the critical recurrence ------------------------------
@@ -29,7 +30,6 @@ extern "C" int t2amd_set_decoder_streams(int n) {
 // (t2amd_attn_bwd.cell_q / cell_x) instead of a launch of their own: 5 dependent launches per decoder time step instead of
 // 6 (3 forward + attention/cells + dgrad pair).  Bit-identical gradients either way (tests).  T2AMD_CELL_FOLD=0/1 sets
 // the start-up value, t2amd_set_bptt_cell_fold() changes it at run time.
-#include <stdlib.h>
 static int g_cell_fold = [] { const char* e = getenv("T2AMD_CELL_FOLD"); return e ? (e[0] != '0') : T2_CELL_FOLD_DEFAULT; }();
 extern "C" int t2amd_set_bptt_cell_fold(int on) {
     T2_REQUIRE(on == 0 || on == 1, "set_bptt_cell_fold: 0 or 1");
