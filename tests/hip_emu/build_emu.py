@@ -1,5 +1,5 @@
-"""Builds tests/hip_emu/libt2amd_emu.so: csrc/audio.hip and csrc/optim.hip compiled FOR THE HOST against the stand-in
-HIP header of this directory (test infrastructure only; see hip/hip_runtime.h)."""
+"""Builds tests/hip_emu/libt2amd_emu.so: csrc/audio.hip, csrc/optim.hip and csrc/cell_bwd.h (through cell_bwd_emu.cpp)
+compiled FOR THE HOST against the stand-in HIP header of this directory (test infrastructure only; see hip/hip_runtime.h)."""
 import os
 import subprocess
 
@@ -7,8 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "tacotron2_amd", "csrc")
 OUT = os.path.join(HERE, "libt2amd_emu.so")
-SOURCES = [os.path.join(CSRC, "audio.hip"), os.path.join(CSRC, "optim.hip"), os.path.join(HERE, "emu_runtime.cpp")]
-DEPS = SOURCES + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "common.h"),
+SOURCES = [os.path.join(CSRC, "audio.hip"), os.path.join(CSRC, "optim.hip"), os.path.join(HERE, "emu_runtime.cpp"),
+           os.path.join(HERE, "cell_bwd_emu.cpp")]
+DEPS = SOURCES + [os.path.join(CSRC, "cell_bwd.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(CSRC, "common.h"),
                   os.path.join(ROOT, "include", "tacotron2_amd.h")]
 
 

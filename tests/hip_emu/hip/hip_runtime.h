@@ -43,6 +43,12 @@ static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcpy(p->gcnArchName, "host-emulation"); p->multiProcessorCount = 0; return hipSuccess; }
 
+// the vector types the element-wise kernels use
+struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 v = {x, y, z, w}; return v; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v = {x, y}; return v; }
+
 void emu_launch(dim3 grid, dim3 block, const std::function<void()>& body);
 void emu_syncthreads();
 void emu_exchange(const void* mine, void* partner, size_t bytes, int mask);   // wave-level xor exchange

@@ -162,3 +162,54 @@ def test_fused_adam_kernels_emulated_match_torch_clip_and_adam():
         for n in numel:
             assert float(flat_e[off - 1]) == float(flat_p[off - 1]) and float(flat_e[off + n]) == float(flat_p[off + n])
             off += n + 1
+
+
+@pytest.mark.parametrize("B,H,first,with_keep,splits", [(3, 8, False, True, (2, 4, 1)), (5, 64, True, False, (1, 0, 0)),
+                                                        (2, 260, False, True, (6, 1, 3))])
+def test_emulated_lstm_cell_backward_matches_autograd(B, H, first, with_keep, splits):
+    """csrc/cell_bwd.h -- the cell backward shared by lstm_pointwise_bwd_kernel and the folded attention backward -- run
+    on the CPU from the GPU's source against torch autograd of the reference's arithmetic: nn.LSTMCell's cell
+    (model.py:351-352, 366-370) followed by F.dropout (:353, :371), in float64.  Inputs as the loops present them: the
+    upstream gradient of the dropped-out h as up to three addends, each a sum of partial slabs (split-K dgrad outputs) at
+    a column offset, the carried dL/dc, activated gates and cell states saved by the forward, a byte keep-mask."""
+    import build_emu
+    emu = ctypes.CDLL(build_emu.build())
+    emu.t2amd_emu_cell_bwd.argtypes, emu.t2amd_emu_cell_bwd.restype = [ctypes.POINTER(native.LstmBwd)], ctypes.c_int
+    g = torch.Generator().manual_seed(11 + H)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    pre = rnd(B, 4 * H).double().requires_grad_(True)
+    c_prev = (torch.zeros(B, H) if first else rnd(B, H)).double().requires_grad_(True)
+    keep = (torch.rand(B, H, generator=g) > 0.3).to(torch.uint8) if with_keep else None
+    scale = native.scale_for(0.3) if with_keep else 1.0
+    i, f, gg, o = pre[:, :H].sigmoid(), pre[:, H:2 * H].sigmoid(), pre[:, 2 * H:3 * H].tanh(), pre[:, 3 * H:].sigmoid()
+    c = f * c_prev + i * gg
+    h = o * c.tanh()
+    hd = h * keep.double() * scale if with_keep else h
+    # three addends of the gradient wrt the dropped-out h: n partial slabs each, read at a column offset of a wider slab
+    addends, dh_total = [], torch.zeros(B, H, dtype=torch.float64)
+    for n, off in zip(splits, (4, 0, 8)):
+        if n == 0:
+            addends.append(None)
+            continue
+        slab = rnd(n, B, H + off).contiguous()
+        addends.append((slab[0, :, off:], n, slab.stride(0)))
+        dh_total = dh_total + slab[:, :, off:].double().sum(0)
+    dc_in = rnd(B, H)
+    # the loss whose gradients the cell backward forms: upstream dh on the dropped-out h, the carried dL/dc on c
+    ((hd * dh_total).sum() + (c * dc_in.double()).sum()).backward(inputs=[pre, c_prev])
+    gates = torch.cat([i, f, gg, o], 1).detach().float().contiguous()
+    dc = dc_in.clone()
+    dgates = torch.full((B, 4 * H), float('nan'))
+    dg16 = torch.zeros(B, 4 * H, dtype=torch.bfloat16)
+    saved = native._validate_only
+    native._validate_only = True                                 # descriptors over CPU tensors (the emulated kernel reads them)
+    c32, cp32 = c.detach().float().contiguous(), c_prev.detach().float().contiguous()   # (the descriptor holds raw pointers)
+    try:
+        desc = native.lstm_bwd_desc(B, H, addends, gates, None if first else cp32, c32, keep, scale, dc, dgates, dgates16=dg16)
+    finally:
+        native._validate_only = saved
+    assert emu.t2amd_emu_cell_bwd(ctypes.byref(desc)) == 0
+    err = lambda a, b: ((a.double() - b).abs().max() / (b.abs().max() + 1e-30)).item()
+    assert err(dgates, pre.grad) < 2e-6
+    assert err(dc, c_prev.grad) < 2e-6                            # the new carry: dL/dc_{t-1}
+    assert torch.equal(dg16, dgates.bfloat16())                  # the dgrad GEMM's bf16 operand: round-to-nearest-even
