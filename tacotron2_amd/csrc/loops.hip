@@ -507,7 +507,6 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sHC = (long long)B * (Hd + E);
     const long long sP = (long long)B * P, sPG = (long long)B * (C + 1);
     const float two = 1.0f / (1.0f - 0.5f);
-    hipStream_t s = (hipStream_t)stream;
     for (int t = p->t0; t < p->t0 + p->n_steps; ++t) {
         const int rd = t & 1, wr = rd ^ 1;
         // prenet (dropout p = 0.5 always on, reference model.py:99)
