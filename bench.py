@@ -5,15 +5,19 @@
 
 One "step" = one full training step of the reference loop (reference train.py:208-236) on one
 synthetic LJSpeech-shaped batch per GPU: parse_batch -> forward -> Tacotron2Loss -> backward
-(-> bucketed RCCL gradient all-reduce when N > 1) -> clip_grad_norm_ -> Adam.  Inputs are resident
+(-> bucketed RCCL gradient all-reduce when N > 1: `python bench.py --gpus N` spawns its N ranks itself when it is
+not already running under torch.distributed.run) -> clip_grad_norm_ -> Adam.  Inputs are resident
 in HBM before the timed region.  Metric: VALID mel frames per second, whole job.
 
 Extra objects in the JSON line:
-  roofline      fused LSTM step launch (skinny_wide_kernel<true,3>): algorithmic bytes per launch
-                 / average launch duration measured live with HIP events on the
-                launch stream during one extra, untimed, step; beside it the attention-backward pair of one
-                time step (same method, second extra step) and the whole training step against SURVEY 8d's
-                92 MB-per-padded-time-step bound.
+  roofline      the DOMINANT kernel of the step = whichever of the four kernels of a decoder time step (attention
+                backward + folded cells, fused LSTM pair, BPTT dgrad pair, attention forward) has the largest total
+                duration, each measured live in four extra untimed steps by event pairs that the dispatch itself stamps
+                on the launch stream (hipExtLaunchKernelGGL = the begin/end timestamps rocprofv3 --kernel-trace reads):
+                algorithmic bytes per launch / average launch duration.  `chain` lists all
+                four, `lstm_pair` keeps the round-1/2 headline kernel, `whole_step` is the training step against SURVEY
+                8d's 92 MB-per-padded-time-step bound.  `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is
+                read from profiles/pmc_traffic.json while the SHA-1 over ALL of csrc/ + include/ matches.
   cpu_baseline  the CPU oracle (oracle/tacotron2_oracle.py, a port of the reference) timed on this
                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only): 1 warm-up + 2 timed
                 forward+backward steps, and the same with clip + Adam (reference train.py:229-236).
@@ -41,7 +45,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-size", type=int, default=64)
-    ap.add_argument("--cpu-sample", type=int, default=16, help="utterances in the CPU-baseline sample (0 = skip; 64 = SURVEY 8d's full batch, ~2 min)")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="utterances in the CPU-baseline / parity sample (0 = skip; 64 = BASELINE configs[1]'s whole batch, "
+                    "the default since round 3: ~1.5 min of host time; 16 = every 4th utterance)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (capped at the core count)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-inference", action="store_true",
@@ -63,13 +68,29 @@ def parse_args():
 
 
 def kernel_source_sha1():
-    """Hash of the sources of the dominant kernel (csrc/rnn.hip + csrc/common.h): stamps profiles/pmc_traffic.json."""
+    """Hash of EVERY kernel source (csrc/* and the C ABI header): stamps profiles/pmc_traffic.json, so that a change to any
+    kernel makes the committed traffic numbers read as null instead of as fresh."""
+    import glob
     import hashlib
     h = hashlib.sha1()
-    for f in ("rnn.hip", "common.h"):
-        with open(os.path.join(ROOT, "tacotron2_amd", "csrc", f), "rb") as fh:
+    files = sorted(glob.glob(os.path.join(ROOT, "tacotron2_amd", "csrc", "*")))
+    files.append(os.path.join(ROOT, "include", "tacotron2_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks here, one per GPU (the reference ships
+    its own spawner too, multiproc.py:1-23).  Rank 0 keeps stdout (the ONE JSON line), the others log to gpurun_out/."""
+    from tacotron2_amd.multiproc import launch_env
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("T2AMD_DIST_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one rank per device; "
+                         "T2AMD_DIST_BACKEND=gloo runs the ranks on shared devices as a functional check)" % (n, have))
+    return launch_env([os.path.abspath(__file__)] + sys.argv[1:], n, log_dir=os.path.join(ROOT, "gpurun_out"))
 
 
 def masks_to_engine(masks, device):
@@ -102,7 +123,16 @@ def cpu_baseline(sample_b, seed, threads=16):
     # (128 threads measured 4x SLOWER than 8), so the baseline pins the pool and states the count.
     threads = max(1, min(threads, os.cpu_count() or 1))
     torch.set_num_threads(threads)
-    orc.train_step_grads(sd, hp, batch, masks)                     # warm-up (allocator, thread pool, code paths)
+    # warm-up (allocator, thread pool, code paths): on every 4th utterance when the sample is the whole batch, so that the
+    # default bench run stays within a few minutes
+    if sample_b > 16:
+        w = torch.arange(0, sample_b, 4)
+        wb = (batch[0][w], batch[1][w], batch[2][w], batch[3][w], batch[4][w])
+        wTi, wTo = int(wb[1].max()), int(wb[4].max())
+        wb = (wb[0][:, :wTi].contiguous(), wb[1], wb[2][:, :, :wTo].contiguous(), wb[3][:, :wTo].contiguous(), wb[4])
+        orc.train_step_grads(sd, hp, wb, orc.draw_masks_train(hp, len(w), wTi, wTo, torch.Generator().manual_seed(seed)))
+    else:
+        orc.train_step_grads(sd, hp, batch, masks)
     times = []
     for _ in range(2):
         t0 = time.perf_counter()
@@ -123,17 +153,18 @@ def cpu_baseline(sample_b, seed, threads=16):
     frames = int(ol.sum())
     obj = {"value": frames / dt, "unit": "valid mel-frames/s", "cores": threads, "kind": "port",
            "with_optimizer": frames / (dt + dopt),
-           "sample": "oracle/tacotron2_oracle.py on %d of the 64 utterances (every %dth, Ti_max=%d, To_max=%d, %d valid "
-                     "frames), fp32: 1 warm-up + 2 timed fwd+bwd steps of %.1f s each; clip_grad_norm_ + Adam add %.2f s "
-                     "per step (with_optimizer)" % (sample_b, 64 // sample_b, Ti, To, frames, dt, dopt)}
-    return obj, dict(hp=hp, sd=sd, batch=batch, masks=masks, oloss=float(oloss))
+           "sample": "oracle/tacotron2_oracle.py on %s (Ti_max=%d, To_max=%d, %d valid frames), fp32: 1 warm-up + 2 timed "
+                     "fwd+bwd steps of %.1f s each; clip_grad_norm_ + Adam add %.2f s per step (with_optimizer)"
+                     % ("the whole batch of BASELINE configs[1] (B=64: the batch the GPU leg times)" if sample_b == 64 else
+                        "%d of the 64 utterances (every %dth)" % (sample_b, 64 // sample_b), Ti, To, frames, dt, dopt)}
+    return obj, dict(hp=hp, sd=sd, batch=batch, masks=masks, oloss=float(oloss), B=sample_b)
 
 
 def parity_check(ctx, dev):
     """The engine on the cpu_baseline sub-batch with the oracle's dropout masks: loss against the oracle's, both modes."""
     from tacotron2_amd.model import Tacotron2
     from tacotron2_amd.loss_function import Tacotron2Loss
-    out = {"oracle_loss": ctx['oloss'], "tolerance": {"fp32": 1e-4, "bf16": 2e-2}}
+    out = {"batch": "B=%d of synth_batch(64, 1234)" % ctx['B'], "oracle_loss": ctx['oloss'], "tolerance": {"fp32": 1e-4, "bf16": 2e-2}}
     ok = True
     for prec in ("fp32", "bf16"):
         m = Tacotron2(ctx['hp'])
@@ -255,8 +286,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 through torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     # T2AMD_DIST_BACKEND=gloo lets the N>1 control flow be exercised on a 1-GPU box (ranks share cuda:0); the
@@ -345,94 +376,109 @@ def main():
         elapsed, timed_frames = tmax[0].item(), t[1].item()
     final_loss = float(loss.item())
 
-    # ---- roofline of the dominant kernel: one extra untimed step with HIP-event brackets ------
+    # ---- roofline: the four kernels of a decoder time step, each timed live in its own extra untimed step ------
     roofline = None
     if not args.no_roofline and rank != 0:
-        step(batches[-1])                 # the gradient exchange is collective: every rank runs the two extra steps
-        step(batches[-1])
+        for _ in range(4):                # the gradient exchange is collective: every rank runs the extra steps
+            step(batches[-1])
         torch.cuda.synchronize()
     if not args.no_roofline and rank == 0:
         To = batches[-1][2].shape[2]
         fused = args.decoder_streams == 1
-        native.profile_enable(3 if fused else 2, To)  # role 3 = fused LSTM_d(t-1) || LSTM_a(t); role 2 = LSTM_d(t)
-        step(batches[-1])
-        torch.cuda.synchronize()
-        ev_ms = native.profile_event_overhead()
-        ms, cnt = native.profile_read()
         B, Ha, Hd, E = args.batch_size, hp.attention_rnn_dim, hp.decoder_rnn_dim, hp.encoder_embedding_dim
-
+        A = native.ATT_DIM
         es = 2.0 if args.precision == "bf16" else 4.0     # bytes per MFMA operand element
+        ti_sum = float(batches[-1][1].sum().item())
+        ns = int(os.environ.get("T2AMD_DGRAD_SPLIT", "2"))
+        folded = bool(native.get_bptt_cell_fold())
+
+        def timed_role(role):
+            """Average duration (s) and count of the launches of `role` in one more untimed step: every launch of the
+            role carries its own event pair, stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop events =
+            the kernel begin/end timestamps rocprofv3 --kernel-trace reports)."""
+            native.profile_enable(role, To + 1)
+            step(batches[-1])
+            torch.cuda.synchronize()
+            ms, cnt = native.profile_read()
+            return ((ms / 1e3) / cnt if cnt else 0.0), cnt
 
         def lstm_bytes(K, H, with_gin):
             # weights once + activations in (operand precision) + f32: (pre-activation addend) + bias + gates/c/h
             # out + c_prev + keep mask (+ the bf16 copy of h in bf16 mode)
             return es * (4 * H * K + B * K) + 4.0 * ((B * 4 * H if with_gin else 0) + 4 * H + B * 4 * H
                                                    + 3 * B * H + 0.25 * B * H) + (2.0 * B * H if es == 2.0 else 0.0)
-        alg_bytes = lstm_bytes(Ha + E + Hd, Hd, False) + (lstm_bytes(E + Ha, Ha, True) if fused else 0.0)
-        alg_flops = 2.0 * B * (4 * Hd * (Ha + E + Hd) + (4 * Ha * (E + Ha) if fused else 0))
-        # Every launch of the role carries its own event pair, stamped by the dispatch itself (hipExtLaunchKernelGGL
-        # start/stop events = the kernel begin/end timestamps rocprofv3 --kernel-trace reports); ev_ms is 0 in this
-        # mode (it is the calibrated empty-bracket cost of the older hipEventRecord brackets).
-        raw_s = (ms / 1e3) / max(cnt, 1)
-        avg_s = max(raw_s - ev_ms / 1e3, 1e-9)
-        achieved = alg_bytes / avg_s / 1e9
+        Kd, Ka = Ha + E + Hd, E + Ha
         mm = "bf16 MFMA (f32 accumulate)" if es == 2.0 else "exact-f32 MFMA"
-        kname = ("%s (one decoder time step: decoder LSTM of step t-1 (64x2560x4096) + attention "
-                 "LSTM of step t (64x1536x4096), %s + fused cells)"
-                 % ("skinny_wide_kernel<true,3>" if es == 2.0 else "skinny_gemm_kernel<true,3,false>", mm)) if fused else \
-                ("skinny_gemm_kernel<true,2> (decoder LSTM step: 64x2560x4096 exact-f32 MFMA GEMM + fused cell; runs on the "
-                 "side stream concurrently with the attention chain, so its duration includes sharing the CUs)")
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler
-        # around itself); null if the file is absent.
-        # (the file records the hash of the kernel's source it was measured on: a stale measurement reads as null)
-        traffic = None
+        # SURVEY 8d: the encoder memory + its projection (Ti x 640 elements per utterance) once per attention pass;
+        # with the cells folded in, the backward launch also moves both LSTMs' saved gates, cell states, masks and
+        # carries and writes the gate gradients: per hidden unit 4 gates + c + c_prev + dc in/out + 4 gate gradients =
+        # 12 floats, 1 mask byte, 4 bf16 (the dgrad operand copy, bf16 mode)
+        attn_bytes = es * 640.0 * ti_sum
+        cell_bytes = B * (Ha + Hd) * (12 * 4.0 + 1.0 + (8.0 if es == 2.0 else 0.0)) if folded else 0.0
+        specs = [
+            # (key, profiling role, kernel symbol, what, algorithmic bytes per launch, flops per launch)
+            ("lstm_pair", 3 if fused else 2,
+             ("skinny_wide_kernel<true,3>" if es == 2.0 else "skinny_gemm_kernel<true,3,false>") if fused else "skinny_gemm_kernel<true,2>",
+             "decoder LSTM of step t-1 (64x2560x4096) + attention LSTM of step t (64x1536x4096), %s + fused cells" % mm
+             if fused else "decoder LSTM step on the side stream (its duration includes sharing the CUs)",
+             lstm_bytes(Kd, Hd, False) + (lstm_bytes(Ka, Ha, True) if fused else 0.0),
+             2.0 * B * (4 * Hd * Kd + (4 * Ha * Ka if fused else 0))),
+            ("attention_forward", 5, "attn_fwd_fused_kernel",
+             "energies (K_e), granule hand-off, softmax + context (K_c) of one decoder time step, 4 workgroups per utterance",
+             attn_bytes + es * A * Ha, 2.0 * (B * A * Ha + ti_sum * (A * 62 + A + E))),
+            ("attention_backward", 4, "attn_bwd_main_kernel",
+             "K_b1 phase, granule hand-off, K_b2 phase" + (", the step's two LSTM cell backwards" if folded else "") +
+             " of one decoder time step, 4 workgroups per utterance",
+             attn_bytes + cell_bytes, 2.0 * (2 * B * A * Ha + ti_sum * (3 * A * 62 + 2 * A + 2 * E))),
+            ("dgrad_pair", 6, "skinny_wide_kernel<false,3>" if es == 2.0 else "skinny_gemm_kernel<false,3,false>",
+             "BPTT data gradients dgates_d(t-1).Wd_cat (64x4096x2560) + dgates_a(t).Wa_rec (64x4096x1536), split-K %d, %s" % (ns, mm),
+             es * (4 * Hd * Kd + 4 * Ha * Ka) + es * B * (4 * Hd + 4 * Ha) + 4.0 * ns * B * (Kd + Ka),
+             2.0 * B * (4 * Hd * Kd + 4 * Ha * Ka)),
+        ]
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (bench.py cannot run the profiler around
+        # itself).  The file records the hash of ALL kernel sources it was measured on: a stale measurement reads as null.
+        pmc = {}
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
                 rec = json.load(fh)
             if rec.get("source_sha1") == kernel_source_sha1():
-                traffic = rec.get(("fused_" if fused else "single_") + args.precision)
+                pmc = rec.get("kernels_" + args.precision, {})
         except Exception:
-            traffic = None
-        roofline = {"kernel": kname, "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic,
-                    "avg_launch_us": avg_s * 1e6, "avg_bracket_us": raw_s * 1e6, "empty_bracket_us": ev_ms * 1e3,
-                    "launches": cnt, "algorithmic_bytes_per_launch": alg_bytes,
-                    "mfma": {"achieved_tflops": alg_flops / avg_s / 1e12,
-                             "peak_tflops": 2500.0 if es == 2.0 else 157.3,
-                             "frac": alg_flops / avg_s / 1e12 / (2500.0 if es == 2.0 else 157.3)}}
-        # ---- the attention-backward pair (K_b1 + K_b2) of one time step, same method, one more untimed step ---------
-        native.profile_enable(4, To)
-        step(batches[-1])
-        torch.cuda.synchronize()
-        ev4 = native.profile_event_overhead()
-        ms4, cnt4 = native.profile_read()
-        if cnt4 > 0:
-            ti_sum = float(batches[-1][1].sum().item())
-            ab_bytes = es * 640.0 * ti_sum                    # the encoder memory + its projection, once per step
-            ab_s = max((ms4 / 1e3) / cnt4 - ev4 / 1e3, 1e-9)
-            folded = bool(native.get_bptt_cell_fold())
-            # with the cells folded in, the launch also moves both LSTMs' saved gates, cell states, masks and carries
-            # and writes the gate gradients (f32 + the bf16 operand copy of the dgrad GEMM in bf16 mode): per hidden
-            # unit 4 gates + c + c_prev + dc in/out + 4 gate gradients = 12 floats, 1 mask byte, 4 bf16
-            hd = hp.attention_rnn_dim + hp.decoder_rnn_dim
-            cell_bytes = B * hd * (12 * 4.0 + 1.0 + (8.0 if es == 2.0 else 0.0)) if folded else 0.0
-            roofline["attention_backward"] = {
-                "kernels": ("attn_bwd_main_kernel, one launch per decoder time step: K_b1 phase, granule hand-off, K_b2 "
-                            "phase" + (", the step's two LSTM cell backwards" if folded else "") +
-                            " (hipEventRecord bracket minus the calibrated empty bracket)"),
-                "algorithmic_bytes_per_step": ab_bytes + cell_bytes, "attention_bytes": ab_bytes, "cell_bytes": cell_bytes,
-                "avg_pair_us": ab_s * 1e6, "empty_bracket_us": ev4 * 1e3,
-                "achieved": (ab_bytes + cell_bytes) / ab_s / 1e9, "unit": "GB/s",
-                "frac": (ab_bytes + cell_bytes) / ab_s / 1e9 / 8000.0, "launches": cnt4}
+            pmc = {}
+        peak_tf = 2500.0 if es == 2.0 else 157.3
+        chain = {}
+        for key, role, sym, what, nbytes, flops in specs:
+            if not fused and key in ("attention_forward", "attention_backward", "dgrad_pair"):
+                continue
+            avg_s, cnt = timed_role(role)
+            if cnt == 0:
+                continue
+            t = pmc.get(key)
+            chain[key] = {"kernel": "%s (%s)" % (sym, what), "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": 8000.0,
+                          "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / 8000.0,
+                          "traffic": t.get("hbm_bytes") if t else None, "traffic_detail": t,
+                          "avg_launch_us": avg_s * 1e6, "launches": cnt, "total_ms_per_step": avg_s * cnt * 1e3,
+                          "algorithmic_bytes_per_launch": nbytes,
+                          "mfma": {"achieved_tflops": flops / avg_s / 1e12, "peak_tflops": peak_tf,
+                                   "frac": flops / avg_s / 1e12 / peak_tf}}
+        dominant = max(chain, key=lambda k: chain[k]["total_ms_per_step"])
+        roofline = dict(chain[dominant])
+        roofline["dominant_of"] = ("the four kernels of a decoder time step by total duration in this run (%s); rocprofv3 "
+                                   "--kernel-trace --stats of the same command: profiles/"
+                                   % ", ".join("%s %.1f ms" % (k, v["total_ms_per_step"]) for k, v in chain.items()))
+        roofline["chain"] = chain
+        roofline["chain_us_per_time_step"] = sum(v["avg_launch_us"] for v in chain.values())
+        if "lstm_pair" in chain:
+            roofline["lstm_pair"] = {k: chain["lstm_pair"][k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "traffic",
+                                                                       "algorithmic_bytes_per_launch", "mfma")}
         # ---- the whole training step against SURVEY 8d's per-padded-time-step bound ---------------------------------
-        ti_sum = float(batches[-1][1].sum().item())
         per_step = 2.0 * (18189969 * es + 640.0 * ti_sum * es) + 2.0 * B * 12300 * es
         ms_step = 1e3 * elapsed / args.steps
         roofline["whole_step"] = {
             "algorithmic_bytes_per_padded_time_step": per_step, "time_steps": To, "ms_per_step": ms_step,
             "achieved": per_step * To / (ms_step / 1e3) / 1e9, "unit": "GB/s",
             "frac": per_step * To / (ms_step / 1e3) / 1e9 / 8000.0,
-            "dependent_launches_per_time_step": 2 + (2 if native.get_bptt_cell_fold() else 3),
+            "dependent_launches_per_time_step": 2 + (2 if folded else 3),
             "note": "SURVEY 8d: 2 x (step weights + encoder memory) + saved activations per padded time step; encoder, "
                     "postnet, dense weight-gradient GEMMs and the optimiser are inside ms_per_step but not in the bytes"}
     # ---- the same step in fp32 parity mode, reported beside a bf16 run (fewer steps, same batches) ----------

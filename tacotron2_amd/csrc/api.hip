@@ -123,6 +123,33 @@ extern "C" int t2amd_debug_launch_chain_(float* p, int n, int blocks, void* stre
     return 0;
 }
 
+// tests only (tests/test_zz9_dp_gpu.py: co-residency stress): `ncus` workgroups that each take a whole CU's LDS
+// (160 KB dynamic: nothing else that needs LDS can be placed beside them) and sleep until `*stop` becomes non-zero or
+// `ms` milliseconds of the 100 MHz wall clock have passed -- the stand-in for a co-resident RCCL kernel that takes CUs
+// away from the engine's hand-off kernels.  `arrived` counts the workgroups that have started.
+__global__ void t2_hold_cu_kernel(unsigned long long ticks, const int* stop, int* arrived) {
+    extern __shared__ char hold_smem[];
+    if (threadIdx.x == 0) {
+        hold_smem[0] = 1;
+        atomicAdd(arrived, 1);
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < ticks) {
+            if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+}
+extern "C" int t2amd_debug_hold_cus_(int ncus, float ms, const int* stop, int* arrived, void* stream) {
+    T2_REQUIRE(ncus > 0 && ncus <= 256 && ms > 0.f && ms <= 5000.f && stop && arrived, "debug_hold_cus: bad args");
+    const int lds = 160 * 1024;
+    if (hipFuncSetAttribute((const void*)t2_hold_cu_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        T2_FAIL("debug_hold_cus: cannot raise the LDS limit");
+    hipLaunchKernelGGL(t2_hold_cu_kernel, dim3(ncus), dim3(64), lds, (hipStream_t)stream,
+                       (unsigned long long)(ms * 1e5f), stop, arrived);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 // tools/microbench_launch.py: the same chain captured once into a hipGraph and replayed `reps` times; returns the
 // average milliseconds per replay (HIP events on `stream`), or a negative HIP error code.
 extern "C" float t2amd_debug_graph_chain_(float* p, int n, int blocks, int reps, void* stream) {

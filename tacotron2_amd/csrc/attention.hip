@@ -883,8 +883,8 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
         p.token = g_attn_fwd_token;
         p.kc_smem_off = (int)(lds_ea / sizeof(float));
         p.delay = fwd_delay;
-        if (a->memory16) T2_LAUNCH(attn_fwd_fused_kernel<true>, dim3(NSL, a->B), dim3(KE_NT), lds_ea + lds_c, s, p);
-        else T2_LAUNCH(attn_fwd_fused_kernel<false>, dim3(NSL, a->B), dim3(KE_NT), lds_ea + lds_c, s, p);
+        if (a->memory16) T2_LAUNCH_ROLE(5, attn_fwd_fused_kernel<true>, dim3(NSL, a->B), dim3(KE_NT), lds_ea + lds_c, s, p);
+        else T2_LAUNCH_ROLE(5, attn_fwd_fused_kernel<false>, dim3(NSL, a->B), dim3(KE_NT), lds_ea + lds_c, s, p);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
@@ -1816,15 +1816,13 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
             (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             g_attn_bwd_lds_cell = (int)ldsf;
         }
-        t2amd_profile_mark_(4, 0, s);
         if (gran) {
-            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
-            else T2_LAUNCH((attn_bwd_main_kernel<true, false, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            if (a->memory16) T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, true, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, false, true, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
         } else {
-            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
-            else T2_LAUNCH((attn_bwd_main_kernel<true, false, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            if (a->memory16) T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, true, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, false, true, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
         }
-        t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
@@ -1841,15 +1839,13 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
             (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             g_attn_bwd_lds_fused = (int)ldsf;
         }
-        t2amd_profile_mark_(4, 0, s);
         if (gran) {
-            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
-            else T2_LAUNCH((attn_bwd_main_kernel<true, false, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            if (a->memory16) T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, true, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, false, false, true>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
         } else {
-            if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<true, true, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
-            else T2_LAUNCH((attn_bwd_main_kernel<true, false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            if (a->memory16) T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, true, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
+            else T2_LAUNCH_ROLE(4, (attn_bwd_main_kernel<true, false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), ldsf, s, p);
         }
-        t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
     } else {
         t2amd_profile_mark_(4, 0, s);          // role 4: the attention backward pair of one time step (bench.py roofline)

@@ -2,6 +2,7 @@
 // Wave = 64 lanes everywhere; MFMA f32 forms are exact-f32 (k-ordered fmaf chain).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include "../../include/tacotron2_amd.h"
@@ -35,6 +36,21 @@ extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s);
 #define T2_LAUNCH(kern, grid, block, lds, stream, ...)                                 \
     do {                                                                               \
         if (!t2amd_validate_only_flag_())                                              \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);           \
+    } while (0)
+
+// The same launch carrying an event pair when bench.py's roofline leg profiles role `role` (t2amd_profile_enable): the
+// pair is stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop events = the kernel begin/end timestamps
+// rocprofv3 --kernel-trace reports), so there is no bracket overhead to calibrate away.  Roles: 3 fused LSTM pair of a
+// decoder time step, 4 attention backward (+ folded cells), 5 attention forward (one-launch form), 6 BPTT dgrad pair.
+extern "C" bool t2amd_profile_pair_(int tag, hipEvent_t* e0, hipEvent_t* e1);
+#define T2_LAUNCH_ROLE(role, kern, grid, block, lds, stream, ...)                      \
+    do {                                                                               \
+        if (t2amd_validate_only_flag_()) break;                                        \
+        hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                     \
+        if (t2amd_profile_pair_(role, &pe0_, &pe1_))                                   \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, pe0_, pe1_, 0, __VA_ARGS__); \
+        else                                                                           \
             hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);           \
     } while (0)
 
@@ -142,7 +158,6 @@ __device__ __forceinline__ void t2_ts_mark(bool on, unsigned long long* ts, int 
 }
 
 // internal entry points shared between translation units (not part of the C ABI)
-extern "C" bool t2amd_profile_pair_(int tag, hipEvent_t* e0, hipEvent_t* e1);
 extern "C" unsigned long long* t2amd_debug_ts_();
 int t2amd_proj_finish_small_(const t2amd_small_linear* a, int* out_lengths, uint8_t* active, int* done_count, int t,
                              int max_steps, float thr, int gate_row, void* stream);

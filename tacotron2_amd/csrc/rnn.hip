@@ -1178,17 +1178,17 @@ extern "C" int t2amd_skinny_gemm2_f32(const t2amd_skinny_gemm* a, const t2amd_sk
         if (b) { d.p[1].gx = t2_cdiv(b->N, 32); total += d.p[1].gx * d.p[1].gy * d.p[1].gz; } else { d.p[1] = d.p[0]; }
         if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<false, 1>), dim3(total), dim3(512), 0, s, d);
         else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<false, 2>), dim3(total), dim3(512), 0, s, d);
-        else if (a->tag == 3) T2_LAUNCH((skinny_wide_kernel<false, 3>), dim3(total), dim3(512), 0, s, d);
+        else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_wide_kernel<false, 3>), dim3(total), dim3(512), 0, s, d);   // BPTT dgrad pair
         else T2_LAUNCH((skinny_wide_kernel<false, 0>), dim3(total), dim3(512), 0, s, d);
     } else if (a->bf16) {
         if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1, true>), dim3(total), dim3(256), 0, s, d);
         else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2, true>), dim3(total), dim3(256), 0, s, d);
-        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<false, 3, true>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_gemm_kernel<false, 3, true>), dim3(total), dim3(256), 0, s, d);
         else T2_LAUNCH((skinny_gemm_kernel<false, 0, true>), dim3(total), dim3(256), 0, s, d);
     } else {
         if (a->tag == 1) T2_LAUNCH((skinny_gemm_kernel<false, 1, false>), dim3(total), dim3(256), 0, s, d);
         else if (a->tag == 2) T2_LAUNCH((skinny_gemm_kernel<false, 2, false>), dim3(total), dim3(256), 0, s, d);
-        else if (a->tag == 3) T2_LAUNCH((skinny_gemm_kernel<false, 3, false>), dim3(total), dim3(256), 0, s, d);
+        else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_gemm_kernel<false, 3, false>), dim3(total), dim3(256), 0, s, d);
         else T2_LAUNCH((skinny_gemm_kernel<false, 0, false>), dim3(total), dim3(256), 0, s, d);
     }
     T2_LAUNCH_CHECK();

@@ -22,8 +22,15 @@ What is different (MI355X-first):
   * the engine writes every gradient STRAIGHT into its bucket (``GradSync.out`` hands the kernels views of the
     flat buffers, 256-byte aligned), so nothing is packed or copied before the all-reduce either.
 
-Only ``tacotron2_amd.model.Tacotron2`` is supported: its backward is the engine's, which knows when a bucket is
-complete.  Any other module raises (the reference's hook-based path is not restated here).
+``tacotron2_amd.model.Tacotron2`` is exchanged by its own backward (the engine knows when a bucket is complete).
+Any other ``nn.Module`` takes the hook-driven path below -- the reference's contract for arbitrary modules
+(distributed.py:126-173) without its shape: gradients are gathered into size-capped flat buckets in the order autograd
+finishes them and every bucket is all-reduced asynchronously the moment its last gradient has been accumulated,
+overlapping the rest of the backward; one end-of-backward callback waits for them and hands the means back.
+
+Round 3: the flat buckets are PERSISTENT (allocated and zero-filled once, not 112.8 MB of ``torch.zeros`` per backward)
+and the mean is formed by the collective itself on RCCL (``ReduceOp.AVG``: no ``div_`` pass over every bucket); ``gloo``
+(CPU tests, single-GPU functional runs) has no AVG and keeps SUM + one scale.
 """
 import torch
 import torch.distributed as dist
@@ -64,20 +71,33 @@ def _flat_broadcast(tensors, src=0):
 ALIGN_ELEMS = 64           # every gradient starts on a 256-byte boundary of its bucket (vector stores in the kernels)
 
 
+def _mean_op(group=None):
+    """(reduce op, needs a division afterwards).  RCCL averages in the collective; gloo only sums."""
+    if dist.is_initialized() and dist.get_backend(group) == 'nccl' and hasattr(dist.ReduceOp, 'AVG'):
+        return dist.ReduceOp.AVG, False
+    return dist.ReduceOp.SUM, True
+
+
 class GradSync(object):
     """Bucketed asynchronous gradient all-reduce driven by the engine's backward.
 
-    Per backward: ``start(device)`` allocates the three flat buckets, the engine asks ``out(name, shape)`` for the
+    Per backward: ``start(device)`` makes the three flat buckets current, the engine asks ``out(name, shape)`` for the
     tensor each gradient kernel writes into (a view of the bucket), ``bucket_ready(bucket)`` launches that bucket's
     all-reduce the moment its last gradient has been enqueued, ``finish()`` orders the compute stream behind all of
-    them and forms the mean."""
+    them (and forms the mean where the collective could not).
+
+    The buckets persist across steps.  They are handed to autograd as the parameters' gradients, so a step that finds a
+    live ``p.grad`` still pointing into them (gradient accumulation: no ``zero_grad`` since the last backward) gets a
+    fresh set instead -- writing the new gradients over the old ones would double them."""
 
     def __init__(self, named_params, world_size=None, group=None):
+        named_params = list(named_params)
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
         self.layout = {}                                  # bucket -> [(name, offset, numel)]
         self.sizes = {}
         self.where = {}                                   # name -> (bucket, offset, numel)
+        self.params = [p for _, p in named_params]
         for name, p in named_params:
             b = bucket_of(name)
             off = (self.sizes.get(b, 0) + ALIGN_ELEMS - 1) // ALIGN_ELEMS * ALIGN_ELEMS
@@ -86,18 +106,41 @@ class GradSync(object):
             self.sizes[b] = off + p.numel()
         self.flat = {}
         self.pending = []
+        self._persistent = {}                             # (device, dtype) -> {bucket: flat}
+        self.fresh_allocations = 0                        # how many times a bucket set was allocated (tests)
         # gloo (host-staged; only ever used with GPU tensors to exercise this path on a single-GPU box) completes each
         # bucket before the next is launched: three host-staged all-reduces in flight at once buy nothing and share
         # torch's pinned staging buffers.  RCCL -- the production backend -- stays fully asynchronous.
         self.serial = dist.is_initialized() and dist.get_backend(group) == 'gloo'
+        self.op, self.divide = _mean_op(group)
+
+    def _aliased(self, flats):
+        """True when some live ``p.grad`` still points into one of these flat buffers."""
+        spans = [(f.data_ptr(), f.data_ptr() + f.numel() * f.element_size()) for f in flats.values()]
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                continue
+            a = g.data_ptr()
+            for lo, hi in spans:
+                if lo <= a < hi:
+                    return True
+        return False
 
     def start(self, device=None, dtype=torch.float32):
         self.pending = []
         self.flat = {}
-        if device is not None:
-            for b, n in self.sizes.items():
-                # zero-filled: the alignment gaps travel through the all-reduce too and must stay finite
-                self.flat[b] = torch.zeros(n, dtype=dtype, device=device)
+        if device is None:
+            return
+        key = (str(device), dtype)
+        flats = self._persistent.get(key)
+        if flats is None or self._aliased(flats):
+            # zero-filled once: the alignment gaps travel through the all-reduce too and must stay finite (the kernels
+            # only ever write the gradients' own extents, so the gaps stay zero for the life of the buffers)
+            flats = {b: torch.zeros(n, dtype=dtype, device=device) for b, n in self.sizes.items()}
+            self._persistent[key] = flats
+            self.fresh_allocations += 1
+        self.flat = dict(flats)
 
     def out(self, name, shape):
         """The tensor the engine's kernels write gradient ``name`` into: a view of its bucket."""
@@ -121,34 +164,107 @@ class GradSync(object):
                 if g.data_ptr() != view.data_ptr():
                     view.copy_(g)
                     grads[name] = view
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work = dist.all_reduce(flat, op=self.op, group=self.group, async_op=True)
         if self.serial:
             work.wait()
         self.pending.append((flat, work))
 
     def finish(self):
-        """Order the compute stream behind every outstanding all-reduce and form the mean."""
+        """Order the compute stream behind every outstanding all-reduce (and form the mean after a SUM)."""
         for flat, work in self.pending:
             work.wait()
-            flat.div_(self.world)
+            if self.divide:
+                flat.mul_(1.0 / self.world)
         self.pending = []
 
 
+# ---- any other nn.Module: hook-driven buckets ------------------------------------------------------------------------
+HOOK_BUCKET_BYTES = 32 << 20       # xGMI ring all-reduce of 32 MB ~ 0.4 ms: large enough to be bandwidth- not latency-bound
+
+
+class HookSync(object):
+    """Gradient exchange for a module whose backward is torch's (reference distributed.py:126-173 semantics: after
+    ``backward()`` every ``p.grad`` is the world mean).  Parameters are grouped, in REVERSE registration order (roughly the
+    order autograd finishes them), into buckets of at most ``HOOK_BUCKET_BYTES`` per dtype; a post-accumulate hook per
+    parameter copies its gradient into the bucket and the last arrival launches the bucket's asynchronous all-reduce;
+    one callback queued on the autograd engine at the first arrival waits for every launched bucket, sweeps up buckets a
+    partial backward left incomplete (unused parameters), and copies the means back into ``p.grad``."""
+
+    def __init__(self, module, group=None, bucket_bytes=None):
+        bucket_bytes = HOOK_BUCKET_BYTES if bucket_bytes is None else bucket_bytes
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.op, self.divide = _mean_op(group)
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets = []                                 # each: dict(params, offsets, numel, dtype, flat, arrived, work)
+        self.bucket_of = {}
+        cur = {}
+        for p in reversed(params):
+            b = cur.get(p.dtype)
+            if b is None or (b['numel'] + p.numel()) * p.element_size() > bucket_bytes and b['params']:
+                b = dict(params=[], offsets=[], numel=0, dtype=p.dtype, flat=None, arrived=0, work=None)
+                self.buckets.append(b)
+                cur[p.dtype] = b
+            b['offsets'].append(b['numel'])
+            b['params'].append(p)
+            b['numel'] += p.numel()
+            self.bucket_of[p] = b
+        self.armed = False
+        self.handles = [p.register_post_accumulate_grad_hook(self._arrived) for p in params]
+
+    def _launch(self, b, only_present=False):
+        first = next(p for p in b['params'] if p.grad is not None)
+        if b['flat'] is None or b['flat'].device != first.grad.device:
+            b['flat'] = torch.zeros(b['numel'], dtype=b['dtype'], device=first.grad.device)
+        elif only_present:
+            b['flat'].zero_()
+        for p, off in zip(b['params'], b['offsets']):
+            if p.grad is not None:
+                b['flat'][off:off + p.numel()].view_as(p.grad).copy_(p.grad)
+        b['work'] = dist.all_reduce(b['flat'], op=self.op, group=self.group, async_op=True)
+
+    def _arrived(self, p):
+        if not self.armed:
+            self.armed = True
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(self._finish)
+        b = self.bucket_of[p]
+        b['arrived'] += 1
+        if b['arrived'] == len(b['params']):
+            self._launch(b)
+
+    def _finish(self):
+        self.armed = False
+        for b in self.buckets:
+            if b['work'] is None and b['arrived'] > 0:   # some of its parameters took no part in this backward
+                self._launch(b, only_present=True)
+        for b in self.buckets:
+            if b['work'] is not None:
+                b['work'].wait()
+                if self.divide:
+                    b['flat'].mul_(1.0 / self.world)
+                for p, off in zip(b['params'], b['offsets']):
+                    if p.grad is not None:
+                        p.grad.copy_(b['flat'][off:off + p.numel()].view_as(p.grad))
+            b['work'], b['arrived'] = None, 0
+
+
 def apply_gradient_allreduce(module):
-    """Make ``module`` data-parallel in place and return it (reference distributed.py:126-173)."""
+    """Make ``module`` data-parallel in place and return it (reference distributed.py:126-173).  Idempotent: the
+    reference wraps the model twice (train.py:79 and :179) -- a second call re-broadcasts rank 0's state and returns the
+    module, already exchanging gradients."""
     if not dist.is_initialized():
         raise RuntimeError("apply_gradient_allreduce: torch.distributed is not initialised "
                            "(reference train.py:27-39 init_distributed does this first)")
     _flat_broadcast([v for v in module.state_dict().values() if torch.is_tensor(v)], 0)
-    if getattr(module, '_t2amd_dp_applied', False):      # the reference wraps twice (train.py:79,179)
+    if getattr(module, '_t2amd_dp_applied', False):
         return module
-    module._t2amd_dp_applied = True
 
     from .model import Tacotron2
     if isinstance(module, Tacotron2):
         # engine-driven: the autograd Function calls bucket_ready()/finish() itself
         module._grad_sync = GradSync(list(module.named_parameters()))
-        return module
-
-    raise TypeError("apply_gradient_allreduce: only tacotron2_amd.model.Tacotron2 is data-parallel here (its backward is "
-                    "the engine's and knows when a gradient bucket is complete); got %s" % type(module).__name__)
+    else:
+        module._hook_sync = HookSync(module)
+    module._t2amd_dp_applied = True
+    return module

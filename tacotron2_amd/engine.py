@@ -465,6 +465,65 @@ def _weight_cache(model):
     return cache
 
 
+def invalidate_weight_cache(model):
+    """Drop every packed / transposed / bf16 weight image of ``model``: the next call rebuilds them from the parameters.
+    Needed only after writes the cache key cannot see (``param.data`` edits, raw-pointer optimisers); ``load_state_dict``,
+    ``.to()`` / ``.cuda()`` / ``.half()`` and ``optim.FusedAdam`` invalidate by themselves."""
+    cache = getattr(model, '_weight_cache', None)
+    if cache is not None:
+        cache.clear()
+
+
+# Content guard of the weight-image cache (ADVICE r02).  Writes through ``param.data`` (an EMA swap, ``p.data.copy_``) or
+# by a raw-pointer optimiser change the weights without touching anything the cache key is made of, and the engine would
+# go on multiplying by stale packed images while reading other operands live.  Every call therefore enqueues one pass over
+# all parameters (the global-norm kernel of csrc/optim.hip: 113 MB, ~25 us on an MI355X) -- the weights' signature.
+#   * key changed since the previous call (an optimiser step, load_state_dict, ...): the images are rebuilt anyway; the
+#     signature is recorded with them, asynchronously -- a training loop never synchronises here;
+#   * key unchanged (the images are about to be REUSED: inference calls, validation, a step after a ``.data`` edit): the
+#     signature is read back (one event wait, ~tens of us) and compared with the recorded one BEFORE any image is used;
+#     a difference drops the cache, so this very call already runs on fresh images, and a note on stderr names the
+#     explicit remedy.  T2AMD_WEIGHT_GUARD=0 turns the guard off.
+WEIGHT_GUARD = os.environ.get('T2AMD_WEIGHT_GUARD', '1') != '0'
+
+
+def _guard_weights(model, run, P):
+    if not WEIGHT_GUARD or nv.validate_only():
+        return
+    cache = run.cache
+    params = [p for p in P.values() if p.dtype == torch.float32 and p.is_cuda]
+    if not params or len(params) > nv.MAX_TENSORS:
+        return
+    key = (_PACK_GEN[0], str(run.dev)) + tuple((p.data_ptr(), p._version) for p in params)
+    g = cache.get('__guard__')
+    fresh = g is None or g['key'] != key
+    if fresh:
+        L, blocks = nv.tensor_list(params)
+        g = dict(key=key, L=L, blocks=blocks, keep=params,
+                 ws=torch.empty(blocks, dtype=torch.float64, device=run.dev),
+                 dev=torch.empty(2, 2, dtype=torch.float32, device=run.dev),
+                 host=torch.zeros(2, 2, dtype=torch.float32).pin_memory())
+        cache['__guard__'] = g
+    slot = 0 if fresh else 1                       # 0: signature recorded with the images, 1: signature of this call
+    nv.grad_norm(g['L'], g['blocks'], 0.0, g['ws'], g['dev'][slot])
+    g['host'][slot].copy_(g['dev'][slot], non_blocking=True)
+    if fresh:
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    ev.synchronize()                               # stream order: the slot-0 copy of an earlier call has landed too
+    if float(g['host'][1][0]) != float(g['host'][0][0]):
+        import sys
+        print("tacotron2_amd: the parameters changed without their version counters changing (a write through "
+              "param.data or a raw pointer); the packed weight images are rebuilt for this call.  Call "
+              "model.invalidate_weight_cache() (or engine.bump_weight_generation()) after such an edit.",
+              file=sys.stderr, flush=True)
+        keep = dict(g)
+        cache.clear()
+        keep['host'][0].copy_(keep['host'][1])
+        cache['__guard__'] = keep
+
+
 def _cached_bias_sum(run, tag, b1, b2):
     return run.cached(tag, [b1, b2], lambda: _bias_sum(run, b1, b2))
 
@@ -546,6 +605,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
                           "There is no CPU path; the CPU oracle lives in oracle/ for tests." % dev)
     nv.load()
     run = _Run(dev, getattr(model, 'precision', 'fp32'), _weight_cache(model))
+    _guard_weights(model, run, P)
     P, _ = _embed_attention(run, P)
     ms = MaskSource(model.dropout_masks, dev)
     c = _Ctx()
@@ -1125,6 +1185,8 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     for n, p in P.items():
         if p.dtype != torch.float32:
             raise NativeError("parameter %s is %s: the engine reads f32, fp16 or bf16 parameters" % (n, p.dtype))
+    if not low:
+        _guard_weights(model, run, P)
     P, _ = _embed_attention(run, P)
     ms = MaskSource(model.dropout_masks, dev)
     B, Ti = text.shape

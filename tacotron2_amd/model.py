@@ -138,6 +138,38 @@ class Tacotron2(nn.Module):
         self.precision = 'fp32'
         self._output_dtype = None
 
+    # -- the engine's packed weight images (engine._Run.cached) live on the module but are not part of it ------------
+    def invalidate_weight_cache(self):
+        """Drop the packed / transposed / bf16 weight images; the next call rebuilds them (needed after ``param.data``
+        edits -- everything torch tracks, ``load_state_dict`` and device / dtype moves invalidate by themselves)."""
+        engine.invalidate_weight_cache(self)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weight_cache()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_weight_cache()
+        return out
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_weight_cache', None)          # device images of the weights: rebuilt on demand, never pickled
+        state.pop('_grad_sync', None)             # process-group state of the data-parallel wrapper
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ('_weight_cache', '_grad_sync'):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     # -- inference.ipynb cell 7: ``model.cuda().eval().half()`` -----------------------------------
     def half(self):
         """Reduced-precision mode without reduced-precision *storage*: the parameters stay f32 master

@@ -4,7 +4,8 @@
     the world-mean gradient, bucketed postnet -> decoder -> encoder, and the tensors handed back
     are views into the flat bucket buffers;
   * the same through GradSync.out(): the engine's kernels write into the buckets directly;
-  * apply_gradient_allreduce: state broadcast from rank 0; modules other than Tacotron2 are refused.
+  * apply_gradient_allreduce: state broadcast from rank 0; Tacotron2 is exchanged by the engine's backward through
+    persistent buckets, any other module through hook-driven buckets (world mean, unused parameters, double wrap).
   (N ranks x B == mean of the single-rank gradients with the REAL engine: tests/test_zz9_dp_gpu.py.)
 """
 import os
@@ -78,13 +79,47 @@ def _worker(rank, world, port, q):
             other = torch.randn(p.shape, generator=g_other)
             assert torch.allclose(sync.out(n, p.shape), (mine2[n] + other) / 2, atol=1e-6), n
 
-        # ---- any other module is refused (only the engine knows when a bucket is complete) ----
+        # ---- the buckets persist across backwards; a live p.grad that still points into them forces a fresh set ----
+        n_alloc = sync.fresh_allocations
+        keep_ptr = sync.flat['decoder'].data_ptr()
+        sync.start(torch.device('cpu'))
+        assert sync.fresh_allocations == n_alloc and sync.flat['decoder'].data_ptr() == keep_ptr
+        some = next(iter(model.parameters()))
+        some.grad = sync.out(next(iter(dict(model.named_parameters()))), some.shape)      # gradient accumulation in progress
+        sync.start(torch.device('cpu'))
+        assert sync.fresh_allocations == n_alloc + 1
+        some.grad = None
+
+        # ---- any other module: hook-driven buckets, world mean in p.grad after backward (reference distributed.py:126-173)
+        torch.manual_seed(100 + rank)                       # ranks start from different weights: rank 0's must win
         net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+        unused = torch.nn.Linear(3, 3)
+        net.add_module('unused', unused)
+        import tacotron2_amd.distributed as D
+        D.HOOK_BUCKET_BYTES, keep_bb = 64, D.HOOK_BUCKET_BYTES      # tiny buckets: several of them, launched at different times
         try:
-            apply_gradient_allreduce(net)
-            raise AssertionError("generic module accepted")
-        except TypeError:
-            pass
+            assert apply_gradient_allreduce(net) is net
+        finally:
+            D.HOOK_BUCKET_BYTES = keep_bb
+        assert apply_gradient_allreduce(net) is net         # second wrap: no second set of hooks
+        assert len(net._hook_sync.buckets) > 1
+        w0 = [p.detach().clone() for p in net.parameters()]
+        gather = [torch.zeros_like(w0[0]) for _ in range(world)]
+        dist.all_gather(gather, w0[0])
+        assert torch.equal(gather[0], gather[1])            # state broadcast
+        ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+        ref.load_state_dict({k: v for k, v in net.state_dict().items() if not k.startswith('unused')})
+        for step in range(2):                               # twice: the per-backward state resets
+            xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(50 + 10 * step + r)) for r in range(world)]
+            for q_ in ref.parameters():
+                q_.grad = None
+            for r in range(world):
+                (ref[2](ref[1](ref[0](xs[r]))).pow(2).sum() / world).backward()
+            net.zero_grad()
+            net[2](net[1](net[0](xs[rank]))).pow(2).sum().backward()
+            for a, b in zip([net[0].weight, net[0].bias, net[2].weight, net[2].bias], ref.parameters()):
+                assert torch.allclose(a.grad, b.grad, atol=1e-6), (step, a.grad, b.grad)
+            assert unused.weight.grad is None
         apply_gradient_allreduce(model)                     # the reference wraps twice (train.py:79,179); harmless
         m = reduce_tensor(torch.tensor(float(rank + 1)), world)
         assert abs(m.item() - 1.5) < 1e-6

@@ -356,3 +356,31 @@ def test_bench_inference_leg_plumbing(native_lib, monkeypatch, capsys):
     for v in out.values():
         assert v["decode_steps_per_s"] > 0 and 0 < v["hbm_roofline"]["frac"]
         assert v["utterance_steps_per_s"] == pytest.approx(v["B"] * v["decode_steps_per_s"])
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` outside torch.distributed.run starts the N ranks itself (the driver's SCALE
+    run must not die on "launch through torch.distributed.run"; reference multiproc.py:1-23 is the same idea).  Here, on a
+    box without GPUs, every rank must get as far as the GPU check with its own RANK / WORLD_SIZE / MASTER_* environment."""
+    import subprocess
+    import sys
+    from tacotron2_amd import multiproc
+    envs = multiproc.rank_environments(4, 2950, base={})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and all(e["WORLD_SIZE"] == "4" for e in envs)
+    assert all(e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "2950" and e["LOCAL_RANK"] == e["RANK"] for e in envs)
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box check of the spawn path")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, T2AMD_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr                       # rank 0 reached the device check ...
+    with open(os.path.join(root, "gpurun_out", "rank1.log")) as f:
+        assert "needs an MI355X" in f.read()                   # ... and so did rank 1, in its own process
+    # without the gloo override the launcher itself refuses: RCCL needs one device per rank
+    env.pop("T2AMD_DIST_BACKEND")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr

@@ -143,3 +143,70 @@ def test_reduced_precision_parameter_storage_in_inference(native_lib):
     x, _ = low.parse_batch(batch)
     with _pytest.raises(NativeError, match="master weights"):
         low(x)
+
+
+def test_weight_image_cache_sees_param_data_edits(native_lib, capfd):
+    """packed / transposed / bf16 weight images are cached per weight version; a write through ``param.data``
+    changes neither the storage address nor the version counter.  The content guard (engine._guard_weights) must notice
+    it BEFORE the cached images are reused: the call after the edit equals a fresh model holding the edited weights,
+    in inference (both decode paths) and in a training step; deepcopy / pickle do not carry the device images."""
+    import copy
+    import pickle
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    from tacotron2_amd.model import Tacotron2
+    hp = create_hparams("max_decoder_steps=24")
+    hp.gate_threshold = 2.0
+    torch.manual_seed(3)
+    model = Tacotron2(hp).cuda().eval()
+    seq = torch.randint(1, 148, (1, 19)).cuda().long()
+    from oracle import tacotron2_oracle as orc
+    keep = orc.draw_masks_infer(hp, 1, 24, torch.Generator().manual_seed(2)).cuda()
+    for prec in ('fp32', 'bf16'):
+        model.precision = prec
+        model.dropout_masks = dict(prenet_infer=keep)
+        a = [o.clone() for o in model.inference(seq)]
+        b = model.inference(seq)                             # images reused, guard compares equal
+        assert torch.equal(a[0], b[0])
+        capfd.readouterr()
+        with torch.no_grad():
+            for n, p in model.named_parameters():            # an "EMA swap": every LSTM / projection weight through .data
+                if n.startswith('decoder.') and p.dim() == 2:
+                    p.data.mul_(0.97)
+        got = model.inference(seq)
+        assert "version counters" in capfd.readouterr().err
+        fresh = Tacotron2(hp).cuda().eval()
+        fresh.load_state_dict(model.state_dict())
+        fresh.precision = prec
+        fresh.dropout_masks = dict(prenet_infer=keep)
+        want = fresh.inference(seq)
+        for g_, w_ in zip(got, want):
+            assert torch.equal(g_, w_), prec
+        assert not torch.equal(got[0], a[0])
+    # copies carry parameters, not device images or process-group state
+    assert len(model._weight_cache) > 0
+    twin = copy.deepcopy(model)
+    assert not getattr(twin, '_weight_cache', None)
+    blob = pickle.dumps(model)
+    assert len(blob) < 1.3 * 4 * sum(p.numel() for p in model.parameters()) + (1 << 20)
+    # training: the edit between two steps (same FusedAdam generation, same version counters)
+    model.train()
+    model.precision = 'bf16'
+    model.dropout_masks = None
+    batch = gu.make_train_batch([13, 9], [22, 17], hp.n_mel_channels, 5)
+
+    def grads(m):
+        torch.manual_seed(8)
+        m.zero_grad()
+        x, y = m.parse_batch(tuple(t.clone() for t in batch))
+        Tacotron2Loss()(m(x), y).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    grads(model)
+    with torch.no_grad():
+        model.decoder.attention_rnn.weight_hh.data.mul_(1.1)
+    g1 = grads(model)
+    fresh = Tacotron2(hp).cuda().train()
+    fresh.load_state_dict(model.state_dict())
+    fresh.precision = 'bf16'
+    g2 = grads(fresh)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k

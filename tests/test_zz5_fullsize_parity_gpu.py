@@ -1,12 +1,18 @@
 """Parity at BASELINE scale against the LIVE oracle (shared dropout masks), both precision modes.
 
-  (i)   training: every 4th utterance of ``synth_batch(64, 1234)`` -- 16 utterances, Ti_max = 177, To = 870
-        (BASELINE configs[1] horizon: 870 dependent decoder steps forward and through BPTT), reference
-        model.py:405-411 under autograd;
+  (i)   training: the WHOLE of ``synth_batch(64, 1234)`` -- B = 64, Ti_max = 177, To = 870: BASELINE configs[1] itself,
+        the batch bench.py times (870 dependent decoder steps forward and through BPTT, every row of every 64-row
+        tile and every workgroup of the 4 x B attention grids live), reference model.py:405-411 under autograd;
+        ``T2AMD_FULLSIZE_B=16`` restores round 2's every-4th-utterance sub-batch (a quarter of the oracle time);
   (ii)  inference, B = 1, Ti = 100 (BASELINE configs[3]): greedy decode to a REAL gate stop beyond 300 steps,
         stop index exact, once with a comfortable and once with a SMALL crossing margin, reference
         model.py:435-449;
-  (iii) batched ragged inference with configs[4]'s length distribution (32 texts) against per-utterance oracle runs.
+  (iii) batched ragged inference with configs[4]'s length distribution (32 texts) against per-utterance oracle runs;
+  (iv)  BASELINE configs[4] itself: 256 ragged texts, >= 400 decoder steps with real stops -- the engine's stop vector
+        against the batched oracle's and sampled utterances against per-utterance B = 1 oracle runs (fp32 mode: exact
+        stops, 1e-4), then the bf16 mode (the skinny_wide64 / attn_energy4 kernels of B >= 256) against the same
+        oracle with the bf16 tolerance and exact stops wherever the oracle's own crossing margin exceeds the measured
+        bf16 gate noise; reference model.py:418-454 per utterance.
 
 Tolerances (stated here, measured values land in gpurun_out/parity_fullsize_*.json):
   fp32 mode   outputs mean |diff| < 1e-4 (north star: mel L1 < 1e-4), max < 5e-4 * max(1, max|ref|);
@@ -57,15 +63,20 @@ def full_train_case():
     hp = gu.make_hparams("")
     sd = gu.build_state_dict(hp, 1234)
     full = synth_batch(64, 1234)
-    idx = torch.arange(0, 64, 4)
+    Bs = int(os.environ.get("T2AMD_FULLSIZE_B", "64"))
+    idx = torch.arange(0, 64, 64 // Bs)[:Bs]
     text, il, mel, gate, ol = (t[idx] for t in full)
     Ti, To = int(il.max()), int(ol.max())
     assert To == 870 and Ti == 177
     batch = (text[:, :Ti].contiguous(), il, mel[:, :, :To].contiguous(), gate[:, :To].contiguous(), ol)
-    masks = orc.draw_masks_train(hp, 16, Ti, To, torch.Generator().manual_seed(1234))
+    masks = orc.draw_masks_train(hp, Bs, Ti, To, torch.Generator().manual_seed(1234))
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    import time
+    t0 = time.perf_counter()
     oloss, oout, ograds, obufs = orc.train_step_grads(sd, hp, batch, masks)
-    return dict(hp=hp, sd=sd, batch=batch, masks=masks, oloss=oloss, oout=oout, ograds=ograds, obufs=obufs)
+    return dict(hp=hp, sd=sd, batch=batch, masks=masks, oloss=oloss, oout=oout, ograds=ograds, obufs=obufs, B=Bs,
+                shape="B=%d of synth_batch(64,1234) (BASELINE configs[1]%s), Ti=%d, To=%d; oracle step %.1f s"
+                      % (Bs, "" if Bs == 64 else ": every %dth utterance" % (64 // Bs), Ti, To, time.perf_counter() - t0))
 
 
 def _engine_step(case, precision):
@@ -111,7 +122,7 @@ def test_train_step_To870_fp32(native_lib, full_train_case):
         mean, mx, rmax = _stats(msd[k].float(), v.float())
         if not mx < 1e-5 * max(1.0, rmax):
             bad.append(dict(what='buffer ' + k, max=mx, refmax=rmax))
-    _report("train_fp32", dict(shape="B=16 (every 4th of synth_batch(64,1234)), Ti=177, To=870", rows=rows, bad=bad))
+    _report("train_B%d_fp32" % c['B'], dict(shape=c['shape'], rows=rows, bad=bad))
     assert not bad, bad[:8]
 
 
@@ -142,7 +153,7 @@ def test_train_step_To870_bf16(native_lib, full_train_case):
     el, ol = float(loss.detach()), float(c['oloss'])
     rows.append(dict(what="bf16 summary", engine_loss=el, oracle_loss=ol, grad_cosine=cos, worst_rel_l2=worst,
                      worst_tensor=worst_k))
-    _report("train_bf16", dict(shape="B=16, Ti=177, To=870", rows=rows, fails=fails))
+    _report("train_B%d_bf16" % c['B'], dict(shape=c['shape'], rows=rows, fails=fails))
     assert not fails, fails
     assert abs(el - ol) < 2e-2 * abs(ol)
     assert cos > 0.995, cos
@@ -302,3 +313,141 @@ def test_batched_inference_config5_lengths(native_lib):
         assert rows['compaction_' + prec]['mel_max_diff'] < 1e-5 and rows['compaction_' + prec]['align_max_diff'] < 1e-6
     model.compact_min_rows = None
     model.precision = 'fp32'
+
+
+# ---------------------------------------------------------------------------------------------------
+# (iv) BASELINE configs[4] at its real batch size: 256 ragged texts, real stops
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config5_case():
+    """256 texts with configs[4]'s length distribution, the gate made to rise slowly (see (ii)), decoded by the BATCHED
+    oracle without stopping; the threshold is then put where at least a third of the utterances stop before the cap, at
+    most eight inside the initial transient, with the widest worst-case margin over every (utterance, step) the
+    stop rule looks at."""
+    from tacotron2_amd.synth import synth_lengths
+    B, steps = 256, 440
+    ti, _ = synth_lengths(B, 1234)
+    lens = [int(v) for v in ti]
+    hp = gu.make_hparams("max_decoder_steps=%d" % steps)
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()
+    wg[:, hp.decoder_rnn_dim:] *= -1.0
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    text = gu.make_text(lens, 778)
+    keep = orc.draw_masks_infer(hp, B, steps, torch.Generator().manual_seed(11))
+    il = torch.tensor(lens)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    import time
+    t0 = time.perf_counter()
+    (mel_o, post_o, gate_o, al_o), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0, input_lengths=il)
+    oracle_s = time.perf_counter() - t0
+    sig = torch.sigmoid(gate_o.reshape(B, steps).double())
+    best = None
+    for thr in torch.linspace(float(sig.min()), float(sig.max()), 1200)[1:-1].tolist():
+        over = sig > thr
+        stop = torch.where(over.any(1), over.float().argmax(1) + 1, torch.full((B,), steps))
+        if int((stop < steps).sum()) < B // 3 or int((stop < 30).sum()) > 8:
+            continue
+        looked = torch.arange(steps).unsqueeze(0) < stop.unsqueeze(1)          # what the stop rule reads
+        per_utt = torch.where(looked, (sig - thr).abs(), torch.full_like(sig, 9.0)).min(1).values
+        marg = float(per_utt.min())
+        if best is None or marg > best[1]:
+            best = (thr, marg, stop, per_utt)
+    assert best is not None
+    thr, marg, stop, per_utt = best
+    return dict(B=B, steps=steps, lens=lens, hp_str="max_decoder_steps=%d" % steps, sd=sd, text=text, keep=keep, il=il,
+                thr=thr, margin=marg, stop=stop, per_utt_margin=per_utt, mel=mel_o, post=post_o, align=al_o, sig=sig,
+                oracle_s=oracle_s)
+
+
+def _config5_engine(c, precision):
+    ohp = gu.make_hparams(c['hp_str'])
+    ohp.gate_threshold = c['thr']
+    model = _model(ohp, c['sd']).eval()
+    model.precision = precision
+    model.dropout_masks = dict(prenet_infer=c['keep'].to(DEV))
+    with torch.no_grad():
+        out = model.inference(c['text'].to(DEV), c['il'].to(DEV))
+    torch.cuda.synchronize()
+    return ohp, model, out
+
+
+def test_config5_B256_fp32_stops_and_per_utterance_oracle(native_lib, config5_case):
+    c = config5_case
+    B, steps, stop = c['B'], c['steps'], c['stop']
+    ohp, model, out = _config5_engine(c, 'fp32')
+    got = model.last_inference_lengths.tolist()
+    rows = dict(shape="B=256 ragged (synth_lengths(256,1234): Ti %d..%d), max_decoder_steps=%d" % (min(c['lens']), max(c['lens']), steps),
+                threshold=c['thr'], margin=c['margin'], batched_oracle_seconds=c['oracle_s'],
+                stopped_before_cap=int((stop < steps).sum()), earliest_stop=int(stop.min()),
+                stops_equal=(got == stop.tolist()), decode_path=model.last_decode_path, per_utterance=[])
+    _report("infer_config5_B256_fp32", rows)
+    assert got == stop.tolist(), [(b, got[b], int(stop[b])) for b in range(B) if got[b] != int(stop[b])][:8]
+    # the whole batch against the batched oracle (masked frames beyond each stop are zero on both sides)
+    Tout = out[0].shape[2]
+    assert Tout == int(stop.max())
+    valid = (torch.arange(Tout).unsqueeze(0) < stop.unsqueeze(1))
+    for i, (nm, ref) in enumerate((('mel', c['mel']), ('mel_post', c['post']))):
+        ref = ref[:, :, :Tout] * valid.unsqueeze(1).to(ref.dtype)
+        mean, mx, rmax = _stats(out[i], ref)
+        rows[nm + '_vs_batched_oracle'] = dict(mean=mean, max=mx, refmax=rmax)
+        assert mean < 1e-4 and mx < 5e-4 * max(1.0, rmax), (nm, rows[nm + '_vs_batched_oracle'])
+    # >= 16 sampled utterances against per-utterance B = 1 oracle runs on the unpadded text (reference semantics)
+    early = [b for b in range(B) if int(stop[b]) < steps]
+    sample = sorted(set([0, 1, B // 2, B - 2, B - 1] + early[::max(1, len(early) // 12)][:12] + list(range(7, B, 37))))
+    assert len(sample) >= 16
+    for b in sample:
+        L = int(stop[b])
+        Lb = c['lens'][b]
+        oref, olen, _ = orc.tacotron2_inference(c['sd'], ohp, c['text'][b:b + 1, :Lb], c['keep'][:, :, b:b + 1])
+        assert olen.tolist() == [L], (b, olen.tolist(), L)
+        r = dict(b=b, Ti=Lb, stop=L)
+        for nm, g_, w_ in (('mel', out[0][b, :, :L], oref[0][0]), ('mel_post', out[1][b, :, :L], oref[1][0]),
+                           ('align', out[3][b, :L, :Lb], oref[3][0])):
+            mean, mx, rmax = _stats(g_, w_)
+            r[nm] = dict(mean=mean, max=mx, refmax=rmax)
+        rows['per_utterance'].append(r)
+        _report("infer_config5_B256_fp32", rows)
+        for nm in ('mel', 'mel_post', 'align'):
+            assert r[nm]['mean'] < 1e-4 and r[nm]['max'] < 5e-4 * max(1.0, r[nm]['refmax']), r
+        assert out[0][b, :, L:].abs().sum().item() == 0
+
+
+def test_config5_B256_bf16_kernels_against_the_oracle(native_lib, config5_case):
+    """The bf16 mode at B = 256 runs skinny_wide64_kernel / attn_energy4_kernel (csrc/rnn.hip, csrc/attention.hip): the
+    first END-TO-END check of those two against the oracle.  bf16 operands move the gate by ~1e-4..1e-3, so a stop is
+    only required to be exact where the oracle's own crossing margin for that utterance exceeds BF16_GATE_NOISE; the
+    others may differ by the few frames the trajectory needs to clear the threshold (reported)."""
+    BF16_GATE_NOISE = 3e-3
+    c = config5_case
+    B, steps, stop = c['B'], c['steps'], c['stop']
+    ohp, model, out = _config5_engine(c, 'bf16')
+    got = model.last_inference_lengths.cpu()
+    safe = c['per_utt_margin'] > BF16_GATE_NOISE
+    gate_e = torch.sigmoid(out[2].float().cpu().reshape(B, -1).double())
+    Tg = gate_e.shape[1]
+    both = (torch.arange(Tg).unsqueeze(0) < torch.minimum(got, stop).unsqueeze(1))
+    gate_noise = float(((gate_e - c['sig'][:, :Tg]).abs() * both).max())
+    mism = [(b, int(got[b]), int(stop[b]), float(c['per_utt_margin'][b])) for b in range(B) if int(got[b]) != int(stop[b])]
+    rows = dict(shape="B=256 ragged, max_decoder_steps=%d, bf16 mode" % steps, decode_path=model.last_decode_path,
+                threshold=c['thr'], utterances_with_safe_margin=int(safe.sum()), stops_equal=B - len(mism),
+                stop_mismatches=mism[:40], measured_sigmoid_gate_noise_max=gate_noise, BF16_GATE_NOISE=BF16_GATE_NOISE)
+    # outputs on the frames both sides produced
+    scale = max(float(c['mel'].abs().mean()), 1e-3)
+    num = den = 0.0
+    worst = (0.0, -1)
+    for b in range(B):
+        n = int(min(got[b], stop[b]))
+        d = (out[0][b, :, :n].float().cpu() - c['mel'][b, :, :n]).abs()
+        num += float(d.sum()); den += d.numel()
+        if float(d.mean()) > worst[0]:
+            worst = (float(d.mean()), b)
+    rows.update(mel_mean_abs_diff=num / den, oracle_mel_mean_abs=scale, worst_utterance_mel_mean=worst[0], worst_utterance=worst[1])
+    _report("infer_config5_B256_bf16", rows)
+    assert torch.isfinite(out[1]).all()
+    assert gate_noise < BF16_GATE_NOISE, rows
+    bad = [m for m in mism if m[3] > BF16_GATE_NOISE]
+    assert not bad, bad[:8]
+    assert int(safe.sum()) >= B // 4, "the margin rule leaves too few utterances to pin: %d" % int(safe.sum())
+    assert num / den < 2e-2 * scale, rows
+    assert worst[0] < 0.1 * scale, rows

@@ -110,6 +110,69 @@ def test_persistent_real_gate_stop(native_lib):
     assert (pout[0] - cout[0]).abs().mean().item() < 1e-4
 
 
+def test_persistent_gate_stop_small_margin(native_lib):
+    """The stop rule under a SMALL crossing margin (1e-4 on sigmoid(gate), reference model.py:443).  The persistent kernel
+    computes in the launch chain's bf16 mode, so the threshold is put on the bf16 launch chain's OWN forced trajectory:
+    1e-4 below a first-crossing value beyond 300 steps whose running maximum lies at least 1e-4 below the threshold.
+    Persistent kernel and chain must stop on that very frame.  The same is then asked against the f32 ORACLE's trajectory
+    with the margin the measured bf16-vs-f32 gate noise allows (recorded; the 1e-4-margin case against the oracle is
+    the fp32 chain's, tests/test_zz5)."""
+    hp = gu.make_hparams("max_decoder_steps=520")
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()
+    wg[:, hp.decoder_rnn_dim:] *= -1.0
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    text = gu.make_text([100], 4242)
+    keep = orc.draw_masks_infer(hp, 1, 520, torch.Generator().manual_seed(9))
+    hp.gate_threshold = 2.0
+    model = _model(hp, sd)
+    pf, _, ppath = _run(model, text, keep, True)
+    cf, _, cpath = _run(model, text, keep, False)
+    assert ppath == 'persistent' and cpath.startswith('launch chain')
+    sig_p = torch.sigmoid(pf[2].reshape(-1).double())
+    sig_c = torch.sigmoid(cf[2].reshape(-1).double())
+    (_, _, gate_o, _), _, _ = orc.tacotron2_inference(sd, hp, text, keep, 520, 2.0)
+    sig_o = torch.sigmoid(gate_o.reshape(-1).double())
+    rec = dict(persistent_vs_chain_sigmoid_gate_max=float((sig_p - sig_c).abs().max()),
+               persistent_vs_oracle_sigmoid_gate_max=float((sig_p - sig_o).abs().max()), cases=[])
+    # (a) 1e-4 margin on the chain's own trajectory
+    cand = None
+    for t in range(300, 520):
+        m = float(sig_c[:t].max())
+        if float(sig_c[t]) - m >= 2e-4:
+            cand = (float(sig_c[t]) - 1e-4, t + 1)
+            break
+    assert cand is not None, "no first crossing with a 2e-4 step beyond frame 300"
+    hp.gate_threshold = cand[0]
+    _, plen, ppath = _run(model, text, keep, True)
+    _, clen, _ = _run(model, text, keep, False)
+    rec['cases'].append(dict(kind="1e-4 below the bf16 chain's crossing value", threshold=cand[0], expected_stop=cand[1],
+                             persistent_stop=plen, chain_stop=clen, path=ppath))
+    # (b) against the oracle's trajectory: the smallest margin that is still 4x the measured bf16-vs-f32 gate noise
+    noise = rec['persistent_vs_oracle_sigmoid_gate_max']
+    want = max(1e-4, 4.0 * noise)
+    ocand = None
+    for t in range(300, 520):
+        m = float(sig_o[:t].max())
+        if float(sig_o[t]) - m >= 2.0 * want:
+            ocand = (float(sig_o[t]) - want, t + 1)
+            break
+    olen = None
+    if ocand is not None:
+        hp.gate_threshold = ocand[0]
+        _, olen, _ = _run(model, text, keep, True)
+        rec['cases'].append(dict(kind="oracle trajectory, margin = max(1e-4, 4 x measured gate noise)", margin=want,
+                                 threshold=ocand[0], expected_stop=ocand[1], persistent_stop=olen))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_persistent_gate_stop_small_margin.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    assert ppath == 'persistent'
+    assert plen == clen == cand[1], rec
+    assert rec['persistent_vs_chain_sigmoid_gate_max'] < 2e-5, rec
+    if ocand is not None:
+        assert olen == ocand[1], rec
+
+
 def test_persistent_gives_up_and_the_launch_chain_takes_over(native_lib, capsys, monkeypatch):
     """A workgroup that never arrives (shared GPU, fewer than H/4 free CUs): every spin is bounded, the kernel reports
     T2AMD_PERSIST_TIMEOUT, and Tacotron2.inference decodes the utterance on the launch chain -- same result as asking for

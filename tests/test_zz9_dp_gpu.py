@@ -108,14 +108,18 @@ def _worker(rank, world, port, precision, q):
             dist.all_gather(both, chk)
             assert torch.equal(both[0], both[1]), "single-rank gradients of shard %d differ between the ranks" % s
         worst, bad = 0.0, []
-        for k, g in grads.items():
-            want = (single[0][1][k].double() + single[1][1][k].double()) / 2
-            scale = want.abs().max().item() + 1e-30
-            err = (g.double() - want).abs().max().item()
-            own = (g.double() - single[rank][1][k].double()).abs().max().item()       # = what a missing exchange gives
-            worst = max(worst, err / scale)
-            if err > 2e-7 * scale + 1e-12:
-                bad.append((k, err / scale, own / scale))
+
+        def compare(grads, tag):
+            nonlocal worst
+            for k, g in grads.items():
+                want = (single[0][1][k].double() + single[1][1][k].double()) / 2
+                scale = want.abs().max().item() + 1e-30
+                err = (g.double() - want).abs().max().item()
+                own = (g.double() - single[rank][1][k].double()).abs().max().item()   # = what a missing exchange gives
+                worst = max(worst, err / scale)
+                if err > 2e-7 * scale + 1e-12:
+                    bad.append((tag, k, err / scale, own / scale))
+        compare(grads, 0)
         assert not bad, bad[:12]
         assert abs(float(mean_loss) - (float(single[0][0]) + float(single[1][0])) / 2) < 1e-6 * abs(float(mean_loss))
         # gradients are views of the three flat buckets (no copy back), BN statistics stay this rank's own
@@ -124,6 +128,17 @@ def _worker(rank, world, port, precision, q):
         views = pg[names[0]].grad.untyped_storage().data_ptr() == pg[names[-1]].grad.untyped_storage().data_ptr()
         for k, v in bn_after[rank].items():
             assert torch.equal(model.state_dict()[k], v), k
+        # DESIGN round 2 recorded ONE run of this test with a 1e-3 discrepancy that never reappeared.  The exchange is
+        # therefore repeated REPEATS more times in this process pair (same weights, same shard, same masks: the same
+        # expected mean every time); any repeat that differs is reported with its index and tensor.
+        first = {k: g.clone() for k, g in grads.items()}
+        unequal_repeats = 0
+        for rep in range(1, 1 + int(os.environ.get("T2AMD_DP_REPEATS", "24"))):
+            _, g2 = run(rank)
+            compare(g2, rep)
+            unequal_repeats += int(any(not torch.equal(g2[k], first[k]) for k in first))
+        assert not bad, bad[:12]
+        assert unequal_repeats == 0, "%d repeats of the same exchange were not bit-identical to the first" % unequal_repeats
         # one optimiser step on the averaged gradients keeps the ranks identical
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
