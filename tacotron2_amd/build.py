@@ -31,6 +31,36 @@ def up_to_date():
 
 
 STAMPS_OUT = os.path.join(HERE, "lib", "libtacotron2_amd_stamps.so")
+# TORCH_LIBRARY registration of the loop-level entry points over the same C ABI (csrc/torch_ops.cpp): host-only C++,
+# compiled with g++ against torch's headers, linked to the library above (found beside it through $ORIGIN)
+TORCH_OPS_SRC = os.path.join(HERE, "csrc", "torch_ops.cpp")
+TORCH_OPS_OUT = os.path.join(HERE, "lib", "libtacotron2_amd_torch.so")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_torch_ops(force=False, verbose=True):
+    deps = [TORCH_OPS_SRC, os.path.join(HERE, "..", "include", "tacotron2_amd.h"), OUT]
+    if not force and os.path.exists(TORCH_OPS_OUT) and all(os.path.getmtime(f) <= os.path.getmtime(TORCH_OPS_OUT)
+                                                            for f in deps[:2]):
+        return TORCH_OPS_OUT
+    import shutil
+    if shutil.which(CXX) is None:
+        if os.path.exists(TORCH_OPS_OUT):
+            return TORCH_OPS_OUT
+        raise RuntimeError("tacotron2_amd.build: no C++ compiler (%s) for csrc/torch_ops.cpp" % CXX)
+    import torch
+    ti = os.path.dirname(torch.__file__)
+    abi = int(bool(torch._C._GLIBCXX_USE_CXX11_ABI))
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % abi, "-I" + os.path.join(ti, "include"),
+           "-I" + os.path.join(ti, "include", "torch", "csrc", "api", "include"), "-I" + os.path.join(rocm, "include"),
+           TORCH_OPS_SRC, "-o", TORCH_OPS_OUT, "-L" + os.path.join(ti, "lib"), "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip",
+           "-L" + os.path.dirname(OUT), "-ltacotron2_amd", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(ti, "lib")]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_OPS_OUT
 
 
 def _compile_objects(obj_dir, extra, verbose):
@@ -68,6 +98,7 @@ def build(force=False, verbose=True, stamps=False):
         _link(_compile_objects(OBJ_DIR + "_stamps", ["-DT2AMD_PHASE_STAMPS"], verbose), STAMPS_OUT, verbose)
         return STAMPS_OUT
     if not force and up_to_date():
+        build_torch_ops(verbose=verbose)
         return OUT
     if not force and os.path.exists(OUT) and not os.path.exists(HIPCC):
         # a box without the toolchain: the library shipped with the snapshot is the only one there can be
@@ -78,6 +109,7 @@ def build(force=False, verbose=True, stamps=False):
         for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):
             os.remove(o)
     _link(_compile_objects(OBJ_DIR, [], verbose), OUT, verbose)
+    build_torch_ops(force=force, verbose=verbose)
     return OUT
 
 

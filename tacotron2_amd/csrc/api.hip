@@ -123,6 +123,104 @@ extern "C" int t2amd_debug_launch_chain_(float* p, int n, int blocks, void* stre
     return 0;
 }
 
+// tools/microbench_edge.py: what ONE all-to-all edge of a decoder time step costs when it is kept inside a persistent
+// launch instead of being a kernel boundary (VERDICT r02 item 3; MI355X_MICROARCH.md price list rows barrier-xcd,
+// publish-large, handoff-payload).  Geometry of the training chain: `gridDim.x` co-resident 512-thread workgroups (one per
+// CU: `lds_bytes` pins that), every workgroup PUBLISHES `pub_bytes` of a shared buffer (its slice of h / ctx / gate
+// gradients: plain 16-byte stores, every wave drains them, lane 0 release-fences), arrives at an XCD-hierarchical barrier
+// (per-XCC arrival counter -> top counter -> per-XCC generation word, the guide's barrier-xcd), acquire-fences and
+// CONSUMES `con_bytes` of the buffer (what the next phase reads: the whole 128 KB bf16 h for an LSTM tile, 4 KB for an
+// attention workgroup) with 16-byte loads, `work_ns` of sleep standing in for the phase's own work.  All spins are
+// bounded (status != 0: a workgroup gave up).  clk[0] = wall-clock ticks (100 MHz) of workgroup 0 over `rounds` edges.
+struct EdgeParams {
+    float4* buf; long long buf_f4; unsigned* xcnt; unsigned* top; unsigned* gen; unsigned* census; int rounds;
+    int pub_f4, con_f4, work_sleeps; unsigned long long* clk; int* status; float* sink;
+};
+__global__ void __launch_bounds__(512) t2_edge_kernel(EdgeParams p) {
+    extern __shared__ float t2_edge_lds[];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    // census: how many workgroups live on each XCC (placement is observed, never assumed), then one flat barrier
+    if (tid == 0) {
+        atomicAdd(&p.census[xcc], 1u);
+        __hip_atomic_fetch_add(&p.census[8], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(&p.census[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            if (++spins > (1 << 22)) { atomicExch(p.status, 1); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_flag = spins > (1 << 22);
+    }
+    __syncthreads();
+    if (s_flag) return;
+    const unsigned mine = __hip_atomic_load(&p.census[xcc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned nx = 0;
+    for (int i = 0; i < 8; ++i) nx += __hip_atomic_load(&p.census[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    float acc = 0.f;
+    const unsigned long long t0 = wall_clock64();
+    for (int r = 0; r < p.rounds; ++r) {
+        // the phase's own work
+        for (int i = 0; i < p.work_sleeps; ++i) __builtin_amdgcn_s_sleep(16);
+        // publish this workgroup's slice
+        float4* mineb = p.buf + ((long long)blockIdx.x * p.pub_f4) % p.buf_f4;
+        for (int i = tid; i < p.pub_f4; i += 512) mineb[i] = make_float4((float)r, acc, 1.f, 2.f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned target = (unsigned)(r + 1);
+            const unsigned got = __hip_atomic_fetch_add(&p.xcnt[xcc * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            if (got + 1 == mine * target) {              // last arriver of this XCC: cross-XCC stage
+                __hip_atomic_fetch_add(p.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(p.top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nx * target) {
+                    if (++spins > (1 << 22)) { atomicExch(p.status, 2); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __hip_atomic_store(&p.gen[xcc * 32], target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                while (__hip_atomic_load(&p.gen[xcc * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    if (++spins > (1 << 22)) { atomicExch(p.status, 3); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_flag = spins > (1 << 22);
+        }
+        __syncthreads();
+        if (s_flag) return;
+        // consume
+        const float4* src = p.buf + ((long long)blockIdx.x * 64) % p.buf_f4;
+        for (int i = tid; i < p.con_f4; i += 512) {
+            const float4 v = src[(i) % p.buf_f4];
+            acc += v.x + v.w;
+        }
+        if (tid < 64) t2_edge_lds[tid] = acc;
+    }
+    if (tid == 0 && blockIdx.x == 0) p.clk[0] = wall_clock64() - t0;
+    if (acc == 123.456f) p.sink[0] = acc;
+}
+// counters: 8*32+8*32+1+9 zeroed uint32 laid out as [xcnt 256][gen 256][top 1][pad 7][census 9]; buf: >= buf_bytes device
+// bytes; clk 1 uint64; status 1 zeroed int32; sink 1 float
+extern "C" int t2amd_debug_edge_(void* buf, long long buf_bytes, unsigned* counters, int rounds, int blocks, int lds_bytes,
+                                 int pub_bytes, int con_bytes, int work_sleeps, unsigned long long* clk, int* status,
+                                 float* sink, void* stream) {
+    if (!buf || !counters || !clk || !status || !sink || rounds < 1 || blocks < 1 || blocks > 512 || buf_bytes < 4096) return -1;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)t2_edge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        return -2;
+    EdgeParams p;
+    p.buf = (float4*)buf; p.buf_f4 = buf_bytes / 16; p.xcnt = counters; p.gen = counters + 256; p.top = counters + 512;
+    p.census = counters + 520; p.rounds = rounds; p.pub_f4 = pub_bytes / 16; p.con_f4 = con_bytes / 16;
+    p.work_sleeps = work_sleeps; p.clk = clk; p.status = status; p.sink = sink;
+    hipLaunchKernelGGL(t2_edge_kernel, dim3(blocks), dim3(512), lds_bytes < 256 ? 256 : lds_bytes, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // tests only (tests/test_zz9_dp_gpu.py: co-residency stress): `ncus` workgroups that each take a whole CU's LDS
 // (160 KB dynamic: nothing else that needs LDS can be placed beside them) and sleep until `*stop` becomes non-zero or
 // `ms` milliseconds of the 100 MHz wall clock have passed -- the stand-in for a co-resident RCCL kernel that takes CUs

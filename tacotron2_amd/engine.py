@@ -652,7 +652,9 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         desc.C = nv.ptr(Cst)
         desc.lens = nv.ptr(lens32, torch.int32)
         c.enc_lstm.append(dict(GX=GX, C=Cst, Whh=Whh, Wih=Wih, desc=desc))
-    nv.lstm_seq_fwd2(c.enc_lstm[0]['desc'], c.enc_lstm[1]['desc'])      # both directions, one launch per step
+    nv.lstm_seq_fwd2(c.enc_lstm[0]['desc'], c.enc_lstm[1]['desc'],      # both directions, one launch per step
+                     reads=[L_[k_] for L_ in c.enc_lstm for k_ in ('Whh', 'GX')] + [lens32],
+                     writes=[memory] + [L_['C'] for L_ in c.enc_lstm])
     c.x3, c.memory = x3, memory
 
     # ---- decoder: hoisted dense parts ------------------------------------------------------
@@ -735,7 +737,11 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         d.bf16 = 1
         for k_, v_ in c.bf16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
-    nv.decoder_train_fwd_loop(d)                                                         # model.py:405-411
+    nv.decoder_train_fwd_loop(d,                                                         # model.py:405-411
+                              reads=[Wa_rec, Wd_cat, bias_d, Wq, U, vvec, memory, pm, lens32, keep_att, keep_dec]
+                              + ([c.bf16[k_] for k_ in ('Wa_rec16', 'Wd_cat16', 'memory16', 'Wq16')] if run.bf16 else []),
+                              writes=[GA] + list(slabs.values())
+                              + ([c.bf16[k_] for k_ in ('HA16', 'HD16', 'CTX16')] if run.bf16 else []))
 
     # mel + gate projection over all steps (model.py:373-378)
     Wpg, bpg = _packed_projection(run, P, Cm, Hd, E)             # rows: Cm mel channels, then the gate
@@ -879,7 +885,12 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
             setattr(bw, k_, nv.ptr(v_, torch.bfloat16))
         if slab16:
             bw.dg16_step_a, bw.dg16_step_d = B * 4 * Ha, B * 4 * Hd
-    nv.decoder_train_bwd_loop(bw)
+    nv.decoder_train_bwd_loop(bw,
+                              reads=[Wa_recT, Wd_catT, DHC, cont(d_align), T['Wq'], T['U'], T['vvec'], T['pm'], c.memory,
+                                     T['lens32'], T['GA'], c.keep['att'], c.keep['dec']]
+                              + [S[k_] for k_ in ('HA', 'CA', 'GD', 'HD', 'CD', 'CTX', 'Q', 'ALIGN', 'CUM')]
+                              + ([b16['Wa_recT16'], b16['Wd_catT16'], c.bf16['memory16']] if run.bf16 else []),
+                              writes=list(out.values()) + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if run.bf16 else []))
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
     DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)
 
@@ -1011,7 +1022,9 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         bdesc.append(desc)
         DGs.append(DG)
         keepalive.append((WhhT, dX, dc))
-    nv.lstm_seq_bwd2(bdesc[0], bdesc[1])                                 # both directions, paired launches
+    nv.lstm_seq_bwd2(bdesc[0], bdesc[1],                                 # both directions, paired launches
+                     reads=[k_[0] for k_ in keepalive] + [L_[k_] for L_ in c.enc_lstm for k_ in ('GX', 'C')] + [c.lens32, dmem],
+                     writes=DGs + [k_[i_] for k_ in keepalive for i_ in (1, 2)])
     for d, sfx in enumerate(('', '_reverse')):
         L, DG = c.enc_lstm[d], DGs[d]
         dWih = G('encoder.lstm.weight_ih_l0' + sfx, 4 * He, E)
@@ -1144,7 +1157,9 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
         timing = torch.zeros(32, dtype=torch.int64, device=dev)
         model.last_persist_timing = timing
         d.timing = nv.ptr(timing, torch.int64)
-    nv.decoder_infer_persistent(d)
+    nv.decoder_infer_persistent(d, reads=[i16['Wa_cat16'], i16['Wd_cat16'], bias_a, bias_d, Wq, U, vvec, Wf, bf, W2, memory, pm, keep],
+                                writes=[st['PG'], st['ALIGN'], out_lengths, status, steps_done, mailbox]
+                                + ([trace] if trace is not None else []) + ([timing] if timing is not None else []))
     code = int(status.item())
     if code != 0:
         print("tacotron2_amd: the persistent decode kernel gave up (status %d: %d workgroups were not co-resident "
@@ -1234,7 +1249,9 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         desc.C = nv.ptr(Cst)
         desc.lens = nv.ptr(lens32, torch.int32)
         idesc.append((desc, GX, Cst))
-    nv.lstm_seq_fwd2(idesc[0][0], idesc[1][0])
+    nv.lstm_seq_fwd2(idesc[0][0], idesc[1][0],
+                     reads=[P['encoder.lstm.weight_hh_l0'], P['encoder.lstm.weight_hh_l0_reverse'], idesc[0][1], idesc[1][1], lens32],
+                     writes=[memory, idesc[0][2], idesc[1][2]])
 
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
     pm = run.empty(B, Ti, A)
@@ -1322,6 +1339,8 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         d.bf16 = 1
         for k_, v_ in i16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
+    infer_reads = [P['decoder.prenet.layers.0.linear_layer.weight'], P['decoder.prenet.layers.1.linear_layer.weight'],
+                   Wa_cat, bias_a, Wd_cat, bias_d, Wq, U, vvec, Wpg, bpg] + ([Wf_, bf_] if B > 8 else [])
     # One utterance in the bf16 mode: the whole loop as ONE persistent launch, LSTM weights resident in LDS
     # (csrc/decode_persist.hip).  Anything it cannot take -- or a timeout because the GPU is shared and H/4 workgroups
     # are not co-resident -- goes through the launch chain below.
@@ -1356,7 +1375,8 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     while t < max_steps and not ran_persistent:
         n = min(poll_steps, max_steps - t)
         d.t0, d.n_steps = t, n
-        nv.decoder_infer_steps(d)
+        nv.decoder_infer_steps(d, reads=infer_reads + [memory, pm, lens32, keep] + (list(i16.values()) if run.bf16 else []),
+                               writes=list(st.values()) + [out_lengths, active, done])
         t += n
         ndone = int(done.item())                # one device->host sync per poll_steps steps
         if ndone >= Bc:

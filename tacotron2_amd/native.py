@@ -17,6 +17,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("T2AMD_LIB", os.path.join(_HERE, "lib", "libtacotron2_amd.so"))
 
+TORCH_OPS_PATH = os.path.join(_HERE, "lib", "libtacotron2_amd_torch.so")
+
 ATT_DIM = 128
 LOC_FILTERS = 32
 LOC_KERNEL = 31
@@ -424,9 +426,9 @@ def decoder_persist_supported(desc):
     return msg.decode() if msg else "unsupported"
 
 
-def decoder_infer_persistent(desc):
+def decoder_infer_persistent(desc, reads=None, writes=None):
     """The whole free-running decode loop of ONE utterance as one persistent launch (csrc/decode_persist.hip)."""
-    _check(load().t2amd_decoder_infer_persistent_f32(C.byref(desc), _stream()), "t2amd_decoder_infer_persistent_f32")
+    _loop("decoder_infer_persistent", "t2amd_decoder_infer_persistent_f32", [desc], reads, writes)
 
 
 def tacotron2_loss_fwd(mel, post, tgt, gate, gate_tgt, ws, out4):
@@ -1085,14 +1087,66 @@ def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory
 # ----------------------------------------------------------------------------
 # loops
 # ----------------------------------------------------------------------------
-def decoder_train_fwd_loop(desc):
-    lib = load()
-    _check(lib.t2amd_decoder_train_fwd_loop_f32(C.byref(desc), _stream()), "t2amd_decoder_train_fwd_loop_f32")
+# The loop-level entry points are also registered with the PyTorch dispatcher (csrc/torch_ops.cpp, TORCH_LIBRARY over
+# the same C ABI: torch.ops.tacotron2_amd.*).  When that library is present the engine's loops go through it -- the
+# descriptor travels as a CPU uint8 tensor, the tensors it points into as the op's `reads` / `writes` lists -- otherwise
+# (and for the instrumented T2AMD_LIB builds, the validate-only CPU runs, and T2AMD_TORCH_OPS=0) through ctypes.
+_torch_ops = None
 
 
-def decoder_train_bwd_loop(desc):
-    lib = load()
-    _check(lib.t2amd_decoder_train_bwd_loop_f32(C.byref(desc), _stream()), "t2amd_decoder_train_bwd_loop_f32")
+def torch_ops():
+    """torch.ops.tacotron2_amd, or None when the registration library is absent / disabled."""
+    global _torch_ops
+    if _torch_ops is None:
+        ok = (os.environ.get("T2AMD_TORCH_OPS", "1") != "0" and "T2AMD_LIB" not in os.environ
+              and os.path.exists(TORCH_OPS_PATH))
+        if ok:
+            load()                                    # the C ABI library first: the ops library resolves against it
+            torch.ops.load_library(TORCH_OPS_PATH)
+            _torch_ops = torch.ops.tacotron2_amd
+        else:
+            _torch_ops = False
+    return _torch_ops or None
+
+
+def _desc_tensor(desc):
+    return torch.frombuffer(desc, dtype=torch.uint8)          # zero-copy view of the ctypes struct
+
+
+def _dev_tensors(ts):
+    return [t for t in ts if t is not None and torch.is_tensor(t) and t.is_cuda]
+
+
+def _via_ops(name, descs, reads, writes):
+    """Run loop `name` through the dispatcher when possible; False -> the caller takes the ctypes route."""
+    ops = None if _validate_only else torch_ops()
+    if ops is None or reads is None or writes is None:
+        return False
+    w = _dev_tensors(writes)
+    if not w:
+        return False
+    getattr(ops, name)(*[_desc_tensor(d) for d in descs], _dev_tensors(reads), w)
+    return True
+
+
+last_loop_route = None          # 'torch.ops' / 'ctypes': which way the most recent loop-level call went (tests)
+
+
+def _loop(name, cname, descs, reads, writes):
+    global last_loop_route
+    if _via_ops(name, descs, reads, writes):
+        last_loop_route = 'torch.ops'
+        return
+    last_loop_route = 'ctypes'
+    _check(getattr(load(), cname)(*[C.byref(d) for d in descs], _stream()), cname)
+
+
+def decoder_train_fwd_loop(desc, reads=None, writes=None):
+    _loop("decoder_train_fwd", "t2amd_decoder_train_fwd_loop_f32", [desc], reads, writes)
+
+
+def decoder_train_bwd_loop(desc, reads=None, writes=None):
+    _loop("decoder_train_bwd", "t2amd_decoder_train_bwd_loop_f32", [desc], reads, writes)
 
 
 def lstm_seq_fwd(desc):
@@ -1100,14 +1154,12 @@ def lstm_seq_fwd(desc):
     _check(lib.t2amd_lstm_seq_fwd_f32(C.byref(desc), _stream()), "t2amd_lstm_seq_fwd_f32")
 
 
-def lstm_seq_fwd2(d0, d1):
-    lib = load()
-    _check(lib.t2amd_lstm_seq_fwd2_f32(C.byref(d0), C.byref(d1), _stream()), "t2amd_lstm_seq_fwd2_f32")
+def lstm_seq_fwd2(d0, d1, reads=None, writes=None):
+    _loop("encoder_lstm_fwd", "t2amd_lstm_seq_fwd2_f32", [d0, d1], reads, writes)
 
 
-def lstm_seq_bwd2(d0, d1):
-    lib = load()
-    _check(lib.t2amd_lstm_seq_bwd2_f32(C.byref(d0), C.byref(d1), _stream()), "t2amd_lstm_seq_bwd2_f32")
+def lstm_seq_bwd2(d0, d1, reads=None, writes=None):
+    _loop("encoder_lstm_bwd", "t2amd_lstm_seq_bwd2_f32", [d0, d1], reads, writes)
 
 
 def lstm_seq_bwd(desc):
@@ -1115,9 +1167,8 @@ def lstm_seq_bwd(desc):
     _check(lib.t2amd_lstm_seq_bwd_f32(C.byref(desc), _stream()), "t2amd_lstm_seq_bwd_f32")
 
 
-def decoder_infer_steps(desc):
-    lib = load()
-    _check(lib.t2amd_decoder_infer_steps_f32(C.byref(desc), _stream()), "t2amd_decoder_infer_steps_f32")
+def decoder_infer_steps(desc, reads=None, writes=None):
+    _loop("decoder_infer_steps", "t2amd_decoder_infer_steps_f32", [desc], reads, writes)
 
 
 # ----------------------------------------------------------------------------

@@ -210,3 +210,52 @@ def test_weight_image_cache_sees_param_data_edits(native_lib, capfd):
     g2 = grads(fresh)
     for k in g1:
         assert torch.equal(g1[k], g2[k]), k
+
+
+def test_loops_run_through_the_torch_dispatcher(native_lib):
+    """The engine's loop-level calls go through torch.ops.tacotron2_amd.* (TORCH_LIBRARY, csrc/torch_ops.cpp) and give
+    the same bits as the ctypes route over the same C ABI: one training step and one batched inference."""
+    from tacotron2_amd import native
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    from tacotron2_amd.model import Tacotron2
+    assert native.torch_ops() is not None
+    hp = create_hparams("max_decoder_steps=20")
+    hp.gate_threshold = 2.0
+    torch.manual_seed(4)
+    model = Tacotron2(hp).cuda().train()
+    batch = gu.make_train_batch([14, 9, 6], [25, 19, 12], hp.n_mel_channels, 6)
+    text = gu.make_text([12, 7], 3).cuda()
+    lens = torch.tensor([12, 7]).cuda()
+
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    def run():
+        res = {}
+        model.load_state_dict(sd0)               # a training step moves the BatchNorm running statistics inference reads
+        for prec in ('fp32', 'bf16'):
+            model.train()
+            model.precision = prec
+            torch.manual_seed(9)
+            model.zero_grad()
+            x, y = model.parse_batch(tuple(t.clone() for t in batch))
+            loss = Tacotron2Loss()(model(x), y)
+            loss.backward()
+            route_train = native.last_loop_route
+            res[prec] = [loss.detach().clone()] + [p.grad.clone() for p in model.parameters()]
+            model.eval()
+            torch.manual_seed(10)
+            res[prec] += [o.clone() for o in model.inference(text, lens)]
+            res[prec + '_routes'] = (route_train, native.last_loop_route)
+        return res
+    keep = native._torch_ops
+    a = run()
+    assert a['fp32_routes'] == ('torch.ops', 'torch.ops') and a['bf16_routes'] == ('torch.ops', 'torch.ops'), a['fp32_routes']
+    try:
+        native._torch_ops = False
+        b = run()
+    finally:
+        native._torch_ops = keep
+    assert b['fp32_routes'] == ('ctypes', 'ctypes')
+    for prec in ('fp32', 'bf16'):
+        for u, v in zip(a[prec], b[prec]):
+            assert torch.equal(u, v), prec

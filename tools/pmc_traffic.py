@@ -2,9 +2,9 @@
 `bench.py --steps 1 --warmup 0` into profiles/pmc_traffic.json (what bench.py reports as roofline.traffic for each of
 the four kernels of a decoder time step) and a per-kernel CSV.
 
-    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out_csv> [precision] [calib_fetch_dir]
+    python tools/pmc_traffic.py <fetch_dir> <write_dir> <out_csv> [precision] [calib_fetch_dir] [calib_write_dir]
 
-FETCH_SIZE / WRITE_SIZE are in KB.  On gfx950 FETCH_SIZE counts a wide (16 B/lane) coalesced streaming read at HALF its
+FETCH_SIZE / WRITE_SIZE are in KiB (1024 bytes: the calibration below reads 2.048 with 1000-byte units, 2.000 with 1024).  On gfx950 FETCH_SIZE counts a wide (16 B/lane) coalesced streaming read at HALF its
 bytes (MI355X_MICROARCH.md, HBM) and is uncalibrated for other access shapes: `calib_fetch_dir` holds a FETCH_SIZE pass of
 tools/probe/fetch_calib (1 GiB read once per access shape), from which the bytes-per-counted-byte factor of every shape
 is taken; without it the guide's x2 is applied to the LDS-DMA weight streams and the attention kernels are reported with
@@ -48,22 +48,27 @@ def per_kernel(d, counter):
     return {k: (v[0], max(len(v[1]), 1)) for k, v in acc.items()}
 
 
-def calibration(calib_dir):
-    """shape -> true bytes per byte FETCH_SIZE counted (1.0 = the counter is exact for that shape)."""
+def calibration(calib_dir, write_dir=None):
+    """shape -> true bytes per byte FETCH_SIZE counted (1.0 = the counter is exact for that shape); "write" -> the same
+    for WRITE_SIZE on a 16 B/lane coalesced store stream."""
     out = {}
+    if write_dir:
+        for k, (kb, n) in per_kernel(write_dir, "WRITE_SIZE").items():
+            if "calib_w16" in k and kb > 0:
+                out["write"] = CALIB_BYTES / (kb / n * 1024.0)
     if not calib_dir:
         return out
     for k, (kb, n) in per_kernel(calib_dir, "FETCH_SIZE").items():
         for shape in ("calib_b4", "calib_b8", "calib_b16", "calib_seg128", "calib_seg256", "calib_lds16"):
             if shape + "(" in k or k.startswith(shape) or (" " + shape) in k:
-                out[shape] = CALIB_BYTES / (kb / n * 1e3)
+                out[shape] = CALIB_BYTES / (kb / n * 1024.0)
     return out
 
 
 def main():
     fetch_dir, write_dir, out_csv = sys.argv[1:4]
     prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
-    cal = calibration(sys.argv[5] if len(sys.argv) > 5 else None)
+    cal = calibration(sys.argv[5] if len(sys.argv) > 5 else None, sys.argv[6] if len(sys.argv) > 6 else None)
     fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     rows = []
     for k in sorted(fe, key=lambda k: -fe[k][0]):
@@ -82,6 +87,7 @@ def main():
     rec_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     rec = json.load(open(rec_path)) if os.path.exists(rec_path) else {}
     kernels = {}
+    wfac = cal.get("write", 1.0)                       # true bytes per counted WRITE_SIZE byte (calib_w16), 1.0 if not run
     for key, (sub, shapes) in CHAIN[prec].items():
         for k, n, f_kb, w_kb in rows:
             if sub not in k:
@@ -98,8 +104,8 @@ def main():
                 e["fetch_factor_source"] = "MI355X_MICROARCH.md: x2 for 16 B/lane streaming reads (not re-calibrated)"
             else:
                 factor = None
-                e["hbm_bytes_bounds"] = [f_kb * 1e3 + w_kb * 1e3, 2 * f_kb * 1e3 + w_kb * 1e3]
-            e["hbm_bytes"] = (factor * f_kb * 1e3 + w_kb * 1e3) if factor else None
+                e["hbm_bytes_bounds"] = [(f_kb + w_kb) * 1024.0, (2 * f_kb + w_kb) * 1024.0]
+            e["hbm_bytes"] = ((factor * f_kb + w_kb * wfac) * 1024.0) if factor else None
             kernels[key] = e
             break
     rec["kernels_" + prec] = kernels

@@ -61,6 +61,11 @@ __global__ void calib_lds16(const float4* p, size_t n, float* sink) {
     if (buf[wave][lane].x == 123.456f) sink[0] = 1.f;
 }
 
+// WRITE_SIZE calibration: 1 GiB written once, 16 bytes per lane coalesced
+__global__ void calib_w16(float4* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
 int main() {
     const size_t bytes = 1ull << 30;
     void* buf; float* sink;
@@ -74,8 +79,9 @@ int main() {
         hipLaunchKernelGGL(calib_seg128, dim3(4096), dim3(256), 0, 0, (const float*)buf, bytes / 512, sink);
         hipLaunchKernelGGL(calib_seg256, dim3(4096), dim3(256), 0, 0, (const float4*)buf, bytes / 1024, sink);
         hipLaunchKernelGGL(calib_lds16, dim3(4096), dim3(256), 0, 0, (const float4*)buf, bytes / 16, sink);
+        hipLaunchKernelGGL(calib_w16, dim3(4096), dim3(256), 0, 0, (float4*)buf, bytes / 16);
         CK(hipDeviceSynchronize());
     }
-    printf("fetch_calib: 6 kernels x 2 launches, %zu bytes read per launch\n", bytes);
+    printf("fetch_calib: 7 kernels x 2 launches, %zu bytes read per launch\n", bytes);
     return 0;
 }
