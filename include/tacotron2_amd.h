@@ -693,7 +693,7 @@ int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* stream);
 /* Persistent, weight-stationary decode loop for ONE utterance (reference model.py:435-449 Decoder.inference's loop
  * around Decoder.decode :340-379; Prenet :97-100; Attention :43-86; LocationLayer :22-26): ONE launch of H/4
  * co-resident workgroups runs every step until the gate fires or max_steps is reached.  Each workgroup keeps its 16 rows
- * of both LSTM matrices (bf16) in LDS for the whole utterance; the six per-step vectors (p2, h_att, partial energies,
+ * of both LSTM matrices (bf16 in LDS, or f32 split between LDS and registers: weights_f32) for the whole utterance; the six per-step vectors (p2, h_att, partial energies,
  * context, h_dec, p1 + stop flag) travel between workgroups as 8-byte {step + 1, f32} granules (agent-scope relaxed
  * stores / polled loads, no fences).  Prenet layer 0 is folded through the frame projection (Wf below).  Requires
  * attention_rnn_dim == decoder_rnn_dim = H, H/4 <= number of CUs, Ti <= 256 (t2amd_decoder_persist_supported).  Spins
@@ -726,6 +726,11 @@ typedef struct t2amd_dec_persist {
     float* trace;          /* NULL, or [max_steps][H + E + H + P + P]: h_att, ctx, h_dec, p1(t+1), p2(t+1) per step (tests) */
     unsigned long long* timing; /* NULL, or [32] zeroed by the caller: 100 MHz ticks per phase, summed over the steps, of
                                  * thread 0 of the first ([0..15]) and of the last ([16..31]) workgroup (tools) */
+    int weights_f32;       /* 0: Wa16 / Wd16 are bf16 (throughput mode).  1: they point at the SAME matrices in f32 (the fp32
+                            * parity mode: exact f32 products, the arithmetic of the fp32 launch chain): a workgroup then
+                            * keeps its 16 attention-LSTM rows in LDS (16 x 1792 x 4 = 112 KB) and its 16 decoder-LSTM rows in
+                            * REGISTERS (160 per lane: the CU's 512 KB register file holds what its 160 KB of LDS cannot);
+                            * needs H and E multiples of 256 */
 } t2amd_dec_persist;
 
 long long t2amd_decoder_persist_mailbox_bytes(int Ti, int E, int H, int P);

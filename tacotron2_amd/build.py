@@ -113,8 +113,20 @@ def build(force=False, verbose=True, stamps=False):
     return OUT
 
 
+def build_variant(tag, defines, verbose=True):
+    """An A/B build next to the product library: every ``-D<define>`` applied to all translation units, output
+    ``lib/libtacotron2_amd_<tag>.so`` (select it with T2AMD_LIB=<path>; tools only)."""
+    out = os.path.join(HERE, "lib", "libtacotron2_amd_%s.so" % tag)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    _link(_compile_objects(OBJ_DIR + "_" + tag, ["-D" + d for d in defines], verbose), out, verbose)
+    return out
+
+
 if __name__ == "__main__":
-    if "--stamps" in sys.argv:
+    if "--variant" in sys.argv:                       # python -m tacotron2_amd.build --variant epifirst T2AMD_SW_EPI_FIRST
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    elif "--stamps" in sys.argv:
         print(build(stamps=True))
     else:
         build(force="--force" in sys.argv)

@@ -149,6 +149,71 @@ __device__ __forceinline__ void pb_dot_seg(const unsigned short* __restrict__ Wr
     }
 }
 
+// ---- exact-f32 weights (t2amd_dec_persist.weights_f32) --------------------------------------------------------------
+// A row's LDS / register image is laid out segment by segment in the SAME split order as the staged input vectors
+// (pb_xoff), so a dot product is an element-wise walk over two identically permuted arrays: lane l takes the float4s
+// l, l + 64, ... of the segment -- lane-consecutive 16-byte LDS reads on both sides.
+// position `pos` of a split segment of length `len` -> the k it holds (pos is a multiple of 4: four consecutive k)
+__device__ __forceinline__ int pb_xinv4(int pos, int len) {
+    const int half = len >> 1;
+    return pos < half ? (pos >> 2) * 8 : ((pos - half) >> 2) * 8 + 4;
+}
+// acc[u] += image row u [seg_off .. seg_off + seg_len) . xs: f32 rows in LDS
+__device__ __forceinline__ void pb_dot_seg_f32(const float* __restrict__ Wrows, int K, int seg_off, int seg_len,
+                                               const float* __restrict__ xs, float (&acc)[4], int lane) {
+    const int n4 = seg_len >> 2;
+    for (int i4 = lane; i4 < n4; i4 += 64) {
+        const float4 x = *reinterpret_cast<const float4*>(xs + i4 * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 w = *reinterpret_cast<const float4*>(Wrows + (size_t)u * K + seg_off + i4 * 4);
+            float s = acc[u];
+            s = fmaf(w.x, x.x, s); s = fmaf(w.y, x.y, s); s = fmaf(w.z, x.z, s); s = fmaf(w.w, x.w, s);
+            acc[u] = s;
+        }
+    }
+}
+#define PB_RJ 4                          // float4s per lane, row and 1024-wide segment held in registers (H, E <= 1024)
+// the same against register-resident rows: wr[u][j] = float4 (lane + 64 j) of row u's segment
+__device__ __forceinline__ void pb_dot_reg(const float4 (&wr)[4][PB_RJ], int nj, const float* __restrict__ xs,
+                                           float (&acc)[4], int lane) {
+#pragma unroll
+    for (int j = 0; j < PB_RJ; ++j) {
+        if (j < nj) {
+            const float4 x = *reinterpret_cast<const float4*>(xs + (lane + 64 * j) * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s = acc[u];
+                s = fmaf(wr[u][j].x, x.x, s); s = fmaf(wr[u][j].y, x.y, s); s = fmaf(wr[u][j].z, x.z, s); s = fmaf(wr[u][j].w, x.w, s);
+                acc[u] = s;
+            }
+        }
+    }
+}
+
+// the ctx segment: units 0..2 from LDS rows [3][E] (split image), unit 3 from registers
+__device__ __forceinline__ void pb_dot_ctx(const float4 (&wr)[1][PB_RJ], const float* __restrict__ Wl, int E, int nj,
+                                           const float* __restrict__ xs, float (&acc)[4], int lane) {
+#pragma unroll
+    for (int j = 0; j < PB_RJ; ++j) {
+        if (j < nj) {
+            const int o = (lane + 64 * j) * 4;
+            const float4 x = *reinterpret_cast<const float4*>(xs + o);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const float4 w = *reinterpret_cast<const float4*>(Wl + (size_t)u * E + o);
+                float s = acc[u];
+                s = fmaf(w.x, x.x, s); s = fmaf(w.y, x.y, s); s = fmaf(w.z, x.z, s); s = fmaf(w.w, x.w, s);
+                acc[u] = s;
+            }
+            float s = acc[3];
+            s = fmaf(wr[0][j].x, x.x, s); s = fmaf(wr[0][j].y, x.y, s); s = fmaf(wr[0][j].z, x.z, s); s = fmaf(wr[0][j].w, x.w, s);
+            acc[3] = s;
+        }
+    }
+}
+
+template <bool F32W>
 __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const t2amd_dec_persist& a = p.a;
@@ -167,9 +232,11 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     }
 
     // ---- LDS carve (all offsets multiples of 16 bytes) -------------------------------------------------------
-    unsigned short* Wa_s = reinterpret_cast<unsigned short*>(smem_raw);            // [16][Ka] bf16
+    unsigned short* Wa_s = reinterpret_cast<unsigned short*>(smem_raw);            // [16][Ka] bf16 (F32W: [16][Ka] f32, Wd in registers)
     unsigned short* Wd_s = Wa_s + (size_t)16 * Ka;                                 // [16][Kd] bf16
-    float* xp2_s = reinterpret_cast<float*>(Wd_s + (size_t)16 * Kd);               // [P]   split layout
+    float* const Waf_s = reinterpret_cast<float*>(smem_raw);
+    float* const Wdc_s = Waf_s + (size_t)16 * Ka;                                  // F32W: [4 gates][3 units][E] ctx segment of the decoder rows
+    float* xp2_s = F32W ? Wdc_s + (size_t)12 * E : reinterpret_cast<float*>(Wd_s + (size_t)16 * Kd);   // [P]   split layout
     float* xctx_s = xp2_s + P;                                                     // [E]   split layout
     float* xha_s = xctx_s + E;                                                     // [H]   split layout
     float* xhd_s = xha_s + H;                                                      // [H]   split layout
@@ -190,7 +257,41 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     pb_u64* const G_p1 = G_hd + H;                  // [P] + stop granule at [P]
 
     // ---- one-time: this workgroup's LSTM rows -> LDS (row g*4+u of the image = row g*H + 4k + u of the matrix) ----
-    {
+    // F32W: the decoder-LSTM rows of this wave (gate `wave`, units 0..3) live in registers: segment s of row u as float4s
+    // lane + 64 j of its split image
+    // (the ctx segment of units 0..2 goes to LDS behind the attention rows -- 3/4 of 16 x E x 4 bytes = 24 KB is what the
+    // LDS still has -- so that the register file is not overcommitted: wd1 holds unit 3 only)
+    float4 wd0[4][PB_RJ], wd1[1][PB_RJ], wd2[4][PB_RJ];        // segments h_a [H], ctx [E] (unit 3), h_d [H]
+    const int njH = H >> 8, njE = E >> 8;                        // float4s per lane (H, E multiples of 256)
+    if constexpr (F32W) {
+        const float* __restrict__ Wa = reinterpret_cast<const float*>(a.Wa16);
+        const float* __restrict__ Wd = reinterpret_cast<const float*>(a.Wd16);
+        // attention-LSTM rows -> LDS image: row r = gate*4 + unit, segments [P | E | H] each in split order
+        const int q4 = Ka >> 2;
+        for (int i = tid; i < 16 * q4; i += PB_NT) {
+            const int r = i / q4, pos = (i - r * q4) * 4;
+            const long long grow = (long long)(r >> 2) * H + 4 * k + (r & 3);
+            int so, sl;
+            if (pos < P) { so = 0; sl = P; } else if (pos < P + E) { so = P; sl = E; } else { so = P + E; sl = H; }
+            const int kk = so + pb_xinv4(pos - so, sl);
+            *reinterpret_cast<float4*>(Waf_s + (size_t)r * Ka + pos) = *reinterpret_cast<const float4*>(Wa + grow * Ka + kk);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* row = Wd + ((long long)wave * H + 4 * k + u) * Kd;
+#pragma unroll
+            for (int j = 0; j < PB_RJ; ++j) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                wd0[u][j] = j < njH ? *reinterpret_cast<const float4*>(row + pb_xinv4((lane + 64 * j) * 4, H)) : z;
+                if (u == 3) wd1[0][j] = j < njE ? *reinterpret_cast<const float4*>(row + H + pb_xinv4((lane + 64 * j) * 4, E)) : z;
+                else if (j < njE) *reinterpret_cast<float4*>(Wdc_s + ((size_t)(wave * 3 + u) * E) + (lane + 64 * j) * 4) =
+                    *reinterpret_cast<const float4*>(row + H + pb_xinv4((lane + 64 * j) * 4, E));
+                wd2[u][j] = j < njH ? *reinterpret_cast<const float4*>(row + H + E + pb_xinv4((lane + 64 * j) * 4, H)) : z;
+            }
+        }
+        for (int i = tid; i < P; i += PB_NT) xp2_s[i] = 0.f;
+        for (int i = tid; i < 2 * TIP; i += PB_NT) win_s[i] = 0.f;
+    } else {
         const int ua = Ka >> 3, ud = Kd >> 3;       // 16-byte units per row
         const uint4* __restrict__ Wa = reinterpret_cast<const uint4*>(a.Wa16);
         const uint4* __restrict__ Wd = reinterpret_cast<const uint4*>(a.Wd16);
@@ -210,10 +311,13 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
 
     // ---- one-time: register-resident slices ------------------------------------------------------------------
     // folded projection rows r = k + j*NWG < NF: thread holds elements e = tid + 256*i of each
-    float wf[PB_MAXFR][PB_MAXKPT];
-    float bf_[PB_MAXFR];
+    // (F32W: the register file also holds the decoder-LSTM rows, so the per-workgroup row budgets are those of H >= 704:
+    // at most 2 projection rows, 1 prenet row, 2 context channels -- checked by t2amd_decoder_persist_supported)
+    constexpr int MAXFR = F32W ? 2 : PB_MAXFR, MAXP2R = F32W ? 1 : PB_MAXP2R, MAXEPW = F32W ? 2 : PB_MAXEPW;
+    float wf[MAXFR][PB_MAXKPT];
+    float bf_[MAXFR];
 #pragma unroll
-    for (int j = 0; j < PB_MAXFR; ++j) {
+    for (int j = 0; j < MAXFR; ++j) {
         const int r = k + j * NWG;
         bf_[j] = (r < NF) ? a.bias_f[r] : 0.f;
 #pragma unroll
@@ -223,16 +327,16 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         }
     }
     // prenet layer-2 rows r = k + j*NWG < P: element tid (P <= 256)
-    float w2[PB_MAXP2R];
+    float w2[MAXP2R];
 #pragma unroll
-    for (int j = 0; j < PB_MAXP2R; ++j) {
+    for (int j = 0; j < MAXP2R; ++j) {
         const int r = k + j * NWG;
         w2[j] = (r < P && tid < P) ? a.W2[(long long)r * P + tid] : 0.f;
     }
     // context: thread i < Ti keeps memory[i][EPW channels of this workgroup]
-    float memr[PB_MAXEPW];
+    float memr[MAXEPW];
 #pragma unroll
-    for (int c = 0; c < PB_MAXEPW; ++c) memr[c] = (tid < Ti && c < EPW) ? a.memory[(long long)tid * E + k * EPW + c] : 0.f;
+    for (int c = 0; c < MAXEPW; ++c) memr[c] = (tid < Ti && c < EPW) ? a.memory[(long long)tid * E + k * EPW + c] : 0.f;
     // attention slice of this workgroup: dims team*16 .. +15, positions pgx + NPG*pl (pl < 8).  Thread (td = tid & 15,
     // slot = tid >> 4) keeps H/16 elements of W_q row team*16 + td (part `slot` of the row) for the q phase, and for the
     // energy phase -- where slot = 2*pl + c -- the 31 taps of window channel c of U row td, v[td] and pm[position][td]
@@ -262,6 +366,21 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
     float accA[4] = {0.f, 0.f, 0.f, 0.f}, accD[4] = {0.f, 0.f, 0.f, 0.f};
     const unsigned short* WaW = Wa_s + (size_t)wave * 4 * Ka;      // this wave's gate: rows wave*4 .. wave*4+3
     const unsigned short* WdW = Wd_s + (size_t)wave * 4 * Kd;
+    const float* WaF = Waf_s + (size_t)wave * 4 * Ka;
+    // the two dot products, by operand form
+#define PB_DOT_A(SEG_OFF, SEG_LEN, XS)                                                        \
+    do {                                                                                      \
+        if constexpr (F32W) pb_dot_seg_f32(WaF, Ka, SEG_OFF, SEG_LEN, XS, accA, lane);        \
+        else pb_dot_seg(WaW, Ka, SEG_OFF, SEG_LEN, XS, accA, lane);                           \
+    } while (0)
+#define PB_DOT_D(SEGI, SEG_OFF, SEG_LEN, XS)                                                  \
+    do {                                                                                      \
+        if constexpr (F32W) {                                                                 \
+            if (SEGI == 0) pb_dot_reg(wd0, njH, XS, accD, lane);                              \
+            else if (SEGI == 1) pb_dot_ctx(wd1, Wdc_s + (size_t)wave * 3 * E, E, njE, XS, accD, lane); \
+            else pb_dot_reg(wd2, njH, XS, accD, lane);                                        \
+        } else pb_dot_seg(WdW, Kd, SEG_OFF, SEG_LEN, XS, accD, lane);                         \
+    } while (0)
     const float thr = a.gate_threshold;
     float* const trace = a.trace;
     const int TRW = H + E + H + P + P;
@@ -295,7 +414,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         PB_T(0);
 
         // (2) attention LSTM: accA already holds the ctx(t-1) and h_a(t-1) parts
-        pb_dot_seg(WaW, Ka, 0, P, xp2_s, accA, lane);
+        PB_DOT_A(0, P, xp2_s);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float s = row16_sum(accA[u]);                       // 16-lane partials; the cell thread adds the four
@@ -326,8 +445,8 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         // keep-masks of the prenet outputs this workgroup will publish for step t + 1: fetched here (first use ~8 us away;
         // issued in front of a sweep they would hold that wave's polls back: returns are in order)
         if (t + 1 < a.max_steps) {
-            if (ct >= 0 && ct < PB_MAXFR && k + ct * NWG < P) keep1 = a.keep_prenet[((long long)(t + 1) * 2 + 0) * P + k + ct * NWG];
-            if (ct >= 0 && ct < PB_MAXP2R && k + ct * NWG < P) keep2 = a.keep_prenet[((long long)(t + 1) * 2 + 1) * P + k + ct * NWG];
+            if (ct >= 0 && ct < MAXFR && k + ct * NWG < P) keep1 = a.keep_prenet[((long long)(t + 1) * 2 + 0) * P + k + ct * NWG];
+            if (ct >= 0 && ct < MAXP2R && k + ct * NWG < P) keep2 = a.keep_prenet[((long long)(t + 1) * 2 + 1) * P + k + ct * NWG];
         }
 
         // (4) q for this workgroup's 16 attention dims, then the partial energy over those dims of its (up to) 8 positions
@@ -375,8 +494,8 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
 
         // (5) the h_a(t) parts of the decoder LSTM of this step and of the attention LSTM of the next one (the partial
         // energies are on their way meanwhile)
-        pb_dot_seg(WdW, Kd, 0, H, xha_s, accD, lane);
-        pb_dot_seg(WaW, Ka, P + E, H, xha_s, accA, lane);
+        PB_DOT_D(0, 0, H, xha_s);
+        PB_DOT_A(P + E, H, xha_s);
         PB_T(3);
 
         // (6) energies = fixed-order sum of the 8 team partials; softmax; this workgroup's context channels
@@ -424,7 +543,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
             if ((lane & 15) == 0) red_s[16 + (tid >> 4)] = ls;
             // context partials: 16-lane sums of ex[i] * memory[i][c] (normalised below)
 #pragma unroll
-            for (int c = 0; c < PB_MAXEPW; ++c) {
+            for (int c = 0; c < MAXEPW; ++c) {
                 if (c < EPW) {
                     const float s = row16_sum(ex * memr[c]);
                     if ((lane & 15) == 0) red_s[32 + c * 16 + (tid >> 4)] = s;
@@ -464,7 +583,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         PB_T(7);
 
         // (8) decoder LSTM: accD holds the h_a(t) and h_d(t-1) parts
-        pb_dot_seg(WdW, Kd, H, E, xctx_s, accD, lane);
+        PB_DOT_D(1, H, E, xctx_s);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float s = row16_sum(accD[u]);
@@ -486,7 +605,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
             if (trace) trace[(long long)t * TRW + H + E + 4 * k + ct] = h;
         }
         PB_T(8);
-        pb_dot_seg(WaW, Ka, P, E, xctx_s, accA, lane);                // ctx(t) part of the next attention LSTM
+        PB_DOT_A(P, E, xctx_s);                                       // ctx(t) part of the next attention LSTM
         PB_T(9);
 
         // (9) h_d(t)
@@ -504,7 +623,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
                 xr[i] = e < H ? xhd_s[pb_xoff(e, H)] : (e < KF ? xctx_s[pb_xoff(e - H, E)] : 0.f);
             }
 #pragma unroll
-            for (int j = 0; j < PB_MAXFR; ++j) {
+            for (int j = 0; j < MAXFR; ++j) {
                 if (k + j * NWG < NF) {                               // workgroup-uniform: rows this workgroup owns
                     float s = 0.f;
 #pragma unroll
@@ -514,7 +633,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
                 }
             }
             __syncthreads();
-            if (ct >= 0 && ct < PB_MAXFR) {
+            if (ct >= 0 && ct < MAXFR) {
                 const int r = k + ct * NWG;
                 if (r < NF) {
                     float y;
@@ -528,7 +647,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
                     // bias of row tid lives in register bf_[tid] of every thread: select without dynamic indexing
                     float b = bf_[0];
 #pragma unroll
-                    for (int j = 1; j < PB_MAXFR; ++j) b = (ct == j) ? bf_[j] : b;
+                    for (int j = 1; j < MAXFR; ++j) b = (ct == j) ? bf_[j] : b;
                     y += b;
                     if (r < P) {
                         float v = fmaxf(y, 0.f);
@@ -550,7 +669,7 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
             }
         }
         PB_T(11);
-        pb_dot_seg(WdW, Kd, H + E, H, xhd_s, accD, lane);             // h_d(t) part of the next decoder LSTM
+        PB_DOT_D(2, H + E, H, xhd_s);                                 // h_d(t) part of the next decoder LSTM
         PB_T(12);
 
         // (11) p1(t+1) and the stop flag; prenet layer 2
@@ -584,14 +703,14 @@ __global__ __launch_bounds__(PB_NT, 1) void decode_persistent_b1_kernel(PersistP
         {
             const float x = tid < P ? xp1_s[tid] : 0.f;
 #pragma unroll
-            for (int j = 0; j < PB_MAXP2R; ++j) {
+            for (int j = 0; j < MAXP2R; ++j) {
                 if (k + j * NWG < P) {
                     const float s = row16_sum(w2[j] * x);
                     if ((lane & 15) == 0) red_s[192 + j * 16 + (tid >> 4)] = s;
                 }
             }
             __syncthreads();
-            if (ct >= 0 && ct < PB_MAXP2R) {
+            if (ct >= 0 && ct < MAXP2R) {
                 const int r = k + ct * NWG;
                 if (r < P) {
                     float y;
@@ -628,7 +747,9 @@ extern "C" long long t2amd_decoder_persist_mailbox_bytes(int Ti, int E, int H, i
 static long long persist_lds_bytes(const t2amd_dec_persist* a, int tip) {
     const long long Ka = a->P + a->E + a->H, Kd = 2ll * a->H + a->E;
     const long long TiP4 = (a->Ti + 3) & ~3;
-    return 2 * 16 * (Ka + Kd) + 4 * (a->P + a->E + 2ll * a->H + a->P + 4 + TiP4 + 2ll * tip + 64 + 256 + 256 + 16);
+    // f32: the attention rows and 12 of the 16 ctx segments of the decoder rows (the rest of the decoder rows: registers)
+    const long long rows = a->weights_f32 ? 4 * (16 * Ka + 12ll * a->E) : 2 * 16 * (Ka + Kd);
+    return rows + 4 * (a->P + a->E + 2ll * a->H + a->P + 4 + TiP4 + 2ll * tip + 64 + 256 + 256 + 16);
 }
 
 // 0 = this geometry can run on the persistent kernel; otherwise the reason is left in t2amd_last_error()
@@ -647,6 +768,10 @@ extern "C" int t2amd_decoder_persist_supported(const t2amd_dec_persist* a) {
     T2_REQUIRE((a->H + a->E + PB_NT - 1) / PB_NT <= PB_MAXKPT, "dec_persist: H + E too wide");
     T2_REQUIRE(a->H / 16 <= PB_MAXQ, "dec_persist: H too wide for the query slice");
     const int tip = ((a->Ti + 2 * PB_HALO + 2) + 3) & ~3;
+    T2_REQUIRE(!a->weights_f32 || (a->H % 256 == 0 && a->E % 256 == 0 && a->H <= 256 * PB_RJ && a->E <= 256 * PB_RJ && a->P % 8 == 0),
+               "dec_persist: f32 weights need H and E multiples of 256, <= 1024 (register-resident decoder-LSTM rows)");
+    T2_REQUIRE(!a->weights_f32 || ((a->P + a->C + 1 + nwg - 1) / nwg <= 2 && (a->P + nwg - 1) / nwg <= 1 && a->E / nwg <= 2),
+               "dec_persist: f32 weights leave registers for 2 projection rows, 1 prenet row and 2 context channels per workgroup");
     T2_REQUIRE(persist_lds_bytes(a, tip) <= 160 * 1024 - 1024, "dec_persist: the LSTM rows of one workgroup do not fit in 160 KB of LDS");
     return T2AMD_OK;
 }
@@ -658,7 +783,7 @@ extern "C" int t2amd_decoder_infer_persistent_f32(const t2amd_dec_persist* a, vo
                "dec_persist: null weights/inputs");
     T2_REQUIRE(a->PG && a->ALIGN && a->out_length && a->status && a->steps_done && a->mailbox, "dec_persist: null outputs/state");
     T2_REQUIRE(t2_aligned16(a->Wa16) && t2_aligned16(a->Wd16) && (reinterpret_cast<uintptr_t>(a->mailbox) & 7u) == 0,
-               "dec_persist: bf16 weights must be 16-byte aligned, the mailbox 8-byte aligned");
+               "dec_persist: the LSTM weights must be 16-byte aligned, the mailbox 8-byte aligned");
     T2_REQUIRE(a->max_steps > 0, "dec_persist: max_steps");
     PersistParams p;
     p.a = *a;
@@ -689,7 +814,8 @@ extern "C" int t2amd_decoder_infer_persistent_f32(const t2amd_dec_persist* a, vo
     if (lds > 64 * 1024 && lds > g_persist_lds) {
         // exactly what is needed: the kernel also owns a few hundred bytes of static LDS (the compiler's scratch for
         // __syncthreads_or), so asking for all 160 KB of dynamic LDS is refused
-        if (hipFuncSetAttribute((const void*)decode_persistent_b1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)decode_persistent_b1_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)decode_persistent_b1_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             T2_FAIL("dec_persist: cannot raise the dynamic LDS limit");
         g_persist_lds = (int)lds;
     }
@@ -698,7 +824,8 @@ extern "C" int t2amd_decoder_infer_persistent_f32(const t2amd_dec_persist* a, vo
         hipMemsetAsync(a->status, 0, sizeof(int), s) != hipSuccess || hipMemsetAsync(a->out_length, 0, sizeof(int), s) != hipSuccess ||
         hipMemsetAsync(a->steps_done, 0, sizeof(int), s) != hipSuccess)
         T2_FAIL("dec_persist: memset failed");
-    hipLaunchKernelGGL(decode_persistent_b1_kernel, dim3(p.nwg), dim3(PB_NT), (size_t)lds, s, p);
+    if (a->weights_f32) hipLaunchKernelGGL(decode_persistent_b1_kernel<true>, dim3(p.nwg), dim3(PB_NT), (size_t)lds, s, p);
+    else hipLaunchKernelGGL(decode_persistent_b1_kernel<false>, dim3(p.nwg), dim3(PB_NT), (size_t)lds, s, p);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -493,27 +493,33 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     float e_gin[4] = {0.f, 0.f, 0.f, 0.f}, e_bias[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f;
     int e_keep_raw = 1;
     int e_len = 0x7fffffff;
-    if (LSTM && egr < B) {
-        const int H = p.H;
-        const int* lens_ = p.lens;
-        const float* gin_ = p.gin;
-        const float* bias_ = p.bias;
-        const float* cprev_ = p.c_prev;
-        const uint8_t* keep_ = p.keep;
-        const long long ld_gin_ = p.ld_gin, ld_cprev_ = p.ld_cprev, ld_keep_ = p.ld_keep;
-        if (lens_) e_len = lens_[egr];
-        if (gin_) {
-            const float* g = gin_ + (long long)egr * ld_gin_;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e_gin[q] = g[q * H + ej];
-        }
-        if (bias_) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e_bias[q] = bias_[q * H + ej];
-        }
-        if (cprev_) e_cp = cprev_[(long long)egr * ld_cprev_ + ej];
-        if (keep_) e_keep_raw = keep_[(long long)egr * ld_keep_ + ej];
+    // Issued BEHIND the first tile's DMA (round 3; T2AMD_SW_EPI_FIRST=1 at build time restores "before"): the eleven loads
+    // and their 64-bit address arithmetic used to stand between kernel entry and the first weight byte (1.5 us to the first
+    // DMA against 0.7 us in the dgrad form, which has no such operands).  The counted vmcnt waits stay correct wherever the
+    // compiler finally places these loads: returns are in order, so a wait can only cover more than it needs, never less.
+#define SW_LOAD_EPI()                                                                                  \
+    if (LSTM && egr < B) {                                                                             \
+        const int H = p.H;                                                                             \
+        const int* lens_ = p.lens;                                                                     \
+        const float* gin_ = p.gin;                                                                     \
+        const float* bias_ = p.bias;                                                                   \
+        const float* cprev_ = p.c_prev;                                                                \
+        const uint8_t* keep_ = p.keep;                                                                 \
+        const long long ld_gin_ = p.ld_gin, ld_cprev_ = p.ld_cprev, ld_keep_ = p.ld_keep;              \
+        if (lens_) e_len = lens_[egr];                                                                 \
+        if (gin_) {                                                                                    \
+            const float* g = gin_ + (long long)egr * ld_gin_;                                          \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) e_gin[q] = g[q * H + ej];                    \
+        }                                                                                              \
+        if (bias_) {                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) e_bias[q] = bias_[q * H + ej];               \
+        }                                                                                              \
+        if (cprev_) e_cp = cprev_[(long long)egr * ld_cprev_ + ej];                                    \
+        if (keep_) e_keep_raw = keep_[(long long)egr * ld_keep_ + ej];                                 \
     }
+#ifdef T2AMD_SW_EPI_FIRST
+    SW_LOAD_EPI()
+#endif
 
     // DMA sources.  X: instruction q of this wave fills tile rows 8*wave + 4q + lg, LDS chunk l15 <- global
     // chunk l15 ^ (row & 15).  W: this wave fills weight-tile rows 4*wave + lg.
@@ -648,6 +654,11 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     if (kt_end > kt_beg) {
         SW_TS(1);
         SW_ISSUE(0)
+#ifndef T2AMD_SW_EPI_FIRST
+        __builtin_amdgcn_sched_barrier(0);
+        SW_LOAD_EPI()
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         SW_ISSUE(1)
         SW_ISSUE(2)
         SW_ISSUE(3)
@@ -673,6 +684,10 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped duplicate tiles
     }
+#ifndef T2AMD_SW_EPI_FIRST
+    else { SW_LOAD_EPI() }
+#endif
+#undef SW_LOAD_EPI
 #undef SW_ISSUE
 #undef SW_SEEK
 #undef SW_READ

@@ -972,7 +972,13 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     # prenet backward (model.py:99 under autograd)
     W2 = P['decoder.prenet.layers.1.linear_layer.weight']
     dp2 = run.empty(rowsD, Pd)
-    _ng(run, dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
+    if use16 and b16['DGA16'].shape[0] == To and (4 * Ha) % 64 == 0:
+        # bf16 mode: dp2 = dG_a . W_ih_a[:, :P] on the bf16-resident product -- the gate gradients are already a bf16
+        # K-contiguous slab ([To.B][4H]); the weight block is transposed once per weight version
+        WpT16 = run.cached('Wih_a_pT16', [Wih_a], lambda: Wih_a[:, :Pd].t().contiguous().to(torch.bfloat16))
+        nv.gemm16_tn(dp2, b16['DGA16'].view(rowsD, 4 * Ha), WpT16)
+    else:
+        _ng(run, dp2, DGA2, Wih_a[:, :Pd], b_kn=True)
     nv.relu_dropout_bwd(dp2, T['p2'], 2.0)
     dW2 = G('decoder.prenet.layers.1.linear_layer.weight', Pd, Pd)
     _rg(run, dW2, dp2, T['p1'], a_km=True, b_kn=True)
@@ -1131,6 +1137,7 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
     d.Ti, d.E, d.H, d.P, d.C = Ti, E, H, Pd, Cm
     d.max_steps = hp.max_decoder_steps
     d.gate_threshold = float(hp.gate_threshold)
+    d.weights_f32 = 0 if run.bf16 else 1            # fp32 parity mode: exact f32 rows (LDS + registers), same launch
     why = nv.decoder_persist_supported(d)
     if why is not None:
         model.last_decode_path = 'launch chain (%s)' % why
@@ -1142,7 +1149,12 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
     if getattr(model, 'persist_trace', False):
         trace = run.zeros(hp.max_decoder_steps, 2 * H + E + 2 * Pd)
         model.last_persist_trace = trace
-    d.Wa16, d.Wd16 = nv.ptr(i16['Wa_cat16'], torch.bfloat16), nv.ptr(i16['Wd_cat16'], torch.bfloat16)
+    if run.bf16:
+        wa_, wd_ = i16['Wa_cat16'], i16['Wd_cat16']
+        d.Wa16, d.Wd16 = nv.ptr(wa_, torch.bfloat16), nv.ptr(wd_, torch.bfloat16)
+    else:
+        wa_, wd_ = Wa_cat, Wd_cat
+        d.Wa16, d.Wd16 = nv.ptr(wa_), nv.ptr(wd_)
     d.bias_a, d.bias_d = nv.ptr(bias_a), nv.ptr(bias_d)
     d.Wq, d.U, d.v, d.Wf, d.bias_f, d.W2 = nv.ptr(Wq), nv.ptr(U), nv.ptr(vvec), nv.ptr(Wf), nv.ptr(bf), nv.ptr(W2.contiguous())
     d.memory, d.pm = nv.ptr(memory), nv.ptr(pm)
@@ -1157,7 +1169,7 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
         timing = torch.zeros(32, dtype=torch.int64, device=dev)
         model.last_persist_timing = timing
         d.timing = nv.ptr(timing, torch.int64)
-    nv.decoder_infer_persistent(d, reads=[i16['Wa_cat16'], i16['Wd_cat16'], bias_a, bias_d, Wq, U, vvec, Wf, bf, W2, memory, pm, keep],
+    nv.decoder_infer_persistent(d, reads=[wa_, wd_, bias_a, bias_d, Wq, U, vvec, Wf, bf, W2, memory, pm, keep],
                                 writes=[st['PG'], st['ALIGN'], out_lengths, status, steps_done, mailbox]
                                 + ([trace] if trace is not None else []) + ([timing] if timing is not None else []))
     code = int(status.item())
@@ -1341,14 +1353,14 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
     infer_reads = [P['decoder.prenet.layers.0.linear_layer.weight'], P['decoder.prenet.layers.1.linear_layer.weight'],
                    Wa_cat, bias_a, Wd_cat, bias_d, Wq, U, vvec, Wpg, bpg] + ([Wf_, bf_] if B > 8 else [])
-    # One utterance in the bf16 mode: the whole loop as ONE persistent launch, LSTM weights resident in LDS
-    # (csrc/decode_persist.hip).  Anything it cannot take -- or a timeout because the GPU is shared and H/4 workgroups
+    # One utterance: the whole loop as ONE persistent launch, LSTM weights resident on the CUs -- bf16 rows in LDS in the
+    # bf16 mode, exact f32 rows split between LDS and registers in the fp32 parity mode (csrc/decode_persist.hip).  Anything it cannot take -- or a timeout because the GPU is shared and H/4 workgroups
     # are not co-resident -- goes through the launch chain below.
     ran_persistent = False
     model.last_decode_path = 'launch chain'
-    if B == 1 and run.bf16 and not ragged and Ha == Hd and PERSISTENT_DECODE and not nv.validate_only():
+    if B == 1 and not ragged and Ha == Hd and PERSISTENT_DECODE and not nv.validate_only():
         ran_persistent = _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat,
-                                            bias_a, bias_d, Wq, U, vvec, Wpg, bpg, i16, Ti)
+                                            bias_a, bias_d, Wq, U, vvec, Wpg, bpg, i16 if run.bf16 else None, Ti)
     # ---- the launch chain, with early-exit compaction of the batch -----------------------------------
     # Finished utterances keep occupying every launch until the slowest one stops.  At a poll, once enough of them
     # have finished to free a 64-row tile of the LSTM kernels (or to reach the matrix-vector kernels of B <= 8), the

@@ -234,6 +234,7 @@ class DecPersist(C.Structure):
         ("memory", _f32p), ("pm", _f32p), ("keep_prenet", C.c_void_p),
         ("PG", _f32p), ("ALIGN", _f32p), ("out_length", C.c_void_p), ("status", C.c_void_p),
         ("steps_done", C.c_void_p), ("mailbox", C.c_void_p), ("trace", _f32p), ("timing", C.c_void_p),
+        ("weights_f32", C.c_int),
     ]
 
 

@@ -22,12 +22,12 @@ DEV = "cuda"
 OUT = os.path.join(gu.ROOT, "gpurun_out")
 
 
-def _model(hp, sd):
+def _model(hp, sd, precision='bf16'):
     from tacotron2_amd.model import Tacotron2
     m = Tacotron2(hp)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
-    m.precision = 'bf16'
+    m.precision = precision
     return m
 
 
@@ -194,3 +194,71 @@ def test_persistent_gives_up_and_the_launch_chain_takes_over(native_lib, capsys,
         assert torch.equal(a, b)
     gout, glen, gpath = _run(model, text, keep, True)              # and the next call runs persistently again
     assert gpath == 'persistent' and glen == clen
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp32 parity mode on the persistent kernel (round 3): exact f32 LSTM rows held on the CU -- attention rows in LDS, decoder
+# rows in REGISTERS (t2amd_dec_persist.weights_f32) -- so BASELINE configs[3] no longer has to choose between the 1e-4 /
+# bit-exact-stop mode and the one-launch decode loop.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Ti,steps", [(100, 160), (187, 64), (7, 40)])
+def test_persistent_fp32_matches_launch_chain_and_oracle(native_lib, Ti, steps):
+    hp = gu.make_hparams("max_decoder_steps=%d" % steps)
+    hp.gate_threshold = 2.0
+    sd = gu.build_state_dict(hp, 321, perturb_bn=True)
+    text = gu.make_text([Ti], 55)
+    keep = orc.draw_masks_infer(hp, 1, steps, torch.Generator().manual_seed(4))
+    model = _model(hp, sd, 'fp32')
+    pout, plen, ppath = _run(model, text, keep, True)
+    cout, clen, cpath = _run(model, text, keep, False)
+    assert ppath == 'persistent', ppath
+    assert cpath.startswith('launch chain'), cpath
+    assert plen == clen == steps
+    (omel, opost, ogate, oalign), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0)
+    rows = dict(shape="fp32 H=%d Ti=%d steps=%d" % (hp.attention_rnn_dim, Ti, steps))
+    for i, (nm, ref) in enumerate((("mel", omel), ("mel_post", opost), ("gate", ogate), ("align", oalign))):
+        d = (pout[i] - ref).abs()
+        dc = (pout[i] - cout[i]).abs()
+        rows[nm] = dict(vs_oracle_mean=float(d.mean()), vs_oracle_max=float(d.max()), vs_chain_max=float(dc.max()),
+                        refmax=float(ref.abs().max()))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_persistent_fp32_Ti%d.json" % Ti), "w") as f:
+        json.dump(rows, f, indent=1)
+    for nm in ("mel", "mel_post", "gate", "align"):      # the fp32-mode tolerances of tests/test_zz5
+        assert rows[nm]["vs_oracle_mean"] < 1e-4 and rows[nm]["vs_oracle_max"] < 5e-4 * max(1.0, rows[nm]["refmax"]), (nm, rows)
+
+
+def test_persistent_fp32_real_gate_stop_exact_with_1e4_margin(native_lib):
+    """Greedy decode to the gate stop on the ORACLE's trajectory (first crossing beyond 300 steps), once with the widest
+    margin it offers and once 1e-4 below the crossing value: the f32 persistent kernel stops on the oracle's frame."""
+    hp = gu.make_hparams("max_decoder_steps=520")
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()
+    wg[:, hp.decoder_rnn_dim:] *= -1.0
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    text = gu.make_text([100], 4242)
+    keep = orc.draw_masks_infer(hp, 1, 520, torch.Generator().manual_seed(9))
+    (omel, _, gate_o, _), _, _ = orc.tacotron2_inference(sd, hp, text, keep, 520, 2.0)
+    sig = torch.sigmoid(gate_o.reshape(-1))
+    best = None
+    for t in range(300, 520):
+        m = float(sig[:t].max())
+        if float(sig[t]) > m and (best is None or (float(sig[t]) - m) / 2 > best[2]):
+            best = (m + (float(sig[t]) - m) / 2, t + 1, (float(sig[t]) - m) / 2)
+    assert best is not None
+    cases = [best]
+    t = best[1] - 1
+    if float(sig[t]) - float(sig[:t].max()) > 4e-4:
+        cases.append((float(sig[t]) - 1e-4, t + 1, 1e-4))
+    rows = []
+    for thr, L, margin in cases:
+        hp.gate_threshold = thr
+        model = _model(hp, sd, 'fp32')
+        pout, plen, ppath = _run(model, text, keep, True)
+        rows.append(dict(threshold=thr, margin=margin, oracle_stop=L, persistent_stop=plen, path=ppath,
+                         mel_mean=float((pout[0] - omel[:, :, :pout[0].shape[2]]).abs().mean()) if plen == L else None))
+        with open(os.path.join(OUT, "parity_persistent_fp32_gate_stop.json"), "w") as f:
+            json.dump(rows, f, indent=1)
+        assert ppath == 'persistent' and plen == L, rows
+        assert rows[-1]['mel_mean'] < 1e-4
+    assert len(cases) == 2
