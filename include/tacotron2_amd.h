@@ -489,6 +489,15 @@ long long t2amd_attn_bwd_ws_floats(int B, int Ti);
  * {token, value} granules polled by their consumers, 0 = write-through stores + drain + token + payload loads,
  * -1 = library default / environment T2AMD_ATTN_GRANULES.  Bit-identical results. */
 int t2amd_set_attn_bwd_granules(int on);
+/* Number of in-launch hand-offs of the one-launch attention forms that were ABANDONED since the last reset (their bounded
+ * 50 ms spin ran out: the workgroups of an utterance were not co-resident, e.g. a shared or partitioned GPU).  Such a
+ * launch poisons its outputs with NaN; a caller that finds a non-finite loss / gradient norm asks here whether that is
+ * the reason and, if so, selects the separate-launch forms (t2amd_set_attn_fwd_fused(0), T2AMD_ATTN_FUSED_BWD=0 /
+ * t2amd_set_attn_bwd_fused(0)).  Synchronises with the device; -1 on error. */
+int t2amd_attn_handoff_timeouts(int reset);
+/* 0: the attention backward of a step as two launches (K_b1, K_b2; no in-launch hand-off, the LSTM cell backwards in
+ * their own launch); 1: one launch (default); -1: the T2AMD_ATTN_FUSED_BWD environment default */
+int t2amd_set_attn_bwd_fused(int on);
 
 /* ------------------------------------------------------------------------------------
  * Device-resident time loops.  One host call enqueues every step's kernels.

@@ -25,6 +25,29 @@
 #include <stdlib.h>
 #include <stddef.h>
 
+// Abandoned in-launch hand-offs (bounded spins that ran out: a workgroup of an utterance never became resident within
+// 50 ms).  The kernels poison their outputs with NaN so that nothing can use a half-exchanged step; this counter says WHY
+// a step went non-finite: the host reads it (t2amd_attn_handoff_timeouts) when the gradient norm is not finite and
+// switches to the separate-launch forms, which make no co-residency assumption.  Cold path only.
+__device__ unsigned int t2_attn_timeouts = 0u;
+__device__ __forceinline__ void t2_attn_gave_up() { atomicAdd(&t2_attn_timeouts, 1u); }
+extern "C" int t2amd_attn_handoff_timeouts(int reset) {
+    if (t2amd_validate_only_flag_()) return 0;
+    unsigned int v = 0u;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(t2_attn_timeouts), sizeof(v)) != hipSuccess) return -1;
+    if (reset && v != 0u) {
+        const unsigned int z = 0u;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(t2_attn_timeouts), &z, sizeof(z));
+    }
+    return (int)(v > 0x7fffffffu ? 0x7fffffffu : v);
+}
+// tests only: what a timed-out hand-off does to the counter
+__global__ void t2_attn_bump_kernel() { t2_attn_gave_up(); }
+extern "C" int t2amd_debug_attn_timeout_(void* stream) {
+    hipLaunchKernelGGL(t2_attn_bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 #define AD T2AMD_ATT_DIM       // 128
 #define NTAP T2AMD_LOC_TAPS    // 62
@@ -816,7 +839,7 @@ __global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams 
             __builtin_amdgcn_s_sleep(1);
 #pragma unroll
             for (int k = 0; k < NSL; ++k) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; break; }
+            if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; t2_attn_gave_up(); break; }
         }
 #pragma unroll
         for (int k = 0; k < NSL; ++k) e_first[k] = bad ? __builtin_nanf("") : __uint_as_float((unsigned)x[k]);
@@ -1259,7 +1282,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 if (__all((unsigned)(xd >> 32) == p.token)) break;
                 __builtin_amdgcn_s_sleep(1);
                 xd = __hip_atomic_load(grow + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; break; }
+                if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; t2_attn_gave_up(); break; }
             }
             if (bad && lane == 0) gflag_s[0] = 1;
         }
@@ -1295,7 +1318,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             unsigned spins_ = 0;
             while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.token) {
                 __builtin_amdgcn_s_sleep(1);
-                if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { poison = true; break; }
+                if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { poison = true; t2_attn_gave_up(); break; }
             }
         }
         __syncthreads();
@@ -1631,7 +1654,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 unsigned spins_ = 0;
                 while (__hip_atomic_load(flags2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.token) {
                     __builtin_amdgcn_s_sleep(1);
-                    if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; break; }
+                    if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; t2_attn_gave_up(); break; }
                 }
             }
             bad = __any(bad);
@@ -1722,6 +1745,12 @@ extern "C" int t2amd_set_attn_bwd_granules(int on) {
     return T2AMD_OK;
 }
 static unsigned g_attn_bwd_token = 0;      // one launch counter for both one-launch forms: a token never repeats in ws (never zero)
+static int g_attn_bwd_fused = -1;          // -1: T2AMD_ATTN_FUSED_BWD / default (one launch); 0 / 1: t2amd_set_attn_bwd_fused
+extern "C" int t2amd_set_attn_bwd_fused(int on) {
+    T2_REQUIRE(on == 0 || on == 1 || on == -1, "set_attn_bwd_fused: -1 (default), 0 or 1");
+    g_attn_bwd_fused = on;
+    return T2AMD_OK;
+}
 
 extern "C" long long t2amd_attn_bwd_ws_floats(int B, int Ti) {
     const long long goff = ((long long)B * Ti + 12ll * B + 1) / 2 * 2;
@@ -1781,7 +1810,8 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     // units, default 16), then polls).  Round 1 measured 71.6 vs 72.1 ms per training step -- with a hand-off that did not
     // drain the stores before the token and was therefore racy; with the drain round 2 measures 71.5 vs 72.1 ms over 16
     // steps, twice (profiles/r02_i_fused_bwd_after_fix.txt).  Bit-identical to the two-launch path (tests).
-    static const bool fused = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+    static const bool fused_env = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
+    const bool fused = g_attn_bwd_fused < 0 ? fused_env : g_attn_bwd_fused != 0;
     // pre-poll pause in s_sleep units: 16 for the token form; the granule form is flat from 4 to 16 (63.7 / 63.55 / 63.8 ms
     // per training step at 4 / 8 / 16; 64.2 at 0, 64.9 at 64: profiles/r02_y_granule_delay_sweep.txt)
     static const int fused_delay_env = [] { const char* e = getenv("T2AMD_ATTN_FUSED_DELAY"); const int v = e ? atoi(e) : -1; return v > 100 ? 100 : v; }();

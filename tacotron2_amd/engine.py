@@ -524,6 +524,28 @@ def _guard_weights(model, run, P):
         cache['__guard__'] = keep
 
 
+def handle_nonfinite_step(log=None):
+    """Call when a training step produced a non-finite loss / gradient norm.  If the reason is an ABANDONED in-launch
+    hand-off of the one-launch attention forms (their four workgroups per utterance were not co-resident within 50 ms: a
+    shared or partitioned GPU; the kernels then poison the step with NaN rather than use half-exchanged data), say so
+    and select the separate-launch forms for the rest of the process -- bit-identical results, no co-residency
+    assumption.  Returns the number of abandoned hand-offs (0: the non-finite values have another cause)."""
+    n = nv.attn_handoff_timeouts(reset=True)
+    if n > 0:
+        nv.set_attn_fwd_fused(0)
+        nv.set_attn_bwd_fused(0)
+        nv.set_bptt_cell_fold(0)
+        msg = ("tacotron2_amd: %d in-launch attention hand-off(s) timed out (the workgroups of an utterance were not "
+               "co-resident within 50 ms -- is the GPU shared or partitioned?); that step was poisoned with NaN and is "
+               "skipped; the separate-launch forms are selected from here on" % n)
+        if log is not None:
+            log(msg)
+        else:
+            import sys
+            print(msg, file=sys.stderr, flush=True)
+    return n
+
+
 def _cached_bias_sum(run, tag, b1, b2):
     return run.cached(tag, [b1, b2], lambda: _bias_sum(run, b1, b2))
 
@@ -1139,6 +1161,16 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
     d.gate_threshold = float(hp.gate_threshold)
     d.weights_f32 = 0 if run.bf16 else 1            # fp32 parity mode: exact f32 rows (LDS + registers), same launch
     why = nv.decoder_persist_supported(d)
+    if why is None and not nv.validate_only():
+        # H/4 workgroups of ~137 KB LDS must all be co-resident: one per CU.  A partitioned / CU-masked device that shows
+        # fewer CUs can never run it -- do not pay the 30 ms give-up for finding that out
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if cus < H // 4:
+            why = "the device shows %d CUs, the kernel needs %d co-resident workgroups" % (cus, H // 4)
+    if why is None and getattr(model, '_persist_backoff', 0) > 0:
+        # the kernel timed out recently on this model (shared GPU): straight to the launch chain for a while, then try again
+        model._persist_backoff -= 1
+        why = "persistent kernel timed out recently, %d more call(s) on the launch chain" % model._persist_backoff
     if why is not None:
         model.last_decode_path = 'launch chain (%s)' % why
         return False
@@ -1181,8 +1213,12 @@ def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_
         nv.fill(st['ALIGN'], 0.0)
         out_lengths.zero_()
         model.last_decode_path = 'launch chain (persistent kernel timed out)'
+        # exponential back-off: 4, 8, ... up to 256 calls on the launch chain before the next attempt
+        model._persist_timeouts = getattr(model, '_persist_timeouts', 0) + 1
+        model._persist_backoff = min(256, 2 << model._persist_timeouts)
         return False
     model.last_decode_path = 'persistent'
+    model._persist_timeouts = 0
     return True
 
 

@@ -273,7 +273,7 @@ SYMBOLS = [
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
-    "t2amd_set_attn_bwd_granules", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
+    "t2amd_set_attn_bwd_granules", "t2amd_attn_handoff_timeouts", "t2amd_set_attn_bwd_fused", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
@@ -335,6 +335,8 @@ def _argtypes():
         "t2amd_get_bptt_cell_fold": [],
         "t2amd_attn_bwd_ws_floats": [_I, _I],
         "t2amd_set_attn_bwd_granules": [_I],
+        "t2amd_attn_handoff_timeouts": [_I],
+        "t2amd_set_attn_bwd_fused": [_I],
         "t2amd_attn_fwd_ws_floats": [_I, _I],
         "t2amd_set_attn_fwd_fused": [_I],
         "t2amd_lstm_step_small_f32": [pt(LstmStep), _P],
@@ -1012,6 +1014,19 @@ def attn_bwd_ws_floats(B, Ti):
 def set_attn_bwd_granules(on):
     """First hand-off of the one-launch attention backward: 1 granules, 0 drained stores + token, -1 library default."""
     _check(load().t2amd_set_attn_bwd_granules(int(on)), "t2amd_set_attn_bwd_granules")
+
+
+def attn_handoff_timeouts(reset=True):
+    """Abandoned in-launch hand-offs of the one-launch attention forms since the last reset (synchronises)."""
+    n = load().t2amd_attn_handoff_timeouts(1 if reset else 0)
+    if n < 0:
+        raise NativeError("t2amd_attn_handoff_timeouts failed")
+    return n
+
+
+def set_attn_bwd_fused(on):
+    """1: the attention backward of a step as one launch (default), 0: K_b1 / K_b2 as separate launches, -1: default."""
+    _check(load().t2amd_set_attn_bwd_fused(int(on)), "t2amd_set_attn_bwd_fused")
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,

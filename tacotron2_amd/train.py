@@ -28,7 +28,7 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
-from . import native
+from . import engine, native
 from .data_utils import TextMelCollate, TextMelLoader
 from .distributed import apply_gradient_allreduce, reduce_tensor
 from .hparams import create_hparams
@@ -257,6 +257,10 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
                 bad_steps += 1
                 print("Warning: non-finite gradient norm at iteration {} (loss {}): optimiser step skipped "
                       "({} in a row)".format(iteration, reduced_loss, bad_steps), flush=True)
+                # was it an abandoned in-launch hand-off (a GPU shared with another job)?  Then say so and go on with the
+                # separate-launch forms instead of counting towards divergence
+                if not native.validate_only() and engine.handle_nonfinite_step(lambda m: print(m, flush=True)) > 0:
+                    bad_steps -= 1
                 if bad_steps >= MAX_NONFINITE_STEPS:
                     raise FloatingPointError("%d consecutive iterations with a non-finite gradient norm: the run "
                                              "has diverged (last loss %r)" % (bad_steps, reduced_loss))

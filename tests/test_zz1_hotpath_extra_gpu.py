@@ -259,3 +259,46 @@ def test_loops_run_through_the_torch_dispatcher(native_lib):
     for prec in ('fp32', 'bf16'):
         for u, v in zip(a[prec], b[prec]):
             assert torch.equal(u, v), prec
+
+
+def test_attention_handoff_timeouts_are_reported_and_handled(native_lib, capfd):
+    """an abandoned in-launch hand-off poisons the step with NaN; the host must be able to learn WHY.  The
+    kernels count give-ups in a device word; engine.handle_nonfinite_step reads it, reports, and selects the
+    separate-launch forms (no co-residency assumption), which give the same bits."""
+    import ctypes as C
+    from tacotron2_amd import engine, native
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    from tacotron2_amd.model import Tacotron2
+    assert native.attn_handoff_timeouts(reset=True) >= 0
+    assert native.attn_handoff_timeouts(reset=False) == 0
+    assert engine.handle_nonfinite_step() == 0                   # nothing timed out: forms untouched
+    hp = create_hparams("")
+    torch.manual_seed(21)
+    model = Tacotron2(hp).cuda().train()
+    model.precision = 'bf16'
+    batch = gu.make_train_batch([15, 11, 8, 6], [28, 21, 17, 9], hp.n_mel_channels, 8)
+
+    def grads():
+        torch.manual_seed(3)
+        model.zero_grad()
+        x, y = model.parse_batch(tuple(t.clone() for t in batch))
+        Tacotron2Loss()(model(x), y).backward()
+        return [p.grad.clone() for p in model.parameters()]
+    ref = grads()
+    f = native_lib.t2amd_debug_attn_timeout_                     # what a timed-out spin does to the counter
+    f.argtypes = [C.c_void_p]
+    assert f(native._stream()) == 0 and f(native._stream()) == 0
+    torch.cuda.synchronize()
+    fold0 = native.get_bptt_cell_fold()
+    try:
+        assert engine.handle_nonfinite_step() == 2
+        assert "hand-off(s) timed out" in capfd.readouterr().err
+        assert native.attn_handoff_timeouts(reset=False) == 0    # reset by the handler
+        assert native.get_bptt_cell_fold() == 0                  # separate-launch forms selected ...
+        got = grads()
+        for a, b in zip(got, ref):                               # ... and they compute the same bits
+            assert torch.equal(a, b)
+    finally:
+        native.set_attn_fwd_fused(-1)
+        native.set_attn_bwd_fused(-1)
+        native.set_bptt_cell_fold(fold0)

@@ -192,8 +192,14 @@ def test_persistent_gives_up_and_the_launch_chain_takes_over(native_lib, capsys,
     assert plen == clen
     for a, b in zip(pout, cout):
         assert torch.equal(a, b)
-    gout, glen, gpath = _run(model, text, keep, True)              # and the next call runs persistently again
-    assert gpath == 'persistent' and glen == clen
+    # after a timeout the model stays on the launch chain for a few calls (exponential back-off: a shared GPU would time
+    # out again, 30 ms each), then tries the persistent kernel again
+    gout, glen, gpath = _run(model, text, keep, True)
+    assert gpath.startswith('launch chain (persistent kernel timed out recently') and glen == clen, gpath
+    assert model._persist_backoff == 3
+    model._persist_backoff = 0
+    gout, glen, gpath = _run(model, text, keep, True)
+    assert gpath == 'persistent' and glen == clen and model._persist_timeouts == 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
