@@ -626,6 +626,14 @@ int t2amd_lstm_seq_bwd_f32(const t2amd_lstm_seq* p, void* stream);
 /* Both directions of the bi-LSTM in lockstep, one launch per step for the pair (q may be NULL). */
 int t2amd_lstm_seq_fwd2_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, void* stream);
 int t2amd_lstm_seq_bwd2_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, void* stream);
+/* The same forward recurrence for ONE utterance (B == 1, H <= 256; Encoder.inference, reference model.py:192-201) as ONE
+ * persistent launch of 2 x H/4 co-resident workgroups: W_hh rows in registers, h exchanged as {step + 1, f32} granules in
+ * `mailbox` (t2amd_lstm_seq_persistent_mailbox_bytes(H, ndir) bytes, zeroed by the call).  Inference only: writes `out`,
+ * leaves GX / C untouched.  Bounded spins: *status != 0 afterwards = a workgroup gave up, run t2amd_lstm_seq_fwd2_f32. */
+long long t2amd_lstm_seq_persistent_mailbox_bytes(int H, int ndir);
+int t2amd_lstm_seq_persistent_supported(const t2amd_lstm_seq* p);
+int t2amd_lstm_seq_fwd2_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned long long* mailbox,
+                                       int* status, void* stream);
 
 /* Free-running decoder (reference model.py:418-454 Decoder.inference), any B: per-utterance
  * stop flags on the device, stop test sigmoid(gate) > threshold (strict) after the frame is

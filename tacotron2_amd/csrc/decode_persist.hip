@@ -829,3 +829,139 @@ extern "C" int t2amd_decoder_infer_persistent_f32(const t2amd_dec_persist* a, vo
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
+
+
+// =====================================================================================================================
+// Encoder bi-LSTM of ONE utterance as one persistent launch (reference model.py:192-201 Encoder.inference, the nn.LSTM
+// call :197-199).  The launch chain spends T dependent launches of ~6 us on it (0.6 ms of a 14 ms single-utterance
+// call); here 2 x H/4 co-resident workgroups (both directions in one launch) keep their 16 rows of W_hh in REGISTERS
+// (4 KB per wave at H = 256) and exchange h as {step + 1, f32} granules, double-buffered by step parity (a producer
+// may run one step ahead of its slowest reader, never two: it needs every workgroup's h of the previous step first).
+// Inference only: writes the outputs, not the gate / cell slabs the training backward reads.  Bounded spins; on a
+// timeout *status != 0 and the caller must run t2amd_lstm_seq_fwd2_f32 instead.
+// =====================================================================================================================
+#define EP_NT 256
+#define EP_MAXJ 4                        // H / 64 h values per lane: H <= 256
+struct EncPersistParams {
+    t2amd_lstm_seq d[2];
+    int ndir, nwg_dir;
+    pb_u64* mailbox;                     // [ndir][2][H]
+    int* status;
+    long long timeout_ticks;
+};
+
+__global__ __launch_bounds__(EP_NT, 1) void encoder_bilstm_persistent_kernel(EncPersistParams p) {
+    __shared__ float os_s[16];
+    __shared__ int fail_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = (int)blockIdx.x / p.nwg_dir, k = (int)blockIdx.x % p.nwg_dir;
+    const t2amd_lstm_seq& a = p.d[dir];
+    const int H = a.H, T = a.T, nj = H >> 6;
+    pb_u64* const box = p.mailbox + (size_t)dir * 2 * H;
+    // this wave's gate rows (gate = wave, units 4k .. 4k+3): element lane + 64 j of each, in registers
+    float wr[4][EP_MAXJ];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float* row = a.Whh + ((long long)wave * H + 4 * k + u) * H;
+#pragma unroll
+        for (int j = 0; j < EP_MAXJ; ++j) wr[u][j] = j < nj ? row[lane + 64 * j] : 0.f;
+    }
+    float c = 0.f;
+    if (tid == 0) fail_s = 0;
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const int t = a.reverse ? T - 1 - s : s;
+        // this unit's four pre-activation addends (hoisted x . W_ih^T + biases): issued before the wait
+        float gin[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tid < 4) {
+            const float* g = a.GX + (long long)t * 4 * H + 4 * k + tid;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gin[q] = g[q * H];
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (s > 0) {
+            // h(s-1) of the whole direction: lane polls granules lane + 64 j of buffer (s-1) & 1 until they carry tag s
+            const pb_u64* g = box + (size_t)((s - 1) & 1) * H;
+            pb_u64 x[EP_MAXJ];
+            const unsigned tag = (unsigned)s;
+#pragma unroll
+            for (int j = 0; j < EP_MAXJ; ++j) x[j] = __hip_atomic_load(g + (j < nj ? lane + 64 * j : lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = wall_clock64();
+            unsigned spins = 0;
+            bool bad = false;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < EP_MAXJ; ++j) ok = ok && (j >= nj || (unsigned)(x[j] >> 32) == tag);
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int j = 0; j < EP_MAXJ; ++j) x[j] = __hip_atomic_load(g + (j < nj ? lane + 64 * j : lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((++spins & 31u) == 0 && pb_give_up(t0, p.status, p.timeout_ticks)) { bad = true; break; }
+            }
+            if (bad && lane == 0) fail_s = 1;
+#pragma unroll
+            for (int j = 0; j < EP_MAXJ; ++j) {
+                const float h = j < nj ? __uint_as_float((unsigned)x[j]) : 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = fmaf(wr[u][j], h, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float v = wave_reduce_sum(acc[u]);
+            if (lane == 0) os_s[wave * 4 + u] = v;
+        }
+        __syncthreads();
+        if (fail_s) return;
+        if (tid < 4) {
+            const float gi = t2_sigmoid(os_s[tid] + gin[0]), gf = t2_sigmoid(os_s[4 + tid] + gin[1]);
+            const float gg = tanhf(os_s[8 + tid] + gin[2]), go = t2_sigmoid(os_s[12 + tid] + gin[3]);
+            c = gf * c + gi * gg;
+            const float h = go * tanhf(c);
+            pb_publish(box + (size_t)(s & 1) * H + 4 * k + tid, (unsigned)s + 1u, h);
+            a.out[(long long)t * a.ld_out + 4 * k + tid] = h;
+        }
+        __syncthreads();                                            // os_s is rewritten by the next step
+    }
+}
+
+extern "C" long long t2amd_lstm_seq_persistent_mailbox_bytes(int H, int ndir) { return 8ll * ndir * 2 * H; }
+
+// 0 = this geometry can run persistently (one utterance, H a multiple of 64 up to 256); else T2AMD_ERR_ARG with the reason
+extern "C" int t2amd_lstm_seq_persistent_supported(const t2amd_lstm_seq* p) {
+    T2_REQUIRE(p != nullptr, "lstm_seq_persistent: null args");
+    T2_REQUIRE(p->B == 1, "lstm_seq_persistent: one utterance only (a batch would exchange B x H granules per step)");
+    T2_REQUIRE(p->H % 64 == 0 && p->H >= 64 && p->H <= 64 * EP_MAXJ, "lstm_seq_persistent: H must be a multiple of 64, <= 256");
+    T2_REQUIRE(p->T > 0, "lstm_seq_persistent: T");
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_lstm_seq_fwd2_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned long long* mailbox,
+                                                  int* status, void* stream) {
+    T2_PROPAGATE(t2amd_lstm_seq_persistent_supported(p));
+    T2_REQUIRE(p->Whh && p->GX && p->out && mailbox && status, "lstm_seq_persistent: null pointer");
+    if (q) {
+        T2_PROPAGATE(t2amd_lstm_seq_persistent_supported(q));
+        T2_REQUIRE(q->T == p->T && q->H == p->H && q->Whh && q->GX && q->out, "lstm_seq_persistent: the two directions must match");
+    }
+    T2_REQUIRE((reinterpret_cast<uintptr_t>(mailbox) & 7u) == 0, "lstm_seq_persistent: the mailbox must be 8-byte aligned");
+    EncPersistParams e;
+    e.d[0] = *p;
+    e.d[1] = q ? *q : *p;
+    e.ndir = q ? 2 : 1;
+    e.nwg_dir = p->H / 4;
+    e.mailbox = mailbox;
+    e.status = status;
+    const char* te = getenv("T2AMD_PB_TIMEOUT_TICKS");
+    e.timeout_ticks = te ? atoll(te) : PB_TIMEOUT_TICKS;
+    if (e.timeout_ticks < 1) e.timeout_ticks = 1;
+    if (t2amd_validate_only_flag_()) return T2AMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(mailbox, 0, (size_t)t2amd_lstm_seq_persistent_mailbox_bytes(p->H, e.ndir), s) != hipSuccess ||
+        hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess)
+        T2_FAIL("lstm_seq_persistent: memset failed");
+    hipLaunchKernelGGL(encoder_bilstm_persistent_kernel, dim3(e.ndir * e.nwg_dir), dim3(EP_NT), 0, s, e);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}

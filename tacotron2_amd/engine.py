@@ -1124,6 +1124,8 @@ class Tacotron2TrainFunction(torch.autograd.Function):
 COMPACT_BATCH = os.environ.get('T2AMD_COMPACT_BATCH', '1') != '0'
 # T2AMD_DECODE_PERSISTENT=0 keeps single-utterance bf16 decoding on the launch chain (A/B runs, shared GPUs)
 PERSISTENT_DECODE = os.environ.get('T2AMD_DECODE_PERSISTENT', '1') != '0'
+# T2AMD_ENCODER_PERSISTENT=0 keeps the single-utterance encoder bi-LSTM on the launch chain (A/B runs, shared GPUs)
+PERSISTENT_ENCODER = os.environ.get('T2AMD_ENCODER_PERSISTENT', '1') != '0'
 
 
 def _folded_projection(run, P, hp, Wpg, bpg):
@@ -1297,9 +1299,28 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         desc.C = nv.ptr(Cst)
         desc.lens = nv.ptr(lens32, torch.int32)
         idesc.append((desc, GX, Cst))
-    nv.lstm_seq_fwd2(idesc[0][0], idesc[1][0],
-                     reads=[P['encoder.lstm.weight_hh_l0'], P['encoder.lstm.weight_hh_l0_reverse'], idesc[0][1], idesc[1][1], lens32],
-                     writes=[memory, idesc[0][2], idesc[1][2]])
+    enc_persistent = False
+    if (B == 1 and not ragged and PERSISTENT_ENCODER and not nv.validate_only()
+            and getattr(model, '_enc_persist_backoff', 0) <= 0 and nv.lstm_seq_persistent_supported(idesc[0][0]) is None
+            and torch.cuda.get_device_properties(dev).multi_processor_count >= He // 2):
+        # one utterance: the whole bi-LSTM as ONE persistent launch (W_hh rows in registers, h as granules) instead of Ti
+        # dependent launches; a timeout (shared GPU) falls back to the launch chain, with a back-off like the decoder's
+        ebox = torch.empty(nv.load().t2amd_lstm_seq_persistent_mailbox_bytes(He, 2) // 8, dtype=torch.int64, device=dev)
+        estat = torch.zeros(1, dtype=torch.int32, device=dev)
+        nv.lstm_seq_fwd2_persistent(idesc[0][0], idesc[1][0], ebox, estat)
+        enc_persistent = int(estat.item()) == 0
+        if not enc_persistent:
+            import sys
+            print("tacotron2_amd: the persistent encoder kernel gave up (its %d workgroups were not co-resident within 30 ms); "
+                  "running the launch chain" % (He // 2), file=sys.stderr, flush=True)
+            model._enc_persist_backoff = 16
+    elif getattr(model, '_enc_persist_backoff', 0) > 0:
+        model._enc_persist_backoff -= 1
+    model.last_encoder_path = 'persistent' if enc_persistent else 'launch chain'
+    if not enc_persistent:
+        nv.lstm_seq_fwd2(idesc[0][0], idesc[1][0],
+                         reads=[P['encoder.lstm.weight_hh_l0'], P['encoder.lstm.weight_hh_l0_reverse'], idesc[0][1], idesc[1][1], lens32],
+                         writes=[memory, idesc[0][2], idesc[1][2]])
 
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
     pm = run.empty(B, Ti, A)

@@ -275,6 +275,7 @@ SYMBOLS = [
     "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
     "t2amd_set_attn_bwd_granules", "t2amd_attn_handoff_timeouts", "t2amd_set_attn_bwd_fused", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
+    "t2amd_lstm_seq_persistent_mailbox_bytes", "t2amd_lstm_seq_persistent_supported", "t2amd_lstm_seq_fwd2_persistent_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
     "t2amd_decoder_persist_mailbox_bytes", "t2amd_decoder_persist_supported", "t2amd_decoder_infer_persistent_f32",
@@ -327,6 +328,9 @@ def _argtypes():
         "t2amd_lstm_seq_bwd_f32": [pt(LstmSeq), _P],
         "t2amd_lstm_seq_fwd2_f32": [pt(LstmSeq), pt(LstmSeq), _P],
         "t2amd_lstm_seq_bwd2_f32": [pt(LstmSeq), pt(LstmSeq), _P],
+        "t2amd_lstm_seq_persistent_mailbox_bytes": [_I, _I],
+        "t2amd_lstm_seq_persistent_supported": [pt(LstmSeq)],
+        "t2amd_lstm_seq_fwd2_persistent_f32": [pt(LstmSeq), pt(LstmSeq), _P, _P, _P],
         "t2amd_decoder_infer_steps_f32": [pt(DecInfer), _P],
         "t2amd_struct_sizes": [pt(C.c_int), _I],
         "t2amd_set_validate_only": [_I],
@@ -391,6 +395,7 @@ def load():
     lib.t2amd_attn_bwd_ws_floats.restype = C.c_longlong
     lib.t2amd_attn_fwd_ws_floats.restype = C.c_longlong
     lib.t2amd_decoder_persist_mailbox_bytes.restype = C.c_longlong
+    lib.t2amd_lstm_seq_persistent_mailbox_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
     sizes = (C.c_int * 32)()
@@ -1172,6 +1177,24 @@ def lstm_seq_fwd(desc):
 
 def lstm_seq_fwd2(d0, d1, reads=None, writes=None):
     _loop("encoder_lstm_fwd", "t2amd_lstm_seq_fwd2_f32", [d0, d1], reads, writes)
+
+
+def lstm_seq_persistent_supported(desc):
+    """None when the encoder bi-LSTM of this geometry can run as one persistent launch, else the reason."""
+    lib = load()
+    if lib.t2amd_lstm_seq_persistent_supported(C.byref(desc)) == 0:
+        return None
+    msg = lib.t2amd_last_error()
+    return msg.decode() if msg else "unsupported"
+
+
+def lstm_seq_fwd2_persistent(d0, d1, mailbox, status):
+    """Both directions of a single-utterance encoder bi-LSTM as one persistent launch (csrc/decode_persist.hip)."""
+    need = load().t2amd_lstm_seq_persistent_mailbox_bytes(d0.H, 2)
+    if mailbox.numel() * mailbox.element_size() < need:
+        raise NativeError("lstm_seq_fwd2_persistent: mailbox of %d bytes, %d needed" % (mailbox.numel() * mailbox.element_size(), need))
+    _check(load().t2amd_lstm_seq_fwd2_persistent_f32(C.byref(d0), C.byref(d1), ptr(mailbox, torch.int64), ptr(status, torch.int32),
+                                                     _stream()), "t2amd_lstm_seq_fwd2_persistent_f32")
 
 
 def lstm_seq_bwd2(d0, d1, reads=None, writes=None):

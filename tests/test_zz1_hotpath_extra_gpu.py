@@ -63,8 +63,9 @@ def test_smaller_attention_geometry_trains_like_the_oracle(native_lib):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_smaller_attention_geometry_decodes_like_the_oracle(native_lib, precision):
-    """Same geometry through Tacotron2.inference at the default widths: B = 1 (the persistent kernel in bf16 mode, the
-    launch chain in fp32 mode) and a ragged batch of three, forced length, against the f32 oracle."""
+    """Same geometry through Tacotron2.inference at the default widths: B = 1 (the persistent kernel in both modes since
+    round 3: bf16 rows in LDS / exact f32 rows in LDS + registers) and a ragged batch of three, forced length, against the
+    f32 oracle."""
     from oracle import tacotron2_oracle as orc
     from tacotron2_amd.model import Tacotron2
     steps = 36
@@ -84,7 +85,7 @@ def test_smaller_attention_geometry_decodes_like_the_oracle(native_lib, precisio
             out = model.inference(text.cuda(), il.cuda() if il is not None else None)
         torch.cuda.synchronize()
         if len(lens) == 1:
-            assert model.last_decode_path == ('persistent' if precision == 'bf16' else 'launch chain'), model.last_decode_path
+            assert model.last_decode_path == 'persistent', model.last_decode_path
             (omel, opost, ogate, oalign), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0)
             refs = [(omel, out[0].float().cpu()), (oalign, out[3].float().cpu())]
         else:

@@ -268,3 +268,39 @@ def test_persistent_fp32_real_gate_stop_exact_with_1e4_margin(native_lib):
         assert ppath == 'persistent' and plen == L, rows
         assert rows[-1]['mel_mean'] < 1e-4
     assert len(cases) == 2
+
+
+@pytest.mark.parametrize("Ti", [100, 187, 5])
+def test_persistent_encoder_bilstm_matches_launch_chain_and_oracle(native_lib, Ti):
+    """Encoder.inference's bi-LSTM (reference model.py:192-201) for one utterance as ONE persistent launch (W_hh rows in
+    registers, h exchanged as granules; csrc/decode_persist.hip) against the Ti-launch chain and the oracle, fp32 mode:
+    same inputs, another summation order."""
+    from tacotron2_amd import engine
+    steps = 48
+    hp = gu.make_hparams("max_decoder_steps=%d" % steps)
+    hp.gate_threshold = 2.0
+    sd = gu.build_state_dict(hp, 77, perturb_bn=True)
+    text = gu.make_text([Ti], 56)
+    keep = orc.draw_masks_infer(hp, 1, steps, torch.Generator().manual_seed(6))
+    model = _model(hp, sd, 'fp32')
+    res = {}
+    old = engine.PERSISTENT_ENCODER
+    try:
+        for on in (True, False):
+            engine.PERSISTENT_ENCODER = on
+            out, _, _ = _run(model, text, keep, True)
+            res[on] = out
+            assert model.last_encoder_path == ('persistent' if on else 'launch chain'), model.last_encoder_path
+    finally:
+        engine.PERSISTENT_ENCODER = old
+    (omel, opost, ogate, oalign), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0)
+    rows = {}
+    for i, (nm, ref) in enumerate((("mel", omel), ("mel_post", opost), ("gate", ogate), ("align", oalign))):
+        rows[nm] = dict(vs_chain_max=float((res[True][i] - res[False][i]).abs().max()),
+                        vs_oracle_mean=float((res[True][i] - ref).abs().mean()), vs_oracle_max=float((res[True][i] - ref).abs().max()),
+                        refmax=float(ref.abs().max()))
+    with open(os.path.join(OUT, "parity_persistent_encoder_Ti%d.json" % Ti), "w") as f:
+        json.dump(rows, f, indent=1)
+    for nm in rows:
+        assert rows[nm]["vs_oracle_mean"] < 1e-4 and rows[nm]["vs_oracle_max"] < 5e-4 * max(1.0, rows[nm]["refmax"]), (nm, rows)
+        assert rows[nm]["vs_chain_max"] < 1e-4 * max(1.0, rows[nm]["refmax"]), (nm, rows)
