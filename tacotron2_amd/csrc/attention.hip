@@ -1259,6 +1259,14 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             dva[dt][r] = 0.f;
             dqa[dt][r] = 0.f;
         }
+#ifdef T2AMD_ATTN_BWD_LATE                     // A/B builds only (python -m tacotron2_amd.build --variant ...): the round-2 order
+    constexpr bool EARLY = false;
+#else
+    constexpr bool EARLY = FUSED && GRAN;      // staging and tanh ahead of the first hand-off (see below)
+#endif
+    float ua[2][16];
+    UFrag16 uf;
+    float th_pre[2][2][4];
     bool poison = false;
     if constexpr (FUSED && GRAN) {
         // First hand-off, granule form: no drain, no token, no second round trip -- every thread polls the granule of its
@@ -1268,10 +1276,40 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         // (dq_s proper is written after the tile loop).
         int* const gflag_s = reinterpret_cast<int*>(dq_s + 4);
         if (tid == 0) gflag_s[0] = 0;                  // published by the barriers inside kb1_phase
+        // (round 3) the windows and the U slice go to LDS BEFORE K_b1 (their loads were the first ones issued: they have
+        // landed by the time K_b1's own operands are touched; K_b1's barriers publish them) ...
+        if constexpr (EARLY) {
+            stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
+            stage_u_finish(ureg, u_s, tid);
+        }
         kb1_phase<M16, true>(p, smem + p.kb1_smem_off, ds, b, ts_on);
+        // ... so that the part of the tile loop that does NOT depend on K_b1 -- location product, + q + processed memory,
+        // tanh -- runs HERE, while the partners' granules are on their way (it replaces the pre-poll pause), instead of
+        // behind the hand-off: th of this lane's first two position tiles stays in registers.  Same operations on the same
+        // values in the same order: bit-identical.
+        if constexpr (!EARLY) {
+            for (int d_ = 0; d_ < p.fused_delay; ++d_) __builtin_amdgcn_s_sleep(1);
+        } else {
+            if (a.bf16) load_u_frag16(uf, u_s, l15, lg);
+            else load_u_frag(ua, u_s, 0, l15, lg);
+            const int nmt_e = (len_raw + 15) >> 4;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int mt = wv + rr * KB2_NW;
+                if (mt < nmt_e) {
+                    f32x4 acc0, acc1;
+                    if (a.bf16) loc_tile16(uf, win_s, TIP, mt * 16 + l15, lg, acc0, acc1);
+                    else loc_tile(ua, win_s, TIP, mt * 16 + l15, lg, acc0, acc1);
+                    const float pmv[2][4] = {{pmA[rr].x, pmA[rr].y, pmA[rr].z, pmA[rr].w}, {pmB[rr].x, pmB[rr].y, pmB[rr].z, pmB[rr].w}};
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) th_pre[rr][dt][r] = t2_tanh((dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r]);
+                }
+            }
+        }
         const at_u64* grow = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + (long long)b * (Ti + NTS);   // (uniform)
         const int gi = tid < Ti + NTS ? tid : Ti + NTS - 1;          // Ti + NTS <= 512 (host check)
-        for (int d_ = 0; d_ < p.fused_delay; ++d_) __builtin_amdgcn_s_sleep(1);
         at_u64 xd = __hip_atomic_load(grow + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         {
             // bounded like every spin here: 50 ms of the 100 MHz wall clock, then NaN instead of a hung GPU
@@ -1344,15 +1382,17 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             de_s[ti] = (ti < len) ? wrow[ti] * (dwv - sdot) : 0.f;
         }
     }
-    stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
-    stage_u_finish(ureg, u_s, tid);
+    if constexpr (!EARLY) {
+        stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
+        stage_u_finish(ureg, u_s, tid);
+    }
     __syncthreads();
     T2_TS(49);
     T2_STAGE_RETURN(1);
-    float ua[2][16];
-    UFrag16 uf;
-    if (a.bf16) load_u_frag16(uf, u_s, l15, lg);
-    else load_u_frag(ua, u_s, 0, l15, lg);
+    if constexpr (!EARLY) {
+        if (a.bf16) load_u_frag16(uf, u_s, l15, lg);
+        else load_u_frag(ua, u_s, 0, l15, lg);
+    }
     // U^T as the A operand of dcol^T = U^T dpre: A[i = tap][k = lg], k-step (dt, r) <-> dim dt*16 + 4*lg + r
     float ut[4][2][4];
 #pragma unroll
@@ -1393,9 +1433,12 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 o1 = *reinterpret_cast<float4*>(dpmb + (long long)pos * AD + 16);
             }
         }
-        f32x4 acc0, acc1;
-        if (a.bf16) loc_tile16(uf, win_s, TIP, pos, lg, acc0, acc1);
-        else loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
+        const bool pre = EARLY && round < 2;          // th of this tile was formed ahead of the hand-off
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (!pre) {
+            if (a.bf16) loc_tile16(uf, win_s, TIP, pos, lg, acc0, acc1);
+            else loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
+        }
         const float de = de_s[pos];
         float dp[2][4];
         const float pmv[2][4] = {{pm0.x, pm0.y, pm0.z, pm0.w}, {pm1.x, pm1.y, pm1.z, pm1.w}};
@@ -1403,8 +1446,9 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float x = (dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r];
-                const float th = t2_tanh(x);
+                float th;
+                if (pre) th = round == 0 ? th_pre[0][dt][r] : th_pre[1][dt][r];
+                else th = t2_tanh((dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r]);
                 const float g = de * vv[dt][r] * (1.f - th * th);
                 dva[dt][r] = fmaf(de, th, dva[dt][r]);
                 dqa[dt][r] += g;
