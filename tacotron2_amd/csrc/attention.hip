@@ -247,7 +247,7 @@ static int attn_dbg_stage() {
 // phase.  GRAN: the partial energies leave as 8-byte {launch token, f32} granules, [B][Ti][4 slices], instead of floats.
 // `after_prologue` runs once every prologue load has been issued and h has been staged (i.e. landed): what it issues
 // flies behind the q phase and the tiles without holding up anything of this phase (loads complete in order).
-template <bool GRAN, class Hook>
+template <bool GRAN, bool EARLYP, class Hook>
 __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, const int ds, const int b, bool& ts_on,
                                          Hook&& after_prologue) {
     const t2amd_attn_fwd& a = p.a;
@@ -285,6 +285,16 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
     // q[d] = W_q[d][:] . h for the slice's 32 dims: 16 threads per row, 256 contiguous bytes per group and
     // instruction.  h goes through LDS (one float4 per thread), so a thread keeps only its 16 W_q float4 in flight
     // and the whole 1024-wide row is one round trip.
+#ifdef T2AMD_ATTN_FWD_LATE                     // A/B builds only: the round-2 order
+    constexpr bool EARLY = false;
+#else
+    constexpr bool EARLY = GRAN && EARLYP;     // one-launch form of the bf16 mode: location product ahead of the q product (see
+                                               // below; the fp32-mode instantiation has no registers left for it: 25 spills)
+#endif
+    const bool split16 = a.loc_split_bf16 != 0;
+    float ua[2][16];
+    UFrag16 uf;
+    f32x4 loc0[2], loc1[2];
     float qacc = 0.f;
     {
         const int d = tid >> 4, part = tid & 15;
@@ -319,7 +329,28 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
             for (int j = tid + KE_NT; j < n4; j += KE_NT) h_s4[j] = h4[j];
         }
         after_prologue();
+        if constexpr (EARLY) {
+            // (round 3) the windows and the U slice go to LDS ahead of the q product -- their loads were issued before
+            // the W_q stream, so they have landed -- and the location product of this lane's first two position tiles,
+            // which needs nothing else, runs while the W_q rows are still on their way (same MFMAs on the same operands
+            // as in the tile loop below: bit-identical)
+            stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
+            stage_u_finish(ureg, u_s, tid);
+        }
         __syncthreads();
+        if constexpr (EARLY) {
+            if (split16) load_u_frag16(uf, u_s, l15, lg);
+            else load_u_frag(ua, u_s, 0, l15, lg);
+            const int nmt_e = (len_raw + 15) >> 4;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int mt = wv + rr * (KE_NT / 64);
+                if (mt < nmt_e) {
+                    if (split16) loc_tile16(uf, win_s, TIP, mt * 16 + l15, lg, loc0[rr], loc1[rr]);
+                    else loc_tile(ua, win_s, TIP, mt * 16 + l15, lg, loc0[rr], loc1[rr]);
+                }
+            }
+        }
         if (wq16) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -348,8 +379,10 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
             qacc = fmaf(ww.w, x.w, qacc);
         }
     }
-    stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
-    stage_u_finish(ureg, u_s, tid);
+    if constexpr (!EARLY) {
+        stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
+        stage_u_finish(ureg, u_s, tid);
+    }
     {
         const int d = tid >> 4, part = tid & 15;
         qacc = row16_sum(qacc);
@@ -363,11 +396,10 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
     __syncthreads();
     T2_TS(1);
     T2_STAGE_RETURN(1);
-    const bool split16 = a.loc_split_bf16 != 0;
-    float ua[2][16];
-    UFrag16 uf;
-    if (split16) load_u_frag16(uf, u_s, l15, lg);
-    else load_u_frag(ua, u_s, 0, l15, lg);
+    if constexpr (!EARLY) {
+        if (split16) load_u_frag16(uf, u_s, l15, lg);
+        else load_u_frag(ua, u_s, 0, l15, lg);
+    }
     float qv[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -390,7 +422,10 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
             }
         }
         f32x4 acc0, acc1;
-        if (split16) loc_tile16(uf, win_s, TIP, pos, lg, acc0, acc1);
+        if (EARLY && round < 2) {
+            acc0 = round == 0 ? loc0[0] : loc0[1];
+            acc1 = round == 0 ? loc1[0] : loc1[1];
+        } else if (split16) loc_tile16(uf, win_s, TIP, pos, lg, acc0, acc1);
         else loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
         float e = vv[0][0] * t2_tanh(acc0[0] + qv[0][0] + pm0.x);
         e = fmaf(vv[0][1], t2_tanh(acc0[1] + qv[0][1] + pm0.y), e);
@@ -415,7 +450,7 @@ __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     if (p.a.active && !p.a.active[blockIdx.y]) return;
-    ke_phase<false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {});
+    ke_phase<false, false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -816,7 +851,7 @@ __global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams 
     const int tid = threadIdx.x;
     KcPre<M16> r;
     float e_first[4] = {0.f, 0.f, 0.f, 0.f};
-    ke_phase<true>(p, smem, sl, b, ts_on, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
+    ke_phase<true, M16>(p, smem, sl, b, ts_on, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
     T2_TS(16);
     {
         // thread ti < len polls the four granules of position ti (32 contiguous bytes).  Bounded like every spin here:
