@@ -16,8 +16,9 @@ Differences from the torch pair, all deliberate:
   * ``step()`` without ``clip_norm`` is a plain Adam step; ``clip_norm`` returns the pre-clip global
     norm as a 0-d device tensor, like ``clip_grad_norm_``;
   * with ``clip_norm``, a non-finite global norm skips the update ON THE DEVICE (weights and moments untouched,
-    no host synchronisation); the caller that later reads the norm calls ``undo_step_count()`` so the bias
-    correction does not count the skipped step.
+    no host synchronisation); the step counts (bias correction) are corrected by the next ``step()`` -- which reads the
+    norm from an asynchronous pinned copy -- or by ``undo_step_count()`` if the caller read the norm first; either way only
+    the counters of the parameters that step covered are touched.
 Unsupported options raise (amsgrad, maximize, capturable, differentiable, decoupled weight decay,
 sparse or non-f32 gradients): there is no silent fallback to torch's implementation.
 """
@@ -33,6 +34,9 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False)
         self._ws = None
         self._norm = None
+        self._norm_host = None        # pinned copy of the last step's [norm, coef]: read without a synchronisation
+        self._norm_event = None
+        self._pending = None          # step counters the last clipped step incremented, until its norm is known
 
     def _check_group(self, group):
         for flag in ('amsgrad', 'maximize', 'capturable', 'differentiable', 'decoupled_weight_decay'):
@@ -45,6 +49,7 @@ class FusedAdam(torch.optim.Adam):
     def step(self, closure=None, clip_norm=None):
         if closure is not None:
             raise nv.NativeError("FusedAdam: closures are not supported")
+        self._settle_previous()
         work = []                                            # (group, params, grads, exp_avgs, exp_avg_sqs, steps)
         for group in self.param_groups:
             self._check_group(group)
@@ -84,6 +89,13 @@ class FusedAdam(torch.optim.Adam):
             self._norm = torch.empty(2, dtype=torch.float32, device=dev)
             nv.grad_norm(L, blocks, float(clip_norm), self._ws, self._norm)
             norm = self._norm
+            # the host learns whether this step was skipped WITHOUT waiting for it: an asynchronous copy to pinned memory
+            # and an event, looked at by the next step() (or by undo_step_count(), whichever comes first)
+            if self._norm_host is None:
+                self._norm_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+                self._norm_event = torch.cuda.Event()
+            self._norm_host.copy_(self._norm, non_blocking=True)
+            self._norm_event.record()
 
         for group, ps, gs, ms, vs, steps in work:
             beta1, beta2 = group['betas']
@@ -105,15 +117,34 @@ class FusedAdam(torch.optim.Adam):
                 nv.adam_step(L, h, norm)
             for s in steps:
                 s += 1.0
+        if norm is not None:
+            self._pending = dict(steps=[s for w in work for s in w[5]], undone=False)
         # the kernels update the weights through raw pointers: torch's version counters do not see it
         from . import engine
         engine.bump_weight_generation()
         return norm[0] if norm is not None else None
 
+    def _undo(self):
+        if self._pending is not None and not self._pending['undone']:
+            for s in self._pending['steps']:             # exactly the counters that step incremented, no others
+                s -= 1.0
+            self._pending['undone'] = True
+
+    def _settle_previous(self):
+        """A clipped step whose global norm turned out non-finite was skipped on the device: take it out of the step counts
+        (bias correction) of exactly the parameters it covered.  Its norm was copied to pinned memory when it ran; by the
+        time the next step is enqueued that copy has landed (a whole forward / backward lies between), so this does not
+        stall the host -- the wait below only ever triggers for back-to-back steps."""
+        if self._pending is None or self._pending['undone']:
+            return
+        if not self._norm_event.query():
+            self._norm_event.synchronize()
+        if not math.isfinite(float(self._norm_host[0])):
+            self._undo()
+        self._pending = None
+
     def undo_step_count(self):
-        """The last ``step(clip_norm=...)`` was skipped on the device (non-finite norm): take it out of the counts."""
-        for group in self.param_groups:
-            for p in group['params']:
-                st = self.state.get(p)
-                if st and 'step' in st and float(st['step']) > 0:
-                    st['step'] -= 1.0
+        """The last ``step(clip_norm=...)`` was skipped on the device (non-finite norm): take it out of the counts.  Kept for
+        callers that read the norm themselves (tacotron2_amd.train); since round 3 the next ``step()`` does this on its own,
+        and only the counters of the parameters that step covered are touched."""
+        self._undo()

@@ -88,3 +88,49 @@ def test_train_driver_with_fused_optimizer(native_lib, tmp_path):
     assert len(ck["optimizer"]["state"]) == 60
     plain = torch.optim.Adam(tr.load_model(create_hparams(hpstr)).parameters())
     plain.load_state_dict(ck["optimizer"])                       # the reference's optimiser reads the checkpoint
+
+
+def test_fused_adam_skipped_step_fixes_its_own_step_counts(native_lib):
+    """a step whose global norm is not finite is skipped on the device; the bias-correction step counts must
+    not count it -- without the caller doing anything, and only for the parameters that step covered."""
+    import math
+    from tacotron2_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(300, device="cuda"))
+    b = torch.nn.Parameter(torch.randn(77, 5, device="cuda"))
+    c = torch.nn.Parameter(torch.randn(9, device="cuda"))            # never gets a gradient in the skipped step
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in (a, b, c)]
+    opt = FusedAdam([a, b, c], lr=1e-2, weight_decay=1e-6)
+    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-6)
+
+    def grads(ps, seed, with_c=True, poison=False):
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        for i, p in enumerate(ps):
+            p.grad = None if (i == 2 and not with_c) else torch.randn(p.shape, device="cuda", generator=g)
+        if poison:
+            ps[0].grad[3] = float("nan")
+
+    # step 1: all three parameters, finite
+    grads([a, b, c], 1); grads(ref, 1)
+    opt.step(clip_norm=1.0)
+    torch.nn.utils.clip_grad_norm_(ref, 1.0); ropt.step()
+    # step 2: NaN gradient, c has no gradient -> skipped on the device; the reference loop skips it by hand
+    before = [p.detach().clone() for p in (a, b, c)]
+    grads([a, b, c], 2, with_c=False, poison=True)
+    n = opt.step(clip_norm=1.0)
+    assert not math.isfinite(float(n))
+    for p, q in zip((a, b, c), before):
+        assert torch.equal(p.detach(), q)                             # weights untouched
+    # step 3: finite again; nobody called undo_step_count()
+    grads([a, b, c], 3); grads(ref, 3)
+    opt.step(clip_norm=1.0)
+    torch.nn.utils.clip_grad_norm_(ref, 1.0); ropt.step()
+    torch.cuda.synchronize()
+    assert [float(opt.state[p]['step']) for p in (a, b, c)] == [2.0, 2.0, 2.0]
+    for p, q in zip((a, b, c), ref):
+        assert (p.detach() - q.detach()).abs().max().item() < 3e-6
+    # the explicit call still works and is idempotent for one step
+    grads([a, b, c], 4, poison=True)
+    opt.step(clip_norm=1.0)
+    opt.undo_step_count(); opt.undo_step_count()
+    assert [float(opt.state[p]['step']) for p in (a, b, c)] == [2.0, 2.0, 2.0]
