@@ -91,11 +91,14 @@ class FusedAdam(torch.optim.Adam):
             norm = self._norm
             # the host learns whether this step was skipped WITHOUT waiting for it: an asynchronous copy to pinned memory
             # and an event, looked at by the next step() (or by undo_step_count(), whichever comes first)
-            if self._norm_host is None:
-                self._norm_host = torch.zeros(2, dtype=torch.float32).pin_memory()
-                self._norm_event = torch.cuda.Event()
-            self._norm_host.copy_(self._norm, non_blocking=True)
-            self._norm_event.record()
+            if dev.type == 'cuda':
+                if self._norm_host is None:
+                    self._norm_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+                    self._norm_event = torch.cuda.Event()
+                self._norm_host.copy_(self._norm, non_blocking=True)
+                self._norm_event.record()
+            else:                                 # host tensors (the CPU emulation of the kernels in tests/): nothing to wait for
+                self._norm_host, self._norm_event = self._norm, None
 
         for group, ps, gs, ms, vs, steps in work:
             beta1, beta2 = group['betas']
@@ -137,7 +140,7 @@ class FusedAdam(torch.optim.Adam):
         stall the host -- the wait below only ever triggers for back-to-back steps."""
         if self._pending is None or self._pending['undone']:
             return
-        if not self._norm_event.query():
+        if self._norm_event is not None and not self._norm_event.query():
             self._norm_event.synchronize()
         if not math.isfinite(float(self._norm_host[0])):
             self._undo()
