@@ -98,7 +98,7 @@ def build(force=False, verbose=True, stamps=False):
         _link(_compile_objects(OBJ_DIR + "_stamps", ["-DT2AMD_PHASE_STAMPS"], verbose), STAMPS_OUT, verbose)
         return STAMPS_OUT
     if not force and up_to_date():
-        build_torch_ops(verbose=verbose)
+        _torch_ops_best_effort(False, verbose)
         return OUT
     if not force and os.path.exists(OUT) and not os.path.exists(HIPCC):
         # a box without the toolchain: the library shipped with the snapshot is the only one there can be
@@ -109,8 +109,20 @@ def build(force=False, verbose=True, stamps=False):
         for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):
             os.remove(o)
     _link(_compile_objects(OBJ_DIR, [], verbose), OUT, verbose)
-    build_torch_ops(force=force, verbose=verbose)
+    _torch_ops_best_effort(force, verbose)
     return OUT
+
+
+def _torch_ops_best_effort(force, verbose):
+    """The dispatcher registration is an ADDITIONAL route to the same C ABI: a box that cannot compile it (no g++, other
+    torch headers) still has the whole engine through ctypes -- say so, do not fail the build."""
+    try:
+        build_torch_ops(force=force, verbose=verbose)
+    except Exception as e:                                   # noqa: BLE001
+        print("tacotron2_amd.build: TORCH_LIBRARY registration not built (%s: %s); the engine uses the ctypes route"
+              % (type(e).__name__, e), file=sys.stderr)
+        if os.path.exists(TORCH_OPS_OUT) and os.path.getmtime(TORCH_OPS_OUT) < os.path.getmtime(OUT):
+            os.remove(TORCH_OPS_OUT)                         # never pair a stale registration with a newer library
 
 
 def build_variant(tag, defines, verbose=True):
