@@ -36,6 +36,7 @@ import torch
 import torch.distributed as dist
 
 BUCKET_ORDER = ('postnet', 'decoder', 'encoder')      # order in which the engine finishes them
+_TRACE = __import__('os').environ.get('T2AMD_DP_TRACE', '0') == '1'      # rank 0 prints the host time of every bucket exchange
 
 
 def bucket_of(param_name):
@@ -164,9 +165,17 @@ class GradSync(object):
                 if g.data_ptr() != view.data_ptr():
                     view.copy_(g)
                     grads[name] = view
+        trace = _TRACE and dist.get_rank(self.group) == 0
+        if trace:
+            import time
+            t0 = time.perf_counter()
         work = dist.all_reduce(flat, op=self.op, group=self.group, async_op=True)
         if self.serial:
             work.wait()
+        if trace:
+            print("GradSync: bucket %s (%.1f MB) all_reduce%s returned after %.1f ms" % (
+                bucket, flat.numel() * flat.element_size() / 1e6, " + wait" if self.serial else "", 1e3 * (time.perf_counter() - t0)),
+                file=__import__('sys').stderr, flush=True)
         self.pending.append((flat, work))
 
     def finish(self):
@@ -249,6 +258,23 @@ class HookSync(object):
             b['work'], b['arrived'] = None, 0
 
 
+def ranks_sharing_a_device(module, group=None):
+    """How many ranks of the group sit on the same physical GPU as this one (1 = the product configuration, one rank per
+    GPU).  Compared by (host name, device UUID or visible-devices string + index)."""
+    p = next((q for q in module.parameters() if q.is_cuda), None)
+    if p is None:
+        return 1
+    import os
+    import socket
+    props = torch.cuda.get_device_properties(p.device)
+    ident = getattr(props, 'uuid', None)
+    ident = str(ident) if ident is not None else "%s:%d" % (os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', '')), p.device.index)
+    me = (socket.gethostname(), ident)
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, me, group=group)
+    return sum(1 for e in everyone if e == me)
+
+
 def apply_gradient_allreduce(module):
     """Make ``module`` data-parallel in place and return it (reference distributed.py:126-173).  Idempotent: the
     reference wraps the model twice (train.py:79 and :179) -- a second call re-broadcasts rank 0's state and returns the
@@ -264,6 +290,21 @@ def apply_gradient_allreduce(module):
     if isinstance(module, Tacotron2):
         # engine-driven: the autograd Function calls bucket_ready()/finish() itself
         module._grad_sync = GradSync(list(module.named_parameters()))
+        sharing = ranks_sharing_a_device(module)
+        if sharing > 1:
+            # Several PROCESSES on one GPU (a functional check on a single-GPU box; never the product layout): their
+            # kernels are time-sliced by the hardware scheduler, and a kernel that spins on an in-launch hand-off holds its
+            # CUs until it is pre-empted -- measured 11.4 s per training step with the one-launch attention forms against
+            # 0.18 s with the separate launches (profiles/r03_o_*).  Select the separate-launch forms: same bits.
+            from . import native as nv
+            if not nv.validate_only():
+                nv.set_attn_fwd_fused(0)
+                nv.set_attn_bwd_fused(0)
+                nv.set_bptt_cell_fold(0)
+            if dist.get_rank() == 0:
+                import sys
+                print("tacotron2_amd: %d ranks share one GPU: the separate-launch forms of the attention step are selected "
+                      "(in-launch hand-offs and time-sliced processes do not mix)" % sharing, file=sys.stderr, flush=True)
     else:
         module._hook_sync = HookSync(module)
     module._t2amd_dp_applied = True

@@ -495,15 +495,19 @@ def _guard_weights(model, run, P):
     if not params or len(params) > nv.MAX_TENSORS:
         return
     key = (_PACK_GEN[0], str(run.dev)) + tuple((p.data_ptr(), p._version) for p in params)
+    ptrs = tuple(p.data_ptr() for p in params)
     g = cache.get('__guard__')
     fresh = g is None or g['key'] != key
-    if fresh:
+    if g is None or g['ptrs'] != ptrs:
+        # buffers and the tensor list are made once per set of parameter storages (not per step: no allocation, no
+        # pinned-memory call in the training loop)
         L, blocks = nv.tensor_list(params)
-        g = dict(key=key, L=L, blocks=blocks, keep=params,
+        g = dict(key=key, ptrs=ptrs, L=L, blocks=blocks, keep=params,
                  ws=torch.empty(blocks, dtype=torch.float64, device=run.dev),
                  dev=torch.empty(2, 2, dtype=torch.float32, device=run.dev),
                  host=torch.zeros(2, 2, dtype=torch.float32).pin_memory())
         cache['__guard__'] = g
+    g['key'] = key
     slot = 0 if fresh else 1                       # 0: signature recorded with the images, 1: signature of this call
     nv.grad_norm(g['L'], g['blocks'], 0.0, g['ws'], g['dev'][slot])
     g['host'][slot].copy_(g['dev'][slot], non_blocking=True)
