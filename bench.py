@@ -373,7 +373,16 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed_frames = sum(frames[args.warmup:])
+    per_rank = None
     if world > 1:
+        # SURVEY 8e "efficiency risks": ranks draw different batches, so their padded horizons (To_max) and step times
+        # differ and the slowest rank sets the pace at every exchange; reported per rank next to the MAX the value uses
+        mine = torch.tensor([elapsed, float(timed_frames), float(sum(b[2].shape[2] for b in batches[args.warmup:]))],
+                            dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = {"seconds": [float(e[0]) for e in every], "valid_frames": [float(e[1]) for e in every],
+                    "padded_time_steps": [float(e[2]) for e in every]}
         t = torch.tensor([elapsed, float(timed_frames)], dtype=torch.float64, device=dev)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -564,6 +573,9 @@ def main():
         }
         out["padded_frames_per_s"] = sum(b[2].shape[2] * args.batch_size for b in batches[args.warmup:]) \
             * args.gpus / elapsed if world == 1 else None
+        if per_rank:
+            out["ranks"] = per_rank
+            out["padded_frames_per_s"] = args.batch_size * sum(per_rank["padded_time_steps"]) / elapsed
         if roofline:
             out["roofline"] = roofline
         if fp32_leg:
