@@ -133,8 +133,8 @@ typedef struct t2amd_gemm16_desc {
 } t2amd_gemm16_desc;
 int t2amd_gemm16_tn(const t2amd_gemm16_desc* d, void* stream);
 
-/* dst[(b (T + 2 pad) + pad + t)][c] (bf16) = src[(b T + t)][c]; dst ([B (T + 2 pad) + 2 pad][C], zeroed by the caller: halo rows
- * are not written) is the image the window mode reads. */
+/* dst[(b (T + 2 pad) + pad + t)][c] (bf16) = src[(b T + t)][c]; dst ([B (T + 2 pad) + 2 pad][C]; every row is written, the halo
+ * rows with zeros: it need not be initialised) is the image the window mode reads. */
 int t2amd_cast_halo_bf16(const float* src, long long lds, void* dst, long long rows, int C, int T, int pad, void* stream);
 
 /* dst[c][r] (bf16, row stride ldd >= rows_padded; columns rows..rows_padded-1 zeroed) = src[r][c]; src is f32

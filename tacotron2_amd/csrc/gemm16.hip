@@ -301,30 +301,35 @@ __global__ __launch_bounds__(256) void transpose_cast16_kernel(const void* __res
 }
 
 // dst[(b Tp + pad + t)][c] (bf16) = src[(b T + t)][c] (f32): the channel-last image with `pad` zero rows around every utterance
-// that the window mode above reads; dst must have been zeroed once (the halo rows are never written).
+// that the window mode above reads.  The kernel walks the IMAGE rows -- all (rows / T) * Tp of them plus the 2 * pad rows
+// the last utterance's windows reach into -- and writes the zero halos itself (round 3: the image no longer has to be
+// zero-filled first, one pass instead of two over it).
 __global__ __launch_bounds__(256) void cast_halo16_kernel(const float* __restrict__ src, long long lds_, unsigned short* __restrict__ dst,
-                                                          long long rows, int C4, int T, int Tp, int pad) {
+                                                          long long img_rows, long long nb, int C4, int T, int Tp, int pad) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * C4) return;
-    const long long r = i / C4;
-    const int c4 = (int)(i - r * C4);
-    const long long b = r / T;
-    const int t = (int)(r - b * T);
-    const float4 v = *reinterpret_cast<const float4*>(src + r * lds_ + c4 * 4);
-    uint2 o;
-    o.x = (unsigned)t2_f32_to_bf16(v.x) | ((unsigned)t2_f32_to_bf16(v.y) << 16);
-    o.y = (unsigned)t2_f32_to_bf16(v.z) | ((unsigned)t2_f32_to_bf16(v.w) << 16);
-    *reinterpret_cast<uint2*>(dst + ((b * Tp + pad + t) * (long long)(C4 * 4)) + c4 * 4) = o;
+    if (i >= img_rows * C4) return;
+    const long long R = i / C4;
+    const int c4 = (int)(i - R * C4);
+    const long long b = R / Tp;
+    const int t = (int)(R - b * Tp) - pad;
+    uint2 o = make_uint2(0u, 0u);
+    if (b < nb && t >= 0 && t < T) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (b * T + t) * lds_ + c4 * 4);
+        o.x = (unsigned)t2_f32_to_bf16(v.x) | ((unsigned)t2_f32_to_bf16(v.y) << 16);
+        o.y = (unsigned)t2_f32_to_bf16(v.z) | ((unsigned)t2_f32_to_bf16(v.w) << 16);
+    }
+    *reinterpret_cast<uint2*>(dst + (R * (long long)(C4 * 4)) + c4 * 4) = o;
 }
 
 extern "C" int t2amd_cast_halo_bf16(const float* src, long long lds_, void* dst, long long rows, int C, int T, int pad, void* stream) {
     T2_REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && T > 0 && rows % T == 0 && pad >= 0 && lds_ % 4 == 0 &&
                    t2_aligned16(src) && t2_aligned16(dst),
                "cast_halo: rows must be whole utterances of T, C a multiple of 4, 16-byte aligned operands");
-    const long long n = rows * (C / 4);
+    const long long nb = rows / T, img_rows = nb * (T + 2 * pad) + 2 * pad;     // dst holds img_rows rows of C bf16
+    const long long n = img_rows * (C / 4);
     T2_REQUIRE((n + 255) / 256 < (1ll << 31), "cast_halo: too large");
-    T2_LAUNCH(cast_halo16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, lds_, (unsigned short*)dst, rows,
-              C / 4, T, T + 2 * pad, pad);
+    T2_LAUNCH(cast_halo16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, lds_, (unsigned short*)dst,
+              img_rows, nb, C / 4, T, T + 2 * pad, pad);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -345,8 +345,8 @@ def _conv16_ok(run, rows, T, C):
 def _halo_image(run, x, T, pad):
     """bf16 image of the channel-last rows x (rows = B T) with `pad` zero rows around every utterance."""
     rows, C = x.shape
-    img = torch.zeros((rows // T) * (T + 2 * pad) + 2 * pad, C, dtype=torch.bfloat16, device=x.device)
-    nv.cast_halo_bf16(x, img, T, pad)
+    img = torch.empty((rows // T) * (T + 2 * pad) + 2 * pad, C, dtype=torch.bfloat16, device=x.device)
+    nv.cast_halo_bf16(x, img, T, pad)             # writes every row of the image, halos included
     return img
 
 def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training, lens=None):

@@ -663,7 +663,8 @@ def conv16(Cm, img16, W16, B, T, pad, bias=None, accumulate=False):
 
 
 def cast_halo_bf16(src, dst, T, pad):
-    """dst[(b (T + 2 pad) + pad + t), c] (bf16) = src[(b T + t), c]; dst must be zeroed (halo rows are not written)."""
+    """dst[(b (T + 2 pad) + pad + t), c] (bf16) = src[(b T + t), c]; every row of the image -- (rows / T) (T + 2 pad) + 2 pad of
+    them -- is written, the halo rows with zeros (dst need not be initialised)."""
     ps, lds, rows, Cc = _mat(src)
     if dst.dtype != torch.bfloat16 or dst.shape[1] != Cc or dst.shape[0] < (rows // T) * (T + 2 * pad) + 2 * pad:
         raise NativeError("cast_halo_bf16: shape mismatch src=%s dst=%s" % (tuple(src.shape), tuple(dst.shape)))

@@ -893,8 +893,12 @@ def test_conv16_window_product_matches_conv1d(nv, B, T, Ci, Co, k):
     bias = rnd(Co, seed=322)
     xb, Wb = x.bfloat16().float(), W.bfloat16().float()
     ref = F.conv1d(xb.view(B, T, Ci).transpose(1, 2), Wb, bias, padding=pad).transpose(1, 2).reshape(B * T, Co)
-    img = torch.zeros(B * (T + 2 * pad) + 2 * pad, Ci, dtype=torch.bfloat16, device=DEV)
-    nv.cast_halo_bf16(dv(x), img, T, pad)
+    img = torch.full((B * (T + 2 * pad) + 2 * pad, Ci), float('nan'), dtype=torch.bfloat16, device=DEV)   # poisoned: the kernel
+    nv.cast_halo_bf16(dv(x), img, T, pad)                                                                # writes the halos itself
+    halo = torch.ones(B * (T + 2 * pad) + 2 * pad, dtype=torch.bool)
+    for b_ in range(B):
+        halo[b_ * (T + 2 * pad) + pad:b_ * (T + 2 * pad) + pad + T] = False
+    assert torch.all(img.cpu()[halo] == 0) and torch.isfinite(img.float()).all()
     Wp16 = W.permute(0, 2, 1).reshape(Co, k * Ci).contiguous().bfloat16().to(DEV)          # [co][tap Ci + ci]
     y = torch.full((B * T, Co), float('nan'), device=DEV)
     nv.conv16(y, img, Wp16, B, T, pad, bias=dv(bias))
@@ -907,7 +911,7 @@ def test_conv16_window_product_matches_conv1d(nv, B, T, Ci, Co, k):
     gb = g.bfloat16().float()
     dref = F.conv_transpose1d(gb.view(B, T, Co).transpose(1, 2), Wb, padding=pad).transpose(1, 2).reshape(B * T, Ci)
     if Co % 64 == 0:
-        gimg = torch.zeros(B * (T + 2 * pad) + 2 * pad, Co, dtype=torch.bfloat16, device=DEV)
+        gimg = torch.full((B * (T + 2 * pad) + 2 * pad, Co), float('nan'), dtype=torch.bfloat16, device=DEV)
         nv.cast_halo_bf16(dv(g), gimg, T, pad)
         Wd16 = W.flip(2).permute(1, 2, 0).reshape(Ci, k * Co).contiguous().bfloat16().to(DEV)
         dx = torch.full((B * T, Ci), float('nan'), device=DEV)
