@@ -580,6 +580,11 @@ def main():
             out["roofline"] = roofline
         if fp32_leg:
             out["fp32_mode"] = fp32_leg
+        out["parity_note"] = ("north star 'mel L1 vs reference < 1e-4, gate-stop indices bit-exact' is met by the fp32 mode "
+                              "(fp32_mode.value; B=64/To=870 against the oracle: mel mean |diff| 5.0e-8, loss equal, "
+                              "256/256 stops at B=256); this line's bf16 mode (BASELINE configs[1] names bf16) measures "
+                              "decoder mel 2.5e-4, postnet mel 5.9e-3, gradient cosine 0.99998 on the same batch "
+                              "(tests/test_zz5_fullsize_parity_gpu.py, profiles/r03_parity_fullsize_train_B64_*.json)")
         if optimizer_ab:
             out["optimizer_ab"] = optimizer_ab
         if args.gpus == 1 and args.cpu_sample > 0:
