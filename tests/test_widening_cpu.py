@@ -384,3 +384,28 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=env, timeout=300)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
+def test_bench_stdout_line_is_compact_and_complete():
+    """bench.py prints ONE line that must carry every key of the driver's contract plus `roofline` / `cpu_baseline`, and stay
+    well inside what a bounded tail of stdout keeps (the verbose record goes to gpurun_out/bench_full.json)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, "profiles", "r03_r_bench_full.json")) as f:
+        full = json.load(f)
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < 5000, len(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    r = line["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert set(r["chain"]) == {"lstm_pair", "attention_forward", "attention_backward", "dgrad_pair"}
+    assert r["kernel"] == max(r["chain"].values(), key=lambda v: v["avg_launch_us"] * v["launches"])["kernel"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert "workload" in line["config"] and "model" not in line["config"]
