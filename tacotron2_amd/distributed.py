@@ -260,16 +260,17 @@ class HookSync(object):
 
 def ranks_sharing_a_device(module, group=None):
     """How many ranks of the group sit on the same physical GPU as this one (1 = the product configuration, one rank per
-    GPU).  Compared by (host name, device UUID or visible-devices string + index)."""
+    GPU).  Compared by (host name, device UUID, visible-devices strings, device index)."""
     p = next((q for q in module.parameters() if q.is_cuda), None)
     if p is None:
         return 1
     import os
     import socket
     props = torch.cuda.get_device_properties(p.device)
-    ident = getattr(props, 'uuid', None)
-    ident = str(ident) if ident is not None else "%s:%d" % (os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', '')), p.device.index)
-    me = (socket.gethostname(), ident)
+    # UUID AND visible-devices string AND index: a runtime that reports the same (empty) UUID for every GPU must not make
+    # eight ranks on eight GPUs look like one shared device
+    vis = "|".join(os.environ.get(k, '') for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
+    me = (socket.gethostname(), str(getattr(props, 'uuid', '')), vis, p.device.index)
     everyone = [None] * dist.get_world_size(group)
     dist.all_gather_object(everyone, me, group=group)
     return sum(1 for e in everyone if e == me)
