@@ -107,6 +107,10 @@ int t2amd_gemm_f32(const t2amd_gemm_desc* d, void* stream);
  * is written to (co, ci, tap) (packed conv-weight grad -> torch Conv1d layout, Ci = perm_ci). */
 int t2amd_splitk_reduce_f32(const float* partials, int nsplit, long long stride, float* out,
                             long long n, int accumulate, int perm_taps, int perm_ci, void* stream);
+/* out[r][c] (row stride ldo >= cols) (+)= sum_s partials[s*stride + r*cols + c]: partials of a product that fills a column
+ * block of a wider matrix. */
+int t2amd_splitk_reduce2d_f32(const float* partials, int nsplit, long long stride, float* out, int rows, int cols,
+                              long long ldo, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * bf16-resident product (csrc/gemm16.hip): C[M][N] (f32) = A[M][K] . B[N][K]^T (+ bias[n]), A and B bf16 and
@@ -132,6 +136,16 @@ typedef struct t2amd_gemm16_desc {
     int win_T, win_Tp;
 } t2amd_gemm16_desc;
 int t2amd_gemm16_tn(const t2amd_gemm16_desc* d, void* stream);
+/* The same product with K-MAJOR operands: C[M][N] = sum_k A[k][m] . B[k][n], A = [K][lda], B = [K][ldb] bf16 with m / n
+ * contiguous -- the layout of the time loops' [To.B][.] slabs and of channel-last activation images, so the weight gradients
+ * dW = dG^T . X of nn.LSTMCell (reference model.py:352-371 under autograd) and nn.Conv1d (layers.py:37-39) need no
+ * transposed copies; fragments are formed by gfx950's transposing LDS read.  M, N multiples of 8; lda / ldb multiples of 8
+ * and possibly SMALLER than M / N (overlapping rows: B[k][n] = img[k Ci + n], n < taps Ci, is the sliding window of a
+ * convolution over a channel-last image); any K > 0; win_T = win_Tp = 0; bias / accumulate / splitk as above. */
+int t2amd_gemm16_kk(const t2amd_gemm16_desc* d, void* stream);
+/* Up to four such products in ONE launch (same M, same splitk; each with its own A offset / K / B / C): their workgroups run
+ * side by side on the same rows of A, which is then read once -- the input blocks [x | ctx | h] of an LSTM's weight gradient. */
+int t2amd_gemm16_kk_group(const t2amd_gemm16_desc* d, int count, void* stream);
 
 /* dst[(b (T + 2 pad) + pad + t)][c] (bf16) = src[(b T + t)][c]; dst ([B (T + 2 pad) + 2 pad][C]; every row is written, the halo
  * rows with zeros: it need not be initialised) is the image the window mode reads. */

@@ -463,6 +463,38 @@ extern "C" int t2amd_splitk_reduce_f32(const float* partials, int nsplit, long l
     return T2AMD_OK;
 }
 
+// out[r][c] (row stride ldo) (+)= sum_s partials[s][r cols + c]: the split-K partials of a product that fills a column
+// block of a wider matrix (one input block of [dW_ih | dW_hh]).
+__global__ void splitk_reduce2d_kernel(const float* __restrict__ part, int nsplit, long long stride, float* __restrict__ out,
+                                       long long n, int cols, long long ldo, int accumulate) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        int k = 0;
+        for (; k + 4 <= nsplit; k += 4) {
+            const float v0 = part[(long long)k * stride + i], v1 = part[(long long)(k + 1) * stride + i];
+            const float v2 = part[(long long)(k + 2) * stride + i], v3 = part[(long long)(k + 3) * stride + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; k < nsplit; ++k) s += part[(long long)k * stride + i];
+        const long long r = i / cols;
+        const long long o = r * ldo + (i - r * cols);
+        if (accumulate) s += out[o];
+        out[o] = s;
+    }
+}
+
+extern "C" int t2amd_splitk_reduce2d_f32(const float* partials, int nsplit, long long stride, float* out, int rows, int cols,
+                                         long long ldo, int accumulate, void* stream) {
+    T2_REQUIRE(partials && out && nsplit >= 1 && rows > 0 && cols > 0 && ldo >= cols, "splitk_reduce2d: bad args");
+    const long long n = (long long)rows * cols;
+    int blocks = t2_cdiv(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    T2_LAUNCH(splitk_reduce2d_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, partials, nsplit, stride, out, n, cols, ldo,
+              accumulate);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 // =========================================================================================
 // Split-bf16 GEMM ("bf16x3"): every f32 operand element x is split on its way into LDS into
 // hi = bf16(x) and lo = bf16(x - hi) (round-to-nearest-even, v_cvt_pk_bf16_f32), and the product

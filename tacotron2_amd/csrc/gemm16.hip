@@ -238,6 +238,256 @@ extern "C" int t2amd_gemm16_tn(const t2amd_gemm16_desc* dp, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------
+// K-MAJOR operands: C[M][N] (f32) = sum_k A[k][m] . B[k][n], A = [K][lda] and B = [K][ldb] bf16 with m / n contiguous -- the
+// layout every slab of the time loops and every channel-last activation image already has ([To.B][.], [(b, t)][channel]),
+// so the weight-gradient products dW = dG^T . X need no transposed copies (round 3; before, transpose_cast16_kernel made
+// K-contiguous images of both operands first: ~0.5 ms per training step of pure copying).
+//
+// Same tile (256 x 256 x 64, 8 waves 2 x 4, 32x32x16 MFMA, two LDS stages, LDS-DMA) as gemm16_tn_kernel; what differs is the
+// LDS image and the fragment read:
+//   * an operand tile is 64 k-rows x 512 B (256 m); a wave DMA instruction copies 2 k-rows;
+//   * fragments come from gfx950's transposing LDS read: ds_read_b64_tr_b16 -- each 16-lane group reads a [4 k][16 m] block
+//     (lane i: 8 bytes = m 4 (i & 3) .. +3 of row k + (i >> 2)) and lane i receives the four k values of column i.  Two of them
+//     (k + 0..3, k + 4..7) are the 8 bf16 of a v_mfma_f32_32x32x16_bf16 operand (lanes 0-31: k 0..7, lanes 32-63: k 8..15);
+//   * bank conflicts are removed on the DMA SOURCE: slot s (16 B) of row k holds global chunk s ^ (4 (k & 3)); the 32 lanes a
+//     transposing read services together (4 rows x 64 B) then cover all 16 slots of a 256-byte bank row;
+//   * rows may overlap (ldb < N): B[k][n] = img[k Ci + n], n < taps Ci, is the sliding window of a 1-d convolution over a
+//     channel-last bf16 image -- the weight gradient of nn.Conv1d is this product against the output gradient's image;
+//   * K need not be a multiple of 64: the rows of the last tile past K are read from row K - 1 (finite) and A's are zeroed
+//     in LDS by the wave that fetched them.
+// Replaces (bf16 mode): autograd's dW of the two decoder nn.LSTMCell (reference model.py:352-371) and of every nn.Conv1d of
+// encoder and postnet whose channel count is a multiple of 8 (model.py:141-146, 174-175; layers.py:37-39).
+// ---------------------------------------------------------------------------------------
+typedef float g16_f32x2 __attribute__((ext_vector_type(2)));
+
+// Up to four products share one launch (same M, same split count): the column tiles of problem j follow those of problem
+// j - 1 in the grid, so that the workgroups an XCD runs at once multiply the SAME rows of A against different B's -- the
+// three input blocks of an LSTM's weight gradient read dG once instead of three times (a 256-column block alone is bound
+// by streaming its 456 MB of dG, not by the MFMA).
+#define G16_GROUP 4
+struct Gemm16GroupParams {
+    t2amd_gemm16_desc d[G16_GROUP];
+    int coltile_end[G16_GROUP];      // running count of column tiles
+    int count;
+};
+
+__global__ __launch_bounds__(G16_NT) void gemm16_kk_kernel(Gemm16GroupParams p) {
+    // [A stage 0 | A stage 1 | B stage 0 | B stage 1], 32 KB each = 64 k-rows x 512 B
+    __shared__ __attribute__((aligned(16))) char smem[4 * G16_IMG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const G16Tile tile = g16_tile_id();
+    const int split = tile.bz;
+    int prob = 0;
+#pragma unroll
+    for (int j = 0; j + 1 < G16_GROUP; ++j)
+        if (j + 1 < p.count && tile.bx >= p.coltile_end[j]) prob = j + 1;
+    const int bx = tile.bx - (prob > 0 ? p.coltile_end[prob - 1] : 0);
+    // the problem's fields, read once (a reference into the kernel-argument array would reload them at every use)
+    struct { const void* A; const void* B; float* C; int M, N, K; long long lda, ldb, ldc; long long strideSplitC; int accumulate;
+             const float* bias; int splitk; } d;
+    d.A = p.d[prob].A; d.B = p.d[prob].B; d.C = p.d[prob].C; d.M = p.d[prob].M; d.N = p.d[prob].N; d.K = p.d[prob].K;
+    d.lda = p.d[prob].lda; d.ldb = p.d[prob].ldb; d.ldc = p.d[prob].ldc; d.strideSplitC = p.d[prob].strideSplitC;
+    d.accumulate = p.d[prob].accumulate; d.bias = p.d[prob].bias; d.splitk = p.d[prob].splitk;
+    const int row0 = tile.by * G16_T, col0 = bx * G16_T;
+    const int M = d.M, N = d.N;
+    const int nkt_all = (d.K + G16_BK - 1) / G16_BK;
+    const int per_split = (nkt_all + d.splitk - 1) / d.splitk;
+    const int kt_beg = split * per_split;
+    int kt_end = kt_beg + per_split;
+    if (kt_end > nkt_all) kt_end = nkt_all;
+    const int nk = kt_end > kt_beg ? kt_end - kt_beg : 0;
+    const int rem = d.K - (nkt_all - 1) * G16_BK;                       // rows of the last k tile (1..64)
+    const int ztile = (kt_end == nkt_all && rem < G16_BK) ? nk - 1 : -1; // this split's tile with rows past K, if any
+
+    // ---- DMA sources: instruction i of this wave fills rows 16 i + 2 wave + (lane >> 5), slot lane & 31 ----
+    const int rsub = 2 * wave + lhi;
+    const long long arow = d.lda * 2, brow = d.ldb * 2;                 // bytes per k-row
+    const char* asrc[4];
+    const char* bsrc[4];
+    {
+        const int cl = l31 ^ ((rsub & 3) << 2);                         // logical 16-byte chunk held by slot lane & 31
+        int ma = row0 + 8 * cl, nb = col0 + 8 * cl;
+        ma = ma + 8 <= M ? ma : M - 8;                                  // clamped columns: their products are never stored
+        nb = nb + 8 <= N ? nb : N - 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long k = (long long)kt_beg * G16_BK + 16 * i + rsub;
+            asrc[i] = reinterpret_cast<const char*>(d.A) + k * arow + (long long)ma * 2;
+            bsrc[i] = reinterpret_cast<const char*>(d.B) + k * brow + (long long)nb * 2;
+        }
+    }
+#define KK_ISSUE(STAGE, KT)                                                                                      \
+    {                                                                                                            \
+        char* ad_ = smem + (STAGE) * G16_IMG + wave * 1024;                                                      \
+        char* bd_ = smem + (2 + (STAGE)) * G16_IMG + wave * 1024;                                                \
+        if ((KT) != ztile) {                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+                __builtin_amdgcn_global_load_lds((g16_gptr)(asrc[i]), (g16_lptr)(ad_ + i * 8192), 16, 0, 0);     \
+                __builtin_amdgcn_global_load_lds((g16_gptr)(bsrc[i]), (g16_lptr)(bd_ + i * 8192), 16, 0, 0);     \
+                asrc[i] += 64 * arow; bsrc[i] += 64 * brow;                                                      \
+            }                                                                                                    \
+        } else {                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+                const int over = 16 * i + rsub - (rem - 1);          /* rows past the last one: read that one */ \
+                const char* a_ = over > 0 ? asrc[i] - over * arow : asrc[i];                                     \
+                const char* b_ = over > 0 ? bsrc[i] - over * brow : bsrc[i];                                     \
+                __builtin_amdgcn_global_load_lds((g16_gptr)(a_), (g16_lptr)(ad_ + i * 8192), 16, 0, 0);          \
+                __builtin_amdgcn_global_load_lds((g16_gptr)(b_), (g16_lptr)(bd_ + i * 8192), 16, 0, 0);          \
+            }                                                                                                    \
+        }                                                                                                        \
+    }
+    // the wave that fetched a row past K zeroes A's copy of it once its own DMA has landed (B's is finite: 0 x finite = 0)
+#define KK_LANDED(STAGE, KT)                                                                                     \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                             \
+    if ((KT) == ztile) {                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                            \
+            if (16 * i + rsub >= rem)                                                                            \
+                *reinterpret_cast<f32x4*>(smem + (STAGE) * G16_IMG + i * 8192 + wave * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+    }                                                                                                            \
+    __builtin_amdgcn_s_barrier();
+
+    // ---- fragment addresses.  Lane = (group g = lane >> 4, i = lane & 15): row 8 (g >> 1) + (i >> 2) of a k-step, logical
+    //      chunk (tile's first) + 2 (g & 1) + ((i & 3) >> 1), byte 8 (i & 1) in it; physical slot = chunk ^ 4 (row & 3).
+    //      k-step ks adds 16 rows (8192 B), the second read of a fragment 4 rows (2048 B), the stage 32768 B: immediates. ----
+    unsigned aaddr[4], baddr[2];
+    {
+        const unsigned base = (unsigned)reinterpret_cast<size_t>((g16_lptr)(smem));
+        const int g = lane >> 4, i = lane & 15;
+        const int r = 8 * (g >> 1) + (i >> 2);
+        const int sw = (i >> 2) << 2;
+        const int sub = 2 * (g & 1) + ((i & 3) >> 1);
+        const unsigned in = (unsigned)(r * 512 + (i & 1) * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) aaddr[t] = base + in + (unsigned)((((wm * 16 + 4 * t + sub) ^ sw)) << 4);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) baddr[t] = base + 2 * G16_IMG + in + (unsigned)((((wn * 8 + 4 * t + sub) ^ sw)) << 4);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment halves: [tile][0] = k + 0..3, [tile][1] = k + 4..7
+    g16_f32x2 fa[4][2], fb[2][2], ga[4][2], gb[2][2];
+#define KK_READ(STAGE, KS, A_, B_)                                                                               \
+    asm volatile(                                                                                                \
+        "ds_read_b64_tr_b16 %0, %12 offset:%18\n\t"                                                              \
+        "ds_read_b64_tr_b16 %1, %12 offset:%19\n\t"                                                              \
+        "ds_read_b64_tr_b16 %8, %16 offset:%18\n\t"                                                              \
+        "ds_read_b64_tr_b16 %9, %16 offset:%19\n\t"                                                              \
+        "ds_read_b64_tr_b16 %2, %13 offset:%18\n\t"                                                              \
+        "ds_read_b64_tr_b16 %3, %13 offset:%19\n\t"                                                              \
+        "ds_read_b64_tr_b16 %10, %17 offset:%18\n\t"                                                             \
+        "ds_read_b64_tr_b16 %11, %17 offset:%19\n\t"                                                             \
+        "ds_read_b64_tr_b16 %4, %14 offset:%18\n\t"                                                              \
+        "ds_read_b64_tr_b16 %5, %14 offset:%19\n\t"                                                              \
+        "ds_read_b64_tr_b16 %6, %15 offset:%18\n\t"                                                              \
+        "ds_read_b64_tr_b16 %7, %15 offset:%19"                                                                  \
+        : "=&v"(A_[0][0]), "=&v"(A_[0][1]), "=&v"(A_[1][0]), "=&v"(A_[1][1]), "=&v"(A_[2][0]), "=&v"(A_[2][1]),  \
+          "=&v"(A_[3][0]), "=&v"(A_[3][1]), "=&v"(B_[0][0]), "=&v"(B_[0][1]), "=&v"(B_[1][0]), "=&v"(B_[1][1])   \
+        : "v"(aaddr[0]), "v"(aaddr[1]), "v"(aaddr[2]), "v"(aaddr[3]), "v"(baddr[0]), "v"(baddr[1]),              \
+          "i"((STAGE) * G16_IMG + (KS) * 8192), "i"((STAGE) * G16_IMG + (KS) * 8192 + 2048)                      \
+        : "memory");
+#define KK_WAIT(A_, B_)                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+                 : "+v"(A_[0][0]), "+v"(A_[0][1]), "+v"(A_[1][0]), "+v"(A_[1][1]), "+v"(A_[2][0]), "+v"(A_[2][1]), \
+                   "+v"(A_[3][0]), "+v"(A_[3][1]), "+v"(B_[0][0]), "+v"(B_[0][1]), "+v"(B_[1][0]), "+v"(B_[1][1]) : : "memory");
+#define KK_OP(X_) __builtin_bit_cast(g16_bf16x8, __builtin_shufflevector(X_[0], X_[1], 0, 1, 2, 3))
+#define KK_MFMA(A_, B_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                            \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(KK_OP(A_[i]), KK_OP(B_[j]), acc[i][j], 0, 0, 0);
+#define KK_TILE(STAGE)                                                                                           \
+    {                                                                                                            \
+        KK_READ(STAGE, 0, fa, fb) KK_WAIT(fa, fb)                                                                \
+        KK_READ(STAGE, 1, ga, gb) __builtin_amdgcn_sched_barrier(0); KK_MFMA(fa, fb) __builtin_amdgcn_sched_barrier(0); KK_WAIT(ga, gb) \
+        KK_READ(STAGE, 2, fa, fb) __builtin_amdgcn_sched_barrier(0); KK_MFMA(ga, gb) __builtin_amdgcn_sched_barrier(0); KK_WAIT(fa, fb) \
+        KK_READ(STAGE, 3, ga, gb) __builtin_amdgcn_sched_barrier(0); KK_MFMA(fa, fb) __builtin_amdgcn_sched_barrier(0); KK_WAIT(ga, gb) \
+        KK_MFMA(ga, gb)                                                                                          \
+    }
+
+    if (nk > 0) {
+        KK_ISSUE(0, 0)
+        KK_LANDED(0, 0)
+        for (int kt = 0; kt + 1 < nk; kt += 2) {
+            KK_ISSUE(1, kt + 1)                         // tile kt + 1 in flight while tile kt is multiplied
+            KK_TILE(0)
+            KK_LANDED(1, kt + 1)
+            if (kt + 2 < nk) KK_ISSUE(0, kt + 2)
+            KK_TILE(1)
+            KK_LANDED(0, kt + 2)
+        }
+        if (nk & 1) KK_TILE(0)
+    }
+#undef KK_ISSUE
+#undef KK_LANDED
+#undef KK_READ
+#undef KK_WAIT
+#undef KK_OP
+#undef KK_MFMA
+#undef KK_TILE
+
+    // ---- epilogue: D layout of the 32 x 32 MFMA: lane -> column l31, register r -> row (r & 3) + 8 (r >> 2) + 4 lhi ----
+    float* __restrict__ C = d.C + (long long)split * d.strideSplitC;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int gn = col0 + wn * 64 + tn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = row0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (gm < M && gn < N) {
+                    float* cp = C + (long long)gm * d.ldc + gn;
+                    float val = acc[tm][tn][r];
+                    if (d.bias) val += d.bias[gn];
+                    if (d.accumulate) val += *cp;
+                    *cp = val;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int t2amd_gemm16_kk_group(const t2amd_gemm16_desc* dp, int count, void* stream) {
+    T2_REQUIRE(dp != nullptr && count >= 1 && count <= G16_GROUP, "gemm16_kk: 1..4 descriptors");
+    Gemm16GroupParams p;
+    p.count = count;
+    int coltiles = 0;
+    for (int j = 0; j < G16_GROUP; ++j) {
+        p.d[j] = dp[j < count ? j : count - 1];
+        if (j >= count) { p.coltile_end[j] = coltiles; continue; }
+        t2amd_gemm16_desc& d = p.d[j];
+        T2_REQUIRE(d.A && d.B && d.C, "gemm16_kk: null operand");
+        T2_REQUIRE(d.M >= 8 && d.N >= 8 && d.K > 0 && d.M % 8 == 0 && d.N % 8 == 0, "gemm16_kk: M and N must be positive multiples of 8, K positive");
+        T2_REQUIRE(t2_aligned16(d.A) && t2_aligned16(d.B) && d.lda > 0 && d.ldb > 0 && d.lda % 8 == 0 && d.ldb % 8 == 0,
+                   "gemm16_kk: operands must be 16-byte aligned with row strides that are multiples of 8 elements");
+        T2_REQUIRE(d.win_Tp == 0 && d.win_T == 0, "gemm16_kk: no window epilogue (overlapping rows are expressed by lda / ldb < M / N)");
+        if (d.splitk < 1) d.splitk = 1;
+        T2_REQUIRE(d.splitk == 1 || (!d.bias && !d.accumulate), "gemm16_kk: split-K needs a plain epilogue");
+        T2_REQUIRE(d.M == p.d[0].M && d.splitk == p.d[0].splitk, "gemm16_kk: the products of one launch share M and the split count");
+        coltiles += t2_cdiv(d.N, G16_T);
+        p.coltile_end[j] = coltiles;
+    }
+    dim3 grid(coltiles, t2_cdiv(p.d[0].M, G16_T), p.d[0].splitk);
+    T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm16_kk: grid too large");
+    T2_LAUNCH(gemm16_kk_kernel, grid, dim3(G16_NT), 0, (hipStream_t)stream, p);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_gemm16_kk(const t2amd_gemm16_desc* dp, void* stream) { return t2amd_gemm16_kk_group(dp, 1, stream); }
+
+// ---------------------------------------------------------------------------------------
 // Transposing cast: dst[c][r] (bf16, row stride ldd >= rows, columns rows..rpad-1 zeroed) = src[r][c], src f32 or bf16.
 // The K-contiguous bf16 image of a [To.B][C] slab for the weight-gradient products above (K = To.B rounded up to 64).
 // 64 x 64 tiles through LDS: 256-byte reads along c, 128-byte writes along r.

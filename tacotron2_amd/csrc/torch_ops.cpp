@@ -11,6 +11,9 @@
 //                                                                                         t2amd_decoder_infer_persistent_f32
 //   conv_gemm / conv_gemm16                 the dense products of the encoder / postnet convolution stacks and of the
 //                                           deferred weight gradients (model.py:141-146, 174-175)   t2amd_gemm_f32 / t2amd_gemm16_tn
+//   wgrad_gemm16                            1..4 K-major weight-gradient products dW = dG^T . X in one launch (desc = that many
+//                                           t2amd_gemm16_desc back to back; model.py:352-371, layers.py:37-39 under autograd)
+//                                                                                         t2amd_gemm16_kk_group
 //
 // Calling convention of every op:  op(Tensor desc, Tensor[] reads, Tensor(a!)[] writes) -> ()
 //   desc    a CPU uint8 tensor holding the bytes of the entry point's descriptor struct (raw device pointers and sizes,
@@ -85,6 +88,14 @@ void conv_gemm(const at::Tensor& d, at::TensorList reads, at::TensorList writes)
 void conv_gemm16(const at::Tensor& d, at::TensorList reads, at::TensorList writes) {
     check(t2amd_gemm16_tn(as_desc<t2amd_gemm16_desc>(d, "conv_gemm16"), launch_stream(reads, writes, "conv_gemm16")), "conv_gemm16");
 }
+void wgrad_gemm16(const at::Tensor& d, at::TensorList reads, at::TensorList writes) {
+    TORCH_CHECK(d.device().is_cpu() && d.scalar_type() == at::kByte && d.is_contiguous() && d.numel() > 0 &&
+                    d.numel() % sizeof(t2amd_gemm16_desc) == 0 && d.numel() / sizeof(t2amd_gemm16_desc) <= 4,
+                "tacotron2_amd::wgrad_gemm16: desc must hold 1..4 t2amd_gemm16_desc (", sizeof(t2amd_gemm16_desc), " bytes each) as CPU uint8");
+    check(t2amd_gemm16_kk_group(reinterpret_cast<const t2amd_gemm16_desc*>(d.data_ptr()),
+                                static_cast<int>(d.numel() / sizeof(t2amd_gemm16_desc)), launch_stream(reads, writes, "wgrad_gemm16")),
+          "wgrad_gemm16");
+}
 
 [[noreturn]] void no_cpu_path() {
     TORCH_CHECK(false, "tacotron2_amd: the engine runs on the MI355X only; there is no CPU compute path "
@@ -104,6 +115,7 @@ TORCH_LIBRARY(tacotron2_amd, m) {
     m.def("decoder_infer_persistent(Tensor desc, Tensor[] reads, Tensor(a!)[] writes) -> ()");
     m.def("conv_gemm(Tensor desc, Tensor[] reads, Tensor(a!)[] writes) -> ()");
     m.def("conv_gemm16(Tensor desc, Tensor[] reads, Tensor(a!)[] writes) -> ()");
+    m.def("wgrad_gemm16(Tensor desc, Tensor[] reads, Tensor(a!)[] writes) -> ()");
     m.def("abi_version() -> int", []() -> int64_t { return t2amd_abi_version(); });
 }
 
@@ -116,6 +128,7 @@ TORCH_LIBRARY_IMPL(tacotron2_amd, CUDA, m) {          // the CUDA dispatch key i
     m.impl("decoder_infer_persistent", decoder_infer_persistent);
     m.impl("conv_gemm", conv_gemm);
     m.impl("conv_gemm16", conv_gemm16);
+    m.impl("wgrad_gemm16", wgrad_gemm16);
 }
 
 TORCH_LIBRARY_IMPL(tacotron2_amd, CPU, m) {
@@ -127,4 +140,5 @@ TORCH_LIBRARY_IMPL(tacotron2_amd, CPU, m) {
     m.impl("decoder_infer_persistent", cpu1);
     m.impl("conv_gemm", cpu1);
     m.impl("conv_gemm16", cpu1);
+    m.impl("wgrad_gemm16", cpu1);
 }

@@ -112,22 +112,85 @@ def _choose_splitk(M, N, K, batch=1, precision=0, a_km=False, b_kn=False):
 
 
 def _choose_splitk16(M, N, K):
-    """Split count for the bf16-resident product (csrc/gemm16.hip: 256 x 256 tiles, one workgroup per CU): fill whole rounds
-    of 256 workgroups, mild preference for fewer partial slabs, at least 32 k-steps of 64 per slab."""
+    """Split count for the bf16-resident products (csrc/gemm16.hip: 256 x 256 x 64 tile steps, one workgroup per CU) by a time
+    model fitted to rocprofv3 dispatch times on MI355X (profiles/r03_v_gemm16_trace.csv): rounds of 256 workgroups, 1.9 us
+    per tile step, ~4 us of prologue / epilogue per round, and the partial slabs read back at ~5 TB/s by the reduction.  A
+    product of a few tiles over a 55 k-deep K (the weight gradient of an 80-channel convolution: 4 tiles) takes dozens of
+    splits; one that already fills the chip takes none."""
     t256 = ((M + 255) // 256) * ((N + 255) // 256)
-    best, best_score = 1, -1.0
-    for s in range(1, 33):
-        if s > 1 and K // s < 2048:
+    nkt = (K + 63) // 64
+    best, best_t = 1, None
+    for s in range(1, 65):
+        if s > 1 and nkt // s < 8:
             break
-        w = t256 * s / 256.0
-        score = w / math.ceil(w) * min(1.0, w / 0.85) - 0.015 * (s - 1)
-        if score > best_score:
-            best, best_score = s, score
+        rounds = math.ceil(t256 * s / 256.0)
+        t = rounds * (math.ceil(nkt / s) * 1.9 + 4.0)
+        if s > 1:
+            t += (s + 1) * M * N * 4 / 5.0e6 + 3.0
+        if best_t is None or t < best_t - 1e-9:
+            best, best_t = s, t
     return best
 
 
 # T2AMD_WGRAD16=0 keeps the decoder-LSTM weight gradients on the f32-source GEMM in the bf16 mode (A/B runs)
 WGRAD16 = os.environ.get('T2AMD_WGRAD16', '1') != '0'
+
+
+# T2AMD_WGRAD_KK=0 keeps the round-2 route of the bf16 weight gradients (transposed K-contiguous copies + gemm16_tn, and the
+# f32-source GEMM for the convolutions) instead of the K-major product on the slabs / halo images themselves (A/B runs)
+WGRAD_KK = os.environ.get('T2AMD_WGRAD_KK', '1') != '0'
+
+
+def _kk_to(run, out, A16, B16, K, M, N, lda=None, ldb=None, perm=None):
+    """out (+ optional (taps, Ci) permutation of a packed conv-weight gradient) = sum_k A16[k, :M]^T B16[k, :N] on the K-major
+    bf16 product, split along K to fill the chip; ``out`` may be a column block of a wider matrix."""
+    sk = _choose_splitk16(M, N, K)
+    if sk == 1 and perm is None:
+        nv.gemm16_kk(out, A16, B16, K, M=M, N=N, lda=lda, ldb=ldb)
+        return
+    part = run.empty(sk, M * N)
+    nv.gemm16_kk(part[0].view(M, N), A16, B16, K, M=M, N=N, lda=lda, ldb=ldb, splitk=sk, partials=part)
+    if perm is not None:
+        nv.splitk_reduce(part, sk, out, perm_taps=perm[0], perm_ci=perm[1])
+    else:
+        nv.splitk_reduce2d(part, sk, out)
+
+
+def _lstm_wgrad_kk(run, dG2, B, parts, outs):
+    """The same weight gradients from the slabs as they are (round 3): dG [To.B][4H] and every input slab [To.B][.] are
+    K-major bf16 operands of native.gemm16_kk; an input read from the PREVIOUS time step is dG from row B on against the
+    slab from row 0 -- no transposed copies.  The input blocks are separate products of ONE launch (gemm16_kk_group): their
+    workgroups share the rows of dG, which is read once; each writes its own column block of dW_ih / dW_hh."""
+    rowsD, G4 = dG2.shape
+    widths = [src.shape[1] for src, _ in parts]
+    offs = [0]
+    for w in widths:
+        offs.append(offs[-1] + w)
+    jobs = []                                       # (destination block, A, B, K, width)
+    for dW, i0, i1 in outs:
+        base = offs[i0]
+        for i in range(i0, i1):
+            src, shifted = parts[i]
+            if src.dtype != torch.bfloat16:
+                src = run.cast16(src)
+            blk = dW[:, offs[i] - base:offs[i + 1] - base]
+            if shifted and rowsD <= B:
+                blk.zero_()
+            elif shifted:
+                jobs.append((blk, dG2[B:], src, rowsD - B, widths[i]))
+            else:
+                jobs.append((blk, dG2, src, rowsD, widths[i]))
+    if not jobs:
+        return
+    sk = _choose_splitk16(G4, sum((j[4] + 255) // 256 * 256 for j in jobs), rowsD)
+    if sk == 1:
+        nv.gemm16_kk_group([dict(Cm=blk, A16=A, B16=Bm, K=K, M=G4, N=w) for blk, A, Bm, K, w in jobs])
+        return
+    parts_ = [run.empty(sk, G4 * w) for _, _, _, _, w in jobs]
+    nv.gemm16_kk_group([dict(Cm=pt[0].view(G4, w), A16=A, B16=Bm, K=K, M=G4, N=w, splitk=sk, partials=pt)
+                        for (blk, A, Bm, K, w), pt in zip(jobs, parts_)])
+    for (blk, _, _, _, _), pt in zip(jobs, parts_):
+        nv.splitk_reduce2d(pt, sk, blk)
 
 
 def _lstm_wgrad16(run, dG2, B, parts, outs):
@@ -136,8 +199,11 @@ def _lstm_wgrad16(run, dG2, B, parts, outs):
     bf16 images are made first (transposing cast, K padded to the tile depth with zeros); an input the step reads from
     the PREVIOUS time step (ctx_{t-1}, h_{t-1}) is written B columns to the right, which turns its
     dG[B:]^T . x[:(To-1).B] into the same full-K product (the first B columns are zero).
-    ``parts``: (slab2d, shifted) per input block, in weight-column order; ``outs``: (dW tensor, first block, last block + 1)."""
+    ``parts``: (slab2d, shifted) per input block, in weight-column order; ``outs``: (dW tensor, first block, last block + 1).
+    (Round 2's route; since round 3 the K-major product above is the default, T2AMD_WGRAD_KK=0 selects this one.)"""
     rowsD, G4 = dG2.shape
+    if WGRAD_KK and G4 % 8 == 0 and all(src.shape[1] % 8 == 0 for src, _ in parts):
+        return _lstm_wgrad_kk(run, dG2, B, parts, outs)
     Kp = ((rowsD + B + 63) // 64) * 64
     GT = run.empty16(G4, Kp)
     nv.transpose_cast_bf16(dG2, GT)
@@ -342,6 +408,13 @@ def _conv16_ok(run, rows, T, C):
     return run.bf16 and CONV16 and C % 64 == 0 and T > 0 and rows % T == 0 and rows >= 4096 and not nv.validate_only()
 
 
+def _conv_wgrad_kk_ok(run, rows, T, Ci, Co):
+    """The K-major weight-gradient product needs whole utterances of T rows, channel counts of whole 16-byte chunks and a K
+    long enough to be worth two image casts."""
+    return run.bf16 and CONV16 and WGRAD_KK and Ci % 8 == 0 and Co % 8 == 0 and T > 0 and rows % T == 0 and rows >= 4096 \
+        and not nv.validate_only()
+
+
 def _halo_image(run, x, T, pad):
     """bf16 image of the channel-last rows x (rows = B T) with `pad` zero rows around every utterance."""
     rows, C = x.shape
@@ -359,6 +432,7 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                          % (torch.Size([1, x.shape[1], 1]),))
     for i in range(n_layers):
+        ximg = None
         W = P['%s.%d.0.conv.weight' % (prefix, i)]
         bias = P['%s.%d.0.conv.bias' % (prefix, i)]
         gamma = P['%s.%d.1.weight' % (prefix, i)]
@@ -383,7 +457,8 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         elif _conv16_ok(run, rows, T, Ci):
             # bf16 mode: the convolution as a product of sliding windows of a bf16 image with zero halo rows (csrc/gemm16.hip)
             W16 = run.cached('convfwd16.%s.%d' % (prefix, i), [W], lambda Wp=Wp: run.cast16(Wp))
-            nv.conv16(y, _halo_image(run, x, T, pad), W16, rows // T, T, pad, bias=bias)
+            ximg = _halo_image(run, x, T, pad)
+            nv.conv16(y, ximg, W16, rows // T, T, pad, bias=bias)
         else:
             _fg(run, y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
         if training:
@@ -401,7 +476,8 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         keep = masks[i] if masks is not None else None
         nv.bn_act_fwd(y, z, mean, invstd, gamma, beta, acts[i],
                       keep.view(rows, Co) if keep is not None else None, 2.0, lens, T if lens is not None else 0)
-        saved.append(dict(x=x, y=y, z=z, mean=mean, invstd=invstd, keep=keep, W=W, act=acts[i], layer=i))
+        saved.append(dict(x=x, y=y, z=z, mean=mean, invstd=invstd, keep=keep, W=W, act=acts[i], layer=i,
+                          ximg=ximg if (training and WGRAD_KK) else None))     # the weight gradient multiplies it again
         x = z
     return x, saved
 
@@ -431,7 +507,18 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
         grads['%s.%d.0.conv.bias' % (prefix, i)] = dbias
         # weight gradient: dW[co][(tap,ci)] = sum_r g[r][co] * x[r + tap - pad][ci]
         dW = G('%s.%d.0.conv.weight' % (prefix, i), Co, Ci, k)
-        _rg(run, dW.view(Co, Ci * k), g, s['x'], a_km=True, b_kn=True, convB=(T, Ci, pad), perm=(k, Ci))
+        gimg = None
+        if _conv_wgrad_kk_ok(run, rows, T, Ci, Co):
+            # bf16 mode: ONE K-major product over the two halo images (csrc/gemm16.hip, gemm16_kk): K runs over the image rows
+            # (b, t) of pitch T + 2 pad, A = g's image from row `pad` on (zero where t >= T), B[k][(tap, ci)] = x's image
+            # flat[k Ci + tap Ci + ci] -- overlapping rows, ldb = Ci -- i.e. the very windows the forward multiplied
+            ximg = s.get('ximg')
+            if ximg is None:
+                ximg = _halo_image(run, s['x'], T, pad)
+            gimg = _halo_image(run, g, T, pad)
+            _kk_to(run, dW, gimg[pad:], ximg, (rows // T) * (T + 2 * pad), Co, k * Ci, lda=Co, ldb=Ci, perm=(k, Ci))
+        else:
+            _rg(run, dW.view(Co, Ci * k), g, s['x'], a_km=True, b_kn=True, convB=(T, Ci, pad), perm=(k, Ci))
         grads['%s.%d.0.conv.weight' % (prefix, i)] = dW
         # data gradient
         if i > 0 or first_dx is not None:
@@ -447,7 +534,7 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
                 # tap-reversed weights [Ci][k Co]
                 Wd16 = run.cached('convdgrad16.%s.%d' % (prefix, i), [W], lambda W=W: W.flip(2).permute(1, 2, 0).reshape(
                     W.shape[1], W.shape[2] * W.shape[0]).contiguous().to(torch.bfloat16))
-                nv.conv16(dx, _halo_image(run, g, T, pad), Wd16, rows // T, T, pad, accumulate=acc)
+                nv.conv16(dx, gimg if gimg is not None else _halo_image(run, g, T, pad), Wd16, rows // T, T, pad, accumulate=acc)
             else:
                 _ng(run, dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
             g = dx

@@ -259,7 +259,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
     "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
-    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_gemm16_tn", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16",
+    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_splitk_reduce2d_f32", "t2amd_gemm16_tn", "t2amd_gemm16_kk", "t2amd_gemm16_kk_group", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
@@ -291,7 +291,10 @@ def _argtypes():
         "t2amd_gemm_f32": [pt(GemmDesc), _P],
         "t2amd_gemm_tile_size": [_I, _I, _I, _I, _I, _I],
         "t2amd_splitk_reduce_f32": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
+        "t2amd_splitk_reduce2d_f32": [_P, _I, _L, _P, _I, _I, _L, _I, _P],
         "t2amd_gemm16_tn": [pt(Gemm16Desc), _P],
+        "t2amd_gemm16_kk": [pt(Gemm16Desc), _P],
+        "t2amd_gemm16_kk_group": [pt(Gemm16Desc), _I, _P],
         "t2amd_transpose_cast_bf16": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_cast_halo_bf16": [_P, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
@@ -662,6 +665,56 @@ def conv16(Cm, img16, W16, B, T, pad, bias=None, accumulate=False):
     _check(lib.t2amd_gemm16_tn(C.byref(d), _stream()), "t2amd_gemm16_tn")
 
 
+def _kk_desc(Cm, A16, B16, K, M=None, N=None, lda=None, ldb=None, splitk=1, partials=None, accumulate=False, bias=None):
+    d = Gemm16Desc()
+    pa, lda0, ra, wa = _mat(A16, torch.bfloat16)
+    pb, ldb0, rb, wb = _mat(B16, torch.bfloat16)
+    M = wa if M is None else M
+    N = wb if N is None else N
+    lda = lda0 if lda is None else lda
+    ldb = ldb0 if ldb is None else ldb
+    # the elements a product touches must lie inside the tensors handed in (contiguous storage from their first element)
+    span_a = (ra - 1) * lda0 + wa
+    span_b = (rb - 1) * ldb0 + wb
+    if K < 1 or (K - 1) * lda + M > span_a or (K - 1) * ldb + N > span_b or Cm.shape[0] != M or Cm.shape[1] != N:
+        raise NativeError("gemm16_kk: shape mismatch A=%s B=%s C=%s M=%d N=%d K=%d lda=%d ldb=%d"
+                          % (tuple(A16.shape), tuple(B16.shape), tuple(Cm.shape), M, N, K, lda, ldb))
+    d.A, d.B, d.M, d.N, d.K, d.lda, d.ldb = pa, pb, M, N, K, lda, ldb
+    d.splitk = splitk
+    if splitk > 1:
+        if partials is None or partials.numel() < splitk * M * N:
+            raise NativeError("gemm16_kk: split-K needs a (splitk, M*N) partials buffer")
+        d.C, d.ldc, d.strideSplitC = ptr(partials), N, M * N
+    else:
+        d.C, d.ldc = _mat(Cm)[:2]
+    d.accumulate = 1 if accumulate else 0
+    d.bias = ptr(bias)
+    return d
+
+
+def gemm16_kk(Cm, A16, B16, K, M=None, N=None, lda=None, ldb=None, splitk=1, partials=None, accumulate=False, bias=None):
+    """Cm[M,N] (f32) = sum_k A16[k, m] . B16[k, n]: bf16 K-MAJOR operands (csrc/gemm16.hip, transposing LDS reads) -- the
+    layout of the time loops' slabs and of channel-last images.  ``A16`` / ``B16`` are 2-D bf16 tensors whose rows are the k
+    index; ``M`` / ``N`` / ``lda`` / ``ldb`` default to their widths and row strides.  A row stride SMALLER than the width
+    expresses overlapping rows (B[k][n] = img[k Ci + n], n < taps Ci: the windows of a convolution); the tensor must then
+    hold the last row's reach.  With ``splitk`` > 1 the partial products go to ``partials`` (splitk, M*N)."""
+    d = _kk_desc(Cm, A16, B16, K, M, N, lda, ldb, splitk, partials, accumulate, bias)
+    _check(load().t2amd_gemm16_kk(C.byref(d), _stream()), "t2amd_gemm16_kk")
+
+
+def gemm16_kk_group(problems):
+    """Up to four K-major products in one launch (same M, same splitk): ``problems`` is a list of keyword dictionaries of
+    gemm16_kk.  Their workgroups run side by side on the same rows of A (read once): the input blocks of an LSTM's dW."""
+    if not 1 <= len(problems) <= 4:
+        raise NativeError("gemm16_kk_group: 1..4 problems, got %d" % len(problems))
+    arr = (Gemm16Desc * len(problems))(*[_kk_desc(**kw) for kw in problems])
+    # through the dispatcher when the registration library is there (torch.ops.tacotron2_amd.wgrad_gemm16), else ctypes
+    reads = [kw[k_] for kw in problems for k_ in ('A16', 'B16')]
+    writes = [kw['partials'] if kw.get('partials') is not None else kw['Cm'] for kw in problems]
+    if not _via_ops("wgrad_gemm16", [arr], reads, writes):
+        _check(load().t2amd_gemm16_kk_group(arr, len(problems), _stream()), "t2amd_gemm16_kk_group")
+
+
 def cast_halo_bf16(src, dst, T, pad):
     """dst[(b (T + 2 pad) + pad + t), c] (bf16) = src[(b T + t), c]; every row of the image -- (rows / T) (T + 2 pad) + 2 pad of
     them -- is written, the halo rows with zeros (dst need not be initialised)."""
@@ -692,6 +745,13 @@ def splitk_reduce(partials, nsplit, out, accumulate=False, perm_taps=0, perm_ci=
     _check(lib.t2amd_splitk_reduce_f32(ptr(partials), nsplit, _i64(n), ptr(out), _i64(n),
                                        1 if accumulate else 0, perm_taps, perm_ci, _stream()),
            "t2amd_splitk_reduce_f32")
+
+
+def splitk_reduce2d(partials, nsplit, out, accumulate=False):
+    """out[r, c] (+)= sum_s partials[s][r cols + c]; ``out`` may be a column block of a wider matrix."""
+    po, ldo, rows, cols = _mat(out)
+    _check(load().t2amd_splitk_reduce2d_f32(ptr(partials), nsplit, _i64(rows * cols), po, rows, cols, _i64(ldo),
+                                            1 if accumulate else 0, _stream()), "t2amd_splitk_reduce2d_f32")
 
 
 # ----------------------------------------------------------------------------

@@ -179,7 +179,7 @@ def test_torch_library_ops_are_registered(native_lib):
     assert ops is not None, "lib/libtacotron2_amd_torch.so missing: python -m tacotron2_amd.build"
     assert ops.abi_version() == native.load().t2amd_abi_version()
     names = ("encoder_lstm_fwd", "encoder_lstm_bwd", "decoder_train_fwd", "decoder_train_bwd", "decoder_infer_steps",
-             "decoder_infer_persistent", "conv_gemm", "conv_gemm16")
+             "decoder_infer_persistent", "conv_gemm", "conv_gemm16", "wgrad_gemm16")
     for n in names:
         schema = str(getattr(ops, n).default._schema)
         assert "Tensor[] reads" in schema and "Tensor(a!)[] writes" in schema, schema

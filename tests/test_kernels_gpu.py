@@ -868,6 +868,121 @@ def test_gemm16_tn_matches_f32_product_of_the_bf16_operands(nv, M, N, K, pad):
         assert (part.view(sk, M, N).sum(0).cpu() - ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(256, 256, 64, 0), (304, 520, 192, 8), (1024, 768, 1285, 0), (72, 40, 130, 24), (8, 8, 1, 0),
+                                       (512, 264, 63, 0)])
+def test_gemm16_kk_matches_f32_product_of_the_bf16_operands(nv, M, N, K, pad):
+    """C = A^T . B with bf16 K-MAJOR operands ([K][M], [K][N]): LDS-DMA of 64 k-rows x 512 B, fragments by the transposing LDS
+    read (ds_read_b64_tr_b16).  Products of bf16 values are exact in f32, so the result equals an f32 matmul of the same
+    operands to summation-order accuracy.  Asymmetric operands (a ramp along m and along k): a transposed fragment, a wrong k
+    order between A and B or a mis-swizzled slot cannot pass; K that is not a multiple of 64 exercises the zeroed tail rows
+    (the rows behind K are NaN in A and B: nothing past K may be multiplied), padded row strides the clamped columns."""
+    A = (rnd(K, M + pad, seed=330) * (1 + torch.arange(M + pad).float().unsqueeze(0) / M) * (1 + torch.arange(K).float().unsqueeze(1) / K)).bfloat16()
+    B = (rnd(K, N + pad, seed=331) * (1 + 2 * torch.arange(N + pad).float().unsqueeze(0) / N)).bfloat16()
+    ref = A[:, :M].float().t() @ B[:, :N].float()
+    Ad = torch.full((K + 70, M + pad), float('nan'), dtype=torch.bfloat16, device=DEV)
+    Bd = torch.full((K + 70, N + pad), float('nan'), dtype=torch.bfloat16, device=DEV)
+    Ad[:K] = A.to(DEV)
+    Bd[:K] = B.to(DEV)
+    Cm = torch.full((M, N), float('nan'), device=DEV)
+    nv.gemm16_kk(Cm, Ad[:K, :M], Bd[:K, :N], K)
+    tol = 2e-6 * max(K, 16) ** 0.5 * float(ref.abs().max())
+    assert (Cm.cpu() - ref).abs().max().item() < tol
+    bias = rnd(N, seed=332)
+    nv.gemm16_kk(Cm, Ad[:K, :M], Bd[:K, :N], K, accumulate=True, bias=dv(bias))
+    assert (Cm.cpu() - (2 * ref + bias)).abs().max().item() < 2 * tol
+    for sk in (2, 3):
+        if K < 64 * sk:
+            continue
+        part = torch.full((sk, M * N), float('nan'), device=DEV)
+        nv.gemm16_kk(Cm, Ad[:K, :M], Bd[:K, :N], K, splitk=sk, partials=part)
+        assert (part.view(sk, M, N).sum(0).cpu() - ref).abs().max().item() < tol
+        wide = torch.full((M, N + 24), 5.0, device=DEV)                      # the partials reduced into a column block
+        nv.splitk_reduce2d(part, sk, wide[:, 16:16 + N])
+        assert (wide[:, 16:16 + N].cpu() - ref).abs().max().item() < tol
+        assert torch.all(wide[:, :16].cpu() == 5.0) and torch.all(wide[:, 16 + N:].cpu() == 5.0)
+        nv.splitk_reduce2d(part, sk, wide[:, 16:16 + N], accumulate=True)
+        assert (wide[:, 16:16 + N].cpu() - 2 * ref).abs().max().item() < 2 * tol
+
+
+def test_gemm16_kk_shifted_rows_are_a_row_offset(nv):
+    """dG[B:]^T . x[:rows - B] -- the weight gradient of an input the step reads from the PREVIOUS time step -- is the same
+    product with A starting B rows further down: no copy, no padded image."""
+    rows, Bsz, G4, W = 640, 64, 264, 136
+    dG = rnd(rows, G4, seed=340).bfloat16()
+    x = rnd(rows, W, seed=341).bfloat16()
+    ref = dG[Bsz:].float().t() @ x[:rows - Bsz].float()
+    Cm = torch.full((G4, W), float('nan'), device=DEV)
+    nv.gemm16_kk(Cm, dG.to(DEV)[Bsz:], x.to(DEV), rows - Bsz)
+    assert (Cm.cpu() - ref).abs().max().item() < 2e-6 * rows ** 0.5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("sk", [1, 3])
+def test_gemm16_kk_group_shares_one_launch(nv, sk):
+    """The input blocks of an LSTM's weight gradient as ONE launch: three products with their own widths, row offsets (the
+    block read from the previous time step starts Bsz rows further down in dG), K and destinations (column blocks of two
+    matrices) -- each equals its own f32 product; widths that are not multiples of the tile (the last column tile of a problem
+    must not spill into the next problem's columns)."""
+    rows, Bsz, G4 = 777, 8, 520
+    widths = (264, 40, 512)
+    dG = rnd(rows, G4, seed=360).bfloat16()
+    xs = [(rnd(rows, w, seed=361 + i) * (1 + torch.arange(w).float().unsqueeze(0) / w)).bfloat16() for i, w in enumerate(widths)]
+    shifted = (False, True, True)
+    dGd = dG.to(DEV)
+    dWih = torch.full((G4, widths[0] + widths[1]), float('nan'), device=DEV)
+    dWhh = torch.full((G4, widths[2]), float('nan'), device=DEV)
+    dests = (dWih[:, :widths[0]], dWih[:, widths[0]:], dWhh)
+    probs, parts = [], []
+    for x, sh, dst, w in zip(xs, shifted, dests, widths):
+        A = dGd[Bsz:] if sh else dGd
+        K = rows - Bsz if sh else rows
+        if sk == 1:
+            probs.append(dict(Cm=dst, A16=A, B16=x.to(DEV), K=K, M=G4, N=w))
+        else:
+            pt = torch.full((sk, G4 * w), float('nan'), device=DEV)
+            parts.append(pt)
+            probs.append(dict(Cm=pt[0].view(G4, w), A16=A, B16=x.to(DEV), K=K, M=G4, N=w, splitk=sk, partials=pt))
+    nv.gemm16_kk_group(probs)
+    for pt, dst in zip(parts, dests):
+        nv.splitk_reduce2d(pt, sk, dst)
+    for x, sh, dst in zip(xs, shifted, dests):
+        ref = (dG[Bsz:].float().t() @ x[:rows - Bsz].float()) if sh else (dG.float().t() @ x.float())
+        assert (dst.cpu() - ref).abs().max().item() < 2e-6 * rows ** 0.5 * float(ref.abs().max())
+    with pytest.raises(Exception):
+        nv.gemm16_kk_group(probs + probs)                                  # more than four problems
+
+
+@pytest.mark.parametrize("B,T,Ci,Co,k", [(3, 37, 64, 96, 5), (5, 200, 128, 304, 5), (2, 9, 64, 64, 3), (4, 50, 80, 512, 5), (4, 50, 512, 80, 5)])
+def test_gemm16_kk_conv_weight_gradient_over_the_halo_images(nv, B, T, Ci, Co, k):
+    """dW[co][tap][ci] = sum_{b,t} g[b,t,co] x[b,t+tap-pad,ci] as ONE K-major product over the two bf16 halo images the
+    convolution's forward and data gradient already make: A = g's image from row `pad` on ([K][Co]), B[k][n] = x's image
+    flat[k Ci + n], n < k Ci (overlapping rows: ldb = Ci).  Equals autograd of F.conv1d on the bf16-rounded operands; the halos
+    keep utterances apart."""
+    import torch.nn.functional as F
+    pad = (k - 1) // 2
+    Tp = T + 2 * pad
+    x = rnd(B * T, Ci, seed=350)
+    g = rnd(B * T, Co, seed=351)
+    xb = x.bfloat16().float().view(B, T, Ci).transpose(1, 2).requires_grad_(False)
+    Wt = torch.zeros(Co, Ci, k, requires_grad=True)
+    F.conv1d(xb, Wt, None, padding=pad).backward(g.bfloat16().float().view(B, T, Co).transpose(1, 2))
+    ref = Wt.grad.permute(0, 2, 1).reshape(Co, k * Ci)                    # [co][tap Ci + ci]
+    ximg = torch.full((B * Tp + 2 * pad, Ci), float('nan'), dtype=torch.bfloat16, device=DEV)
+    gimg = torch.full((B * Tp + 2 * pad, Co), float('nan'), dtype=torch.bfloat16, device=DEV)
+    nv.cast_halo_bf16(dv(x), ximg, T, pad)
+    nv.cast_halo_bf16(dv(g), gimg, T, pad)
+    K = B * Tp
+    dW = torch.full((Co, k * Ci), float('nan'), device=DEV)
+    nv.gemm16_kk(dW, gimg[pad:], ximg, K, M=Co, N=k * Ci, lda=Co, ldb=Ci)
+    tol = 3e-6 * (B * T) ** 0.5 * float(ref.abs().max())
+    assert (dW.cpu() - ref).abs().max().item() < tol
+    sk = 2
+    part = torch.full((sk, Co * k * Ci), float('nan'), device=DEV)
+    nv.gemm16_kk(dW, gimg[pad:], ximg, K, M=Co, N=k * Ci, lda=Co, ldb=Ci, splitk=sk, partials=part)
+    out = torch.empty(Co, Ci, k, device=DEV)
+    nv.splitk_reduce(part, sk, out, perm_taps=k, perm_ci=Ci)              # (co, tap, ci) -> torch's (co, ci, tap)
+    assert (out.cpu() - Wt.grad).abs().max().item() < tol
+
+
 @pytest.mark.parametrize("rows,cols,rpad", [(130, 70, 192), (64, 64, 64), (1000, 257, 1024), (512, 256, 576)])
 def test_transpose_cast_bf16(nv, rows, cols, rpad):
     src = rnd(rows, cols + 3, seed=310)[:, :cols]                       # a row stride that is not the width: scalar paths

@@ -1,6 +1,6 @@
 """BASELINE configs[3] (Tacotron2.inference, batch 1, Ti = 100): decode steps/s of every variant of the decode loop.
     python tools/bench_decode_b1.py [--steps 1000]
-Variants: persistent weight-stationary kernel (bf16 mode), launch chain bf16, launch chain fp32.  Forced length (gate
+Variants: persistent weight-stationary kernel (bf16 and fp32 weights), launch chain bf16, launch chain fp32.  Forced length (gate
 threshold above 1) so that the timing does not depend on the random weights; whole Tacotron2.inference call inside the
 timed region (encoder + loop + postnet); the loop alone is reported from the difference to a 1-step call."""
 import json
@@ -58,12 +58,15 @@ PHASES = None
 out = {"steps": STEPS, "Ti": 100}
 import contextlib
 with contextlib.redirect_stdout(sys.stderr):
-    for name, prec, pers in (("persistent_bf16", "bf16", True), ("launch_chain_bf16", "bf16", False),
-                             ("launch_chain_fp32", "fp32", False)):
+    for name, prec, pers in (("persistent_bf16", "bf16", True), ("persistent_fp32", "fp32", True),
+                             ("launch_chain_bf16", "bf16", False), ("launch_chain_fp32", "fp32", False)):
         full, path = timed(prec, pers, STEPS)
         one, _ = timed(prec, pers, 1)
         if pers:
+            PHASES = None
             timed(prec, pers, STEPS, phases=True)             # separate run: the phase clock is not in the timed numbers
+            if PHASES:
+                out[name + "_phases"] = PHASES
         es = 2.0 if prec == "bf16" else 4.0
         step_bytes = es * (18189969 + 640 * 100.0)
         loop = max(full - one, 1e-9)
@@ -71,6 +74,4 @@ with contextlib.redirect_stdout(sys.stderr):
                      "decode_steps_per_s_whole_call": STEPS / full, "us_per_step_loop_only": 1e6 * loop / (STEPS - 1),
                      "hbm_roofline_frac_whole_call": step_bytes * STEPS / full / 8e12}
 engine.PERSISTENT_DECODE = True
-if PHASES:
-    out["persistent_phases"] = PHASES
 print(json.dumps(out))

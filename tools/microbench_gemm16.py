@@ -43,6 +43,14 @@ def main():
             pp = torch.empty(s, M * N, device=dev) if s > 1 else None
             ms = timeit(lambda: native.gemm16_tn(Cm, A16, B16, splitk=s, partials=pp))
             line += "  gemm16/sk%d %7.3f ms %6.0f TF" % (s, ms, 2.0 * M * N * K / ms * 1e-9)
+        if M <= 4096 and M * K <= 4096 * 55680:
+            # the same product from K-major operands ([K][M], [K][N]: the layout the slabs have), transposing LDS reads
+            At16, Bt16 = A16.t().contiguous(), B16.t().contiguous()
+            for s in sorted({1, sk}):
+                pp = torch.empty(s, M * N, device=dev) if s > 1 else None
+                ms = timeit(lambda: native.gemm16_kk(Cm, At16, Bt16, K, splitk=s, partials=pp))
+                line += "  kk/sk%d %7.3f ms %6.0f TF" % (s, ms, 2.0 * M * N * K / ms * 1e-9)
+            del At16, Bt16
         # the f32-source bf16 kernel on the same product (K-contiguous operands)
         ms = timeit(lambda: (native.gemm(part[0].view(M, N), A, B, fast=2, splitk=sk, partials=part) if sk > 1
                              else native.gemm(Cm, A, B, fast=2)))
