@@ -130,7 +130,8 @@ typedef struct t2amd_gemm16_desc {
     int accumulate;         /* C += (splitk must be 1) */
     const float* bias;      /* [N] or NULL (splitk must be 1) */
     /* window mode (win_Tp > 0; nn.Conv1d over channel-last rows, reference layers.py:37-39 / model.py:141-146, 174-175):
-     * A is a bf16 image [B][Tp = T + 2 pad][Ci] with zero halo rows (t2amd_cast_halo_bf16), lda = Ci, K = k Ci -- row
+     * A is a bf16 image [B][Tp = T + 2 pad][Ci] with zero halo rows (t2amd_cast_halo_bf16), lda = Ci, K = k Ci rounded up to 64
+     * (B's columns behind k Ci zero, t2amd_pack_conv_bf16; the windows' overhang stays inside the image's last halo) -- row
      * m = b Tp + t of A is the k-tap window of output (b, t), overlapping its neighbours; M = B Tp window rows are
      * multiplied and those with t < win_T are stored to the compact rows b win_T + t of C.  splitk must be 1. */
     int win_T, win_Tp;
@@ -150,6 +151,11 @@ int t2amd_gemm16_kk_group(const t2amd_gemm16_desc* d, int count, void* stream);
 /* dst[(b (T + 2 pad) + pad + t)][c] (bf16) = src[(b T + t)][c]; dst ([B (T + 2 pad) + 2 pad][C]; every row is written, the halo
  * rows with zeros: it need not be initialised) is the image the window mode reads. */
 int t2amd_cast_halo_bf16(const float* src, long long lds, void* dst, long long rows, int C, int T, int pad, void* stream);
+
+/* bf16 weight image of nn.Conv1d (W f32 [Co][Ci][k], reference layers.py:37-39) for the window mode, Kp >= row length, the
+ * columns behind it zero: reversed = 0 -> out[Co][Kp], out[co][tap Ci + ci] = W[co][ci][tap] (forward);
+ * reversed = 1 -> out[Ci][Kp], out[ci][(k - 1 - tap) Co + co] = W[co][ci][tap] (data gradient: windows of g's image). */
+int t2amd_pack_conv_bf16(const float* W, void* out, int Co, int Ci, int k, int Kp, int reversed, void* stream);
 
 /* dst[c][r] (bf16, row stride ldd >= rows_padded; columns rows..rows_padded-1 zeroed) = src[r][c]; src is f32
  * (src_is_bf16 = 0) or bf16, row stride lds elements: the K-contiguous image of a [rows][cols] slab. */

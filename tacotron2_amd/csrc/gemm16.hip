@@ -571,6 +571,38 @@ __global__ __launch_bounds__(256) void cast_halo16_kernel(const float* __restric
     *reinterpret_cast<uint2*>(dst + (R * (long long)(C4 * 4)) + c4 * 4) = o;
 }
 
+// bf16 weight images of nn.Conv1d (W f32 [Co][Ci][k], torch layout) for the window products above, one launch each, columns
+// k C .. Kp - 1 zero (Kp = the row length rounded up to the 64-deep k-steps; the windows' overhang meets zeros):
+//   forward   out[co][tap Ci + ci]           = W[co][ci][tap]          (reversed = 0, rows = Co, inner = Ci)
+//   dgrad     out[ci][(k - 1 - tap) Co + co] = W[co][ci][tap]          (reversed = 1, rows = Ci, inner = Co)
+// Replaces a transpose + cast (forward) and an ATen flip / permute / contiguous / cast chain (data gradient) per layer and
+// optimiser step.
+__global__ __launch_bounds__(256) void pack_conv16_kernel(const float* __restrict__ W, unsigned short* __restrict__ out, int Co, int Ci,
+                                                          int k, int Kp, int reversed) {
+    const int rows = reversed ? Ci : Co, inner = reversed ? Co : Ci;
+    const long long n = (long long)rows * Kp;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / Kp), c = (int)(i - (long long)r * Kp);
+        unsigned short v = 0;
+        if (c < k * inner) {
+            const int tap = c / inner, j = c - tap * inner;
+            const int co = reversed ? j : r, ci = reversed ? r : j, t = reversed ? k - 1 - tap : tap;
+            v = t2_f32_to_bf16(W[((long long)co * Ci + ci) * k + t]);
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int t2amd_pack_conv_bf16(const float* W, void* out, int Co, int Ci, int k, int Kp, int reversed, void* stream) {
+    T2_REQUIRE(W && out && Co > 0 && Ci > 0 && k > 0 && Kp >= k * (reversed ? Co : Ci), "pack_conv: bad arguments");
+    const long long n = (long long)(reversed ? Ci : Co) * Kp;
+    int blocks = t2_cdiv(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    T2_LAUNCH(pack_conv16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, (unsigned short*)out, Co, Ci, k, Kp, reversed);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 extern "C" int t2amd_cast_halo_bf16(const float* src, long long lds_, void* dst, long long rows, int C, int T, int pad, void* stream) {
     T2_REQUIRE(src && dst && rows > 0 && C > 0 && C % 4 == 0 && T > 0 && rows % T == 0 && pad >= 0 && lds_ % 4 == 0 &&
                    t2_aligned16(src) && t2_aligned16(dst),

@@ -402,10 +402,13 @@ def _bias_sum(run, b1, b2):
 CONV16 = os.environ.get('T2AMD_CONV16', '1') != '0'
 
 
-def _conv16_ok(run, rows, T, C):
-    """The window form needs whole utterances of T rows, a channel count the 64-deep k-steps divide (a k-step never
-    straddles two taps) and enough rows for 256-row tiles to fill the chip."""
-    return run.bf16 and CONV16 and C % 64 == 0 and T > 0 and rows % T == 0 and rows >= 4096 and not nv.validate_only()
+def _conv16_ok(run, rows, T, C, k=5):
+    """The window form needs whole utterances of T rows, image rows of whole 16-byte chunks (C % 8), a window length k C
+    whose round-up to the 64-deep k-steps stays inside the trailing halo (the weight image is zero there: an 80-channel
+    layer's 400-long window runs as 448) and enough rows for 256-row tiles to fill the chip."""
+    klen = k * C
+    return run.bf16 and CONV16 and C % 8 == 0 and T > 0 and rows % T == 0 and rows >= 4096 and not nv.validate_only() \
+        and ((klen + 63) // 64 * 64 - klen) <= (k - 1) * C
 
 
 def _conv_wgrad_kk_ok(run, rows, T, Ci, Co):
@@ -441,7 +444,7 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         rv = bufs['%s.%d.1.running_var' % (prefix, i)]
         Co, Ci, k = W.shape
         pad = (k - 1) // 2
-        Wp = run.cached('convfwd.%s.%d' % (prefix, i), [W], lambda W=W: run.pack_conv_fwd(W))
+        packed = lambda W=W, i=i: run.cached('convfwd.%s.%d' % (prefix, i), [W], lambda: run.pack_conv_fwd(W))   # noqa: E731
         y = run.empty(rows, Co)
         invstd = run.empty(Co)
         K = Ci * k
@@ -452,15 +455,15 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
             # in eval mode where mean is the running mean -- so the product has a plain epilogue and can be split along K.
             sk = max(1, min(10, K // 256))
             part = run.empty(sk, rows * Co)
-            nv.gemm(part[0].view(rows, Co), x, Wp, convA=(T, Ci, pad, 1), splitk=sk, partials=part, fast=run.fwdp)
+            nv.gemm(part[0].view(rows, Co), x, packed(), convA=(T, Ci, pad, 1), splitk=sk, partials=part, fast=run.fwdp)
             nv.splitk_reduce(part, sk, y)
-        elif _conv16_ok(run, rows, T, Ci):
+        elif _conv16_ok(run, rows, T, Ci, k):
             # bf16 mode: the convolution as a product of sliding windows of a bf16 image with zero halo rows (csrc/gemm16.hip)
-            W16 = run.cached('convfwd16.%s.%d' % (prefix, i), [W], lambda Wp=Wp: run.cast16(Wp))
+            W16 = run.cached('convfwd16.%s.%d' % (prefix, i), [W], lambda W=W: nv.pack_conv_bf16(W))
             ximg = _halo_image(run, x, T, pad)
             nv.conv16(y, ximg, W16, rows // T, T, pad, bias=bias)
         else:
-            _fg(run, y, x, Wp, bias=bias, convA=(T, Ci, pad, 1))
+            _fg(run, y, x, packed(), bias=bias, convA=(T, Ci, pad, 1))
         if training:
             mean = run.empty(Co)
             nv.bn_stats(y, run.ws(Co), mean, invstd, rm, rv, BN_MOMENTUM, BN_EPS)
@@ -477,7 +480,11 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         nv.bn_act_fwd(y, z, mean, invstd, gamma, beta, acts[i],
                       keep.view(rows, Co) if keep is not None else None, 2.0, lens, T if lens is not None else 0)
         saved.append(dict(x=x, y=y, z=z, mean=mean, invstd=invstd, keep=keep, W=W, act=acts[i], layer=i,
-                          ximg=ximg if (training and WGRAD_KK) else None))     # the weight gradient multiplies it again
+                          # the weight gradient multiplies the image again -- except the stack's own input: the reference
+                          # masks mel_outputs IN PLACE after the postnet has run (model.py:491-495, `.data.masked_fill_`), so
+                          # autograd's saved input of the first postnet convolution is the MASKED one; the backward therefore
+                          # rebuilds layer 0's image from the slab as it is by then
+                          ximg=ximg if (training and WGRAD_KK and i > 0) else None))
         x = z
     return x, saved
 
@@ -522,20 +529,19 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
         grads['%s.%d.0.conv.weight' % (prefix, i)] = dW
         # data gradient
         if i > 0 or first_dx is not None:
-            Wd = run.cached('convdgrad.%s.%d' % (prefix, i), [W], lambda W=W: run.pack_conv_dgrad(W))
             if i == 0:
                 dx = first_dx
                 acc = first_dx_accumulate
             else:
                 dx = run.empty(rows, Ci)
                 acc = False
-            if _conv16_ok(run, rows, T, Co):
+            if _conv16_ok(run, rows, T, Co, k):
                 # dx[r][ci] = sum_{tap, co} g[r + pad - tap][co] W[co][ci][tap]: windows of g's halo image against the
                 # tap-reversed weights [Ci][k Co]
-                Wd16 = run.cached('convdgrad16.%s.%d' % (prefix, i), [W], lambda W=W: W.flip(2).permute(1, 2, 0).reshape(
-                    W.shape[1], W.shape[2] * W.shape[0]).contiguous().to(torch.bfloat16))
+                Wd16 = run.cached('convdgrad16.%s.%d' % (prefix, i), [W], lambda W=W: nv.pack_conv_bf16(W, reversed=True))
                 nv.conv16(dx, gimg if gimg is not None else _halo_image(run, g, T, pad), Wd16, rows // T, T, pad, accumulate=acc)
             else:
+                Wd = run.cached('convdgrad.%s.%d' % (prefix, i), [W], lambda W=W: run.pack_conv_dgrad(W))
                 _ng(run, dx, g, Wd, accumulate=acc, convA=(T, Co, pad, -1))
             g = dx
     return g

@@ -259,7 +259,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
     "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
-    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_splitk_reduce2d_f32", "t2amd_gemm16_tn", "t2amd_gemm16_kk", "t2amd_gemm16_kk_group", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16",
+    "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_splitk_reduce2d_f32", "t2amd_gemm16_tn", "t2amd_gemm16_kk", "t2amd_gemm16_kk_group", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16", "t2amd_pack_conv_bf16",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
@@ -297,6 +297,7 @@ def _argtypes():
         "t2amd_gemm16_kk_group": [pt(Gemm16Desc), _I, _P],
         "t2amd_transpose_cast_bf16": [_P, _I, _L, _P, _L, _I, _I, _I, _P],
         "t2amd_cast_halo_bf16": [_P, _L, _P, _L, _I, _I, _I, _P],
+        "t2amd_pack_conv_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
         "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
         "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
         "t2amd_bn_act_fwd_f32": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _L, _F, _P, _I, _P],
@@ -654,12 +655,15 @@ def conv16(Cm, img16, W16, B, T, pad, bias=None, accumulate=False):
     Ci = img16.shape[1]
     Tp = T + 2 * pad
     pw, ldw, Co, K = _mat(W16, torch.bfloat16)
-    if img16.shape[0] < B * Tp + 2 * pad or K != (2 * pad + 1) * Ci or Cm.shape[0] != B * T or Cm.shape[1] != Co:
+    # K may be the window length k Ci rounded up to the 64-deep k-steps (zero weight columns, pack_conv_bf16): the overhang of
+    # the last real window, row (B - 1) Tp + T - 1, must stay inside the image's trailing 2 pad halo rows
+    klen = (2 * pad + 1) * Ci
+    if img16.shape[0] < B * Tp + 2 * pad or K < klen or K - klen > 2 * pad * Ci or Cm.shape[0] != B * T or Cm.shape[1] != Co:
         raise NativeError("conv16: shape mismatch img=%s W=%s C=%s" % (tuple(img16.shape), tuple(W16.shape), tuple(Cm.shape)))
     d.A, d.lda = ptr(_fullc(img16), torch.bfloat16), Ci
     d.B, d.ldb = pw, ldw
     d.C, d.ldc = _mat(Cm)[:2]
-    d.M, d.N, d.K = B * Tp, Co, K
+    d.M, d.N, d.K = (B - 1) * Tp + T, Co, K             # window rows up to the last real output (the rest would be discarded)
     d.splitk, d.accumulate, d.bias = 1, 1 if accumulate else 0, ptr(bias)
     d.win_T, d.win_Tp = T, Tp
     _check(lib.t2amd_gemm16_tn(C.byref(d), _stream()), "t2amd_gemm16_tn")
@@ -713,6 +717,18 @@ def gemm16_kk_group(problems):
     writes = [kw['partials'] if kw.get('partials') is not None else kw['Cm'] for kw in problems]
     if not _via_ops("wgrad_gemm16", [arr], reads, writes):
         _check(load().t2amd_gemm16_kk_group(arr, len(problems), _stream()), "t2amd_gemm16_kk_group")
+
+
+def pack_conv_bf16(W, reversed=False):
+    """bf16 image of a Conv1d weight (Co, Ci, k) for the window mode: [Co][Kp] rows (tap, ci) for the forward, or, with
+    ``reversed``, [Ci][Kp] rows (k - 1 - tap, co) for the data gradient; Kp = the row length rounded up to 64, zero behind it."""
+    Co, Ci, k = W.shape
+    rows, inner = (Ci, Co) if reversed else (Co, Ci)
+    Kp = (k * inner + 63) // 64 * 64
+    out = torch.empty(rows, Kp, dtype=torch.bfloat16, device=W.device)
+    _check(load().t2amd_pack_conv_bf16(ptr(_fullc(W)), ptr(out, torch.bfloat16), Co, Ci, k, Kp, 1 if reversed else 0, _stream()),
+           "t2amd_pack_conv_bf16")
+    return out
 
 
 def cast_halo_bf16(src, dst, T, pad):

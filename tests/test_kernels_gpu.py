@@ -996,7 +996,8 @@ def test_transpose_cast_bf16(nv, rows, cols, rpad):
         assert torch.all(dst[:, rpad:].cpu() == 7.0)
 
 
-@pytest.mark.parametrize("B,T,Ci,Co,k", [(3, 37, 64, 96, 5), (5, 200, 128, 300, 5), (2, 9, 64, 64, 3)])
+@pytest.mark.parametrize("B,T,Ci,Co,k", [(3, 37, 64, 96, 5), (5, 200, 128, 300, 5), (2, 9, 64, 64, 3), (4, 60, 80, 512, 5), (3, 41, 512, 80, 5),
+                                         (2, 5, 40, 40, 3)])
 def test_conv16_window_product_matches_conv1d(nv, B, T, Ci, Co, k):
     """nn.Conv1d over channel-last rows as a product of sliding windows of a bf16 image with zero halo rows (gemm16 window
     mode): equals F.conv1d on the bf16-rounded operands, utterance by utterance (nothing leaks across the halos), with
@@ -1014,7 +1015,11 @@ def test_conv16_window_product_matches_conv1d(nv, B, T, Ci, Co, k):
     for b_ in range(B):
         halo[b_ * (T + 2 * pad) + pad:b_ * (T + 2 * pad) + pad + T] = False
     assert torch.all(img.cpu()[halo] == 0) and torch.isfinite(img.float()).all()
-    Wp16 = W.permute(0, 2, 1).reshape(Co, k * Ci).contiguous().bfloat16().to(DEV)          # [co][tap Ci + ci]
+    Wp16 = nv.pack_conv_bf16(dv(W))                                                       # [co][tap Ci + ci], zero behind k Ci
+    Kp = (k * Ci + 63) // 64 * 64
+    want = torch.zeros(Co, Kp, dtype=torch.bfloat16)
+    want[:, :k * Ci] = W.permute(0, 2, 1).reshape(Co, k * Ci).bfloat16()
+    assert torch.equal(Wp16.cpu(), want)
     y = torch.full((B * T, Co), float('nan'), device=DEV)
     nv.conv16(y, img, Wp16, B, T, pad, bias=dv(bias))
     tol = 3e-6 * (k * Ci) ** 0.5 * float(ref.abs().max())
@@ -1025,10 +1030,13 @@ def test_conv16_window_product_matches_conv1d(nv, B, T, Ci, Co, k):
     g = rnd(B * T, Co, seed=323)
     gb = g.bfloat16().float()
     dref = F.conv_transpose1d(gb.view(B, T, Co).transpose(1, 2), Wb, padding=pad).transpose(1, 2).reshape(B * T, Ci)
-    if Co % 64 == 0:
+    if Co % 8 == 0:
         gimg = torch.full((B * (T + 2 * pad) + 2 * pad, Co), float('nan'), dtype=torch.bfloat16, device=DEV)
         nv.cast_halo_bf16(dv(g), gimg, T, pad)
-        Wd16 = W.flip(2).permute(1, 2, 0).reshape(Ci, k * Co).contiguous().bfloat16().to(DEV)
+        Wd16 = nv.pack_conv_bf16(dv(W), reversed=True)                                    # [ci][(k - 1 - tap) Co + co]
+        wantd = torch.zeros(Ci, (k * Co + 63) // 64 * 64, dtype=torch.bfloat16)
+        wantd[:, :k * Co] = W.flip(2).permute(1, 2, 0).reshape(Ci, k * Co).bfloat16()
+        assert torch.equal(Wd16.cpu(), wantd)
         dx = torch.full((B * T, Ci), float('nan'), device=DEV)
         nv.conv16(dx, gimg, Wd16, B, T, pad)
         assert (dx.cpu() - dref).abs().max().item() < 3e-6 * (k * Co) ** 0.5 * float(dref.abs().max())

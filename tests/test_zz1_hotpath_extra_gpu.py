@@ -303,3 +303,49 @@ def test_attention_handoff_timeouts_are_reported_and_handled(native_lib, capfd):
         native.set_attn_fwd_fused(-1)
         native.set_attn_bwd_fused(-1)
         native.set_bptt_cell_fold(fold0)
+
+
+def test_weight_gradient_routes_agree_including_the_masked_postnet_input(native_lib):
+    """bf16 mode: the weight gradients straight from the K-major slabs / halo images (engine.WGRAD_KK, gemm16_kk with
+    transposing LDS reads) against round 2's route (transposed copies + f32-source convolution gradients) on one model, batch
+    and dropout seed, at a size where both are active (postnet rows >= 4096).  Both round the same operands to bf16, so every
+    gradient agrees to summation order -- including the FIRST postnet convolution's, whose saved input the reference masks in
+    place after the forward (model.py:491-495): an image kept from the forward would be the unmasked one (98 % off)."""
+    from tacotron2_amd import engine
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    from tacotron2_amd.model import Tacotron2
+    from tacotron2_amd.synth import synth_batch
+    dev = torch.device("cuda", 0)
+    hp = create_hparams()
+    hp.batch_size = 8
+    torch.manual_seed(hp.seed)
+    model = Tacotron2(hp).to(dev)
+    model.precision = "bf16"
+    model.train()
+    criterion = Tacotron2Loss()
+    batch = tuple(t.to(dev) for t in synth_batch(8, 4321))
+    start = engine.WGRAD_KK
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def grads_of(kk):
+        engine.WGRAD_KK = kk
+        model.load_state_dict(sd)
+        torch.manual_seed(5)
+        model.zero_grad()
+        x, y = model.parse_batch(batch)
+        loss = criterion(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.item()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    try:
+        l1, g1 = grads_of(True)
+        l0, g0 = grads_of(False)
+    finally:
+        engine.WGRAD_KK = start
+    assert batch[2].shape[2] * 8 >= 4096                         # the window / K-major routes were the ones running
+    assert l1 == l0
+    rel = {k: float((g1[k] - g0[k]).abs().max() / g0[k].abs().max().clamp_min(1e-30)) for k in g0}
+    worst = max(rel, key=rel.get)
+    assert rel[worst] < 2e-5, (worst, rel[worst])
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
