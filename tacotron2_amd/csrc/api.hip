@@ -248,6 +248,20 @@ extern "C" int t2amd_debug_hold_cus_(int ncus, float ms, const int* stop, int* a
     return T2AMD_OK;
 }
 
+// A HIP stream whose kernels run on CUs [first, first + count) only (hipExtStreamCreateWithCUMask): lets a latency-bound
+// chain of small launches and a throughput product run side by side without competing for the same CUs.
+extern "C" void* t2amd_debug_stream_cu_range_(int first, int count) {
+    if (first < 0 || count <= 0 || first + count > 1024) return nullptr;
+    uint32_t mask[32] = {0};
+    for (int i = first; i < first + count; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, 32, mask) != hipSuccess) return nullptr;
+    return (void*)s;
+}
+extern "C" int t2amd_debug_stream_destroy_(void* stream) {
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? T2AMD_OK : T2AMD_ERR_LAUNCH;
+}
+
 // tools/microbench_launch.py: the same chain captured once into a hipGraph and replayed `reps` times; returns the
 // average milliseconds per replay (HIP events on `stream`), or a negative HIP error code.
 extern "C" float t2amd_debug_graph_chain_(float* p, int n, int blocks, int reps, void* stream) {
