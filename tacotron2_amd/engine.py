@@ -1245,6 +1245,11 @@ def _folded_projection(run, P, hp, Wpg, bpg):
                                   P['decoder.gate_layer.linear_layer.bias']], fold)
 
 
+# Batches of up to this many utterances are decoded one utterance after the other on the persistent single-utterance kernel
+# (T2AMD_SMALL_BATCH_PERSISTENT=1 keeps them on the launch chain; measured: tools/bench_infer.py --small)
+SMALL_BATCH_PERSISTENT = int(os.environ.get('T2AMD_SMALL_BATCH_PERSISTENT', '3'))
+
+
 def _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat, bias_a, bias_d, Wq, U,
                        vvec, Wpg, bpg, i16, Ti):
     """reference model.py:435-449 (Decoder.inference loop) for B == 1 as one persistent launch.  Returns False when the
@@ -1515,6 +1520,30 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     if B == 1 and not ragged and Ha == Hd and PERSISTENT_DECODE and not nv.validate_only():
         ran_persistent = _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat,
                                             bias_a, bias_d, Wq, U, vvec, Wpg, bpg, i16 if run.bf16 else None, Ti)
+    elif 2 <= B <= SMALL_BATCH_PERSISTENT and Ha == Hd and PERSISTENT_DECODE and not nv.validate_only():
+        # Two (or three) utterances: the launch chain's matrix-vector step costs ~38 us whatever B <= 8 is, the persistent
+        # kernel 12 us per utterance and step -- so the utterances are decoded ONE AFTER THE OTHER on the persistent kernel,
+        # each against its own rows of the encoder memory and of the dropout stream (rows of a batch never interact in
+        # Decoder.inference, reference model.py:418-454), and their outputs land in the batch's arrays.
+        lens_host = lens32.tolist()
+        ran_persistent = True
+        for b in range(B):
+            Tb = int(lens_host[b])
+            st_b = dict(PG=run.zeros(max_steps, 1, Cm + 1), ALIGN=run.zeros(1, max_steps, Tb))
+            ol_b = torch.zeros(1, dtype=torch.int32, device=dev)
+            if not _decode_persistent(model, run, P, hp, memory[b, :Tb], pm[b, :Tb], keep[:, :, b:b + 1].contiguous(), st_b, ol_b,
+                                      Wa_cat, Wd_cat, bias_a, bias_d, Wq, U, vvec, Wpg, bpg, i16 if run.bf16 else None, Tb):
+                ran_persistent = False
+                break
+            st['PG'][:, b] = st_b['PG'][:, 0]
+            st['ALIGN'][b, :, :Tb] = st_b['ALIGN'][0]
+            out_lengths[b:b + 1] = ol_b
+        if ran_persistent:
+            model.last_decode_path = 'persistent (%d utterances, one after the other)' % B
+        else:
+            nv.fill(st['PG'], 0.0)
+            nv.fill(st['ALIGN'], 0.0)
+            out_lengths.zero_()
     # ---- the launch chain, with early-exit compaction of the batch -----------------------------------
     # Finished utterances keep occupying every launch until the slowest one stops.  At a poll, once enough of them
     # have finished to free a 64-row tile of the LSTM kernels (or to reach the matrix-vector kernels of B <= 8), the

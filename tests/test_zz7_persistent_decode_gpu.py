@@ -304,3 +304,75 @@ def test_persistent_encoder_bilstm_matches_launch_chain_and_oracle(native_lib, T
     for nm in rows:
         assert rows[nm]["vs_oracle_mean"] < 1e-4 and rows[nm]["vs_oracle_max"] < 5e-4 * max(1.0, rows[nm]["refmax"]), (nm, rows)
         assert rows[nm]["vs_chain_max"] < 1e-4 * max(1.0, rows[nm]["refmax"]), (nm, rows)
+
+
+@pytest.mark.parametrize("precision,B", [("bf16", 2), ("fp32", 3)])
+def test_two_or_three_utterances_decode_one_after_the_other_on_the_persistent_kernel(native_lib, precision, B):
+    """B = 2 / 3 ragged texts: the engine decodes the utterances consecutively on the single-utterance persistent kernel, each
+    against its own rows of the encoder memory and of the dropout stream (engine.SMALL_BATCH_PERSISTENT; 12 us per utterance
+    and step against the launch chain's ~38 us per step).  Real gate stops: the same stop frame per utterance as the launch
+    chain, outputs as close to the chain's as the single-utterance kernel's are, and against the oracle's batched inference
+    the fp32 form holds the parity tolerance."""
+    from tacotron2_amd import engine
+    steps = 96
+    hp = gu.make_hparams("max_decoder_steps=%d" % steps)
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    in_lens = [61, 40, 23][:B]
+    text = gu.make_text(in_lens, 9)
+    lens = torch.tensor(in_lens)
+    keep = orc.draw_masks_infer(hp, B, steps, torch.Generator().manual_seed(12))
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()
+    wg[:, hp.decoder_rnn_dim:] *= -1.0                       # gate trajectories that move (as in the single-utterance tests)
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    # a threshold every utterance crosses for the first time at a frame of its own, with the widest margin the forced
+    # trajectories of the oracle offer (the bf16 route's gate noise is ~1e-3)
+    (_, _, ogate, _), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0, input_lengths=lens)
+    probs = torch.sigmoid(ogate.double().reshape(B, -1))
+    best = None
+    for cand in probs[:, 4:80].reshape(-1).tolist():
+        for thr_ in (cand - 2e-3, cand + 2e-3):
+            first, margin = [], 1.0
+            for b in range(B):
+                over = (probs[b] > thr_).nonzero()
+                if over.numel() == 0:
+                    first = None
+                    break
+                t0 = int(over[0])
+                first.append(t0)
+                margin = min(margin, float((probs[b, :t0 + 1] - thr_).abs().min()))
+            if first is None or min(first) < 3 or len(set(first)) < 2:
+                continue
+            if best is None or margin > best[0]:
+                best = (margin, thr_, first)
+    assert best is not None and best[0] > 5e-4, best
+    thr = best[1]
+    hp.gate_threshold = thr
+    (omel, opost, ogate, oalign), olen, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, thr, input_lengths=lens)
+    model = _model(hp, sd, precision)
+    model.dropout_masks = dict(prenet_infer=keep.to(DEV))
+    outs = {}
+    old = engine.SMALL_BATCH_PERSISTENT
+    try:
+        for route, cap in (("persistent", 3), ("chain", 1)):
+            engine.SMALL_BATCH_PERSISTENT = cap
+            with torch.no_grad():
+                o = model.inference(text.to(DEV), lens.to(DEV))
+            torch.cuda.synchronize()
+            outs[route] = ([t.float().cpu() for t in o], model.last_inference_lengths.cpu().tolist(), model.last_decode_path)
+    finally:
+        engine.SMALL_BATCH_PERSISTENT = old
+    (p, plen, ppath), (c, clen, cpath) = outs["persistent"], outs["chain"]
+    assert ppath.startswith('persistent (%d utterances' % B), ppath
+    assert cpath.startswith('launch chain'), cpath
+    assert plen == clen, (plen, clen)
+    assert len(set(plen)) > 1 or B == 1                      # the utterances really stop at different frames
+    if precision == "fp32":
+        assert plen == [int(v) for v in olen.tolist()], (plen, olen)
+    T = min(p[0].shape[2], c[0].shape[2])
+    for i, nm in enumerate(("mel", "mel_post")):
+        d = (p[i][:, :, :T] - c[i][:, :, :T]).abs()
+        assert float(d.max()) < (2e-4 if precision == "fp32" else 5e-2), (nm, float(d.max()))
+    if precision == "fp32":
+        To = min(T, omel.shape[2])
+        assert float((p[0][:, :, :To] - omel[:, :, :To]).abs().max()) < 1e-4
+    assert all(torch.isfinite(t).all() for t in p)

@@ -18,7 +18,10 @@ native.load()
 PREC = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "fp32"
 out = {"precision": PREC}
 ONLY = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None      # e.g. --only config5_B256
-for name, B, steps in (("config4_B1", 1, 1000), ("B16", 16, 400), ("B64", 64, 400), ("config5_B256", 256, 400)):
+CASES = (("config4_B1", 1, 1000), ("B16", 16, 400), ("B64", 64, 400), ("config5_B256", 256, 400))
+if "--small" in sys.argv:        # B = 2 .. 8: the launch chain against consecutive single-utterance persistent decodes
+    CASES = tuple(("B%d" % b, b, 400) for b in (2, 3, 4, 8))
+for name, B, steps in CASES:
     if ONLY and name not in ONLY:
         continue
     hp = create_hparams()
@@ -45,7 +48,8 @@ for name, B, steps in (("config4_B1", 1, 1000), ("B16", 16, 400), ("B64", 64, 40
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     T = o[0].shape[2]
-    out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt, "utterance_steps_per_s": B * T / dt}
+    out[name] = {"B": B, "steps": T, "seconds": dt, "decode_steps_per_s": T / dt, "utterance_steps_per_s": B * T / dt,
+                 "decode_path": m.last_decode_path}
     print(name, json.dumps(out[name]), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/bench_infer_%s%s.json" % (PREC, "_" + "_".join(ONLY) if ONLY else ""), "w"), indent=1)
