@@ -409,3 +409,20 @@ def test_bench_stdout_line_is_compact_and_complete():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in line["cpu_baseline"], k
     assert "workload" in line["config"] and "model" not in line["config"]
+
+
+def test_splitk_model_of_the_bf16_resident_products():
+    """engine._choose_splitk16 (a time model fitted to rocprofv3 dispatch times): a product that fills the chip
+    takes no split, one of a few tiles over a 55 k-deep K takes dozens (the old whole-rounds heuristic gave the 512 x 400
+    weight gradient of the first postnet layer ONE split: 1.2 ms for 23 GFLOP), every slab keeps at least 8 tile steps."""
+    from tacotron2_amd import engine
+    K = 55680
+    assert engine._choose_splitk16(55680, 4096, 256) == 1                 # 3488 tiles: nothing to gain
+    assert engine._choose_splitk16(8192, 8192, 8192) == 1
+    few = engine._choose_splitk16(512, 400, K)                            # 4 tiles
+    assert 32 <= few <= 64
+    assert 6 <= engine._choose_splitk16(512, 2560, K) <= 24               # 20 tiles
+    for M, N in ((4096, 1792), (4096, 2560), (512, 2560), (80, 2560), (512, 400), (4096, 256)):
+        s = engine._choose_splitk16(M, N, K)
+        assert 1 <= s <= 64 and ((K + 63) // 64) // s >= 8, (M, N, s)
+    assert engine._choose_splitk16(512, 2560, 640) == 1                   # a shallow K cannot be split at all
