@@ -406,11 +406,15 @@ def main():
         frames.append(int(b[4].sum()))
     torch.cuda.synchronize()
 
+    ITEM_EACH_STEP = os.environ.get('T2AMD_BENCH_ITEM', '0') == '1'
+
     def step(batch):
         model.zero_grad()
         x, y = model.parse_batch(batch)
         y_pred = model(x)
         loss = criterion(y_pred, y)
+        if ITEM_EACH_STEP:
+            loss.item()                 # reference train.py reads the loss back between forward and backward in every iteration
         loss.backward()
         if args.fused_optimizer:
             optimizer.step(clip_norm=hp.grad_clip_thresh)

@@ -654,6 +654,23 @@ long long t2amd_lstm_seq_persistent_mailbox_bytes(int H, int ndir);
 int t2amd_lstm_seq_persistent_supported(const t2amd_lstm_seq* p);
 int t2amd_lstm_seq_fwd2_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned long long* mailbox,
                                        int* status, void* stream);
+/* The same recurrence for a BATCH (B > 1: the training forward, batched inference) as ONE persistent launch of
+ * ndir x ceil(B / 32) x H/4 co-resident workgroups: each keeps its 16 gate rows of W_hh in registers as exact-f32 MFMA
+ * fragments and the cell state of its 32 x 4 cells; h(s) is handed on through the output slab itself (write-through stores,
+ * one step counter per workgroup in `flags` -- t2amd_lstm_seq_batch_persistent_flag_bytes(B, H, ndir) bytes, zeroed by the
+ * call -- polled by the H/4 workgroups of the same direction and row group).  Writes everything the launch chain writes
+ * (out, C, GX overwritten with the activated gates): the backward is unchanged.  Exact f32 like t2amd_lstm_seq_fwd2_f32 (other
+ * summation order: ~2e-7).  Bounded spins: *status != 0 afterwards = a workgroup gave up (GPU shared?): recompute GX and run
+ * t2amd_lstm_seq_fwd2_f32.  `cus` = the device's CU count (at most 4 workgroups per CU are assumed co-resident).
+ * `poison` (may be NULL): for callers that do not read `status` back -- the training step, where a host sync per step would
+ * tie the step time to the host's enqueue speed -- a give-up writes NaN to *poison behind the launch (the step goes non-finite
+ * and is skipped like an abandoned attention hand-off) and t2amd_encoder_handoff_timeouts() counts it. */
+long long t2amd_lstm_seq_batch_persistent_flag_bytes(int B, int H, int ndir);
+int t2amd_lstm_seq_batch_persistent_supported(const t2amd_lstm_seq* p, int ndir, int cus);
+int t2amd_lstm_seq_fwd2_batch_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned* flags, int* status,
+                                             float* poison, void* stream);
+/* give-ups of that launch since the last reset (synchronises the device); negative on a runtime error */
+int t2amd_encoder_handoff_timeouts(int reset);
 
 /* Free-running decoder (reference model.py:418-454 Decoder.inference), any B: per-utterance
  * stop flags on the device, stop test sigmoid(gate) > threshold (strict) after the frame is

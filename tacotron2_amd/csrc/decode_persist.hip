@@ -965,3 +965,235 @@ extern "C" int t2amd_lstm_seq_fwd2_persistent_f32(const t2amd_lstm_seq* p, const
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// The same recurrence for a BATCH (training forward at B = 64, batched inference) as one persistent launch.
+// Workgroup (direction, row group of 32 utterances, unit group k of 4 hidden units) keeps its 16 gate rows of W_hh in
+// registers as MFMA B-fragments for the whole sequence and owns the cell state of its 32 x 4 cells.  Per step it needs
+// h(s-1) of its 32 rows -- all H units, produced by the H/4 workgroups of its own (direction, row group) -- multiplies
+// [32 x H] . [H x 16] on the exact-f32 MFMA (each wave a quarter of K, partial sums through LDS) and runs the cell.
+// Hand-off = the guide's R1 form (Guideline 16): h is stored write-through (sc1), every storing wave drains its stores,
+// ONE lane stores the workgroup's step counter; consumers poll the H/4 counters of their group (one wave, relaxed), then
+// read h with sc1 loads.  h(s) lives in the output slab itself: every row is written once, nothing is double-buffered.
+// Rows of a batch never interact, so a row group only ever waits for its own H/4 workgroups.  Bounded spins as above.
+// ---------------------------------------------------------------------------------------
+#define EB_NT 256
+#define EB_ROWS 32
+
+struct EncBatchParams {
+    t2amd_lstm_seq d[2];
+    int ndir, nrg, nk;                   // directions, row groups, unit groups (H / 4)
+    unsigned* flags;                     // [ndir][nrg][nk] step counters, zeroed by the call
+    int* status;
+    long long timeout_ticks;
+    int delay;                           // s_sleep units (64 clocks) before the first poll of a step
+};
+
+__device__ __forceinline__ void eb_store_sc1(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 eb_load_sc1(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(EB_NT) void encoder_bilstm_batch_persistent_kernel(EncBatchParams p) {
+    __shared__ __attribute__((aligned(16))) float red_s[4][2][16][17];     // [k quarter][row tile][row][gate col (+1 pad)]
+    __shared__ int fail_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_dir = p.nrg * p.nk;
+    const int dir = (int)blockIdx.x / per_dir, rg = ((int)blockIdx.x % per_dir) / p.nk, k = (int)blockIdx.x % p.nk;
+    const t2amd_lstm_seq& a = p.d[dir];
+    const int H = a.H, T = a.T, B = a.B;
+    unsigned* const flags = p.flags + ((size_t)dir * p.nrg + rg) * p.nk;
+    const int r0 = rg * EB_ROWS;
+    // B-fragments of this wave's k quarter [64 wave, 64 wave + 64): MFMA (i, e) multiplies k = 64 wave + 16 i + 4 (lane >> 4) + e;
+    // gate column n = lane & 15 = 4 u + g  ->  row g H + 4 k + u of W_hh
+    const int n = lane & 15, kq = lane >> 4;
+    float wb[4][4];
+    {
+        const float* row = a.Whh + ((long long)(n & 3) * H + 4 * k + (n >> 2)) * H + 64 * wave + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = (64 * wave + 16 * i + 4 * kq + 3 < H) ? *reinterpret_cast<const f32x4*>(row + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            wb[i][0] = v[0]; wb[i][1] = v[1]; wb[i][2] = v[2]; wb[i][3] = v[3];
+        }
+    }
+    // the cell this thread owns (threads 0..127): row r0 + (tid >> 2), unit 4 k + (tid & 3)
+    const int crow = r0 + (tid >> 2), cu = 4 * k + (tid & 3);
+    const bool cell = tid < 128 && crow < B;
+    const int len = cell ? a.lens[crow] : 0;
+    float c = 0.f;
+    if (tid == 0) fail_s = 0;
+    __syncthreads();
+    // A-fragment rows of this lane: r0 + 16 mt + (lane & 15), clamped (padding rows are never stored)
+    int arow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { const int r = r0 + 16 * mt + (lane & 15); arow[mt] = r < B ? r : B - 1; }
+
+    for (int s = 0; s < T; ++s) {
+        const int t = a.reverse ? T - 1 - s : s;
+        const int tp = a.reverse ? t + 1 : t - 1;
+        float gin[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell) {
+            const float* g = a.GX + ((long long)crow * T + t) * 4 * H + cu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gin[q] = g[(long long)q * H];
+        }
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (s > 0) {
+            if (wave == 0) {                                      // one wave polls the group's counters (relaxed, agent scope)
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                bool bad = false;
+                // a short pause first: 64 workgroups polling the two cache lines of their group's counters delay the very
+                // stores they wait for (the decode kernel's lesson)
+                for (int d_ = 0; d_ < p.delay; ++d_) __builtin_amdgcn_s_sleep(1);
+                for (;;) {
+                    bool ok = true;
+                    for (int j = lane; j < p.nk; j += 64)
+                        ok = ok && __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)s;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 31u) == 0 && pb_give_up(t0, p.status, p.timeout_ticks)) { bad = true; break; }
+                }
+                if (bad && lane == 0) fail_s = 1;
+            }
+            __syncthreads();
+            if (fail_s) return;
+            // h(s-1) of this lane's two rows, this wave's k quarter: 4 x 16 bytes per row tile, straight from L2 (sc1)
+            f32x4 hv[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float* hp = a.out + ((long long)arow[mt] * T + tp) * a.ld_out + 64 * wave + 4 * kq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    hv[mt][i] = (64 * wave + 16 * i + 4 * kq + 3 < H) ? eb_load_sc1(hp + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // the wait is tied to the loaded registers: the MFMAs below cannot be scheduled in front of it
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(hv[0][0]), "+v"(hv[0][1]), "+v"(hv[0][2]), "+v"(hv[0][3]), "+v"(hv[1][0]), "+v"(hv[1][1]), "+v"(hv[1][2]),
+                           "+v"(hv[1][3]) : : "memory");
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[mt][i][e], wb[i][e], acc[mt], 0, 0, 0);
+        }
+        // D layout of the 16 x 16 MFMA: lane -> column n, register r -> row 4 (lane >> 4) + r
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red_s[wave][mt][4 * kq + r][n] = acc[mt][r];
+        __syncthreads();
+        float h = 0.f, sg[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cell) {
+            const int lr = tid >> 2, u = tid & 3;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pre[g] = ((red_s[0][lr >> 4][lr & 15][4 * u + g] + red_s[1][lr >> 4][lr & 15][4 * u + g]) +
+                          (red_s[2][lr >> 4][lr & 15][4 * u + g] + red_s[3][lr >> 4][lr & 15][4 * u + g])) + gin[g];
+            float gi = t2_sigmoid(pre[0]), gf = t2_sigmoid(pre[1]), gg = tanhf(pre[2]), go = t2_sigmoid(pre[3]);
+            float cn = gf * c + gi * gg;
+            h = go * tanhf(cn);
+            if (t >= len) { gi = gf = gg = go = 0.f; cn = 0.f; h = 0.f; }     // packed-sequence semantics (model.py:180-188)
+            c = cn;
+            sg[0] = gi; sg[1] = gf; sg[2] = gg; sg[3] = go;
+        }
+        // the four units of a row sit in four neighbouring lanes: one 16-byte write-through store per row (R1 payload)
+        {
+            const float h1 = __shfl_down(h, 1), h2 = __shfl_down(h, 2), h3 = __shfl_down(h, 3);
+            if (cell && (tid & 3) == 0)
+                eb_store_sc1(a.out + ((long long)crow * T + t) * a.ld_out + 4 * k, f32x4{h, h1, h2, h3});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores (R1) ...
+        __syncthreads();                                             // ... (and red_s may be rewritten)
+        if (tid == 0) __hip_atomic_store(flags + k, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cell) {                                                  // what only the backward reads goes out behind the flag
+            float* g = a.GX + ((long long)crow * T + t) * 4 * H + cu;
+            g[0] = sg[0]; g[(long long)H] = sg[1]; g[2ll * H] = sg[2]; g[3ll * H] = sg[3];
+            a.C[((long long)t * B + crow) * H + cu] = c;
+        }
+    }
+}
+
+// Give-ups of the launch above since the last reset.  The training step does not read `status` back (a host sync at the
+// top of every step makes the step time follow the host's enqueue speed); instead a one-thread launch behind the kernel
+// turns a give-up into a NaN in the step's data -- the step goes non-finite, is skipped by the finite-norm check like an
+// abandoned attention hand-off, and engine.handle_nonfinite_step() finds the reason here.
+__device__ unsigned int t2_enc_batch_timeouts = 0u;
+__global__ void encoder_batch_poison_kernel(const int* status, float* poison) {
+    if (*status != 0) {
+        atomicAdd(&t2_enc_batch_timeouts, 1u);
+        *poison = __builtin_nanf("");
+    }
+}
+// tests: the finishing launch alone, on a status word the caller sets
+extern "C" int t2amd_debug_encoder_poison_(const int* status, float* poison, void* stream) {
+    T2_REQUIRE(status && poison, "debug_encoder_poison: null args");
+    hipLaunchKernelGGL(encoder_batch_poison_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, status, poison);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+extern "C" int t2amd_encoder_handoff_timeouts(int reset) {
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(t2_enc_batch_timeouts), sizeof(v)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned int z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(t2_enc_batch_timeouts), &z, sizeof(z));
+    }
+    return (int)v;
+}
+
+extern "C" long long t2amd_lstm_seq_batch_persistent_flag_bytes(int B, int H, int ndir) {
+    return 4ll * ndir * ((B + EB_ROWS - 1) / EB_ROWS) * (H / 4);
+}
+
+// 0 = this geometry can run as one persistent launch here; else T2AMD_ERR_ARG with the reason
+extern "C" int t2amd_lstm_seq_batch_persistent_supported(const t2amd_lstm_seq* p, int ndir, int cus) {
+    T2_REQUIRE(p != nullptr, "lstm_seq_batch_persistent: null args");
+    T2_REQUIRE(p->H % 64 == 0 && p->H >= 64 && p->H <= 256, "lstm_seq_batch_persistent: H must be a multiple of 64, <= 256");
+    T2_REQUIRE(p->T > 0 && p->B > 0, "lstm_seq_batch_persistent: B, T");
+    const long long wgs = (long long)ndir * ((p->B + EB_ROWS - 1) / EB_ROWS) * (p->H / 4);
+    T2_REQUIRE(wgs <= 4ll * cus, "lstm_seq_batch_persistent: more workgroups than can be co-resident (4 per CU)");
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_lstm_seq_fwd2_batch_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned* flags, int* status,
+                                                        float* poison, void* stream) {
+    T2_REQUIRE(p && p->Whh && p->GX && p->out && p->C && p->lens && flags && status, "lstm_seq_batch_persistent: null pointer");
+    T2_REQUIRE(p->H % 64 == 0 && p->H >= 64 && p->H <= 256 && p->T > 0 && p->B > 0, "lstm_seq_batch_persistent: geometry");
+    T2_REQUIRE(p->ld_out % 4 == 0 && (reinterpret_cast<uintptr_t>(p->out) & 15u) == 0, "lstm_seq_batch_persistent: out must be 16-byte aligned rows");
+    if (q) T2_REQUIRE(q->T == p->T && q->H == p->H && q->B == p->B && q->Whh && q->GX && q->out && q->C && q->lens && q->ld_out % 4 == 0 &&
+                          (reinterpret_cast<uintptr_t>(q->out) & 15u) == 0, "lstm_seq_batch_persistent: the two directions must match");
+    EncBatchParams e;
+    e.d[0] = *p;
+    e.d[1] = q ? *q : *p;
+    e.ndir = q ? 2 : 1;
+    e.nrg = (p->B + EB_ROWS - 1) / EB_ROWS;
+    e.nk = p->H / 4;
+    e.flags = flags;
+    e.status = status;
+    const char* te = getenv("T2AMD_PB_TIMEOUT_TICKS");
+    e.timeout_ticks = te ? atoll(te) : PB_TIMEOUT_TICKS;
+    if (e.timeout_ticks < 1) e.timeout_ticks = 1;
+    const char* de = getenv("T2AMD_EB_DELAY");
+    e.delay = de ? atoi(de) : 16;
+    if (t2amd_validate_only_flag_()) return T2AMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(flags, 0, (size_t)t2amd_lstm_seq_batch_persistent_flag_bytes(p->B, p->H, e.ndir), s) != hipSuccess ||
+        hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess)
+        T2_FAIL("lstm_seq_batch_persistent: memset failed");
+    hipLaunchKernelGGL(encoder_bilstm_batch_persistent_kernel, dim3(e.ndir * e.nrg * e.nk), dim3(EB_NT), 0, s, e);
+    T2_LAUNCH_CHECK();
+    if (poison) {
+        hipLaunchKernelGGL(encoder_batch_poison_kernel, dim3(1), dim3(1), 0, s, status, poison);
+        T2_LAUNCH_CHECK();
+    }
+    return T2AMD_OK;
+}
+

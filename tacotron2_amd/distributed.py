@@ -302,6 +302,8 @@ def apply_gradient_allreduce(module):
                 nv.set_attn_fwd_fused(0)
                 nv.set_attn_bwd_fused(0)
                 nv.set_bptt_cell_fold(0)
+                from . import engine
+                engine.ENCODER_BATCH_PERSISTENT = False          # the persistent encoder launch spins on hand-offs too
             if dist.get_rank() == 0:
                 import sys
                 print("tacotron2_amd: %d ranks share one GPU: the separate-launch forms of the attention step are selected "

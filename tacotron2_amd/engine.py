@@ -547,6 +547,43 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
     return g
 
 
+# T2AMD_ENCODER_BATCH_PERSISTENT=0 keeps the encoder bi-LSTM of a batch on the launch chain (one launch per time step).
+# The TRAINING forward takes the persistent launch only with T2AMD_ENCODER_BATCH_PERSISTENT_TRAIN=1: the launch itself is
+# 0.5 ms shorter than its 170-launch chain (tools/ab_encoder_batch_persistent.py), but the training step gains from it only
+# in a loop that reads the loss back every iteration (train.py, as the reference's: 61.35 vs 61.72 ms per step); in a loop
+# that never synchronises (bench.py) the step measured 63.1 / 62.2 against 63.0 / 61.7 ms (profiles/r03_zd_*), so the
+# default stays the chain there.
+ENCODER_BATCH_PERSISTENT = os.environ.get('T2AMD_ENCODER_BATCH_PERSISTENT', '1') != '0'
+ENCODER_BATCH_PERSISTENT_TRAIN = os.environ.get('T2AMD_ENCODER_BATCH_PERSISTENT_TRAIN', '0') == '1'
+
+
+def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None):
+    """Both directions of the encoder bi-LSTM of a batch (reference model.py:181-188): ONE persistent launch (csrc/
+    decode_persist.hip, encoder_bilstm_batch_persistent_kernel: W_hh fragments in registers, h handed on through the output
+    slab with write-through stores + step counters) instead of T dependent launches -- 4.3 vs 7.3 us per step at B = 64.  A
+    bounded-spin give-up (its workgroups were not co-resident: a shared GPU) recomputes the pre-activations the kernel had
+    begun to overwrite (``regen_gx``), runs the launch chain and stays on it for a while.  With ``poison`` (the training
+    step) the status is NOT read back -- a host sync at the top of every step ties the step time to the host's enqueue speed
+    (measured: 72 instead of 61 ms per step in the first process on a fresh box) -- a give-up turns ``poison[0]`` into NaN
+    instead, the step goes non-finite and handle_nonfinite_step() finds the reason.  Returns the path taken."""
+    import sys
+    if ENCODER_BATCH_PERSISTENT and (poison is None or ENCODER_BATCH_PERSISTENT_TRAIN) and d0.B > 1 and not nv.validate_only():
+        if getattr(model, '_enc_batch_backoff', 0) > 0:
+            model._enc_batch_backoff -= 1
+        elif nv.lstm_seq_batch_persistent_supported(d0, 2, torch.cuda.get_device_properties(dev).multi_processor_count) is None:
+            flags = torch.empty(nv.lstm_seq_batch_persistent_flag_words(d0.B, d0.H, 2), dtype=torch.int32, device=dev)
+            status = torch.empty(1, dtype=torch.int32, device=dev)
+            nv.lstm_seq_fwd2_batch_persistent(d0, d1, flags, status, poison)
+            if poison is not None or int(status.item()) == 0:
+                return 'persistent'
+            print("tacotron2_amd: the persistent encoder kernel gave up (its workgroups were not co-resident within 30 ms -- is "
+                  "the GPU shared?); running the launch chain", file=sys.stderr, flush=True)
+            model._enc_batch_backoff = 16
+            regen_gx()
+    nv.lstm_seq_fwd2(d0, d1, reads=reads, writes=writes)
+    return 'launch chain'
+
+
 def _weight_cache(model):
     cache = getattr(model, '_weight_cache', None)
     if cache is None:
@@ -627,6 +664,18 @@ def handle_nonfinite_step(log=None):
     shared or partitioned GPU; the kernels then poison the step with NaN rather than use half-exchanged data), say so
     and select the separate-launch forms for the rest of the process -- bit-identical results, no co-residency
     assumption.  Returns the number of abandoned hand-offs (0: the non-finite values have another cause)."""
+    global ENCODER_BATCH_PERSISTENT
+    ne = nv.encoder_handoff_timeouts(reset=True)
+    if ne > 0:
+        ENCODER_BATCH_PERSISTENT = False
+        msg = ("tacotron2_amd: the persistent encoder launch gave up %d time(s) (its workgroups were not co-resident within "
+               "30 ms -- is the GPU shared or partitioned?); that step was poisoned with NaN and is skipped; the encoder "
+               "runs on the launch chain from here on" % ne)
+        if log is not None:
+            log(msg)
+        else:
+            import sys
+            print(msg, file=sys.stderr, flush=True)
     n = nv.attn_handoff_timeouts(reset=True)
     if n > 0:
         nv.set_attn_fwd_fused(0)
@@ -640,7 +689,7 @@ def handle_nonfinite_step(log=None):
         else:
             import sys
             print(msg, file=sys.stderr, flush=True)
-    return n
+    return n + ne
 
 
 def _cached_bias_sum(run, tag, b1, b2):
@@ -770,10 +819,15 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         desc.out, desc.ld_out = nv.ptr(out_view), E
         desc.C = nv.ptr(Cst)
         desc.lens = nv.ptr(lens32, torch.int32)
-        c.enc_lstm.append(dict(GX=GX, C=Cst, Whh=Whh, Wih=Wih, desc=desc))
-    nv.lstm_seq_fwd2(c.enc_lstm[0]['desc'], c.enc_lstm[1]['desc'],      # both directions, one launch per step
-                     reads=[L_[k_] for L_ in c.enc_lstm for k_ in ('Whh', 'GX')] + [lens32],
-                     writes=[memory] + [L_['C'] for L_ in c.enc_lstm])
+        c.enc_lstm.append(dict(GX=GX, C=Cst, Whh=Whh, Wih=Wih, desc=desc, bsum=bsum))
+
+    def regen_gx():
+        for L_ in c.enc_lstm:
+            _fg(run, L_['GX'], x3, L_['Wih'], bias=L_['bsum'])
+    model.last_encoder_path = _encoder_lstm_fwd(
+        model, text.device, c.enc_lstm[0]['desc'], c.enc_lstm[1]['desc'], regen_gx,
+        reads=[L_[k_] for L_ in c.enc_lstm for k_ in ('Whh', 'GX')] + [lens32],
+        writes=[memory] + [L_['C'] for L_ in c.enc_lstm], poison=memory if training else None)
     c.x3, c.memory = x3, memory
 
     # ---- decoder: hoisted dense parts ------------------------------------------------------
@@ -1420,9 +1474,14 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         model._enc_persist_backoff -= 1
     model.last_encoder_path = 'persistent' if enc_persistent else 'launch chain'
     if not enc_persistent:
-        nv.lstm_seq_fwd2(idesc[0][0], idesc[1][0],
-                         reads=[P['encoder.lstm.weight_hh_l0'], P['encoder.lstm.weight_hh_l0_reverse'], idesc[0][1], idesc[1][1], lens32],
-                         writes=[memory, idesc[0][2], idesc[1][2]])
+        def regen_gx():
+            for d_, sfx_ in enumerate(('', '_reverse')):
+                nv.gemm(idesc[d_][1], x3, P['encoder.lstm.weight_ih_l0' + sfx_],
+                        bias=_cached_bias_sum(run, 'enc_bias' + sfx_, P['encoder.lstm.bias_ih_l0' + sfx_], P['encoder.lstm.bias_hh_l0' + sfx_]))
+        model.last_encoder_path = _encoder_lstm_fwd(
+            model, dev, idesc[0][0], idesc[1][0], regen_gx,
+            reads=[P['encoder.lstm.weight_hh_l0'], P['encoder.lstm.weight_hh_l0_reverse'], idesc[0][1], idesc[1][1], lens32],
+            writes=[memory, idesc[0][2], idesc[1][2]])
 
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
     pm = run.empty(B, Ti, A)

@@ -276,6 +276,7 @@ SYMBOLS = [
     "t2amd_set_attn_bwd_granules", "t2amd_attn_handoff_timeouts", "t2amd_set_attn_bwd_fused", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_lstm_seq_persistent_mailbox_bytes", "t2amd_lstm_seq_persistent_supported", "t2amd_lstm_seq_fwd2_persistent_f32",
+    "t2amd_lstm_seq_batch_persistent_flag_bytes", "t2amd_lstm_seq_batch_persistent_supported", "t2amd_lstm_seq_fwd2_batch_persistent_f32", "t2amd_encoder_handoff_timeouts",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
     "t2amd_decoder_persist_mailbox_bytes", "t2amd_decoder_persist_supported", "t2amd_decoder_infer_persistent_f32",
@@ -335,6 +336,10 @@ def _argtypes():
         "t2amd_lstm_seq_persistent_mailbox_bytes": [_I, _I],
         "t2amd_lstm_seq_persistent_supported": [pt(LstmSeq)],
         "t2amd_lstm_seq_fwd2_persistent_f32": [pt(LstmSeq), pt(LstmSeq), _P, _P, _P],
+        "t2amd_lstm_seq_batch_persistent_flag_bytes": [_I, _I, _I],
+        "t2amd_lstm_seq_batch_persistent_supported": [pt(LstmSeq), _I, _I],
+        "t2amd_lstm_seq_fwd2_batch_persistent_f32": [pt(LstmSeq), pt(LstmSeq), _P, _P, _P, _P],
+        "t2amd_encoder_handoff_timeouts": [_I],
         "t2amd_decoder_infer_steps_f32": [pt(DecInfer), _P],
         "t2amd_struct_sizes": [pt(C.c_int), _I],
         "t2amd_set_validate_only": [_I],
@@ -400,6 +405,7 @@ def load():
     lib.t2amd_attn_fwd_ws_floats.restype = C.c_longlong
     lib.t2amd_decoder_persist_mailbox_bytes.restype = C.c_longlong
     lib.t2amd_lstm_seq_persistent_mailbox_bytes.restype = C.c_longlong
+    lib.t2amd_lstm_seq_batch_persistent_flag_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
     sizes = (C.c_int * 32)()
@@ -1272,6 +1278,39 @@ def lstm_seq_fwd2_persistent(d0, d1, mailbox, status):
         raise NativeError("lstm_seq_fwd2_persistent: mailbox of %d bytes, %d needed" % (mailbox.numel() * mailbox.element_size(), need))
     _check(load().t2amd_lstm_seq_fwd2_persistent_f32(C.byref(d0), C.byref(d1), ptr(mailbox, torch.int64), ptr(status, torch.int32),
                                                      _stream()), "t2amd_lstm_seq_fwd2_persistent_f32")
+
+
+def lstm_seq_batch_persistent_supported(desc, ndir, cus):
+    """None when the encoder bi-LSTM of this batch can run as one persistent launch on a device of `cus` CUs, else the reason."""
+    lib = load()
+    if lib.t2amd_lstm_seq_batch_persistent_supported(C.byref(desc), int(ndir), int(cus)) == 0:
+        return None
+    msg = lib.t2amd_last_error()
+    return msg.decode() if msg else "unsupported"
+
+
+def lstm_seq_batch_persistent_flag_words(B, H, ndir=2):
+    return int(load().t2amd_lstm_seq_batch_persistent_flag_bytes(int(B), int(H), int(ndir))) // 4
+
+
+def lstm_seq_fwd2_batch_persistent(d0, d1, flags, status, poison=None):
+    """Both directions of the encoder bi-LSTM of a BATCH as one persistent launch (csrc/decode_persist.hip).  ``poison``: an
+    f32 tensor whose first element becomes NaN if a workgroup gave up (for callers that do not read ``status`` back)."""
+    lib = load()
+    need = lib.t2amd_lstm_seq_batch_persistent_flag_bytes(d0.B, d0.H, 2)
+    if flags.numel() * flags.element_size() < need:
+        raise NativeError("lstm_seq_fwd2_batch_persistent: flags of %d bytes, %d needed" % (flags.numel() * flags.element_size(), need))
+    _check(lib.t2amd_lstm_seq_fwd2_batch_persistent_f32(C.byref(d0), C.byref(d1), C.c_void_p(flags.data_ptr()), ptr(status, torch.int32),
+                                                        ptr(poison) if poison is not None else None, _stream()),
+           "t2amd_lstm_seq_fwd2_batch_persistent_f32")
+
+
+def encoder_handoff_timeouts(reset=True):
+    """Give-ups of the batched persistent encoder launch since the last reset (synchronises)."""
+    n = load().t2amd_encoder_handoff_timeouts(1 if reset else 0)
+    if n < 0:
+        raise NativeError("t2amd_encoder_handoff_timeouts failed")
+    return n
 
 
 def lstm_seq_bwd2(d0, d1, reads=None, writes=None):

@@ -349,3 +349,53 @@ def test_weight_gradient_routes_agree_including_the_masked_postnet_input(native_
     worst = max(rel, key=rel.get)
     assert rel[worst] < 2e-5, (worst, rel[worst])
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+def test_encoder_launch_give_up_poisons_the_step_and_is_reported(native_lib, capfd):
+    """The training step does not read the persistent encoder launch's status back (a host sync per step); a give-up is
+    turned into a NaN in the step's data by a one-thread launch behind the kernel and counted in the library.  Here that
+    finishing launch runs alone on a status word set by the test: nothing happens on 0; on a non-zero status the poison
+    word is NaN, the counter says 1, engine.handle_nonfinite_step() reports it, resets the counter and moves the encoder to
+    the launch chain; and a real training forward takes the persistent route with a finite result."""
+    import ctypes as C
+    from tacotron2_amd import engine, native
+    lib = native.load()
+    fn = lib.t2amd_debug_encoder_poison_
+    fn.argtypes, fn.restype = [C.c_void_p, C.c_void_p, C.c_void_p], C.c_int
+    native.encoder_handoff_timeouts(reset=True)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    word = torch.ones(4, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    assert fn(status.data_ptr(), word.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    assert torch.all(word == 1) and native.encoder_handoff_timeouts(reset=False) == 0
+    status.fill_(3)
+    assert fn(status.data_ptr(), word.data_ptr(), stream) == 0
+    torch.cuda.synchronize()
+    assert torch.isnan(word[0]) and torch.all(word[1:] == 1)
+    assert native.encoder_handoff_timeouts(reset=False) == 1
+    keep = engine.ENCODER_BATCH_PERSISTENT
+    try:
+        engine.ENCODER_BATCH_PERSISTENT = True
+        assert engine.handle_nonfinite_step() >= 1
+        assert "persistent encoder launch gave up 1 time" in capfd.readouterr().err
+        assert engine.ENCODER_BATCH_PERSISTENT is False and native.encoder_handoff_timeouts(reset=False) == 0
+        # a real training forward: the persistent route (opt-in for training), finite outputs, nothing counted
+        engine.ENCODER_BATCH_PERSISTENT = True
+        keep_train, engine.ENCODER_BATCH_PERSISTENT_TRAIN = engine.ENCODER_BATCH_PERSISTENT_TRAIN, True
+        from tacotron2_amd.loss_function import Tacotron2Loss
+        from tacotron2_amd.model import Tacotron2
+        from tacotron2_amd.synth import synth_batch
+        hp = create_hparams()
+        hp.batch_size = 4
+        torch.manual_seed(hp.seed)
+        model = Tacotron2(hp).cuda().train()
+        x, y = model.parse_batch(tuple(t.cuda() for t in synth_batch(4, 99)))
+        loss = Tacotron2Loss()(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert model.last_encoder_path == 'persistent' and bool(torch.isfinite(loss))
+        assert native.encoder_handoff_timeouts(reset=False) == 0
+        engine.ENCODER_BATCH_PERSISTENT_TRAIN = keep_train
+    finally:
+        engine.ENCODER_BATCH_PERSISTENT = keep

@@ -376,3 +376,53 @@ def test_two_or_three_utterances_decode_one_after_the_other_on_the_persistent_ke
         To = min(T, omel.shape[2])
         assert float((p[0][:, :, :To] - omel[:, :, :To]).abs().max()) < 1e-4
     assert all(torch.isfinite(t).all() for t in p)
+
+
+@pytest.mark.parametrize("B,T", [(64, 61), (7, 23), (40, 9), (256, 50)])
+def test_batched_encoder_bilstm_persistent_matches_the_launch_chain(native_lib, B, T):
+    """Encoder bi-LSTM of a batch (reference model.py:181-188, packed-sequence semantics) as ONE persistent launch -- W_hh
+    fragments in registers, h handed on through the output slab (write-through stores + step counters) -- against the launch
+    chain on the same ragged batch: h, cell states and the activated gates the backward reads agree to summation order (both
+    exact f32), rows behind an utterance's length are zero in both, partial row groups (B = 7, 40) included."""
+    from tacotron2_amd import native as nv
+    H, E = 256, 512
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    lens = torch.randint(max(1, T // 3), T + 1, (B,), generator=g).sort(descending=True)[0].to(torch.int32)
+    lens[0] = T
+    lens = lens.to(DEV)
+    Whh = [(torch.randn(4 * H, H, generator=g) * 0.06).to(DEV) for _ in range(2)]
+    GX0 = [(torch.randn(B * T, 4 * H, generator=g) * 0.5).to(DEV) for _ in range(2)]
+
+    def run(persistent):
+        mem = torch.full((B, T, E), float('nan'), device=DEV)
+        descs, keep = [], []
+        for d in range(2):
+            GX, Cst = GX0[d].clone(), torch.full((T, B, H), float('nan'), device=DEV)
+            desc = nv.LstmSeq()
+            desc.B, desc.T, desc.H, desc.reverse = B, T, H, d
+            desc.Whh, desc.GX = nv.ptr(Whh[d]), nv.ptr(GX)
+            ov = mem.view(B * T, E)[:, d * H:(d + 1) * H]
+            desc.out, desc.ld_out = nv.ptr(ov), E
+            desc.C, desc.lens = nv.ptr(Cst), nv.ptr(lens, torch.int32)
+            descs.append(desc)
+            keep.append((GX, Cst))
+        if persistent:
+            assert nv.lstm_seq_batch_persistent_supported(descs[0], 2, torch.cuda.get_device_properties(0).multi_processor_count) is None
+            flags = torch.full((nv.lstm_seq_batch_persistent_flag_words(B, H, 2),), 77, dtype=torch.int32, device=DEV)   # poisoned: the
+            status = torch.full((1,), 5, dtype=torch.int32, device=DEV)                                                   # call zeroes them
+            nv.lstm_seq_fwd2_batch_persistent(descs[0], descs[1], flags, status)
+            assert int(status.item()) == 0
+        else:
+            nv.lstm_seq_fwd2(descs[0], descs[1])
+        torch.cuda.synchronize()
+        return mem.cpu(), [(a.cpu(), b.cpu()) for a, b in keep]
+
+    mp, kp = run(True)
+    mc, kc = run(False)
+    assert torch.isfinite(mp).all()
+    assert (mp - mc).abs().max().item() < 2e-6
+    for d in range(2):
+        assert (kp[d][0] - kc[d][0]).abs().max().item() < 2e-6          # activated gates (GX overwritten)
+        assert (kp[d][1] - kc[d][1]).abs().max().item() < 2e-6          # cell states
+    valid = torch.arange(T).unsqueeze(0) < lens.cpu().unsqueeze(1)
+    assert torch.all(mp[~valid] == 0)
