@@ -426,3 +426,59 @@ def test_splitk_model_of_the_bf16_resident_products():
         s = engine._choose_splitk16(M, N, K)
         assert 1 <= s <= 64 and ((K + 63) // 64) // s >= 8, (M, N, s)
     assert engine._choose_splitk16(512, 2560, 640) == 1                   # a shallow K cannot be split at all
+
+
+def test_encoder_launch_routing_and_fallback_host_logic(monkeypatch):
+    """engine._encoder_lstm_fwd without a GPU (the native calls are replaced): inference reads the status back and, on a
+    give-up, recomputes the pre-activations, runs the launch chain and stays on it for 16 calls; the training forward takes
+    the persistent launch only when asked to, hands it the poison word and never reads the status; B == 1 and a refused
+    geometry go to the chain."""
+    import types
+    import torch
+    from tacotron2_amd import engine
+    calls = []
+
+    class FakeStatus(object):
+        value = 0
+
+    def fake_persistent(d0, d1, flags, status, poison=None):
+        calls.append(('persistent', poison is not None))
+        status.fill_(FakeStatus.value)
+
+    monkeypatch.setattr(engine.nv, 'validate_only', lambda: False)
+    monkeypatch.setattr(engine.nv, 'lstm_seq_batch_persistent_supported', lambda d, n, cus: None)
+    monkeypatch.setattr(engine.nv, 'lstm_seq_batch_persistent_flag_words', lambda B, H, n=2: 8)
+    monkeypatch.setattr(engine.nv, 'lstm_seq_fwd2_batch_persistent', fake_persistent)
+    monkeypatch.setattr(engine.nv, 'lstm_seq_fwd2', lambda d0, d1, reads=None, writes=None: calls.append(('chain',)))
+    monkeypatch.setattr(torch.cuda, 'get_device_properties', lambda dev: types.SimpleNamespace(multi_processor_count=256))
+    monkeypatch.setattr(engine, 'ENCODER_BATCH_PERSISTENT', True)
+    monkeypatch.setattr(engine, 'ENCODER_BATCH_PERSISTENT_TRAIN', False)
+    model = types.SimpleNamespace()
+    d = types.SimpleNamespace(B=64, H=256)
+    regen = lambda: calls.append(('regen',))                                   # noqa: E731
+    cpu = torch.device('cpu')
+    assert engine._encoder_lstm_fwd(model, cpu, d, d, regen, [], []) == 'persistent'
+    assert calls == [('persistent', False)]
+    # a give-up in inference: pre-activations recomputed, chain, back-off
+    del calls[:]
+    FakeStatus.value = 2
+    assert engine._encoder_lstm_fwd(model, cpu, d, d, regen, [], []) == 'launch chain'
+    assert calls == [('persistent', False), ('regen',), ('chain',)] and model._enc_batch_backoff == 16
+    del calls[:]
+    assert engine._encoder_lstm_fwd(model, cpu, d, d, regen, [], []) == 'launch chain'
+    assert calls == [('chain',)] and model._enc_batch_backoff == 15
+    # training: the chain unless asked; with the switch the launch gets the poison word and the status is never read
+    model2 = types.SimpleNamespace()
+    del calls[:]
+    word = torch.zeros(4)
+    assert engine._encoder_lstm_fwd(model2, cpu, d, d, regen, [], [], poison=word) == 'launch chain'
+    monkeypatch.setattr(engine, 'ENCODER_BATCH_PERSISTENT_TRAIN', True)
+    assert engine._encoder_lstm_fwd(model2, cpu, d, d, regen, [], [], poison=word) == 'persistent'     # status 2 is not looked at
+    assert calls == [('chain',), ('persistent', True)]
+    # one utterance / a refused geometry: the chain
+    del calls[:]
+    FakeStatus.value = 0
+    assert engine._encoder_lstm_fwd(model2, cpu, types.SimpleNamespace(B=1, H=256), d, regen, [], []) == 'launch chain'
+    monkeypatch.setattr(engine.nv, 'lstm_seq_batch_persistent_supported', lambda d, n, cus: "too many workgroups")
+    assert engine._encoder_lstm_fwd(model2, cpu, d, d, regen, [], []) == 'launch chain'
+    assert calls == [('chain',), ('chain',)]
