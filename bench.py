@@ -69,17 +69,10 @@ def parse_args():
 
 def kernel_source_sha1():
     """Hash of EVERY kernel source (csrc/* and the C ABI header): stamps profiles/pmc_traffic.json, so that a change to any
-    kernel makes the committed traffic numbers read as null instead of as fresh."""
-    import glob
-    import hashlib
-    h = hashlib.sha1()
-    files = sorted(glob.glob(os.path.join(ROOT, "tacotron2_amd", "csrc", "*")))
-    files.append(os.path.join(ROOT, "include", "tacotron2_amd.h"))
-    for f in files:
-        h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()
+    kernel makes the committed traffic numbers read as null instead of as fresh.  The same hash is compiled into the
+    library (tacotron2_amd.build.source_sha1 -> t2amd_source_sha1) and printed in the line as `build`."""
+    from tacotron2_amd.build import source_sha1
+    return source_sha1()
 
 
 def spawn_ranks(n):
@@ -325,6 +318,16 @@ def compact_line(out):
                           "note": "model.precision='fp32': the mode that meets mel L1 < 1e-4 and bit-exact gate stops"}
     if "optimizer_ab" in out:
         o["optimizer_ab"] = {k: _r(v, 2) for k, v in out["optimizer_ab"].items()}
+    if "build" in out:
+        b = out["build"]
+        o["build"] = {"library_sha1": b["library_sha1"][:12], "matches_sources": b["library_sha1"] == b["source_sha1"],
+                      "matches_pmc_traffic": b["library_sha1"] == b["pmc_traffic_sha1"]}
+    tl = out.get("timed_loop")
+    if tl:
+        ps = tl["per_step_ms"]
+        o["timed_loop"] = {"step_ms_min": min(ps), "step_ms_max": max(ps), "device_allocs": tl["device_allocs"],
+                           "allocator_calls_per_step": _r(tl["allocator_calls_per_step"], 1),
+                           "full_gc_collections_ms": tl["full_gc_collections_ms"], "gc_frozen": tl["gc_frozen"]}
     c = out.get("cpu_baseline")
     if c:
         o["cpu_baseline"] = {"value": _r(c["value"], 1), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
@@ -429,14 +432,41 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # what the timed loop is audited by: one event per step on the launch stream (never waited for
+    # inside the loop), the caching allocator's device-allocation counter, and the collector's full collections
+    import gc
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    gc_full = []
+
+    def _gc_cb(phase, info, _t=[0.0]):
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        elif info["generation"] == 2:
+            gc_full.append(round(1e3 * (time.perf_counter() - _t[0]), 2))
+    gc.callbacks.append(_gc_cb)
+    mem0 = torch.cuda.memory_stats(dev)
+    step_events[0].record()
     t0 = time.perf_counter()
     for i in range(args.warmup, n_iter):
         loss = step(batches[i])
+        step_events[i - args.warmup + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.callbacks.remove(_gc_cb)
+    mem1 = torch.cuda.memory_stats(dev)
+    from tacotron2_amd import engine as _engine
+    timed_loop = {
+        "per_step_ms": [round(step_events[j].elapsed_time(step_events[j + 1]), 3) for j in range(args.steps)],
+        "device_allocs": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
+        "device_frees": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0),
+        "alloc_retries": mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0),
+        "reserved_GB": round(mem1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2),
+        "allocator_calls_per_step": (mem1.get("allocation.all.allocated", 0) - mem0.get("allocation.all.allocated", 0)) / max(args.steps, 1),
+        "full_gc_collections_ms": gc_full, "gc_frozen": bool(_engine._gc_state["frozen"]),
+        "arena": _engine.arena_stats()}
     timed_frames = sum(frames[args.warmup:])
     per_rank = None
     if world > 1:
@@ -641,6 +671,13 @@ def main():
         if per_rank:
             out["ranks"] = per_rank
             out["padded_frames_per_s"] = args.batch_size * sum(per_rank["padded_time_steps"]) / elapsed
+        out["timed_loop"] = timed_loop
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+                pmc_sha = json.load(fh).get("source_sha1")
+        except Exception:                          # noqa: BLE001
+            pmc_sha = None
+        out["build"] = {"library_sha1": native.library_sha1(), "source_sha1": kernel_source_sha1(), "pmc_traffic_sha1": pmc_sha}
         if roofline:
             out["roofline"] = roofline
         if fp32_leg:

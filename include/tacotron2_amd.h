@@ -41,6 +41,9 @@ extern "C" {
 #define T2AMD_ATT_SLICES 4 /* workgroups per utterance in every attention kernel; partial slabs have this many slices */
 
 int t2amd_abi_version(void);
+/* SHA-1 (40 hex digits) over csrc/ and this header, compiled in by tacotron2_amd/build.py: the binding refuses a library
+ * that was not built from the sources beside it, and bench.py prints it next to the hash recorded with the PMC passes. */
+const char* t2amd_source_sha1(void);
 const char* t2amd_last_error(void);
 /* sizeof() of every struct below, in declaration order, for binding self-checks. */
 int t2amd_struct_sizes(int* out, int max_n);

@@ -23,11 +23,37 @@ CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 FLAGS = CFLAGS + ["-shared"]
 
 
+STAMP = OUT + ".sha1"
+
+
+def source_sha1():
+    """SHA-1 over EVERY kernel source (csrc/*) and the C-ABI header, names included.  It is compiled into the library
+    (``t2amd_source_sha1()``, csrc/api.hip), written beside it (``libtacotron2_amd.so.sha1``), recorded with the PMC passes
+    (profiles/pmc_traffic.json) and printed in the bench line: binary, counters and sources are provably the same tree."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(HERE, "csrc", "*")))
+    files.append(os.path.join(HERE, "..", "include", "tacotron2_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def built_sha1():
+    """The source hash the shipped library was built from (None: no library / no stamp)."""
+    try:
+        with open(STAMP) as fh:
+            return fh.read().strip() or None
+    except OSError:
+        return None
+
+
 def up_to_date():
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(f) <= t for f in DEPS if os.path.exists(f))
+    """The library exists and was built from exactly these sources -- by content, not by mtime (a
+    checkout or a snapshot copy resets mtimes, a hash cannot be fooled either way)."""
+    return os.path.exists(OUT) and built_sha1() == source_sha1()
 
 
 STAMPS_OUT = os.path.join(HERE, "lib", "libtacotron2_amd_stamps.so")
@@ -66,12 +92,21 @@ def build_torch_ops(force=False, verbose=True):
 def _compile_objects(obj_dir, extra, verbose):
     os.makedirs(obj_dir, exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in HDRS if os.path.exists(h))
+    sha = source_sha1()
+    sha_file = os.path.join(obj_dir, "api.sha1")           # the hash api.o was compiled with
+    try:
+        with open(sha_file) as fh:
+            api_sha = fh.read().strip()
+    except OSError:
+        api_sha = None
     jobs = []
     for src in SRC:
         obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
-        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+        is_api = os.path.basename(src) == "api.hip"
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t) and not (is_api and api_sha != sha):
             continue
-        jobs.append([HIPCC] + CFLAGS + extra + ["-c", src, "-o", obj])
+        # the hash of ALL sources is compiled into api.o (t2amd_source_sha1): it is rebuilt whenever any source changed
+        jobs.append([HIPCC] + CFLAGS + extra + (['-DT2AMD_SOURCE_SHA1="%s"' % sha] if is_api else []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -80,6 +115,8 @@ def _compile_objects(obj_dir, extra, verbose):
 
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as ex:
         list(ex.map(run, jobs))
+    with open(sha_file, "w") as fh:
+        fh.write(sha)
     return [os.path.join(obj_dir, os.path.basename(s)[:-4] + ".o") for s in SRC]
 
 
@@ -108,7 +145,10 @@ def build(force=False, verbose=True, stamps=False):
     if force:
         for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):
             os.remove(o)
+    sha = source_sha1()
     _link(_compile_objects(OBJ_DIR, [], verbose), OUT, verbose)
+    with open(STAMP, "w") as fh:
+        fh.write(sha + "\n")
     _torch_ops_best_effort(force, verbose)
     return OUT
 

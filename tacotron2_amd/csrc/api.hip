@@ -14,6 +14,12 @@ static int g_validate_only = 0;
 extern "C" int t2amd_validate_only_flag_(void) { return g_validate_only; }
 extern "C" int t2amd_set_validate_only(int on) { g_validate_only = on ? 1 : 0; return T2AMD_OK; }
 extern "C" int t2amd_abi_version(void) { return T2AMD_ABI_VERSION; }
+// SHA-1 of every kernel source + the header this binary was built from (tacotron2_amd/build.py passes it in); "" for a
+// build made by hand without it.  native.load() refuses a library whose hash is not that of the sources beside it.
+#ifndef T2AMD_SOURCE_SHA1
+#define T2AMD_SOURCE_SHA1 ""
+#endif
+extern "C" const char* t2amd_source_sha1(void) { return T2AMD_SOURCE_SHA1; }
 
 extern "C" int t2amd_struct_sizes(int* out, int max_n) {
     const int sizes[] = {

@@ -1159,7 +1159,20 @@ extern "C" int t2amd_lstm_seq_batch_persistent_supported(const t2amd_lstm_seq* p
     T2_REQUIRE(p->H % 64 == 0 && p->H >= 64 && p->H <= 256, "lstm_seq_batch_persistent: H must be a multiple of 64, <= 256");
     T2_REQUIRE(p->T > 0 && p->B > 0, "lstm_seq_batch_persistent: B, T");
     const long long wgs = (long long)ndir * ((p->B + EB_ROWS - 1) / EB_ROWS) * (p->H / 4);
-    T2_REQUIRE(wgs <= 4ll * cus, "lstm_seq_batch_persistent: more workgroups than can be co-resident (4 per CU)");
+    // Co-residency is a property of THIS build's register allocation, so it is asked of the runtime, not assumed (ADVICE
+    // r03); and the launch only takes 3/4 of what fits, so that a kernel running beside it on another stream (an RCCL
+    // bucket, a side stream) does not turn into a 30 ms give-up.  Without a device (validate-only runs) the geometry alone
+    // is checked against the 4 per CU the kernel is written for.
+    int per_cu = 4;
+    if (!t2amd_validate_only_flag_()) {
+        static int occ = 0;
+        if (occ == 0) {
+            int n = 0;
+            occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, encoder_bilstm_batch_persistent_kernel, EB_NT, 0) == hipSuccess && n > 0) ? n : -1;
+        }
+        if (occ > 0) per_cu = occ;
+    }
+    T2_REQUIRE(4 * wgs <= 3ll * per_cu * cus, "lstm_seq_batch_persistent: more workgroups than 3/4 of what can be co-resident");
     return T2AMD_OK;
 }
 

@@ -219,6 +219,8 @@ class HookSync(object):
             b['numel'] += p.numel()
             self.bucket_of[p] = b
         self.armed = False
+        self.next_launch = 0                              # buckets [0, next_launch) have been launched in this backward
+        self._graph_task = None
         self.handles = [p.register_post_accumulate_grad_hook(self._arrived) for p in params]
 
     def _launch(self, b, only_present=False):
@@ -233,20 +235,47 @@ class HookSync(object):
         b['work'] = dist.all_reduce(b['flat'], op=self.op, group=self.group, async_op=True)
 
     def _arrived(self, p):
-        if not self.armed:
+        from torch.autograd import Variable
+        seq = getattr(Variable._execution_engine, '_t2amd_seq', None)
+        if not self.armed or self._graph_task != _current_graph_task():
+            # first arrival of THIS backward.  A backward that raised before its callback ran leaves `armed` set and
+            # half-counted buckets behind: the graph-task identity tells a new backward from the same one, and the
+            # counters start again
+            if self.armed:
+                for b in self.buckets:
+                    b['work'], b['arrived'] = None, 0
+                self.next_launch = 0
             self.armed = True
-            from torch.autograd import Variable
+            self._graph_task = _current_graph_task()
             Variable._execution_engine.queue_callback(self._finish)
+        del seq
         b = self.bucket_of[p]
         b['arrived'] += 1
-        if b['arrived'] == len(b['params']):
+        self._launch_ready()
+
+    def _launch_ready(self):
+        """Collectives must be issued in the SAME order on every rank: buckets are launched strictly in bucket order --
+        bucket i waits for buckets < i -- never in order of completion (which differs between ranks as soon as they
+        disagree about which parameters took part).  Parameters that take part must still be the same set on every
+        rank; ranks that disagree launch different bucket counts and hang, as with torch's DDP."""
+        while self.next_launch < len(self.buckets):
+            b = self.buckets[self.next_launch]
+            if b['arrived'] < len(b['params']):
+                return
             self._launch(b)
+            self.next_launch += 1
 
     def _finish(self):
         self.armed = False
-        for b in self.buckets:
-            if b['work'] is None and b['arrived'] > 0:   # some of its parameters took no part in this backward
+        # buckets a partial backward left incomplete (unused parameters), still in bucket order; a bucket none of whose
+        # parameters took part is skipped on every rank alike
+        for i in range(self.next_launch, len(self.buckets)):
+            b = self.buckets[i]
+            if b['work'] is None and b['arrived'] == len(b['params']):
+                self._launch(b)
+            elif b['work'] is None and b['arrived'] > 0:
                 self._launch(b, only_present=True)
+        self.next_launch = 0
         for b in self.buckets:
             if b['work'] is not None:
                 b['work'].wait()
@@ -256,6 +285,19 @@ class HookSync(object):
                     if p.grad is not None:
                         p.grad.copy_(b['flat'][off:off + p.numel()].view_as(p.grad))
             b['work'], b['arrived'] = None, 0
+
+
+def _current_graph_task():
+    """Identity of the backward pass that is running (None outside one): tells HookSync a new backward from the one it
+    armed for.  torch exposes it as ``torch._C._current_graph_task_id()``; -1 / missing -> None."""
+    f = getattr(torch._C, '_current_graph_task_id', None)
+    if f is None:
+        return None
+    try:
+        v = f()
+    except Exception:                                     # noqa: BLE001
+        return None
+    return None if v == -1 else v
 
 
 def ranks_sharing_a_device(module, group=None):
@@ -270,10 +312,23 @@ def ranks_sharing_a_device(module, group=None):
     # UUID AND visible-devices string AND index: a runtime that reports the same (empty) UUID for every GPU must not make
     # eight ranks on eight GPUs look like one shared device
     vis = "|".join(os.environ.get(k, '') for k in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'))
-    me = (socket.gethostname(), str(getattr(props, 'uuid', '')), vis, p.device.index)
+    uuid = str(getattr(props, 'uuid', '') or '')
+    if uuid.strip('0-') == '':
+        uuid = ''                                         # an all-zero UUID is no identity either
+    me = (socket.gethostname(), uuid, vis, p.device.index)
     everyone = [None] * dist.get_world_size(group)
     dist.all_gather_object(everyone, me, group=group)
-    return sum(1 for e in everyone if e == me)
+    return sum(1 for e in everyone if _same_device(e, me))
+
+
+def _same_device(a, b):
+    """Two ranks' (host, uuid, visible-devices, index) records name the same GPU: by UUID when both have a real one -- the
+    same GPU can be reached through different HIP_VISIBLE_DEVICES strings -- else by visibility string + index."""
+    if a[0] != b[0]:
+        return False
+    if a[1] and b[1]:
+        return a[1] == b[1]
+    return a[2:] == b[2:]
 
 
 def apply_gradient_allreduce(module):
@@ -284,7 +339,8 @@ def apply_gradient_allreduce(module):
         raise RuntimeError("apply_gradient_allreduce: torch.distributed is not initialised "
                            "(reference train.py:27-39 init_distributed does this first)")
     _flat_broadcast([v for v in module.state_dict().values() if torch.is_tensor(v)], 0)
-    if getattr(module, '_t2amd_dp_applied', False):
+    # idempotence is decided by the exchange objects themselves, not by a flag that a copy could carry without them
+    if getattr(module, '_grad_sync', None) is not None or getattr(module, '_hook_sync', None) is not None:
         return module
 
     from .model import Tacotron2

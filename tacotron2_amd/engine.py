@@ -57,9 +57,10 @@ class MaskSource(object):
     engine layouts:  enc[i] (B,Ti,E)   prenet[i] (To,B,P)   att (To,B,Ha)   dec (To,B,Hd)
                      post[i] (B,To,C)  prenet_infer (steps,2,B,P)"""
 
-    def __init__(self, injected, device):
+    def __init__(self, injected, device, run=None):
         self.injected = injected or {}
         self.device = device
+        self.run = run                   # the step's allocator (engine._Run): masks live exactly as long as the step
         self.seed = None
         self.offset = 0
 
@@ -73,7 +74,7 @@ class MaskSource(object):
             return m
         if self.seed is None:
             self.seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        out = self.run.empty8(*shape) if self.run is not None else torch.empty(shape, dtype=torch.uint8, device=self.device)
         nv.philox_keep_mask(out, p, self.seed, self.offset)
         self.offset += (out.numel() + 3) // 4 * 4
         return out
@@ -236,7 +237,18 @@ def _lstm_wgrad16(run, dG2, B, parts, outs):
 
 
 class _Ctx(object):
-    pass
+    """What a training forward keeps for its backward.  Owns the lease of the step arena its slabs live in."""
+    arena = None
+
+    def release(self):
+        a, self.arena = self.arena, None
+        _arena_release(a)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:                # interpreter shutdown
+            pass
 
 
 class _EvalCtx(object):
@@ -302,12 +314,136 @@ def bump_weight_generation():
     _PACK_GEN[0] += 1
 
 
+# ----------------------------------------------------------------------------
+# step arena (SURVEY 8b "Ownership": nothing on the hot path calls hipMalloc)
+# ----------------------------------------------------------------------------
+# Every slab a training step needs between `forward` and the end of `backward` (activations saved for BPTT, keep-masks,
+# halo images, split-K partials, gradient slabs: ~11 GB at B = 64, To = 870) used to be its own ``torch.empty``: ~270 calls
+# per step whose sizes follow the batch's (Ti_max, To_max).  The caching allocator serves most of them from its pool, but
+# every change of shape splits / regroups its blocks and now and then ends in a ``hipMalloc`` of a GB in the middle of the
+# step (profiles/r04_a_diag_before.json: two in 20 fresh batches, 13 ms each; the driver's loop read 65.3 ms per step where
+# a replay of the same batches reads 61.6).  The engine now owns ONE region per in-flight step and bumps a pointer through
+# it: the region is leased by `_forward`, handed back when `backward` has enqueued its last kernel (or when the saved context
+# is dropped without one: eval-mode forwards, ``torch.no_grad()``), and reused by the next step as it is -- the kernels of
+# consecutive steps are ordered by the stream they share, which is part of the pool key.  What OUTLIVES a step never comes
+# from it: the four outputs, every parameter gradient (autograd may keep the very tensor as ``p.grad``), the cached weight
+# images (`_Run.cached`).  The region grows in chunks during the first step(s) and is then replaced by a single chunk of
+# 1.25 x the largest step seen, so a steady-state loop makes no allocator call for slabs at all.  T2AMD_ARENA=0 restores
+# per-slab ``torch.empty``.
+ARENA = os.environ.get('T2AMD_ARENA', '1') != '0'
+ARENA_CHUNK = int(float(os.environ.get('T2AMD_ARENA_CHUNK_GB', '2')) * 2 ** 30)
+ARENA_HEADROOM = float(os.environ.get('T2AMD_ARENA_HEADROOM', '1.25'))
+
+
+class _Arena(object):
+    ALIGN = 256
+
+    def __init__(self, device):
+        self.dev = device
+        self.chunks = []                 # uint8 tensors
+        self.ci, self.off = 0, 0         # bump position: chunk index, byte offset inside it
+        self.used = 0                    # aligned bytes handed out since the lease began
+        self.peak = 0                    # largest `used` of any lease
+        self.busy = False
+        self.growths = 0                 # torch.empty calls this arena has made (chunks + consolidations)
+        self.leases = 0
+
+    def capacity(self):
+        return sum(c.numel() for c in self.chunks)
+
+    def alloc(self, nbytes):
+        """`nbytes` of device memory as a uint8 view, 256-byte aligned (what hipMalloc / the caching allocator give)."""
+        n = max(int(nbytes), 1)
+        na = (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        while True:
+            if self.ci < len(self.chunks):
+                ch = self.chunks[self.ci]
+                if self.off + na <= ch.numel():
+                    v = ch[self.off:self.off + n]
+                    self.off += na
+                    self.used += na
+                    return v
+                self.ci += 1
+                self.off = 0
+                continue
+            self.chunks.append(torch.empty(max(na, ARENA_CHUNK), dtype=torch.uint8, device=self.dev))
+            self.growths += 1
+
+    def release(self):
+        """End of a lease.  A step that needed more than one chunk leaves ONE chunk with headroom for the next."""
+        self.peak = max(self.peak, self.used)
+        if len(self.chunks) > 1:
+            want = int(self.peak * ARENA_HEADROOM)
+            want = (want + (1 << 28) - 1) >> 28 << 28                      # whole 256 MiB
+            self.chunks = []                                               # back to torch's pool before the new request
+            self.chunks.append(torch.empty(want, dtype=torch.uint8, device=self.dev))
+            self.growths += 1
+        self.ci, self.off, self.used = 0, 0, 0
+        self.busy = False
+
+
+import threading
+
+_ARENAS = {}                      # (device, stream id) -> [arena, ...]; more than one only while steps overlap in time
+_ARENA_LOCK = threading.Lock()    # backward runs on autograd's device thread
+
+
+def _arena_key(device):
+    if device.type == 'cuda':
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        return ('cuda', idx, torch.cuda.current_stream(idx).cuda_stream)
+    return (device.type, 0, 0)
+
+
+def _arena_acquire(device):
+    if not ARENA:
+        return None
+    key = _arena_key(device)
+    with _ARENA_LOCK:
+        pool = _ARENAS.setdefault(key, [])
+        for a in pool:
+            if not a.busy:
+                break
+        else:
+            a = _Arena(device)
+            pool.append(a)
+        a.busy = True
+        a.leases += 1
+        return a
+
+
+def _arena_release(a):
+    if a is None:
+        return
+    with _ARENA_LOCK:
+        if a.busy:
+            a.release()
+
+
+def arena_stats(model=None):
+    """Counters of the step arenas of this process (tools / tests): capacity and peak in bytes, allocator calls made."""
+    with _ARENA_LOCK:
+        return [dict(key=str(k), chunks=len(a.chunks), capacity=a.capacity(), peak=a.peak, growths=a.growths,
+                     leases=a.leases, busy=a.busy) for k, pool in _ARENAS.items() for a in pool]
+
+
+def release_arenas():
+    """Give every idle arena's memory back to torch's pool (e.g. before switching to inference on a small device)."""
+    with _ARENA_LOCK:
+        for k in list(_ARENAS):
+            _ARENAS[k] = [a for a in _ARENAS[k] if a.busy]
+            if not _ARENAS[k]:
+                del _ARENAS[k]
+
+
 class _Run(object):
     """Allocation + kernel helpers bound to one device."""
 
-    def __init__(self, device, precision='fp32', cache=None):
+    def __init__(self, device, precision='fp32', cache=None, arena=None):
         self.dev = device
         self._ws = None
+        self.arena = arena
+        self._persist = 0                # > 0 inside `cached`: what is made there outlives the step
         self.cache = cache if cache is not None else {}
         if precision not in ('fp32', 'bf16'):
             raise NativeError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
@@ -322,12 +458,34 @@ class _Run(object):
         hit = self.cache.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
-        val = fn()
+        self._persist += 1               # weight images live across steps: never in the step arena
+        try:
+            val = fn()
+        finally:
+            self._persist -= 1
         self.cache[tag] = (key, val)
         return val
 
+    def _alloc(self, shape, dtype, esize):
+        if self.arena is None or self._persist:
+            return torch.empty(shape, dtype=dtype, device=self.dev)
+        n = 1
+        for v in shape:
+            n *= int(v)
+        return self.arena.alloc(n * esize).view(dtype).view(*shape)
+
+    def out_empty(self, *shape):
+        """f32 tensor that OUTLIVES the step (outputs, parameter gradients): always torch's allocator."""
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
     def empty16(self, *shape):
-        return torch.empty(shape, dtype=torch.bfloat16, device=self.dev)
+        return self._alloc(shape, torch.bfloat16, 2)
+
+    def empty8(self, *shape):
+        return self._alloc(shape, torch.uint8, 1)
+
+    def empty_i32(self, *shape):
+        return self._alloc(shape, torch.int32, 4)
 
     def cast16(self, t):
         out = self.empty16(*t.shape)
@@ -335,7 +493,7 @@ class _Run(object):
         return out
 
     def empty(self, *shape):
-        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+        return self._alloc(shape, torch.float32, 4)
 
     def zeros(self, *shape):
         t = self.empty(*shape)
@@ -345,7 +503,7 @@ class _Run(object):
     def ws(self, n):
         need = 2 * 64 * n
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.float64, device=self.dev)
+            self._ws = self._alloc((need,), torch.float64, 8)
         return self._ws
 
     # C[M,N] (+)= A.B with automatic split-K for skinny outputs over a long K
@@ -421,7 +579,7 @@ def _conv_wgrad_kk_ok(run, rows, T, Ci, Co):
 def _halo_image(run, x, T, pad):
     """bf16 image of the channel-last rows x (rows = B T) with `pad` zero rows around every utterance."""
     rows, C = x.shape
-    img = torch.empty((rows // T) * (T + 2 * pad) + 2 * pad, C, dtype=torch.bfloat16, device=x.device)
+    img = run.empty16((rows // T) * (T + 2 * pad) + 2 * pad, C)
     nv.cast_halo_bf16(x, img, T, pad)             # writes every row of the image, halos included
     return img
 
@@ -494,7 +652,7 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
     (written to ``first_dx`` if given).  ``G(name, *shape)`` allocates a parameter gradient (a view of its
     data-parallel bucket when gradients are exchanged, distributed.GradSync.out)."""
     if G is None:
-        G = lambda name, *shape: run.empty(*shape)                                   # noqa: E731
+        G = lambda name, *shape: run.out_empty(*shape)                               # noqa: E731
     for i in range(len(saved) - 1, -1, -1):
         s = saved[i]
         W = s['W']
@@ -557,7 +715,7 @@ ENCODER_BATCH_PERSISTENT = os.environ.get('T2AMD_ENCODER_BATCH_PERSISTENT', '1')
 ENCODER_BATCH_PERSISTENT_TRAIN = os.environ.get('T2AMD_ENCODER_BATCH_PERSISTENT_TRAIN', '0') == '1'
 
 
-def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None):
+def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None, run=None):
     """Both directions of the encoder bi-LSTM of a batch (reference model.py:181-188): ONE persistent launch (csrc/
     decode_persist.hip, encoder_bilstm_batch_persistent_kernel: W_hh fragments in registers, h handed on through the output
     slab with write-through stores + step counters) instead of T dependent launches -- 4.3 vs 7.3 us per step at B = 64.  A
@@ -571,14 +729,18 @@ def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None):
         if getattr(model, '_enc_batch_backoff', 0) > 0:
             model._enc_batch_backoff -= 1
         elif nv.lstm_seq_batch_persistent_supported(d0, 2, torch.cuda.get_device_properties(dev).multi_processor_count) is None:
-            flags = torch.empty(nv.lstm_seq_batch_persistent_flag_words(d0.B, d0.H, 2), dtype=torch.int32, device=dev)
-            status = torch.empty(1, dtype=torch.int32, device=dev)
+            ei32 = run.empty_i32 if run is not None else (lambda n: torch.empty(n, dtype=torch.int32, device=dev))
+            flags = ei32(nv.lstm_seq_batch_persistent_flag_words(d0.B, d0.H, 2))
+            status = ei32(1)
             nv.lstm_seq_fwd2_batch_persistent(d0, d1, flags, status, poison)
             if poison is not None or int(status.item()) == 0:
+                model._enc_batch_timeouts = 0
                 return 'persistent'
             print("tacotron2_amd: the persistent encoder kernel gave up (its workgroups were not co-resident within 30 ms -- is "
                   "the GPU shared?); running the launch chain", file=sys.stderr, flush=True)
-            model._enc_batch_backoff = 16
+            # exponential back-off, as _decode_persistent: 4, 8, ... up to 256 calls on the launch chain before the next try
+            model._enc_batch_timeouts = getattr(model, '_enc_batch_timeouts', 0) + 1
+            model._enc_batch_backoff = min(256, 2 << model._enc_batch_timeouts)
             regen_gx()
     nv.lstm_seq_fwd2(d0, d1, reads=reads, writes=writes)
     return 'launch chain'
@@ -604,7 +766,9 @@ def invalidate_weight_cache(model):
         cache.clear()
 
 
-# Content guard of the weight-image cache.  Writes through ``param.data`` (an EMA swap, ``p.data.copy_``) or
+# Content guard of the weight-image cache.  A HEURISTIC, not a proof: the signature is the global L2 norm of
+# all parameters, so an edit that preserves it (swapping two tensors of equal norm, a sign flip) is not seen -- the explicit
+# remedies are model.invalidate_weight_cache() / engine.bump_weight_generation().  Writes through ``param.data`` (an EMA swap, ``p.data.copy_``) or
 # by a raw-pointer optimiser change the weights without touching anything the cache key is made of, and the engine would
 # go on multiplying by stale packed images while reading other operands live.  Every call therefore enqueues one pass over
 # all parameters (the global-norm kernel of csrc/optim.hip: 113 MB, ~25 us on an MI355X) -- the weights' signature.
@@ -646,7 +810,8 @@ def _guard_weights(model, run, P):
     ev = torch.cuda.Event()
     ev.record()
     ev.synchronize()                               # stream order: the slot-0 copy of an earlier call has landed too
-    if float(g['host'][1][0]) != float(g['host'][0][0]):
+    now, then = float(g['host'][1][0]), float(g['host'][0][0])
+    if now != then and not (now != now and then != then):      # NaN weights: the same (non-)signature, not a change
         import sys
         print("tacotron2_amd: the parameters changed without their version counters changing (a write through "
               "param.data or a raw pointer); the packed weight images are rebuilt for this call.  Call "
@@ -772,11 +937,12 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         raise NativeError("tacotron2_amd: the engine runs on the MI355X only (got %s tensors). "
                           "There is no CPU path; the CPU oracle lives in oracle/ for tests." % dev)
     nv.load()
-    run = _Run(dev, getattr(model, 'precision', 'fp32'), _weight_cache(model))
+    c = _Ctx()
+    c.arena = _arena_acquire(dev)        # handed back by backward(), or by c's destructor when there is none
+    run = _Run(dev, getattr(model, 'precision', 'fp32'), _weight_cache(model), c.arena)
     _guard_weights(model, run, P)
     P, _ = _embed_attention(run, P)
-    ms = MaskSource(model.dropout_masks, dev)
-    c = _Ctx()
+    ms = MaskSource(model.dropout_masks, dev, run)
     B = text.shape[0]
     Ti = int(max_len)
     To = mels.shape[2]
@@ -827,7 +993,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     model.last_encoder_path = _encoder_lstm_fwd(
         model, text.device, c.enc_lstm[0]['desc'], c.enc_lstm[1]['desc'], regen_gx,
         reads=[L_[k_] for L_ in c.enc_lstm for k_ in ('Whh', 'GX')] + [lens32],
-        writes=[memory] + [L_['C'] for L_ in c.enc_lstm], poison=memory if training else None)
+        writes=[memory] + [L_['C'] for L_ in c.enc_lstm], poison=memory if training else None, run=run)
     c.x3, c.memory = x3, memory
 
     # ---- decoder: hoisted dense parts ------------------------------------------------------
@@ -887,7 +1053,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     d.B, d.Ti, d.To, d.E, d.Ha, d.Hd = B, Ti, To, E, Ha, Hd
     slabs = dict(HA=run.empty(To, B, Ha), CA=run.empty(To, B, Ha), GD=run.empty(To, B, 4 * Hd),
                  HD=run.empty(To, B, Hd), CD=run.empty(To, B, Hd), CTX=run.empty(To, B, E),
-                 Q=run.empty(To, B, A), ALIGN=run.empty(B, To, Ti), CUM=run.empty(To, B, Ti),
+                 Q=run.empty(To, B, A), ALIGN=run.out_empty(B, To, Ti), CUM=run.empty(To, B, Ti),
                  cum_work=run.empty(B, Ti),
                  attn_ws=run.empty(nv.attn_fwd_ws_floats(B, Ti) + nv.attn_bwd_ws_floats(B, Ti)))
     d.Wa_rec, d.Wd_cat, d.bias_d = nv.ptr(Wa_rec), nv.ptr(Wd_cat), nv.ptr(bias_d)
@@ -922,7 +1088,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     _fg(run, PG, slabs['HD'].view(rowsD, Hd), Wpg[:, :Hd])
     _fg(run, PG, slabs['CTX'].view(rowsD, E), Wpg[:, Hd:], accumulate=True, bias=bpg)
     mel_cl = run.empty(B, To, Cm)
-    gate = run.empty(B, To)
+    gate = run.out_empty(B, To)
     nv.split_projection(PG, mel_cl, gate, olens32)                                       # model.py:326-336, 495
 
     # ---- postnet (model.py:141-146) -------------------------------------------------------
@@ -933,8 +1099,8 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     post_cl, c.post_saved = _conv_stack_fwd(run, P, bufs, 'postnet.convolutions', npost,
                                             mel_cl.view(rowsP, Cm), To, [2] * (npost - 1) + [0],
                                             post_masks, training)
-    mel = run.empty(B, Cm, To)
-    mel_post = run.empty(B, Cm, To)
+    mel = run.out_empty(B, Cm, To)
+    mel_post = run.out_empty(B, Cm, To)
     nv.finalize_outputs(mel_cl, post_cl.view(B, To, Cm), mel, mel_post, olens32)         # model.py:511, 487-497
 
     c.run = run
@@ -973,7 +1139,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     def G(name, *shape):
         """Where the kernels write the gradient of parameter ``name``: straight into its bucket when gradients
         are exchanged (no packing pass before the all-reduce), a fresh buffer otherwise."""
-        return sync.out(name, shape) if sync is not None else run.empty(*shape)
+        return sync.out(name, shape) if sync is not None else run.out_empty(*shape)
 
     # a smaller attention geometry: the kernels produce compiled-geometry gradients, cropped into place further down
     own_shape = {n: tuple(P[n].shape) for n in (_ATT_Q, _ATT_M, _ATT_V, _ATT_D, _ATT_C)}
@@ -1232,6 +1398,32 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     return g
 
 
+# The collector pause that hid in the headline (round 4; profiles/r04_b_diag_phases.json).  A training step makes a few
+# thousand container objects (descriptors, dicts of slabs, closures); CPython counts them, and about once per dozen steps
+# early in a run the count trips a FULL (generation-2) collection -- which walks every container object of the process,
+# ~1.5 M of them once torch is imported: 60-130 ms on the host in the middle of `backward`, the GPU idle behind it.  In the
+# driver's 20-step window exactly one lands: 65.3-67.2 ms per step where the same batches replayed read 61.5 (the whole gap
+# VERDICT r03 "What's weak" #2 found, reproduced on step 9 of two differently ordered batch lists with gc.callbacks).  After
+# the first complete training step everything that exists by then (modules, torch, the engine's caches) is collected once
+# and moved to the permanent generation (`gc.freeze()`, what long-running servers do after start-up): later collections only
+# walk what was made since -- a few thousand objects, well under a millisecond.  Reference counting is untouched, nothing
+# is ever leaked but cyclic garbage that already existed at that moment.  T2AMD_GC_FREEZE=0 leaves the collector alone.
+GC_FREEZE = os.environ.get('T2AMD_GC_FREEZE', '1') != '0'
+_gc_state = {'train_forwards': 0, 'frozen': False}
+
+
+def settle_gc(force=False):
+    """Collect once, then freeze the survivors out of later collections.  Called by the engine at the top of the second
+    training forward of a process; training loops may call it themselves after their own set-up."""
+    if _gc_state['frozen'] and not force:
+        return False
+    import gc
+    gc.collect()
+    gc.freeze()
+    _gc_state['frozen'] = True
+    return True
+
+
 class Tacotron2TrainFunction(torch.autograd.Function):
     """forward(model, names, buffers, text, in_lens, mels, max_len, out_lens, *params)."""
 
@@ -1243,11 +1435,19 @@ class Tacotron2TrainFunction(torch.autograd.Function):
                 raise NativeError("parameter %s is %s: training keeps f32 master weights (select the bf16 compute mode "
                                   "with model.half() / hparams.fp16_run; reduced-precision parameter storage is accepted "
                                   "by inference only)" % (n, p.dtype))
+        if GC_FREEZE and model.training and not _gc_state['frozen']:
+            _gc_state['train_forwards'] += 1
+            if _gc_state['train_forwards'] == 2:     # one whole step has run: its one-time objects exist by now
+                settle_gc()
         outs, c = _forward(model, P, buffers, text, in_lens, mels, max_len, out_lens, model.training)
         # an eval-mode forward (validation, reference train.py:133) can never be differentiated: its activation
         # slabs are released right here instead of living until the outputs die
         ctx.model, ctx.names, ctx.P = model, names, P
-        ctx.c = c if model.training else _EvalCtx()
+        if model.training:
+            ctx.c = c
+        else:
+            ctx.c = _EvalCtx()
+            c.release()                  # nothing of an eval-mode forward is read again: the arena is free for the next call
         ctx.set_materialize_grads(False)
         return outs
 
@@ -1258,13 +1458,17 @@ class Tacotron2TrainFunction(torch.autograd.Function):
                               "retain_graph / a second backward through the same forward is not supported")
         if not ctx.c.training:
             raise NativeError("backward through an eval-mode forward is not supported")
-        grads = _backward(ctx.model, ctx.P, ctx.c, d_mel, d_post, d_gate, d_align)
+        c = ctx.c
+        try:
+            grads = _backward(ctx.model, ctx.P, c, d_mel, d_post, d_gate, d_align)
+        finally:
+            ctx.c = None
+            c.release()                  # every kernel that reads the step's slabs is enqueued: the next step may reuse them
         out = []
         for n in ctx.names:
             if n not in grads:
                 raise NativeError("internal error: no gradient produced for %s" % n)
             out.append(grads[n].view(ctx.P[n].shape))
-        ctx.c = None
         return (None,) * 8 + tuple(out)
 
 

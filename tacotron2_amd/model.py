@@ -113,6 +113,10 @@ class Decoder(nn.Module):
         self.gate_layer = LinearNorm(hparams.decoder_rnn_dim + enc, 1, bias=True, w_init_gain='sigmoid')
 
 
+# attributes distributed.apply_gradient_allreduce() leaves on a module: never copied or pickled with it
+_DP_STATE = ('_grad_sync', '_hook_sync', '_t2amd_dp_applied')
+
+
 class Tacotron2(nn.Module):
     def __init__(self, hparams):
         super().__init__()
@@ -157,7 +161,11 @@ class Tacotron2(nn.Module):
     def __getstate__(self):
         state = dict(self.__dict__)
         state.pop('_weight_cache', None)          # device images of the weights: rebuilt on demand, never pickled
-        state.pop('_grad_sync', None)             # process-group state of the data-parallel wrapper
+        # process-group state of the data-parallel wrapper -- AND the flag that says it is there: a copy that kept
+        # `_t2amd_dp_applied` without the exchange would make apply_gradient_allreduce() return early and then train
+        # without any all-reduce, ranks drifting apart silently
+        for k in _DP_STATE:
+            state.pop(k, None)
         return state
 
     def __deepcopy__(self, memo):
@@ -165,7 +173,7 @@ class Tacotron2(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ('_weight_cache', '_grad_sync'):
+            if k == '_weight_cache' or k in _DP_STATE:
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         return new

@@ -258,7 +258,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 
 # every exported symbol of include/tacotron2_amd.h
 SYMBOLS = [
-    "t2amd_abi_version", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
+    "t2amd_abi_version", "t2amd_source_sha1", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
     "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_splitk_reduce2d_f32", "t2amd_gemm16_tn", "t2amd_gemm16_kk", "t2amd_gemm16_kk_group", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16", "t2amd_pack_conv_bf16",
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
@@ -408,6 +408,19 @@ def load():
     lib.t2amd_lstm_seq_batch_persistent_flag_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
+    # the binary must be THESE sources' binary (by content: a snapshot copy or a checkout resets mtimes).  An explicitly
+    # selected library (T2AMD_LIB: instrumented / A-B variants built by tacotron2_amd.build) carries the hash of the same
+    # tree; T2AMD_ALLOW_STALE_LIB=1 is the escape hatch for a deliberately older binary.
+    lib.t2amd_source_sha1.restype = C.c_char_p
+    lib.t2amd_source_sha1.argtypes = []
+    built = (lib.t2amd_source_sha1() or b"").decode()
+    if os.path.isdir(os.path.join(_HERE, "csrc")) and os.environ.get("T2AMD_ALLOW_STALE_LIB", "0") != "1":
+        from . import build as _build
+        want = _build.source_sha1()
+        if built != want:
+            raise NativeError("tacotron2_amd: %s was built from other sources (binary %s, sources %s): run "
+                              "`python -m tacotron2_amd.build` (or set T2AMD_ALLOW_STALE_LIB=1 to use it anyway)"
+                              % (LIB_PATH, built or "<unstamped>", want))
     sizes = (C.c_int * 32)()
     n = lib.t2amd_struct_sizes(sizes, 32)
     if n != len(_STRUCTS):
@@ -418,6 +431,11 @@ def load():
                               % (st.__name__, C.sizeof(st), sizes[i]))
     _lib = lib
     return lib
+
+
+def library_sha1():
+    """Source hash compiled into the loaded library (``t2amd_source_sha1``)."""
+    return (load().t2amd_source_sha1() or b"").decode()
 
 
 _validate_only = False

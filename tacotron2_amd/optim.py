@@ -146,6 +146,16 @@ class FusedAdam(torch.optim.Adam):
             self._undo()
         self._pending = None
 
+    def state_dict(self):
+        """A checkpoint taken between a device-skipped step and the next ``step()`` must not carry step counts one too high
+        (bias correction after resume): the skipped step is settled first."""
+        self._settle_previous()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._pending = None             # its step tensors belong to the state that is being replaced
+        return super().load_state_dict(state_dict)
+
     def undo_step_count(self):
         """The last ``step(clip_norm=...)`` was skipped on the device (non-finite norm): take it out of the counts.  Kept for
         callers that read the norm themselves (tacotron2_amd.train); since round 3 the next ``step()`` does this on its own,

@@ -82,3 +82,29 @@ def test_oracle_edge_cases():
     assert out[0].shape == (1, 80, 2) and out[3].shape == (1, 2, 3)
     assert torch.isfinite(loss)
     assert abs(out[3].sum().item() - 2.0) < 1e-5       # attention weights sum to one
+
+
+def test_oracle_equals_reference_digest_at_the_timed_size():
+    """The oracle at BASELINE configs[1] itself -- synth_batch(64, 1234), B = 64, Ti = 177, To = 870, the batch bench.py
+    times and tests/test_zz5 checks the engine on -- against the digest of the REFERENCE's results on the same weights, batch
+    and dropout masks (tests/golden/make_golden_fullsize.py; the generator also compares tensor against tensor: 2e-5 / 5e-5).
+    One oracle forward + backward, ~40 s of CPU.  Tolerances: integrals and samples of the outputs 2e-5 of their scale,
+    gradient L2 norms 1e-4, gradient samples 1e-3 of the tensor's largest sample, loss 1e-6."""
+    import os
+    import sys
+    sys.path.insert(0, gu.GOLDEN_DIR)
+    try:
+        import make_golden_fullsize as mf
+    finally:
+        sys.path.remove(gu.GOLDEN_DIR)
+    dg = torch.load(os.path.join(gu.GOLDEN_DIR, mf.NAME + ".pt"), weights_only=False)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    try:
+        hp, sd, batch, masks, Ti, To = mf.fullsize_case()
+        assert (Ti, To) == (dg['meta']['Ti'], dg['meta']['To'])
+        loss, out, grads, _ = orc.train_step_grads(sd, hp, batch, masks)
+    finally:
+        torch.set_num_threads(threads)
+    worst = mf.compare_to_digest(dg, out, loss, grads)
+    print("oracle vs the reference's digest at B=64/To=870:", worst)

@@ -173,3 +173,35 @@ def test_oracle_equals_reference_live_on_more_cases(monkeypatch, seed, in_lens, 
         sys.path[:] = path_before
         for loaded in set(sys.modules) - before:
             del sys.modules[loaded]
+
+
+def test_fullsize_digest_is_the_references(monkeypatch):
+    """The committed digest tests/golden/fullsize_train_B64.pt IS the reference's result at the size that is timed
+    (BASELINE configs[1]: synth_batch(64, 1234), B = 64, Ti = 177, To = 870): the unmodified reference model.py /
+    loss_function.py is run here on that batch, the seed-1234 weights and the oracle's seeded dropout masks (replayed in the
+    reference's draw order) -- one forward + backward, ~1 min of CPU -- and its outputs, loss and all 60 gradients are held
+    against the digest.  tests/test_oracle_golden.py holds the ORACLE to the same digest (anywhere), tests/test_zz5 the GPU
+    box's oracle run: together reference -> oracle -> engine at B = 64 / To = 870 (VERDICT r03 missing #5)."""
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    before = set(sys.modules)
+    real_dropout = torch.nn.functional.dropout
+    path_before = list(sys.path)
+    threads = torch.get_num_threads()
+    try:
+        sys.path.insert(0, gu.GOLDEN_DIR)
+        import make_golden_fullsize as mf
+        import make_golden as mg
+        dg = torch.load(os.path.join(gu.GOLDEN_DIR, mf.NAME + ".pt"), weights_only=False)
+        torch.set_num_threads(8)
+        hp, sd, batch, masks, Ti, To = mf.fullsize_case()
+        assert (Ti, To) == (dg['meta']['Ti'], dg['meta']['To']) == (177, 870)
+        ref_model, ref_loss = mg.import_reference()
+        out, loss, grads, dt = mf.run_reference(ref_model, ref_loss, hp, sd, batch, masks, To)
+        worst = mf.compare_to_digest(dg, out, loss, grads, out_tol=2e-6, grad_tol=2e-5, loss_tol=1e-7)
+        print("reference (live, %.1f s) vs committed digest: %s" % (dt, worst))
+    finally:
+        torch.set_num_threads(threads)
+        torch.nn.functional.dropout = real_dropout
+        sys.path[:] = path_before
+        for loaded in set(sys.modules) - before:
+            del sys.modules[loaded]

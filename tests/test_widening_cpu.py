@@ -430,7 +430,7 @@ def test_splitk_model_of_the_bf16_resident_products():
 
 def test_encoder_launch_routing_and_fallback_host_logic(monkeypatch):
     """engine._encoder_lstm_fwd without a GPU (the native calls are replaced): inference reads the status back and, on a
-    give-up, recomputes the pre-activations, runs the launch chain and stays on it for 16 calls; the training forward takes
+    give-up, recomputes the pre-activations, runs the launch chain and stays on it for 4, 8, ... 256 calls (exponential back-off); the training forward takes
     the persistent launch only when asked to, hands it the poison word and never reads the status; B == 1 and a refused
     geometry go to the chain."""
     import types
@@ -463,10 +463,10 @@ def test_encoder_launch_routing_and_fallback_host_logic(monkeypatch):
     del calls[:]
     FakeStatus.value = 2
     assert engine._encoder_lstm_fwd(model, cpu, d, d, regen, [], []) == 'launch chain'
-    assert calls == [('persistent', False), ('regen',), ('chain',)] and model._enc_batch_backoff == 16
+    assert calls == [('persistent', False), ('regen',), ('chain',)] and model._enc_batch_backoff == 4
     del calls[:]
     assert engine._encoder_lstm_fwd(model, cpu, d, d, regen, [], []) == 'launch chain'
-    assert calls == [('chain',)] and model._enc_batch_backoff == 15
+    assert calls == [('chain',)] and model._enc_batch_backoff == 3
     # training: the chain unless asked; with the switch the launch gets the poison word and the status is never read
     model2 = types.SimpleNamespace()
     del calls[:]

@@ -76,6 +76,19 @@ def full_train_case():
     import time
     t0 = time.perf_counter()
     oloss, oout, ograds, obufs = orc.train_step_grads(sd, hp, batch, masks)
+    if Bs == 64:
+        # the oracle THIS box just ran is held to the digest of the reference's own results at this size
+        # (tests/golden/make_golden_fullsize.py; /root/reference does not exist here): reference -> oracle -> engine
+        import sys
+        sys.path.insert(0, gu.GOLDEN_DIR)
+        try:
+            import make_golden_fullsize as mf
+        finally:
+            sys.path.remove(gu.GOLDEN_DIR)
+        dg = torch.load(os.path.join(gu.GOLDEN_DIR, mf.NAME + ".pt"), weights_only=False)
+        worst = mf.compare_to_digest(dg, oout, oloss, ograds)
+        _report("oracle_vs_reference_digest_B64", dict(worst_relative_deviation=worst, digest_meta={
+            k: v for k, v in dg['meta'].items() if not isinstance(v, dict)}))
     return dict(hp=hp, sd=sd, batch=batch, masks=masks, oloss=oloss, oout=oout, ograds=ograds, obufs=obufs, B=Bs,
                 shape="B=%d of synth_batch(64,1234) (BASELINE configs[1]%s), Ti=%d, To=%d; oracle step %.1f s"
                       % (Bs, "" if Bs == 64 else ": every %dth utterance" % (64 // Bs), Ti, To, time.perf_counter() - t0))
