@@ -144,7 +144,18 @@ def cpu_baseline(sample_b, seed, threads=16):
     opt.step()
     dopt = time.perf_counter() - t0
     frames = int(ol.sum())
-    obj = {"value": frames / dt, "unit": "valid mel-frames/s", "cores": threads, "kind": "port",
+    # port-vs-reference calibration: the REAL reference and this port timed on the same batch, host and
+    # thread count in the build container, recorded with the full-size digest (tests/golden/make_golden_fullsize.py)
+    calib = None
+    try:
+        meta = torch.load(os.path.join(ROOT, "tests", "golden", "fullsize_train_B64.pt"), weights_only=False)["meta"]
+        calib = {"where": "build container, %d threads, %s" % (meta["threads"], meta["batch"]),
+                 "reference_frames_per_s": round(meta["reference_frames_per_s"], 1),
+                 "port_frames_per_s": round(meta["oracle_frames_per_s"], 1),
+                 "port_over_reference": round(meta["oracle_frames_per_s"] / meta["reference_frames_per_s"], 3)}
+    except Exception:                                   # noqa: BLE001
+        pass
+    obj = {"value": frames / dt, "unit": "valid mel-frames/s", "cores": threads, "kind": "port", "calibration": calib,
            "with_optimizer": frames / (dt + dopt),
            "sample": "oracle/tacotron2_oracle.py on %s (Ti_max=%d, To_max=%d, %d valid frames), fp32: 1 warm-up + 2 timed "
                      "fwd+bwd steps of %.1f s each; clip_grad_norm_ + Adam add %.2f s per step (with_optimizer)"
@@ -331,7 +342,8 @@ def compact_line(out):
     c = out.get("cpu_baseline")
     if c:
         o["cpu_baseline"] = {"value": _r(c["value"], 1), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
-                             "with_optimizer": _r(c["with_optimizer"], 1), "sample": c["sample"].split(", fp32:")[0] + "; 1 warm-up + 2 timed fwd+bwd steps"}
+                             "with_optimizer": _r(c["with_optimizer"], 1), "sample": c["sample"].split(", fp32:")[0] + "; 1 warm-up + 2 timed fwd+bwd steps",
+                             "calibration": c.get("calibration")}
     pc = out.get("parity_check")
     if pc:
         o["parity_check"] = {k: _r(v, 9) for k, v in pc.items() if k != "tolerance"}

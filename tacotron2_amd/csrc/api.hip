@@ -227,6 +227,160 @@ extern "C" int t2amd_debug_edge_(void* buf, long long buf_bytes, unsigned* count
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+// ---- tools/microbench_edge_flagdata.py (round 4; VERDICT r03 item 3): the two all-to-all edges of a FORWARD decoder time step as
+// FLAG + DATA hand-offs (Guideline 16 R1: 16-byte write-through payload stores, every storing wave drains, ONE relaxed flag store
+// per workgroup; consumers poll the 256 flags with one wave, then read the payload with sc1 loads straight from L2) -- not a
+// barrier (tools/microbench_edge.py measured that: 6.1-8.6 us) and not granules.  256 co-resident 512-thread workgroups
+// alternate two roles per round, in the chain's own geometry:
+//   role L ("LSTM pair", workgroup j of 256): waits for the 256 T flags of the previous round, reads `con_l` bytes of what the
+//          attention step left (ctx / h: the activation matrix every LSTM workgroup streams), publishes its 64 rows x 16 B
+//          h-slice (4 hidden units, f32) and ONE flag;
+//   role T ("attention", workgroup (b, s) = (j / 4, j % 4)): waits for the 256 L flags, reads its utterance's whole h row
+//          (4 KB = 256 x 16 B from 256 different producers), publishes its 128-channel context slice (512 B) and ONE flag.
+// Every payload word carries the round number: a consumer that reads a stale word counts it (`stale`), so the number is for a
+// hand-off that is also CORRECT.  mode 0: both roles in one persistent launch; mode 1 / 2: one role's body of one round as a
+// launch of its own (no flags: the kernel boundary orders them) -- the host alternates them for the launch-chain comparison.
+struct EdgeFDParams {
+    f32x4* h;            // [64][256] float4: row b, producer j
+    f32x4* ctx;          // [64][4][32] float4: utterance b, slice s
+    unsigned* flagL;      // [256]
+    unsigned* flagT;      // [256]
+    int rounds, mode, round0, con_l_f4, delay, work_l, work_t;
+    unsigned long long* clk;   // [4]: total ticks, ticks spent waiting in role T, in role L
+    int* status;
+    unsigned* stale;
+};
+typedef unsigned u32x4_efd __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void efd_store_sc1(f32x4* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+static __device__ __forceinline__ f32x4 efd_load_sc1(const f32x4* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+static __device__ __forceinline__ bool efd_wait(const unsigned* flags, unsigned target, int delay, int* status, int lane) {
+    // one wave polls 256 flags: 16 bytes (4 flags) per lane, relaxed agent-scope loads, after a short pause
+    for (int d = 0; d < delay; ++d) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+        u32x4_efd f;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(flags + 4 * lane) : "memory");
+        const bool ok = f.x >= target && f.y >= target && f.z >= target && f.w >= target;
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0 && wall_clock64() - t0 > 3000000ull) { if (lane == 0) atomicExch(status, 1); return false; }
+    }
+}
+__global__ __launch_bounds__(512) void t2_edge_flagdata_kernel(EdgeFDParams p) {
+    __shared__ int s_fail;
+    __shared__ unsigned long long s_wait[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = blockIdx.x, b = j >> 2, sl = j & 3;
+    if (tid == 0) { s_fail = 0; s_wait[0] = s_wait[1] = 0; }
+    __syncthreads();
+    float acc = 0.f;
+    unsigned stale = 0;
+    const unsigned long long t_begin = wall_clock64();
+    const int r_lo = p.mode == 0 ? 0 : p.round0, r_hi = p.mode == 0 ? p.rounds : p.round0 + 1;
+    for (int r = r_lo; r < r_hi; ++r) {
+        const float tag = (float)(r + 1);
+        if (p.mode != 2) {
+            // ---------------- role L ----------------
+            if (r > 0) {
+                if (p.mode == 0) {
+                    if (wave == 0) {
+                        const unsigned long long w0 = wall_clock64();
+                        if (!efd_wait(p.flagT, (unsigned)r, p.delay, p.status, lane) && lane == 0) s_fail = 1;
+                        if (lane == 0) s_wait[1] += wall_clock64() - w0;
+                    }
+                    __syncthreads();
+                    if (s_fail) return;
+                }
+                // what the LSTM workgroup streams: ctx of every utterance (and as much more as con_l asks for, wrapping)
+                for (int i = tid; i < p.con_l_f4; i += 512) {
+                    const f32x4 v = p.mode == 0 ? efd_load_sc1(p.ctx + (i & 8191)) : p.ctx[i & 8191];
+                    if (v.x != (float)r) ++stale;
+                    acc += v.y;
+                }
+            }
+            for (int i = 0; i < p.work_l; ++i) __builtin_amdgcn_s_sleep(16);
+            if (tid < 64) {
+                const f32x4 v = f32x4{tag, acc, (float)j, 1.f};
+                if (p.mode == 0) efd_store_sc1(p.h + tid * 256 + j, v); else p.h[tid * 256 + j] = v;
+            }
+            if (p.mode == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains (only wave 0 stored)
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.flagL + j, (unsigned)(r + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (p.mode != 1) {
+            // ---------------- role T ----------------
+            if (p.mode == 0) {
+                if (wave == 0) {
+                    const unsigned long long w0 = wall_clock64();
+                    if (!efd_wait(p.flagL, (unsigned)(r + 1), p.delay, p.status, lane) && lane == 0) s_fail = 1;
+                    if (lane == 0) s_wait[0] += wall_clock64() - w0;
+                }
+                __syncthreads();
+                if (s_fail) return;
+            }
+            if (tid < 256) {                                              // the utterance's h: 256 x 16 B from 256 producers
+                const f32x4 v = p.mode == 0 ? efd_load_sc1(p.h + b * 256 + tid) : p.h[b * 256 + tid];
+                if (v.x != tag) ++stale;
+                acc += v.z;
+            }
+            for (int i = 0; i < p.work_t; ++i) __builtin_amdgcn_s_sleep(16);
+            if (tid < 32) {
+                const f32x4 v = f32x4{tag, acc, 2.f, 3.f};
+                if (p.mode == 0) efd_store_sc1(p.ctx + (b * 4 + sl) * 32 + tid, v); else p.ctx[(b * 4 + sl) * 32 + tid] = v;
+            }
+            if (p.mode == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(p.flagT + j, (unsigned)(r + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (stale) atomicAdd(p.stale, stale);
+    if (tid == 0 && blockIdx.x == 0 && p.mode == 0) {
+        p.clk[0] = wall_clock64() - t_begin;
+        p.clk[1] = s_wait[0];
+        p.clk[2] = s_wait[1];
+    }
+    if (acc == 123.456f) p.status[0] = 7;
+}
+// h: 64*256 float4 (256 KB), ctx: 8192 float4 (128 KB), flags: 512 zeroed uint32, clk: 4 uint64, status / stale: zeroed.
+// mode 0: one persistent launch of `rounds` rounds; mode 3: the launch chain -- `rounds` x (L launch, T launch).
+extern "C" int t2amd_debug_edge_flagdata_(void* h, void* ctx, unsigned* flags, int rounds, int mode, int con_l_bytes, int delay,
+                                          int work_l, int work_t, int lds_bytes, unsigned long long* clk, int* status,
+                                          unsigned* stale, void* stream) {
+    if (!h || !ctx || !flags || !clk || !status || !stale || rounds < 1) return -1;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)t2_edge_flagdata_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        return -2;
+    EdgeFDParams p;
+    p.h = (f32x4*)h; p.ctx = (f32x4*)ctx; p.flagL = flags; p.flagT = flags + 256; p.rounds = rounds; p.round0 = 0;
+    p.con_l_f4 = con_l_bytes / 16; p.delay = delay; p.work_l = work_l; p.work_t = work_t; p.clk = clk; p.status = status; p.stale = stale;
+    const int lds = lds_bytes < 256 ? 256 : lds_bytes;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) {
+        p.mode = 0;
+        hipLaunchKernelGGL(t2_edge_flagdata_kernel, dim3(256), dim3(512), lds, s, p);
+    } else {
+        for (int r = 0; r < rounds; ++r) {
+            p.round0 = r;
+            p.mode = 1;
+            hipLaunchKernelGGL(t2_edge_flagdata_kernel, dim3(256), dim3(512), lds, s, p);
+            p.mode = 2;
+            hipLaunchKernelGGL(t2_edge_flagdata_kernel, dim3(256), dim3(512), lds, s, p);
+        }
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 // tests only (tests/test_zz9_dp_gpu.py: co-residency stress): `ncus` workgroups that each take a whole CU's LDS
 // (160 KB dynamic: nothing else that needs LDS can be placed beside them) and sleep until `*stop` becomes non-zero or
 // `ms` milliseconds of the 100 MHz wall clock have passed -- the stand-in for a co-resident RCCL kernel that takes CUs

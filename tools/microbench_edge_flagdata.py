@@ -1,0 +1,97 @@
+"""The one edge round 3 did not measure: the two all-to-all edges of a FORWARD decoder time step as FLAG + DATA
+hand-offs inside one persistent launch, next to the same two phases as two dependent launches per time step.
+
+    timeout 300 python tools/microbench_edge_flagdata.py          # on the GPU box; writes gpurun_out/microbench_edge_flagdata.json
+
+csrc/api.hip, t2_edge_flagdata_kernel: 256 co-resident 512-thread workgroups (the chain's geometry, one per CU) alternate the
+LSTM-pair role (publish a 64 x 16 B h-slice + ONE flag; wait for the 256 attention flags; stream `con_l` bytes of ctx) and the
+attention role (wait for the 256 LSTM flags; read the utterance's 4 KB h row from 256 producers; publish a 512 B context slice
++ ONE flag).  Payload stores are 16-byte write-through (sc1), every storing wave drains, the flag is one relaxed agent-scope
+store; one wave polls the 256 flags (16 B per lane) after a short pause; payload loads are sc1.  Every word carries the round
+number and stale words are counted -- the cost is that of a CORRECT hand-off.
+
+What decides a persistent forward pair (DESIGN 6 worksheet): a round of two in-launch edges against the two kernel boundaries
+it replaces, with the phases' own work in place (work = s_sleep units: the edge is hidden or not behind uneven arrival).
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tacotron2_amd import native as nv
+
+lib = nv.load()
+f = lib.t2amd_debug_edge_flagdata_
+f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+              C.c_void_p, C.c_void_p]
+f.restype = C.c_int
+LDS = 100000                                   # one workgroup per CU, as the weight-streaming kernels
+dev = "cuda"
+
+
+def run(mode, rounds, con_l, delay, work_l, work_t):
+    h = torch.zeros(64 * 256 * 4, device=dev)
+    ctx = torch.zeros(8192 * 4, device=dev)
+    flags = torch.zeros(512, dtype=torch.int32, device=dev)
+    clk = torch.zeros(4, dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    stale = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = f(h.data_ptr(), ctx.data_ptr(), flags.data_ptr(), rounds, mode, con_l, delay, work_l, work_t, LDS, clk.data_ptr(),
+           status.data_ptr(), stale.data_ptr(), nv._stream())
+    e1.record()
+    torch.cuda.synchronize()
+    ev_us = e0.elapsed_time(e1) * 1e3 / rounds
+    c = clk.tolist()
+    return dict(rc=rc, status=int(status.item()), stale_words=int(stale.item()), us_per_round_events=ev_us,
+                us_per_round_device_clock=c[0] / 100.0 / rounds if mode == 0 else None,
+                us_waiting_for_lstm_flags_per_round=c[1] / 100.0 / rounds if mode == 0 else None,
+                us_waiting_for_attention_flags_per_round=c[2] / 100.0 / rounds if mode == 0 else None)
+
+
+def best_of(n, *a):
+    rs = [run(*a) for _ in range(n)]
+    bad = [r for r in rs if r["rc"] != 0 or r["status"] != 0]
+    if bad:
+        return bad[0]
+    return min(rs, key=lambda r: r["us_per_round_events"])
+
+
+R = 2000
+out = {"rounds": R, "geometry": "256 workgroups x 512 threads, %d B of LDS each (one per CU)" % LDS,
+       "payload": "L publishes 64 x 16 B, T reads 4 KB (256 producers); T publishes 512 B, L reads con_l bytes of ctx", "cases": []}
+run(0, 200, 131072, 8, 0, 0)                    # warm-up (code object, clocks)
+run(3, 200, 131072, 8, 0, 0)
+for label, con_l, work_l, work_t in (("bare edges (L reads 16 B)", 16, 0, 0),
+                                     ("L streams ctx f32 (128 KB)", 131072, 0, 0),
+                                     ("L streams ctx + h bf16-sized (320 KB)", 327680, 0, 0),
+                                     ("128 KB + phase work ~4.3 / ~4.3 us", 131072, 10, 10),
+                                     ("128 KB + phase work ~8.6 / ~6.5 us (the chain's kernel bodies)", 131072, 20, 15)):
+    chain = best_of(3, 3, R, con_l, 0, work_l, work_t)
+    row = {"case": label, "con_l_bytes": con_l, "work_units": [work_l, work_t],
+           "two_launches_us_per_round": chain["us_per_round_events"], "persistent": {}}
+    for delay in (0, 4, 8, 16, 32):
+        p = best_of(3, 0, R, con_l, delay, work_l, work_t)
+        row["persistent"]["delay_%d" % delay] = p
+    ok = [v for v in row["persistent"].values() if v.get("rc") == 0 and v.get("status") == 0]
+    if ok:
+        b = min(ok, key=lambda v: v["us_per_round_events"])
+        row["best_persistent_us_per_round"] = b["us_per_round_events"]
+        row["in_launch_minus_launches_us_per_round"] = b["us_per_round_events"] - chain["us_per_round_events"]
+        row["stale_words_total"] = sum(v["stale_words"] for v in ok)
+    out["cases"].append(row)
+    print("%-64s two launches %6.2f us/round | persistent best %6.2f (%s) stale %s" % (
+        label, chain["us_per_round_events"], row.get("best_persistent_us_per_round", float("nan")),
+        " ".join("%s:%.2f" % (k[6:], v["us_per_round_events"]) for k, v in row["persistent"].items() if "us_per_round_events" in v),
+        row.get("stale_words_total")))
+    if ok:
+        print("    waits per round (best): for LSTM flags %.2f us, for attention flags %.2f us" % (
+            b["us_waiting_for_lstm_flags_per_round"], b["us_waiting_for_attention_flags_per_round"]))
+os.makedirs("gpurun_out", exist_ok=True)
+with open("gpurun_out/microbench_edge_flagdata.json", "w") as fh:
+    json.dump(out, fh, indent=1)
