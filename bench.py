@@ -312,17 +312,20 @@ def compact_line(out):
         def kern(v):
             return {"kernel": v["kernel"].split(" (")[0], "achieved": _r(v["achieved"], 1), "frac": _r(v["frac"]),
                     "traffic": _r(v["traffic"], 0) if v.get("traffic") else None, "avg_launch_us": _r(v["avg_launch_us"], 2),
+                    "us_per_time_step": _r(v.get("us_per_time_step", v["avg_launch_us"]), 2),
                     "launches": v["launches"], "algorithmic_bytes_per_launch": _r(v["algorithmic_bytes_per_launch"], 0),
                     "mfma_frac": _r(v["mfma"]["frac"])}
         top = kern(r)
         top.update(bound="hbm", peak=8000.0, unit="GB/s",
-                   dominant_of="largest total duration of the 4 kernels of a decoder time step, event pairs stamped by the dispatch")
+                   dominant_of="largest total duration among the kernels of the decoder time loops (forward: one persistent launch "
+                               "or LSTM pair + attention step; backward: attention backward + dgrad pair), event pairs stamped by the dispatch")
         top["chain"] = {k: kern(v) for k, v in r["chain"].items()}
         top["chain_us_per_time_step"] = _r(r["chain_us_per_time_step"], 2)
         w = r["whole_step"]
         top["whole_step"] = {"algorithmic_bytes_per_padded_time_step": w["algorithmic_bytes_per_padded_time_step"],
                              "time_steps": w["time_steps"], "achieved": _r(w["achieved"], 1), "frac": _r(w["frac"]),
-                             "dependent_launches_per_time_step": w["dependent_launches_per_time_step"]}
+                             "dependent_launches_per_time_step": w["dependent_launches_per_time_step"],
+                             "forward_loop": w.get("forward_loop")}
         o["roofline"] = top
     if "fp32_mode" in out:
         o["fp32_mode"] = {"value": _r(out["fp32_mode"]["value"], 1), "ms_per_step": _r(out["fp32_mode"]["ms_per_step"], 2),
@@ -536,8 +539,17 @@ def main():
         # 12 floats, 1 mask byte, 4 bf16 (the dgrad operand copy, bf16 mode)
         attn_bytes = es * 640.0 * ti_sum
         cell_bytes = B * (Ha + Hd) * (12 * 4.0 + 1.0 + (8.0 if es == 2.0 else 0.0)) if folded else 0.0
+        persistent_fwd = getattr(model, "last_train_decoder_path", "") == "persistent"
+        lstm_pair_bytes = lstm_bytes(Kd, Hd, False) + lstm_bytes(Ka, Ha, True)
+        attn_fwd_bytes = es * 640.0 * ti_sum + es * A * Ha
         specs = [
             # (key, profiling role, kernel symbol, what, algorithmic bytes per launch, flops per launch)
+            ("decoder_forward_persistent", 7, "dec_train_fwd_persistent_kernel",
+             "the WHOLE teacher-forced forward loop in one launch: per time step the LSTM pair (decoder LSTM of step t-1 beside the "
+             "attention LSTM of step t, bf16 MFMA + fused cells) and the attention step (energies, granule hand-off, softmax + context), "
+             "flag + data hand-offs between them; 256 co-resident workgroups",
+             To * (lstm_pair_bytes + attn_fwd_bytes),
+             To * (2.0 * B * (4 * Hd * Kd + 4 * Ha * Ka) + 2.0 * (B * A * Ha + ti_sum * (A * 62 + A + E)))),
             ("lstm_pair", 3 if fused else 2,
              ("skinny_wide_kernel<true,3>" if es == 2.0 else "skinny_gemm_kernel<true,3,false>") if fused else "skinny_gemm_kernel<true,2>",
              "decoder LSTM of step t-1 (64x2560x4096) + attention LSTM of step t (64x1536x4096), %s + fused cells" % mm
@@ -571,6 +583,10 @@ def main():
         for key, role, sym, what, nbytes, flops in specs:
             if not fused and key in ("attention_forward", "attention_backward", "dgrad_pair"):
                 continue
+            if key == "decoder_forward_persistent" and not persistent_fwd:
+                continue
+            if persistent_fwd and key in ("lstm_pair", "attention_forward"):
+                continue                           # their bodies run inside the persistent launch: no launches of their own
             avg_s, cnt = timed_role(role)
             if cnt == 0:
                 continue
@@ -579,6 +595,9 @@ def main():
                           "unit": "GB/s", "frac": nbytes / avg_s / 1e9 / 8000.0,
                           "traffic": t.get("hbm_bytes") if t else None, "traffic_detail": t,
                           "avg_launch_us": avg_s * 1e6, "launches": cnt, "total_ms_per_step": avg_s * cnt * 1e3,
+                          # one launch of the persistent loop covers every time step: its share of a time step beside the
+                          # per-step launches of the backward loop
+                          "us_per_time_step": avg_s * 1e6 / (To if key == "decoder_forward_persistent" else 1),
                           "algorithmic_bytes_per_launch": nbytes,
                           "mfma": {"achieved_tflops": flops / avg_s / 1e12, "peak_tflops": peak_tf,
                                    "frac": flops / avg_s / 1e12 / peak_tf}}
@@ -588,7 +607,7 @@ def main():
                                    "--kernel-trace --stats of the same command: profiles/"
                                    % ", ".join("%s %.1f ms" % (k, v["total_ms_per_step"]) for k, v in chain.items()))
         roofline["chain"] = chain
-        roofline["chain_us_per_time_step"] = sum(v["avg_launch_us"] for v in chain.values())
+        roofline["chain_us_per_time_step"] = sum(v["us_per_time_step"] for v in chain.values())
         if "lstm_pair" in chain:
             roofline["lstm_pair"] = {k: chain["lstm_pair"][k] for k in ("kernel", "achieved", "frac", "avg_launch_us", "traffic",
                                                                        "algorithmic_bytes_per_launch", "mfma")}
@@ -599,7 +618,8 @@ def main():
             "algorithmic_bytes_per_padded_time_step": per_step, "time_steps": To, "ms_per_step": ms_step,
             "achieved": per_step * To / (ms_step / 1e3) / 1e9, "unit": "GB/s",
             "frac": per_step * To / (ms_step / 1e3) / 1e9 / 8000.0,
-            "dependent_launches_per_time_step": 2 + (2 if folded else 3),
+            "dependent_launches_per_time_step": (0 if persistent_fwd else 2) + (2 if folded else 3),
+            "forward_loop": "one persistent launch for all time steps" if persistent_fwd else "two dependent launches per time step",
             "note": "SURVEY 8d: 2 x (step weights + encoder memory) + saved activations per padded time step; encoder, "
                     "postnet, dense weight-gradient GEMMs and the optimiser are inside ms_per_step but not in the bytes"}
     # ---- the same step in fp32 parity mode, reported beside a bf16 run (fewer steps, same batches) ----------

@@ -572,6 +572,21 @@ typedef struct t2amd_dec_train {
 
 int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream);
 
+/* The same loop as ONE persistent launch (reference model.py:405-411 around Decoder.decode :340-379; BASELINE north_star:
+ * "the decode loop is fused into a persistent wavefront-resident kernel").  max(Ha/8 + Hd/8, 4 B) co-resident 512-thread
+ * workgroups alternate the LSTM-tile role and the attention role of every time step; the two all-to-all edges of a step are
+ * flag + data hand-offs (write-through payload, one step counter per workgroup in `flags`:
+ * t2amd_decoder_train_fwd_persistent_flag_bytes(B, Ha) bytes, zeroed by the call).  Same arithmetic in the same order as the
+ * launch chain above: every output is bit-identical to it.  bf16 operand mode only (p->bf16 with every bf16 copy present),
+ * B <= 64, Ti <= 512; `_supported` returns 0 when the geometry fits a device of `cus` compute units (every workgroup must be
+ * resident at once), else T2AMD_ERR_ARG with the reason in t2amd_last_error().  Spins are bounded (50 ms of the wall clock):
+ * a give-up sets *status != 0 and every workgroup leaves; with `poison` non-NULL a one-thread launch behind the kernel
+ * turns poison[0] into NaN in that case (for callers that do not read status back) and counts it for
+ * t2amd_attn_handoff_timeouts(). */
+long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha);
+int t2amd_decoder_train_fwd_persistent_supported(const t2amd_dec_train* p, int cus);
+int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, unsigned* flags, int* status, float* poison, void* stream);
+
 /* BPTT through the same loop (what autograd replays for reference train.py:226). */
 typedef struct t2amd_dec_train_bwd {
     t2amd_dec_train f;       /* the forward description (slabs now inputs) */

@@ -22,6 +22,7 @@
 // kernel: results are bit-reproducible run to run.
 #include "common.h"
 #include "cell_bwd.h"
+#include "skinny_wide.h"
 #include <stdlib.h>
 #include <stddef.h>
 
@@ -73,14 +74,26 @@ __device__ __forceinline__ int tap_offset(int tap, int TIP) {
 // thread) are issued with the rest of the prologue loads and only written after them (a conditional load inside the
 // staging loop is waited for on the spot); utterances longer than the block take the remaining passes in a loop.
 struct WinRegs { float wp, cm; };
+// SC1 (the persistent training-forward kernel): values another workgroup of the SAME launch wrote (write-through) are read
+// with device-scope loads that bypass this CU's L1 -- a plain load may hit a line cached before the producer's store.
+template <bool SC1> __device__ __forceinline__ float ld_xwg(const float* p) {
+    if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool SC1> __device__ __forceinline__ void st_xwg(float* p, float v) {
+    if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool SC1 = false>
 __device__ __forceinline__ WinRegs stage_windows_issue(int TIP, int Ti, const float* wprev, const float* cum, int tid) {
     int ti = tid - HALO;
     ti = ti < 0 ? 0 : (ti > Ti - 1 ? Ti - 1 : ti);       // clamped: always a valid element, selected below
     WinRegs r;
-    r.cm = cum[ti];
-    r.wp = wprev ? wprev[ti] : 0.f;
+    r.cm = ld_xwg<SC1>(cum + ti);
+    r.wp = wprev ? ld_xwg<SC1>(wprev + ti) : 0.f;
     return r;
 }
+template <bool SC1 = false>
 __device__ __forceinline__ void stage_windows_finish(const WinRegs& r, float* win_s, int TIP, int Ti, const float* wprev,
                                                      const float* cum, int tid, int nthreads) {
     if (tid < TIP) {
@@ -92,8 +105,8 @@ __device__ __forceinline__ void stage_windows_finish(const WinRegs& r, float* wi
     for (int i = tid + nthreads; i < TIP; i += nthreads) {
         const int ti = i - HALO;
         const bool in = (ti >= 0 && ti < Ti);
-        win_s[i] = (in && wprev) ? wprev[ti] : 0.f;
-        win_s[TIP + i] = in ? cum[ti] : 0.f;
+        win_s[i] = (in && wprev) ? ld_xwg<SC1>(wprev + ti) : 0.f;
+        win_s[TIP + i] = in ? ld_xwg<SC1>(cum + ti) : 0.f;
     }
 }
 // the slice's 32 rows of U (1984 contiguous floats, 16-byte aligned): one float4 per thread
@@ -247,7 +260,9 @@ static int attn_dbg_stage() {
 // phase.  GRAN: the partial energies leave as 8-byte {launch token, f32} granules, [B][Ti][4 slices], instead of floats.
 // `after_prologue` runs once every prologue load has been issued and h has been staged (i.e. landed): what it issues
 // flies behind the q phase and the tiles without holding up anything of this phase (loads complete in order).
-template <bool GRAN, bool EARLYP, class Hook>
+// PERSIST (the persistent training-forward kernel): h, the previous weights and the cumulative weights were written by other
+// workgroups of this very launch -- device-scope (sc1) loads.
+template <bool GRAN, bool EARLYP, bool PERSIST, class Hook>
 __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, const int ds, const int b, bool& ts_on,
                                          Hook&& after_prologue) {
     const t2amd_attn_fwd& a = p.a;
@@ -276,7 +291,7 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
     const float* wprev_b = a.w_prev ? a.w_prev + (long long)b * a.ld_wprev : nullptr;
     const float* cum_b = a.cum + (long long)b * Ti;
     const float4 ureg = stage_u_issue(a.U + (long long)ds * DSL * NTAP, tid);
-    const WinRegs wreg = stage_windows_issue(TIP, Ti, wprev_b, cum_b, tid);
+    const WinRegs wreg = stage_windows_issue<PERSIST>(TIP, Ti, wprev_b, cum_b, tid);
     float vv[2][4];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -324,7 +339,13 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
         }
         {
             // h staged behind the W_q loads: its store is the first consumer of the whole prologue
-            const float4 hv = h4[tid < n4 ? tid : 0];
+            float4 hv;
+            if constexpr (PERSIST) {
+                const float* hq = a.h + (long long)b * a.ld_h + 4 * (tid < n4 ? tid : 0);
+                hv.x = ld_xwg<true>(hq); hv.y = ld_xwg<true>(hq + 1); hv.z = ld_xwg<true>(hq + 2); hv.w = ld_xwg<true>(hq + 3);
+            } else {
+                hv = h4[tid < n4 ? tid : 0];
+            }
             if (tid < n4) h_s4[tid] = hv;
             for (int j = tid + KE_NT; j < n4; j += KE_NT) h_s4[j] = h4[j];
         }
@@ -334,7 +355,7 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
             // the W_q stream, so they have landed -- and the location product of this lane's first two position tiles,
             // which needs nothing else, runs while the W_q rows are still on their way (same MFMAs on the same operands
             // as in the tile loop below: bit-identical)
-            stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
+            stage_windows_finish<PERSIST>(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
             stage_u_finish(ureg, u_s, tid);
         }
         __syncthreads();
@@ -380,7 +401,7 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
         }
     }
     if constexpr (!EARLY) {
-        stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
+        stage_windows_finish<PERSIST>(wreg, win_s, TIP, Ti, wprev_b, cum_b, tid, KE_NT);
         stage_u_finish(ureg, u_s, tid);
     }
     {
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     if (p.a.active && !p.a.active[blockIdx.y]) return;
-    ke_phase<false, false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {});
+    ke_phase<false, false, false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -643,9 +664,9 @@ struct KcPre {
     float c_old0;
     int len;
 };
-template <bool M16, bool LOAD_E> __device__ __forceinline__ void kc_issue(const AttnFwdParams& p, int cs, int b, KcPre<M16>& r, float (&e_first)[4]);
-template <bool M16, bool FUSED> __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, int cs, int b, bool& ts_on,
-                                                                         const KcPre<M16>& r, const float (&e_first)[4]);
+template <bool M16, bool LOAD_E, bool PERSIST = false> __device__ __forceinline__ void kc_issue(const AttnFwdParams& p, int cs, int b, KcPre<M16>& r, float (&e_first)[4]);
+template <bool M16, bool FUSED, bool PERSIST = false> __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, int cs, int b, bool& ts_on,
+                                                                                          const KcPre<M16>& r, const float (&e_first)[4]);
 
 template <bool M16>
 __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
@@ -662,7 +683,7 @@ __global__ __launch_bounds__(KC_NT) void attn_context_kernel(AttnFwdParams p) {
 }
 
 // LOAD_E: the four partial energies of this thread's first position are loaded here (two-launch form), first
-template <bool M16, bool LOAD_E>
+template <bool M16, bool LOAD_E, bool PERSIST>
 __device__ __forceinline__ void kc_issue(const AttnFwdParams& p, const int cs, const int b, KcPre<M16>& r, float (&e_first)[4]) {
     constexpr int CPT = M16 ? 8 : 4;          // channels per thread
     constexpr int KC_MAXR = KcPre<M16>::MAXR;
@@ -700,7 +721,7 @@ __device__ __forceinline__ void kc_issue(const AttnFwdParams& p, const int cs, c
     }
     // slice 0 also carries the cumulative weights forward: its read-modify-write operand is fetched now
     r.c_old0 = 0.f;
-    if (cs == 0) r.c_old0 = cum_b[tc0];
+    if (cs == 0) r.c_old0 = ld_xwg<PERSIST>(cum_b + tc0);
     // The context rows do not depend on the softmax.  Rows past the utterance are clamped to row 0 (an L1 hit) and
     // get weight 0 below: the kernel is bound by the rows it moves, skipping the padding is worth the scalar wait.
 #pragma unroll
@@ -713,7 +734,9 @@ __device__ __forceinline__ void kc_issue(const AttnFwdParams& p, const int cs, c
 }
 
 // FUSED: Ti <= KC_NT (one position per thread; the host checks), e_first came through the granules
-template <bool M16, bool FUSED>
+// PERSIST: the weights row and the cumulative weights (read by the utterance's four workgroups at the next time step of the
+// same launch) and the bf16 context (read by every LSTM tile) leave as write-through stores; the caller drains them.
+template <bool M16, bool FUSED, bool PERSIST>
 __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, const int cs, const int b, bool& ts_on,
                                           const KcPre<M16>& r, const float (&e_first)[4]) {
     constexpr int CPT = M16 ? 8 : 4;
@@ -779,10 +802,10 @@ __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, c
             const float w = w_s[ti] * inv;
             w_s[ti] = w;
             if (cs == 0) {
-                wout[ti] = w;
-                const float c_old = (ti == tid) ? c_old0 : cum[ti];
+                st_xwg<PERSIST>(wout + ti, w);
+                const float c_old = (ti == tid) ? c_old0 : ld_xwg<PERSIST>(cum + ti);
                 if (csave) csave[ti] = c_old;
-                cum[ti] = c_old + w;
+                st_xwg<PERSIST>(cum + ti, c_old + w);
             }
         }
     }
@@ -825,7 +848,11 @@ __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, c
         float s = 0.f;
         for (int q = 0; q < parts; ++q) s += part_s[q * EC + c];
         a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c] = s;
-        if (a.ctx16_out) reinterpret_cast<unsigned short*>(a.ctx16_out)[(long long)b * a.ld_ctx16 + cs * EC + c] = t2_f32_to_bf16(s);
+        if (a.ctx16_out) {
+            unsigned short* c16 = reinterpret_cast<unsigned short*>(a.ctx16_out) + (long long)b * a.ld_ctx16 + cs * EC + c;
+            if constexpr (PERSIST) __hip_atomic_store(c16, t2_f32_to_bf16(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *c16 = t2_f32_to_bf16(s);
+        }
     }
     T2_TS(21);
 }
@@ -840,6 +867,36 @@ __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, c
 // long-latency operand -- are issued behind K_e's prologue and land during the q phase and the tiles.  Same per-thread
 // arithmetic and summation order as the two launches: bit-identical weights, context and cumulative weights.
 // ---------------------------------------------------------------------------------------
+// The energy hand-off of the one-launch forms: thread ti < len polls the four granules of position ti (32 contiguous bytes)
+// until they carry this step's token.  Bounded like every spin here: 50 ms of the 100 MHz wall clock, then NaN energies
+// (-> NaN weights and context) instead of a hung GPU.
+__device__ __forceinline__ void fwd_energy_granules(const AttnFwdParams& p, const int b, const int len, float (&e_first)[4]) {
+    const t2amd_attn_fwd& a = p.a;
+    const int tid = threadIdx.x;
+    const int Ti = a.Ti;
+    const at_u64* g = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + ((long long)b * Ti + (tid < Ti ? tid : Ti - 1)) * NSL;
+    const bool need = tid < len;
+    for (int d_ = 0; d_ < p.delay; ++d_) __builtin_amdgcn_s_sleep(1);
+    at_u64 x[NSL];
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0_ = wall_clock64();
+    unsigned spins_ = 0;
+    bool bad = false;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) ok = ok && (unsigned)(x[k] >> 32) == p.token;
+        if (__all(ok || !need)) break;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; t2_attn_gave_up(); break; }
+    }
+#pragma unroll
+    for (int k = 0; k < NSL; ++k) e_first[k] = bad ? __builtin_nanf("") : __uint_as_float((unsigned)x[k]);
+}
+
 template <bool M16>
 __global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams p) {
     static_assert(KE_NT == KC_NT, "one thread mapping for both phases");
@@ -851,34 +908,9 @@ __global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams 
     const int tid = threadIdx.x;
     KcPre<M16> r;
     float e_first[4] = {0.f, 0.f, 0.f, 0.f};
-    ke_phase<true, M16>(p, smem, sl, b, ts_on, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
+    ke_phase<true, M16, false>(p, smem, sl, b, ts_on, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
     T2_TS(16);
-    {
-        // thread ti < len polls the four granules of position ti (32 contiguous bytes).  Bounded like every spin here:
-        // 50 ms of the 100 MHz wall clock, then NaN energies (-> NaN weights and context) instead of a hung GPU.
-        const int Ti = a.Ti;
-        const at_u64* g = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + ((long long)b * Ti + (tid < Ti ? tid : Ti - 1)) * NSL;
-        const bool need = tid < r.len;
-        for (int d_ = 0; d_ < p.delay; ++d_) __builtin_amdgcn_s_sleep(1);
-        at_u64 x[NSL];
-#pragma unroll
-        for (int k = 0; k < NSL; ++k) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0_ = wall_clock64();
-        unsigned spins_ = 0;
-        bool bad = false;
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < NSL; ++k) ok = ok && (unsigned)(x[k] >> 32) == p.token;
-            if (__all(ok || !need)) break;
-            __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-            for (int k = 0; k < NSL; ++k) x[k] = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((++spins_ & 255u) == 0 && wall_clock64() - t0_ > 5000000ll) { bad = true; t2_attn_gave_up(); break; }
-        }
-#pragma unroll
-        for (int k = 0; k < NSL; ++k) e_first[k] = bad ? __builtin_nanf("") : __uint_as_float((unsigned)x[k]);
-    }
+    fwd_energy_granules(p, b, r.len, e_first);
     kc_finish<M16, true>(p, smem + p.kc_smem_off, sl, b, ts_on, r, e_first);
 }
 
@@ -952,6 +984,311 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     if (a->memory16) T2_LAUNCH(attn_context_kernel<true>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     else T2_LAUNCH(attn_context_kernel<false>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// =========================================================================================
+// The teacher-forced decoder loop, forward, as ONE persistent launch (round 4; BASELINE north_star: "the decode loop is fused
+// into a persistent wavefront-resident kernel"; reference model.py:405-411 around Decoder.decode :340-379).
+//
+// The launch chain runs a time step as two dependent launches -- the fused LSTM pair (skinny_wide_kernel: LSTM_a(t) beside
+// LSTM_d(t-1)) and the one-launch attention step (attn_fwd_fused_kernel) -- 2 x To kernel boundaries of ~2.95 us each on an
+// MI355X (trivial 256-workgroup kernels, tools/microbench_edge_flagdata.py).  Here the same two bodies, unchanged in their
+// arithmetic (skinny_wide_body, ke_phase / kc_finish: device functions shared with those kernels), alternate inside one
+// launch of max(Ha/8 + Hd/8, 4 B) co-resident 512-thread workgroups, one per CU, and the two all-to-all edges of a step are
+// FLAG + DATA hand-offs (Guideline 16 R1; measured 2.1 us per edge in this geometry, profiles/r04_microbench_edge_flagdata.json):
+//   workgroup j < Ha/8       LSTM_a tile j;  Ha/8 <= j < Ha/8 + Hd/8   LSTM_d tile;   j < 4 B   attention workgroup (b, s) = (j/4, j%4)
+//   L(t):  wait until every attention workgroup has finished step t-1 (flagT >= t) -> LSTM_a(t) | LSTM_d(t-1): activations by sc1
+//          LDS-DMA, h and its bf16 copy out as write-through stores -> every wave drains -> LSTM_a tiles: flagA[j] = t+1
+//   T(t):  wait until every LSTM_a tile has finished step t (flagA >= t+1) -> K_e, energy granules among the utterance's four
+//          workgroups, K_c: weights / cumulative weights / bf16 context out write-through -> drain -> flagT[j] = t+1
+// LSTM_d tiles publish nothing of their own: the workgroup that ran LSTM_d(t-1) publishes flagT[j] = t+1 only after it, so
+// "all flagT >= t+1" also says h_d(t-1) is complete.  Every exchanged tensor is written once per step with sc1 stores and
+// read with sc1 loads / sc1 DMA; nothing else in the arithmetic differs from the chain: outputs are BIT-IDENTICAL to it.
+// Spins are bounded (wall clock); a give-up sets *status and every workgroup leaves at its next wait.
+// =========================================================================================
+struct DecTrainPersist {
+    t2amd_dec_train d;
+    int tip, kc_smem_off, delay_a, delay_t, fail_off;
+    unsigned token0;
+    long long gran_off, ws_floats;
+    unsigned* flagA;           // [Ha/8]
+    unsigned* flagT;           // [4 B]
+    int* status;
+    long long timeout_ticks;
+    unsigned long long* ts;
+    unsigned long long* prof;   // tools only (t2amd_debug_dtp_prof_): [2 workgroups][4] accumulated wall-clock ticks -- wait for
+                                // the attention flags, LSTM tile, wait for the LSTM flags, attention step -- of workgroup 0
+                                // (LSTM_a tile 0 + attention (0, 0)) and of workgroup Ha/8 (LSTM_d tile 0)
+};
+
+typedef unsigned dtp_u32x4 __attribute__((ext_vector_type(4)));
+// one wave: all n flags >= target?  (16 bytes per lane when the count allows, else one word per lane and pass)
+__device__ __forceinline__ bool dtp_wait(const unsigned* flags, const int n, const unsigned target, const int delay, int* status,
+                                         const long long ticks, const int lane) {
+    for (int d_ = 0; d_ < delay; ++d_) __builtin_amdgcn_s_sleep(1);
+    const long long t0 = wall_clock64();
+    unsigned spins = 0;
+    const bool vec = (n & 3) == 0 && n <= 256;
+    for (;;) {
+        bool ok = true;
+        if (vec) {
+            if (4 * lane < n) {
+                dtp_u32x4 f;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(flags + 4 * lane) : "memory");
+                ok = f.x >= target && f.y >= target && f.z >= target && f.w >= target;
+            }
+        } else {
+            for (int i = lane; i < n; i += 64) ok = ok && __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+        }
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;     // somebody gave up
+            if (wall_clock64() - t0 > ticks) { if (lane == 0) atomicExch(status, 1); return false; }
+        }
+    }
+}
+
+__device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t, SkinnyParams& a) {
+    // attention LSTM of step t: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T   (loops.hip fill_a, bf16 operands)
+    const long long sHa = (long long)d.B * d.Ha, sE = (long long)d.B * d.E;
+    const unsigned short* c16 = (const unsigned short*)d.CTX16;
+    const unsigned short* h16 = (const unsigned short*)d.HA16;
+    a = SkinnyParams{};
+    a.nseg = 2;
+    a.x[0].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr; a.x[0].ld = d.E; a.x[0].width = d.E;
+    a.x[1].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr; a.x[1].ld = d.Ha; a.x[1].width = d.Ha;
+    a.x[2].p = nullptr; a.x[2].ld = 0; a.x[2].width = 0;
+    a.W = (const float*)d.Wa_rec16; a.Ktot = d.E + d.Ha; a.H = d.Ha; a.B = d.B; a.N = 4 * d.Ha;
+    a.gin = d.GA + (long long)t * d.B * 4 * d.Ha; a.ld_gin = 4 * d.Ha;
+    a.c_prev = t ? d.CA + (t - 1) * sHa : nullptr; a.ld_cprev = d.Ha;
+    a.gates_out = d.GA + (long long)t * d.B * 4 * d.Ha; a.ld_gates = 4 * d.Ha;
+    a.c_out = d.CA + t * sHa; a.ld_c = d.Ha;
+    a.h_out = d.HA + t * sHa; a.ld_h = d.Ha;
+    a.h16_out = (unsigned short*)d.HA16 + t * sHa; a.ld_h16 = d.Ha;
+    a.keep = d.keep_att ? d.keep_att + t * sHa : nullptr; a.ld_keep = d.Ha; a.keep_scale = d.scale_att;
+    a.gx = d.Ha / 8; a.gy = 1; a.gz = 1;
+}
+__device__ __forceinline__ void dtp_fill_d(const t2amd_dec_train& d, const int u, SkinnyParams& a) {
+    // decoder LSTM of step u: gates = bias_d + [h_att_u | ctx_u | h_dec_{u-1}] . Wd_cat^T   (loops.hip fill_d, bf16 operands)
+    const long long sHa = (long long)d.B * d.Ha, sHd = (long long)d.B * d.Hd, sE = (long long)d.B * d.E;
+    const unsigned short* c16 = (const unsigned short*)d.CTX16;
+    const unsigned short* ha16 = (const unsigned short*)d.HA16;
+    unsigned short* hd16 = (unsigned short*)d.HD16;
+    a = SkinnyParams{};
+    a.nseg = 3;
+    a.x[0].p = (const float*)(ha16 + u * sHa); a.x[0].ld = d.Ha; a.x[0].width = d.Ha;
+    a.x[1].p = (const float*)(c16 + u * sE); a.x[1].ld = d.E; a.x[1].width = d.E;
+    a.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd) : nullptr; a.x[2].ld = d.Hd; a.x[2].width = d.Hd;
+    a.W = (const float*)d.Wd_cat16; a.Ktot = d.Ha + d.E + d.Hd; a.H = d.Hd; a.B = d.B; a.N = 4 * d.Hd;
+    a.bias = d.bias_d;
+    a.c_prev = u ? d.CD + (u - 1) * sHd : nullptr; a.ld_cprev = d.Hd;
+    a.gates_out = d.GD + (long long)u * d.B * 4 * d.Hd; a.ld_gates = 4 * d.Hd;
+    a.c_out = d.CD + u * sHd; a.ld_c = d.Hd;
+    a.h_out = d.HD + u * sHd; a.ld_h = d.Hd;
+    a.h16_out = hd16 + u * sHd; a.ld_h16 = d.Hd;
+    a.keep = d.keep_dec ? d.keep_dec + u * sHd : nullptr; a.ld_keep = d.Hd; a.keep_scale = d.scale_dec;
+    a.gx = d.Hd / 8; a.gy = 1; a.gz = 1;
+}
+
+// The loop description is read from the kernel-argument segment INSIDE every iteration, through a pointer the compiler cannot
+// see through: as an ordinary by-value argument every field (and every address derived from one: LICM) is loaded / computed
+// once at entry and carried across the whole loop -- 256 VGPRs, 263 SGPR + 119 VGPR spills, 480 B of scratch per lane in the
+// first build.  Scalar loads from the constant cache once per time step cost nothing next to that.
+__device__ __forceinline__ const DecTrainPersist& dtp_args_late() {
+    typedef const char __attribute__((address_space(4))) * kptr_t;
+    kptr_t k = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return *reinterpret_cast<const DecTrainPersist*>((const char*)k);
+}
+
+__global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainPersist P_entry) {
+    extern __shared__ __attribute__((aligned(16))) char psmem_[];
+    const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int To = P_entry.d.To;
+    bool ts_on = false;
+    if (tid == 0) reinterpret_cast<int*>(psmem_ + P_entry.fail_off)[0] = 0;
+    __syncthreads();
+    for (int t = 0; t <= To; ++t) {
+        const DecTrainPersist& P = dtp_args_late();
+        const t2amd_dec_train& d = P.d;
+        int zero = 0;
+        asm volatile("" : "+s"(zero));                   // LDS addresses are formed per iteration too
+        char* const psmem = psmem_ + zero;
+        float* const smem = reinterpret_cast<float*>(psmem);
+        int* const fail_s = reinterpret_cast<int*>(psmem + P.fail_off);      // behind both phases' regions
+        const int nA = d.Ha / 8, nL = nA + d.Hd / 8, nT = NSL * d.B;
+        const bool isA = j < nA, isD = j >= nA && j < nL, isT = j < nT;
+        const int b = j / NSL, sl = j % NSL;
+        const bool prof_on = P.prof != nullptr && tid == 0 && (j == 0 || j == nA);
+        unsigned long long* const prof = P.prof + (j == 0 ? 0 : 4);
+        unsigned long long c0 = prof_on ? wall_clock64() : 0ull, c1;
+#define DTP_PROF(slot) do { if (prof_on) { c1 = wall_clock64(); prof[slot] += c1 - c0; c0 = c1; } } while (0)
+        // ---------------- L(t) ----------------
+        if (t > 0 && (isA || isD)) {
+            if (wave == 0 && !dtp_wait(P.flagT, nT, (unsigned)t, P.delay_a, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
+            __syncthreads();
+            if (fail_s[0]) return;
+        }
+        DTP_PROF(0);
+        if ((isA && t < To) || (isD && t > 0)) {
+            // ONE call site for both roles (two inlined copies of the tile body in sibling branches crash hipcc's SimplifyCFG)
+            SkinnyParams sp;
+            if (isA) dtp_fill_a(d, t, sp);
+            else dtp_fill_d(d, t - 1, sp);
+            skinny_wide_body<true, true>(sp, isA ? j : j - nA, psmem, P.ts);
+        }
+        // every storing wave drains its write-through stores (R1), then ONE flag per LSTM_a tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (isA && t < To && tid == 0) __hip_atomic_store(P.flagA + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DTP_PROF(1);
+        if (t == To) break;
+        // ---------------- T(t) ----------------
+        if (isT) {
+            if (wave == 0 && !dtp_wait(P.flagA, nA, (unsigned)(t + 1), P.delay_t, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
+            __syncthreads();
+            if (fail_s[0]) return;
+            DTP_PROF(2);
+            const long long sHa = (long long)d.B * d.Ha, sE = (long long)d.B * d.E;
+            AttnFwdParams ap;
+            ap.a = t2amd_attn_fwd{};
+            ap.a.B = d.B; ap.a.Ti = d.Ti; ap.a.E = d.E; ap.a.Hq = d.Ha;
+            ap.a.h = d.HA + t * sHa; ap.a.ld_h = d.Ha;
+            ap.a.Wq = d.Wq; ap.a.U = d.U; ap.a.v = d.v; ap.a.pm = d.pm; ap.a.memory = d.memory; ap.a.lens = d.lens;
+            ap.a.ws = d.attn_ws; ap.a.ws_floats = P.ws_floats;
+            ap.a.w_prev = t ? d.ALIGN + (long long)(t - 1) * d.Ti : nullptr; ap.a.ld_wprev = (long long)To * d.Ti;
+            ap.a.cum = d.cum_work;
+            ap.a.cum_save = d.CUM + (long long)t * d.B * d.Ti;
+            ap.a.w_out = d.ALIGN + (long long)t * d.Ti; ap.a.ld_wout = (long long)To * d.Ti;
+            ap.a.ctx_out = d.CTX + t * sE; ap.a.ld_ctx = d.E;
+            ap.a.q_out = d.Q + (long long)t * d.B * AD; ap.a.ld_q = AD;
+            ap.a.ctx16_out = (void*)((unsigned short*)d.CTX16 + t * sE); ap.a.ld_ctx16 = d.E;
+            ap.a.loc_split_bf16 = 1; ap.a.memory16 = d.memory16; ap.a.Wq16 = d.Wq16;
+            ap.tip = P.tip; ap.dbg = 0; ap.ts = P.ts;
+            ap.token = P.token0 + (unsigned)t; ap.gran_off = P.gran_off; ap.kc_smem_off = P.kc_smem_off; ap.delay = 0;
+            KcPre<true> r;
+            float e_first[4] = {0.f, 0.f, 0.f, 0.f};
+            ke_phase<true, true, true>(ap, smem, sl, b, ts_on, [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
+            fwd_energy_granules(ap, b, r.len, e_first);
+            kc_finish<true, true, true>(ap, smem + P.kc_smem_off, sl, b, ts_on, r, e_first);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(P.flagT + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            DTP_PROF(3);
+        }
+#undef DTP_PROF
+    }
+}
+
+// A give-up of the launch above turns one word of the step's data into NaN (the launch's own status is not read back by
+// the training step: no host sync in the loop) and is counted, like an abandoned attention hand-off.
+__global__ void dec_train_persist_poison_kernel(const int* status, float* poison) {
+    if (*status != 0) {
+        t2_attn_gave_up();
+        *poison = __builtin_nanf("");
+    }
+}
+
+// tools only: 8 zeroed device uint64 that the next launches accumulate their phase clocks into (NULL switches it off)
+static unsigned long long* g_dtp_prof = nullptr;
+extern "C" int t2amd_debug_dtp_prof_(unsigned long long* buf) { g_dtp_prof = buf; return T2AMD_OK; }
+
+extern "C" long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha) {
+    return 4ll * (Ha / 8 + (long long)NSL * B);
+}
+
+static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out) {
+    T2_REQUIRE(p != nullptr, "dec_train_fwd_persistent: null args");
+    T2_REQUIRE(p->bf16 && p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16 && p->memory16 && p->Wq16,
+               "dec_train_fwd_persistent: bf16 operand mode only (bf16 copies of the weights, the recurrent slabs, the memory and W_q)");
+    T2_REQUIRE(p->B > 0 && p->B <= SK_ROWS, "dec_train_fwd_persistent: one 64-row tile (B <= 64)");
+    T2_REQUIRE(p->Ti > 0 && p->Ti <= KC_NT && p->To > 0, "dec_train_fwd_persistent: one position per thread (Ti <= 512)");
+    T2_REQUIRE(p->E % 128 == 0 && p->Ha % 128 == 0 && p->Hd % 128 == 0 && p->Ha <= 2048, "dec_train_fwd_persistent: E, Ha, Hd multiples of 128, Ha <= 2048");
+    const int tip = attn_tip(p->Ti);
+    const size_t lds_e = sizeof(float) * (2 * (size_t)tip + DSL + DSL * NTAP + (size_t)p->Ha);
+    const int EC = p->E / NCS;
+    T2_REQUIRE(EC % 8 == 0, "dec_train_fwd_persistent: E a multiple of 32");
+    int parts = KC_NT / (EC / 8);
+    if (parts > 32) parts = 32;
+    T2_REQUIRE(parts >= 1, "dec_train_fwd_persistent: E too large");
+    const size_t lds_c = sizeof(float) * ((size_t)((p->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
+    const size_t lds_ea = (lds_e + 15) / 16 * 16;
+    T2_REQUIRE(lds_ea + lds_c <= 64 * 1024, "dec_train_fwd_persistent: Ti too large for the LDS windows");
+    size_t lds = (size_t)SW_NBUF * (SW_XB + SW_WB);
+    if (lds_ea + lds_c > lds) lds = lds_ea + lds_c;
+    lds = (lds + 15) / 16 * 16;
+    *fail_off_out = (int)lds;
+    *lds_out = lds + 16;
+    *tip_out = tip;
+    *kc_off_out = (int)(lds_ea / sizeof(float));
+    return T2AMD_OK;
+}
+
+// 0 = this loop can run as one persistent launch on a device with `cus` compute units; else T2AMD_ERR_ARG + reason
+extern "C" int t2amd_decoder_train_fwd_persistent_supported(const t2amd_dec_train* p, int cus) {
+    size_t lds; int tip, kc, fo;
+    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo));
+    const int nL = p->Ha / 8 + p->Hd / 8, nT = NSL * p->B;
+    const int grid = nL > nT ? nL : nT;
+    // one workgroup per CU (96 KB of LDS each): every one of them must be resident at once
+    T2_REQUIRE(grid <= cus, "dec_train_fwd_persistent: more workgroups than compute units (they must all be co-resident)");
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, unsigned* flags, int* status, float* poison,
+                                                      void* stream) {
+    size_t lds; int tip, kc, fo;
+    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo));
+    T2_REQUIRE(flags && status, "dec_train_fwd_persistent: null flags / status");
+    T2_REQUIRE(p->Wa_rec && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->GA && p->memory && p->pm && p->lens &&
+                   p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work && p->attn_ws,
+               "dec_train_fwd_persistent: null pointer");
+    const int B = p->B, Ti = p->Ti;
+    const long long fwd_ws_floats = t2amd_attn_fwd_ws_floats(B, Ti);
+    DecTrainPersist P;
+    P.d = *p;
+    P.tip = tip; P.kc_smem_off = kc; P.fail_off = fo;
+    // pre-poll pauses in s_sleep units (tuning knobs, read per call so that a tool can sweep them in one process)
+    { const char* e = getenv("T2AMD_DTP_DELAY_L"); const int v = e ? atoi(e) : 64; P.delay_a = v < 0 ? 0 : (v > 400 ? 400 : v); }
+    { const char* e = getenv("T2AMD_DTP_DELAY_T"); const int v = e ? atoi(e) : 64; P.delay_t = v < 0 ? 0 : (v > 400 ? 400 : v); }
+    P.gran_off = ((long long)NSL * B * Ti + 3) / 4 * 4;
+    P.ws_floats = fwd_ws_floats;
+    T2_REQUIRE((reinterpret_cast<uintptr_t>(p->attn_ws + P.gran_off) & 7u) == 0, "dec_train_fwd_persistent: attn_ws must be 8-byte aligned");
+    // one token per time step, never zero, never one the granule block (zeroed below) has seen
+    if (g_attn_fwd_token > 0xf0000000u - (unsigned)p->To) g_attn_fwd_token = 0;
+    P.token0 = g_attn_fwd_token + 1;
+    g_attn_fwd_token += (unsigned)p->To;
+    P.flagA = flags; P.flagT = flags + p->Ha / 8;
+    P.status = status;
+    const char* te = getenv("T2AMD_DTP_TIMEOUT_TICKS");
+    P.timeout_ticks = te ? atoll(te) : 5000000ll;                   // 50 ms of the 100 MHz wall clock
+    if (P.timeout_ticks < 1) P.timeout_ticks = 1;
+    P.ts = attn_ts_buffer();
+    P.prof = g_dtp_prof;
+    if (t2amd_validate_only_flag_()) return T2AMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    T2_PROPAGATE(t2amd_fill_f32(p->cum_work, (long long)B * Ti, 0.f, stream));
+    T2_PROPAGATE(t2amd_fill_f32(p->attn_ws + P.gran_off, fwd_ws_floats - P.gran_off, 0.f, stream));
+    if (hipMemsetAsync(flags, 0, (size_t)t2amd_decoder_train_fwd_persistent_flag_bytes(B, p->Ha), s) != hipSuccess ||
+        hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess)
+        T2_FAIL("dec_train_fwd_persistent: memset failed");
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)dec_train_fwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            T2_FAIL("dec_train_fwd_persistent: cannot raise the dynamic LDS limit");
+        lds_set = lds;
+    }
+    const int nL = p->Ha / 8 + p->Hd / 8, nT = NSL * B;
+    // role 7 of bench.py's roofline leg: the whole forward loop of the step is this one launch
+    T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
+    T2_LAUNCH_CHECK();
+    if (poison) {
+        hipLaunchKernelGGL(dec_train_persist_poison_kernel, dim3(1), dim3(1), 0, s, status, poison);
+        T2_LAUNCH_CHECK();
+    }
     return T2AMD_OK;
 }
 

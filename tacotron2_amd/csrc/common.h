@@ -42,7 +42,8 @@ extern "C" void t2amd_profile_mark_(int tag, int end, hipStream_t s);
 // The same launch carrying an event pair when bench.py's roofline leg profiles role `role` (t2amd_profile_enable): the
 // pair is stamped by the dispatch itself (hipExtLaunchKernelGGL start/stop events = the kernel begin/end timestamps
 // rocprofv3 --kernel-trace reports), so there is no bracket overhead to calibrate away.  Roles: 3 fused LSTM pair of a
-// decoder time step, 4 attention backward (+ folded cells), 5 attention forward (one-launch form), 6 BPTT dgrad pair.
+// decoder time step, 4 attention backward (+ folded cells), 5 attention forward (one-launch form), 6 BPTT dgrad pair,
+// 7 the persistent forward loop (all time steps' LSTM pairs and attention steps in ONE launch).
 extern "C" bool t2amd_profile_pair_(int tag, hipEvent_t* e0, hipEvent_t* e1);
 #define T2_LAUNCH_ROLE(role, kern, grid, block, lds, stream, ...)                      \
     do {                                                                               \

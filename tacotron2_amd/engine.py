@@ -711,8 +711,11 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
 # in a loop that reads the loss back every iteration (train.py, as the reference's: 61.35 vs 61.72 ms per step); in a loop
 # that never synchronises (bench.py) the step measured 63.1 / 62.2 against 63.0 / 61.7 ms (profiles/r03_zd_*), so the
 # default stays the chain there.
+# Round 4: re-measured once the collector pause and the allocator calls were out of the step (tools/ab_engine_flag.py, four
+# alternating blocks in one process): 60.93 vs 61.35 ms per training step with the persistent launch -- it is now the default
+# for training too (T2AMD_ENCODER_BATCH_PERSISTENT_TRAIN=0 keeps the chain).
 ENCODER_BATCH_PERSISTENT = os.environ.get('T2AMD_ENCODER_BATCH_PERSISTENT', '1') != '0'
-ENCODER_BATCH_PERSISTENT_TRAIN = os.environ.get('T2AMD_ENCODER_BATCH_PERSISTENT_TRAIN', '0') == '1'
+ENCODER_BATCH_PERSISTENT_TRAIN = os.environ.get('T2AMD_ENCODER_BATCH_PERSISTENT_TRAIN', '1') != '0'
 
 
 def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None, run=None):
@@ -743,6 +746,29 @@ def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None, 
             model._enc_batch_backoff = min(256, 2 << model._enc_batch_timeouts)
             regen_gx()
     nv.lstm_seq_fwd2(d0, d1, reads=reads, writes=writes)
+    return 'launch chain'
+
+
+# The teacher-forced decoder loop as ONE persistent launch (csrc/attention.hip dec_train_fwd_persistent_kernel; bf16 mode,
+# B <= 64, one workgroup per CU) -- the default since round 4; T2AMD_TRAIN_FWD_PERSISTENT=0 keeps the launch chain (two
+# dependent launches per time step).  Bit-identical either way (tests/test_zz6_train_persistent_gpu.py); measured on one
+# MI355X, alternating blocks in one process (tools/ab_train_fwd_persistent.py, profiles/r04_*_ab_train_fwd_persistent.json):
+# forward 25.55 vs 25.86 ms, whole training step 61.8 vs 62.3 ms.
+TRAIN_FWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_FWD_PERSISTENT', '1') != '0'
+
+
+def _decoder_train_fwd(model, run, d, poison, reads, writes):
+    """reference model.py:405-411.  The persistent launch when it is selected and the geometry fits this device; the status is
+    not read back (no host sync in the training loop): a give-up -- its workgroups were not co-resident within 50 ms: a shared
+    GPU -- turns ``poison[0]`` into NaN, the step goes non-finite and handle_nonfinite_step() switches back to the chain."""
+    if TRAIN_FWD_PERSISTENT and run.bf16 and not nv.validate_only():
+        cus = torch.cuda.get_device_properties(run.dev).multi_processor_count
+        if nv.decoder_train_fwd_persistent_supported(d, cus) is None:
+            flags = run.empty_i32(nv.decoder_train_fwd_persistent_flag_words(d.B, d.Ha))
+            status = run.empty_i32(1)
+            nv.decoder_train_fwd_persistent(d, flags, status, poison)
+            return 'persistent'
+    nv.decoder_train_fwd_loop(d, reads=reads, writes=writes)
     return 'launch chain'
 
 
@@ -843,6 +869,8 @@ def handle_nonfinite_step(log=None):
             print(msg, file=sys.stderr, flush=True)
     n = nv.attn_handoff_timeouts(reset=True)
     if n > 0:
+        global TRAIN_FWD_PERSISTENT
+        TRAIN_FWD_PERSISTENT = False
         nv.set_attn_fwd_fused(0)
         nv.set_attn_bwd_fused(0)
         nv.set_bptt_cell_fold(0)
@@ -1076,11 +1104,11 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         d.bf16 = 1
         for k_, v_ in c.bf16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
-    nv.decoder_train_fwd_loop(d,                                                         # model.py:405-411
-                              reads=[Wa_rec, Wd_cat, bias_d, Wq, U, vvec, memory, pm, lens32, keep_att, keep_dec]
-                              + ([c.bf16[k_] for k_ in ('Wa_rec16', 'Wd_cat16', 'memory16', 'Wq16')] if run.bf16 else []),
-                              writes=[GA] + list(slabs.values())
-                              + ([c.bf16[k_] for k_ in ('HA16', 'HD16', 'CTX16')] if run.bf16 else []))
+    model.last_train_decoder_path = _decoder_train_fwd(
+        model, run, d, poison=slabs['CTX'] if training else None,                         # model.py:405-411
+        reads=[Wa_rec, Wd_cat, bias_d, Wq, U, vvec, memory, pm, lens32, keep_att, keep_dec]
+        + ([c.bf16[k_] for k_ in ('Wa_rec16', 'Wd_cat16', 'memory16', 'Wq16')] if run.bf16 else []),
+        writes=[GA] + list(slabs.values()) + ([c.bf16[k_] for k_ in ('HA16', 'HD16', 'CTX16')] if run.bf16 else []))
 
     # mel + gate projection over all steps (model.py:373-378)
     Wpg, bpg = _packed_projection(run, P, Cm, Hd, E)             # rows: Cm mel channels, then the gate

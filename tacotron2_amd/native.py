@@ -271,6 +271,7 @@ SYMBOLS = [
     "t2amd_fold_location_f32", "t2amd_unfold_location_grads_f32",
     "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
+    "t2amd_decoder_train_fwd_persistent_flag_bytes", "t2amd_decoder_train_fwd_persistent_supported", "t2amd_decoder_train_fwd_persistent_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
     "t2amd_set_attn_bwd_granules", "t2amd_attn_handoff_timeouts", "t2amd_set_attn_bwd_fused", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
@@ -328,6 +329,9 @@ def _argtypes():
         "t2amd_attention_step_fwd_f32": [pt(AttnFwd), _P],
         "t2amd_attention_step_bwd_f32": [pt(AttnBwd), _P],
         "t2amd_decoder_train_fwd_loop_f32": [pt(DecTrain), _P],
+        "t2amd_decoder_train_fwd_persistent_flag_bytes": [_I, _I],
+        "t2amd_decoder_train_fwd_persistent_supported": [pt(DecTrain), _I],
+        "t2amd_decoder_train_fwd_persistent_f32": [pt(DecTrain), _P, _P, _P, _P],
         "t2amd_decoder_train_bwd_loop_f32": [pt(DecTrainBwd), _P],
         "t2amd_lstm_seq_fwd_f32": [pt(LstmSeq), _P],
         "t2amd_lstm_seq_bwd_f32": [pt(LstmSeq), _P],
@@ -406,6 +410,7 @@ def load():
     lib.t2amd_decoder_persist_mailbox_bytes.restype = C.c_longlong
     lib.t2amd_lstm_seq_persistent_mailbox_bytes.restype = C.c_longlong
     lib.t2amd_lstm_seq_batch_persistent_flag_bytes.restype = C.c_longlong
+    lib.t2amd_decoder_train_fwd_persistent_flag_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
     # the binary must be THESE sources' binary (by content: a snapshot copy or a checkout resets mtimes).  An explicitly
@@ -1296,6 +1301,32 @@ def lstm_seq_fwd2_persistent(d0, d1, mailbox, status):
         raise NativeError("lstm_seq_fwd2_persistent: mailbox of %d bytes, %d needed" % (mailbox.numel() * mailbox.element_size(), need))
     _check(load().t2amd_lstm_seq_fwd2_persistent_f32(C.byref(d0), C.byref(d1), ptr(mailbox, torch.int64), ptr(status, torch.int32),
                                                      _stream()), "t2amd_lstm_seq_fwd2_persistent_f32")
+
+
+def decoder_train_fwd_persistent_supported(desc, cus):
+    """None when the teacher-forced decoder loop can run as ONE persistent launch on a device of `cus` CUs, else the reason."""
+    lib = load()
+    if lib.t2amd_decoder_train_fwd_persistent_supported(C.byref(desc), int(cus)) == 0:
+        return None
+    msg = lib.t2amd_last_error()
+    return msg.decode() if msg else "unsupported"
+
+
+def decoder_train_fwd_persistent_flag_words(B, Ha):
+    return int(load().t2amd_decoder_train_fwd_persistent_flag_bytes(int(B), int(Ha))) // 4
+
+
+def decoder_train_fwd_persistent(desc, flags, status, poison=None):
+    """reference model.py:405-411 (the teacher-forced loop) as one persistent launch (csrc/attention.hip,
+    dec_train_fwd_persistent_kernel): bit-identical to decoder_train_fwd_loop.  ``poison``: an f32 tensor whose first element
+    becomes NaN if a workgroup gave up (for callers that do not read ``status`` back)."""
+    lib = load()
+    need = lib.t2amd_decoder_train_fwd_persistent_flag_bytes(desc.B, desc.Ha)
+    if flags.dtype != torch.int32 or flags.numel() * 4 < need:
+        raise NativeError("decoder_train_fwd_persistent: int32 flags of %d bytes needed" % need)
+    _check(lib.t2amd_decoder_train_fwd_persistent_f32(C.byref(desc), C.c_void_p(flags.data_ptr()), ptr(status, torch.int32),
+                                                      ptr(poison) if poison is not None else None, _stream()),
+           "t2amd_decoder_train_fwd_persistent_f32")
 
 
 def lstm_seq_batch_persistent_supported(desc, ndir, cus):

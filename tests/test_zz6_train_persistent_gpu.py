@@ -1,0 +1,115 @@
+"""The teacher-forced decoder loop as ONE persistent launch (csrc/attention.hip dec_train_fwd_persistent_kernel; reference
+model.py:405-411 around Decoder.decode :340-379) against the launch chain it replaces: same model, batch and dropout masks.
+
+The persistent launch runs the SAME tile / attention bodies in the same arithmetic order; what differs is how the time steps
+hand data to each other (flag + data hand-offs inside one launch instead of kernel boundaries).  So the bar is BIT-IDENTITY of
+everything the step produces: the four outputs, the loss, all 60 gradients and the BatchNorm buffers -- for a ragged small batch,
+for partial geometries (B < 64: fewer attention workgroups than LSTM tiles) and for a full 64-row batch; plus what a give-up
+does (bounded spin -> NaN in the step's data, counted, and engine.handle_nonfinite_step() goes back to the chain)."""
+import os
+
+import pytest
+import torch
+
+import golden_util as gu
+from tacotron2_amd import engine, native
+from tacotron2_amd.loss_function import Tacotron2Loss
+from tacotron2_amd.model import Tacotron2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _step(m, batch, persistent, seed=7):
+    keep = engine.TRAIN_FWD_PERSISTENT
+    engine.TRAIN_FWD_PERSISTENT = persistent
+    try:
+        m.zero_grad()
+        torch.manual_seed(seed)                               # the Philox keep-masks are seeded from torch's RNG
+        x, y = m.parse_batch(batch)
+        out = m(x)
+        loss = Tacotron2Loss()(out, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return ([o.detach().clone() for o in out], loss.detach().clone(),
+                {k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                {k: v.detach().clone() for k, v in m.named_buffers()}, m.last_train_decoder_path)
+    finally:
+        engine.TRAIN_FWD_PERSISTENT = keep
+
+
+def _model(hp_str=""):
+    hp = gu.make_hparams(hp_str)
+    torch.manual_seed(1234)
+    m = Tacotron2(hp).to(DEV).train()
+    m.precision = "bf16"
+    return m, hp
+
+
+@pytest.mark.parametrize("in_lens,out_lens", [([23, 17, 9], [41, 33, 12]),                      # 12 attention workgroups, 256 LSTM tiles
+                                              ([37] + [30] * 20 + [11] * 12, [55] * 30 + [19] * 3),   # B = 33
+                                              (list(range(100, 36, -1)), [64 + (i % 7) for i in range(64)])])   # B = 64: every role on every workgroup
+def test_persistent_train_forward_is_bit_identical_to_the_launch_chain(native_lib, in_lens, out_lens):
+    m, hp = _model()
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch(in_lens, out_lens, hp.n_mel_channels, 5))
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    o0, l0, g0, b0, p0 = _step(m, batch, False)
+    m.load_state_dict(state)                                  # the BatchNorm running statistics moved: same start for both
+    o1, l1, g1, b1, p1 = _step(m, batch, True)
+    assert p0 == "launch chain" and p1 == "persistent"
+    assert native.attn_handoff_timeouts(reset=False) == 0
+    for i in range(4):
+        assert torch.isfinite(o1[i]).all() and torch.equal(o0[i], o1[i]), i
+    assert float(l0) == float(l1)
+    assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
+    assert [k for k in b0 if not torch.equal(b0[k], b1[k])] == []
+
+
+def test_persistent_train_forward_smaller_model_geometry(native_lib):
+    """H = 128 / E = 128: 16 + 16 LSTM tiles, 4 B attention workgroups -- more attention workgroups than tiles."""
+    m, hp = _model(gu.TINY_HP)
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch([14, 12, 9, 9, 6, 5, 5, 3, 2, 2], [20, 11, 18, 7, 13, 20, 5, 9, 12, 6], hp.n_mel_channels, 9))
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    o0, l0, g0, _, p0 = _step(m, batch, False)
+    m.load_state_dict(state)
+    o1, l1, g1, _, p1 = _step(m, batch, True)
+    assert (p0, p1) == ("launch chain", "persistent")
+    assert all(torch.equal(a, b) for a, b in zip(o0, o1)) and float(l0) == float(l1)
+    assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
+
+
+def test_fp32_mode_and_unsupported_geometries_stay_on_the_chain(native_lib):
+    m, hp = _model()
+    m.precision = "fp32"
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch([9, 5], [12, 7], hp.n_mel_channels, 3))
+    assert _step(m, batch, True)[4] == "launch chain"
+    m.precision = "bf16"
+    big = tuple(t.to(DEV) for t in gu.make_train_batch([8] * 65, [6] * 65, hp.n_mel_channels, 3))      # B = 65 > one row tile
+    assert _step(m, big, True)[4] == "launch chain"
+
+
+def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_lib, monkeypatch):
+    """A timeout of one tick makes every wait give up at once: status is set, the finishing launch turns the step's data into
+    NaN and counts it; handle_nonfinite_step() reports it and selects the launch chain (and the separate-launch attention
+    forms, which make no co-residency assumption either) for the rest of the process."""
+    m, hp = _model()
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 12, 7], [22, 15, 9], hp.n_mel_channels, 11))
+    native.attn_handoff_timeouts(reset=True)
+    monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "1")
+    forms = (native.get_attn_fwd_fused() if hasattr(native, "get_attn_fwd_fused") else None)
+    try:
+        o, loss, g, _, path = _step(m, batch, True)
+        assert path == "persistent"
+        assert not torch.isfinite(loss)                       # poisoned, not silently wrong
+        said = []
+        n = engine.handle_nonfinite_step(log=said.append)
+        assert n >= 1 and said and engine.TRAIN_FWD_PERSISTENT is False
+        monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
+        o2, loss2, _, _, path2 = _step(m, batch, engine.TRAIN_FWD_PERSISTENT)
+        assert path2 == "launch chain" and torch.isfinite(loss2)
+    finally:
+        engine.TRAIN_FWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_FWD_PERSISTENT', '1') != '0'
+        native.set_attn_fwd_fused(-1)
+        native.set_attn_bwd_fused(-1)
+        native.set_bptt_cell_fold(1)
+        del forms

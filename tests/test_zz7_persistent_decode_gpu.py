@@ -378,7 +378,21 @@ def test_two_or_three_utterances_decode_one_after_the_other_on_the_persistent_ke
     assert all(torch.isfinite(t).all() for t in p)
 
 
-@pytest.mark.parametrize("B,T", [(64, 61), (7, 23), (40, 9), (256, 50)])
+def test_batched_encoder_bilstm_persistent_leaves_a_co_residency_margin(native_lib):
+    """the launch takes at most 3/4 of the workgroups the runtime says can be co-resident (occupancy query, not a
+    hard-coded 4 per CU): B = 256 at H = 256 would need every slot of a 256-CU device and goes to the launch chain; B = 192 fits."""
+    from tacotron2_amd import native as nv
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    d = nv.LstmSeq()
+    d.B, d.T, d.H = 256, 50, 256
+    why = nv.lstm_seq_batch_persistent_supported(d, 2, cus)
+    if cus <= 256:
+        assert why is not None and "co-resident" in why
+    d.B = 192 if cus >= 256 else 64
+    assert nv.lstm_seq_batch_persistent_supported(d, 2, cus) is None
+
+
+@pytest.mark.parametrize("B,T", [(64, 61), (7, 23), (40, 9), (192, 50)])
 def test_batched_encoder_bilstm_persistent_matches_the_launch_chain(native_lib, B, T):
     """Encoder bi-LSTM of a batch (reference model.py:181-188, packed-sequence semantics) as ONE persistent launch -- W_hh
     fragments in registers, h handed on through the output slab (write-through stores + step counters) -- against the launch
