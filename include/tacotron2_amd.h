@@ -687,6 +687,15 @@ long long t2amd_lstm_seq_batch_persistent_flag_bytes(int B, int H, int ndir);
 int t2amd_lstm_seq_batch_persistent_supported(const t2amd_lstm_seq* p, int ndir, int cus);
 int t2amd_lstm_seq_fwd2_batch_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned* flags, int* status,
                                              float* poison, void* stream);
+/* BPTT of the same recurrence for a batch as ONE persistent launch (reference model.py:181-188 under autograd) instead of
+ * 2 T dependent launches (t2amd_lstm_seq_bwd2_f32): same workgroup layout, flag buffer size and hand-off as the forward launch
+ * above; the gate gradients go straight into p->DG (the slab the weight-gradient GEMMs read), the recurrent data gradient is a
+ * split-bf16 (hi + lo, three products, f32 accumulate: ~2^-17 relative) MFMA product against W_hh^T rows held in registers.
+ * Reads WhhT, GX (activated gates), C, lens, dout; dX / dc of the descriptor are not used.  Results equal the chain's to that
+ * product's rounding.  `_supported` / status / poison as for the forward launch. */
+int t2amd_lstm_seq_bwd2_batch_persistent_supported(const t2amd_lstm_seq* p, int ndir, int cus);
+int t2amd_lstm_seq_bwd2_batch_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned* flags, int* status,
+                                             float* poison, void* stream);
 /* give-ups of that launch since the last reset (synchronises the device); negative on a runtime error */
 int t2amd_encoder_handoff_timeouts(int reset);
 

@@ -1015,7 +1015,7 @@ struct DecTrainPersist {
     unsigned* flagA;           // [Ha/8]
     unsigned* flagT;           // [4 B]
     int* status;
-    long long timeout_ticks;
+    long long timeout_ticks, census_ticks;
     unsigned long long* ts;
     unsigned long long* prof;   // tools only (t2amd_debug_dtp_prof_): [2 workgroups][4] accumulated wall-clock ticks -- wait for
                                 // the attention flags, LSTM tile, wait for the LSTM flags, attention step -- of workgroup 0
@@ -1111,6 +1111,26 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
     bool ts_on = false;
     if (tid == 0) reinterpret_cast<int*>(psmem_ + P_entry.fail_off)[0] = 0;
     __syncthreads();
+    // Census: every workgroup of the launch must be RESIDENT at once (they wait for each other).  A workgroup that is not --
+    // CUs held by another process or kernel -- would only be dispatched when a resident one exits, which never happens while
+    // they spin: found out HERE, within 2 ms and before anything is written, instead of at the first hand-off after 50 ms.
+    if (wave == 0) {
+        unsigned* const census = P_entry.flagT + NSL * P_entry.d.B;
+        if (lane == 0) atomicAdd(census, 1u);
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        bool bad = false;
+        while (__hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 15u) == 0) {
+                if (__hip_atomic_load(P_entry.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = true; break; }
+                if (wall_clock64() - t0 > P_entry.census_ticks) { if (lane == 0) atomicCAS(P_entry.status, 0, 3); bad = true; break; }
+            }
+        }
+        if (bad && lane == 0) reinterpret_cast<int*>(psmem_ + P_entry.fail_off)[0] = 1;
+    }
+    __syncthreads();
+    if (reinterpret_cast<int*>(psmem_ + P_entry.fail_off)[0]) return;
     for (int t = 0; t <= To; ++t) {
         const DecTrainPersist& P = dtp_args_late();
         const t2amd_dec_train& d = P.d;
@@ -1197,7 +1217,7 @@ static unsigned long long* g_dtp_prof = nullptr;
 extern "C" int t2amd_debug_dtp_prof_(unsigned long long* buf) { g_dtp_prof = buf; return T2AMD_OK; }
 
 extern "C" long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha) {
-    return 4ll * (Ha / 8 + (long long)NSL * B);
+    return 4ll * (Ha / 8 + (long long)NSL * B + 1);          // LSTM_a tile counters, attention counters, the arrival census
 }
 
 static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out) {
@@ -1266,6 +1286,7 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     const char* te = getenv("T2AMD_DTP_TIMEOUT_TICKS");
     P.timeout_ticks = te ? atoll(te) : 5000000ll;                   // 50 ms of the 100 MHz wall clock
     if (P.timeout_ticks < 1) P.timeout_ticks = 1;
+    P.census_ticks = P.timeout_ticks < 200000ll ? P.timeout_ticks : 200000ll;      // 2 ms
     P.ts = attn_ts_buffer();
     P.prof = g_dtp_prof;
     if (t2amd_validate_only_flag_()) return T2AMD_OK;

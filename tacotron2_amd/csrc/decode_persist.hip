@@ -1149,6 +1149,254 @@ extern "C" int t2amd_encoder_handoff_timeouts(int reset) {
     return (int)v;
 }
 
+// ---------------------------------------------------------------------------------------
+// BPTT of the same recurrence for a BATCH as one persistent launch (round 4; reference model.py:181-188
+// under autograd).  The chain runs a step as two dependent launches -- the pointwise cell backward (rnn.hip) and the recurrent
+// data gradient dh(s-1) = dG(s) . W_hh (64 x 4H x H, split-K 4) -- 2 T launches of 5.0 + 6.3 us.  Here workgroup (direction,
+// row group of 32 utterances, unit group k of 4 hidden units) owns the same 32 x 4 cells as in the forward launch: it keeps
+// the cells' dc carry in registers, writes their four gate gradients straight into the DG slab the weight-gradient GEMMs read
+// -- write-through, R1 hand-off through per-workgroup step counters exactly as the forward hands h on -- and forms its four
+// columns of the NEXT step's recurrent gradient, dh[b][4k + u] = sum_n dG[b][n] W_hh[n][4k + u] over all 4H gate columns of its
+// 32 rows, which the H/4 workgroups of its own (direction, row group) have just produced.  W_hh^T rows of its four units live in
+// registers as split-bf16 MFMA B-fragments (hi + lo), the dG rows are split on the way in, and the product is
+// Ah.Bh + Ah.Bl + Al.Bh on v_mfma_f32_16x16x32_bf16 with f32 accumulation: ~2^-17 relative per product (what the engine's other
+// gradient GEMMs use in the parity mode: gemm_bf16x3), each wave a quarter of K, partial sums through LDS.  Per step and
+// workgroup: one poll of H/4 counters, 32 x 4H x 4 B = 128 KB of gate gradients from L2, 48 MFMAs per wave.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 eb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned eb_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void eb_split8(const f32x4& a, const f32x4& b, eb_u32x4& hi, eb_u32x4& lo) {
+    hi.x = t2_cvt_pk_bf16(a[0], a[1]); hi.y = t2_cvt_pk_bf16(a[2], a[3]);
+    hi.z = t2_cvt_pk_bf16(b[0], b[1]); hi.w = t2_cvt_pk_bf16(b[2], b[3]);
+    lo.x = t2_cvt_pk_bf16(a[0] - __uint_as_float(hi.x << 16), a[1] - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = t2_cvt_pk_bf16(a[2] - __uint_as_float(hi.y << 16), a[3] - __uint_as_float(hi.y & 0xffff0000u));
+    lo.z = t2_cvt_pk_bf16(b[0] - __uint_as_float(hi.z << 16), b[1] - __uint_as_float(hi.z & 0xffff0000u));
+    lo.w = t2_cvt_pk_bf16(b[2] - __uint_as_float(hi.w << 16), b[3] - __uint_as_float(hi.w & 0xffff0000u));
+}
+#define EBB_KS 8          // k-steps of 32 per wave: 4 waves x 8 x 32 = 4H = 1024 gate columns (H = 256); fewer for smaller H
+
+// FULL: H = 256, every wave runs all EBB_KS k-steps -- row tile 0 is complete while exactly 16 loads of row tile 1 are
+// outstanding (a counted wait); smaller H issues fewer loads and waits for all of them (a runtime choice between the two
+// waits cost 64 registers and the second workgroup per CU).
+template <bool FULL>
+__global__ __launch_bounds__(EB_NT) void encoder_bilstm_batch_persistent_bwd_kernel(EncBatchParams p) {
+    __shared__ __attribute__((aligned(16))) float red_s[4][2][16][4];     // [k quarter][row tile][row][unit]
+    __shared__ int fail_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_dir = p.nrg * p.nk;
+    const int dir = (int)blockIdx.x / per_dir, rg = ((int)blockIdx.x % per_dir) / p.nk, k = (int)blockIdx.x % p.nk;
+    const t2amd_lstm_seq& a = p.d[dir];
+    const int H = a.H, T = a.T, B = a.B, G4 = 4 * H;
+    unsigned* const flags = p.flags + ((size_t)dir * p.nrg + rg) * p.nk;
+    const int r0 = rg * EB_ROWS;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int kq = G4 / 4;                       // gate columns per wave (256 at H = 256)
+    const int nks = kq / 32;                     // k-steps of this wave (<= EBB_KS)
+    // B fragments: MFMA k index 8 lg + e of k-step ks <-> gate column n = kq wave + 32 ks + 8 lg + e; column n' = l15 < 4 <-> unit
+    // 4 k + l15 (the other twelve columns of the tile are zero): W_hh[n][4k + u] = WhhT[4k + u][n]
+    eb_u32x4 bh[EBB_KS], bl[EBB_KS];
+    {
+        const float* wrow = a.WhhT + (long long)(4 * k + (l15 & 3)) * G4 + kq * wave + 8 * lg;
+#pragma unroll
+        for (int ks = 0; ks < EBB_KS; ++ks) {
+            f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+            if (ks < nks && l15 < 4) {
+                w0 = *reinterpret_cast<const f32x4*>(wrow + 32 * ks);
+                w1 = *reinterpret_cast<const f32x4*>(wrow + 32 * ks + 4);
+            }
+            eb_split8(w0, w1, bh[ks], bl[ks]);
+        }
+    }
+    // the cell this thread owns (threads 0..127): row r0 + (tid >> 2), unit 4 k + (tid & 3)
+    const int crow = r0 + (tid >> 2), cu = 4 * k + (tid & 3);
+    const bool cell = tid < 128 && crow < B;
+    const int len = cell ? a.lens[crow] : 0;
+    float dc = 0.f;                               // dL/dc carried to the previous step (processing order)
+    if (tid == 0) fail_s = 0;
+    __syncthreads();
+    int arow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { const int r = r0 + 16 * mt + l15; arow[mt] = r < B ? r : B - 1; }
+
+    for (int s = T - 1; s >= 0; --s) {            // reverse of the processing order
+        const int t = a.reverse ? T - 1 - s : s;
+        const int tp = a.reverse ? t + 1 : t - 1; // the step before this one in processing order
+        // ---- this step's cell operands: none of them depends on another workgroup (issued ahead of the wait below) ----
+        float g4[4] = {0.f, 0.f, 0.f, 0.f}, cc = 0.f, cp = 0.f, dho = 0.f;
+        if (cell) {
+            const float* g = a.GX + ((long long)crow * T + t) * G4 + cu;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g4[q] = g[(long long)q * H];
+            cc = a.C[((long long)t * B + crow) * H + cu];
+            if (s > 0) cp = a.C[((long long)tp * B + crow) * H + cu];
+            dho = a.dout[((long long)crow * T + t) * a.ld_dout + cu];
+        }
+        // ---- the recurrent gradient into this step: dG of step s+1 (all 4H columns of my 32 rows) . my W_hh columns ----
+        float dhrec = 0.f;
+        if (s < T - 1) {
+            if (wave == 0) {
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                bool bad = false;
+                const unsigned target = (unsigned)(T - 1 - s);       // every workgroup of the group has finished step s+1
+                for (int d_ = 0; d_ < p.delay; ++d_) __builtin_amdgcn_s_sleep(1);
+                for (;;) {
+                    bool ok = true;
+                    for (int j = lane; j < p.nk; j += 64)
+                        ok = ok && __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 31u) == 0 && pb_give_up(t0, p.status, p.timeout_ticks)) { bad = true; break; }
+                }
+                if (bad && lane == 0) fail_s = 1;
+            }
+            __syncthreads();
+            if (fail_s) return;
+            const int tn = a.reverse ? t - 1 : t + 1;                 // time index of processing step s+1
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            // the gate gradients of BOTH row tiles in one round trip (32 x 16 B per lane in flight: one workgroup per CU has the
+            // whole register file; as two waited halves a step measured 7.75 us, profiles/r04_microbench_encoder_bwd_persistent.json)
+            f32x4 x0[2][EBB_KS], x1[2][EBB_KS];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float* grow = a.DG + ((long long)arow[mt] * T + tn) * G4 + kq * wave + 8 * lg;
+#pragma unroll
+                for (int ks = 0; ks < EBB_KS; ++ks) {
+                    x0[mt][ks] = (ks < nks) ? eb_load_sc1(grow + 32 * ks) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x1[mt][ks] = (ks < nks) ? eb_load_sc1(grow + 32 * ks + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                // the waits are tied to the loaded registers (the MFMAs below cannot be scheduled in front of them); loads
+                // return in order, so row tile 0 is complete while the 16 loads of row tile 1 are still outstanding
+                if (mt == 0 && FULL)
+                    asm volatile("s_waitcnt vmcnt(16)"
+                                 : "+v"(x0[0][0]), "+v"(x0[0][1]), "+v"(x0[0][2]), "+v"(x0[0][3]), "+v"(x0[0][4]), "+v"(x0[0][5]), "+v"(x0[0][6]), "+v"(x0[0][7]),
+                                   "+v"(x1[0][0]), "+v"(x1[0][1]), "+v"(x1[0][2]), "+v"(x1[0][3]), "+v"(x1[0][4]), "+v"(x1[0][5]), "+v"(x1[0][6]), "+v"(x1[0][7])
+                                 : : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(x0[1][0]), "+v"(x0[1][1]), "+v"(x0[1][2]), "+v"(x0[1][3]), "+v"(x0[1][4]), "+v"(x0[1][5]), "+v"(x0[1][6]), "+v"(x0[1][7]),
+                                   "+v"(x1[1][0]), "+v"(x1[1][1]), "+v"(x1[1][2]), "+v"(x1[1][3]), "+v"(x1[1][4]), "+v"(x1[1][5]), "+v"(x1[1][6]), "+v"(x1[1][7])
+                                 : : "memory");
+#pragma unroll
+                for (int ks = 0; ks < EBB_KS; ++ks) {
+                    if (ks < nks) {
+                        eb_u32x4 ah, al;
+                        eb_split8(x0[mt][ks], x1[mt][ks], ah, al);
+#define EBB_M(A_, B_) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(eb_bf16x8, (A_)), __builtin_bit_cast(eb_bf16x8, (B_)), acc[mt], 0, 0, 0)
+                        EBB_M(al, bh[ks]);
+                        EBB_M(ah, bl[ks]);
+                        EBB_M(ah, bh[ks]);
+#undef EBB_M
+                    }
+                }
+            }
+            // D layout: lane -> column n' = l15 (unit, < 4 meaningful), register r -> row 4 lg + r
+            if (l15 < 4) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red_s[wave][mt][4 * lg + r][l15] = acc[mt][r];
+            }
+            __syncthreads();
+            if (cell) {
+                const int lr = tid >> 2, u = tid & 3;
+                dhrec = (red_s[0][lr >> 4][lr & 15][u] + red_s[1][lr >> 4][lr & 15][u]) +
+                        (red_s[2][lr >> 4][lr & 15][u] + red_s[3][lr >> 4][lr & 15][u]);
+            }
+        }
+        // ---- the cell backward (arithmetic of cell_bwd_finish, csrc/cell_bwd.h, without dropout) ----
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        if (cell) {
+#pragma clang fp contract(off)
+            if (t < len) {
+                const float dh = (dho + dhrec) + 0.f;
+                const float tc = tanhf(cc);
+                const float d_o = dh * tc;
+                const float dcc = dc + dh * g4[3] * (1.f - tc * tc);
+                o0 = dcc * g4[2] * g4[0] * (1.f - g4[0]);
+                o1 = dcc * cp * g4[1] * (1.f - g4[1]);
+                o2 = dcc * g4[0] * (1.f - g4[2] * g4[2]);
+                o3 = d_o * g4[3] * (1.f - g4[3]);
+                dc = dcc * g4[1];
+            } else {
+                dc = 0.f;                        // packed-sequence semantics: steps behind the utterance carry nothing
+            }
+        }
+        // the four units of a row sit in four neighbouring lanes: one 16-byte write-through store per row and gate (R1 payload)
+        {
+            float* dg = a.DG + ((long long)crow * T + t) * G4 + 4 * k;
+            const float v[4] = {o0, o1, o2, o3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float y1 = __shfl_down(v[q], 1), y2 = __shfl_down(v[q], 2), y3 = __shfl_down(v[q], 3);
+                if (cell && (tid & 3) == 0) eb_store_sc1(dg + (long long)q * H, f32x4{v[q], y1, y2, y3});
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores (R1) ...
+        __syncthreads();                                             // ... (and red_s may be rewritten)
+        if (tid == 0) __hip_atomic_store(flags + k, (unsigned)(T - s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+extern "C" int t2amd_lstm_seq_bwd2_batch_persistent_supported(const t2amd_lstm_seq* p, int ndir, int cus) {
+    T2_REQUIRE(p != nullptr, "lstm_seq_bwd_batch_persistent: null args");
+    T2_REQUIRE(p->H % 64 == 0 && p->H >= 64 && p->H <= 256, "lstm_seq_bwd_batch_persistent: H must be a multiple of 64, <= 256");
+    T2_REQUIRE(p->T > 0 && p->B > 0, "lstm_seq_bwd_batch_persistent: B, T");
+    const long long wgs = (long long)ndir * ((p->B + EB_ROWS - 1) / EB_ROWS) * (p->H / 4);
+    int per_cu = 2;
+    if (!t2amd_validate_only_flag_()) {
+        static int occ = 0;
+        if (occ == 0) {
+            int n = 0;
+            occ = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, encoder_bilstm_batch_persistent_bwd_kernel<true>, EB_NT, 0) == hipSuccess && n > 0) ? n : -1;
+        }
+        if (occ > 0) per_cu = occ;
+    }
+    T2_REQUIRE(4 * wgs <= 3ll * per_cu * cus, "lstm_seq_bwd_batch_persistent: more workgroups than 3/4 of what can be co-resident");
+    return T2AMD_OK;
+}
+
+extern "C" int t2amd_lstm_seq_bwd2_batch_persistent_f32(const t2amd_lstm_seq* p, const t2amd_lstm_seq* q, unsigned* flags, int* status,
+                                                        float* poison, void* stream) {
+    T2_REQUIRE(p && p->WhhT && p->GX && p->C && p->lens && p->dout && p->DG && flags && status, "lstm_seq_bwd_batch_persistent: null pointer");
+    T2_REQUIRE(p->H % 64 == 0 && p->H >= 64 && p->H <= 256 && p->T > 0 && p->B > 0, "lstm_seq_bwd_batch_persistent: geometry");
+    T2_REQUIRE((reinterpret_cast<uintptr_t>(p->DG) & 15u) == 0 && (reinterpret_cast<uintptr_t>(p->WhhT) & 15u) == 0,
+               "lstm_seq_bwd_batch_persistent: DG and WhhT must be 16-byte aligned");
+    if (q) T2_REQUIRE(q->T == p->T && q->H == p->H && q->B == p->B && q->WhhT && q->GX && q->C && q->lens && q->dout && q->DG &&
+                          (reinterpret_cast<uintptr_t>(q->DG) & 15u) == 0 && (reinterpret_cast<uintptr_t>(q->WhhT) & 15u) == 0,
+                      "lstm_seq_bwd_batch_persistent: the two directions must match");
+    EncBatchParams e;
+    e.d[0] = *p;
+    e.d[1] = q ? *q : *p;
+    e.ndir = q ? 2 : 1;
+    e.nrg = (p->B + EB_ROWS - 1) / EB_ROWS;
+    e.nk = p->H / 4;
+    e.flags = flags;
+    e.status = status;
+    const char* te = getenv("T2AMD_PB_TIMEOUT_TICKS");
+    e.timeout_ticks = te ? atoll(te) : PB_TIMEOUT_TICKS;
+    if (e.timeout_ticks < 1) e.timeout_ticks = 1;
+    const char* de = getenv("T2AMD_EBB_DELAY");
+    e.delay = de ? atoi(de) : 8;          // measured: 1.21 ms at 4-8, 1.23 at 0 / 16, 1.44 at 64 (B = 64, T = 177)
+    if (t2amd_validate_only_flag_()) return T2AMD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(flags, 0, (size_t)t2amd_lstm_seq_batch_persistent_flag_bytes(p->B, p->H, e.ndir), s) != hipSuccess ||
+        hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess)
+        T2_FAIL("lstm_seq_bwd_batch_persistent: memset failed");
+    if (4 * p->H / 4 / 32 == EBB_KS) hipLaunchKernelGGL(encoder_bilstm_batch_persistent_bwd_kernel<true>, dim3(e.ndir * e.nrg * e.nk), dim3(EB_NT), 0, s, e);
+    else hipLaunchKernelGGL(encoder_bilstm_batch_persistent_bwd_kernel<false>, dim3(e.ndir * e.nrg * e.nk), dim3(EB_NT), 0, s, e);
+    T2_LAUNCH_CHECK();
+    if (poison) {
+        hipLaunchKernelGGL(encoder_batch_poison_kernel, dim3(1), dim3(1), 0, s, status, poison);
+        T2_LAUNCH_CHECK();
+    }
+    return T2AMD_OK;
+}
+
 extern "C" long long t2amd_lstm_seq_batch_persistent_flag_bytes(int B, int H, int ndir) {
     return 4ll * ndir * ((B + EB_ROWS - 1) / EB_ROWS) * (H / 4);
 }

@@ -772,6 +772,27 @@ def _decoder_train_fwd(model, run, d, poison, reads, writes):
     return 'launch chain'
 
 
+# BPTT of the encoder bi-LSTM as ONE persistent launch (csrc/decode_persist.hip, encoder_bilstm_batch_persistent_bwd_kernel)
+# instead of 2 T dependent launches; T2AMD_ENCODER_BWD_PERSISTENT=0 keeps the chain.  Equal to the chain's gradients to the
+# rounding of its split-bf16 recurrent product (~2^-17 per product).
+ENCODER_BWD_PERSISTENT = os.environ.get('T2AMD_ENCODER_BWD_PERSISTENT', '1') != '0'
+
+
+def _encoder_lstm_bwd(model, run, d0, d1, poison, reads, writes):
+    """The persistent launch when selected and the geometry fits; the status is not read back (no host sync in the training
+    loop): a give-up turns ``poison[0]`` into NaN, the gradient norm goes non-finite, the step is skipped and
+    handle_nonfinite_step() selects the chain."""
+    if ENCODER_BWD_PERSISTENT and ENCODER_BATCH_PERSISTENT and d0.B > 1 and not nv.validate_only():
+        cus = torch.cuda.get_device_properties(run.dev).multi_processor_count
+        if nv.lstm_seq_bwd2_batch_persistent_supported(d0, 2, cus) is None:
+            flags = run.empty_i32(nv.lstm_seq_batch_persistent_flag_words(d0.B, d0.H, 2))
+            status = run.empty_i32(1)
+            nv.lstm_seq_bwd2_batch_persistent(d0, d1, flags, status, poison)
+            return 'persistent'
+    nv.lstm_seq_bwd2(d0, d1, reads=reads, writes=writes)
+    return 'launch chain'
+
+
 def _weight_cache(model):
     cache = getattr(model, '_weight_cache', None)
     if cache is None:
@@ -1395,9 +1416,10 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         bdesc.append(desc)
         DGs.append(DG)
         keepalive.append((WhhT, dX, dc))
-    nv.lstm_seq_bwd2(bdesc[0], bdesc[1],                                 # both directions, paired launches
-                     reads=[k_[0] for k_ in keepalive] + [L_[k_] for L_ in c.enc_lstm for k_ in ('GX', 'C')] + [c.lens32, dmem],
-                     writes=DGs + [k_[i_] for k_ in keepalive for i_ in (1, 2)])
+    model.last_encoder_bwd_path = _encoder_lstm_bwd(
+        model, run, bdesc[0], bdesc[1], poison=DGs[0],                   # both directions (model.py:181-188 under autograd)
+        reads=[k_[0] for k_ in keepalive] + [L_[k_] for L_ in c.enc_lstm for k_ in ('GX', 'C')] + [c.lens32, dmem],
+        writes=DGs + [k_[i_] for k_ in keepalive for i_ in (1, 2)])
     for d, sfx in enumerate(('', '_reverse')):
         L, DG = c.enc_lstm[d], DGs[d]
         dWih = G('encoder.lstm.weight_ih_l0' + sfx, 4 * He, E)

@@ -278,6 +278,7 @@ SYMBOLS = [
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_lstm_seq_persistent_mailbox_bytes", "t2amd_lstm_seq_persistent_supported", "t2amd_lstm_seq_fwd2_persistent_f32",
     "t2amd_lstm_seq_batch_persistent_flag_bytes", "t2amd_lstm_seq_batch_persistent_supported", "t2amd_lstm_seq_fwd2_batch_persistent_f32", "t2amd_encoder_handoff_timeouts",
+    "t2amd_lstm_seq_bwd2_batch_persistent_supported", "t2amd_lstm_seq_bwd2_batch_persistent_f32",
     "t2amd_reflect_pad_f32", "t2amd_reflect_index", "t2amd_stft_magnitude_f32", "t2amd_mel_log_compress_f32",
     "t2amd_optim_chunk", "t2amd_grad_norm_f32", "t2amd_adam_step_f32",
     "t2amd_decoder_persist_mailbox_bytes", "t2amd_decoder_persist_supported", "t2amd_decoder_infer_persistent_f32",
@@ -343,6 +344,8 @@ def _argtypes():
         "t2amd_lstm_seq_batch_persistent_flag_bytes": [_I, _I, _I],
         "t2amd_lstm_seq_batch_persistent_supported": [pt(LstmSeq), _I, _I],
         "t2amd_lstm_seq_fwd2_batch_persistent_f32": [pt(LstmSeq), pt(LstmSeq), _P, _P, _P, _P],
+        "t2amd_lstm_seq_bwd2_batch_persistent_supported": [pt(LstmSeq), _I, _I],
+        "t2amd_lstm_seq_bwd2_batch_persistent_f32": [pt(LstmSeq), pt(LstmSeq), _P, _P, _P, _P],
         "t2amd_encoder_handoff_timeouts": [_I],
         "t2amd_decoder_infer_steps_f32": [pt(DecInfer), _P],
         "t2amd_struct_sizes": [pt(C.c_int), _I],
@@ -1352,6 +1355,27 @@ def lstm_seq_fwd2_batch_persistent(d0, d1, flags, status, poison=None):
     _check(lib.t2amd_lstm_seq_fwd2_batch_persistent_f32(C.byref(d0), C.byref(d1), C.c_void_p(flags.data_ptr()), ptr(status, torch.int32),
                                                         ptr(poison) if poison is not None else None, _stream()),
            "t2amd_lstm_seq_fwd2_batch_persistent_f32")
+
+
+def lstm_seq_bwd2_batch_persistent_supported(desc, ndir, cus):
+    """None when the encoder bi-LSTM's BPTT of this batch can run as one persistent launch on a device of `cus` CUs, else the reason."""
+    lib = load()
+    if lib.t2amd_lstm_seq_bwd2_batch_persistent_supported(C.byref(desc), int(ndir), int(cus)) == 0:
+        return None
+    msg = lib.t2amd_last_error()
+    return msg.decode() if msg else "unsupported"
+
+
+def lstm_seq_bwd2_batch_persistent(d0, d1, flags, status, poison=None):
+    """BPTT of both directions of the encoder bi-LSTM of a BATCH as one persistent launch (csrc/decode_persist.hip,
+    encoder_bilstm_batch_persistent_bwd_kernel) instead of 2 T dependent launches (lstm_seq_bwd2)."""
+    lib = load()
+    need = lib.t2amd_lstm_seq_batch_persistent_flag_bytes(d0.B, d0.H, 2)
+    if flags.numel() * flags.element_size() < need:
+        raise NativeError("lstm_seq_bwd2_batch_persistent: flags of %d bytes, %d needed" % (flags.numel() * flags.element_size(), need))
+    _check(lib.t2amd_lstm_seq_bwd2_batch_persistent_f32(C.byref(d0), C.byref(d1), C.c_void_p(flags.data_ptr()), ptr(status, torch.int32),
+                                                        ptr(poison) if poison is not None else None, _stream()),
+           "t2amd_lstm_seq_bwd2_batch_persistent_f32")
 
 
 def encoder_handoff_timeouts(reset=True):
