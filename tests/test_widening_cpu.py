@@ -72,6 +72,25 @@ def test_mel_filterbank_structure():
     assert np.all(np.abs(area[20:] - 1.0) < 0.15)
 
 
+def test_mel_filterbank_against_an_independent_public_implementation():
+    """The one table of the front end with no artefact of the reference to be held against (reference layers.py:50-53 calls
+    librosa.filters.mel, which is not installed and not vendored): the oracle's restatement of librosa 0.6.0 (Slaney scale,
+    norm=1) is checked against an INDEPENDENT public implementation that is in this image -- Hugging Face
+    transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney"), documented as equivalent to librosa's -- on the
+    reference's configuration (hparams.py:36-42: 22,050 Hz, n_fft 1024, 80 mels, 0-8000 Hz) and on two others: equal to 1e-12.
+    The product's table (tacotron2_amd.audio) is held to the oracle's by test_product_tables_match_oracle_and_reference_digest."""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    import numpy as np
+    from oracle import audio_oracle as ao
+    for sr, n_fft, n_mels, fmin, fmax in ((22050, 1024, 80, 0.0, 8000.0), (16000, 512, 40, 50.0, 7600.0), (22050, 2048, 128, 0.0, None)):
+        ref = audio_utils.mel_filter_bank(num_frequency_bins=1 + n_fft // 2, num_mel_filters=n_mels, min_frequency=fmin,
+                                          max_frequency=fmax if fmax is not None else sr / 2.0, sampling_rate=sr,
+                                          norm="slaney", mel_scale="slaney")
+        mine = np.asarray(ao.librosa_mel(sr, n_fft, n_mels, fmin, fmax), dtype=np.float64)
+        assert mine.shape == (n_mels, 1 + n_fft // 2) and ref.shape == mine.shape[::-1]
+        assert float(np.abs(ref.T - mine).max()) < 1e-12 * max(1.0, float(np.abs(mine).max()))
+
+
 def test_reflect_index_rule(native_lib):
     T, pad = 37, 9
     ref = torch.nn.functional.pad(torch.arange(T, dtype=torch.float32).view(1, 1, T), (pad, pad), mode='reflect').view(-1)
@@ -392,6 +411,18 @@ def test_bench_stdout_line_is_compact_and_complete():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
+    # round 4: the forward loop is one persistent launch -- the chain of the line is that launch + the two backward kernels
+    with open(os.path.join(root, "profiles", "r04_g_bench_full.json")) as f:
+        full4 = json.load(f)
+    line4 = bench.compact_line(full4)
+    assert len(json.dumps(line4)) < 5200
+    r4 = line4["roofline"]
+    assert set(r4["chain"]) == {"decoder_forward_persistent", "attention_backward", "dgrad_pair"}
+    assert r4["kernel"] == max(r4["chain"].values(), key=lambda v: v["avg_launch_us"] * v["launches"])["kernel"]
+    assert abs(r4["chain"]["decoder_forward_persistent"]["us_per_time_step"] * r4["whole_step"]["time_steps"]
+               - r4["chain"]["decoder_forward_persistent"]["avg_launch_us"]) < 1.0
+    assert line4["timed_loop"]["device_allocs"] <= 1 and line4["timed_loop"]["full_gc_collections_ms"] == [] and "build" in line4
+    assert line4["cpu_baseline"]["calibration"]["port_over_reference"] > 0
     with open(os.path.join(root, "profiles", "r03_r_bench_full.json")) as f:
         full = json.load(f)
     line = bench.compact_line(full)
