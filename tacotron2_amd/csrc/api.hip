@@ -246,6 +246,8 @@ struct EdgeFDParams {
     unsigned* flagL;      // [256]
     unsigned* flagT;      // [256]
     int rounds, mode, round0, con_l_f4, delay, work_l, work_t;
+    int hier;             // 1: two-level wait -- workgroups 0..7 poll the 256 flags (wave 1) and republish one word each (go[8], own 128-byte
+                          // lines behind the flags); every workgroup's wave 0 polls go[j & 7] only
     unsigned long long* clk;   // [4]: total ticks, ticks spent waiting in role T, in role L
     int* status;
     unsigned* stale;
@@ -273,6 +275,25 @@ static __device__ __forceinline__ bool efd_wait(const unsigned* flags, unsigned 
         if ((++spins & 63u) == 0 && wall_clock64() - t0 > 3000000ull) { if (lane == 0) atomicExch(status, 1); return false; }
     }
 }
+// two-level wait: `go` = 8 words on 8 separate 128-byte lines.  Collector workgroups (blockIdx < 8): wave 1 sweeps the 256 flags and
+// stores go[blockIdx] = target; every workgroup: wave 0 polls go[blockIdx & 7].
+static __device__ __forceinline__ bool efd_wait_hier(const unsigned* flags, unsigned* go, unsigned target, int delay, int* status, int lane,
+                                                     int wave, int j) {
+    if (wave == 1 && j < 8) {
+        if (!efd_wait(flags, target, delay, status, lane)) return false;
+        if (lane == 0) __hip_atomic_store(go + 32 * j, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    if (wave != 0) return true;
+    const unsigned long long t0 = wall_clock64();
+    unsigned spins = 0;
+    for (;;) {
+        const unsigned v = __hip_atomic_load(go + 32 * (j & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0 && wall_clock64() - t0 > 3000000ull) { if (lane == 0) atomicExch(status, 2); return false; }
+    }
+}
 __global__ __launch_bounds__(512) void t2_edge_flagdata_kernel(EdgeFDParams p) {
     __shared__ int s_fail;
     __shared__ unsigned long long s_wait[2];
@@ -290,7 +311,9 @@ __global__ __launch_bounds__(512) void t2_edge_flagdata_kernel(EdgeFDParams p) {
             // ---------------- role L ----------------
             if (r > 0) {
                 if (p.mode == 0) {
-                    if (wave == 0) {
+                    if (p.hier) {
+                        if (!efd_wait_hier(p.flagT, p.flagT + 512, (unsigned)r, p.delay, p.status, lane, wave, j) && lane == 0) s_fail = 1;
+                    } else if (wave == 0) {
                         const unsigned long long w0 = wall_clock64();
                         if (!efd_wait(p.flagT, (unsigned)r, p.delay, p.status, lane) && lane == 0) s_fail = 1;
                         if (lane == 0) s_wait[1] += wall_clock64() - w0;
@@ -319,7 +342,9 @@ __global__ __launch_bounds__(512) void t2_edge_flagdata_kernel(EdgeFDParams p) {
         if (p.mode != 1) {
             // ---------------- role T ----------------
             if (p.mode == 0) {
-                if (wave == 0) {
+                if (p.hier) {
+                    if (!efd_wait_hier(p.flagL, p.flagL + 1024, (unsigned)(r + 1), p.delay, p.status, lane, wave, j) && lane == 0) s_fail = 1;
+                } else if (wave == 0) {
                     const unsigned long long w0 = wall_clock64();
                     if (!efd_wait(p.flagL, (unsigned)(r + 1), p.delay, p.status, lane) && lane == 0) s_fail = 1;
                     if (lane == 0) s_wait[0] += wall_clock64() - w0;
@@ -352,8 +377,10 @@ __global__ __launch_bounds__(512) void t2_edge_flagdata_kernel(EdgeFDParams p) {
     }
     if (acc == 123.456f) p.status[0] = 7;
 }
-// h: 64*256 float4 (256 KB), ctx: 8192 float4 (128 KB), flags: 512 zeroed uint32, clk: 4 uint64, status / stale: zeroed.
-// mode 0: one persistent launch of `rounds` rounds; mode 3: the launch chain -- `rounds` x (L launch, T launch).
+// h: 64*256 float4 (256 KB), ctx: 8192 float4 (128 KB), flags: 1280 zeroed uint32 (256 + 256 step counters, then the 2 x 8 "go"
+// words of the two-level wait on their own 128-byte lines), clk: 4 uint64, status / stale: zeroed.
+// mode 0: one persistent launch of `rounds` rounds (mode 4: the same with the two-level wait); mode 3: the launch chain --
+// `rounds` x (L launch, T launch).
 extern "C" int t2amd_debug_edge_flagdata_(void* h, void* ctx, unsigned* flags, int rounds, int mode, int con_l_bytes, int delay,
                                           int work_l, int work_t, int lds_bytes, unsigned long long* clk, int* status,
                                           unsigned* stale, void* stream) {
@@ -366,7 +393,8 @@ extern "C" int t2amd_debug_edge_flagdata_(void* h, void* ctx, unsigned* flags, i
     p.con_l_f4 = con_l_bytes / 16; p.delay = delay; p.work_l = work_l; p.work_t = work_t; p.clk = clk; p.status = status; p.stale = stale;
     const int lds = lds_bytes < 256 ? 256 : lds_bytes;
     hipStream_t s = (hipStream_t)stream;
-    if (mode == 0) {
+    p.hier = mode == 4 ? 1 : 0;
+    if (mode == 0 || mode == 4) {
         p.mode = 0;
         hipLaunchKernelGGL(t2_edge_flagdata_kernel, dim3(256), dim3(512), lds, s, p);
     } else {

@@ -35,7 +35,7 @@ dev = "cuda"
 def run(mode, rounds, con_l, delay, work_l, work_t):
     h = torch.zeros(64 * 256 * 4, device=dev)
     ctx = torch.zeros(8192 * 4, device=dev)
-    flags = torch.zeros(512, dtype=torch.int32, device=dev)
+    flags = torch.zeros(1280, dtype=torch.int32, device=dev)
     clk = torch.zeros(4, dtype=torch.int64, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     stale = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -48,6 +48,7 @@ def run(mode, rounds, con_l, delay, work_l, work_t):
     torch.cuda.synchronize()
     ev_us = e0.elapsed_time(e1) * 1e3 / rounds
     c = clk.tolist()
+    mode = 0 if mode == 4 else mode
     return dict(rc=rc, status=int(status.item()), stale_words=int(stale.item()), us_per_round_events=ev_us,
                 us_per_round_device_clock=c[0] / 100.0 / rounds if mode == 0 else None,
                 us_waiting_for_lstm_flags_per_round=c[1] / 100.0 / rounds if mode == 0 else None,
@@ -78,6 +79,11 @@ for label, con_l, work_l, work_t in (("bare edges (L reads 16 B)", 16, 0, 0),
     for delay in (0, 4, 8, 16, 32):
         p = best_of(3, 0, R, con_l, delay, work_l, work_t)
         row["persistent"]["delay_%d" % delay] = p
+    row["persistent_two_level_wait"] = {}
+    for delay in (0, 4, 16):
+        row["persistent_two_level_wait"]["delay_%d" % delay] = best_of(3, 4, R, con_l, delay, work_l, work_t)
+    print("    two-level wait (8 collectors republish one word each): " + " ".join(
+        "%s:%.2f(stale %d)" % (k[6:], v["us_per_round_events"], v["stale_words"]) for k, v in row["persistent_two_level_wait"].items() if "us_per_round_events" in v))
     ok = [v for v in row["persistent"].values() if v.get("rc") == 0 and v.get("status") == 0]
     if ok:
         b = min(ok, key=lambda v: v["us_per_round_events"])
