@@ -13,6 +13,13 @@ python -m pytest tests -m gpu -q --durations=6 > $out/${tag}_pytest_gpu.log 2>&1
 tail -12 $out/${tag}_pytest_gpu.log
 bash tools/pmc_pass.sh $tag | tail -4                     # first: the bench line below then carries this build's traffic
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?"; tail -c 1200 $out/${tag}_bench.json; tail -2 $out/${tag}_bench.err
+# two ranks over RCCL whenever the box shows two GPUs (every box of rounds 1-4 showed one)
+ngpu=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null)
+if [ "${ngpu:-1}" -ge 2 ]; then
+  timeout 600 python bench.py --gpus 2 --steps 8 --warmup 2 --cpu-sample 0 --no-inference --no-fp32-leg > $out/${tag}_bench_2gpu_rccl.json 2> $out/${tag}_bench_2gpu_rccl.err; echo "2-GPU RCCL bench rc=$?"; cut -c1-400 $out/${tag}_bench_2gpu_rccl.json
+else
+  echo "one GPU visible: no RCCL world-size-2 run" | tee $out/${tag}_bench_2gpu_rccl.txt
+fi
 timeout 300 python tools/bench_decode_b1.py > $out/${tag}_decode_b1.json 2> /dev/null; cut -c1-700 $out/${tag}_decode_b1.json
 timeout 300 python tools/bench_infer.py --precision bf16 > $out/${tag}_bench_infer_bf16.txt 2>&1; grep "^config\|^B" $out/${tag}_bench_infer_bf16.txt
 timeout 300 python tools/bench_infer.py --precision fp32 > $out/${tag}_bench_infer_fp32.txt 2>&1; grep "^config\|^B" $out/${tag}_bench_infer_fp32.txt
