@@ -503,6 +503,10 @@ typedef struct t2amd_attn_bwd {
      * word B*Ti on) the first hand-off of the one-launch form may travel as 8-byte {launch token, value} granules in the
      * block behind the token words (t2amd_set_attn_bwd_granules). */
     long long ws_floats;
+    /* optional bf16 copy of Wq ([128][Hq] bf16, 16-byte aligned, Hq % 8 == 0): the closing product dh = Wq^T dq streams it instead
+     * of the f32 rows (dq and the sums stay f32) -- the engine's bf16 compute mode; the folded and the separate-launch forms
+     * read the same copy in the same order and stay bit-identical to each other. */
+    const void* Wq16;
 } t2amd_attn_bwd;
 
 int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream);

@@ -58,7 +58,17 @@ typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
 #define DSL (AD / NSL)         // 32 attention dims per K_e / K_b2 workgroup
 #define NCS 4                  // context-channel slices (K_c workgroups per utterance)
 #define NTS 4                  // position slices (K_b1 workgroups per utterance)
-#define DCL 68                 // dcol_s row stride (floats)
+#define DCL 68                 // dcol_s row stride (floats) of the position-major image (A/B builds: -DT2AMD_DCOL_ROWMAJOR)
+// Round 4: dcol lives TAP-MAJOR, dcolT_s[64 taps][NP + 4]: the product is formed transposed (dpre as the A operand, U^T as
+// the B operand: the very same registers, same products summed over the same k order -> the same bits), so a lane holds FOUR
+// POSITIONS of one tap and stores them as one float4, and col2im's 31 reads per output walk consecutive addresses --
+// conflict-free, where the position-major image made 64 consecutive rows of a float4-aligned stride share 16 banks (4-way).
+// (NP + 4) / 4 is odd for NP a multiple of 8, so the 16 tap rows of a float4 store cover all 64 banks as well.
+#ifdef T2AMD_DCOL_ROWMAJOR
+#define DCOL_FLOATS(np) ((size_t)(np) * DCL)
+#else
+#define DCOL_FLOATS(np) ((size_t)64 * ((np) + 4))
+#endif
 #define DPL 48                 // dpre_s row stride (floats): 48*lg mod 64 = {0,48,32,16}: conflict-free A reads
 
 static inline int attn_tip(int Ti) { return (((Ti + 15) / 16) * 16 + 2 * HALO + 2 + 3) / 4 * 4; }
@@ -1602,7 +1612,10 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     float* win_s = smem;                      // [2][TIP]
     float* de_s = win_s + 2 * TIP;            // [NP]
     float* dcol_s = de_s + NP;                // [NP][DCL]
-    float* dpre_s = dcol_s + (size_t)NP * DCL;  // [NP][DPL]
+    float* dpre_s = dcol_s + DCOL_FLOATS(NP);   // [NP][DPL]
+#ifndef T2AMD_DCOL_ROWMAJOR
+    const int NPP = NP + 4;                     // row stride of the tap-major dcol image
+#endif
     float* red_s = dpre_s + (size_t)NP * DPL;   // [NW][2][32]
     float* dq_s = red_s + KB2_NW * 2 * DSL;   // [32]
     float* u_s = dq_s + DSL;                  // [32][62]
@@ -1676,6 +1689,13 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             stage_u_finish(ureg, u_s, tid);
         }
         kb1_phase<M16, true>(p, smem + p.kb1_smem_off, ds, b, ts_on);
+#ifndef T2AMD_BWD_LATE_POLL
+        // (round 4) the first poll is issued BEFORE the independent work below: its round trip overlaps that work (59.48 vs
+        // 59.63 ms per step over three alternating pairs of builds, same loss bits; -DT2AMD_BWD_LATE_POLL restores the old order)
+        const at_u64* grow_e = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + (long long)b * (Ti + NTS);
+        const int gi_e = tid < Ti + NTS ? tid : Ti + NTS - 1;
+        at_u64 xd_e = __hip_atomic_load(grow_e + gi_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         // ... so that the part of the tile loop that does NOT depend on K_b1 -- location product, + q + processed memory,
         // tanh -- runs HERE, while the partners' granules are on their way (it replaces the pre-poll pause), instead of
         // behind the hand-off: th of this lane's first two position tiles stays in registers.  Same operations on the same
@@ -1703,7 +1723,11 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         }
         const at_u64* grow = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + (long long)b * (Ti + NTS);   // (uniform)
         const int gi = tid < Ti + NTS ? tid : Ti + NTS - 1;          // Ti + NTS <= 512 (host check)
+#ifndef T2AMD_BWD_LATE_POLL
+        at_u64 xd = xd_e;
+#else
         at_u64 xd = __hip_atomic_load(grow + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         {
             // bounded like every spin here: 50 ms of the 100 MHz wall clock, then NaN instead of a hung GPU
             const long long t0_ = wall_clock64();
@@ -1800,6 +1824,15 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
     // bf16 mode: the same operand as one v_mfma_f32_16x16x32_bf16 fragment per tap tile.  MFMA k index 8*lg + e stands
     // for dim (e < 4 ? 4*lg + e : 16 + 4*lg + e - 4), so that the B fragment is exactly this lane's dpre registers.
     const bool use16 = a.bf16 != 0;
+    // Row stride of dpre_s.  f32 products: 48 (the dU A-fragment reads of the four lane groups, rows lg + 4j, land on four disjoint
+    // 16-bank windows).  bf16 products read rows 8 lg + e instead (8 x 48 = 0 mod 64: all four lane groups on the SAME 16 banks,
+    // 4-way) and the tile loop's float4 stores of 16 consecutive rows hit 4 distinct bank groups (4-way): a stride of 36 makes the
+    // stores conflict-free (36 l mod 64 covers all sixteen multiples of 4) and the reads 2-way.  (-DT2AMD_DPL48 keeps 48 for both.)
+#ifdef T2AMD_DPL48
+    const int dpl = DPL;
+#else
+    const int dpl = use16 ? 36 : DPL;
+#endif
     uint4 utb[4];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) {
@@ -1857,23 +1890,38 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#ifdef T2AMD_DCOL_ROWMAJOR
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf16x8, utb[tt]),
                                                            __builtin_bit_cast(at_bf16x8, dpb), c, 0, 0, 0);
                 *reinterpret_cast<float4*>(&dcol_s[(size_t)pos * DCL + tt * 16 + 4 * lg]) = make_float4(c[0], c[1], c[2], c[3]);
+#else
+                // transposed: this lane's column is tap tt*16 + l15, its four rows are positions mt*16 + 4*lg + r
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(at_bf16x8, dpb),
+                                                           __builtin_bit_cast(at_bf16x8, utb[tt]), c, 0, 0, 0);
+                *reinterpret_cast<float4*>(&dcol_s[(size_t)(tt * 16 + l15) * NPP + mt * 16 + 4 * lg]) = make_float4(c[0], c[1], c[2], c[3]);
+#endif
             }
         } else {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#ifdef T2AMD_DCOL_ROWMAJOR
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ut[tt][dt][r], dp[dt][r], c, 0, 0, 0);
                 *reinterpret_cast<float4*>(&dcol_s[(size_t)pos * DCL + tt * 16 + 4 * lg]) = make_float4(c[0], c[1], c[2], c[3]);
+#else
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[dt][r], ut[tt][dt][r], c, 0, 0, 0);
+                *reinterpret_cast<float4*>(&dcol_s[(size_t)(tt * 16 + l15) * NPP + mt * 16 + 4 * lg]) = make_float4(c[0], c[1], c[2], c[3]);
+#endif
             }
         }
-        *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * DPL + 4 * lg]) = make_float4(dp[0][0], dp[0][1], dp[0][2], dp[0][3]);
-        *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * DPL + 16 + 4 * lg]) = make_float4(dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
+        *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * dpl + 4 * lg]) = make_float4(dp[0][0], dp[0][1], dp[0][2], dp[0][3]);
+        *reinterpret_cast<float4*>(&dpre_s[(size_t)pos * dpl + 16 + 4 * lg]) = make_float4(dp[1][0], dp[1][1], dp[1][2], dp[1][3]);
         if (pos < len) {
             o0.x += dp[0][0]; o0.y += dp[0][1]; o0.z += dp[0][2]; o0.w += dp[0][3];
             o1.x += dp[1][0]; o1.y += dp[1][1]; o1.z += dp[1][2]; o1.w += dp[1][3];
@@ -1901,20 +1949,42 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             cq_s2 = addend_issue4(cq.dh[2], b, cq_j);
         }
     }
+    // bf16 mode (a.Wq16): the rows are streamed as bf16 -- 16 bytes = EIGHT columns, half the bytes of the stream whose issue
+    // alone took 1.2 us of this launch (8 waves x 16 instructions x 1 KB through the CU's 64 B/clk path); a thread then owns
+    // 8 columns and only half of the lanes load.  Same fmaf chain over the 16 dims per column, same order of the partial sums.
+#ifdef T2AMD_BWD_WQ_F32                       // A/B builds: the f32 rows in both modes (round 3)
+    const bool wq16 = false;
+#else
+    const bool wq16 = a.Wq16 != nullptr;
+#endif
     float4 wq_pre[16];
     if constexpr (CELL) {
         // group g = tid >> 6 takes dims 16g .. 16g+15 of ALL 128, lane c4 the float4 column ds*Hq/16 + c4
         const int H4 = Hq >> 2, QC = Hq >> 4;
         const int g = tid >> 6, c4 = tid & 63;
-        const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(g * 16) * H4 + ds * QC;
+        if (wq16) {
+            const int H8 = Hq >> 3, QC8 = QC >> 1;               // 16-byte units of 8 bf16 columns
+            const float4* __restrict__ W8 = reinterpret_cast<const float4*>(a.Wq16) + (long long)(g * 16) * H8 + ds * QC8;
 #pragma unroll
-        for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (c4 < QC ? c4 : 0)];
+            for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W8[(long long)dd * H8 + (c4 < QC8 ? c4 : 0)];
+        } else {
+            const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(g * 16) * H4 + ds * QC;
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (c4 < QC ? c4 : 0)];
+        }
     } else {
         const int H4 = Hq >> 2;
         const int half = tid >> 8, t8 = tid & 255;
-        const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(dbase + half * 16) * H4;
+        if (wq16) {
+            const int H8 = Hq >> 3;
+            const float4* __restrict__ W8 = reinterpret_cast<const float4*>(a.Wq16) + (long long)(dbase + half * 16) * H8;
 #pragma unroll
-        for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (t8 < H4 ? t8 : 0)];
+            for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W8[(long long)dd * H8 + (t8 < H8 ? t8 : 0)];
+        } else {
+            const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(dbase + half * 16) * H4;
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) wq_pre[dd] = W4[(long long)dd * H4 + (t8 < H4 ? t8 : 0)];
+        }
     }
     T2_TS(56);
     // ... and the read-modify-write operand of this wave's dU tile (wave w owns tap tile w&3, dim tile w>>2)
@@ -1981,7 +2051,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) old[r] = dU_old[r];                    // fetched right after the tile loop
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-        const float* ap = dpre_s + (size_t)lg * DPL + dt * 16 + l15;
+        const float* ap = dpre_s + (size_t)lg * dpl + dt * 16 + l15;
         const float* bp = win_s + toff + lg;
         // npos is a multiple of 16: chunks of 16 positions (four k-steps), the next chunk's eight LDS operands are
         // read while the current chunk's four MFMAs issue (an unpipelined loop pays the LDS latency per MFMA pair)
@@ -1995,7 +2065,7 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
                 for (int e = 0; e < 8; ++e) {
                     const int ps = s + 8 * lg + e;
                     const int pc = ps < npos ? ps : 0;          // rows past npos were never written: read row 0, use 0
-                    av[e] = ap16[(size_t)pc * DPL];
+                    av[e] = ap16[(size_t)pc * dpl];
                     bv[e] = bp16[pc];
                 }
 #pragma unroll
@@ -2011,11 +2081,11 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         }
         float a_cur[4], b_cur[4], a_nxt[4], b_nxt[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a_cur[j] = ap[(size_t)(4 * j) * DPL]; b_cur[j] = bp[4 * j]; }
+        for (int j = 0; j < 4; ++j) { a_cur[j] = ap[(size_t)(4 * j) * dpl]; b_cur[j] = bp[4 * j]; }
         for (int s = 0; s < (use16 ? 0 : npos); s += 16) {
             const int sn = (s + 16 < npos) ? s + 16 : s;        // clamped: the last prefetch re-reads this chunk
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { a_nxt[j] = ap[(size_t)(sn + 4 * j) * DPL]; b_nxt[j] = bp[sn + 4 * j]; }
+            for (int j = 0; j < 4; ++j) { a_nxt[j] = ap[(size_t)(sn + 4 * j) * dpl]; b_nxt[j] = bp[sn + 4 * j]; }
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0], b_cur[0], c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1], b_cur[1], c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[2], b_cur[2], c0, 0, 0, 0);
@@ -2061,7 +2131,11 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
             for (int k = 0; k < LK; ++k) {
                 int row = tip_ - k + HALO;
                 row = row < 0 ? 0 : (row > npos - 1 ? npos - 1 : row);
+#ifdef T2AMD_DCOL_ROWMAJOR
                 v[k] = dcol_s[(size_t)row * DCL + c * LK + k];
+#else
+                v[k] = dcol_s[(size_t)(c * LK + k) * NPP + row];
+#endif
             }
             float s = 0.f;
 #pragma unroll
@@ -2103,17 +2177,36 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         }
         __syncthreads();
         T2_TS(54);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int dd = 0; dd < 16; ++dd) {
-            const float gq = dqall_s[g * 16 + dd];
-            acc.x = fmaf(gq, wq_pre[dd].x, acc.x);
-            acc.y = fmaf(gq, wq_pre[dd].y, acc.y);
-            acc.z = fmaf(gq, wq_pre[dd].z, acc.z);
-            acc.w = fmaf(gq, wq_pre[dd].w, acc.w);
-        }
         float4* part_s = reinterpret_cast<float4*>(dh_s);      // [8 groups][QC]
-        if (c4 < QC) part_s[g * QC + c4] = acc;
+        if (wq16) {
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const float gq = dqall_s[g * 16 + dd];
+                const unsigned u0 = __float_as_uint(wq_pre[dd].x), u1 = __float_as_uint(wq_pre[dd].y);
+                const unsigned u2 = __float_as_uint(wq_pre[dd].z), u3 = __float_as_uint(wq_pre[dd].w);
+                a0.x = fmaf(gq, __uint_as_float(u0 << 16), a0.x);
+                a0.y = fmaf(gq, __uint_as_float(u0 & 0xffff0000u), a0.y);
+                a0.z = fmaf(gq, __uint_as_float(u1 << 16), a0.z);
+                a0.w = fmaf(gq, __uint_as_float(u1 & 0xffff0000u), a0.w);
+                a1.x = fmaf(gq, __uint_as_float(u2 << 16), a1.x);
+                a1.y = fmaf(gq, __uint_as_float(u2 & 0xffff0000u), a1.y);
+                a1.z = fmaf(gq, __uint_as_float(u3 << 16), a1.z);
+                a1.w = fmaf(gq, __uint_as_float(u3 & 0xffff0000u), a1.w);
+            }
+            if (c4 < (QC >> 1)) { part_s[g * QC + 2 * c4] = a0; part_s[g * QC + 2 * c4 + 1] = a1; }
+        } else {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int dd = 0; dd < 16; ++dd) {
+                const float gq = dqall_s[g * 16 + dd];
+                acc.x = fmaf(gq, wq_pre[dd].x, acc.x);
+                acc.y = fmaf(gq, wq_pre[dd].y, acc.y);
+                acc.z = fmaf(gq, wq_pre[dd].z, acc.z);
+                acc.w = fmaf(gq, wq_pre[dd].w, acc.w);
+            }
+            if (c4 < QC) part_s[g * QC + c4] = acc;
+        }
         __syncthreads();
         if (cq_on) {
             // slab k of a separate launch = (dims 32k .. 32k+15) + (dims 32k+16 .. 32k+31); slabs are added in index order
@@ -2141,6 +2234,51 @@ __global__ __launch_bounds__(KB2_NT) void attn_bwd_main_kernel(AttnBwdParams p) 
         const int half = tid >> 8, t8 = tid & 255;
         const float4* __restrict__ W4 = reinterpret_cast<const float4*>(a.Wq) + (long long)(dbase + half * 16) * H4;
         float* __restrict__ dh = a.dh_out + (long long)ds * a.dh_split_stride + (long long)b * a.ld_dh;
+        if (wq16) {
+            // bf16 rows: thread t8 of each half owns the 8 columns 8 k8 .. 8 k8 + 7 (same per-column fmaf chain, half 0 + half 1)
+            const int H8 = Hq >> 3;
+            const float4* __restrict__ W8 = reinterpret_cast<const float4*>(a.Wq16) + (long long)(dbase + half * 16) * H8;
+            for (int k0 = 0; k0 < H8; k0 += 256) {
+                const int k8 = k0 + t8;
+                const bool ok = k8 < H8;
+                float4 w[16];
+                if (k0 == 0) {
+#pragma unroll
+                    for (int dd = 0; dd < 16; ++dd) w[dd] = wq_pre[dd];
+                } else {
+#pragma unroll
+                    for (int dd = 0; dd < 16; ++dd) w[dd] = W8[(long long)dd * H8 + (ok ? k8 : 0)];
+                }
+                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int dd = 0; dd < 16; ++dd) {
+                    const float gq = dq_s[half * 16 + dd];
+                    const unsigned u0 = __float_as_uint(w[dd].x), u1 = __float_as_uint(w[dd].y);
+                    const unsigned u2 = __float_as_uint(w[dd].z), u3 = __float_as_uint(w[dd].w);
+                    a0.x = fmaf(gq, __uint_as_float(u0 << 16), a0.x);
+                    a0.y = fmaf(gq, __uint_as_float(u0 & 0xffff0000u), a0.y);
+                    a0.z = fmaf(gq, __uint_as_float(u1 << 16), a0.z);
+                    a0.w = fmaf(gq, __uint_as_float(u1 & 0xffff0000u), a0.w);
+                    a1.x = fmaf(gq, __uint_as_float(u2 << 16), a1.x);
+                    a1.y = fmaf(gq, __uint_as_float(u2 & 0xffff0000u), a1.y);
+                    a1.z = fmaf(gq, __uint_as_float(u3 << 16), a1.z);
+                    a1.w = fmaf(gq, __uint_as_float(u3 & 0xffff0000u), a1.w);
+                }
+                if (half == 1 && ok) {
+                    *reinterpret_cast<float4*>(dh_s + k8 * 8) = a0;
+                    *reinterpret_cast<float4*>(dh_s + k8 * 8 + 4) = a1;
+                }
+                __syncthreads();
+                if (half == 0 && ok) {
+                    const float4 o0 = *reinterpret_cast<const float4*>(dh_s + k8 * 8), o1 = *reinterpret_cast<const float4*>(dh_s + k8 * 8 + 4);
+                    a0.x += o0.x; a0.y += o0.y; a0.z += o0.z; a0.w += o0.w;
+                    a1.x += o1.x; a1.y += o1.y; a1.z += o1.z; a1.w += o1.w;
+                    *reinterpret_cast<float4*>(dh + k8 * 8) = a0;
+                    *reinterpret_cast<float4*>(dh + k8 * 8 + 4) = a1;
+                }
+                if (k0 + 256 < H8) __syncthreads();
+            }
+        } else
         for (int k0 = 0; k0 < H4; k0 += 256) {
             const int k4 = k0 + t8;
             const bool ok = k4 < H4;
@@ -2213,7 +2351,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
     p.ts = attn_ts_buffer();
     hipStream_t s = (hipStream_t)stream;
     const size_t lds1 = sizeof(float) * ((size_t)a->E + 2 * (size_t)((a->Ti + NTS - 1) / NTS) + 8);
-    const size_t lds2 = sizeof(float) * (2 * (size_t)p.tip + p.np + (size_t)p.np * (DCL + DPL) + KB2_NW * 2 * DSL + DSL +
+    const size_t lds2 = sizeof(float) * (2 * (size_t)p.tip + p.np + DCOL_FLOATS(p.np) + (size_t)p.np * DPL + KB2_NW * 2 * DSL + DSL +
                                          DSL * NTAP + (size_t)a->Hq);
     T2_REQUIRE(lds1 <= 64 * 1024, "attn_bwd: E too large");
     T2_REQUIRE(lds2 <= 160 * 1024, "attn_bwd: Ti needs more than 160 KiB of LDS");
@@ -2241,6 +2379,7 @@ extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* strea
         g_attn_bwd_lds = (int)lds2;
     }
     T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && a->E % 8 == 0), "attn_bwd: memory16 must be 16-byte aligned, E a multiple of 8");
+    T2_REQUIRE(!a->Wq16 || (t2_aligned16(a->Wq16) && a->Hq % 32 == 0), "attn_bwd: Wq16 must be 16-byte aligned, Hq a multiple of 32");
     // One launch (default since round 2; T2AMD_ATTN_FUSED_BWD=0 restores the two launches): K_b1 runs as the first phase
     // of K_b2's launch and the four workgroups of an utterance hand their dw slices to each other through memory
     // (write-through stores drained by every wave, a per-launch token, a short pause (T2AMD_ATTN_FUSED_DELAY, s_sleep

@@ -292,6 +292,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;
         ab.bf16 = f.bf16 ? 1 : 0;
         ab.memory16 = f.bf16 ? f.memory16 : nullptr;
+        ab.Wq16 = f.bf16 ? f.Wq16 : nullptr;
         return t2amd_attention_step_bwd_f32(&ab, st);
     };
     auto cell_a = [&](int t, t2amd_lstm_bwd& la) {

@@ -1277,7 +1277,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
                               reads=[Wa_recT, Wd_catT, DHC, cont(d_align), T['Wq'], T['U'], T['vvec'], T['pm'], c.memory,
                                      T['lens32'], T['GA'], c.keep['att'], c.keep['dec']]
                               + [S[k_] for k_ in ('HA', 'CA', 'GD', 'HD', 'CD', 'CTX', 'Q', 'ALIGN', 'CUM')]
-                              + ([b16['Wa_recT16'], b16['Wd_catT16'], c.bf16['memory16']] if run.bf16 else []),
+                              + ([b16['Wa_recT16'], b16['Wd_catT16'], c.bf16['memory16'], c.bf16['Wq16']] if run.bf16 else []),
                               writes=list(out.values()) + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if run.bf16 else []))
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
     DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)

@@ -151,6 +151,7 @@ class AttnBwd(C.Structure):
         ("memory16", C.c_void_p),
         ("cell_q", C.POINTER(LstmBwd)), ("cell_x", C.POINTER(LstmBwd)),
         ("ws_floats", _i64),
+        ("Wq16", C.c_void_p),
     ]
 
 
@@ -1175,7 +1176,7 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
 
 def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory, lens, w, w_prev, cum_before,
                        dwin_part, dcum_acc, d_pm, dU_acc, dv_acc, dq_out, dh_parts, ws, bf16=False, memory16=None,
-                       cell_q=None, cell_x=None):
+                       cell_q=None, cell_x=None, Wq16=None):
     """dwin_part: (ATT_SLICES, B, 2, Ti) in/out; dcum_acc: (B, Ti) in/out; dh_parts: (ATT_SLICES, B, Hq) out.
     cell_q / cell_x: descriptors of lstm_bwd_desc() to run inside this launch (t2amd_attn_bwd.cell_q / cell_x)."""
     lib = load()
@@ -1211,6 +1212,8 @@ def attention_step_bwd(dctx_list, dctx_total, d_w_extra, q, Wq, U, v, pm, memory
         a.cell_q = C.pointer(cell_q)
     if cell_x is not None:
         a.cell_x = C.pointer(cell_x)
+    if Wq16 is not None:
+        a.Wq16 = ptr(_fullc(Wq16), torch.bfloat16)
     _check(lib.t2amd_attention_step_bwd_f32(C.byref(a), _stream()), "t2amd_attention_step_bwd_f32")
 
 
