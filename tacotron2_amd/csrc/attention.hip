@@ -272,9 +272,12 @@ static int attn_dbg_stage() {
 // flies behind the q phase and the tiles without holding up anything of this phase (loads complete in order).
 // PERSIST (the persistent training-forward kernel): h, the previous weights and the cumulative weights were written by other
 // workgroups of this very launch -- device-scope (sc1) loads.
-template <bool GRAN, bool EARLYP, bool PERSIST, class Hook>
+// `before_h` runs right before the load of h is issued, with every other prologue load already in flight: the persistent
+// kernel waits for the LSTM tiles' flags THERE, so that the W_q rows, the processed-memory rows, U, v and the windows -- none of
+// which depends on this step's h -- travel during that wait instead of behind it.
+template <bool GRAN, bool EARLYP, bool PERSIST, class Pre, class Hook>
 __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, const int ds, const int b, bool& ts_on,
-                                         Hook&& after_prologue) {
+                                         Pre&& before_h, Hook&& after_prologue) {
     const t2amd_attn_fwd& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
@@ -349,6 +352,7 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
         }
         {
             // h staged behind the W_q loads: its store is the first consumer of the whole prologue
+            before_h();
             float4 hv;
             if constexpr (PERSIST) {
                 const float* hq = a.h + (long long)b * a.ld_h + 4 * (tid < n4 ? tid : 0);
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     if (p.a.active && !p.a.active[blockIdx.y]) return;
-    ke_phase<false, false, false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {});
+    ke_phase<false, false, false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {}, [] {});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams 
     const int tid = threadIdx.x;
     KcPre<M16> r;
     float e_first[4] = {0.f, 0.f, 0.f, 0.f};
-    ke_phase<true, M16, false>(p, smem, sl, b, ts_on, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
+    ke_phase<true, M16, false>(p, smem, sl, b, ts_on, [] {}, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
     T2_TS(16);
     fwd_energy_granules(p, b, r.len, e_first);
     kc_finish<M16, true>(p, smem + p.kc_smem_off, sl, b, ts_on, r, e_first);
@@ -1178,9 +1182,11 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
         if (t == To) break;
         // ---------------- T(t) ----------------
         if (isT) {
+#ifdef T2AMD_DTP_WAIT_FIRST                     // A/B builds: the round-4 first form (wait, then the whole prologue)
             if (wave == 0 && !dtp_wait(P.flagA, nA, (unsigned)(t + 1), P.delay_t, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
             __syncthreads();
             if (fail_s[0]) return;
+#endif
             DTP_PROF(2);
             const long long sHa = (long long)d.B * d.Ha, sE = (long long)d.B * d.E;
             AttnFwdParams ap;
@@ -1201,7 +1207,20 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             ap.token = P.token0 + (unsigned)t; ap.gran_off = P.gran_off; ap.kc_smem_off = P.kc_smem_off; ap.delay = 0;
             KcPre<true> r;
             float e_first[4] = {0.f, 0.f, 0.f, 0.f};
-            ke_phase<true, true, true>(ap, smem, sl, b, ts_on, [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
+#ifdef T2AMD_DTP_WAIT_FIRST
+            ke_phase<true, true, true>(ap, smem, sl, b, ts_on, [] {}, [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
+#else
+            // the wait for the LSTM_a tiles of this step sits INSIDE the prologue, right before the one load that needs them (h):
+            // W_q, processed memory, U, v and the windows are on their way while the flags are polled.  (A give-up lets the phase
+            // run on with whatever h holds -- status is set, the step is poisoned behind the launch -- and leaves right after it.)
+            ke_phase<true, true, true>(ap, smem, sl, b, ts_on,
+                                       [&] {
+                                           if (wave == 0 && !dtp_wait(P.flagA, nA, (unsigned)(t + 1), P.delay_t, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
+                                           __syncthreads();
+                                       },
+                                       [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
+            if (fail_s[0]) return;
+#endif
             fwd_energy_granules(ap, b, r.len, e_first);
             kc_finish<true, true, true>(ap, smem + P.kc_smem_off, sl, b, ts_on, r, e_first);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
