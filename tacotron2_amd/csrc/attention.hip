@@ -1012,22 +1012,30 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
 // launch of max(Ha/8 + Hd/8, 4 B) co-resident 512-thread workgroups, one per CU, and the two all-to-all edges of a step are
 // FLAG + DATA hand-offs (Guideline 16 R1; measured 2.1 us per edge in this geometry, profiles/r04_microbench_edge_flagdata.json):
 //   workgroup j < Ha/8       LSTM_a tile j;  Ha/8 <= j < Ha/8 + Hd/8   LSTM_d tile;   j < 4 B   attention workgroup (b, s) = (j/4, j%4)
-//   L(t):  wait until every attention workgroup has finished step t-1 (flagT >= t) -> LSTM_a(t) | LSTM_d(t-1): activations by sc1
-//          LDS-DMA, h and its bf16 copy out as write-through stores -> every wave drains -> LSTM_a tiles: flagA[j] = t+1
-//   T(t):  wait until every LSTM_a tile has finished step t (flagA >= t+1) -> K_e, energy granules among the utterance's four
-//          workgroups, K_c: weights / cumulative weights / bf16 context out write-through -> drain -> flagT[j] = t+1
-// LSTM_d tiles publish nothing of their own: the workgroup that ran LSTM_d(t-1) publishes flagT[j] = t+1 only after it, so
-// "all flagT >= t+1" also says h_d(t-1) is complete.  Every exchanged tensor is written once per step with sc1 stores and
-// read with sc1 loads / sc1 DMA; nothing else in the arithmetic differs from the chain: outputs are BIT-IDENTICAL to it.
+//   L(t):  LSTM_a(t) | LSTM_d(t-2): activations by sc1 LDS-DMA.  The wait for the attention of step t-1 (every workgroup's
+//          flagT >= t) sits INSIDE the tile (DtpGate): weights and the ungated activation segments stream first, only the
+//          segments that need step t-1 -- ctx(t-1) for LSTM_a, h_dec(t-3) for LSTM_d -- are issued behind it.  h and its bf16
+//          copy out as write-through stores -> every wave drains -> LSTM_a tiles: flagA[j] = t+1
+//   T(t):  K_e prologue; right before its one load of h: wait until every LSTM_a tile has finished step t (flagA >= t+1) ->
+//          energy granules among the utterance's four workgroups, K_c: weights / cumulative weights / bf16 context out
+//          write-through -> drain -> flagT[j] = t+1.  A workgroup WITHOUT an attention role (B < 64) observes flagA the same
+//          way and raises its flagT[j] too: flagT has one counter per workgroup, so "all flagT >= t+1" says that every tile of
+//          L(t) -- LSTM_d's included, which publish nothing of their own -- is complete, and every workgroup has observed it.
+// Every exchanged tensor is written once per step with sc1 stores and read with sc1 loads / sc1 DMA; nothing else in the
+// arithmetic differs from the chain: outputs are BIT-IDENTICAL to it.
 // Spins are bounded (wall clock); a give-up sets *status and every workgroup leaves at its next wait.
 // =========================================================================================
+#ifndef T2AMD_DTP_LAG
+#define T2AMD_DTP_LAG 1          // steps the decoder LSTM trails the attention LSTM by inside the persistent launch (1 or 2; A/B builds)
+#endif
+constexpr int DTP_LAG = T2AMD_DTP_LAG;
 struct DecTrainPersist {
     t2amd_dec_train d;
     int tip, kc_smem_off, delay_a, delay_t, fail_off;
     unsigned token0;
     long long gran_off, ws_floats;
-    unsigned* flagA;           // [Ha/8]
-    unsigned* flagT;           // [4 B]
+    unsigned* flagA;           // [Ha/8]           LSTM_a tile j has finished step t: t + 1
+    unsigned* flagT;           // [workgroups]     workgroup j has finished L(t) and, if it has one, its attention step t: t + 1
     int* status;
     long long timeout_ticks, census_ticks;
     unsigned long long* ts;
@@ -1064,6 +1072,33 @@ __device__ __forceinline__ bool dtp_wait(const unsigned* flags, const int n, con
     }
 }
 
+// The tile's gate (skinny_wide.h): "every attention workgroup has finished step t-1", polled once at the tile's entry and, only if
+// that poll did not see every flag yet, again (blocking) where the tile first needs ctx.
+struct DtpGate {
+    static constexpr bool on = true;
+    const unsigned* flags; int n; unsigned target; int delay; int* status; long long ticks; int* fail_s;
+    unsigned f0, f1, f2, f3;
+    bool early_ok;
+    __device__ __forceinline__ void early_issue(const int wave, const int lane) {
+        f0 = f1 = f2 = f3 = 0xffffffffu;
+        early_ok = false;
+        if (wave == 0 && n <= 256) {
+            const int i = 4 * lane;
+            if (i < n) f0 = __hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i + 1 < n) f1 = __hip_atomic_load(flags + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i + 2 < n) f2 = __hip_atomic_load(flags + i + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i + 3 < n) f3 = __hip_atomic_load(flags + i + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __device__ __forceinline__ void early_check(const int wave, const int) {
+        if (wave == 0 && n <= 256) early_ok = __all(f0 >= target && f1 >= target && f2 >= target && f3 >= target);
+    }
+    __device__ __forceinline__ void wait(const int wave, const int lane) {
+        if (wave == 0 && !early_ok && !dtp_wait(flags, n, target, delay, status, ticks, lane) && lane == 0) fail_s[0] = 1;
+        __syncthreads();
+    }
+};
+
 __device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t, SkinnyParams& a) {
     // attention LSTM of step t: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T   (loops.hip fill_a, bf16 operands)
     const long long sHa = (long long)d.B * d.Ha, sE = (long long)d.B * d.E;
@@ -1071,9 +1106,14 @@ __device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t
     const unsigned short* h16 = (const unsigned short*)d.HA16;
     a = SkinnyParams{};
     a.nseg = 2;
-    a.x[0].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr; a.x[0].ld = d.E; a.x[0].width = d.E;
-    a.x[1].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr; a.x[1].ld = d.Ha; a.x[1].width = d.Ha;
+    // visited [h_att | ctx] over Wa_rec = [ctx columns | h_att columns] (explicit weight columns; the chain asks the per-step kernel
+    // for the same order, loops.hip): h_att(t-1) has been complete since this workgroup's own attention phase of step t-1, so its
+    // eight k-tiles run while the slowest attention workgroup is still producing ctx(t-1) -- the gate sits in front of segment 1.
+    a.x[0].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr; a.x[0].ld = d.Ha; a.x[0].width = d.Ha;
+    a.x[1].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr; a.x[1].ld = d.E; a.x[1].width = d.E;
     a.x[2].p = nullptr; a.x[2].ld = 0; a.x[2].width = 0;
+    a.wcol[0] = d.E; a.wcol[1] = 0; a.wcol[2] = d.E + d.Ha;
+    a.gate_seg = 1;
     a.W = (const float*)d.Wa_rec16; a.Ktot = d.E + d.Ha; a.H = d.Ha; a.B = d.B; a.N = 4 * d.Ha;
     a.gin = d.GA + (long long)t * d.B * 4 * d.Ha; a.ld_gin = 4 * d.Ha;
     a.c_prev = t ? d.CA + (t - 1) * sHa : nullptr; a.ld_cprev = d.Ha;
@@ -1104,6 +1144,8 @@ __device__ __forceinline__ void dtp_fill_d(const t2amd_dec_train& d, const int u
     a.h16_out = hd16 + u * sHd; a.ld_h16 = d.Hd;
     a.keep = d.keep_dec ? d.keep_dec + u * sHd : nullptr; a.ld_keep = d.Hd; a.keep_scale = d.scale_dec;
     a.gx = d.Hd / 8; a.gy = 1; a.gz = 1;
+    a.wcol[0] = -1;               // stored order [h_att | ctx | h_dec]: h_att(u) first, what step u's attention made behind the gate
+    a.gate_seg = DTP_LAG == 2 ? 2 : 1;
 }
 
 // The loop description is read from the kernel-argument segment INSIDE every iteration, through a pointer the compiler cannot
@@ -1129,12 +1171,16 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
     // CUs held by another process or kernel -- would only be dispatched when a resident one exits, which never happens while
     // they spin: found out HERE, within 2 ms and before anything is written, instead of at the first hand-off after 50 ms.
     if (wave == 0) {
-        unsigned* const census = P_entry.flagT + NSL * P_entry.d.B;
+        unsigned* const census = P_entry.flagT + gridDim.x;
         if (lane == 0) atomicAdd(census, 1u);
         const long long t0 = wall_clock64();
         unsigned spins = 0;
         bool bad = false;
-        while (__hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        if (P_entry.census_ticks <= 0) {            // tests: a forced give-up (T2AMD_DTP_TIMEOUT_TICKS=0), whatever the timing
+            if (lane == 0) atomicCAS(P_entry.status, 0, 3);
+            bad = true;
+        }
+        while (!bad && __hip_atomic_load(census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
             __builtin_amdgcn_s_sleep(4);
             if ((++spins & 15u) == 0) {
                 if (__hip_atomic_load(P_entry.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = true; break; }
@@ -1145,7 +1191,12 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
     }
     __syncthreads();
     if (reinterpret_cast<int*>(psmem_ + P_entry.fail_off)[0]) return;
-    for (int t = 0; t <= To; ++t) {
+    // Step t runs  L(t): LSTM_a(t) [t < To]  |  LSTM_d(t - DTP_LAG) [t >= DTP_LAG]   then   T(t): the attention step [t < To].
+    // DTP_LAG = 1 is the chain's pairing.  DTP_LAG = 2 (A/B build) lets the decoder LSTM trail by two steps: h_att(t-2) and ctx(t-2)
+    // are then complete before L(t) begins and only its own recurrence h_dec(t-3), eight of twenty k-tiles, sits behind the tile's
+    // gate instead of twelve.  Measured on one box it is the SLOWER form (23.32 vs 23.02 ms of forward, profiles/r04_j_lag_ab.txt):
+    // the tiles were not waiting on the gate for long in the first place, and the older operands are colder.
+    for (int t = 0; t <= To + DTP_LAG - 1; ++t) {
         const DecTrainPersist& P = dtp_args_late();
         const t2amd_dec_train& d = P.d;
         int zero = 0;
@@ -1153,7 +1204,7 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
         char* const psmem = psmem_ + zero;
         float* const smem = reinterpret_cast<float*>(psmem);
         int* const fail_s = reinterpret_cast<int*>(psmem + P.fail_off);      // behind both phases' regions
-        const int nA = d.Ha / 8, nL = nA + d.Hd / 8, nT = NSL * d.B;
+        const int nA = d.Ha / 8, nL = nA + d.Hd / 8, nT = NSL * d.B, nG = (int)gridDim.x;
         const bool isA = j < nA, isD = j >= nA && j < nL, isT = j < nT;
         const int b = j / NSL, sl = j % NSL;
         const bool prof_on = P.prof != nullptr && tid == 0 && (j == 0 || j == nA);
@@ -1161,32 +1212,39 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
         unsigned long long c0 = prof_on ? wall_clock64() : 0ull, c1;
 #define DTP_PROF(slot) do { if (prof_on) { c1 = wall_clock64(); prof[slot] += c1 - c0; c0 = c1; } } while (0)
         // ---------------- L(t) ----------------
-        if (t > 0 && (isA || isD)) {
-            if (wave == 0 && !dtp_wait(P.flagT, nT, (unsigned)t, P.delay_a, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
+        const bool tile = (isA && t < To) || (isD && t >= DTP_LAG);
+        const bool tail = t >= To;                       // the two trailing iterations: no attention phase around them any more
+        if (DTP_LAG > 1 && tile && tail) {
+            // (nothing ran between the previous tiles and these that would have observed their inputs: wait in front of the tile)
+            if (wave == 0 && !dtp_wait(P.flagT, nG, (unsigned)t, P.delay_a, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
             __syncthreads();
             if (fail_s[0]) return;
         }
         DTP_PROF(0);
-        if ((isA && t < To) || (isD && t > 0)) {
+        if (tile) {
             // ONE call site for both roles (two inlined copies of the tile body in sibling branches crash hipcc's SimplifyCFG)
             SkinnyParams sp;
             if (isA) dtp_fill_a(d, t, sp);
-            else dtp_fill_d(d, t - 1, sp);
-            skinny_wide_body<true, true>(sp, isA ? j : j - nA, psmem, P.ts);
+            else dtp_fill_d(d, t - DTP_LAG, sp);
+            DtpGate gate;
+            gate.flags = P.flagT; gate.n = nG; gate.target = (unsigned)t; gate.delay = P.delay_a; gate.status = P.status;
+            gate.ticks = P.timeout_ticks; gate.fail_s = fail_s;
+            if (t == 0 || (DTP_LAG > 1 && tail)) sp.gate_seg = 0;    // nothing to wait for at the first step; already waited in the tail
+            skinny_wide_body<true, true>(sp, isA ? j : j - nA, psmem, P.ts, gate);
+            if (fail_s[0]) return;
         }
         // every storing wave drains its write-through stores (R1), then ONE flag per LSTM_a tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (isA && t < To && tid == 0) __hip_atomic_store(P.flagA + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         DTP_PROF(1);
-        if (t == To) break;
+        if (tail) {
+            // no attention step left: the counter the last decoder tiles wait for is raised right here
+            if (t < To + DTP_LAG - 1 && tid == 0) __hip_atomic_store(P.flagT + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         // ---------------- T(t) ----------------
         if (isT) {
-#ifdef T2AMD_DTP_WAIT_FIRST                     // A/B builds: the round-4 first form (wait, then the whole prologue)
-            if (wave == 0 && !dtp_wait(P.flagA, nA, (unsigned)(t + 1), P.delay_t, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
-            __syncthreads();
-            if (fail_s[0]) return;
-#endif
             DTP_PROF(2);
             const long long sHa = (long long)d.B * d.Ha, sE = (long long)d.B * d.E;
             AttnFwdParams ap;
@@ -1207,9 +1265,6 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             ap.token = P.token0 + (unsigned)t; ap.gran_off = P.gran_off; ap.kc_smem_off = P.kc_smem_off; ap.delay = 0;
             KcPre<true> r;
             float e_first[4] = {0.f, 0.f, 0.f, 0.f};
-#ifdef T2AMD_DTP_WAIT_FIRST
-            ke_phase<true, true, true>(ap, smem, sl, b, ts_on, [] {}, [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
-#else
             // the wait for the LSTM_a tiles of this step sits INSIDE the prologue, right before the one load that needs them (h):
             // W_q, processed memory, U, v and the windows are on their way while the flags are polled.  (A give-up lets the phase
             // run on with whatever h holds -- status is set, the step is poisoned behind the launch -- and leaves right after it.)
@@ -1220,13 +1275,20 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
                                        },
                                        [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
             if (fail_s[0]) return;
-#endif
             fwd_energy_granules(ap, b, r.len, e_first);
             kc_finish<true, true, true>(ap, smem + P.kc_smem_off, sl, b, ts_on, r, e_first);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(P.flagT + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             DTP_PROF(3);
+        } else {
+            // No attention role (fewer utterances than tiles).  The tiles of the next step wait for EVERY workgroup's counter -- a
+            // tile written by a workgroup without one would be consumed unsynchronised -- and every workgroup must have observed
+            // what an attention workgroup observes (the LSTM_a tiles of this step) before its next tile reads their output.
+            if (wave == 0 && !dtp_wait(P.flagA, nA, (unsigned)(t + 1), P.delay_t, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
+            __syncthreads();
+            if (fail_s[0]) return;
+            if (tid == 0) __hip_atomic_store(P.flagT + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #undef DTP_PROF
     }
@@ -1246,7 +1308,9 @@ static unsigned long long* g_dtp_prof = nullptr;
 extern "C" int t2amd_debug_dtp_prof_(unsigned long long* buf) { g_dtp_prof = buf; return T2AMD_OK; }
 
 extern "C" long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha) {
-    return 4ll * (Ha / 8 + (long long)NSL * B + 1);          // LSTM_a tile counters, attention counters, the arrival census
+    // LSTM_a tile counters, one counter per workgroup of the launch (at most 1024: the grid must fit the device), the arrival census
+    (void)B;
+    return 4ll * (Ha / 8 + 1024 + 1);
 }
 
 static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out) {
@@ -1283,7 +1347,7 @@ extern "C" int t2amd_decoder_train_fwd_persistent_supported(const t2amd_dec_trai
     const int nL = p->Ha / 8 + p->Hd / 8, nT = NSL * p->B;
     const int grid = nL > nT ? nL : nT;
     // one workgroup per CU (96 KB of LDS each): every one of them must be resident at once
-    T2_REQUIRE(grid <= cus, "dec_train_fwd_persistent: more workgroups than compute units (they must all be co-resident)");
+    T2_REQUIRE(grid <= cus && grid <= 1024, "dec_train_fwd_persistent: more workgroups than compute units (they must all be co-resident)");
     return T2AMD_OK;
 }
 
@@ -1301,8 +1365,10 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     P.d = *p;
     P.tip = tip; P.kc_smem_off = kc; P.fail_off = fo;
     // pre-poll pauses in s_sleep units (tuning knobs, read per call so that a tool can sweep them in one process)
-    { const char* e = getenv("T2AMD_DTP_DELAY_L"); const int v = e ? atoi(e) : 64; P.delay_a = v < 0 ? 0 : (v > 400 ? 400 : v); }
-    { const char* e = getenv("T2AMD_DTP_DELAY_T"); const int v = e ? atoi(e) : 64; P.delay_t = v < 0 ? 0 : (v > 400 ? 400 : v); }
+    { const char* e = getenv("T2AMD_DTP_DELAY_L"); const int v = e ? atoi(e) : 4; P.delay_a = v < 0 ? 0 : (v > 400 ? 400 : v); }
+    // (the wait for the LSTM flags sits inside the attention prologue, behind ~70 KB of loads: they ARE its pause -- flat from 0 to 16
+    // units, 23.05 / 23.10 / 23.12 ms of forward; 24.1 at 64)
+    { const char* e = getenv("T2AMD_DTP_DELAY_T"); const int v = e ? atoi(e) : 8; P.delay_t = v < 0 ? 0 : (v > 400 ? 400 : v); }
     P.gran_off = ((long long)NSL * B * Ti + 3) / 4 * 4;
     P.ws_floats = fwd_ws_floats;
     T2_REQUIRE((reinterpret_cast<uintptr_t>(p->attn_ws + P.gran_off) & 7u) == 0, "dec_train_fwd_persistent: attn_ws must be 8-byte aligned");
@@ -1314,8 +1380,8 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     P.status = status;
     const char* te = getenv("T2AMD_DTP_TIMEOUT_TICKS");
     P.timeout_ticks = te ? atoll(te) : 5000000ll;                   // 50 ms of the 100 MHz wall clock
+    P.census_ticks = P.timeout_ticks < 200000ll ? P.timeout_ticks : 200000ll;      // 2 ms; 0 = give up at once (tests)
     if (P.timeout_ticks < 1) P.timeout_ticks = 1;
-    P.census_ticks = P.timeout_ticks < 200000ll ? P.timeout_ticks : 200000ll;      // 2 ms
     P.ts = attn_ts_buffer();
     P.prof = g_dtp_prof;
     if (t2amd_validate_only_flag_()) return T2AMD_OK;

@@ -62,6 +62,8 @@ static int order_after(hipStream_t waiter, hipStream_t signaller, size_t ev_inde
     return T2AMD_OK;
 }
 
+extern "C" int t2amd_lstm_step_fwd2_order_(const t2amd_lstm_step* a, const t2amd_lstm_step* b, int swap01, void* stream);   // rnn.hip
+
 static inline t2amd_seg seg(const float* p, long long ld, int width) {
     t2amd_seg s;
     s.p = p; s.ld = ld; s.width = width;
@@ -177,7 +179,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
             for (int t = t0; t < t1; ++t) {
                 t2amd_lstm_step a;
                 fill_a(t, a);
-                T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, main_s));
+                T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&a, nullptr, p->bf16 ? 1 : 0, main_s));      // same k order as the fused pair
                 T2_PROPAGATE(attention(t, main_s));
             }
             T2_PROPAGATE(order_after(side, main_s, ev++));        // HA, CTX of this chunk exist
@@ -202,7 +204,8 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
             T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
         } else {
             d.tag = 3;     // the pair is profiled as role 3 (its symbol is skinny_gemm_kernel<true, 3>)
-            T2_PROPAGATE(t2amd_lstm_step_fwd2_f32(&d, &a, stream));
+            // bf16 mode: the attention LSTM walks [h_att | ctx] (the persistent loop's order: csrc/attention.hip dtp_fill_a)
+            T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&d, &a, p->bf16 ? 2 : 0, stream));
         }
         if (t == To) break;
         T2_PROPAGATE(attention(t, stream));

@@ -357,7 +357,8 @@ __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     const bool second = (int)blockIdx.x >= dp.nblk0;
     const SkinnyParams p = skinny_select(dp, second);
     const int lb = (int)blockIdx.x - (second ? dp.nblk0 : 0);
-    skinny_wide_body<LSTM, false>(p, lb, smem, dp.ts);
+    NoGate ng;
+    skinny_wide_body<LSTM, false>(p, lb, smem, dp.ts, ng);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -679,12 +680,16 @@ static int fill_lstm(const t2amd_lstm_step* a, SkinnyParams& p) {
     p.keep = a->keep; p.ld_keep = a->ld_keep; p.keep_scale = a->keep_scale;
     p.lens = a->lens; p.t = a->t;
     p.gx = a->H / 4; p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = 1;
+    p.wcol[0] = p.wcol[1] = p.wcol[2] = -1;
     return T2AMD_OK;
 }
 
 // One launch for one or two independent LSTM steps (b may be NULL).  The kernel symbol / profiling
 // role is a's tag.
-extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_lstm_step* b, void* stream) {
+// swap01: bit 0 / bit 1 = visit segment 1 of problem a / b BEFORE its segment 0 (explicit weight columns; the wide bf16 tile only --
+// the other kernels keep the stored order).  The training loop asks for it on the attention LSTM (loops.hip), so that the launch chain
+// sums in the same order as the persistent loop, which starts that LSTM on h_att while ctx is still being produced.
+static int lstm_step_fwd2_impl(const t2amd_lstm_step* a, const t2amd_lstm_step* b, int swap01, void* stream) {
     SkinnyDual d;
     d.ts = t2amd_debug_ts_();
     T2_PROPAGATE(fill_lstm(a, d.p[0]));
@@ -720,6 +725,15 @@ extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_ls
         d.p[0].gx = a->H / 8;
         d.nblk0 = d.p[0].gx * d.p[0].gy;
         total = d.nblk0;
+        for (int k = 0; k < (b ? 2 : 1); ++k) {
+            SkinnyParams& q = d.p[k];
+            if (((swap01 >> k) & 1) && q.nseg >= 2) {
+                const int w0 = q.x[0].width, w1 = q.x[1].width;
+                const t2amd_seg s0 = q.x[0];
+                q.x[0] = q.x[1]; q.x[1] = s0;
+                q.wcol[0] = w0; q.wcol[1] = 0; q.wcol[2] = w0 + w1;
+            }
+        }
         if (b) { d.p[1].gx = b->H / 8; total += d.p[1].gx * d.p[1].gy; } else { d.p[1] = d.p[0]; }
         if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1>), dim3(total), dim3(512));
         else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2>), dim3(total), dim3(512));
@@ -739,6 +753,14 @@ extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_ls
 #undef LSTM_LAUNCH
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
+}
+
+extern "C" int t2amd_lstm_step_fwd2_f32(const t2amd_lstm_step* a, const t2amd_lstm_step* b, void* stream) {
+    return lstm_step_fwd2_impl(a, b, 0, stream);
+}
+// internal (loops.hip): see lstm_step_fwd2_impl
+extern "C" int t2amd_lstm_step_fwd2_order_(const t2amd_lstm_step* a, const t2amd_lstm_step* b, int swap01, void* stream) {
+    return lstm_step_fwd2_impl(a, b, swap01, stream);
 }
 
 extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
@@ -767,6 +789,7 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     const int ktiles = a->Ktot / (a->bf16 ? 128 : 64);
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     p.gx = t2_cdiv(a->N, 16); p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = a->nsplit;
+    p.wcol[0] = p.wcol[1] = p.wcol[2] = -1;
     return T2AMD_OK;
 }
 

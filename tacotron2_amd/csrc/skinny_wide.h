@@ -37,6 +37,14 @@ struct SkinnyParams {
     uint8_t* stop_active; int* stop_lengths; int* stop_done;     // plain epilogue: decode stop test (t2amd_skinny_gemm)
     int stop_col, stop_max_steps; float stop_thr;                // (the step is `t` above)
     int gx, gy, gz;   // logical grid of this problem
+    // K column of W at which segment i starts, or wcol[0] < 0 = "cumulative" (segment i starts where segment i-1 ended).  Explicit
+    // columns let the segments be VISITED in another order than W stores them (wide bf16 tile only): the attention LSTM of the
+    // training loop walks [h_att | ctx] over Wa_rec = [ctx columns | h_att columns], so that in the persistent loop the k-tiles of
+    // h_att -- complete one phase earlier than ctx -- can run ahead of the wait for ctx (gate_seg below).
+    int wcol[3];
+    // persistent loop only: segments with index >= gate_seg are not touched (no DMA issued) before the caller's gate has opened;
+    // 0 or less = no gate inside the tile.
+    int gate_seg;
 };
 
 // Two independent problems in one launch (blocks [0, nblk0) -> p[0], the rest -> p[1]): the decoder
@@ -62,6 +70,7 @@ __device__ __forceinline__ SkinnyParams skinny_select(const SkinnyDual& dp, bool
     SK_SEL(Y); SK_SEL(ldy); SK_SEL(nsplit); SK_SEL(split_stride); SK_SEL(ktiles_per_split); SK_SEL(act);
     SK_SEL(stop_active); SK_SEL(stop_lengths); SK_SEL(stop_done); SK_SEL(stop_col); SK_SEL(stop_max_steps); SK_SEL(stop_thr);
     SK_SEL(gx); SK_SEL(gy); SK_SEL(gz);
+    SK_SEL(wcol[0]); SK_SEL(wcol[1]); SK_SEL(wcol[2]); SK_SEL(gate_seg);
 #undef SK_SEL
     return p;
 }
@@ -109,8 +118,22 @@ __device__ __forceinline__ void skinny_stop_test(const SkinnyParams& p, int row,
 // and h / its bf16 copy leave as write-through (sc1) stores, to be drained by the caller before it publishes its flag
 // (Guideline 16 R1).  Same arithmetic in the same order either way: bit-identical results.
 // `smem`: SW_NBUF * (SW_XB + SW_WB) bytes of LDS, 16-byte aligned; `lb`: the workgroup's index within problem `p`.
-template <bool LSTM, bool PERSIST>
-__device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const int lb, char* const smem, unsigned long long* const ts_buf) {
+// Gate = what the persistent loop hands in so that the tile can start on the operand segments that are already complete and wait
+// for the rest INSIDE the k loop:  early_issue() at entry (one poll, issued before any DMA: loads return in order, so it has
+// landed by the time the first tile has), early_check() right behind the first tile's wait (no stall: everything older than that
+// tile has returned), wait() once, at the workgroup-uniform point where the first DMA of a gated segment is about to be issued
+// (a blocking poll by wave 0 only if the early one did not see every flag, then a barrier).  The slowest workgroup of the
+// previous phase -- the one on the critical path -- finds all flags set in its early poll and never stalls; earlier finishers pay a
+// drained DMA queue they have the slack for.  NoGate: the per-step kernels.
+struct NoGate {
+    static constexpr bool on = false;
+    __device__ __forceinline__ void early_issue(int, int) {}
+    __device__ __forceinline__ void early_check(int, int) {}
+    __device__ __forceinline__ void wait(int, int) {}
+};
+template <bool LSTM, bool PERSIST, class Gate>
+__device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const int lb, char* const smem, unsigned long long* const ts_buf,
+                                                 Gate& gate) {
     constexpr int BK = 128;
     constexpr int XAUX = PERSIST ? 16 : 0;       // aux bit 4 = sc1 on the activation DMA
     bool ts_on = false;
@@ -135,7 +158,9 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
     const int n0 = p.x[0].p ? p.x[0].width / BK : 0;
     const int n1 = (p.nseg > 1 && p.x[1].p) ? p.x[1].width / BK : 0;
     const int n2 = (p.nseg > 2 && p.x[2].p) ? p.x[2].width / BK : 0;
-    const int wo1 = p.x[0].width, wo2 = p.x[0].width + (p.nseg > 1 ? p.x[1].width : 0);
+    const bool wexp = p.wcol[0] >= 0;
+    const int wo0 = wexp ? p.wcol[0] : 0;
+    const int wo1 = wexp ? p.wcol[1] : p.x[0].width, wo2 = wexp ? p.wcol[2] : p.x[0].width + (p.nseg > 1 ? p.x[1].width : 0);
     const int nvt = n0 + n1 + n2;
     int kt_beg = 0, kt_end = nvt;
     if (!LSTM) {
@@ -219,7 +244,7 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         if (seg_ == 0) {                                                                               \
             const char* sp_ = xp0 + loc_ * 256;                                                        \
             xq0 = sp_ + xo0[0]; xq1 = sp_ + xo0[1];                                                    \
-            wq = Wp + loc_ * 256; iss_rem = n0 - loc_;                                                 \
+            wq = Wp + wo0 * 2 + loc_ * 256; iss_rem = n0 - loc_;                                       \
         } else if (seg_ == 1) {                                                                        \
             const char* sp_ = xp1 + loc_ * 256;                                                        \
             xq0 = sp_ + xo1[0]; xq1 = sp_ + xo1[1];                                                    \
@@ -238,8 +263,13 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         else SW_SEEK(2, kt_beg - n0 - n1)
     }
 
+    bool gate_armed = Gate::on && p.gate_seg > 0;
+    if constexpr (Gate::on) gate.early_issue(wave, lane);
 #define SW_ISSUE(BUF)                                                                                  \
     {                                                                                                  \
+        if constexpr (Gate::on) {                                                                      \
+            if (gate_armed && iss_seg >= p.gate_seg) { gate.wait(wave, lane); gate_armed = false; }    \
+        }                                                                                              \
         char* xd_ = Xs + (BUF) * SW_XB + wave * (8 * 256);                                             \
         __builtin_amdgcn_global_load_lds((t2_gptr)(xq0), (t2_lptr)(xd_), 16, 0, XAUX);                 \
         __builtin_amdgcn_global_load_lds((t2_gptr)(xq1), (t2_lptr)(xd_ + 1024), 16, 0, XAUX);          \
@@ -322,6 +352,7 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         SW_ISSUE(2)
         SW_ISSUE(3)
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        if constexpr (Gate::on) gate.early_check(wave, lane);       // (older than tile 0's DMA: it has returned)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SW_TS(2);

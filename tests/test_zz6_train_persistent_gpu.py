@@ -89,13 +89,14 @@ def test_fp32_mode_and_unsupported_geometries_stay_on_the_chain(native_lib):
 
 
 def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_lib, monkeypatch):
-    """A timeout of one tick makes every wait give up at once: status is set, the finishing launch turns the step's data into
+    """T2AMD_DTP_TIMEOUT_TICKS=0 forces the arrival census to give up (a 1-tick timeout is a race: a small launch can finish
+    every wait before its first clock check): status is set, the finishing launch turns the step's data into
     NaN and counts it; handle_nonfinite_step() reports it and selects the launch chain (and the separate-launch attention
     forms, which make no co-residency assumption either) for the rest of the process."""
     m, hp = _model()
     batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 12, 7], [22, 15, 9], hp.n_mel_channels, 11))
     native.attn_handoff_timeouts(reset=True)
-    monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "1")
+    monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
     forms = (native.get_attn_fwd_fused() if hasattr(native, "get_attn_fwd_fused") else None)
     try:
         o, loss, g, _, path = _step(m, batch, True)

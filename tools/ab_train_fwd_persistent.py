@@ -114,11 +114,11 @@ lib = native.load()
 lib.t2amd_debug_dtp_prof_.argtypes = [C.c_void_p]
 prof = torch.zeros(8, dtype=torch.int64, device=dev)
 sweep = {}
-for dl, dt_ in ((64, 64), (96, 96), (128, 128), (192, 192), (128, 64), (64, 128), (200, 100)):
+for dl, dt_ in ((16, 8), (0, 8), (2, 8), (4, 8), (8, 8), (12, 8), (24, 8)):
     os.environ["T2AMD_DTP_DELAY_L"], os.environ["T2AMD_DTP_DELAY_T"] = str(dl), str(dt_)
     ms = min(fwd_only(True) for _ in range(2)) if False else None
     sweep["L%d_T%d" % (dl, dt_)] = None
-os.environ["T2AMD_DTP_DELAY_L"], os.environ["T2AMD_DTP_DELAY_T"] = "64", "64"
+os.environ["T2AMD_DTP_DELAY_L"], os.environ["T2AMD_DTP_DELAY_T"] = "16", "8"
 
 times = {"chain": [], "persistent": [], "fwd_only_chain": [], "fwd_only_persistent": []}
 for _ in range(a.blocks):
@@ -130,7 +130,7 @@ for key in list(sweep):
     dl, dt_ = key[1:].split("_T")
     os.environ["T2AMD_DTP_DELAY_L"], os.environ["T2AMD_DTP_DELAY_T"] = dl, dt_
     sweep[key] = min(fwd_only(True) for _ in range(2))
-os.environ["T2AMD_DTP_DELAY_L"], os.environ["T2AMD_DTP_DELAY_T"] = "64", "64"
+os.environ["T2AMD_DTP_DELAY_L"], os.environ["T2AMD_DTP_DELAY_T"] = "16", "8"
 out["fwd_only_ms_by_prepoll_pause"] = sweep
 print("pause sweep (fwd only, ms):", json.dumps(sweep))
 prof.zero_()
