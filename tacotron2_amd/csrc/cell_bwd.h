@@ -12,6 +12,22 @@
 // kernel has been issued: a runtime-trip-count loop made every slab a separate, fully waited L2 round trip (seven
 // in a row for the decoder cells).  More than four slabs fall back to a loop.
 struct Slab4 { float4 v0, v1, v2, v3; };
+// SC1 (the persistent backward loop, attention.hip): the slabs were written by OTHER workgroups of the SAME launch (the previous
+// time step's dgrad tiles): device-scope loads (two 8-byte relaxed agent-scope loads per float4: sc1, tracked by the compiler's
+// own wait counting, unlike an inline-asm load), never an L2 line that predates them.  Same values, same order of additions.
+template <bool SC1>
+__device__ __forceinline__ float4 cell_ld4(const float* q) {
+    if constexpr (SC1) {
+        typedef unsigned long long u64;
+        const u64 lo = __hip_atomic_load(reinterpret_cast<const u64*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 hi = __hip_atomic_load(reinterpret_cast<const u64*>(q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                           __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+    } else {
+        return *reinterpret_cast<const float4*>(q);
+    }
+}
+template <bool SC1 = false>
 __device__ __forceinline__ Slab4 addend_issue4(const t2amd_addend& ad, int row, int col) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     Slab4 r = {z, z, z, z};
@@ -19,12 +35,13 @@ __device__ __forceinline__ Slab4 addend_issue4(const t2amd_addend& ad, int row, 
     const float* q = ad.p + (long long)row * ad.ld + col;
     const int n = ad.nsplit;
     const long long st = ad.split_stride;
-    r.v0 = *reinterpret_cast<const float4*>(q);
-    if (n > 1) r.v1 = *reinterpret_cast<const float4*>(q + st);
-    if (n > 2) r.v2 = *reinterpret_cast<const float4*>(q + 2 * st);
-    if (n > 3) r.v3 = *reinterpret_cast<const float4*>(q + 3 * st);
+    r.v0 = cell_ld4<SC1>(q);
+    if (n > 1) r.v1 = cell_ld4<SC1>(q + st);
+    if (n > 2) r.v2 = cell_ld4<SC1>(q + 2 * st);
+    if (n > 3) r.v3 = cell_ld4<SC1>(q + 3 * st);
     return r;
 }
+template <bool SC1 = false>
 __device__ __forceinline__ float4 addend_finish4(const Slab4& r, const t2amd_addend& ad, int row, int col) {
     if (!ad.p) return make_float4(0.f, 0.f, 0.f, 0.f);
     const int n = ad.nsplit;
@@ -35,7 +52,7 @@ __device__ __forceinline__ float4 addend_finish4(const Slab4& r, const t2amd_add
     if (n > 4) {
         const float* q = ad.p + (long long)row * ad.ld + col;
         for (int k = 4; k < n; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(q + (long long)k * ad.split_stride);
+            const float4 v = cell_ld4<SC1>(q + (long long)k * ad.split_stride);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
@@ -68,6 +85,8 @@ __device__ __forceinline__ CellOperands cell_bwd_issue(const t2amd_lstm_bwd& a, 
 #define T2_PK4(o) make_uint2((unsigned)t2_f32_to_bf16(o[0]) | ((unsigned)t2_f32_to_bf16(o[1]) << 16), \
                              (unsigned)t2_f32_to_bf16(o[2]) | ((unsigned)t2_f32_to_bf16(o[3]) << 16))
 // dh = (d0 + d1) + d2 in that order (the three addends of t2amd_lstm_bwd.dh, each already summed over its slabs)
+// SC1: the bf16 copy of the gate gradients is what the dgrad tiles of the SAME launch read next: write-through stores.
+template <bool SC1 = false>
 __device__ __forceinline__ void cell_bwd_finish(const t2amd_lstm_bwd& a, const CellOperands& r, const float4& d0,
                                                 const float4& d1, const float4& d2, int b, int j) {
     // no mul+add contraction in here: which products the compiler fuses depends on the surrounding kernel, and the two
@@ -101,10 +120,19 @@ __device__ __forceinline__ void cell_bwd_finish(const t2amd_lstm_bwd& a, const C
     *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(o2[0], o2[1], o2[2], o2[3]);
     *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(o3[0], o3[1], o3[2], o3[3]);
     if (d16) {       // bf16 copy: the dgrad GEMM's MFMA operand in bf16 mode
-        *reinterpret_cast<uint2*>(d16) = T2_PK4(o0);
-        *reinterpret_cast<uint2*>(d16 + H) = T2_PK4(o1);
-        *reinterpret_cast<uint2*>(d16 + 2 * H) = T2_PK4(o2);
-        *reinterpret_cast<uint2*>(d16 + 3 * H) = T2_PK4(o3);
+        if constexpr (SC1) {
+            typedef unsigned long long u64;
+            const uint2 q0 = T2_PK4(o0), q1 = T2_PK4(o1), q2 = T2_PK4(o2), q3 = T2_PK4(o3);
+            __hip_atomic_store(reinterpret_cast<u64*>(d16), (u64)q0.x | ((u64)q0.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<u64*>(d16 + H), (u64)q1.x | ((u64)q1.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<u64*>(d16 + 2 * H), (u64)q2.x | ((u64)q2.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<u64*>(d16 + 3 * H), (u64)q3.x | ((u64)q3.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            *reinterpret_cast<uint2*>(d16) = T2_PK4(o0);
+            *reinterpret_cast<uint2*>(d16 + H) = T2_PK4(o1);
+            *reinterpret_cast<uint2*>(d16 + 2 * H) = T2_PK4(o2);
+            *reinterpret_cast<uint2*>(d16 + 3 * H) = T2_PK4(o3);
+        }
     }
     *reinterpret_cast<float4*>(dcp) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
 }

@@ -42,8 +42,9 @@ struct SkinnyParams {
     // training loop walks [h_att | ctx] over Wa_rec = [ctx columns | h_att columns], so that in the persistent loop the k-tiles of
     // h_att -- complete one phase earlier than ctx -- can run ahead of the wait for ctx (gate_seg below).
     int wcol[3];
-    // persistent loop only: segments with index >= gate_seg are not touched (no DMA issued) before the caller's gate has opened;
-    // 0 or less = no gate inside the tile.
+    // persistent loops only: segments with index >= gate_seg are not touched (no DMA issued) before the caller's gate has opened;
+    // 0 = no gate inside the tile; negative = the gate stands in front of the tile's FIRST DMA (every activation segment is what
+    // the previous phase of the same launch wrote: the BPTT dgrad pair of the persistent backward loop).
     int gate_seg;
 };
 
@@ -125,17 +126,29 @@ __device__ __forceinline__ void skinny_stop_test(const SkinnyParams& p, int row,
 // (a blocking poll by wave 0 only if the early one did not see every flag, then a barrier).  The slowest workgroup of the
 // previous phase -- the one on the critical path -- finds all flags set in its early poll and never stalls; earlier finishers pay a
 // drained DMA queue they have the slack for.  NoGate: the per-step kernels.
+__device__ __forceinline__ int t2_tid_opaque() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 struct NoGate {
     static constexpr bool on = false;
     __device__ __forceinline__ void early_issue(int, int) {}
     __device__ __forceinline__ void early_check(int, int) {}
     __device__ __forceinline__ void wait(int, int) {}
 };
-template <bool LSTM, bool PERSIST, class Gate>
+// XPLAIN (PERSIST only): the activation tiles are fetched with ORDINARY DMA although another workgroup of the same launch wrote
+// them.  Legal only where no stale copy can exist in this XCD's L2: the operand lives at an address that NOTHING read before it
+// was written (a per-step slab), and every 128-byte line of it was written WHOLE by one wave (write-through: the line a writer's
+// L2 may keep is complete and current).  The bf16 gate gradients of the BPTT loop are such an operand (cell_bwd_finish: a wave
+// writes 512 contiguous bytes per gate row); h_att / h_dec of the forward loop are not (eight workgroups share a line).  What it
+// buys: the 80 (48) column tiles that read the same 256 KB of gate gradients hit their XCD's L2 instead of going to the fabric
+// 256 times per step -- 64 MB per step, which is what bounded the phase.
+template <bool LSTM, bool PERSIST, class Gate, bool XPLAIN = false>
 __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const int lb, char* const smem, unsigned long long* const ts_buf,
                                                  Gate& gate) {
     constexpr int BK = 128;
-    constexpr int XAUX = PERSIST ? 16 : 0;       // aux bit 4 = sc1 on the activation DMA
+    constexpr int XAUX = (PERSIST && !XPLAIN) ? 16 : 0;       // aux bit 4 = sc1 on the activation DMA
     bool ts_on = false;
     SW_TS(0);
     char* const Xs = smem;                       // [NBUF][64][256 B]
@@ -146,7 +159,9 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
     const int by = (lb / p.gx) % p.gy;
     const int bz = lb / (p.gx * p.gy);
 
-    const int tid = threadIdx.x;
+    // (persistent backward loop: an opaque thread index per call -- otherwise everything derived from it is hoisted out of the
+    // loop over the time steps and spilled, ~100 scratch reloads per step)
+    const int tid = (PERSIST && !LSTM) ? t2_tid_opaque() : (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
@@ -263,7 +278,7 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         else SW_SEEK(2, kt_beg - n0 - n1)
     }
 
-    bool gate_armed = Gate::on && p.gate_seg > 0;
+    bool gate_armed = Gate::on && p.gate_seg != 0;
     if constexpr (Gate::on) gate.early_issue(wave, lane);
 #define SW_ISSUE(BUF)                                                                                  \
     {                                                                                                  \
@@ -412,7 +427,8 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
                 if (p.bias) o += p.bias[gn];
                 if (p.act == 1) o = fmaxf(o, 0.f);
                 if (p.keep) o = p.keep[(long long)gr * p.ld_keep + gn] ? o * p.keep_scale : 0.f;
-                Y[gn] = o;
+                if constexpr (PERSIST) __hip_atomic_store(&Y[gn], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the next phase of this launch
+                else Y[gn] = o;
                 if (p.h16_out) p.h16_out[(long long)gr * p.ld_h16 + gn] = t2_f32_to_bf16(o);
                 if (p.stop_active && gn == p.stop_col) skinny_stop_test(p, gr, o);
             }

@@ -772,6 +772,27 @@ def _decoder_train_fwd(model, run, d, poison, reads, writes):
     return 'launch chain'
 
 
+# BPTT through the decoder loop as ONE persistent launch (csrc/attention.hip, dec_train_bwd_persistent_kernel) instead of 2 To
+# dependent launches; T2AMD_TRAIN_BWD_PERSISTENT=0 keeps the chain.  Bit-identical to it.
+TRAIN_BWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_BWD_PERSISTENT', '0') != '0'
+
+
+def _decoder_train_bwd(model, run, bw, poison, reads, writes):
+    """reference model.py:405-411 under autograd.  The persistent launch when it is selected and the geometry fits this device;
+    a give-up turns ``poison[0]`` (an element of a gradient) into NaN: the step is skipped, handle_nonfinite_step() selects the chain."""
+    if TRAIN_BWD_PERSISTENT and run.bf16:
+        # (validate-only CPU runs stage and check every step's descriptors too; nothing is launched)
+        cus = 256 if nv.validate_only() else torch.cuda.get_device_properties(run.dev).multi_processor_count
+        if nv.decoder_train_bwd_persistent_supported(bw, cus) is None:
+            descs = run.empty8(nv.decoder_train_bwd_persistent_desc_bytes(bw.f.To))
+            flags = run.empty_i32(nv.decoder_train_bwd_persistent_flag_words())
+            status = run.empty_i32(1)
+            nv.decoder_train_bwd_persistent(bw, descs, flags, status, poison)
+            return 'persistent'
+    nv.decoder_train_bwd_loop(bw, reads=reads, writes=writes)
+    return 'launch chain'
+
+
 # BPTT of the encoder bi-LSTM as ONE persistent launch (csrc/decode_persist.hip, encoder_bilstm_batch_persistent_bwd_kernel)
 # instead of 2 T dependent launches; T2AMD_ENCODER_BWD_PERSISTENT=0 keeps the chain.  Equal to the chain's gradients to the
 # rounding of its split-bf16 recurrent product (~2^-17 per product).
@@ -890,8 +911,9 @@ def handle_nonfinite_step(log=None):
             print(msg, file=sys.stderr, flush=True)
     n = nv.attn_handoff_timeouts(reset=True)
     if n > 0:
-        global TRAIN_FWD_PERSISTENT
+        global TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT
         TRAIN_FWD_PERSISTENT = False
+        TRAIN_BWD_PERSISTENT = False
         nv.set_attn_fwd_fused(0)
         nv.set_attn_bwd_fused(0)
         nv.set_bptt_cell_fold(0)
@@ -1208,7 +1230,10 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     nv.grads_to_channel_last(cont(d_mel), cont(d_post), dmel_cl, dpost_cl)
     _conv_stack_bwd(run, P, g, 'postnet.convolutions', c.post_saved, dpost_cl.view(rowsP, Cm), To,
                     first_dx=dmel_cl.view(rowsP, Cm), first_dx_accumulate=True, G=G)
-    if sync is not None:
+    # The persistent BPTT launch needs every CU to itself (its arrival census gives up after 2 ms): no collective may start beside
+    # it.  The postnet bucket is then launched BEHIND the loop (it travels under the decoder's weight-gradient products instead).
+    defer_postnet = sync is not None and TRAIN_BWD_PERSISTENT and run.bf16
+    if sync is not None and not defer_postnet:
         sync.bucket_ready('postnet')             # travels while the decoder BPTT below runs
     dout = run.empty(rowsD, Cm + 1)
     nv.gather_dout(dmel_cl, cont(d_gate), dout)
@@ -1264,7 +1289,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         setattr(bw, k_, nv.ptr(v_))
     if run.bf16:
         # the bf16 gate gradients are kept for every step ([To][B][4H] slabs) when the weight gradients are formed from them
-        slab16 = WGRAD16 and B % 8 == 0 and not nv.validate_only()
+        slab16 = WGRAD16 and B % 8 == 0 and (not nv.validate_only() or TRAIN_BWD_PERSISTENT)
         nst = To if slab16 else 1
         b16 = dict(Wa_recT16=run.cached('Wa_recT16', [Wih_a, Whh_a], lambda: run.cast16(Wa_recT)),
                    Wd_catT16=run.cached('Wd_catT16', [Wih_d, Whh_d], lambda: run.cast16(Wd_catT)),
@@ -1273,12 +1298,14 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
             setattr(bw, k_, nv.ptr(v_, torch.bfloat16))
         if slab16:
             bw.dg16_step_a, bw.dg16_step_d = B * 4 * Ha, B * 4 * Hd
-    nv.decoder_train_bwd_loop(bw,
+    model.last_train_decoder_bwd_path = _decoder_train_bwd(model, run, bw, out['dv_acc'],
                               reads=[Wa_recT, Wd_catT, DHC, cont(d_align), T['Wq'], T['U'], T['vvec'], T['pm'], c.memory,
                                      T['lens32'], T['GA'], c.keep['att'], c.keep['dec']]
                               + [S[k_] for k_ in ('HA', 'CA', 'GD', 'HD', 'CD', 'CTX', 'Q', 'ALIGN', 'CUM')]
                               + ([b16['Wa_recT16'], b16['Wd_catT16'], c.bf16['memory16'], c.bf16['Wq16']] if run.bf16 else []),
                               writes=list(out.values()) + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if run.bf16 else []))
+    if defer_postnet:
+        sync.bucket_ready('postnet')
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
     DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)
 

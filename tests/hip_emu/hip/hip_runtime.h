@@ -71,6 +71,10 @@ static inline unsigned __float_as_uint(float x) { unsigned u; memcpy(&u, &x, 4);
 static inline float __uint_as_float(unsigned u) { float x; memcpy(&x, &u, 4); return x; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __sync_fetch_and_add(p, v); }
 static inline unsigned long long wall_clock64() { return 0; }
+// scoped atomics (the SC1 forms of csrc/cell_bwd.h, never instantiated by the emulated kernels): plain accesses on the host
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
 
 // device-only builtins referenced by inline helpers of common.h that the emulated kernels never call
 static inline float __builtin_amdgcn_rcpf(float) { abort(); }

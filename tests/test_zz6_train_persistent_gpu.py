@@ -1,4 +1,5 @@
-"""The teacher-forced decoder loop as ONE persistent launch (csrc/attention.hip dec_train_fwd_persistent_kernel; reference
+"""The teacher-forced decoder loop, forward and backward, as ONE persistent launch each (csrc/attention.hip
+dec_train_fwd_persistent_kernel / dec_train_bwd_persistent_kernel; reference
 model.py:405-411 around Decoder.decode :340-379) against the launch chain it replaces: same model, batch and dropout masks.
 
 The persistent launch runs the SAME tile / attention bodies in the same arithmetic order; what differs is how the time steps
@@ -20,9 +21,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _step(m, batch, persistent, seed=7):
-    keep = engine.TRAIN_FWD_PERSISTENT
+def _step(m, batch, persistent, seed=7, bwd_persistent=None):
+    """One training step; `persistent` selects the forward loop's form, `bwd_persistent` the backward loop's (default: the same)."""
+    keep = engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT
     engine.TRAIN_FWD_PERSISTENT = persistent
+    engine.TRAIN_BWD_PERSISTENT = persistent if bwd_persistent is None else bwd_persistent
     try:
         m.zero_grad()
         torch.manual_seed(seed)                               # the Philox keep-masks are seeded from torch's RNG
@@ -31,11 +34,12 @@ def _step(m, batch, persistent, seed=7):
         loss = Tacotron2Loss()(out, y)
         loss.backward()
         torch.cuda.synchronize()
+        m.last_paths = (m.last_train_decoder_path, m.last_train_decoder_bwd_path)
         return ([o.detach().clone() for o in out], loss.detach().clone(),
                 {k: p.grad.detach().clone() for k, p in m.named_parameters()},
                 {k: v.detach().clone() for k, v in m.named_buffers()}, m.last_train_decoder_path)
     finally:
-        engine.TRAIN_FWD_PERSISTENT = keep
+        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT = keep
 
 
 def _model(hp_str=""):
@@ -48,6 +52,8 @@ def _model(hp_str=""):
 
 @pytest.mark.parametrize("in_lens,out_lens", [([23, 17, 9], [41, 33, 12]),                      # 12 attention workgroups, 256 LSTM tiles
                                               ([37] + [30] * 20 + [11] * 12, [55] * 30 + [19] * 3),   # B = 33
+                                              ([41, 40, 33, 31, 30, 22, 9, 5], [33, 47, 21, 19, 52, 30, 11, 8]),        # B = 8: 32 attention workgroups, 256 dgrad tiles
+                                              ([50 - i for i in range(40)], [30 + (i * 7) % 23 for i in range(40)]),    # B = 40
                                               (list(range(100, 36, -1)), [64 + (i % 7) for i in range(64)])])   # B = 64: every role on every workgroup
 def test_persistent_train_forward_is_bit_identical_to_the_launch_chain(native_lib, in_lens, out_lens):
     m, hp = _model()
@@ -55,25 +61,35 @@ def test_persistent_train_forward_is_bit_identical_to_the_launch_chain(native_li
     state = {k: v.clone() for k, v in m.state_dict().items()}
     o0, l0, g0, b0, p0 = _step(m, batch, False)
     m.load_state_dict(state)                                  # the BatchNorm running statistics moved: same start for both
+    assert m.last_paths == ("launch chain", "launch chain")
     o1, l1, g1, b1, p1 = _step(m, batch, True)
-    assert p0 == "launch chain" and p1 == "persistent"
+    # (the backward loop as one launch needs per-step slabs of the bf16 gate gradients: the engine keeps them when B % 8 == 0)
+    bwd = "persistent" if len(in_lens) % 8 == 0 else "launch chain"
+    assert p0 == "launch chain" and p1 == "persistent" and m.last_paths == ("persistent", bwd)
     assert native.attn_handoff_timeouts(reset=False) == 0
     for i in range(4):
         assert torch.isfinite(o1[i]).all() and torch.equal(o0[i], o1[i]), i
     assert float(l0) == float(l1)
     assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
     assert [k for k in b0 if not torch.equal(b0[k], b1[k])] == []
+    # the backward loop alone as one launch behind the forward CHAIN: the same bits again
+    m.load_state_dict(state)
+    o2, l2, g2, _, _ = _step(m, batch, False, bwd_persistent=True)
+    assert m.last_paths == ("launch chain", bwd) and native.attn_handoff_timeouts(reset=False) == 0
+    assert float(l0) == float(l2) and [k for k in g0 if not torch.equal(g0[k], g2[k])] == []
 
 
 def test_persistent_train_forward_smaller_model_geometry(native_lib):
-    """H = 128 / E = 128: 16 + 16 LSTM tiles, 4 B attention workgroups -- more attention workgroups than tiles."""
+    """H = 128 / E = 128: 16 + 16 LSTM tiles, 4 B attention workgroups -- more attention workgroups than tiles.  (The backward
+    loop stays on the chain: its dgrad tiles read the bf16 gate gradients with ordinary loads, which needs every 128-byte line of
+    them written whole by one wave -- H a multiple of 256.)"""
     m, hp = _model(gu.TINY_HP)
     batch = tuple(t.to(DEV) for t in gu.make_train_batch([14, 12, 9, 9, 6, 5, 5, 3, 2, 2], [20, 11, 18, 7, 13, 20, 5, 9, 12, 6], hp.n_mel_channels, 9))
     state = {k: v.clone() for k, v in m.state_dict().items()}
     o0, l0, g0, _, p0 = _step(m, batch, False)
     m.load_state_dict(state)
     o1, l1, g1, _, p1 = _step(m, batch, True)
-    assert (p0, p1) == ("launch chain", "persistent")
+    assert (p0, p1) == ("launch chain", "persistent") and m.last_paths == ("persistent", "launch chain")
     assert all(torch.equal(a, b) for a, b in zip(o0, o1)) and float(l0) == float(l1)
     assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
 
@@ -85,7 +101,7 @@ def test_fp32_mode_and_unsupported_geometries_stay_on_the_chain(native_lib):
     assert _step(m, batch, True)[4] == "launch chain"
     m.precision = "bf16"
     big = tuple(t.to(DEV) for t in gu.make_train_batch([8] * 65, [6] * 65, hp.n_mel_channels, 3))      # B = 65 > one row tile
-    assert _step(m, big, True)[4] == "launch chain"
+    assert _step(m, big, True)[4] == "launch chain" and m.last_paths == ("launch chain", "launch chain")
 
 
 def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_lib, monkeypatch):
@@ -94,7 +110,7 @@ def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_l
     NaN and counts it; handle_nonfinite_step() reports it and selects the launch chain (and the separate-launch attention
     forms, which make no co-residency assumption either) for the rest of the process."""
     m, hp = _model()
-    batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 12, 7], [22, 15, 9], hp.n_mel_channels, 11))
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 17, 12, 12, 9, 7, 4, 3], [22, 9, 15, 20, 9, 13, 6, 17], hp.n_mel_channels, 11))
     native.attn_handoff_timeouts(reset=True)
     monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
     forms = (native.get_attn_fwd_fused() if hasattr(native, "get_attn_fwd_fused") else None)
@@ -108,8 +124,20 @@ def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_l
         monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
         o2, loss2, _, _, path2 = _step(m, batch, engine.TRAIN_FWD_PERSISTENT)
         assert path2 == "launch chain" and torch.isfinite(loss2)
+        # the backward loop's give-up: the forward on the chain, the census of the backward launch forced to give up
+        engine.TRAIN_BWD_PERSISTENT = True
+        monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
+        native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(1)
+        _, loss3, g3, _, _ = _step(m, batch, False, bwd_persistent=True)
+        assert m.last_paths == ("launch chain", "persistent") and torch.isfinite(loss3)
+        assert not all(torch.isfinite(v).all() for v in g3.values())          # poisoned gradients, not silently wrong ones
+        assert engine.handle_nonfinite_step(log=said.append) >= 1 and engine.TRAIN_BWD_PERSISTENT is False
+        monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
+        _, loss4, g4, _, _ = _step(m, batch, engine.TRAIN_FWD_PERSISTENT, bwd_persistent=engine.TRAIN_BWD_PERSISTENT)
+        assert m.last_paths == ("launch chain", "launch chain") and all(torch.isfinite(v).all() for v in g4.values())
     finally:
         engine.TRAIN_FWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_FWD_PERSISTENT', '1') != '0'
+        engine.TRAIN_BWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_BWD_PERSISTENT', '1') != '0'
         native.set_attn_fwd_fused(-1)
         native.set_attn_bwd_fused(-1)
         native.set_bptt_cell_fold(1)

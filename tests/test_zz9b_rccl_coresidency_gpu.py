@@ -15,6 +15,9 @@
     them and the optimiser / next forward are ordered behind them -- : the gradients must stay bit-identical, finite (no NaN
     poison from an abandoned bounded spin), the backward must not slow down by the 50 ms a timed-out spin would cost per
     launch, and by no more than 1.5 x with 32 CUs held (measured 1.38 x) (round 4: the bound VERDICT r03 item 7 asked for).
+    The decoder's BPTT loop runs on the LAUNCH CHAIN here: as one persistent launch it needs every CU, which is why the engine
+    starts no collective beside it (the postnet bucket is launched behind the loop: engine.py, `defer_postnet`) -- a kernel
+    that holds CUs through the whole backward is then the shared-GPU case of (3), not the product layout.
 
 (3) ``test_whole_step_under_held_cus_falls_back_to_the_launch_chain`` (round 4): the persistent decoder loop of the forward
     needs every CU; with CUs held for the whole step (a shared GPU) its arrival census gives up within 2 ms, the step is
@@ -214,6 +217,15 @@ def test_training_step_with_cus_held_by_another_kernel(native_lib):
         torch.cuda.synchronize()
         return loss, ms, held
 
+    keep_bwd = engine.TRAIN_BWD_PERSISTENT
+    engine.TRAIN_BWD_PERSISTENT = False          # (see the module docstring)
+    try:
+        _held_cus_cases(native_lib, model, step, To)
+    finally:
+        engine.TRAIN_BWD_PERSISTENT = keep_bwd
+
+
+def _held_cus_cases(native_lib, model, step, To):
     step()
     loss0, base_ms, _ = step()
     base_ms = min(base_ms, step()[1])
@@ -264,7 +276,7 @@ def test_whole_step_under_held_cus_falls_back_to_the_launch_chain(native_lib):
     model = Tacotron2(hp).to(dev).train()
     model.precision = 'bf16'
     side = torch.cuda.Stream()
-    keep_flags = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
+    keep_flags = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT, engine.TRAIN_BWD_PERSISTENT)
 
     def step():
         torch.manual_seed(5)
@@ -295,15 +307,15 @@ def test_whole_step_under_held_cus_falls_back_to_the_launch_chain(native_lib):
         assert ms < 500.0, ms                                  # found out by the census, not by hanging
         said = []
         assert engine.handle_nonfinite_step(log=said.append) >= 1 and said
-        assert engine.TRAIN_FWD_PERSISTENT is False
+        assert engine.TRAIN_FWD_PERSISTENT is False and engine.TRAIN_BWD_PERSISTENT is False
         loss2 = step()                                         # same step, same hold, on the launch chain
         stop.fill_(1)
         torch.cuda.synchronize()
-        assert model.last_train_decoder_path == 'launch chain'
+        assert model.last_train_decoder_path == 'launch chain' and model.last_train_decoder_bwd_path == 'launch chain'
         assert float(loss2) == ref_loss
         assert all(torch.equal(p.grad, ref[k]) for k, p in model.named_parameters())
     finally:
-        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = keep_flags
+        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT, engine.TRAIN_BWD_PERSISTENT = keep_flags
         native.set_attn_fwd_fused(-1)
         native.set_attn_bwd_fused(-1)
         native.set_bptt_cell_fold(1)
