@@ -540,6 +540,7 @@ def main():
         attn_bytes = es * 640.0 * ti_sum
         cell_bytes = B * (Ha + Hd) * (12 * 4.0 + 1.0 + (8.0 if es == 2.0 else 0.0)) if folded else 0.0
         persistent_fwd = getattr(model, "last_train_decoder_path", "") == "persistent"
+        persistent_bwd = getattr(model, "last_train_decoder_bwd_path", "") == "persistent"      # opt-in: T2AMD_TRAIN_BWD_PERSISTENT=1
         lstm_pair_bytes = lstm_bytes(Kd, Hd, False) + lstm_bytes(Ka, Ha, True)
         attn_fwd_bytes = es * 640.0 * ti_sum + es * A * Ha
         specs = [
@@ -550,6 +551,11 @@ def main():
              "flag + data hand-offs between them; 256 co-resident workgroups",
              To * (lstm_pair_bytes + attn_fwd_bytes),
              To * (2.0 * B * (4 * Hd * Kd + 4 * Ha * Ka) + 2.0 * (B * A * Ha + ti_sum * (A * 62 + A + E)))),
+            ("decoder_backward_persistent", 8, "dec_train_bwd_persistent_kernel",
+             "the WHOLE BPTT loop behind its first two launches in one launch: per time step the attention backward with the two "
+             "folded LSTM cell backwards, then the dgrad pair (split-K %d, bf16 MFMA), flag + data hand-offs between them" % ns,
+             To * (attn_bytes + cell_bytes + es * (4 * Hd * Kd + 4 * Ha * Ka) + es * B * (4 * Hd + 4 * Ha) + 4.0 * ns * B * (Kd + Ka)),
+             To * (2.0 * (2 * B * A * Ha + ti_sum * (3 * A * 62 + 2 * A + 2 * E)) + 2.0 * B * (4 * Hd * Kd + 4 * Ha * Ka))),
             ("lstm_pair", 3 if fused else 2,
              ("skinny_wide_kernel<true,3>" if es == 2.0 else "skinny_gemm_kernel<true,3,false>") if fused else "skinny_gemm_kernel<true,2>",
              "decoder LSTM of step t-1 (64x2560x4096) + attention LSTM of step t (64x1536x4096), %s + fused cells" % mm
@@ -587,6 +593,10 @@ def main():
                 continue
             if persistent_fwd and key in ("lstm_pair", "attention_forward"):
                 continue                           # their bodies run inside the persistent launch: no launches of their own
+            if key == "decoder_backward_persistent" and not persistent_bwd:
+                continue
+            if persistent_bwd and key in ("attention_backward", "dgrad_pair"):
+                continue
             avg_s, cnt = timed_role(role)
             if cnt == 0:
                 continue
@@ -597,7 +607,7 @@ def main():
                           "avg_launch_us": avg_s * 1e6, "launches": cnt, "total_ms_per_step": avg_s * cnt * 1e3,
                           # one launch of the persistent loop covers every time step: its share of a time step beside the
                           # per-step launches of the backward loop
-                          "us_per_time_step": avg_s * 1e6 / (To if key == "decoder_forward_persistent" else 1),
+                          "us_per_time_step": avg_s * 1e6 / (To if key in ("decoder_forward_persistent", "decoder_backward_persistent") else 1),
                           "algorithmic_bytes_per_launch": nbytes,
                           "mfma": {"achieved_tflops": flops / avg_s / 1e12, "peak_tflops": peak_tf,
                                    "frac": flops / avg_s / 1e12 / peak_tf}}
@@ -618,7 +628,8 @@ def main():
             "algorithmic_bytes_per_padded_time_step": per_step, "time_steps": To, "ms_per_step": ms_step,
             "achieved": per_step * To / (ms_step / 1e3) / 1e9, "unit": "GB/s",
             "frac": per_step * To / (ms_step / 1e3) / 1e9 / 8000.0,
-            "dependent_launches_per_time_step": (0 if persistent_fwd else 2) + (2 if folded else 3),
+            "dependent_launches_per_time_step": (0 if persistent_fwd else 2) + (0 if persistent_bwd else (2 if folded else 3)),
+            "backward_loop": "one persistent launch behind the loop's first two" if persistent_bwd else "two dependent launches per time step",
             "forward_loop": "one persistent launch for all time steps" if persistent_fwd else "two dependent launches per time step",
             "note": "SURVEY 8d: 2 x (step weights + encoder memory) + saved activations per padded time step; encoder, "
                     "postnet, dense weight-gradient GEMMs and the optimiser are inside ms_per_step but not in the bytes"}

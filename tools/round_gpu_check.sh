@@ -9,10 +9,10 @@ tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -q --durations=6 > $out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q --durations=6 > $out/${tag}_pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $out/${tag}_pytest_gpu.log
 tail -12 $out/${tag}_pytest_gpu.log
 bash tools/pmc_pass.sh $tag | tail -4                     # first: the bench line below then carries this build's traffic
-python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?"; tail -c 1200 $out/${tag}_bench.json; tail -2 $out/${tag}_bench.err
+timeout 900 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err; echo "bench rc=$?"; tail -c 1200 $out/${tag}_bench.json; tail -2 $out/${tag}_bench.err
 # two ranks over RCCL whenever the box shows two GPUs (every box of rounds 1-4 showed one)
 ngpu=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null)
 if [ "${ngpu:-1}" -ge 2 ]; then
