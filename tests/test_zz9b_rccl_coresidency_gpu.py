@@ -48,10 +48,12 @@ def _free_port():
     return port
 
 
-def _rccl_worker(port, precision, q):
+def _rccl_worker(port, precision, q, bwd_persistent=False):
     import faulthandler
     os.makedirs(OUT, exist_ok=True)
-    log = open(os.path.join(OUT, "rccl_world1_%s.log" % precision), "w")
+    if bwd_persistent:              # the opt-in persistent BPTT launch: the postnet bucket is then launched BEHIND the loop (engine.py)
+        os.environ["T2AMD_TRAIN_BWD_PERSISTENT"] = "1"
+    log = open(os.path.join(OUT, "rccl_world1_%s%s.log" % (precision, "_bwdp" if bwd_persistent else "")), "w")
     faulthandler.enable(log)
     faulthandler.dump_traceback_later(240, exit=True, file=log)
     import torch.distributed as dist
@@ -124,7 +126,10 @@ def _rccl_worker(port, precision, q):
         views = all(any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + 4 * f.numel() for f in sync.flat.values())
                     for p in dp_model.parameters())
         mean_loss = float(reduce_tensor(torch.tensor(got[1][0], device=dev), 1))
-        q.put(dict(ok=not bad and views and sync.fresh_allocations == 1 and mean_loss == got[1][0], bad=bad[:10],
+        bwd_path = getattr(dp_model, "last_train_decoder_bwd_path", None)
+        path_ok = (bwd_path == "persistent") == bool(bwd_persistent)
+        q.put(dict(ok=not bad and views and sync.fresh_allocations == 1 and mean_loss == got[1][0] and path_ok, bad=bad[:10],
+                   decoder_bptt=bwd_path,
                    p_grad_is_a_bucket_view=views, bucket_sets_allocated=sync.fresh_allocations,
                    reduce_op=str(sync.op), divide_pass=sync.divide, seconds_two_steps=dt,
                    bucket_bytes={b: 4 * n for b, n in sync.sizes.items()}, backend=dist.get_backend(), To=To))
@@ -138,12 +143,16 @@ def _rccl_worker(port, precision, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "bf16+persistent BPTT"])
 def test_rccl_world1_bucket_allreduce_is_ordered_and_exact(native_lib, precision):
+    """(third case: the opt-in persistent BPTT launch -- it fills the chip, so the engine launches the postnet bucket behind the
+    loop instead of in front of it; same bar: every gradient and one optimiser step bit-identical to the run without an exchange)"""
     import queue
+    bwdp = precision.endswith("persistent BPTT")
+    precision = precision.split("+")[0]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), precision, q))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), precision, q, bwdp))
     p.start()
     try:
         res = q.get(timeout=300)
@@ -153,7 +162,7 @@ def test_rccl_world1_bucket_allreduce_is_ordered_and_exact(native_lib, precision
     if p.is_alive():
         p.kill()
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "parity_rccl_world1_%s.json" % precision), "w") as f:
+    with open(os.path.join(OUT, "parity_rccl_world1_%s%s.json" % (precision, "_bwdp" if bwdp else "")), "w") as f:
         json.dump(res, f, indent=1)
     assert res.get("ok"), res
 
