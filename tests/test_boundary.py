@@ -238,3 +238,48 @@ def test_persistent_backward_loop_host_staging_validate_only(native_lib):
     finally:
         engine.TRAIN_BWD_PERSISTENT = keep
         native.set_validate_only(False)
+
+
+def test_bucket_launch_order_around_the_persistent_backward_loop(native_lib, monkeypatch):
+    """Data parallel (reference distributed.py:126-173): the engine launches the postnet bucket's all-reduce in front of the
+    decoder BPTT (it travels while the loop runs) -- unless the loop is the ONE persistent launch, which needs every CU to itself:
+    then nothing may be enqueued to run beside it and the bucket goes out BEHIND the loop.  Host logic only (validate-only)."""
+    from tacotron2_amd import engine
+    native.set_validate_only(True)
+    keep = engine.TRAIN_BWD_PERSISTENT
+    events = []
+
+    class FakeSync(object):
+        def __init__(self, model):
+            self.shapes = {k: tuple(p.shape) for k, p in model.named_parameters()}
+
+        def start(self, device=None, dtype=torch.float32):
+            events.append("start")
+
+        def out(self, name, shape):
+            return torch.zeros(*shape)
+
+        def bucket_ready(self, bucket, grads=None):
+            events.append("bucket:" + bucket)
+
+        def finish(self):
+            events.append("finish")
+
+    for name in ("decoder_train_bwd_persistent", "decoder_train_bwd_loop"):
+        real = getattr(native, name)
+        monkeypatch.setattr(native, name, (lambda real, name: lambda *a, **k: (events.append("bptt:" + name), real(*a, **k))[1])(real, name))
+    try:
+        for persistent, want in ((True, ["start", "bptt:decoder_train_bwd_persistent", "bucket:postnet", "bucket:decoder", "bucket:encoder", "finish"]),
+                                 (False, ["start", "bucket:postnet", "bptt:decoder_train_bwd_loop", "bucket:decoder", "bucket:encoder", "finish"])):
+            engine.TRAIN_BWD_PERSISTENT = persistent
+            del events[:]
+            m = Tacotron2(create_hparams("max_decoder_steps=6"))
+            m.precision = "bf16"
+            m._grad_sync = FakeSync(m)
+            x, y = m.parse_batch(gu.make_train_batch([17, 11, 9, 9, 8, 5, 3, 2], [30, 23, 12, 25, 7, 19, 30, 4], 80, 1))
+            out = m(x)
+            (out[0].sum() + out[1].sum() + out[2].sum()).backward()
+            assert events == want, events
+    finally:
+        engine.TRAIN_BWD_PERSISTENT = keep
+        native.set_validate_only(False)
