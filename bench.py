@@ -342,7 +342,13 @@ def compact_line(out):
         o["timed_loop"] = {"step_ms_min": min(ps), "step_ms_max": max(ps), "device_allocs": tl["device_allocs"],
                            "allocator_calls_per_step": _r(tl["allocator_calls_per_step"], 1),
                            "full_gc_collections_ms": tl["full_gc_collections_ms"], "gc_frozen": tl["gc_frozen"],
-                           "handoff_give_ups": tl.get("handoff_give_ups")}
+                           "handoff_give_ups": tl.get("handoff_give_ups"), "device_allocs_ok": tl.get("device_allocs_ok"),
+                           "engine": tl.get("engine")}
+        if "retimed_after_device_alloc" in tl:
+            o["timed_loop"]["retimed_after_device_alloc"] = {k: _r(v, 2) for k, v in tl["retimed_after_device_alloc"].items()
+                                                             if k != "per_step_ms"}
+    if "dp" in out:
+        o["dp"] = out["dp"]
     c = out.get("cpu_baseline")
     if c:
         o["cpu_baseline"] = {"value": _r(c["value"], 1), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
@@ -442,14 +448,25 @@ def main():
             optimizer.step()
         return loss
 
+    from tacotron2_amd import engine as _engine
+    # What a training loop that owns its process and knows its dataset does once, before its first step (no work of a step is
+    # skipped by either): the allocator's pool is shown the largest outputs this data can produce (SURVEY 8d's generator: Ti <=
+    # 187, To <= 870), so that no later batch sends it to hipMalloc in the middle of a step (SURVEY 8b Ownership) ...
+    _engine.reserve_outputs(dev, args.batch_size, 187, 870, hp.n_mel_channels, copies=2)
     for i in range(args.warmup):
         step(batches[i])
+        if i == 0:
+            # ... and after the first complete step everything alive is collected once and frozen out of later garbage collections
+            # (engine.settle_gc; ADVICE r04: the engine no longer does this implicitly inside a forward pass)
+            torch.cuda.synchronize()
+            _engine.settle_gc(quiet=True)
+    if args.warmup == 0:
+        _engine.settle_gc(quiet=True)
     torch.cuda.synchronize()
     # A persistent launch that found the GPU shared (its workgroups not co-resident: arrival census, bounded hand-off spins) has
     # poisoned that warm-up step and counted it.  What train.py does on a non-finite step happens here BEFORE the timed loop: say
     # so, select the launch chains (bit-identical results) and warm up again -- the timed loop then measures what a training run
     # on this GPU would settle into, not a stream of skipped steps.
-    from tacotron2_amd import engine as _engine
     give_ups = {"warmup": 0, "timed": 0}
     if not native.validate_only():
         give_ups["warmup"] = int(_engine.handle_nonfinite_step(lambda m: print(m, file=sys.stderr, flush=True)))
@@ -463,40 +480,68 @@ def main():
     # what the timed loop is audited by: one event per step on the launch stream (never waited for
     # inside the loop), the caching allocator's device-allocation counter, and the collector's full collections
     import gc
-    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    gc_full = []
 
-    def _gc_cb(phase, info, _t=[0.0]):
-        if phase == "start":
-            _t[0] = time.perf_counter()
-        elif info["generation"] == 2:
-            gc_full.append(round(1e3 * (time.perf_counter() - _t[0]), 2))
-    gc.callbacks.append(_gc_cb)
-    mem0 = torch.cuda.memory_stats(dev)
-    step_events[0].record()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_iter):
-        loss = step(batches[i])
-        step_events[i - args.warmup + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.callbacks.remove(_gc_cb)
-    mem1 = torch.cuda.memory_stats(dev)
-    if not native.validate_only():
-        give_ups["timed"] = int(native.attn_handoff_timeouts(reset=False)) + int(native.encoder_handoff_timeouts(reset=False))
-    timed_loop = {
-        "handoff_give_ups": give_ups,
-        "per_step_ms": [round(step_events[j].elapsed_time(step_events[j + 1]), 3) for j in range(args.steps)],
-        "device_allocs": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
-        "device_frees": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0),
-        "alloc_retries": mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0),
-        "reserved_GB": round(mem1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2),
-        "allocator_calls_per_step": (mem1.get("allocation.all.allocated", 0) - mem0.get("allocation.all.allocated", 0)) / max(args.steps, 1),
-        "full_gc_collections_ms": gc_full, "gc_frozen": bool(_engine._gc_state["frozen"]),
-        "arena": _engine.arena_stats()}
+    def timed_run():
+        step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        gc_full = []
+
+        def _gc_cb(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            elif info["generation"] == 2:
+                gc_full.append(round(1e3 * (time.perf_counter() - _t[0]), 2))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        gc.callbacks.append(_gc_cb)
+        mem0 = torch.cuda.memory_stats(dev)
+        step_events[0].record()
+        t0 = time.perf_counter()
+        loss = None
+        for i in range(args.warmup, n_iter):
+            loss = step(batches[i])
+            step_events[i - args.warmup + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        gc.callbacks.remove(_gc_cb)
+        mem1 = torch.cuda.memory_stats(dev)
+        if not native.validate_only():
+            give_ups["timed"] = int(native.attn_handoff_timeouts(reset=False)) + int(native.encoder_handoff_timeouts(reset=False))
+        audit = {
+            "handoff_give_ups": dict(give_ups),
+            "per_step_ms": [round(step_events[j].elapsed_time(step_events[j + 1]), 3) for j in range(args.steps)],
+            "device_allocs": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
+            "device_frees": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0),
+            "alloc_retries": mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0),
+            "reserved_GB": round(mem1.get("reserved_bytes.all.current", 0) / 2 ** 30, 2),
+            "allocator_calls_per_step": (mem1.get("allocation.all.allocated", 0) - mem0.get("allocation.all.allocated", 0)) / max(args.steps, 1),
+            "full_gc_collections_ms": gc_full, "gc_frozen": bool(_engine._gc_state["frozen"]),
+            "arena": _engine.arena_stats(), "engine": _engine.give_up_counters()}
+        return elapsed, loss, audit
+
+    # SURVEY 8b Ownership: nothing on the hot path reaches hipMalloc.  The timed loop ASSERTS it: a window
+    # that saw a device allocation is not reported -- it is timed again (the pool has the block now) and the first window is kept
+    # beside the result; a second window with an allocation is a defect of the engine and ends in a non-zero exit code after the
+    # line is printed.  (Every rank takes the same decision: the count is summed over the ranks.)
+    elapsed, loss, timed_loop = timed_run()
+
+    def _allocs_everywhere(n):
+        if world == 1:
+            return n
+        t_ = torch.tensor([float(n)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_, op=dist.ReduceOp.SUM)
+        return int(t_.item())
+    device_allocs_fail = False
+    if _allocs_everywhere(timed_loop["device_allocs"]) > 0:
+        first = {k: timed_loop[k] for k in ("device_allocs", "per_step_ms")}
+        first["ms_per_step"] = 1e3 * elapsed / args.steps
+        elapsed, loss, timed_loop = timed_run()
+        timed_loop["retimed_after_device_alloc"] = first
+        device_allocs_fail = _allocs_everywhere(timed_loop["device_allocs"]) > 0
+    timed_loop["device_allocs_ok"] = not device_allocs_fail
     timed_frames = sum(frames[args.warmup:])
     per_rank = None
     if world > 1:
@@ -514,6 +559,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed, timed_frames = tmax[0].item(), t[1].item()
     final_loss = float(loss.item())
+    # What a SCALE record needs to be checkable from the line alone: the backend that ran, the world it saw,
+    # one device identity per rank (N ranks on N DISTINCT GPUs), the decoder-loop forms every rank ended on and every rank's
+    # give-up / demotion counters -- "RCCL saw N ranks on N GPUs and nobody fell back to the chain" can be read off it.
+    dp_record = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        core = model
+        mine = {"rank": rank, "device_index": dev_index, "uuid": str(getattr(props, "uuid", "") or ""), "name": props.name,
+                "decoder_fwd": getattr(core, "last_train_decoder_path", None),
+                "decoder_bwd": getattr(core, "last_train_decoder_bwd_path", None),
+                "give_ups": dict(give_ups), "engine": _engine.give_up_counters()}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        uu = [e["uuid"] for e in every]
+        dp_record = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "distinct_devices": len(set(uu)) if all(u.strip("0-") for u in uu) else None,
+                     "all_persistent_fwd": all(e["decoder_fwd"] == "persistent" for e in every),
+                     "ranks": every}
 
     # ---- roofline: the four kernels of a decoder time step, each timed live in its own extra untimed step ------
     roofline = None
@@ -726,6 +789,8 @@ def main():
         }
         out["padded_frames_per_s"] = sum(b[2].shape[2] * args.batch_size for b in batches[args.warmup:]) \
             * args.gpus / elapsed if world == 1 else None
+        if dp_record:
+            out["dp"] = dp_record
         if per_rank:
             out["ranks"] = per_rank
             out["padded_frames_per_s"] = args.batch_size * sum(per_rank["padded_time_steps"]) / elapsed
@@ -770,6 +835,10 @@ def main():
         print(json.dumps(compact_line(out)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if device_allocs_fail:
+        print("bench.py: the timed loop reached the device allocator in two consecutive windows (SURVEY 8b Ownership: nothing on "
+              "the hot path calls hipMalloc): %r" % (timed_loop,), file=sys.stderr, flush=True)
+        raise SystemExit(4)
     if parity is not None and not parity.get("ok", False):
         print("bench.py: the engine's loss does not match the oracle's on the cpu_baseline sub-batch: %r" % (parity,),
               file=sys.stderr, flush=True)

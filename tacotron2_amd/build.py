@@ -32,7 +32,10 @@ def source_sha1():
     (profiles/pmc_traffic.json) and printed in the bench line: binary, counters and sources are provably the same tree."""
     import hashlib
     h = hashlib.sha1()
-    files = sorted(glob.glob(os.path.join(HERE, "csrc", "*")))
+    # exactly what is compiled (ADVICE r04): the .hip sources, their headers and torch_ops.cpp -- not whatever else lies in
+    # csrc/ (an editor backup or a sub-directory used to make import fail with a misleading "built from other sources")
+    files = sorted(f for f in glob.glob(os.path.join(HERE, "csrc", "*"))
+                   if os.path.isfile(f) and f.endswith((".hip", ".h", ".cpp")))
     files.append(os.path.join(HERE, "..", "include", "tacotron2_amd.h"))
     for f in files:
         h.update(os.path.basename(f).encode())

@@ -370,22 +370,30 @@ class _Arena(object):
             self.growths += 1
 
     def release(self):
-        """End of a lease.  A step that needed more than one chunk leaves ONE chunk with headroom for the next."""
+        """End of a lease.  A step that needed more than one chunk leaves ONE chunk with headroom for the next -- made by
+        `consolidate` at the NEXT acquire (`backward`'s finally block calls this while the dying context still
+        holds views into every old chunk, so nothing could go back to the pool before the new request: a transient 2.25 x)."""
         self.peak = max(self.peak, self.used)
+        self.ci, self.off, self.used = 0, 0, 0
+        self.busy = False
+
+    def consolidate(self):
+        """Called with the lock held when the arena is leased again: the previous lease's context is dead by now (or about
+        to be: its views keep their chunks alive on their own), so the old chunks go back to torch's pool first."""
         if len(self.chunks) > 1:
             want = int(self.peak * ARENA_HEADROOM)
             want = (want + (1 << 28) - 1) >> 28 << 28                      # whole 256 MiB
             self.chunks = []                                               # back to torch's pool before the new request
             self.chunks.append(torch.empty(want, dtype=torch.uint8, device=self.dev))
             self.growths += 1
-        self.ci, self.off, self.used = 0, 0, 0
-        self.busy = False
 
 
 import threading
 
 _ARENAS = {}                      # (device, stream id) -> [arena, ...]; more than one only while steps overlap in time
-_ARENA_LOCK = threading.Lock()    # backward runs on autograd's device thread
+# backward runs on autograd's device thread.  Re-entrant (ADVICE r04): regions that hold it allocate container objects, the
+# cyclic collector may then finalise an unreachable _Ctx on the same thread, and its __del__ releases its lease through here.
+_ARENA_LOCK = threading.RLock()
 
 
 def _arena_key(device):
@@ -409,6 +417,7 @@ def _arena_acquire(device):
             pool.append(a)
         a.busy = True
         a.leases += 1
+        a.consolidate()
         return a
 
 
@@ -434,6 +443,20 @@ def release_arenas():
             _ARENAS[k] = [a for a in _ARENAS[k] if a.busy]
             if not _ARENAS[k]:
                 del _ARENAS[k]
+
+
+def reserve_outputs(device, B, Ti_max, To_max, n_mel=80, copies=2):
+    """What outlives a step -- the four outputs of `Tacotron2.forward` (mel, mel_postnet, gate, alignments) -- is a fresh
+    ``torch.empty`` every step (SURVEY 8b Ownership: outputs freshly allocated), and the first batch with a new largest
+    (To, Ti) sends the caching allocator to ``hipMalloc`` in the middle of a step.  A loop that knows its dataset's longest
+    text and clip calls this ONCE: ``copies`` sets of maximum-size outputs are allocated and handed straight back to torch's
+    pool, which then serves every later request of that size or smaller from cache -- no device allocation on the hot path
+    from the second step on (bench.py: `timed_loop.device_allocs`).  Returns the bytes reserved."""
+    shapes = [(B, n_mel, To_max), (B, n_mel, To_max), (B, To_max), (B, To_max, Ti_max)]
+    held = [torch.empty(s, dtype=torch.float32, device=device) for _ in range(int(copies)) for s in shapes]
+    n = sum(t.numel() * 4 for t in held)
+    del held
+    return n
 
 
 class _Run(object):
@@ -472,6 +495,8 @@ class _Run(object):
         n = 1
         for v in shape:
             n *= int(v)
+        if n == 0:                       # (a 1-byte arena view cannot be viewed as a wider dtype; torch.empty takes empty shapes)
+            return torch.empty(shape, dtype=dtype, device=self.dev)
         return self.arena.alloc(n * esize).view(dtype).view(*shape)
 
     def out_empty(self, *shape):
@@ -757,17 +782,40 @@ def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None, 
 TRAIN_FWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_FWD_PERSISTENT', '1') != '0'
 
 
-def _decoder_train_fwd(model, run, d, poison, reads, writes):
-    """reference model.py:405-411.  The persistent launch when it is selected and the geometry fits this device; the status is
-    not read back (no host sync in the training loop): a give-up -- its workgroups were not co-resident within 50 ms: a shared
-    GPU -- turns ``poison[0]`` into NaN, the step goes non-finite and handle_nonfinite_step() switches back to the chain."""
+# Give-ups of the persistent decoder loop seen by forwards that carry no poison word (eval mode: validation batches) -- counted
+# here because nothing turns them into a NaN that a loss check would find; `give_up_counters()` reports them.
+EVAL_GIVE_UPS = [0]
+
+
+def _decoder_train_fwd(model, run, d, poison, reads, writes, regen_ga=None):
+    """reference model.py:405-411.  The persistent launch when it is selected and the geometry fits this device.  TRAINING
+    (``poison`` given): the status is not read back (no host sync in the training loop): a give-up -- its workgroups were not
+    co-resident within 50 ms: a shared GPU -- turns ``poison[0]`` into NaN, the step goes non-finite and
+    handle_nonfinite_step() switches back to the chain.  EVAL (``poison`` None: validation, reference train.py:133): nothing
+    downstream would notice a NaN-free half-written slab, so the status IS read back (one sync per validation batch, as
+    `_encoder_lstm_fwd` does): a give-up is counted, reported, the hoisted input projection the kernel had begun to overwrite is
+    recomputed (``regen_ga``) and the launch chain runs -- with an exponential back-off before the next attempt."""
     if TRAIN_FWD_PERSISTENT and run.bf16 and not nv.validate_only():
         cus = torch.cuda.get_device_properties(run.dev).multi_processor_count
-        if nv.decoder_train_fwd_persistent_supported(d, cus) is None:
+        if poison is None and getattr(model, '_dtp_eval_backoff', 0) > 0:
+            model._dtp_eval_backoff -= 1
+        elif nv.decoder_train_fwd_persistent_supported(d, cus) is None:
             flags = run.empty_i32(nv.decoder_train_fwd_persistent_flag_words(d.B, d.Ha))
             status = run.empty_i32(1)
             nv.decoder_train_fwd_persistent(d, flags, status, poison)
-            return 'persistent'
+            if poison is not None:
+                return 'persistent'
+            if int(status.item()) == 0:
+                model._dtp_eval_timeouts = 0
+                return 'persistent'
+            import sys
+            EVAL_GIVE_UPS[0] += 1
+            print("tacotron2_amd: the persistent decoder loop gave up in an eval-mode forward (its workgroups were not "
+                  "co-resident -- is the GPU shared?); recomputing this batch on the launch chain", file=sys.stderr, flush=True)
+            model._dtp_eval_timeouts = getattr(model, '_dtp_eval_timeouts', 0) + 1
+            model._dtp_eval_backoff = min(256, 2 << model._dtp_eval_timeouts)
+            if regen_ga is not None:
+                regen_ga()               # GA is rewritten in place by the loop (pre-activations -> activated gates)
     nv.decoder_train_fwd_loop(d, reads=reads, writes=writes)
     return 'launch chain'
 
@@ -891,14 +939,74 @@ def _guard_weights(model, run, P):
         cache['__guard__'] = keep
 
 
+# Re-promotion: a give-up demotes the process to the launch chains / separate-launch forms -- correct, but
+# a single foreign kernel on the GPU should not cost a multi-day run its faster forms for good.  After REPROMOTE_AFTER clean
+# training steps the forms that were selected before the demotion are selected again; if they give up again the interval
+# doubles (up to 64 x).  0 = never re-promote.  T2AMD_REPROMOTE_AFTER sets it.
+TRAIN_FWD_REPROMOTE_AFTER = int(os.environ.get('T2AMD_REPROMOTE_AFTER', '200'))
+_DEMOTION = dict(active=False, count=0, clean=0, need=0, saved=None, repromotions=0)
+
+
+def _demote(saved_now):
+    d = _DEMOTION
+    if not d['active']:
+        d['saved'] = saved_now
+    d['active'] = True
+    d['count'] += 1
+    d['clean'] = 0
+    d['need'] = TRAIN_FWD_REPROMOTE_AFTER * (1 << min(d['count'] - 1, 6))
+
+
+def _note_training_step(log=None):
+    """One training forward is about to run.  Counts clean steps while demoted and restores the demoted forms when due."""
+    d = _DEMOTION
+    if not d['active'] or TRAIN_FWD_REPROMOTE_AFTER <= 0:
+        return False
+    d['clean'] += 1
+    if d['clean'] <= d['need']:
+        return False
+    global TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT, ENCODER_BATCH_PERSISTENT
+    sv = d['saved']
+    TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT, ENCODER_BATCH_PERSISTENT = sv['fwd'], sv['bwd'], sv['enc']
+    nv.set_attn_fwd_fused(sv['attn_fwd_fused'])
+    nv.set_attn_bwd_fused(sv['attn_bwd_fused'])
+    nv.set_bptt_cell_fold(sv['cell_fold'])
+    d['active'], d['saved'] = False, None
+    d['repromotions'] += 1
+    msg = ("tacotron2_amd: %d clean training steps since the last abandoned hand-off: the one-launch / persistent forms are "
+           "selected again (a further give-up doubles the interval)" % (d['clean'] - 1))
+    if log is not None:
+        log(msg)
+    else:
+        import sys
+        print(msg, file=sys.stderr, flush=True)
+    return True
+
+
+def give_up_counters():
+    """What a bench line / run log needs to show that nobody fell back silently."""
+    d = _DEMOTION
+    return dict(demotions=d['count'], demoted_now=bool(d['active']), repromotions=d['repromotions'],
+                eval_give_ups=EVAL_GIVE_UPS[0])
+
+
 def handle_nonfinite_step(log=None):
     """Call when a training step produced a non-finite loss / gradient norm.  If the reason is an ABANDONED in-launch
-    hand-off of the one-launch attention forms (their four workgroups per utterance were not co-resident within 50 ms: a
-    shared or partitioned GPU; the kernels then poison the step with NaN rather than use half-exchanged data), say so
-    and select the separate-launch forms for the rest of the process -- bit-identical results, no co-residency
-    assumption.  Returns the number of abandoned hand-offs (0: the non-finite values have another cause)."""
-    global ENCODER_BATCH_PERSISTENT
+    hand-off -- of the one-launch attention forms (their four workgroups per utterance were not co-resident within 50 ms: a
+    shared or partitioned GPU), of the persistent decoder loops (TRAIN_FWD_PERSISTENT / TRAIN_BWD_PERSISTENT: arrival census or
+    a bounded spin) or of the persistent encoder launches; the kernels then poison the step with NaN rather than use
+    half-exchanged data -- say so and select the launch chains and the separate-launch attention forms: this CLEARS
+    ``TRAIN_FWD_PERSISTENT`` / ``TRAIN_BWD_PERSISTENT`` (and ``ENCODER_BATCH_PERSISTENT`` for an encoder give-up) and calls
+    ``set_attn_fwd_fused(0)`` / ``set_attn_bwd_fused(0)`` / ``set_bptt_cell_fold(0)`` -- bit-identical results, no co-residency
+    assumption -- until `_note_training_step` re-promotes them after TRAIN_FWD_REPROMOTE_AFTER clean steps.  Returns the number
+    of abandoned hand-offs (0: the non-finite values have another cause)."""
+    global ENCODER_BATCH_PERSISTENT, TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT
     ne = nv.encoder_handoff_timeouts(reset=True)
+    n = nv.attn_handoff_timeouts(reset=True)
+    if ne > 0 or n > 0:
+        _demote(dict(fwd=TRAIN_FWD_PERSISTENT, bwd=TRAIN_BWD_PERSISTENT, enc=ENCODER_BATCH_PERSISTENT,
+                     attn_fwd_fused=nv.get_attn_fwd_fused(), attn_bwd_fused=nv.get_attn_bwd_fused(),
+                     cell_fold=nv.get_bptt_cell_fold()))
     if ne > 0:
         ENCODER_BATCH_PERSISTENT = False
         msg = ("tacotron2_amd: the persistent encoder launch gave up %d time(s) (its workgroups were not co-resident within "
@@ -909,9 +1017,7 @@ def handle_nonfinite_step(log=None):
         else:
             import sys
             print(msg, file=sys.stderr, flush=True)
-    n = nv.attn_handoff_timeouts(reset=True)
     if n > 0:
-        global TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT
         TRAIN_FWD_PERSISTENT = False
         TRAIN_BWD_PERSISTENT = False
         nv.set_attn_fwd_fused(0)
@@ -920,6 +1026,8 @@ def handle_nonfinite_step(log=None):
         msg = ("tacotron2_amd: %d in-launch attention hand-off(s) timed out (the workgroups of an utterance were not "
                "co-resident within 50 ms -- is the GPU shared or partitioned?); that step was poisoned with NaN and is "
                "skipped; the separate-launch forms are selected from here on" % n)
+        if TRAIN_FWD_REPROMOTE_AFTER > 0:
+            msg += " (and re-selected after %d clean steps)" % _DEMOTION['need']
         if log is not None:
             log(msg)
         else:
@@ -1109,12 +1217,15 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     vvec = P['decoder.attention_layer.v.linear_layer.weight'].view(-1)
 
     GA = run.empty(To, B, 4 * Ha)
-    if run.bf16 and WGRAD16 and Pd % 64 == 0 and (Pd + E) % 8 == 0 and not nv.validate_only():
-        # bf16 mode: the hoisted input projection of the attention LSTM on the bf16-resident product (csrc/gemm16.hip)
-        Wih_a16 = run.cached('Wih_a16', [Wih_a], lambda: run.cast16(Wih_a))
-        nv.gemm16_tn(GA.view(rowsD, 4 * Ha), run.cast16(p2), Wih_a16[:, :Pd], bias=bias_a)
-    else:
-        _fg(run, GA.view(rowsD, 4 * Ha), p2, Wih_a[:, :Pd], bias=bias_a)
+
+    def project_ga():
+        if run.bf16 and WGRAD16 and Pd % 64 == 0 and (Pd + E) % 8 == 0 and not nv.validate_only():
+            # bf16 mode: the hoisted input projection of the attention LSTM on the bf16-resident product (csrc/gemm16.hip)
+            Wih_a16 = run.cached('Wih_a16', [Wih_a], lambda: run.cast16(Wih_a))
+            nv.gemm16_tn(GA.view(rowsD, 4 * Ha), run.cast16(p2), Wih_a16[:, :Pd], bias=bias_a)
+        else:
+            _fg(run, GA.view(rowsD, 4 * Ha), p2, Wih_a[:, :Pd], bias=bias_a)
+    project_ga()
 
     att_p, dec_p = hp.p_attention_dropout, hp.p_decoder_dropout
     keep_att = ms.get('att', None, (To, B, Ha), att_p) if training else None
@@ -1151,7 +1262,8 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         model, run, d, poison=slabs['CTX'] if training else None,                         # model.py:405-411
         reads=[Wa_rec, Wd_cat, bias_d, Wq, U, vvec, memory, pm, lens32, keep_att, keep_dec]
         + ([c.bf16[k_] for k_ in ('Wa_rec16', 'Wd_cat16', 'memory16', 'Wq16')] if run.bf16 else []),
-        writes=[GA] + list(slabs.values()) + ([c.bf16[k_] for k_ in ('HA16', 'HD16', 'CTX16')] if run.bf16 else []))
+        writes=[GA] + list(slabs.values()) + ([c.bf16[k_] for k_ in ('HA16', 'HD16', 'CTX16')] if run.bf16 else []),
+        regen_ga=project_ga)
 
     # mel + gate projection over all steps (model.py:373-378)
     Wpg, bpg = _packed_projection(run, P, Cm, Hd, E)             # rows: Cm mel channels, then the gate
@@ -1485,19 +1597,28 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
 # and moved to the permanent generation (`gc.freeze()`, what long-running servers do after start-up): later collections only
 # walk what was made since -- a few thousand objects, well under a millisecond.  Reference counting is untouched, nothing
 # is ever leaked but cyclic garbage that already existed at that moment.  T2AMD_GC_FREEZE=0 leaves the collector alone.
-GC_FREEZE = os.environ.get('T2AMD_GC_FREEZE', '1') != '0'
+#
+# Round 5: this is a policy of the whole interpreter, so a LIBRARY's forward pass no longer makes it by default.
+# The loops that own their process do it explicitly -- `tacotron2_amd.train` and `bench.py` call engine.settle_gc() after their
+# first complete step -- and T2AMD_GC_FREEZE=1 restores the implicit form (top of the second training forward) for a host
+# loop that cannot be edited (the reference's own train.py); either way it is announced once on stderr.
+GC_FREEZE = os.environ.get('T2AMD_GC_FREEZE', '0') == '1'
 _gc_state = {'train_forwards': 0, 'frozen': False}
 
 
-def settle_gc(force=False):
-    """Collect once, then freeze the survivors out of later collections.  Called by the engine at the top of the second
-    training forward of a process; training loops may call it themselves after their own set-up."""
+def settle_gc(force=False, quiet=False):
+    """Collect once, then freeze the survivors out of later collections (`gc.freeze()`): later full collections walk only
+    what was made since.  For training loops to call after their first complete step; see the note above."""
     if _gc_state['frozen'] and not force:
         return False
     import gc
     gc.collect()
     gc.freeze()
     _gc_state['frozen'] = True
+    if not quiet:
+        import sys
+        print("tacotron2_amd: collected once and froze %d surviving objects out of later garbage collections (gc.freeze(); "
+              "engine.settle_gc)" % gc.get_freeze_count(), file=sys.stderr, flush=True)
     return True
 
 
@@ -1512,6 +1633,8 @@ class Tacotron2TrainFunction(torch.autograd.Function):
                 raise NativeError("parameter %s is %s: training keeps f32 master weights (select the bf16 compute mode "
                                   "with model.half() / hparams.fp16_run; reduced-precision parameter storage is accepted "
                                   "by inference only)" % (n, p.dtype))
+        if model.training:
+            _note_training_step()
         if GC_FREEZE and model.training and not _gc_state['frozen']:
             _gc_state['train_forwards'] += 1
             if _gc_state['train_forwards'] == 2:     # one whole step has run: its one-time objects exist by now

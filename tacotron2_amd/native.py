@@ -433,8 +433,13 @@ def load():
     built = (lib.t2amd_source_sha1() or b"").decode()
     if os.path.isdir(os.path.join(_HERE, "csrc")) and os.environ.get("T2AMD_ALLOW_STALE_LIB", "0") != "1":
         from . import build as _build
-        want = _build.source_sha1()
-        if built != want:
+        try:
+            want = _build.source_sha1()
+        except OSError as e:             # e.g. installed as package data without include/: nothing to compare against
+            want = None
+            if os.environ.get("T2AMD_REQUIRE_SOURCE_HASH", "0") == "1":
+                raise NativeError("tacotron2_amd: cannot hash the kernel sources beside %s (%s)" % (LIB_PATH, e))
+        if want is not None and built != want:
             raise NativeError("tacotron2_amd: %s was built from other sources (binary %s, sources %s): run "
                               "`python -m tacotron2_amd.build` (or set T2AMD_ALLOW_STALE_LIB=1 to use it anyway)"
                               % (LIB_PATH, built or "<unstamped>", want))
@@ -1124,9 +1129,22 @@ def attn_fwd_ws_floats(B, Ti):
     return int(load().t2amd_attn_fwd_ws_floats(int(B), int(Ti)))
 
 
+_attn_fused_sel = {"fwd": -1, "bwd": -1}     # what this process last selected (-1: the library's default / environment)
+
+
 def set_attn_fwd_fused(on):
     """K_e and K_c of an attention step as one launch (1), two launches (0), or the library default (-1)."""
     _check(load().t2amd_set_attn_fwd_fused(int(on)), "t2amd_set_attn_fwd_fused")
+    _attn_fused_sel["fwd"] = int(on)
+
+
+def get_attn_fwd_fused():
+    """The last selection made through set_attn_fwd_fused (-1: none; the library default)."""
+    return _attn_fused_sel["fwd"]
+
+
+def get_attn_bwd_fused():
+    return _attn_fused_sel["bwd"]
 
 
 def attn_bwd_ws_floats(B, Ti):
@@ -1150,6 +1168,7 @@ def attn_handoff_timeouts(reset=True):
 def set_attn_bwd_fused(on):
     """1: the attention backward of a step as one launch (default), 0: K_b1 / K_b2 as separate launches, -1: default."""
     _check(load().t2amd_set_attn_bwd_fused(int(on)), "t2amd_set_attn_bwd_fused")
+    _attn_fused_sel["bwd"] = int(on)
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,

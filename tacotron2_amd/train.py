@@ -224,6 +224,7 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
 
     model.train()
     done = False
+    settled = False
     bad_steps = 0
     for epoch in range(first_epoch, hparams.epochs):
         print("Epoch: {}".format(epoch))
@@ -278,6 +279,13 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
                 if rank == 0:
                     save_checkpoint(model, optimizer, learning_rate, iteration,
                                     os.path.join(output_directory, "checkpoint_{}".format(iteration)))
+            if not settled and not native.validate_only():
+                # this loop owns its process: after its first complete iteration everything that exists by now is collected
+                # once and frozen out of later garbage collections (engine.settle_gc: a full collection walks ~1.5 M objects
+                # once torch is imported, 60-130 ms with the GPU idle behind it); T2AMD_GC_FREEZE_TRAIN=0 leaves the collector alone
+                settled = True
+                if os.environ.get('T2AMD_GC_FREEZE_TRAIN', '1') != '0':
+                    engine.settle_gc()
             iteration += 1
             if max_iterations is not None and iteration >= max_iterations:
                 done = True

@@ -10,6 +10,7 @@
   * engine.settle_gc(): one collection, then the survivors are frozen out of later collections.
 """
 import gc
+import os
 
 import pytest
 import torch
@@ -38,14 +39,21 @@ def test_arena_bump_alignment_growth_and_consolidation(monkeypatch):
     used = a.used
     a.busy = True
     a.release()
-    assert not a.busy and len(a.chunks) == 1 and a.peak == used
+    assert not a.busy and len(a.chunks) == 3 and a.peak == used       # consolidation waits for the next lease
+    a.consolidate()
+    assert len(a.chunks) == 1
     assert a.capacity() >= int(used * engine.ARENA_HEADROOM) and a.capacity() % (1 << 28) == 0
     g = a.growths
     for _ in range(3):                           # the same step again: no allocator call
         a.busy = True
         a.alloc(100); a.alloc(300); a.alloc(3 << 16); a.alloc(60000)
         a.release()
+        a.consolidate()
     assert a.growths == g and len(a.chunks) == 1
+    # an empty shape is served like torch.empty serves it (a 1-byte arena view cannot be viewed as float32)
+    run = engine._Run(torch.device('cpu'), 'fp32', {}, a)
+    z = run.empty(0, 5)
+    assert z.shape == (0, 5) and z.dtype == torch.float32
 
 
 def test_run_keeps_what_outlives_the_step_out_of_the_arena():
@@ -139,10 +147,48 @@ def test_settle_gc_freezes_once():
     frozen_before = gc.get_freeze_count()
     try:
         engine._gc_state['frozen'] = False
-        assert engine.settle_gc() is True
+        assert engine.settle_gc(quiet=True) is True
         assert gc.get_freeze_count() > frozen_before
         n = gc.get_freeze_count()
-        assert engine.settle_gc() is False and gc.get_freeze_count() == n       # only once per process
+        assert engine.settle_gc(quiet=True) is False and gc.get_freeze_count() == n       # only once per process
+        assert engine.GC_FREEZE is (os.environ.get('T2AMD_GC_FREEZE', '0') == '1')    # implicit form is opt-in
     finally:
         gc.unfreeze()
         engine._gc_state.update(was)
+
+
+def test_demoted_forms_are_reselected_after_clean_steps(native_lib, monkeypatch):
+    """a give-up demotes the process to the chains; after TRAIN_FWD_REPROMOTE_AFTER clean training steps
+    what was selected before is selected again, and a repeated give-up doubles the interval.  (Host logic only: the counters
+    the kernels raise are stood in for.)"""
+    said = []
+    state = dict(engine._DEMOTION)
+    flags = (engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
+    fold = native.get_bptt_cell_fold()
+    monkeypatch.setattr(engine, 'TRAIN_FWD_REPROMOTE_AFTER', 3)
+    pending = {'attn': 2, 'enc': 0}
+    monkeypatch.setattr(native, 'attn_handoff_timeouts', lambda reset=True: pending.pop('attn', 0) if reset else pending.get('attn', 0))
+    monkeypatch.setattr(native, 'encoder_handoff_timeouts', lambda reset=True: pending.pop('enc', 0) if reset else pending.get('enc', 0))
+    try:
+        engine._DEMOTION.update(active=False, count=0, clean=0, need=0, saved=None, repromotions=0)
+        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT = True, True
+        native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(1)
+        assert engine.handle_nonfinite_step(log=said.append) == 2
+        assert engine.TRAIN_FWD_PERSISTENT is False and engine.TRAIN_BWD_PERSISTENT is False
+        assert native.get_attn_fwd_fused() == 0 and native.get_attn_bwd_fused() == 0 and native.get_bptt_cell_fold() == 0
+        assert engine.give_up_counters()['demoted_now'] and 're-selected after 3 clean steps' in said[-1]
+        assert [engine._note_training_step(said.append) for _ in range(4)] == [False, False, False, True]
+        assert engine.TRAIN_FWD_PERSISTENT is True and engine.TRAIN_BWD_PERSISTENT is True
+        assert native.get_attn_fwd_fused() == -1 and native.get_attn_bwd_fused() == -1 and native.get_bptt_cell_fold() == 1
+        assert not engine.give_up_counters()['demoted_now'] and engine.give_up_counters()['repromotions'] == 1
+        assert engine._note_training_step(said.append) is False            # nothing to do while not demoted
+        pending['attn'] = 1                                                  # it gives up again: the interval doubles
+        assert engine.handle_nonfinite_step(log=said.append) == 1 and engine._DEMOTION['need'] == 6
+        assert engine.handle_nonfinite_step(log=said.append) == 0          # a non-finite step with another cause changes nothing
+        assert engine._DEMOTION['need'] == 6 and engine._DEMOTION['count'] == 2
+        monkeypatch.setattr(engine, 'TRAIN_FWD_REPROMOTE_AFTER', 0)         # 0 = never
+        assert not any(engine._note_training_step(said.append) for _ in range(20))
+    finally:
+        engine._DEMOTION.clear(); engine._DEMOTION.update(state)
+        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = flags
+        native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(fold)

@@ -7,8 +7,6 @@ hand data to each other (flag + data hand-offs inside one launch instead of kern
 everything the step produces: the four outputs, the loss, all 60 gradients and the BatchNorm buffers -- for a ragged small batch,
 for partial geometries (B < 64: fewer attention workgroups than LSTM tiles) and for a full 64-row batch; plus what a give-up
 does (bounded spin -> NaN in the step's data, counted, and engine.handle_nonfinite_step() goes back to the chain)."""
-import os
-
 import pytest
 import torch
 
@@ -113,7 +111,9 @@ def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_l
     batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 17, 12, 12, 9, 7, 4, 3], [22, 9, 15, 20, 9, 13, 6, 17], hp.n_mel_channels, 11))
     native.attn_handoff_timeouts(reset=True)
     monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
-    forms = (native.get_attn_fwd_fused() if hasattr(native, "get_attn_fwd_fused") else None)
+    # what the test restores at its end: the engine's flags AS THEY WERE AT ENTRY (an environment default
+    # that disagreed with engine.py's left every later in-process test on the opt-in backward form)
+    entry_flags = (engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
     try:
         o, loss, g, _, path = _step(m, batch, True)
         assert path == "persistent"
@@ -136,9 +136,83 @@ def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_l
         _, loss4, g4, _, _ = _step(m, batch, engine.TRAIN_FWD_PERSISTENT, bwd_persistent=engine.TRAIN_BWD_PERSISTENT)
         assert m.last_paths == ("launch chain", "launch chain") and all(torch.isfinite(v).all() for v in g4.values())
     finally:
-        engine.TRAIN_FWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_FWD_PERSISTENT', '1') != '0'
-        engine.TRAIN_BWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_BWD_PERSISTENT', '1') != '0'
+        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry_flags
         native.set_attn_fwd_fused(-1)
         native.set_attn_bwd_fused(-1)
         native.set_bptt_cell_fold(1)
-        del forms
+
+
+def test_a_give_up_in_an_eval_mode_forward_is_seen_and_recomputed_on_the_chain(native_lib, monkeypatch):
+    """an eval-mode forward (validation) carries no poison word, so nothing downstream would notice a
+    give-up of the persistent loop.  The status is read back there: the give-up is counted, the hoisted input projection the
+    loop rewrites in place is recomputed and the launch chain runs -- same outputs, bit for bit, as an undisturbed forward."""
+    m, hp = _model()
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 17, 12, 12, 9, 7, 4, 3], [22, 9, 15, 20, 9, 13, 6, 17], hp.n_mel_channels, 11))
+    m.eval()
+    x, _ = m.parse_batch(batch)
+    entry = engine.TRAIN_FWD_PERSISTENT
+    engine.TRAIN_FWD_PERSISTENT = True
+    try:
+        with torch.no_grad():
+            torch.manual_seed(3)
+            ref = [o.clone() for o in m(x)]
+            assert m.last_train_decoder_path == "persistent"
+            before = engine.give_up_counters()["eval_give_ups"]
+            monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")         # the arrival census gives up at once
+            torch.manual_seed(3)
+            out = [o.clone() for o in m(x)]
+            assert m.last_train_decoder_path == "launch chain"
+            assert engine.give_up_counters()["eval_give_ups"] == before + 1
+            monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
+            for a, b in zip(ref, out):
+                assert torch.equal(a, b)
+            assert m._dtp_eval_backoff > 0                              # the next validation batches stay on the chain for a while
+            torch.manual_seed(3)
+            m(x)
+            assert m.last_train_decoder_path == "launch chain"
+            m._dtp_eval_backoff = 0
+            torch.manual_seed(3)
+            out3 = [o.clone() for o in m(x)]
+            assert m.last_train_decoder_path == "persistent" and all(torch.equal(a, b) for a, b in zip(ref, out3))
+    finally:
+        engine.TRAIN_FWD_PERSISTENT = entry
+    assert native.attn_handoff_timeouts(reset=True) == 0               # (no poison kernel ran: nothing was counted on the device)
+
+
+def test_the_persistent_forms_come_back_after_clean_steps(native_lib, monkeypatch):
+    """one foreign kernel must not cost a long run its faster forms for good."""
+    m, hp = _model()
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 17, 12, 12, 9, 7, 4, 3], [22, 9, 15, 20, 9, 13, 6, 17], hp.n_mel_channels, 11))
+    entry = (engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
+    state = dict(engine._DEMOTION)
+    monkeypatch.setattr(engine, "TRAIN_FWD_REPROMOTE_AFTER", 2)
+    native.attn_handoff_timeouts(reset=True)
+
+    def one():                                                         # (not _step: it would restore the flags itself)
+        m.zero_grad()
+        torch.manual_seed(7)
+        xx, yy = m.parse_batch(batch)
+        ls = Tacotron2Loss()(m(xx), yy)
+        ls.backward()
+        torch.cuda.synchronize()
+        return ls.detach().clone(), m.last_train_decoder_path
+    try:
+        engine._DEMOTION.update(active=False, count=0, clean=0, need=0, saved=None, repromotions=0)
+        engine.TRAIN_FWD_PERSISTENT = True
+        good, path = one()
+        assert path == "persistent" and torch.isfinite(good)
+        monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
+        bad, path = one()
+        monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
+        assert path == "persistent" and not torch.isfinite(bad)
+        said = []
+        assert engine.handle_nonfinite_step(log=said.append) >= 1 and engine.TRAIN_FWD_PERSISTENT is False
+        paths = [one() for _ in range(4)]
+        assert [p for _, p in paths] == ["launch chain", "launch chain", "persistent", "persistent"]
+        assert all(torch.equal(l, good) for l, _ in paths)            # every form gives the same bits
+        assert engine.give_up_counters()["repromotions"] == 1 and not engine.give_up_counters()["demoted_now"]
+    finally:
+        engine._DEMOTION.clear(); engine._DEMOTION.update(state)
+        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry
+        native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(1)
+        native.attn_handoff_timeouts(reset=True)
