@@ -1034,6 +1034,8 @@ constexpr int DTP_LAG = T2AMD_DTP_LAG;
 struct DecTrainPersist {
     t2amd_dec_train d;
     int tip, kc_smem_off, delay_a, delay_t, fail_off;
+    int att_off;               // byte offset of the attention phase's LDS region: 0 (aliases the tile ring) or behind the ring
+    int prefetch;              // 1: the next step's first four k-tiles are fetched from inside the attention phase (needs att_off > 0)
     unsigned token0;
     long long gran_off, ws_floats;
     unsigned* flagA;           // [Ha/8]           LSTM_a tile j has finished step t: t + 1
@@ -1203,13 +1205,16 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
     // are then complete before L(t) begins and only its own recurrence h_dec(t-3), eight of twenty k-tiles, sits behind the tile's
     // gate instead of twelve.  Measured on one box it is the SLOWER form (23.32 vs 23.02 ms of forward, profiles/r04_j_lag_ab.txt):
     // the tiles were not waiting on the gate for long in the first place, and the older operands are colder.
+    // (round 5) ring slots 0..3 of this workgroup hold the first four k-tiles of its NEXT tile: fetched by skinny_wide_prefetch4 from
+    // inside the attention phase of the step before, drained and published by that phase's closing wait + barrier
+    bool pref = false;
     for (int t = 0; t <= To + DTP_LAG - 1; ++t) {
         const DecTrainPersist& P = dtp_args_late();
         const t2amd_dec_train& d = P.d;
         int zero = 0;
         asm volatile("" : "+s"(zero));                   // LDS addresses are formed per iteration too
         char* const psmem = psmem_ + zero;
-        float* const smem = reinterpret_cast<float*>(psmem);
+        float* const smem = reinterpret_cast<float*>(psmem + P.att_off);   // the attention phase's region
         int* const fail_s = reinterpret_cast<int*>(psmem + P.fail_off);      // behind both phases' regions
         const int nA = d.Ha / 8, nL = nA + d.Hd / 8, nT = NSL * d.B, nG = (int)gridDim.x;
         const bool isA = j < nA, isD = j >= nA && j < nL, isT = j < nT;
@@ -1237,9 +1242,24 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             gate.flags = P.flagT; gate.n = nG; gate.target = (unsigned)t; gate.delay = P.delay_a; gate.status = P.status;
             gate.ticks = P.timeout_ticks; gate.fail_s = fail_s;
             if (t == 0 || (DTP_LAG > 1 && tail)) sp.gate_seg = 0;    // nothing to wait for at the first step; already waited in the tail
-            skinny_wide_body<true, true>(sp, isA ? j : j - nA, psmem, P.ts, gate);
+            skinny_wide_body<true, true>(sp, isA ? j : j - nA, psmem, P.ts, gate, pref);
             if (fail_s[0]) return;
         }
+        pref = false;
+        // the next step's tile of this workgroup, if it has one and its first segment can be fetched ahead (h_att(t): complete
+        // once the LSTM flags of step t have been seen, i.e. from the middle of the attention phase below)
+        const bool tileA_next = isA && t + 1 < To, tileD_next = isD && t + 1 >= DTP_LAG && DTP_LAG == 1;
+        const bool pf = P.prefetch != 0 && (tileA_next || tileD_next) &&
+                        skinny_wide_prefetch_ok(d.Ha, tileA_next ? (d.E + d.Ha) / 128 : (d.Ha + d.E + d.Hd) / 128);
+        auto prefetch_next = [&] {
+            // (the description is read from the kernel-argument segment HERE: nothing of it is carried through the attention phase)
+            const t2amd_dec_train& d2 = dtp_args_late().d;
+            const unsigned short* const x0 = (const unsigned short*)d2.HA16 + (long long)t * d2.B * d2.Ha;
+            const bool isA2 = j < d2.Ha / 8;
+            skinny_wide_prefetch4(x0, d2.Ha, (const unsigned short*)(isA2 ? d2.Wa_rec16 : d2.Wd_cat16),
+                                  isA2 ? d2.E + d2.Ha : d2.Ha + d2.E + d2.Hd, isA2 ? d2.Ha : d2.Hd, isA2 ? d2.E : 0, d2.B,
+                                  isA2 ? j : j - d2.Ha / 8, psmem);
+        };
         // every storing wave drains its write-through stores (R1), then ONE flag per LSTM_a tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1282,6 +1302,10 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
                                        },
                                        [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
             if (fail_s[0]) return;
+            // Issued HERE: this workgroup's partial energies are on their way and it is about to wait for its partners' -- a wait
+            // that ends in s_waitcnt vmcnt(0) anyway (loads return in order, and any LDS read the compiler can see is ordered
+            // behind every pending LDS-DMA), so the twelve DMA instructions per wave delay nothing the phase was not waiting for.
+            if (pf) { prefetch_next(); pref = true; }
             fwd_energy_granules(ap, b, r.len, e_first);
             kc_finish<true, true, true>(ap, smem + P.kc_smem_off, sl, b, ts_on, r, e_first);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1296,6 +1320,12 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             __syncthreads();
             if (fail_s[0]) return;
             if (tid == 0) __hip_atomic_store(P.flagT + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pf) {
+                prefetch_next();
+                pref = true;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (nothing else to do until the next tile: land and publish them here)
+                __syncthreads();
+            }
         }
 #undef DTP_PROF
     }
@@ -1320,7 +1350,7 @@ extern "C" long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha
     return 4ll * (Ha / 8 + 1024 + 1);
 }
 
-static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out) {
+static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out, int* att_off_out) {
     T2_REQUIRE(p != nullptr, "dec_train_fwd_persistent: null args");
     T2_REQUIRE(p->bf16 && p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16 && p->memory16 && p->Wq16,
                "dec_train_fwd_persistent: bf16 operand mode only (bf16 copies of the weights, the recurrent slabs, the memory and W_q)");
@@ -1337,9 +1367,20 @@ static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out,
     const size_t lds_c = sizeof(float) * ((size_t)((p->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
     const size_t lds_ea = (lds_e + 15) / 16 * 16;
     T2_REQUIRE(lds_ea + lds_c <= 64 * 1024, "dec_train_fwd_persistent: Ti too large for the LDS windows");
-    size_t lds = (size_t)SW_NBUF * (SW_XB + SW_WB);
+    const size_t ring = (size_t)SW_NBUF * (SW_XB + SW_WB);
+    size_t lds = ring;
     if (lds_ea + lds_c > lds) lds = lds_ea + lds_c;
     lds = (lds + 15) / 16 * 16;
+    *att_off_out = 0;
+    // (round 5) when both fit, the attention phase gets its OWN region behind the ring, so that the ring can take the next step's
+    // first tiles while the attention phase runs (skinny_wide_prefetch4): 96 KB + ~31 KB at Ti = 177.  T2AMD_DTP_PREFETCH=0: A/B runs.
+    const char* const pf_e = getenv("T2AMD_DTP_PREFETCH");      // (read per call: tools A/B it within one process)
+    const bool pf_env = !(pf_e && pf_e[0] == '0');
+    const size_t both = ring + (lds_ea + lds_c + 15) / 16 * 16;
+    if (pf_env && DTP_LAG == 1 && both + 16 <= 160 * 1024) {
+        *att_off_out = (int)ring;
+        lds = both;
+    }
     *fail_off_out = (int)lds;
     *lds_out = lds + 16;
     *tip_out = tip;
@@ -1349,8 +1390,8 @@ static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out,
 
 // 0 = this loop can run as one persistent launch on a device with `cus` compute units; else T2AMD_ERR_ARG + reason
 extern "C" int t2amd_decoder_train_fwd_persistent_supported(const t2amd_dec_train* p, int cus) {
-    size_t lds; int tip, kc, fo;
-    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo));
+    size_t lds; int tip, kc, fo, ao;
+    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo, &ao));
     const int nL = p->Ha / 8 + p->Hd / 8, nT = NSL * p->B;
     const int grid = nL > nT ? nL : nT;
     // one workgroup per CU (96 KB of LDS each): every one of them must be resident at once
@@ -1360,8 +1401,8 @@ extern "C" int t2amd_decoder_train_fwd_persistent_supported(const t2amd_dec_trai
 
 extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, unsigned* flags, int* status, float* poison,
                                                       void* stream) {
-    size_t lds; int tip, kc, fo;
-    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo));
+    size_t lds; int tip, kc, fo, ao;
+    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo, &ao));
     T2_REQUIRE(flags && status, "dec_train_fwd_persistent: null flags / status");
     T2_REQUIRE(p->Wa_rec && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->GA && p->memory && p->pm && p->lens &&
                    p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work && p->attn_ws,
@@ -1371,6 +1412,7 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     DecTrainPersist P;
     P.d = *p;
     P.tip = tip; P.kc_smem_off = kc; P.fail_off = fo;
+    P.att_off = ao; P.prefetch = ao > 0 ? 1 : 0;
     // pre-poll pauses in s_sleep units (tuning knobs, read per call so that a tool can sweep them in one process)
     { const char* e = getenv("T2AMD_DTP_DELAY_L"); const int v = e ? atoi(e) : 4; P.delay_a = v < 0 ? 0 : (v > 400 ? 400 : v); }
     // (the wait for the LSTM flags sits inside the attention prologue, behind ~70 KB of loads: they ARE its pause -- flat from 0 to 16

@@ -144,9 +144,15 @@ struct NoGate {
 // writes 512 contiguous bytes per gate row); h_att / h_dec of the forward loop are not (eight workgroups share a line).  What it
 // buys: the 80 (48) column tiles that read the same 256 KB of gate gradients hit their XCD's L2 instead of going to the fabric
 // 256 times per step -- 64 MB per step, which is what bounded the phase.
+// `pref` (persistent FORWARD loop only, round 5): ring slots 0..3 already hold k-tiles 0..3 of segment 0 -- skinny_wide_prefetch4
+// below issued them one phase ago, while the workgroup sat in its attention step, and the caller has drained and published them
+// (s_waitcnt vmcnt(0) + barrier at the end of that phase).  The tile then starts multiplying at once: what used to stand between
+// its entry and the first MFMA -- address set-up, four tiles of DMA issue and the first tile's L2 round trip, ~2.5 us of a ~9 us
+// phase -- ran under the latency-bound attention step.  Same tiles in the same slots, same k order: bit-identical results.
+// Requires n0 >= 5 (the caller checks skinny_wide_prefetch_ok).
 template <bool LSTM, bool PERSIST, class Gate, bool XPLAIN = false>
 __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const int lb, char* const smem, unsigned long long* const ts_buf,
-                                                 Gate& gate) {
+                                                 Gate& gate, const bool pref = false) {
     constexpr int BK = 128;
     constexpr int XAUX = (PERSIST && !XPLAIN) ? 16 : 0;       // aux bit 4 = sc1 on the activation DMA
     bool ts_on = false;
@@ -273,7 +279,8 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
     }
     xq0 = xq1 = wq = reinterpret_cast<const char*>(p.W);
     if (kt_end > kt_beg) {
-        if (kt_beg < n0) SW_SEEK(0, kt_beg)
+        if (pref) { SW_SEEK(0, 4) iss_kt = kt_beg + 4; }          // (n0 >= 5: tile 4 is still in segment 0)
+        else if (kt_beg < n0) SW_SEEK(0, kt_beg)
         else if (kt_beg < n0 + n1) SW_SEEK(1, kt_beg - n0)
         else SW_SEEK(2, kt_beg - n0 - n1)
     }
@@ -342,9 +349,10 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
     // Same protocol as the 64x16 kernel: every wave issues exactly 3 DMA instructions per tile, so "tile KT+1
     // landed" is vmcnt(6) (tiles KT+2, KT+3 may be pending); the barrier publishes it and frees tile KT's buffer for
     // the DMA of tile KT+4.
-#define SW_STEP(BUF, CUR, NXT)                                               \
+    // WAIT false: the tile this step publishes was prefetched and drained a phase ago (the first three steps of a `pref` tile)
+#define SW_STEP_W(BUF, CUR, NXT, WAIT)                                       \
     {                                                                        \
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     \
+        if (WAIT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           \
         __builtin_amdgcn_s_barrier();                                        \
         __builtin_amdgcn_sched_barrier(0);                                   \
         SW_X(SW_READ, ((BUF) + 1) % SW_NBUF, NXT)                            \
@@ -357,34 +365,48 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
 
     if (kt_end > kt_beg) {
         SW_TS(1);
-        SW_ISSUE(0)
+        if (!pref) {
+            SW_ISSUE(0)
 #ifndef T2AMD_SW_EPI_FIRST
-        __builtin_amdgcn_sched_barrier(0);
-        SW_LOAD_EPI()
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+            SW_LOAD_EPI()
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-        SW_ISSUE(1)
-        SW_ISSUE(2)
-        SW_ISSUE(3)
-        asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        if constexpr (Gate::on) gate.early_check(wave, lane);       // (older than tile 0's DMA: it has returned)
+            SW_ISSUE(1)
+            SW_ISSUE(2)
+            SW_ISSUE(3)
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            if constexpr (Gate::on) gate.early_check(wave, lane);       // (older than tile 0's DMA: it has returned)
+        } else {
+#ifndef T2AMD_SW_EPI_FIRST
+            __builtin_amdgcn_sched_barrier(0);
+            SW_LOAD_EPI()
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SW_TS(2);
         SW_X(SW_READ, 0, SW_SETA)
         SW_X(SW_WAITR, SW_SETA)
         int kt = kt_beg;
+        bool first = pref;                       // (workgroup-uniform)
         for (; kt + 4 <= kt_end; kt += 4) {
-            SW_STEP(0, SW_SETA, SW_SETB)
-            SW_STEP(1, SW_SETB, SW_SETA)
-            SW_STEP(2, SW_SETA, SW_SETB)
-            SW_STEP(3, SW_SETB, SW_SETA)
+            SW_STEP_W(0, SW_SETA, SW_SETB, !first)
+            SW_STEP_W(1, SW_SETB, SW_SETA, !first)
+            SW_STEP_W(2, SW_SETA, SW_SETB, !first)
+            SW_STEP_W(3, SW_SETB, SW_SETA, true)
+            if constexpr (Gate::on) {
+                // the entry poll is older than tile 4's DMA, whose wait stands in the step above: it has returned
+                if (first) gate.early_check(wave, lane);
+            }
+            first = false;
         }
         if (kt < kt_end) {
-            SW_STEP(0, SW_SETA, SW_SETB)
+            SW_STEP_W(0, SW_SETA, SW_SETB, true)
             if (kt + 1 < kt_end) {
-                SW_STEP(1, SW_SETB, SW_SETA)
-                if (kt + 2 < kt_end) SW_STEP(2, SW_SETA, SW_SETB)
+                SW_STEP_W(1, SW_SETB, SW_SETA, true)
+                if (kt + 2 < kt_end) SW_STEP_W(2, SW_SETA, SW_SETB, true)
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the clamped duplicate tiles
@@ -398,7 +420,7 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
 #undef SW_READ
 #undef SW_WAITR
 #undef SW_FMA
-#undef SW_STEP
+#undef SW_STEP_W
 #undef SW_X
 
     // k-quarter partial sums -> LDS (the ring is dead once every wave's DMA has drained)
@@ -472,4 +494,42 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
     }
     SW_TS(5);
+}
+
+// ---------------------------------------------------------------------------------------
+// Persistent forward loop (round 5): k-tiles 0..3 of segment 0 of the NEXT step's LSTM tile, issued from inside the attention
+// phase -- the workgroup's tile of step t+1 multiplies [h_att(t) | ...] first in both roles, and h_att(t) is complete the moment the
+// attention phase has seen the LSTM flags of step t.  Every wave issues the very 12 DMA instructions skinny_wide_body would issue at
+// its entry (SW_ISSUE(0..3)): same sources, same LDS image.  `x0`: bf16 rows of segment 0 (read with sc1: another workgroup of
+// this launch wrote them), `ld0` in elements; `wcol0`: W's K column of segment 0; `bx`: the tile's index; B rows (<= 64).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool skinny_wide_prefetch_ok(const int width0, const int ntiles) { return width0 >= 5 * 128 && ntiles >= 8 && (ntiles & 3) == 0; }
+__device__ __forceinline__ void skinny_wide_prefetch4(const unsigned short* const x0, const long long ld0, const unsigned short* const W,
+                                                      const int Ktot, const int H, const int wcol0, const int B, const int bx,
+                                                      char* const smem) {
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    char* const Xs = smem;
+    char* const Ws = smem + SW_NBUF * SW_XB;
+    const char* xq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = 8 * wave + 4 * q + lg;
+        int gr = r;
+        if (gr > B - 1) gr = B - 1;
+        const int c8 = 8 * (l15 ^ (r & 15));
+        xq[q] = reinterpret_cast<const char*>(x0) + ((long long)gr * ld0 + c8) * 2;
+    }
+    const int c = 4 * wave + lg;
+    const long long wrow = (long long)(c >> 3) * H + bx * 8 + (c & 7);
+    const char* wq = reinterpret_cast<const char*>(W) + (wrow * Ktot + 8 * (l15 ^ (c & 15))) * 2 + (long long)wcol0 * 2;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        char* const xd = Xs + s * SW_XB + wave * (8 * 256);
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq[0] + s * 256), (t2_lptr)(xd), 16, 0, 16);            // aux bit 4 = sc1
+        __builtin_amdgcn_global_load_lds((t2_gptr)(xq[1] + s * 256), (t2_lptr)(xd + 1024), 16, 0, 16);
+        __builtin_amdgcn_global_load_lds((t2_gptr)(wq + s * 256), (t2_lptr)(Ws + s * SW_WB + wave * 1024), 16, 0, 0);
+    }
 }

@@ -107,6 +107,51 @@ def _engine_step(case, precision):
     return model, out, loss
 
 
+def _adjudicate_relu_kink(case, key, g_engine, g_oracle, over):
+    """Direct adjudication of the ReLU-kink carve-out below, from the gradient difference itself.
+
+    If engine and oracle disagree about relu'(z) for ONE pre-activation z[b*, co, t*] ~ 0 of encoder layer i, then dz differs by
+    a scalar delta at that one row and, through the BatchNorm backward (biased batch statistics over all N = B Ti rows,
+    reference model.py:160-167 under autograd),
+        dW_engine[co] - dW_oracle[co] = c * ( window(r*) - mean_r window(r) - zhat[r*] mean_r(zhat[r] window(r)) ),
+    window(r)[ci, tap] = x_in[b, ci, t + tap - pad]: ONE direction in the (Ci x k)-dimensional space of that output channel,
+    computable from the ORACLE's own activations.  So: recompute the oracle's encoder stack up to layer i (CPU, f32), take the
+    rows of channel co whose |z| is smallest, and test whether the observed difference of channel co is parallel to the
+    direction of one of them.  Returns the finding (|z| of the row, cosine); the caller asserts on it."""
+    import torch.nn.functional as F
+    i = int(key.split('.')[2])
+    hp, sd, masks = case['hp'], case['sd'], case['masks']
+    text = case['batch'][0]
+    x = F.embedding(text, sd['embedding.weight']).transpose(1, 2)
+    for l in range(i):
+        x = orc.apply_dropout(F.relu(orc._conv_bn(x, sd, 'encoder.convolutions.%d' % l, True, None)), 0.5, masks['enc'][l])
+    z = orc._conv_bn(x, sd, 'encoder.convolutions.%d' % i, True, None)                 # (B, C, Ti): the pre-activation of relu
+    gamma, beta = sd['encoder.convolutions.%d.1.weight' % i], sd['encoder.convolutions.%d.1.bias' % i]
+    B, C, Ti = z.shape
+    k = sd[key].shape[2]
+    pad = (k - 1) // 2
+    N = B * Ti
+    xp = F.pad(x.double(), (pad, pad))                                                   # (B, Ci, Ti + 2 pad)
+    D = (g_engine.detach().cpu().double() - g_oracle.double())
+    findings = []
+    for co in torch.nonzero(over.reshape(over.shape[0], -1).any(1)).flatten().tolist():
+        zc = z[:, co, :].double()
+        zhat = (zc - float(beta[co])) / float(gamma[co])
+        mean_w = torch.stack([xp[:, :, tap:tap + Ti].sum((0, 2)) for tap in range(k)], 1) / N            # (Ci, k)
+        mean_zw = torch.stack([(zhat.unsqueeze(1) * xp[:, :, tap:tap + Ti]).sum((0, 2)) for tap in range(k)], 1) / N
+        d = D[co]
+        best = None
+        for flat in torch.argsort(zc.abs().flatten())[:6].tolist():                      # the rows nearest the kink
+            b_, t_ = flat // Ti, flat % Ti
+            v = xp[b_, :, t_:t_ + k] - mean_w - float(zhat[b_, t_]) * mean_zw
+            cos = float((d * v).sum() / (d.norm() * v.norm()).clamp_min(1e-300))
+            if best is None or abs(cos) > abs(best['cosine']):
+                best = dict(channel=co, utterance=b_, position=t_, z_oracle=float(zc[b_, t_]), cosine=cos)
+        best['z_scale'] = float(zc.abs().mean())
+        findings.append(best)
+    return findings
+
+
 def test_train_step_To870_fp32(native_lib, full_train_case):
     c = full_train_case
     model, out, loss = _engine_step(c, 'fp32')
@@ -153,6 +198,15 @@ def test_train_step_To870_fp32(native_lib, full_train_case):
             rows[-1].update(outliers=n_out, outlier_channels=chans, rel_l2=rel_l2, rel_l2_without_those_channels=rel_l2_rest)
             if not (chans <= 3 and mx < 2e-2 * rmax and rel_l2 < 1e-3 and rel_l2_rest < 5e-4):
                 bad.append(rows[-1])
+            elif k.startswith('encoder.convolutions.') and k.endswith('.0.conv.weight'):
+                # ... and the reading itself is put to the test (round 5): the difference of every flagged channel must BE the
+                # contribution of one row whose pre-activation sits at the kink -- parallel (|cos| > 0.98) to the direction that
+                # row's relu' flip takes through the BatchNorm backward, with |z| of that row inside the rounding noise of the
+                # K = 2560-term convolution sum (1e-4 of the layer's mean |z|); anything else is NOT accepted as a kink.
+                found = _adjudicate_relu_kink(c, k, p.grad, ref, over)
+                rows[-1].update(kink_rows=found)
+                if not all(abs(f['cosine']) > 0.98 and abs(f['z_oracle']) < 1e-4 * f['z_scale'] for f in found):
+                    bad.append(rows[-1])
     msd = model.state_dict()
     for k, v in c['obufs'].items():
         mean, mx, rmax = _stats(msd[k].float(), v.float())
