@@ -863,7 +863,9 @@ __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, c
     for (int c = tid; c < EC; c += KC_NT) {
         float s = 0.f;
         for (int q = 0; q < parts; ++q) s += part_s[q * EC + c];
-        a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c] = s;
+        // (PERSIST, fp32 mode: the LSTM tiles of this launch read the f32 context itself -- there is no bf16 copy: write-through)
+        if (PERSIST && !a.ctx16_out) st_xwg<PERSIST>(&a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c], s);
+        else a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c] = s;
         if (a.ctx16_out) {
             unsigned short* c16 = reinterpret_cast<unsigned short*>(a.ctx16_out) + (long long)b * a.ld_ctx16 + cs * EC + c;
             if constexpr (PERSIST) __hip_atomic_store(c16, t2_f32_to_bf16(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1036,6 +1038,7 @@ struct DecTrainPersist {
     int tip, kc_smem_off, delay_a, delay_t, fail_off;
     int att_off;               // byte offset of the attention phase's LDS region: 0 (aliases the tile ring) or behind the ring
     int prefetch;              // 1: the next step's first four k-tiles are fetched from inside the attention phase (needs att_off > 0)
+    int timing_no_d;           // tools only: skip the decoder-LSTM tiles (timing ceiling, results are garbage)
     unsigned token0;
     long long gran_off, ws_floats;
     unsigned* flagA;           // [Ha/8]           LSTM_a tile j has finished step t: t + 1
@@ -1103,8 +1106,10 @@ struct DtpGate {
     }
 };
 
+template <bool BF>
 __device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t, SkinnyParams& a) {
-    // attention LSTM of step t: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T   (loops.hip fill_a, bf16 operands)
+    // attention LSTM of step t: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T   (loops.hip fill_a; BF: bf16 operand copies,
+    // else the f32 slabs themselves)
     const long long sHa = (long long)d.B * d.Ha, sE = (long long)d.B * d.E;
     const unsigned short* c16 = (const unsigned short*)d.CTX16;
     const unsigned short* h16 = (const unsigned short*)d.HA16;
@@ -1113,21 +1118,31 @@ __device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t
     // visited [h_att | ctx] over Wa_rec = [ctx columns | h_att columns] (explicit weight columns; the chain asks the per-step kernel
     // for the same order, loops.hip): h_att(t-1) has been complete since this workgroup's own attention phase of step t-1, so its
     // eight k-tiles run while the slowest attention workgroup is still producing ctx(t-1) -- the gate sits in front of segment 1.
-    a.x[0].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr; a.x[0].ld = d.Ha; a.x[0].width = d.Ha;
-    a.x[1].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr; a.x[1].ld = d.E; a.x[1].width = d.E;
+    if constexpr (BF) {
+        a.x[0].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr;
+        a.x[1].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr;
+        a.W = (const float*)d.Wa_rec16;
+    } else {
+        a.x[0].p = t ? d.HA + (t - 1) * sHa : nullptr;
+        a.x[1].p = t ? d.CTX + (t - 1) * sE : nullptr;
+        a.W = d.Wa_rec;
+    }
+    a.x[0].ld = d.Ha; a.x[0].width = d.Ha;
+    a.x[1].ld = d.E; a.x[1].width = d.E;
     a.x[2].p = nullptr; a.x[2].ld = 0; a.x[2].width = 0;
     a.wcol[0] = d.E; a.wcol[1] = 0; a.wcol[2] = d.E + d.Ha;
     a.gate_seg = 1;
-    a.W = (const float*)d.Wa_rec16; a.Ktot = d.E + d.Ha; a.H = d.Ha; a.B = d.B; a.N = 4 * d.Ha;
+    a.Ktot = d.E + d.Ha; a.H = d.Ha; a.B = d.B; a.N = 4 * d.Ha;
     a.gin = d.GA + (long long)t * d.B * 4 * d.Ha; a.ld_gin = 4 * d.Ha;
     a.c_prev = t ? d.CA + (t - 1) * sHa : nullptr; a.ld_cprev = d.Ha;
     a.gates_out = d.GA + (long long)t * d.B * 4 * d.Ha; a.ld_gates = 4 * d.Ha;
     a.c_out = d.CA + t * sHa; a.ld_c = d.Ha;
     a.h_out = d.HA + t * sHa; a.ld_h = d.Ha;
-    a.h16_out = (unsigned short*)d.HA16 + t * sHa; a.ld_h16 = d.Ha;
+    if constexpr (BF) { a.h16_out = (unsigned short*)d.HA16 + t * sHa; a.ld_h16 = d.Ha; }
     a.keep = d.keep_att ? d.keep_att + t * sHa : nullptr; a.ld_keep = d.Ha; a.keep_scale = d.scale_att;
     a.gx = d.Ha / 8; a.gy = 1; a.gz = 1;
 }
+template <bool BF>
 __device__ __forceinline__ void dtp_fill_d(const t2amd_dec_train& d, const int u, SkinnyParams& a) {
     // decoder LSTM of step u: gates = bias_d + [h_att_u | ctx_u | h_dec_{u-1}] . Wd_cat^T   (loops.hip fill_d, bf16 operands)
     const long long sHa = (long long)d.B * d.Ha, sHd = (long long)d.B * d.Hd, sE = (long long)d.B * d.E;
@@ -1136,16 +1151,27 @@ __device__ __forceinline__ void dtp_fill_d(const t2amd_dec_train& d, const int u
     unsigned short* hd16 = (unsigned short*)d.HD16;
     a = SkinnyParams{};
     a.nseg = 3;
-    a.x[0].p = (const float*)(ha16 + u * sHa); a.x[0].ld = d.Ha; a.x[0].width = d.Ha;
-    a.x[1].p = (const float*)(c16 + u * sE); a.x[1].ld = d.E; a.x[1].width = d.E;
-    a.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd) : nullptr; a.x[2].ld = d.Hd; a.x[2].width = d.Hd;
-    a.W = (const float*)d.Wd_cat16; a.Ktot = d.Ha + d.E + d.Hd; a.H = d.Hd; a.B = d.B; a.N = 4 * d.Hd;
+    if constexpr (BF) {
+        a.x[0].p = (const float*)(ha16 + u * sHa);
+        a.x[1].p = (const float*)(c16 + u * sE);
+        a.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd) : nullptr;
+        a.W = (const float*)d.Wd_cat16;
+    } else {
+        a.x[0].p = d.HA + u * sHa;
+        a.x[1].p = d.CTX + u * sE;
+        a.x[2].p = u ? d.HD + (u - 1) * sHd : nullptr;
+        a.W = d.Wd_cat;
+    }
+    a.x[0].ld = d.Ha; a.x[0].width = d.Ha;
+    a.x[1].ld = d.E; a.x[1].width = d.E;
+    a.x[2].ld = d.Hd; a.x[2].width = d.Hd;
+    a.Ktot = d.Ha + d.E + d.Hd; a.H = d.Hd; a.B = d.B; a.N = 4 * d.Hd;
     a.bias = d.bias_d;
     a.c_prev = u ? d.CD + (u - 1) * sHd : nullptr; a.ld_cprev = d.Hd;
     a.gates_out = d.GD + (long long)u * d.B * 4 * d.Hd; a.ld_gates = 4 * d.Hd;
     a.c_out = d.CD + u * sHd; a.ld_c = d.Hd;
     a.h_out = d.HD + u * sHd; a.ld_h = d.Hd;
-    a.h16_out = hd16 + u * sHd; a.ld_h16 = d.Hd;
+    if constexpr (BF) { a.h16_out = hd16 + u * sHd; a.ld_h16 = d.Hd; }
     a.keep = d.keep_dec ? d.keep_dec + u * sHd : nullptr; a.ld_keep = d.Hd; a.keep_scale = d.scale_dec;
     a.gx = d.Hd / 8; a.gy = 1; a.gz = 1;
     a.wcol[0] = -1;               // stored order [h_att | ctx | h_dec]: h_att(u) first, what step u's attention made behind the gate
@@ -1190,6 +1216,10 @@ __device__ __forceinline__ const DecTrainPersist& dtp_args_late() {
     return *reinterpret_cast<const DecTrainPersist*>((const char*)k);
 }
 
+// BF: the bf16 compute mode (bf16 copies of the recurrent operands and weights on the bf16 MFMA, bf16 attention streams); else the
+// fp32 parity mode (round 5): the same loop over the f32 slabs themselves -- tiles on the exact-f32 MFMA (skinny_wide.h, F32), the
+// attention phase in its f32 instantiation -- bit-identical to the fp32 launch chain, which runs the same tile.
+template <bool BF>
 __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainPersist P_entry) {
     extern __shared__ __attribute__((aligned(16))) char psmem_[];
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
@@ -1224,7 +1254,10 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
         unsigned long long c0 = prof_on ? wall_clock64() : 0ull, c1;
 #define DTP_PROF(slot) do { if (prof_on) { c1 = wall_clock64(); prof[slot] += c1 - c0; c0 = c1; } } while (0)
         // ---------------- L(t) ----------------
-        const bool tile = (isA && t < To) || (isD && t >= DTP_LAG);
+        // (P.timing_no_d -- tools only, T2AMD_DTP_TIMING_NO_D=1, NOT legal: h_dec is never produced -- runs the L phase with the
+        // attention LSTM alone: the ceiling of "take the decoder LSTM off the loop's critical path", VERDICT r04 item 2.  A run-time
+        // flag: as a compile-time variant the simplified role selection crashes hipcc's SimplifyCFG.)
+        const bool tile = (isA && t < To) || (isD && t >= DTP_LAG && !P.timing_no_d);
         const bool tail = t >= To;                       // the two trailing iterations: no attention phase around them any more
         if (DTP_LAG > 1 && tile && tail) {
             // (nothing ran between the previous tiles and these that would have observed their inputs: wait in front of the tile)
@@ -1236,29 +1269,30 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
         if (tile) {
             // ONE call site for both roles (two inlined copies of the tile body in sibling branches crash hipcc's SimplifyCFG)
             SkinnyParams sp;
-            if (isA) dtp_fill_a(d, t, sp);
-            else dtp_fill_d(d, t - DTP_LAG, sp);
+            if (isA) dtp_fill_a<BF>(d, t, sp);
+            else dtp_fill_d<BF>(d, t - DTP_LAG, sp);
             DtpGate gate;
             gate.flags = P.flagT; gate.n = nG; gate.target = (unsigned)t; gate.delay = P.delay_a; gate.status = P.status;
             gate.ticks = P.timeout_ticks; gate.fail_s = fail_s;
             if (t == 0 || (DTP_LAG > 1 && tail)) sp.gate_seg = 0;    // nothing to wait for at the first step; already waited in the tail
-            skinny_wide_body<true, true>(sp, isA ? j : j - nA, psmem, P.ts, gate, pref);
+            skinny_wide_body<true, true, DtpGate, false, !BF>(sp, isA ? j : j - nA, psmem, P.ts, gate, pref);
             if (fail_s[0]) return;
         }
         pref = false;
         // the next step's tile of this workgroup, if it has one and its first segment can be fetched ahead (h_att(t): complete
         // once the LSTM flags of step t have been seen, i.e. from the middle of the attention phase below)
-        const bool tileA_next = isA && t + 1 < To, tileD_next = isD && t + 1 >= DTP_LAG && DTP_LAG == 1;
+        const bool tileA_next = isA && t + 1 < To, tileD_next = isD && t + 1 >= DTP_LAG && DTP_LAG == 1 && !P.timing_no_d;
         const bool pf = P.prefetch != 0 && (tileA_next || tileD_next) &&
-                        skinny_wide_prefetch_ok(d.Ha, tileA_next ? (d.E + d.Ha) / 128 : (d.Ha + d.E + d.Hd) / 128);
+                        skinny_wide_prefetch_ok(d.Ha, (tileA_next ? d.E + d.Ha : d.Ha + d.E + d.Hd) / (BF ? 128 : 64), BF ? 128 : 64);
         auto prefetch_next = [&] {
             // (the description is read from the kernel-argument segment HERE: nothing of it is carried through the attention phase)
             const t2amd_dec_train& d2 = dtp_args_late().d;
-            const unsigned short* const x0 = (const unsigned short*)d2.HA16 + (long long)t * d2.B * d2.Ha;
             const bool isA2 = j < d2.Ha / 8;
-            skinny_wide_prefetch4(x0, d2.Ha, (const unsigned short*)(isA2 ? d2.Wa_rec16 : d2.Wd_cat16),
-                                  isA2 ? d2.E + d2.Ha : d2.Ha + d2.E + d2.Hd, isA2 ? d2.Ha : d2.Hd, isA2 ? d2.E : 0, d2.B,
-                                  isA2 ? j : j - d2.Ha / 8, psmem);
+            const void* const x0 = BF ? (const void*)((const unsigned short*)d2.HA16 + (long long)t * d2.B * d2.Ha)
+                                      : (const void*)(d2.HA + (long long)t * d2.B * d2.Ha);
+            const void* const W0 = BF ? (isA2 ? d2.Wa_rec16 : d2.Wd_cat16) : (const void*)(isA2 ? d2.Wa_rec : d2.Wd_cat);
+            skinny_wide_prefetch4<!BF>(x0, d2.Ha, W0, isA2 ? d2.E + d2.Ha : d2.Ha + d2.E + d2.Hd, isA2 ? d2.Ha : d2.Hd,
+                                       isA2 ? d2.E : 0, d2.B, isA2 ? j : j - d2.Ha / 8, psmem);
         };
         // every storing wave drains its write-through stores (R1), then ONE flag per LSTM_a tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1286,28 +1320,30 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             ap.a.w_out = d.ALIGN + (long long)t * d.Ti; ap.a.ld_wout = (long long)To * d.Ti;
             ap.a.ctx_out = d.CTX + t * sE; ap.a.ld_ctx = d.E;
             ap.a.q_out = d.Q + (long long)t * d.B * AD; ap.a.ld_q = AD;
-            ap.a.ctx16_out = (void*)((unsigned short*)d.CTX16 + t * sE); ap.a.ld_ctx16 = d.E;
-            ap.a.loc_split_bf16 = 1; ap.a.memory16 = d.memory16; ap.a.Wq16 = d.Wq16;
+            if constexpr (BF) {
+                ap.a.ctx16_out = (void*)((unsigned short*)d.CTX16 + t * sE); ap.a.ld_ctx16 = d.E;
+                ap.a.loc_split_bf16 = 1; ap.a.memory16 = d.memory16; ap.a.Wq16 = d.Wq16;
+            }
             ap.tip = P.tip; ap.dbg = 0; ap.ts = P.ts;
             ap.token = P.token0 + (unsigned)t; ap.gran_off = P.gran_off; ap.kc_smem_off = P.kc_smem_off; ap.delay = 0;
-            KcPre<true> r;
+            KcPre<BF> r;
             float e_first[4] = {0.f, 0.f, 0.f, 0.f};
             // the wait for the LSTM_a tiles of this step sits INSIDE the prologue, right before the one load that needs them (h):
             // W_q, processed memory, U, v and the windows are on their way while the flags are polled.  (A give-up lets the phase
             // run on with whatever h holds -- status is set, the step is poisoned behind the launch -- and leaves right after it.)
-            ke_phase<true, true, true>(ap, smem, sl, b, ts_on,
+            ke_phase<true, BF, true>(ap, smem, sl, b, ts_on,
                                        [&] {
                                            if (wave == 0 && !dtp_wait(P.flagA, nA, (unsigned)(t + 1), P.delay_t, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
                                            __syncthreads();
                                        },
-                                       [&] { kc_issue<true, false, true>(ap, sl, b, r, e_first); });
+                                       [&] { kc_issue<BF, false, true>(ap, sl, b, r, e_first); });
             if (fail_s[0]) return;
             // Issued HERE: this workgroup's partial energies are on their way and it is about to wait for its partners' -- a wait
             // that ends in s_waitcnt vmcnt(0) anyway (loads return in order, and any LDS read the compiler can see is ordered
             // behind every pending LDS-DMA), so the twelve DMA instructions per wave delay nothing the phase was not waiting for.
             if (pf) { prefetch_next(); pref = true; }
             fwd_energy_granules(ap, b, r.len, e_first);
-            kc_finish<true, true, true>(ap, smem + P.kc_smem_off, sl, b, ts_on, r, e_first);
+            kc_finish<BF, true, true>(ap, smem + P.kc_smem_off, sl, b, ts_on, r, e_first);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(P.flagT + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1352,8 +1388,12 @@ extern "C" long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha
 
 static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out, int* att_off_out) {
     T2_REQUIRE(p != nullptr, "dec_train_fwd_persistent: null args");
-    T2_REQUIRE(p->bf16 && p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16 && p->memory16 && p->Wq16,
-               "dec_train_fwd_persistent: bf16 operand mode only (bf16 copies of the weights, the recurrent slabs, the memory and W_q)");
+    T2_REQUIRE(!p->bf16 || (p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16 && p->memory16 && p->Wq16),
+               "dec_train_fwd_persistent: the bf16 operand mode needs the bf16 copies of the weights, the recurrent slabs, the memory and W_q");
+    {
+        static const bool f32_env = [] { const char* e = getenv("T2AMD_TRAIN_FWD_PERSISTENT_FP32"); return !(e && e[0] == '0'); }();
+        T2_REQUIRE(p->bf16 || f32_env, "dec_train_fwd_persistent: the fp32 form is switched off (T2AMD_TRAIN_FWD_PERSISTENT_FP32=0)");
+    }
     T2_REQUIRE(p->B > 0 && p->B <= SK_ROWS, "dec_train_fwd_persistent: one 64-row tile (B <= 64)");
     T2_REQUIRE(p->Ti > 0 && p->Ti <= KC_NT && p->To > 0, "dec_train_fwd_persistent: one position per thread (Ti <= 512)");
     T2_REQUIRE(p->E % 128 == 0 && p->Ha % 128 == 0 && p->Hd % 128 == 0 && p->Ha <= 2048, "dec_train_fwd_persistent: E, Ha, Hd multiples of 128, Ha <= 2048");
@@ -1361,7 +1401,7 @@ static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out,
     const size_t lds_e = sizeof(float) * (2 * (size_t)tip + DSL + DSL * NTAP + (size_t)p->Ha);
     const int EC = p->E / NCS;
     T2_REQUIRE(EC % 8 == 0, "dec_train_fwd_persistent: E a multiple of 32");
-    int parts = KC_NT / (EC / 8);
+    int parts = KC_NT / (EC / (p->bf16 ? 8 : 4));
     if (parts > 32) parts = 32;
     T2_REQUIRE(parts >= 1, "dec_train_fwd_persistent: E too large");
     const size_t lds_c = sizeof(float) * ((size_t)((p->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
@@ -1413,6 +1453,7 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     P.d = *p;
     P.tip = tip; P.kc_smem_off = kc; P.fail_off = fo;
     P.att_off = ao; P.prefetch = ao > 0 ? 1 : 0;
+    { const char* e = getenv("T2AMD_DTP_TIMING_NO_D"); P.timing_no_d = (e && e[0] == '1') ? 1 : 0; }
     // pre-poll pauses in s_sleep units (tuning knobs, read per call so that a tool can sweep them in one process)
     { const char* e = getenv("T2AMD_DTP_DELAY_L"); const int v = e ? atoi(e) : 4; P.delay_a = v < 0 ? 0 : (v > 400 ? 400 : v); }
     // (the wait for the LSTM flags sits inside the attention prologue, behind ~70 KB of loads: they ARE its pause -- flat from 0 to 16
@@ -1440,15 +1481,18 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     if (hipMemsetAsync(flags, 0, (size_t)t2amd_decoder_train_fwd_persistent_flag_bytes(B, p->Ha), s) != hipSuccess ||
         hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess)
         T2_FAIL("dec_train_fwd_persistent: memset failed");
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)dec_train_fwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    static size_t lds_set[2] = {0, 0};
+    const int bf = p->bf16 ? 1 : 0;
+    if (lds > lds_set[bf]) {
+        const void* fn = bf ? (const void*)dec_train_fwd_persistent_kernel<true> : (const void*)dec_train_fwd_persistent_kernel<false>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             T2_FAIL("dec_train_fwd_persistent: cannot raise the dynamic LDS limit");
-        lds_set = lds;
+        lds_set[bf] = lds;
     }
     const int nL = p->Ha / 8 + p->Hd / 8, nT = NSL * B;
     // role 7 of bench.py's roofline leg: the whole forward loop of the step is this one launch
-    T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
+    if (bf) T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel<true>, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
+    else T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel<false>, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
     T2_LAUNCH_CHECK();
     if (poison) {
         hipLaunchKernelGGL(dec_train_persist_poison_kernel, dim3(1), dim3(1), 0, s, status, poison);

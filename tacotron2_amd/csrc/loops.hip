@@ -168,6 +168,11 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         return t2amd_attention_step_fwd_f32(&at, st);
     };
 
+    // fp32 parity mode (round 5): the training loop's LSTM steps run on the WIDE 64 x 32 tile with f32 operands (csrc/skinny_wide.h,
+    // F32: exact-f32 MFMA) whenever the geometry allows -- the tile the persistent launch of this loop runs, so that chain and
+    // persistent launch are the same arithmetic (T2AMD_FP32_WIDE=0: the 64 x 16 kernel, A/B runs).  Bit 2 of the order argument.
+    static const bool wide32_env = [] { const char* e = getenv("T2AMD_FP32_WIDE"); return !(e && e[0] == '0'); }();
+    const int wide32 = (!p->bf16 && wide32_env && Ha % 8 == 0 && Hd % 8 == 0) ? 4 : 0;
     if (g_dec_streams == 2) {
         // chain A (caller's stream): LSTM_a(t) -> K_e(t) -> K_c(t);  chain D (side stream): LSTM_d(t), trailing
         hipStream_t main_s = (hipStream_t)stream, side = nullptr;
@@ -179,14 +184,14 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
             for (int t = t0; t < t1; ++t) {
                 t2amd_lstm_step a;
                 fill_a(t, a);
-                T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&a, nullptr, p->bf16 ? 1 : 0, main_s));      // same k order as the fused pair
+                T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&a, nullptr, 1 | wide32, main_s));            // same tile and k order as the fused pair
                 T2_PROPAGATE(attention(t, main_s));
             }
             T2_PROPAGATE(order_after(side, main_s, ev++));        // HA, CTX of this chunk exist
             for (int t = t0; t < t1; ++t) {
                 t2amd_lstm_step d;
                 fill_d(t, d);
-                T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, side));
+                T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&d, nullptr, wide32, side));
             }
         }
         T2_PROPAGATE(order_after(main_s, side, ev++));            // join
@@ -199,13 +204,13 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         if (t < To) fill_a(t, a);
         if (t > 0) fill_d(t - 1, d);
         if (t == 0) {
-            T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&a, stream));
+            T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&a, nullptr, wide32, stream));
         } else if (t == To) {
-            T2_PROPAGATE(t2amd_lstm_step_fwd_f32(&d, stream));
+            T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&d, nullptr, wide32, stream));
         } else {
             d.tag = 3;     // the pair is profiled as role 3 (its symbol is skinny_gemm_kernel<true, 3>)
-            // bf16 mode: the attention LSTM walks [h_att | ctx] (the persistent loop's order: csrc/attention.hip dtp_fill_a)
-            T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&d, &a, p->bf16 ? 2 : 0, stream));
+            // the attention LSTM walks [h_att | ctx] (the persistent loop's order: csrc/attention.hip dtp_fill_a)
+            T2_PROPAGATE(t2amd_lstm_step_fwd2_order_(&d, &a, 2 | wide32, stream));
         }
         if (t == To) break;
         T2_PROPAGATE(attention(t, stream));

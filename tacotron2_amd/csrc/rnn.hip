@@ -351,14 +351,14 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
 }
 
 // the wide tile as a kernel of its own: one launch per step (body: skinny_wide.h)
-template <bool LSTM, int TAG>
+template <bool LSTM, int TAG, bool F32 = false>
 __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     __shared__ __attribute__((aligned(16))) char smem[SW_NBUF * (SW_XB + SW_WB)];
     const bool second = (int)blockIdx.x >= dp.nblk0;
     const SkinnyParams p = skinny_select(dp, second);
     const int lb = (int)blockIdx.x - (second ? dp.nblk0 : 0);
     NoGate ng;
-    skinny_wide_body<LSTM, false>(p, lb, smem, dp.ts, ng);
+    skinny_wide_body<LSTM, false, NoGate, false, F32>(p, lb, smem, dp.ts, ng);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -721,7 +721,9 @@ static int lstm_step_fwd2_impl(const t2amd_lstm_step* a, const t2amd_lstm_step* 
         if (a->tag == 1) LSTM_LAUNCH((skinny_wide64_kernel<1>), dim3(total), dim3(512));
         else if (a->tag == 2) LSTM_LAUNCH((skinny_wide64_kernel<2>), dim3(total), dim3(512));
         else LSTM_LAUNCH((skinny_wide64_kernel<0>), dim3(total), dim3(512));
-    } else if (a->bf16 && skinny_wide_enabled() && a->H % 8 == 0 && (!b || b->H % 8 == 0)) {
+    } else if ((a->bf16 || (swap01 & 4)) && skinny_wide_enabled() && a->H % 8 == 0 && (!b || b->H % 8 == 0)) {
+        // (swap01 bit 2, f32 operands: the wide tile on the exact-f32 MFMA -- what the fp32 parity mode's TRAINING loop asks for,
+        // so that its launch chain and its persistent launch are the same arithmetic: csrc/skinny_wide.h, F32)
         d.p[0].gx = a->H / 8;
         d.nblk0 = d.p[0].gx * d.p[0].gy;
         total = d.nblk0;
@@ -735,6 +737,12 @@ static int lstm_step_fwd2_impl(const t2amd_lstm_step* a, const t2amd_lstm_step* 
             }
         }
         if (b) { d.p[1].gx = b->H / 8; total += d.p[1].gx * d.p[1].gy; } else { d.p[1] = d.p[0]; }
+        if (!a->bf16) {
+            if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1, true>), dim3(total), dim3(512));
+            else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2, true>), dim3(total), dim3(512));
+            else if (a->tag == 3) LSTM_LAUNCH((skinny_wide_kernel<true, 3, true>), dim3(total), dim3(512));
+            else LSTM_LAUNCH((skinny_wide_kernel<true, 0, true>), dim3(total), dim3(512));
+        } else
         if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1>), dim3(total), dim3(512));
         else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2>), dim3(total), dim3(512));
         else if (a->tag == 3) LSTM_LAUNCH((skinny_wide_kernel<true, 3>), dim3(total), dim3(512));

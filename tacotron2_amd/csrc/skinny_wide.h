@@ -150,10 +150,17 @@ struct NoGate {
 // its entry and the first MFMA -- address set-up, four tiles of DMA issue and the first tile's L2 round trip, ~2.5 us of a ~9 us
 // phase -- ran under the latency-bound attention step.  Same tiles in the same slots, same k order: bit-identical results.
 // Requires n0 >= 5 (the caller checks skinny_wide_prefetch_ok).
-template <bool LSTM, bool PERSIST, class Gate, bool XPLAIN = false>
+// F32 (round 5: the fp32 parity mode's tile, so that its time loop can be the same persistent launch): the operands are f32 and
+// the products run on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain).  Everything byte-shaped is unchanged -- a
+// tile row is still 256 bytes (64 k instead of 128), a 16-byte chunk is four k values instead of eight, the DMA, the swizzle and
+// the fragment reads are the same instructions -- and a chunk pair feeds four MFMAs of k = 2 instead of one of k = 16: element e of
+// the lane's X and W chunks is one k index in both, which is all the instruction asks for.
+template <bool LSTM, bool PERSIST, class Gate, bool XPLAIN = false, bool F32 = false>
 __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const int lb, char* const smem, unsigned long long* const ts_buf,
                                                  Gate& gate, const bool pref = false) {
-    constexpr int BK = 128;
+    constexpr int BK = F32 ? 64 : 128;       // k per 256-byte tile row
+    constexpr int ES = F32 ? 4 : 2;          // bytes per operand element
+    constexpr int CE = 16 / ES;              // elements per 16-byte chunk
     constexpr int XAUX = (PERSIST && !XPLAIN) ? 16 : 0;       // aux bit 4 = sc1 on the activation DMA
     bool ts_on = false;
     SW_TS(0);
@@ -234,10 +241,10 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         const int r = 8 * wave + 4 * q + lg;
         int gr = rowbase + r;
         if (gr > B - 1) gr = B - 1;
-        const int c8 = 8 * (l15 ^ (r & 15));
-        xo0[q] = ((long long)gr * p.x[0].ld + c8) * 2;
-        xo1[q] = ((long long)gr * p.x[1].ld + c8) * 2;
-        xo2[q] = ((long long)gr * p.x[2].ld + c8) * 2;
+        const int c8 = CE * (l15 ^ (r & 15));
+        xo0[q] = ((long long)gr * p.x[0].ld + c8) * ES;
+        xo1[q] = ((long long)gr * p.x[1].ld + c8) * ES;
+        xo2[q] = ((long long)gr * p.x[2].ld + c8) * ES;
     }
     long long wo;
     {
@@ -249,7 +256,7 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
             wrow = (long long)bx * 32 + c;
             if (wrow > p.N - 1) wrow = p.N - 1;
         }
-        wo = (wrow * p.Ktot + 8 * (l15 ^ (c & 15))) * 2;
+        wo = (wrow * p.Ktot + CE * (l15 ^ (c & 15))) * ES;
     }
     const char* const Wp = reinterpret_cast<const char*>(p.W) + wo;
     const char* const xp0 = reinterpret_cast<const char*>(p.x[0].p);
@@ -265,15 +272,15 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         if (seg_ == 0) {                                                                               \
             const char* sp_ = xp0 + loc_ * 256;                                                        \
             xq0 = sp_ + xo0[0]; xq1 = sp_ + xo0[1];                                                    \
-            wq = Wp + wo0 * 2 + loc_ * 256; iss_rem = n0 - loc_;                                       \
+            wq = Wp + wo0 * ES + loc_ * 256; iss_rem = n0 - loc_;                                       \
         } else if (seg_ == 1) {                                                                        \
             const char* sp_ = xp1 + loc_ * 256;                                                        \
             xq0 = sp_ + xo1[0]; xq1 = sp_ + xo1[1];                                                    \
-            wq = Wp + wo1 * 2 + loc_ * 256; iss_rem = n1 - loc_;                                       \
+            wq = Wp + wo1 * ES + loc_ * 256; iss_rem = n1 - loc_;                                       \
         } else {                                                                                       \
             const char* sp_ = xp2 + loc_ * 256;                                                        \
             xq0 = sp_ + xo2[0]; xq1 = sp_ + xo2[1];                                                    \
-            wq = Wp + wo2 * 2 + loc_ * 256; iss_rem = n2 - loc_;                                       \
+            wq = Wp + wo2 * ES + loc_ * 256; iss_rem = n2 - loc_;                                       \
         }                                                                                              \
         iss_seg = seg_;                                                                                \
     }
@@ -339,10 +346,17 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
 #define SW_WAITR(X0, X1, W0, W1)                                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X0), "+v"(X1), "+v"(W0), "+v"(W1) : : "memory");
 #define SW_FMA(X0, X1, W0, W1)                                                                         \
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X0)),                \
-                                                   __builtin_bit_cast(sk_bf16x8, (W0)), acc0, 0, 0, 0); \
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X1)),                \
-                                                   __builtin_bit_cast(sk_bf16x8, (W1)), acc1, 0, 0, 0);
+    if constexpr (F32) {                                                                               \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                             \
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((X0)[e_], (W0)[e_], acc0, 0, 0, 0);            \
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((X1)[e_], (W1)[e_], acc1, 0, 0, 0);            \
+        }                                                                                              \
+    } else {                                                                                           \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X0)),            \
+                                                       __builtin_bit_cast(sk_bf16x8, (W0)), acc0, 0, 0, 0); \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X1)),            \
+                                                       __builtin_bit_cast(sk_bf16x8, (W1)), acc1, 0, 0, 0); \
+    }
 #define SW_SETA xa0, xa1, wa0, wa1
 #define SW_SETB xb0, xb1, wb0, wb1
 #define SW_X(M, ...) M(__VA_ARGS__)
@@ -503,10 +517,13 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
 // its entry (SW_ISSUE(0..3)): same sources, same LDS image.  `x0`: bf16 rows of segment 0 (read with sc1: another workgroup of
 // this launch wrote them), `ld0` in elements; `wcol0`: W's K column of segment 0; `bx`: the tile's index; B rows (<= 64).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool skinny_wide_prefetch_ok(const int width0, const int ntiles) { return width0 >= 5 * 128 && ntiles >= 8 && (ntiles & 3) == 0; }
-__device__ __forceinline__ void skinny_wide_prefetch4(const unsigned short* const x0, const long long ld0, const unsigned short* const W,
+// (`bk`: k per tile row -- 128 for bf16 operands, 64 for f32)
+__device__ __forceinline__ bool skinny_wide_prefetch_ok(const int width0, const int ntiles, const int bk = 128) { return width0 >= 5 * bk && ntiles >= 8 && (ntiles & 3) == 0; }
+template <bool F32 = false>
+__device__ __forceinline__ void skinny_wide_prefetch4(const void* const x0, const long long ld0, const void* const W,
                                                       const int Ktot, const int H, const int wcol0, const int B, const int bx,
                                                       char* const smem) {
+    constexpr int ES = F32 ? 4 : 2, CE = 16 / ES;
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -519,12 +536,12 @@ __device__ __forceinline__ void skinny_wide_prefetch4(const unsigned short* cons
         const int r = 8 * wave + 4 * q + lg;
         int gr = r;
         if (gr > B - 1) gr = B - 1;
-        const int c8 = 8 * (l15 ^ (r & 15));
-        xq[q] = reinterpret_cast<const char*>(x0) + ((long long)gr * ld0 + c8) * 2;
+        const int c8 = CE * (l15 ^ (r & 15));
+        xq[q] = reinterpret_cast<const char*>(x0) + ((long long)gr * ld0 + c8) * ES;
     }
     const int c = 4 * wave + lg;
     const long long wrow = (long long)(c >> 3) * H + bx * 8 + (c & 7);
-    const char* wq = reinterpret_cast<const char*>(W) + (wrow * Ktot + 8 * (l15 ^ (c & 15))) * 2 + (long long)wcol0 * 2;
+    const char* wq = reinterpret_cast<const char*>(W) + (wrow * Ktot + CE * (l15 ^ (c & 15))) * ES + (long long)wcol0 * ES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         char* const xd = Xs + s * SW_XB + wave * (8 * 256);

@@ -774,8 +774,9 @@ def _encoder_lstm_fwd(model, dev, d0, d1, regen_gx, reads, writes, poison=None, 
     return 'launch chain'
 
 
-# The teacher-forced decoder loop as ONE persistent launch (csrc/attention.hip dec_train_fwd_persistent_kernel; bf16 mode,
-# B <= 64, one workgroup per CU) -- the default since round 4; T2AMD_TRAIN_FWD_PERSISTENT=0 keeps the launch chain (two
+# The teacher-forced decoder loop as ONE persistent launch (csrc/attention.hip dec_train_fwd_persistent_kernel<BF>; both precision
+# modes since round 5 -- the fp32 parity mode runs it on the exact-f32 wide tile, T2AMD_TRAIN_FWD_PERSISTENT_FP32=0 keeps that mode
+# on its chain; B <= 64, one workgroup per CU) -- the default since round 4; T2AMD_TRAIN_FWD_PERSISTENT=0 keeps the launch chain (two
 # dependent launches per time step).  Bit-identical either way (tests/test_zz6_train_persistent_gpu.py); measured on one
 # MI355X, alternating blocks in one process (tools/ab_train_fwd_persistent.py, profiles/r04_*_ab_train_fwd_persistent.json):
 # forward 25.55 vs 25.86 ms, whole training step 61.8 vs 62.3 ms.
@@ -795,7 +796,7 @@ def _decoder_train_fwd(model, run, d, poison, reads, writes, regen_ga=None):
     downstream would notice a NaN-free half-written slab, so the status IS read back (one sync per validation batch, as
     `_encoder_lstm_fwd` does): a give-up is counted, reported, the hoisted input projection the kernel had begun to overwrite is
     recomputed (``regen_ga``) and the launch chain runs -- with an exponential back-off before the next attempt."""
-    if TRAIN_FWD_PERSISTENT and run.bf16 and not nv.validate_only():
+    if TRAIN_FWD_PERSISTENT and not nv.validate_only():          # (both precision modes since round 5)
         cus = torch.cuda.get_device_properties(run.dev).multi_processor_count
         if poison is None and getattr(model, '_dtp_eval_backoff', 0) > 0:
             model._dtp_eval_backoff -= 1

@@ -200,12 +200,13 @@ def test_train_step_To870_fp32(native_lib, full_train_case):
                 bad.append(rows[-1])
             elif k.startswith('encoder.convolutions.') and k.endswith('.0.conv.weight'):
                 # ... and the reading itself is put to the test (round 5): the difference of every flagged channel must BE the
-                # contribution of one row whose pre-activation sits at the kink -- parallel (|cos| > 0.98) to the direction that
+                # contribution of one row whose pre-activation sits at the kink -- parallel (|cos| > 0.99) to the direction that
                 # row's relu' flip takes through the BatchNorm backward, with |z| of that row inside the rounding noise of the
-                # K = 2560-term convolution sum (1e-4 of the layer's mean |z|); anything else is NOT accepted as a kink.
+                # K = 2560-term convolution sum (2e-5 of the layer's mean |z|); anything else is NOT accepted as a kink.
                 found = _adjudicate_relu_kink(c, k, p.grad, ref, over)
                 rows[-1].update(kink_rows=found)
-                if not all(abs(f['cosine']) > 0.98 and abs(f['z_oracle']) < 1e-4 * f['z_scale'] for f in found):
+                # (measured at B = 64: |cos| 0.9995 / 0.99996, |z| 1.3e-6 / 1.2e-6 against a mean |z| of 0.73: profiles/r05_relu_kink_adjudicated.json)
+                if not all(abs(f['cosine']) > 0.99 and abs(f['z_oracle']) < 2e-5 * f['z_scale'] for f in found):
                     bad.append(rows[-1])
     msd = model.state_dict()
     for k, v in c['obufs'].items():

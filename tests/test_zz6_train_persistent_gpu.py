@@ -40,11 +40,11 @@ def _step(m, batch, persistent, seed=7, bwd_persistent=None):
         engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT = keep
 
 
-def _model(hp_str=""):
+def _model(hp_str="", precision="bf16"):
     hp = gu.make_hparams(hp_str)
     torch.manual_seed(1234)
     m = Tacotron2(hp).to(DEV).train()
-    m.precision = "bf16"
+    m.precision = precision
     return m, hp
 
 
@@ -92,12 +92,32 @@ def test_persistent_train_forward_smaller_model_geometry(native_lib):
     assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
 
 
-def test_fp32_mode_and_unsupported_geometries_stay_on_the_chain(native_lib):
+@pytest.mark.parametrize("in_lens,out_lens,hp_str", [([23, 17, 9], [41, 33, 12], ""),          # 12 attention workgroups, 256 LSTM tiles
+                                                     ([37] + [30] * 20 + [11] * 12, [55] * 30 + [19] * 3, ""),         # B = 33
+                                                     (list(range(100, 36, -1)), [64 + (i % 7) for i in range(64)], ""),   # B = 64: every role on every workgroup
+                                                     ([14, 12, 9, 9, 6, 5, 5, 3, 2, 2], [20, 11, 18, 7, 13, 20, 5, 9, 12, 6], gu.TINY_HP)])
+def test_persistent_train_forward_fp32_mode_is_bit_identical_to_its_launch_chain(native_lib, in_lens, out_lens, hp_str):
+    """Round 5: the fp32 parity mode -- the one that meets mel L1 < 1e-4 and bit-exact gate stops -- runs the
+    same persistent launch, tiles on the exact-f32 MFMA (csrc/skinny_wide.h, F32), attention phase in its f32 instantiation.  Its
+    launch chain runs the same wide tile (loops.hip, wide32), so the bar is the bf16 mode's: every bit of the outputs, the loss,
+    all 60 gradients and the BatchNorm buffers.  (TINY_HP: widths of 128 -- two k-tiles per segment, nothing to prefetch.)"""
+    m, hp = _model(hp_str, precision="fp32")
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch(in_lens, out_lens, hp.n_mel_channels, 5))
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    native.attn_handoff_timeouts(reset=True)
+    o0, l0, g0, b0, p0 = _step(m, batch, False, bwd_persistent=False)
+    m.load_state_dict(state)
+    o1, l1, g1, b1, p1 = _step(m, batch, True, bwd_persistent=False)
+    assert (p0, p1) == ("launch chain", "persistent") and native.attn_handoff_timeouts(reset=False) == 0
+    for i in range(4):
+        assert torch.isfinite(o1[i]).all() and torch.equal(o0[i], o1[i]), i
+    assert float(l0) == float(l1)
+    assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
+    assert [k for k in b0 if not torch.equal(b0[k], b1[k])] == []
+
+
+def test_unsupported_geometries_stay_on_the_chain(native_lib):
     m, hp = _model()
-    m.precision = "fp32"
-    batch = tuple(t.to(DEV) for t in gu.make_train_batch([9, 5], [12, 7], hp.n_mel_channels, 3))
-    assert _step(m, batch, True)[4] == "launch chain"
-    m.precision = "bf16"
     big = tuple(t.to(DEV) for t in gu.make_train_batch([8] * 65, [6] * 65, hp.n_mel_channels, 3))      # B = 65 > one row tile
     assert _step(m, big, True)[4] == "launch chain" and m.last_paths == ("launch chain", "launch chain")
 

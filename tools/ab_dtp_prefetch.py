@@ -51,7 +51,7 @@ def one_step(m, batch, form, seed=99):
 batches = [tuple(t.to(dev) for t in synth_batch(64, 1234 + i)) for i in range(STEPS)]
 torch.manual_seed(1234)
 m = Tacotron2(hp).to(dev).train()
-m.precision = "bf16"
+m.precision = os.environ.get("AB_PRECISION", "bf16")
 res = {f: one_step(m, batches[0], f) for f in ("chain", "plain", "prefetch", "prefetch")}
 ref = res["chain"]
 row = {"paths": {f: r[3] for f, r in res.items()}, "loss": {f: float(r[1]) for f, r in res.items()}}
@@ -109,6 +109,21 @@ for f in ("plain", "prefetch"):
     lib.t2amd_debug_dtp_prof_(None)
     out["phase_us_per_time_step_" + f] = [round(v / 100.0 / To, 3) for v in prof.tolist()]
     print(f, out["phase_us_per_time_step_" + f], flush=True)
+# TIMING ONLY (not legal: h_dec is never produced): the L phase with the attention LSTM alone -- the ceiling of taking the decoder
+# LSTM off the loop's critical path
+os.environ["T2AMD_DTP_TIMING_NO_D"] = "1"
+out["timing_only_no_decoder_lstm_tiles"] = {"fwd_plain_ms": [round(fwd_only("plain"), 3) for _ in range(2)],
+                                            "fwd_prefetch_ms": [round(fwd_only("prefetch"), 3) for _ in range(2)]}
+prof = torch.zeros(8, dtype=torch.int64, device=dev)
+lib.t2amd_debug_dtp_prof_(C.c_void_p(prof.data_ptr()))
+select("prefetch")
+with torch.no_grad():
+    m(m.parse_batch(batches[0])[0])
+torch.cuda.synchronize()
+lib.t2amd_debug_dtp_prof_(None)
+out["timing_only_no_decoder_lstm_tiles"]["phase_us_per_time_step_prefetch"] = [round(v / 100.0 / To, 3) for v in prof.tolist()]
+del os.environ["T2AMD_DTP_TIMING_NO_D"]
+print("timing only, no LSTM_d tiles:", json.dumps(out["timing_only_no_decoder_lstm_tiles"]), flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
-with open("gpurun_out/ab_dtp_prefetch.json", "w") as fh:
+with open("gpurun_out/ab_dtp_prefetch_%s.json" % m.precision, "w") as fh:
     json.dump(out, fh, indent=1)
