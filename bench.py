@@ -635,7 +635,7 @@ def main():
              To * (attn_bytes + cell_bytes + es * (4 * Hd * Kd + 4 * Ha * Ka) + es * B * (4 * Hd + 4 * Ha) + 4.0 * ns * B * (Kd + Ka)),
              To * (2.0 * (2 * B * A * Ha + ti_sum * (3 * A * 62 + 2 * A + 2 * E)) + 2.0 * B * (4 * Hd * Kd + 4 * Ha * Ka))),
             ("lstm_pair", 3 if fused else 2,
-             ("skinny_wide_kernel<true,3>" if es == 2.0 else "skinny_gemm_kernel<true,3,false>") if fused else "skinny_gemm_kernel<true,2>",
+             ("skinny_wide_kernel<true,3,%s>" % ("false" if es == 2.0 else "true (exact-f32 wide tile)")) if fused else "skinny_wide_kernel<true,2,...>",
              "decoder LSTM of step t-1 (64x2560x4096) + attention LSTM of step t (64x1536x4096), %s + fused cells" % mm
              if fused else "decoder LSTM step on the side stream (its duration includes sharing the CUs)",
              lstm_bytes(Kd, Hd, False) + (lstm_bytes(Ka, Ha, True) if fused else 0.0),

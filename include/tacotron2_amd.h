@@ -581,7 +581,10 @@ int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* stream);
  * workgroups alternate the LSTM-tile role and the attention role of every time step; the two all-to-all edges of a step are
  * flag + data hand-offs (write-through payload, one step counter per workgroup in `flags`:
  * t2amd_decoder_train_fwd_persistent_flag_bytes(B, Ha) bytes, zeroed by the call).  Same arithmetic in the same order as the
- * launch chain above: every output is bit-identical to it.  bf16 operand mode only (p->bf16 with every bf16 copy present),
+ * launch chain above: every output is bit-identical to it.  Both operand modes since round 5: p->bf16 with every bf16 copy
+ * present (bf16 MFMA tiles, bf16 attention streams), or p->bf16 == 0 -- the fp32 parity mode: the same loop over the f32 slabs,
+ * tiles on the exact-f32 MFMA, which the chain above then runs as well.  Inside the launch a workgroup fetches the first four
+ * k-tiles of its NEXT LSTM tile while it sits in its attention step (T2AMD_DTP_PREFETCH=0 switches that off).
  * B <= 64, Ti <= 512; `_supported` returns 0 when the geometry fits a device of `cus` compute units (every workgroup must be
  * resident at once), else T2AMD_ERR_ARG with the reason in t2amd_last_error().  Spins are bounded (50 ms of the wall clock):
  * a give-up sets *status != 0 and every workgroup leaves; with `poison` non-NULL a one-thread launch behind the kernel

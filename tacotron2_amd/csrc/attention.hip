@@ -1341,9 +1341,11 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             // Issued HERE: this workgroup's partial energies are on their way and it is about to wait for its partners' -- a wait
             // that ends in s_waitcnt vmcnt(0) anyway (loads return in order, and any LDS read the compiler can see is ordered
             // behind every pending LDS-DMA), so the twelve DMA instructions per wave delay nothing the phase was not waiting for.
-            if (pf) { prefetch_next(); pref = true; }
+            if (pf && P.prefetch == 1) { prefetch_next(); pref = true; }
             fwd_energy_granules(ap, b, r.len, e_first);
             kc_finish<BF, true, true>(ap, smem + P.kc_smem_off, sl, b, ts_on, r, e_first);
+            // (T2AMD_DTP_PREFETCH=2, A/B runs: issued here instead, in front of the phase's closing drain)
+            if (pf && P.prefetch == 2) { prefetch_next(); pref = true; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(P.flagT + j, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1386,7 +1388,7 @@ extern "C" long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha
     return 4ll * (Ha / 8 + 1024 + 1);
 }
 
-static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out, int* att_off_out) {
+static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out, int* att_off_out, int* pf_where_out) {
     T2_REQUIRE(p != nullptr, "dec_train_fwd_persistent: null args");
     T2_REQUIRE(!p->bf16 || (p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16 && p->memory16 && p->Wq16),
                "dec_train_fwd_persistent: the bf16 operand mode needs the bf16 copies of the weights, the recurrent slabs, the memory and W_q");
@@ -1416,6 +1418,8 @@ static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out,
     // first tiles while the attention phase runs (skinny_wide_prefetch4): 96 KB + ~31 KB at Ti = 177.  T2AMD_DTP_PREFETCH=0: A/B runs.
     const char* const pf_e = getenv("T2AMD_DTP_PREFETCH");      // (read per call: tools A/B it within one process)
     const bool pf_env = !(pf_e && pf_e[0] == '0');
+    const int pf_where = (pf_e && pf_e[0] == '2') ? 2 : 1;
+    *pf_where_out = pf_where;
     const size_t both = ring + (lds_ea + lds_c + 15) / 16 * 16;
     if (pf_env && DTP_LAG == 1 && both + 16 <= 160 * 1024) {
         *att_off_out = (int)ring;
@@ -1430,8 +1434,8 @@ static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out,
 
 // 0 = this loop can run as one persistent launch on a device with `cus` compute units; else T2AMD_ERR_ARG + reason
 extern "C" int t2amd_decoder_train_fwd_persistent_supported(const t2amd_dec_train* p, int cus) {
-    size_t lds; int tip, kc, fo, ao;
-    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo, &ao));
+    size_t lds; int tip, kc, fo, ao, pw;
+    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo, &ao, &pw));
     const int nL = p->Ha / 8 + p->Hd / 8, nT = NSL * p->B;
     const int grid = nL > nT ? nL : nT;
     // one workgroup per CU (96 KB of LDS each): every one of them must be resident at once
@@ -1441,8 +1445,8 @@ extern "C" int t2amd_decoder_train_fwd_persistent_supported(const t2amd_dec_trai
 
 extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, unsigned* flags, int* status, float* poison,
                                                       void* stream) {
-    size_t lds; int tip, kc, fo, ao;
-    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo, &ao));
+    size_t lds; int tip, kc, fo, ao, pw;
+    T2_PROPAGATE(dtp_geometry(p, &lds, &tip, &kc, &fo, &ao, &pw));
     T2_REQUIRE(flags && status, "dec_train_fwd_persistent: null flags / status");
     T2_REQUIRE(p->Wa_rec && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->GA && p->memory && p->pm && p->lens &&
                    p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work && p->attn_ws,
@@ -1452,7 +1456,7 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     DecTrainPersist P;
     P.d = *p;
     P.tip = tip; P.kc_smem_off = kc; P.fail_off = fo;
-    P.att_off = ao; P.prefetch = ao > 0 ? 1 : 0;
+    P.att_off = ao; P.prefetch = ao > 0 ? pw : 0;
     { const char* e = getenv("T2AMD_DTP_TIMING_NO_D"); P.timing_no_d = (e && e[0] == '1') ? 1 : 0; }
     // pre-poll pauses in s_sleep units (tuning knobs, read per call so that a tool can sweep them in one process)
     { const char* e = getenv("T2AMD_DTP_DELAY_L"); const int v = e ? atoi(e) : 4; P.delay_a = v < 0 ? 0 : (v > 400 ? 400 : v); }
@@ -1529,10 +1533,14 @@ struct AttnBwdParams {
 // PERSIST (the persistent backward loop below): the gradient slabs and the carry partials were written by other workgroups of
 // the SAME launch one time step ago -- device-scope (sc1) loads -- and `before_slabs` (the wait for that step's dgrad tiles) runs
 // right in front of them, BEHIND the memory-row stream, which does not depend on it.
+// `after_rows` (round 5): called right behind the issue of the memory rows -- the one-launch backward issues the operands of ITS tile
+// loop there (processed-memory rows, the d_pm read-modify-write operands: 128 KB per workgroup that nobody touches for the next
+// ~7 us) instead of in front of this phase: loads return in order, and this phase's dw -- what the utterance's three other
+// workgroups are waiting for -- used to queue behind them.
 struct KbNoHook { __device__ __forceinline__ void operator()() const {} };
-template <bool M16, bool GRAN, bool PERSIST = false, class Hook = KbNoHook>
+template <bool M16, bool GRAN, bool PERSIST = false, class Hook = KbNoHook, class Hook2 = KbNoHook>
 __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, const int ts, const int b, bool& ts_on,
-                                          Hook before_slabs = Hook()) {
+                                          Hook before_slabs = Hook(), Hook2 after_rows = Hook2()) {
     constexpr int CPT = M16 ? 8 : 4;           // channels per 16-byte load
     constexpr int KB1_MAXC = M16 ? 2 : 4;      // column groups kept in registers: KB1_MAXC x 32 loads = E <= 512
     const t2amd_attn_bwd& a = p.a;
@@ -1565,6 +1573,7 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
             pm[g][i] = M4[tc * E4 + (c < E4 ? c : l32)];
         }
     }
+    after_rows();
     before_slabs();
     // gradient of the context: up to three addends of up to four slabs each, two channels per thread at most
     float gsl[2][3][4];
@@ -1821,16 +1830,33 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
     const float* __restrict__ pmb = a.pm + (long long)b * Ti * AD + dbase + 4 * lg;
     float* __restrict__ dpmb = a.d_pm + (long long)b * Ti * AD + dbase + 4 * lg;
     const float dv_old = a.dv_acc[(long long)b * AD + dbase + (tid < DSL ? tid : 0)];   // read-modify-write operand, fetched early
-    float4 pmA[2], pmB[2], opA[2], opB[2];      // issued now, consumed in the tile loop
+    float4 pmA[2], pmB[2], opA[2], opB[2];      // consumed in the tile loop
+    // One-launch granule form: the d_pm operands are issued from INSIDE the K_b1 phase, behind its memory rows (kb1_phase,
+    // after_rows) -- nothing reads them before the tile loop, and in front of the phase they delayed its dw by the time the CU's
+    // memory pipe needs for 64 KB.  The processed-memory rows stay here: the early tanh work between the hand-off's publication
+    // and its poll consumes them.  (-DT2AMD_BWD_OPS_FIRST: everything in front, the round-4 order, A/B builds.)
+#ifdef T2AMD_BWD_OPS_FIRST
+    constexpr bool LATE_OPS = false;
+#else
+    constexpr bool LATE_OPS = FUSED && GRAN;
+#endif
+    auto issue_dpm_operands = [&] {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            int pos = (wv + rr * KB2_NW) * 16 + l15;
+            pos = pos < Ti ? pos : Ti - 1;          // clamped; rows past the utterance are never used / stored
+            opA[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD);
+            opB[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD + 16);
+        }
+    };
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         int pos = (wv + rr * KB2_NW) * 16 + l15;
-        pos = pos < Ti ? pos : Ti - 1;          // clamped; rows past the utterance are never used / stored
+        pos = pos < Ti ? pos : Ti - 1;
         pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
         pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
-        opA[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD);
-        opB[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD + 16);
     }
+    if constexpr (!LATE_OPS) issue_dpm_operands();
     float sdv[NTS], w_r, dw_r;
     {
         const int tc = tid < Ti ? tid : Ti - 1;
@@ -1880,7 +1906,11 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
             stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
             stage_u_finish(ureg, u_s, tid);
         }
-        kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs);
+        // (Measured and NOT adopted, round 5: the staging above and the processed-memory rows moved behind the rows' issue as well --
+        // 58.93-59.12 vs 58.37-58.70 ms per step in three alternating pairs of builds: slower.  The compiler already hoists the rows'
+        // issue above the staging's LDS stores, and the early tanh work then waited for rows it used to find landed.)
+        if constexpr (LATE_OPS) kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs, issue_dpm_operands);
+        else kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs);
 #ifndef T2AMD_BWD_LATE_POLL
         // (round 4) the first poll is issued BEFORE the independent work below: its round trip overlaps that work (59.48 vs
         // 59.63 ms per step over three alternating pairs of builds, same loss bits; -DT2AMD_BWD_LATE_POLL restores the old order)

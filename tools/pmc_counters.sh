@@ -17,7 +17,7 @@ for i in range(1, 5):
         for row in csv.DictReader(open(f, newline="")):
             k = row["Kernel_Name"]; acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])].add(row.get("Dispatch_Id"))
 names = sorted({c for k in acc for c in acc[k]})
-want = ("attn_bwd_main_kernel", "skinny_wide_kernel<true, 3>", "skinny_wide_kernel<false, 3>", "attn_fwd_fused_kernel", "gemm16_tn_kernel", "gemm16_kk_kernel",
+want = ("attn_bwd_main_kernel", "skinny_wide_kernel<true, 3,", "skinny_wide_kernel<false, 3,", "attn_fwd_fused_kernel", "gemm16_tn_kernel", "gemm16_kk_kernel",
         "dec_train_fwd_persistent_kernel", "encoder_bilstm_batch_persistent")
 with open("gpurun_out/${tag}_pmc_counters_bf16.csv", "w") as fh:
     fh.write("# rocprofv3 --kernel-trace --pmc <group> (four separate passes) of one bf16 training step; per-launch averages\n")

@@ -24,8 +24,8 @@ CALIB_BYTES = float(1 << 30)
 # per encoder position 512 bf16 memory channels in 256-byte column groups + 128 f32 processed-memory dims in 128-byte slices)
 CHAIN = {
     "bf16": {"decoder_forward_persistent": ("dec_train_fwd_persistent_kernel", {"calib_lds16": 39.2, "calib_seg256": 5.8, "calib_seg128": 2.0}),
-             "lstm_pair": ("skinny_wide_kernel<true, 3>", {"calib_lds16": 1.0}),
-             "dgrad_pair": ("skinny_wide_kernel<false, 3>", {"calib_lds16": 1.0}),
+             "lstm_pair": ("skinny_wide_kernel<true, 3,", {"calib_lds16": 1.0}),
+             "dgrad_pair": ("skinny_wide_kernel<false, 3,", {"calib_lds16": 1.0}),
              "attention_forward": ("attn_fwd_fused_kernel", {"calib_seg256": 1024.0, "calib_seg128": 512.0}),
              "attention_backward": ("attn_bwd_main_kernel", {"calib_seg256": 1024.0, "calib_seg128": 512.0})},
     "fp32": {"lstm_pair": ("skinny_gemm_kernel<true, 3", {"calib_lds16": 1.0}),
