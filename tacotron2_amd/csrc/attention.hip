@@ -860,6 +860,43 @@ __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, c
     }
     __syncthreads();
     T2_TS(20);
+#ifdef T2AMD_SW_VECTOR_WT
+    if constexpr (PERSIST) {
+        // (round 5, measured and NOT adopted: see the epilogue of skinny_wide.h) the context leaves as 16-BYTE write-through stores -- eight consecutive lanes hold eight consecutive channels:
+        // lane 0 of a group writes the bf16 copy as one store (bf16 mode) / lanes 0 and 4 the f32 values as two (fp32 mode, where the
+        // LSTM tiles of this launch read the f32 context itself) -- instead of one fabric write per channel (skinny_wide.h, epilogue).
+        // EC is a multiple of 8 (host check), so a group never straddles the slice.
+        for (int c0 = 0; c0 < EC; c0 += KC_NT) {
+            const int c = c0 + tid;
+            float sv = 0.f;
+            if (c < EC)
+                for (int q = 0; q < parts; ++q) sv += part_s[q * EC + c];
+            float v8[8];
+            v8[0] = sv;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) v8[k] = __shfl_down(sv, k, 64);
+            if (c < EC) {
+                float* const cp = &a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c];
+                if (a.ctx16_out) {
+                    *cp = sv;                                   // only the backward reads the f32 context in the bf16 mode
+                    if ((tid & 7) == 0) {
+                        const sk_u32x4 pk = {(unsigned)t2_f32_to_bf16(v8[0]) | ((unsigned)t2_f32_to_bf16(v8[1]) << 16),
+                                             (unsigned)t2_f32_to_bf16(v8[2]) | ((unsigned)t2_f32_to_bf16(v8[3]) << 16),
+                                             (unsigned)t2_f32_to_bf16(v8[4]) | ((unsigned)t2_f32_to_bf16(v8[5]) << 16),
+                                             (unsigned)t2_f32_to_bf16(v8[6]) | ((unsigned)t2_f32_to_bf16(v8[7]) << 16)};
+                        unsigned short* const c16 = reinterpret_cast<unsigned short*>(a.ctx16_out) + (long long)b * a.ld_ctx16 + cs * EC + c;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(c16), "v"(pk) : "memory");
+                    }
+                } else if ((tid & 3) == 0) {
+                    const f32x4 v = {v8[0], v8[1], v8[2], v8[3]};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(cp), "v"(v) : "memory");
+                }
+            }
+        }
+        T2_TS(21);
+        return;
+    }
+#endif
     for (int c = tid; c < EC; c += KC_NT) {
         float s = 0.f;
         for (int q = 0; q < parts; ++q) s += part_s[q * EC + c];

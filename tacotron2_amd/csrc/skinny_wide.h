@@ -11,6 +11,7 @@
 #define SK_WT (16 * SK_BK)        // floats per W tile
 
 typedef __bf16 sk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned sk_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* t2_gptr;
 typedef __attribute__((address_space(3))) void* t2_lptr;
 
@@ -500,9 +501,36 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
     go_[3 * H + ej] = go;
     p.c_out[(long long)egr * p.ld_c + ej] = cn;
     if constexpr (PERSIST) {
-        // read by other workgroups of this launch (attention: h; the next step's LSTM tiles: the bf16 copy): write-through
+        // read by other workgroups of this launch (attention: h; the next step's LSTM tiles: the bf16 copy): write-through.
+        // (round 5, measured and NOT adopted -- -DT2AMD_SW_VECTOR_WT builds it) As 16-BYTE stores: the eight units of a row sit in
+        // eight consecutive lanes, so lane 0 of the group collects them (seven lane shifts) and writes the bf16 copy as ONE store and,
+        // with lane 4, h as two -- 192 instead of 1024 fabric writes per tile and step in front of the drain the flag waits for
+        // (MI355X_MICROARCH.md: per byte a scalar dword write-through store costs ~6 x, a short ~12.5 x a dwordx4).  Same bits, but
+        // the forward loop measured 22.65 vs 22.0 ms with it (three alternating pairs of builds): the seven ds_bpermute per lane and
+        // their waits sit on the tile's critical tail, and the drain was not waiting for the NUMBER of writes.
+#ifndef T2AMD_SW_VECTOR_WT
         __hip_atomic_store(&p.h_out[(long long)egr * p.ld_h + ej], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (p.h16_out) __hip_atomic_store(&p.h16_out[(long long)egr * p.ld_h16 + ej], t2_f32_to_bf16(hn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        float hv[8];
+        hv[0] = hn;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) hv[k] = __shfl_down(hn, k, 64);      // (lanes of other rows / past the wave: never used)
+        float* const hrow = p.h_out + (long long)egr * p.ld_h + ej;       // ejj 0 -> units 0..3, ejj 4 -> units 4..7
+        if ((ejj & 3) == 0) {
+            const f32x4 v = {hv[0], hv[1], hv[2], hv[3]};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(hrow), "v"(v) : "memory");
+        }
+        if (p.h16_out && ejj == 0) {
+            // (the chain's own conversion, bit for bit)
+            const sk_u32x4 pk = {(unsigned)t2_f32_to_bf16(hv[0]) | ((unsigned)t2_f32_to_bf16(hv[1]) << 16),
+                                 (unsigned)t2_f32_to_bf16(hv[2]) | ((unsigned)t2_f32_to_bf16(hv[3]) << 16),
+                                 (unsigned)t2_f32_to_bf16(hv[4]) | ((unsigned)t2_f32_to_bf16(hv[5]) << 16),
+                                 (unsigned)t2_f32_to_bf16(hv[6]) | ((unsigned)t2_f32_to_bf16(hv[7]) << 16)};
+            unsigned short* const h16row = p.h16_out + (long long)egr * p.ld_h16 + ej;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(h16row), "v"(pk) : "memory");
+        }
+#endif
     } else {
         p.h_out[(long long)egr * p.ld_h + ej] = hn;
         if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
