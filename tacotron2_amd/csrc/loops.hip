@@ -63,6 +63,7 @@ static int order_after(hipStream_t waiter, hipStream_t signaller, size_t ev_inde
 }
 
 extern "C" int t2amd_lstm_step_fwd2_order_(const t2amd_lstm_step* a, const t2amd_lstm_step* b, int swap01, void* stream);   // rnn.hip
+extern "C" int t2amd_skinny_gemm2_order_(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, int order, void* stream);   // rnn.hip
 
 static inline t2amd_seg seg(const float* p, long long ld, int width) {
     t2amd_seg s;
@@ -280,6 +281,9 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
     const int Kd = Ha + E + Hd, Ka = E + Ha;
     const long long strXd = (long long)B * Kd, strXa = (long long)B * Ka;
+    // fp32 parity mode (round 5): the BPTT data gradients on the wide exact-f32 tile too (T2AMD_FP32_WIDE=0: the 64 x 16 kernel)
+    static const bool wide32_env = [] { const char* e = getenv("T2AMD_FP32_WIDE"); return !(e && e[0] == '0'); }();
+    const int wide32b = (!f.bf16 && wide32_env) ? 4 : 0;
 
     T2_PROPAGATE(t2amd_fill_f32(p->d_pm, (long long)B * Ti * T2AMD_ATT_DIM, 0.f, stream));
     T2_PROPAGATE(t2amd_fill_f32(p->dU_acc, (long long)B * T2AMD_ATT_DIM * T2AMD_LOC_TAPS, 0.f, stream));
@@ -390,7 +394,7 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
                 T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, side));
                 t2amd_skinny_gemm g;
                 dgrad_d(t, g);
-                T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, side));
+                T2_PROPAGATE(t2amd_skinny_gemm2_order_(&g, nullptr, wide32b, side));
             }
             T2_PROPAGATE(order_after(main_s, side, ev++));        // dXd of this chunk exists
             for (int t = t0; t >= t1; --t) {
@@ -401,7 +405,7 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
                 if (t > 0) {
                     t2amd_skinny_gemm ga;
                     dgrad_a(t, ga);
-                    T2_PROPAGATE(t2amd_skinny_gemm_f32(&ga, main_s));
+                    T2_PROPAGATE(t2amd_skinny_gemm2_order_(&ga, nullptr, wide32b, main_s));
                 }
             }
         }
@@ -415,7 +419,7 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
         T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&lb, stream));
         t2amd_skinny_gemm g;
         dgrad_d(To - 1, g);
-        T2_PROPAGATE(t2amd_skinny_gemm_f32(&g, stream));
+        T2_PROPAGATE(t2amd_skinny_gemm2_order_(&g, nullptr, wide32b, stream));
     }
     if (pc) {
         // one persistent launch: the kernel arguments of every step's two launches, described by the code that would have made them
@@ -451,7 +455,7 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
             dgrad_d(t - 1, gd);
             ga.tag = 3;
             gd.tag = 3;
-            T2_PROPAGATE(t2amd_skinny_gemm2_f32(&gd, &ga, stream));
+            T2_PROPAGATE(t2amd_skinny_gemm2_order_(&gd, &ga, wide32b, stream));
         } else if (!g_cell_fold) {
             T2_PROPAGATE(t2amd_lstm_pointwise_bwd_f32(&la, stream));
         }

@@ -801,7 +801,17 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     return T2AMD_OK;
 }
 
+static int skinny_gemm2_impl(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, int order, void* stream);
 extern "C" int t2amd_skinny_gemm2_f32(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, void* stream) {
+    return skinny_gemm2_impl(a, b, 0, stream);
+}
+// internal (loops.hip): bit 2 of `order` = f32 operands on the WIDE 64 x 32 tile (csrc/skinny_wide.h, F32: exact-f32 MFMA) -- the BPTT
+// data gradients of the fp32 parity mode's training loop (round 1 measured that tiling 2 % ahead of the 64 x 16 kernel on the fp32
+// step, all of it in this product; the tile body exists since round 5 for that mode's persistent forward loop)
+extern "C" int t2amd_skinny_gemm2_order_(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, int order, void* stream) {
+    return skinny_gemm2_impl(a, b, order, stream);
+}
+static int skinny_gemm2_impl(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, int order, void* stream) {
     SkinnyDual d;
     d.ts = t2amd_debug_ts_();
     T2_PROPAGATE(fill_plain(a, d.p[0]));
@@ -815,11 +825,17 @@ extern "C" int t2amd_skinny_gemm2_f32(const t2amd_skinny_gemm* a, const t2amd_sk
     }
     hipStream_t s = (hipStream_t)stream;
     T2_REQUIRE(!b || (a->bf16 != 0) == (b->bf16 != 0), "skinny_gemm: both problems of a launch must share the operand type");
-    if (a->bf16 && skinny_wide_enabled()) {
+    if ((a->bf16 || (order & 4)) && skinny_wide_enabled()) {
         d.p[0].gx = t2_cdiv(a->N, 32);
         d.nblk0 = d.p[0].gx * d.p[0].gy * d.p[0].gz;
         total = d.nblk0;
         if (b) { d.p[1].gx = t2_cdiv(b->N, 32); total += d.p[1].gx * d.p[1].gy * d.p[1].gz; } else { d.p[1] = d.p[0]; }
+        if (!a->bf16) {
+            if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<false, 1, true>), dim3(total), dim3(512), 0, s, d);
+            else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<false, 2, true>), dim3(total), dim3(512), 0, s, d);
+            else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_wide_kernel<false, 3, true>), dim3(total), dim3(512), 0, s, d);   // BPTT dgrad pair
+            else T2_LAUNCH((skinny_wide_kernel<false, 0, true>), dim3(total), dim3(512), 0, s, d);
+        } else
         if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<false, 1>), dim3(total), dim3(512), 0, s, d);
         else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<false, 2>), dim3(total), dim3(512), 0, s, d);
         else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_wide_kernel<false, 3>), dim3(total), dim3(512), 0, s, d);   // BPTT dgrad pair
