@@ -1570,9 +1570,9 @@ struct AttnBwdParams {
 // PERSIST (the persistent backward loop below): the gradient slabs and the carry partials were written by other workgroups of
 // the SAME launch one time step ago -- device-scope (sc1) loads -- and `before_slabs` (the wait for that step's dgrad tiles) runs
 // right in front of them, BEHIND the memory-row stream, which does not depend on it.
-// `after_rows` (round 5): called right behind the issue of the memory rows -- the one-launch backward issues the operands of ITS tile
-// loop there (processed-memory rows, the d_pm read-modify-write operands: 128 KB per workgroup that nobody touches for the next
-// ~7 us) instead of in front of this phase: loads return in order, and this phase's dw -- what the utterance's three other
+// `after_rows` (round 5): called behind the issue of every load this phase waits for (memory rows, gradient slabs, carries) -- the
+// one-launch backward issues the d_pm read-modify-write operands of ITS tile loop there (64 KB per workgroup that nobody touches for
+// the next ~7 us) instead of in front of this phase: loads return in order, and this phase's dw -- what the utterance's three other
 // workgroups are waiting for -- used to queue behind them.
 struct KbNoHook { __device__ __forceinline__ void operator()() const {} };
 template <bool M16, bool GRAN, bool PERSIST = false, class Hook = KbNoHook, class Hook2 = KbNoHook>
@@ -1610,7 +1610,6 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
             pm[g][i] = M4[tc * E4 + (c < E4 ? c : l32)];
         }
     }
-    after_rows();
     before_slabs();
     // gradient of the context: up to three addends of up to four slabs each, two channels per thread at most
     float gsl[2][3][4];
@@ -1650,6 +1649,7 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
         if (a.d_w_extra) exv = a.d_w_extra[(long long)b * a.ld_dwextra + ti];
         wv0 = a.w[(long long)b * a.ld_w + ti];
     }
+    after_rows();        // (behind EVERY load this phase waits for: rows, gradient slabs, carries)
 
     // ---- consume --------------------------------------------------------------------------------------
 #pragma unroll
@@ -1886,13 +1886,21 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
             opB[rr] = *reinterpret_cast<const float4*>(dpmb + (long long)pos * AD + 16);
         }
     };
+    auto issue_pm_rows = [&] {
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        int pos = (wv + rr * KB2_NW) * 16 + l15;
-        pos = pos < Ti ? pos : Ti - 1;
-        pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
-        pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
-    }
+        for (int rr = 0; rr < 2; ++rr) {
+            int pos = (wv + rr * KB2_NW) * 16 + l15;
+            pos = pos < Ti ? pos : Ti - 1;
+            pmA[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD);
+            pmB[rr] = *reinterpret_cast<const float4*>(pmb + (long long)pos * AD + 16);
+        }
+    };
+#ifdef T2AMD_BWD_PM_LATE
+    constexpr bool PM_LATE = LATE_OPS;       // A/B builds: the processed-memory rows behind K_b1's loads too
+#else
+    constexpr bool PM_LATE = false;
+#endif
+    if constexpr (!PM_LATE) issue_pm_rows();
     if constexpr (!LATE_OPS) issue_dpm_operands();
     float sdv[NTS], w_r, dw_r;
     {
@@ -1946,7 +1954,10 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
         // (Measured and NOT adopted, round 5: the staging above and the processed-memory rows moved behind the rows' issue as well --
         // 58.93-59.12 vs 58.37-58.70 ms per step in three alternating pairs of builds: slower.  The compiler already hoists the rows'
         // issue above the staging's LDS stores, and the early tanh work then waited for rows it used to find landed.)
-        if constexpr (LATE_OPS) kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs, issue_dpm_operands);
+        if constexpr (LATE_OPS) kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs, [&] {
+            if constexpr (PM_LATE) issue_pm_rows();
+            issue_dpm_operands();
+        });
         else kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs);
 #ifndef T2AMD_BWD_LATE_POLL
         // (round 4) the first poll is issued BEFORE the independent work below: its round trip overlaps that work (59.48 vs
