@@ -1575,21 +1575,28 @@ struct AttnBwdParams {
 // the next ~7 us) instead of in front of this phase: loads return in order, and this phase's dw -- what the utterance's three other
 // workgroups are waiting for -- used to queue behind them.
 struct KbNoHook { __device__ __forceinline__ void operator()() const {} };
-template <bool M16, bool GRAN, bool PERSIST = false, class Hook = KbNoHook, class Hook2 = KbNoHook>
-__device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, const int ts, const int b, bool& ts_on,
+// What K_b1 has in flight between the issue of its loads and their first use (round 5: the two halves are separate functions, so
+// that the one-launch backward can issue this phase's loads -- memory rows, gradient slabs, carries: what its dw, the thing the
+// utterance's three other workgroups wait for, is made of -- as the FIRST loads of the launch, ahead of its own prologue).
+template <bool M16>
+struct Kb1Regs {
+    float4 pm[M16 ? 2 : 4][KB1_MAXP];
+    float gsl[2][3][4];
+    float cwv[4], ccv[4], dcv, exv, wv0;
+    int len_raw;
+};
+template <bool M16, bool PERSIST = false, class Hook = KbNoHook, class Hook2 = KbNoHook>
+__device__ __forceinline__ void kb1_issue(const AttnBwdParams& p, const int ts, const int b, bool& ts_on, Kb1Regs<M16>& R,
                                           Hook before_slabs = Hook(), Hook2 after_rows = Hook2()) {
     constexpr int CPT = M16 ? 8 : 4;           // channels per 16-byte load
     constexpr int KB1_MAXC = M16 ? 2 : 4;      // column groups kept in registers: KB1_MAXC x 32 loads = E <= 512
     const t2amd_attn_bwd& a = p.a;
-    const int tid = PERSIST ? t2_tid_opaque() : (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = PERSIST ? t2_tid_opaque() : (int)threadIdx.x;
     const int Ti = a.Ti, E = a.E, B = a.B;
     const int tsz = (Ti + NTS - 1) / NTS;
-    float* dctx_s = smem;            // [E]
-    float* base_s = dctx_s + E;      // [tsz] carries + running dcum (+ extra) per position of the slice
-    float* wl_s = base_s + tsz;      // [tsz] this step's weights
-    float* red_s = wl_s + tsz;       // [KB1_NT / 64]
     T2_TS(32);
     const int len_raw = a.lens ? a.lens[b] : Ti;
+    R.len_raw = len_raw;
     const int t0 = ts * tsz;
     int t1 = t0 + tsz;
     if (t1 > Ti) t1 = Ti;
@@ -1599,7 +1606,6 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
                                     (long long)b * Ti * E4;
     const int grp = tid >> 5, l32 = tid & 31;      // KB1_NG row groups of 32 lanes
     const int npass = (tsz + KB1_NG - 1) / KB1_NG; // passes that hold positions of this slice
-    float4 pm[KB1_MAXC][KB1_MAXP];
 #pragma unroll
     for (int i = 0; i < KB1_MAXP; ++i) {
         const int ti = t0 + grp + KB1_NG * i;
@@ -1607,12 +1613,11 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
 #pragma unroll
         for (int g = 0; g < KB1_MAXC; ++g) {
             const int c = l32 + 32 * g;
-            pm[g][i] = M4[tc * E4 + (c < E4 ? c : l32)];
+            R.pm[g][i] = M4[tc * E4 + (c < E4 ? c : l32)];
         }
     }
     before_slabs();
     // gradient of the context: up to three addends of up to four slabs each, two channels per thread at most
-    float gsl[2][3][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int c = tid + KB1_NT * u;
@@ -1621,17 +1626,17 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
         for (int i = 0; i < 3; ++i) {
             const t2amd_addend& ad = a.dctx[i];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) gsl[u][i][k] = 0.f;
+            for (int k = 0; k < 4; ++k) R.gsl[u][i][k] = 0.f;
             if (ad.p) {
                 const int n = ad.nsplit;
                 const float* q0 = ad.p + (long long)b * ad.ld;       // wave-uniform slab bases (scalar adds only)
                 const float* q1 = q0 + ad.split_stride;
                 const float* q2 = q1 + ad.split_stride;
                 const float* q3 = q2 + ad.split_stride;
-                gsl[u][i][0] = ld_xwg<PERSIST>(q0 + cc);
-                if (n > 1) gsl[u][i][1] = ld_xwg<PERSIST>(q1 + cc);
-                if (n > 2) gsl[u][i][2] = ld_xwg<PERSIST>(q2 + cc);
-                if (n > 3) gsl[u][i][3] = ld_xwg<PERSIST>(q3 + cc);
+                R.gsl[u][i][0] = ld_xwg<PERSIST>(q0 + cc);
+                if (n > 1) R.gsl[u][i][1] = ld_xwg<PERSIST>(q1 + cc);
+                if (n > 2) R.gsl[u][i][2] = ld_xwg<PERSIST>(q2 + cc);
+                if (n > 3) R.gsl[u][i][3] = ld_xwg<PERSIST>(q3 + cc);
             }
         }
     }
@@ -1639,18 +1644,49 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
     const long long ps = (long long)B * 2 * Ti;                 // stride between dim-slice partials
     const float* __restrict__ cw = a.dwin_part + ((long long)b * 2 + 0) * Ti;
     const float* __restrict__ cc_ = a.dwin_part + ((long long)b * 2 + 1) * Ti;
-    float* __restrict__ dcum = a.dcum_acc + (long long)b * Ti;
-    float cwv[4], ccv[4], dcv, exv = 0.f, wv0;
+    const float* __restrict__ dcum = a.dcum_acc + (long long)b * Ti;
+    R.exv = 0.f;
     {
         const int ti = (t0 + tid < t1) ? t0 + tid : t0;         // clamped
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { cwv[k] = ld_xwg<PERSIST>(cw + k * ps + ti); ccv[k] = ld_xwg<PERSIST>(cc_ + k * ps + ti); }
-        dcv = dcum[ti];
-        if (a.d_w_extra) exv = a.d_w_extra[(long long)b * a.ld_dwextra + ti];
-        wv0 = a.w[(long long)b * a.ld_w + ti];
+        for (int k = 0; k < 4; ++k) { R.cwv[k] = ld_xwg<PERSIST>(cw + k * ps + ti); R.ccv[k] = ld_xwg<PERSIST>(cc_ + k * ps + ti); }
+        R.dcv = dcum[ti];
+        if (a.d_w_extra) R.exv = a.d_w_extra[(long long)b * a.ld_dwextra + ti];
+        R.wv0 = a.w[(long long)b * a.ld_w + ti];
     }
     after_rows();        // (behind EVERY load this phase waits for: rows, gradient slabs, carries)
+}
 
+template <bool M16, bool GRAN, bool PERSIST = false>
+__device__ __forceinline__ void kb1_consume(const AttnBwdParams& p, float* smem, const int ts, const int b, bool& ts_on,
+                                            const Kb1Regs<M16>& R) {
+    constexpr int CPT = M16 ? 8 : 4;
+    constexpr int KB1_MAXC = M16 ? 2 : 4;
+    const t2amd_attn_bwd& a = p.a;
+    const int tid = PERSIST ? t2_tid_opaque() : (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int Ti = a.Ti, E = a.E, B = a.B;
+    const int tsz = (Ti + NTS - 1) / NTS;
+    float* dctx_s = smem;            // [E]
+    float* base_s = dctx_s + E;      // [tsz] carries + running dcum (+ extra) per position of the slice
+    float* wl_s = base_s + tsz;      // [tsz] this step's weights
+    float* red_s = wl_s + tsz;       // [KB1_NT / 64]
+    const int len_raw = R.len_raw;
+    const int t0 = ts * tsz;
+    int t1 = t0 + tsz;
+    if (t1 > Ti) t1 = Ti;
+    const int E4 = E / CPT;
+    const float4* __restrict__ M4 = reinterpret_cast<const float4*>(M16 ? a.memory16 : (const void*)a.memory) +
+                                    (long long)b * Ti * E4;
+    const int grp = tid >> 5, l32 = tid & 31;
+    const float4 (&pm)[KB1_MAXC][KB1_MAXP] = R.pm;
+    const float (&gsl)[2][3][4] = R.gsl;
+    const long long ps = (long long)B * 2 * Ti;
+    const float* __restrict__ cw = a.dwin_part + ((long long)b * 2 + 0) * Ti;
+    const float* __restrict__ cc_ = a.dwin_part + ((long long)b * 2 + 1) * Ti;
+    float* __restrict__ dcum = a.dcum_acc + (long long)b * Ti;
+    const float (&cwv)[4] = R.cwv;
+    const float (&ccv)[4] = R.ccv;
+    const float dcv = R.dcv, exv = R.exv, wv0 = R.wv0;
     // ---- consume --------------------------------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -1795,6 +1831,15 @@ __device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, c
     T2_TS(35);
 }
 
+// the whole phase in one piece (the separate-launch kernel, the token-form one-launch kernel, the persistent backward loop)
+template <bool M16, bool GRAN, bool PERSIST = false, class Hook = KbNoHook, class Hook2 = KbNoHook>
+__device__ __forceinline__ void kb1_phase(const AttnBwdParams& p, float* smem, const int ts, const int b, bool& ts_on,
+                                          Hook before_slabs = Hook(), Hook2 after_rows = Hook2()) {
+    Kb1Regs<M16> R;
+    kb1_issue<M16, PERSIST>(p, ts, b, ts_on, R, before_slabs, after_rows);
+    kb1_consume<M16, GRAN, PERSIST>(p, smem, ts, b, ts_on, R);
+}
+
 template <bool M16>
 __global__ __launch_bounds__(KB1_NT) void attn_bwd_dw_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1860,6 +1905,19 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
     float* dh_s = u_s + DSL * NTAP;           // [Hq] second-half partial of dh; CELL: [8][Hq/4] 16-dim partials
     float* dqall_s = dh_s + 2 * (size_t)Hq;   // CELL only: [128] the utterance's dq
     T2_TS(48);
+    // (round 5, measured and NOT adopted: -DT2AMD_BWD_KB1_FIRST builds it) the loads of the K_b1 phase -- memory rows, gradient slabs,
+    // carries: what its dw, the thing the utterance's three other workgroups wait for, is made of -- as the FIRST loads of the launch
+    // (kb1_issue here, kb1_consume where the phase used to run).  Phase stamps say they are issued ~2 us in (behind this prologue's
+    // issue, the wait of the window / U staging for ITS loads and four serialised scalar round trips at the top of the phase), yet
+    // four alternating pairs of builds read 57.08-57.33 vs 56.73-56.91 ms per step: slower -- everything the staging and the early
+    // tanh work touch then queues behind 106 KB of rows and slabs.
+#ifdef T2AMD_BWD_KB1_FIRST
+    constexpr bool KB1_FIRST = FUSED && GRAN && !PERSIST;
+#else
+    constexpr bool KB1_FIRST = false;
+#endif
+    Kb1Regs<M16> kb1r;
+    if constexpr (KB1_FIRST) kb1_issue<M16, false>(p, ds, b, ts_on, kb1r);
     // Prologue loads: all issued before the first is consumed, nothing selected on a fresh load (see K_e).
     const int len_raw = a.lens ? a.lens[b] : Ti;
     const int dbase = ds * DSL;
@@ -1875,7 +1933,7 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
 #ifdef T2AMD_BWD_OPS_FIRST
     constexpr bool LATE_OPS = false;
 #else
-    constexpr bool LATE_OPS = FUSED && GRAN;
+    constexpr bool LATE_OPS = FUSED && GRAN && !KB1_FIRST;      // (KB1_FIRST: everything here is behind K_b1's loads anyway)
 #endif
     auto issue_dpm_operands = [&] {
 #pragma unroll
@@ -1928,6 +1986,7 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
             dva[dt][r] = 0.f;
             dqa[dt][r] = 0.f;
         }
+    T2_TS(62);                                 // (every prologue load of the main body has been issued)
 #ifdef T2AMD_ATTN_BWD_LATE                     // A/B builds only (python -m tacotron2_amd.build --variant ...): the round-2 order
     constexpr bool EARLY = false;
 #else
@@ -1947,16 +2006,23 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
         if (tid == 0) gflag_s[0] = 0;                  // published by the barriers inside kb1_phase
         // (round 3) the windows and the U slice go to LDS BEFORE K_b1 (their loads were the first ones issued: they have
         // landed by the time K_b1's own operands are touched; K_b1's barriers publish them) ...
-        if constexpr (EARLY) {
+#ifdef T2AMD_BWD_STAGE_LATE
+        constexpr bool STAGE_LATE = LATE_OPS && EARLY;    // A/B builds: the window / U staging behind the issue of K_b1's loads
+#else
+        constexpr bool STAGE_LATE = false;
+#endif
+        if constexpr (EARLY && !STAGE_LATE) {
             stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
             stage_u_finish(ureg, u_s, tid);
         }
-        // (Measured and NOT adopted, round 5: the staging above and the processed-memory rows moved behind the rows' issue as well --
-        // 58.93-59.12 vs 58.37-58.70 ms per step in three alternating pairs of builds: slower.  The compiler already hoists the rows'
-        // issue above the staging's LDS stores, and the early tanh work then waited for rows it used to find landed.)
-        if constexpr (LATE_OPS) kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs, [&] {
+        if constexpr (KB1_FIRST) kb1_consume<M16, true, false>(p, smem + p.kb1_smem_off, ds, b, ts_on, kb1r);
+        else if constexpr (LATE_OPS) kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs, [&] {
             if constexpr (PM_LATE) issue_pm_rows();
             issue_dpm_operands();
+            if constexpr (STAGE_LATE) {
+                stage_windows_finish(wreg, win_s, TIP, Ti, wprev_b, cumb_b, tid, KB2_NT);
+                stage_u_finish(ureg, u_s, tid);
+            }
         });
         else kb1_phase<M16, true, PERSIST>(p, smem + p.kb1_smem_off, ds, b, ts_on, before_slabs);
 #ifndef T2AMD_BWD_LATE_POLL
@@ -1991,6 +2057,7 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
                 }
             }
         }
+        T2_TS(59);                     // (the independent work between the hand-off's publication and its poll is done)
         const at_u64* grow = reinterpret_cast<const at_u64*>(a.ws + p.gran_off) + (long long)b * (Ti + NTS);   // (uniform)
         const int gi = tid < Ti + NTS ? tid : Ti + NTS - 1;          // Ti + NTS <= 512 (host check)
 #ifndef T2AMD_BWD_LATE_POLL
@@ -2011,9 +2078,11 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
             }
             if (bad && lane == 0) gflag_s[0] = 1;
         }
+        T2_TS(60);                     // (every granule of this thread's wave carries the token)
         dw_r = __uint_as_float((unsigned)xd);
         if (tid >= Ti && tid < Ti + NTS) dq_s[tid - Ti] = dw_r;
         __syncthreads();
+        T2_TS(61);
 #pragma unroll
         for (int k = 0; k < NTS; ++k) sdv[k] = dq_s[k];
         poison = gflag_s[0] != 0;

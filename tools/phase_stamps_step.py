@@ -45,6 +45,13 @@ for base, nm in names:
     ts = [buf[base + i] for i in range(15) if buf[base + i]]
     if ts:
         print("%-78s %s" % (nm, " ".join("%.2f" % ((t - ts[0]) / 100.0) for t in ts)))
+if buf[48] and buf[32]:
+    print("K_b1 phase inside K_b2: main-body prologue issued %.2f | entry %.2f | operands staged %.2f | dw done %.2f | end %.2f   (us from K_b2's entry)" %
+          tuple((buf[i] - buf[48]) / 100.0 for i in (62, 32, 33, 34, 35)))
+# K_b2's first hand-off in detail (round 5: slots 59-61)
+if buf[48] and buf[59]:
+    print("K_b2 hand-off: independent work done %.2f | wave 0's granules carry the token %.2f | barrier behind them %.2f | staging done %.2f" %
+          tuple((buf[i] - buf[48]) / 100.0 for i in (59, 60, 61, 49)))
 # K_b2's reduce phase in detail (slots 56-58: W_q / cell prefetch issued, lane-group sums written, barrier passed)
 if buf[48] and buf[56]:
     print("K_b2 detail: tiles done %.2f | prefetch issued %.2f | sums in LDS %.2f | barrier passed %.2f | dq stored %.2f" %
