@@ -277,7 +277,9 @@ static int attn_dbg_stage() {
 // `before_h` runs right before the load of h is issued, with every other prologue load already in flight: the persistent
 // kernel waits for the LSTM tiles' flags THERE, so that the W_q rows, the processed-memory rows, U, v and the windows -- none of
 // which depends on this step's h -- travel during that wait instead of behind it.
-template <bool GRAN, bool EARLYP, bool PERSIST, class Pre, class Hook>
+// FASTT: the bf16 compute mode's one-range tanh (common.h t2_tanh_1r) -- chosen by the MODE, never by the launch form: every form of a
+// mode (one launch, two launches, persistent loop) and the backward's recompute (attn_bwd_main_body: M16) use the same function.
+template <bool GRAN, bool EARLYP, bool PERSIST, bool FASTT, class Pre, class Hook>
 __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, const int ds, const int b, bool& ts_on,
                                          Pre&& before_h, Hook&& after_prologue) {
     const t2amd_attn_fwd& a = p.a;
@@ -464,14 +466,14 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
             acc1 = round == 0 ? loc1[0] : loc1[1];
         } else if (split16) loc_tile16(uf, win_s, TIP, pos, lg, acc0, acc1);
         else loc_tile(ua, win_s, TIP, pos, lg, acc0, acc1);
-        float e = vv[0][0] * t2_tanh(acc0[0] + qv[0][0] + pm0.x);
-        e = fmaf(vv[0][1], t2_tanh(acc0[1] + qv[0][1] + pm0.y), e);
-        e = fmaf(vv[0][2], t2_tanh(acc0[2] + qv[0][2] + pm0.z), e);
-        e = fmaf(vv[0][3], t2_tanh(acc0[3] + qv[0][3] + pm0.w), e);
-        e = fmaf(vv[1][0], t2_tanh(acc1[0] + qv[1][0] + pm1.x), e);
-        e = fmaf(vv[1][1], t2_tanh(acc1[1] + qv[1][1] + pm1.y), e);
-        e = fmaf(vv[1][2], t2_tanh(acc1[2] + qv[1][2] + pm1.z), e);
-        e = fmaf(vv[1][3], t2_tanh(acc1[3] + qv[1][3] + pm1.w), e);
+        float e = vv[0][0] * t2_tanh_sel<FASTT>(acc0[0] + qv[0][0] + pm0.x);
+        e = fmaf(vv[0][1], t2_tanh_sel<FASTT>(acc0[1] + qv[0][1] + pm0.y), e);
+        e = fmaf(vv[0][2], t2_tanh_sel<FASTT>(acc0[2] + qv[0][2] + pm0.z), e);
+        e = fmaf(vv[0][3], t2_tanh_sel<FASTT>(acc0[3] + qv[0][3] + pm0.w), e);
+        e = fmaf(vv[1][0], t2_tanh_sel<FASTT>(acc1[0] + qv[1][0] + pm1.x), e);
+        e = fmaf(vv[1][1], t2_tanh_sel<FASTT>(acc1[1] + qv[1][1] + pm1.y), e);
+        e = fmaf(vv[1][2], t2_tanh_sel<FASTT>(acc1[2] + qv[1][2] + pm1.z), e);
+        e = fmaf(vv[1][3], t2_tanh_sel<FASTT>(acc1[3] + qv[1][3] + pm1.w), e);
         e += __shfl_xor(e, 16, 64);
         e += __shfl_xor(e, 32, 64);
         if (lg == 0 && pos < Ti) {
@@ -482,12 +484,12 @@ __device__ __forceinline__ void ke_phase(const AttnFwdParams& p, float* smem, co
     T2_TS(2);
 }
 
-template <int MINW>
+template <int MINW, bool FASTT>
 __global__ __launch_bounds__(KE_NT, MINW) void attn_energy_kernel(AttnFwdParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     bool ts_on = false;
     if (p.a.active && !p.a.active[blockIdx.y]) return;
-    ke_phase<false, false, false>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {}, [] {});
+    ke_phase<false, false, false, FASTT>(p, smem, blockIdx.x, blockIdx.y, ts_on, [] {}, [] {});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -643,14 +645,14 @@ __global__ __launch_bounds__(KE_NT) void attn_energy4_kernel(AttnFwdParams p) {
             for (int r = 0; r < 4; ++r) qv[dt][r] = q_s[u * DSL + dt * 16 + 4 * lg + r];
         f32x4 acc0, acc1;
         loc_tile16(uf, win_s + u * 2 * TIP, TIP, pos, lg, acc0, acc1);
-        float e = vv[0][0] * t2_tanh(acc0[0] + qv[0][0] + pm0.x);
-        e = fmaf(vv[0][1], t2_tanh(acc0[1] + qv[0][1] + pm0.y), e);
-        e = fmaf(vv[0][2], t2_tanh(acc0[2] + qv[0][2] + pm0.z), e);
-        e = fmaf(vv[0][3], t2_tanh(acc0[3] + qv[0][3] + pm0.w), e);
-        e = fmaf(vv[1][0], t2_tanh(acc1[0] + qv[1][0] + pm1.x), e);
-        e = fmaf(vv[1][1], t2_tanh(acc1[1] + qv[1][1] + pm1.y), e);
-        e = fmaf(vv[1][2], t2_tanh(acc1[2] + qv[1][2] + pm1.z), e);
-        e = fmaf(vv[1][3], t2_tanh(acc1[3] + qv[1][3] + pm1.w), e);
+        float e = vv[0][0] * t2_tanh_sel<true>(acc0[0] + qv[0][0] + pm0.x);
+        e = fmaf(vv[0][1], t2_tanh_sel<true>(acc0[1] + qv[0][1] + pm0.y), e);
+        e = fmaf(vv[0][2], t2_tanh_sel<true>(acc0[2] + qv[0][2] + pm0.z), e);
+        e = fmaf(vv[0][3], t2_tanh_sel<true>(acc0[3] + qv[0][3] + pm0.w), e);
+        e = fmaf(vv[1][0], t2_tanh_sel<true>(acc1[0] + qv[1][0] + pm1.x), e);
+        e = fmaf(vv[1][1], t2_tanh_sel<true>(acc1[1] + qv[1][1] + pm1.y), e);
+        e = fmaf(vv[1][2], t2_tanh_sel<true>(acc1[2] + qv[1][2] + pm1.z), e);
+        e = fmaf(vv[1][3], t2_tanh_sel<true>(acc1[3] + qv[1][3] + pm1.w), e);
         e += __shfl_xor(e, 16, 64);
         e += __shfl_xor(e, 32, 64);
         if (lg == 0 && pos < Ti) a.ws[((long long)ds * B + (b0 + u)) * Ti + pos] = e;
@@ -963,7 +965,7 @@ __global__ __launch_bounds__(KE_NT, 2) void attn_fwd_fused_kernel(AttnFwdParams 
     const int tid = threadIdx.x;
     KcPre<M16> r;
     float e_first[4] = {0.f, 0.f, 0.f, 0.f};
-    ke_phase<true, M16, false>(p, smem, sl, b, ts_on, [] {}, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
+    ke_phase<true, M16, false, M16>(p, smem, sl, b, ts_on, [] {}, [&] { kc_issue<M16, false>(p, sl, b, r, e_first); });
     T2_TS(16);
     fwd_energy_granules(p, b, r.len, e_first);
     kc_finish<M16, true>(p, smem + p.kc_smem_off, sl, b, ts_on, r, e_first);
@@ -1034,8 +1036,13 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
         return T2AMD_OK;
     }
     if (form == 2) T2_LAUNCH(attn_energy4_kernel, dim3(NSL, t2_cdiv(a->B, KE4_U)), dim3(KE_NT), lds_e4, s, p);
-    else if (form == 1) T2_LAUNCH((attn_energy_kernel<4>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
-    else T2_LAUNCH((attn_energy_kernel<2>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    else if (form == 1) {
+        if (a->memory16) T2_LAUNCH((attn_energy_kernel<4, true>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+        else T2_LAUNCH((attn_energy_kernel<4, false>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    } else {
+        if (a->memory16) T2_LAUNCH((attn_energy_kernel<2, true>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+        else T2_LAUNCH((attn_energy_kernel<2, false>), dim3(NSL, a->B), dim3(KE_NT), lds_e, s, p);
+    }
     if (a->memory16) T2_LAUNCH(attn_context_kernel<true>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     else T2_LAUNCH(attn_context_kernel<false>, dim3(NCS, a->B), dim3(KC_NT), lds_c, s, p);
     T2_LAUNCH_CHECK();
@@ -1368,7 +1375,7 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             // the wait for the LSTM_a tiles of this step sits INSIDE the prologue, right before the one load that needs them (h):
             // W_q, processed memory, U, v and the windows are on their way while the flags are polled.  (A give-up lets the phase
             // run on with whatever h holds -- status is set, the step is poisoned behind the launch -- and leaves right after it.)
-            ke_phase<true, BF, true>(ap, smem, sl, b, ts_on,
+            ke_phase<true, BF, true, BF>(ap, smem, sl, b, ts_on,
                                        [&] {
                                            if (wave == 0 && !dtp_wait(P.flagA, nA, (unsigned)(t + 1), P.delay_t, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
                                            __syncthreads();
@@ -2053,7 +2060,7 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) th_pre[rr][dt][r] = t2_tanh((dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r]);
+                        for (int r = 0; r < 4; ++r) th_pre[rr][dt][r] = t2_tanh_sel<M16>((dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r]);
                 }
             }
         }
@@ -2213,7 +2220,7 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
             for (int r = 0; r < 4; ++r) {
                 float th;
                 if (pre) th = round == 0 ? th_pre[0][dt][r] : th_pre[1][dt][r];
-                else th = t2_tanh((dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r]);
+                else th = t2_tanh_sel<M16>((dt ? acc1[r] : acc0[r]) + qv[dt][r] + pmv[dt][r]);
                 const float g = de * vv[dt][r] * (1.f - th * th);
                 dva[dt][r] = fmaf(de, th, dva[dt][r]);
                 dqa[dt][r] += g;
@@ -2725,6 +2732,7 @@ static int attn_bwd_step_impl(const t2amd_attn_bwd* a, void* stream, AttnBwdPara
     const size_t lds2c = lds2 + sizeof(float) * ((size_t)a->Hq + AD + 4);
     if ((int)lds2 > 64 * 1024 && (int)lds2 > g_attn_bwd_lds && !t2amd_validate_only_flag_()) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<false, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         g_attn_bwd_lds = (int)lds2;
     }
     T2_REQUIRE(!a->memory16 || (t2_aligned16(a->memory16) && a->E % 8 == 0), "attn_bwd: memory16 must be 16-byte aligned, E a multiple of 8");
@@ -2813,7 +2821,9 @@ static int attn_bwd_step_impl(const t2amd_attn_bwd* a, void* stream, AttnBwdPara
         t2amd_profile_mark_(4, 0, s);          // role 4: the attention backward pair of one time step (bench.py roofline)
         if (a->memory16) T2_LAUNCH(attn_bwd_dw_kernel<true>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
         else T2_LAUNCH(attn_bwd_dw_kernel<false>, dim3(NTS, a->B), dim3(KB1_NT), lds1, s, p);
-        T2_LAUNCH((attn_bwd_main_kernel<false, false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
+        // (M16 of the separate K_b2 launch touches no memory rows: it carries the MODE -- the tanh form the forward used, common.h)
+        if (a->memory16) T2_LAUNCH((attn_bwd_main_kernel<false, true, false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
+        else T2_LAUNCH((attn_bwd_main_kernel<false, false, false, false>), dim3(NSL, a->B), dim3(KB2_NT), lds2, s, p);
         t2amd_profile_mark_(4, 1, s);
         T2_LAUNCH_CHECK();
     }

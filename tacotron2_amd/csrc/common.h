@@ -106,6 +106,25 @@ __device__ __forceinline__ float t2_tanh(float x) {
     return copysignf(ax < 0.625f ? small : big, x);
 }
 
+// One-range form for the bf16 compute mode of the TRAINING loops (round 5): tanh(x) = 1 - 2 / (exp(2x) + 1) straight on v_exp_f32 /
+// v_rcp_f32 -- 5 VALU operations instead of ~17 (no |x|, no polynomial, no select, no copysign); exp -> inf gives 1, exp -> 0 gives -1.
+// Absolute error < 3e-7 like the two-range form's large branch, but NOT relatively accurate near 0 (|x| < 1e-3: the subtraction loses
+// it): fine beside bf16 products (the attention energies sum v * tanh), not for the fp32 parity mode, which keeps t2_tanh.  The
+// attention backward recomputes the forward's tanh with the same selection, so the pair stays consistent.  -DT2AMD_TANH_EXACT: off.
+__device__ __forceinline__ float t2_tanh_1r(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+template <bool FAST>
+__device__ __forceinline__ float t2_tanh_sel(float x) {
+#ifdef T2AMD_TANH_EXACT
+    return t2_tanh(x);
+#else
+    if constexpr (FAST) return t2_tanh_1r(x);
+    else return t2_tanh(x);
+#endif
+}
+
 // DPP lane exchanges (VALU, no LDS crossbar: a __shfl_xor is a ds_bpermute the compiler waits for one at a time).
 // The four steps pair exactly the lanes the xor-1/2/4/8 butterfly pairs, so sums are bitwise the same.
 template <int CTRL>
