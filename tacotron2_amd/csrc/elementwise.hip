@@ -49,6 +49,67 @@ __global__ void colreduce_partial_kernel(const float* __restrict__ x, long long 
     }
 }
 
+// The same reduction on 16-byte loads (round 5): a workgroup is 16 column lanes of four columns (the same 64 columns per
+// blockIdx.x) x 16 row lanes; row lane j of row block rb takes rows rb*16 + j, + 1024, ... four at a time, every load issued
+// before the first use (64 B in flight per thread and tensor).  A wave's load instruction covers four 256-byte row segments.
+// Needs N % 4 == 0, ldx % 4 == 0 and a 16-byte-aligned base; the scalar kernel above stays for everything else.
+#define VCL 16      // column lanes (x 4 columns)
+#define VRL 16      // row lanes
+struct Dbl4 { double v[4]; };
+__device__ __forceinline__ void vred_finish(double (*s1)[64], double (*s2)[64], const Dbl4& a, const Dbl4& q, bool two,
+                                            int cl, int rl, int rb, int col0, int N, double* __restrict__ ws) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s1[rl][cl * 4 + j] = a.v[j];
+        if (two) s2[rl][cl * 4 + j] = q.v[j];
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < 64 && col0 + c < N) {
+        double s = 0.0, t = 0.0;
+#pragma unroll
+        for (int r = 0; r < VRL; ++r) {
+            s += s1[r][c];
+            if (two) t += s2[r][c];
+        }
+        ws[(long long)rb * N + col0 + c] = s;
+        if (two) ws[(long long)(RB + rb) * N + col0 + c] = t;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_partial_vec_kernel(const float* __restrict__ x, long long ldx, int M, int N,
+                                                                    double* __restrict__ ws) {
+    const int cl = threadIdx.x & (VCL - 1), rl = threadIdx.x / VCL;
+    const int col0 = blockIdx.x * 64, col = col0 + cl * 4;
+    const int rb = blockIdx.y;
+    __shared__ double s1[VRL][64], s2[MODE == 0 ? VRL : 1][64];
+    Dbl4 a = {}, q = {};
+    if (col < N) {
+        const long long step = (long long)RB * VRL;
+        long long r = (long long)rb * VRL + rl;
+        auto add = [&](const float4& v) {
+            a.v[0] += (double)v.x; a.v[1] += (double)v.y; a.v[2] += (double)v.z; a.v[3] += (double)v.w;
+            if (MODE == 0) {
+                q.v[0] += (double)v.x * (double)v.x; q.v[1] += (double)v.y * (double)v.y;
+                q.v[2] += (double)v.z * (double)v.z; q.v[3] += (double)v.w * (double)v.w;
+            }
+        };
+        for (; r + 3 * step < M; r += 4 * step) {
+            const float4 v0 = *reinterpret_cast<const float4*>(x + r * ldx + col);
+            const float4 v1 = *reinterpret_cast<const float4*>(x + (r + step) * ldx + col);
+            const float4 v2 = *reinterpret_cast<const float4*>(x + (r + 2 * step) * ldx + col);
+            const float4 v3 = *reinterpret_cast<const float4*>(x + (r + 3 * step) * ldx + col);
+            add(v0); add(v1); add(v2); add(v3);
+        }
+        for (; r < M; r += step) add(*reinterpret_cast<const float4*>(x + r * ldx + col));
+    }
+    vred_finish(s1, s2, a, q, MODE == 0, cl, rl, rb, col0, N, ws);
+}
+
+static inline bool vec4_ok(const void* p, long long ld, int N) { return N % 4 == 0 && ld % 4 == 0 && t2_aligned16(p); }
+static const bool g_ew_scalar = [] { const char* e = getenv("T2AMD_ELEMENTWISE_SCALAR"); return e && atoi(e) != 0; }();   // A/B
+
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ ws, int M, int N, float* mean,
                                          float* invstd, float* rmean, float* rvar, float momentum, float eps) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,7 +136,10 @@ extern "C" int t2amd_bn_stats_f32(const float* x, long long ldx, int M, int N, d
                                   float eps, void* stream) {
     T2_REQUIRE(x && ws && mean && invstd && M > 0 && N > 0, "bn_stats: bad args");
     hipStream_t s = (hipStream_t)stream;
-    T2_LAUNCH((colreduce_partial_kernel<0>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    if (vec4_ok(x, ldx, N) && !g_ew_scalar)
+        T2_LAUNCH((colreduce_partial_vec_kernel<0>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    else
+        T2_LAUNCH((colreduce_partial_kernel<0>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
     T2_LAUNCH(bn_stats_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, M, N, mean, invstd,
                        running_mean, running_var, momentum, eps);
     T2_LAUNCH_CHECK();
@@ -107,7 +171,10 @@ extern "C" int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, dou
                                 int accumulate, void* stream) {
     T2_REQUIRE(x && ws && out && M > 0 && N > 0, "colsum: bad args");
     hipStream_t s = (hipStream_t)stream;
-    T2_LAUNCH((colreduce_partial_kernel<1>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    if (vec4_ok(x, ldx, N) && !g_ew_scalar)
+        T2_LAUNCH((colreduce_partial_vec_kernel<1>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
+    else
+        T2_LAUNCH((colreduce_partial_kernel<1>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, x, ldx, M, N, ws);
     T2_LAUNCH(colsum_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, out, accumulate);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
@@ -138,12 +205,81 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, long long ldx, fl
     }
 }
 
+// 16-byte form: thread = (column lane of four columns, row lane); the per-channel parameters are loaded once per thread, four
+// rows are in flight per thread, and no element pays a 64-bit division (the scalar kernel's i / N).  Same expression per element
+// as above, so the same bits.
+__global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+                                                             long long ldy, int M, int N, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int act,
+                                                             const uint8_t* __restrict__ keep, long long ldkeep, float keep_scale,
+                                                             const int* __restrict__ lens, int T) {
+    const int cl = threadIdx.x & (VCL - 1), rl = threadIdx.x / VCL;
+    const int col = blockIdx.x * 64 + cl * 4;
+    if (col >= N) return;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + col), is = *reinterpret_cast<const float4*>(invstd + col);
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
+    const int step = gridDim.y * VRL;
+    auto one = [&](float xv, float m, float i, float g, float b, unsigned kp, bool dead) -> float {
+        float v = (xv - m) * i * g + b;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = tanhf(v);
+        if (keep) v = kp ? v * keep_scale : 0.f;
+        return dead ? 0.f : v;
+    };
+    auto row = [&](int r, const float4& xv, unsigned kp) {
+        bool dead = false;
+        if (lens) {
+            const int b = r / T, t = r - b * T;
+            dead = t >= lens[b];
+        }
+        float4 o;
+        o.x = one(xv.x, mu.x, is.x, ga.x, be.x, kp & 0xffu, dead);
+        o.y = one(xv.y, mu.y, is.y, ga.y, be.y, (kp >> 8) & 0xffu, dead);
+        o.z = one(xv.z, mu.z, is.z, ga.z, be.z, (kp >> 16) & 0xffu, dead);
+        o.w = one(xv.w, mu.w, is.w, ga.w, be.w, kp >> 24, dead);
+        *reinterpret_cast<float4*>(y + (long long)r * ldy + col) = o;
+    };
+    int r = blockIdx.y * VRL + rl;
+    for (; r + 3 * step < M; r += 4 * step) {
+        float4 xv[4];
+        unsigned kp[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xv[j] = *reinterpret_cast<const float4*>(x + (long long)(r + j * step) * ldx + col);
+            if (keep) kp[j] = *reinterpret_cast<const unsigned*>(keep + (long long)(r + j * step) * ldkeep + col);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row(r + j * step, xv[j], kp[j]);
+    }
+    for (; r < M; r += step) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (long long)r * ldx + col);
+        const unsigned kp = keep ? *reinterpret_cast<const unsigned*>(keep + (long long)r * ldkeep + col) : 0u;
+        row(r, xv, kp);
+    }
+}
+
+// rows of workgroups for the 16-byte elementwise forms: enough for ~8 workgroups per CU, never more than the rows give
+static inline int vec_row_blocks(int M, int N) {
+    int by = 2048 / t2_cdiv(N, 64);
+    if (by < 1) by = 1;
+    const int need = t2_cdiv(M, VRL);
+    return by < need ? by : need;
+}
+
 extern "C" int t2amd_bn_act_fwd_f32(const float* x, long long ldx, float* y, long long ldy, int M, int N,
                                     const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, int act, const uint8_t* keep, long long ldkeep,
                                     float keep_scale, const int* lens, int row_valid_T, void* stream) {
     T2_REQUIRE(x && y && mean && invstd && gamma && beta && M > 0 && N > 0, "bn_act_fwd: bad args");
     T2_REQUIRE(!lens || row_valid_T > 0, "bn_act_fwd: lens needs row_valid_T");
+    if (!g_ew_scalar && vec4_ok(x, ldx, N) && vec4_ok(y, ldy, N) && t2_aligned16(mean) && t2_aligned16(invstd) && t2_aligned16(gamma) &&
+        t2_aligned16(beta) && (!keep || (ldkeep % 4 == 0 && (reinterpret_cast<uintptr_t>(keep) & 3u) == 0))) {
+        T2_LAUNCH(bn_act_fwd_vec_kernel, dim3(t2_cdiv(N, 64), vec_row_blocks(M, N)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                  M, N, mean, invstd, gamma, beta, act, keep, ldkeep, keep_scale, lens, row_valid_T);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
     int blocks = t2_cdiv((long long)M * N, 256);
     if (blocks > 8192) blocks = 8192;
     T2_LAUNCH(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, N, mean,
@@ -217,6 +353,113 @@ __global__ void bn_act_bwd_stage1_kernel(float* __restrict__ dy, long long lddy,
     }
 }
 
+// 16-byte form of stage 1 (layout of colreduce_partial_vec_kernel; two rows in flight per thread: 104 B).  The gate is the
+// scalar kernel's, element by element.
+__global__ __launch_bounds__(256) void bn_act_bwd_stage1_vec_kernel(float* __restrict__ dy, long long lddy, const float* __restrict__ y,
+                                                                    long long ldy, const float* __restrict__ x, long long ldx, int M,
+                                                                    int N, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, int act,
+                                                                    const uint8_t* __restrict__ keep, long long ldkeep,
+                                                                    float keep_scale, double* __restrict__ ws) {
+    const int cl = threadIdx.x & (VCL - 1), rl = threadIdx.x / VCL;
+    const int col0 = blockIdx.x * 64, col = col0 + cl * 4;
+    const int rb = blockIdx.y;
+    __shared__ double s1[VRL][64], s2[VRL][64];
+    Dbl4 a = {}, q = {};
+    if (col < N) {
+        const float4 mu4 = *reinterpret_cast<const float4*>(mean + col), is4 = *reinterpret_cast<const float4*>(invstd + col);
+        const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+        auto gate = [&](float g, float yv, unsigned kp) -> float {
+            if (keep) {
+                if (kp) {
+                    g *= keep_scale;
+                    if (act == 1) g = (yv > 0.f) ? g : 0.f;
+                    else if (act == 2) { const float th = yv / keep_scale; g *= (1.f - th * th); }
+                } else {
+                    g = 0.f;
+                }
+            } else {
+                if (act == 1) g = (yv > 0.f) ? g : 0.f;
+                else if (act == 2) g *= (1.f - yv * yv);
+            }
+            return g;
+        };
+        auto row = [&](long long r, const float4& g4, const float4& y4, const float4& x4, unsigned kp) {
+            float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = gate(g[j], yv[j], keep ? ((kp >> (8 * j)) & 0xffu) : 1u);
+                a.v[j] += (double)g[j];
+                q.v[j] += (double)g[j] * (double)((xv[j] - mu[j]) * is[j]);
+            }
+            *reinterpret_cast<float4*>(dy + r * lddy + col) = make_float4(g[0], g[1], g[2], g[3]);
+        };
+        const long long step = (long long)RB * VRL;
+        long long r = (long long)rb * VRL + rl;
+        for (; r + step < M; r += 2 * step) {
+            const long long r1 = r + step;
+            const float4 g0 = *reinterpret_cast<const float4*>(dy + r * lddy + col), g1 = *reinterpret_cast<const float4*>(dy + r1 * lddy + col);
+            const float4 y0 = *reinterpret_cast<const float4*>(y + r * ldy + col), y1 = *reinterpret_cast<const float4*>(y + r1 * ldy + col);
+            const float4 x0 = *reinterpret_cast<const float4*>(x + r * ldx + col), x1 = *reinterpret_cast<const float4*>(x + r1 * ldx + col);
+            unsigned k0 = 0, k1 = 0;
+            if (keep) {
+                k0 = *reinterpret_cast<const unsigned*>(keep + r * ldkeep + col);
+                k1 = *reinterpret_cast<const unsigned*>(keep + r1 * ldkeep + col);
+            }
+            row(r, g0, y0, x0, k0);
+            row(r1, g1, y1, x1, k1);
+        }
+        for (; r < M; r += step) {
+            const float4 g0 = *reinterpret_cast<const float4*>(dy + r * lddy + col);
+            const float4 y0 = *reinterpret_cast<const float4*>(y + r * ldy + col);
+            const float4 x0 = *reinterpret_cast<const float4*>(x + r * ldx + col);
+            const unsigned k0 = keep ? *reinterpret_cast<const unsigned*>(keep + r * ldkeep + col) : 0u;
+            row(r, g0, y0, x0, k0);
+        }
+    }
+    vred_finish(s1, s2, a, q, true, cl, rl, rb, col0, N, ws);
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_stage2_vec_kernel(float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                                    long long ldx, int M, int N, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+    const int cl = threadIdx.x & (VCL - 1), rl = threadIdx.x / VCL;
+    const int col = blockIdx.x * 64 + cl * 4;
+    if (col >= N) return;
+    const float invM = 1.0f / (float)M;
+    float mu[4], is[4], ga[4], dg[4], db[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        mu[j] = mean[col + j]; is[j] = invstd[col + j]; ga[j] = gamma[col + j]; dg[j] = dgamma[col + j]; db[j] = dbeta[col + j];
+    }
+    auto row = [&](int r, const float4& g4, const float4& x4) {
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xhat = (xv[j] - mu[j]) * is[j];
+            o[j] = ga[j] * is[j] * (g[j] - db[j] * invM - xhat * dg[j] * invM);
+        }
+        *reinterpret_cast<float4*>(dy + (long long)r * lddy + col) = make_float4(o[0], o[1], o[2], o[3]);
+    };
+    const int step = gridDim.y * VRL;
+    int r = blockIdx.y * VRL + rl;
+    for (; r + 3 * step < M; r += 4 * step) {
+        float4 g[4], xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g[j] = *reinterpret_cast<const float4*>(dy + (long long)(r + j * step) * lddy + col);
+            xv[j] = *reinterpret_cast<const float4*>(x + (long long)(r + j * step) * ldx + col);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row(r + j * step, g[j], xv[j]);
+    }
+    for (; r < M; r += step)
+        row(r, *reinterpret_cast<const float4*>(dy + (long long)r * lddy + col), *reinterpret_cast<const float4*>(x + (long long)r * ldx + col));
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int N, float* dgamma, float* dbeta) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -253,6 +496,16 @@ extern "C" int t2amd_bn_act_bwd_f32(float* dy, long long lddy, const float* y, l
                                     float keep_scale, double* ws, float* dgamma, float* dbeta, void* stream) {
     T2_REQUIRE(dy && y && x && mean && invstd && gamma && ws && dgamma && dbeta && M > 0 && N > 0, "bn_act_bwd: bad args");
     hipStream_t s = (hipStream_t)stream;
+    if (!g_ew_scalar && vec4_ok(dy, lddy, N) && vec4_ok(y, ldy, N) && vec4_ok(x, ldx, N) && t2_aligned16(mean) && t2_aligned16(invstd) &&
+        (!keep || (ldkeep % 4 == 0 && (reinterpret_cast<uintptr_t>(keep) & 3u) == 0))) {
+        T2_LAUNCH(bn_act_bwd_stage1_vec_kernel, dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, M, N, mean, invstd,
+                  act, keep, ldkeep, keep_scale, ws);
+        T2_LAUNCH(bn_bwd_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, dgamma, dbeta);
+        T2_LAUNCH(bn_act_bwd_stage2_vec_kernel, dim3(t2_cdiv(N, 64), vec_row_blocks(M, N)), dim3(256), 0, s, dy, lddy, x, ldx, M, N, mean,
+                  invstd, gamma, dgamma, dbeta);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
     T2_LAUNCH(bn_act_bwd_stage1_kernel, dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, M,
                        N, mean, invstd, act, keep, ldkeep, keep_scale, ws);
     T2_LAUNCH(bn_bwd_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, dgamma, dbeta);
@@ -387,6 +640,7 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
 __global__ void philox_keep_kernel(uint8_t* __restrict__ out, long long n, float p, unsigned long long seed,
                                    unsigned long long offset) {
     const long long nquad = (n + 3) / 4;
+    const bool word_ok = (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
     for (long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x; q < nquad;
          q += (long long)gridDim.x * blockDim.x) {
         const unsigned long long ctr = offset / 4 + (unsigned long long)q;
@@ -397,6 +651,16 @@ __global__ void philox_keep_kernel(uint8_t* __restrict__ out, long long n, float
             philox_round(c, k0, k1);
             k0 += 0x9E3779B9u;
             k1 += 0xBB67AE85u;
+        }
+        if (q * 4 + 3 < n && word_ok) {                 // the four bytes of a quad as one store (same bytes)
+            unsigned w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float uu = (float)(c[j] >> 8) * (1.0f / 16777216.0f);   // [0,1)
+                w |= ((uu >= p) ? 1u : 0u) << (8 * j);
+            }
+            *reinterpret_cast<unsigned*>(out + q * 4) = w;
+            continue;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -684,8 +948,23 @@ __global__ void relu_dropout_bwd_kernel(float* __restrict__ dy, const float* __r
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         dy[i] = (y[i] > 0.f) ? dy[i] * scale : 0.f;
 }
+__global__ void relu_dropout_bwd_vec_kernel(float4* __restrict__ dy, const float4* __restrict__ y, float scale, long long n4) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 g = dy[i], v = y[i];
+        dy[i] = make_float4((v.x > 0.f) ? g.x * scale : 0.f, (v.y > 0.f) ? g.y * scale : 0.f, (v.z > 0.f) ? g.z * scale : 0.f,
+                            (v.w > 0.f) ? g.w * scale : 0.f);
+    }
+}
 extern "C" int t2amd_relu_dropout_bwd_f32(float* dy, const float* y, float scale, long long n, void* stream) {
     T2_REQUIRE(dy && y && n > 0, "relu_dropout_bwd: bad args");
+    if (!g_ew_scalar && n % 4 == 0 && t2_aligned16(dy) && t2_aligned16(y)) {
+        int b4 = t2_cdiv(n / 4, 256);
+        if (b4 > 8192) b4 = 8192;
+        T2_LAUNCH(relu_dropout_bwd_vec_kernel, dim3(b4), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<float4*>(dy),
+                  reinterpret_cast<const float4*>(y), scale, n / 4);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
     int blocks = t2_cdiv(n, 256);
     if (blocks > 8192) blocks = 8192;
     T2_LAUNCH(relu_dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, scale, n);

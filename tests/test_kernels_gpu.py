@@ -232,6 +232,49 @@ def test_bn_act_forward_backward(nv, act):
     assert err(yd, ref) < 1e-5
 
 
+@pytest.mark.parametrize("act,N", [(2, 512), (1, 80), (0, 132)])
+def test_bn_16_byte_forms_equal_the_scalar_kernels(nv, act, N):
+    """The BatchNorm apply / backward and the column reductions take a 16-byte path when N % 4 == 0 and every base is 16-byte
+    aligned (elementwise.hip, round 5).  The scalar kernels are reached here through views that start one float into a wider
+    buffer; the elementwise results must be the same bits, the fp64 row reductions (different row order) agree to float rounding."""
+    M, T = 2 * 1031, 1031
+    lens = torch.tensor([1031, 517], dtype=torch.int32, device=DEV)
+
+    def unaligned(t, dtype=torch.float32):                       # same values behind a base that is not 16-byte aligned
+        buf = torch.zeros(t.shape[0], t.shape[1] + 4, dtype=dtype, device=DEV)
+        v = buf[:, 1:1 + t.shape[1]]
+        v.copy_(t)
+        return v
+
+    x = dv(rnd(M, N, seed=40) * 1.3 + 0.2)
+    gamma, beta = dv(0.5 + torch.rand(N, generator=G(41))), dv(rnd(N, seed=42))
+    keep = dv((torch.rand(M, N, generator=G(43)) >= 0.5).to(torch.uint8))
+    gy = dv(rnd(M, N, seed=44))
+    out = {}
+    for form in ("vector", "scalar"):
+        xs = x if form == "vector" else unaligned(x)
+        ws = torch.empty(2 * 64 * N, dtype=torch.float64, device=DEV)
+        mean, invstd = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+        nv.bn_stats(xs, ws, mean, invstd)
+        y = torch.empty(M, N, device=DEV) if form == "vector" else unaligned(torch.empty(M, N, device=DEV))
+        nv.bn_act_fwd(xs, y, mean, invstd, gamma, beta, act, keep, 2.0, lens, T)
+        g = gy.clone() if form == "vector" else unaligned(gy)
+        dgamma, dbeta = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+        nv.bn_act_bwd(g, y, xs, mean, invstd, gamma, act, keep, 2.0, ws, dgamma, dbeta)
+        cs = torch.empty(N, device=DEV)
+        nv.colsum(xs, ws, cs)
+        out[form] = [t.clone().contiguous().cpu() for t in (mean, invstd, y, g, dgamma, dbeta, cs)]
+    v, s = out["vector"], out["scalar"]
+    for i in (0, 1, 4, 5, 6):                                     # statistics and parameter gradients: fp64 sums in another order
+        assert err(v[i], s[i]) < 1e-6, i
+    if torch.equal(v[0], s[0]) and torch.equal(v[1], s[1]):      # same statistics in -> same bits out of the apply
+        assert torch.equal(v[2], s[2])
+    else:
+        assert err(v[2], s[2]) < 1e-6
+    assert err(v[3], s[3]) < 1e-5
+    assert torch.all(v[2][T + 517:] == 0)                         # rows past the second utterance's length are zeroed
+
+
 def test_small_kernels(nv):
     ws = torch.empty(128 * 300, dtype=torch.float64, device=DEV)
     x = rnd(1000, 300, seed=30)
@@ -260,6 +303,13 @@ def test_small_kernels(nv):
     assert torch.equal(m2[:4096], m1[8192:8192 + 4096])
     nv.philox_keep_mask(m2, 0.1, 99, 0)
     assert not torch.equal(m1, m2)
+    # a ragged length behind a base that is not word-aligned (byte stores) gives the stream of the packed stores
+    m3 = torch.full((4200,), 7, dtype=torch.uint8, device=DEV)
+    nv.philox_keep_mask(m3[1:1 + 4099], 0.1, 1234, 0)
+    assert torch.equal(m3[1:1 + 4099], m1[:4099]) and m3[0].item() == 7 and m3[4100].item() == 7
+    m3.fill_(7)
+    nv.philox_keep_mask(m3[:4099], 0.1, 1234, 0)
+    assert torch.equal(m3[:4099], m1[:4099]) and m3[4099].item() == 7
     # copy2d / transpose / fill
     a, b = rnd(33, 70, seed=34), rnd(33, 70, seed=35)
     d = torch.zeros(40, 100, device=DEV)

@@ -1,0 +1,24 @@
+import torch, sys, os
+sys.path.insert(0, '/root/repo')
+from tacotron2_amd import native as nv
+nv.load()
+dev='cuda'
+M,N=55680,512
+x=torch.randn(M,N,device=dev); y=torch.empty_like(x); gy=torch.randn(M,N,device=dev)
+keep=(torch.rand(M,N,device=dev)>=0.5).to(torch.uint8)
+gamma=torch.rand(N,device=dev)+0.5; beta=torch.randn(N,device=dev)
+mean=torch.empty(N,device=dev); invstd=torch.empty(N,device=dev); ws=torch.empty(2*64*N,dtype=torch.float64,device=dev)
+dg=torch.empty(N,device=dev); db=torch.empty(N,device=dev); cs=torch.empty(N,device=dev)
+def t(fn,n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return 1e3*e0.elapsed_time(e1)/n
+print('scalar' if os.environ.get('T2AMD_ELEMENTWISE_SCALAR') else 'vector')
+print(' bn_stats  %.1f us'%t(lambda: nv.bn_stats(x,ws,mean,invstd)))
+print(' bn_act_fwd %.1f us'%t(lambda: nv.bn_act_fwd(x,y,mean,invstd,gamma,beta,2,keep,2.0)))
+print(' bn_act_bwd %.1f us'%t(lambda: nv.bn_act_bwd(gy,y,x,mean,invstd,gamma,2,keep,2.0,ws,dg,db)))
+print(' colsum    %.1f us'%t(lambda: nv.colsum(x,ws,cs)))
