@@ -173,7 +173,8 @@ def build_variant(tag, defines, verbose=True):
     ``lib/libtacotron2_amd_<tag>.so`` (select it with T2AMD_LIB=<path>; tools only)."""
     out = os.path.join(HERE, "lib", "libtacotron2_amd_%s.so" % tag)
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    _link(_compile_objects(OBJ_DIR + "_" + tag, ["-D" + d for d in defines], verbose), out, verbose)
+    # (an entry that starts with '-' is passed to hipcc as it is: a code-generation option instead of a define)
+    _link(_compile_objects(OBJ_DIR + "_" + tag, [d if d.startswith("-") else "-D" + d for d in defines], verbose), out, verbose)
     return out
 
 

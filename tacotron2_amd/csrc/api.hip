@@ -436,6 +436,42 @@ extern "C" int t2amd_debug_hold_cus_(int ncus, float ms, const int* stop, int* a
     return T2AMD_OK;
 }
 
+// tests only (tools/stress_lds_poison.py, tests/test_zz9c_lds_poison_gpu.py): `launches` short kernels of `nwg` workgroups that
+// fill `lds_bytes` of LDS each with `pattern` (0x7fc07fc0: a NaN as f32 and as two bf16) and leave.  Run on a side stream beside
+// the engine's kernels they stand in for ANOTHER PROCESS's kernels on the same CUs: what a workgroup finds in LDS it has not
+// written is then no longer what this process's previous launch left there.  A kernel that reads LDS before writing it (or
+// relies on wave timing instead of a barrier) gives different bits under this; every kernel of the path must not.
+__global__ void t2_poison_lds_kernel(unsigned pattern, int words) {
+    extern __shared__ unsigned poison_smem[];
+    for (int i = threadIdx.x; i < words; i += blockDim.x) poison_smem[i] = pattern;
+    __syncthreads();
+    if (poison_smem[(threadIdx.x * 97) % words] != pattern) __builtin_trap();      // keeps the stores alive
+}
+extern "C" int t2amd_debug_poison_lds_(int nwg, int lds_bytes, unsigned pattern, int launches, void* stream) {
+    T2_REQUIRE(nwg > 0 && nwg <= 4096 && lds_bytes >= 1024 && lds_bytes <= 160 * 1024 && launches > 0 && launches <= 100000,
+               "debug_poison_lds: bad args");
+    if (hipFuncSetAttribute((const void*)t2_poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        T2_FAIL("debug_poison_lds: cannot raise the LDS limit");
+    for (int i = 0; i < launches; ++i)
+        hipLaunchKernelGGL(t2_poison_lds_kernel, dim3(nwg), dim3(256), lds_bytes, (hipStream_t)stream, pattern, lds_bytes / 4);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// tests only: what the LDS poison does for LDS, for the REGISTER file: every VGPR (v8..v255) and AGPR of every lane holds
+// `pattern` when the wave leaves.  A wave of the engine that starts on that SIMD next and reads a register it has not written
+// (the compiler calls that undef; alone on the GPU it finds its own previous launch's values there) now reads NaN.
+__global__ __launch_bounds__(256) void t2_poison_regs_kernel(unsigned pattern) {
+    asm volatile("v_mov_b32 v8, %0\nv_mov_b32 v9, %0\nv_mov_b32 v10, %0\nv_mov_b32 v11, %0\nv_mov_b32 v12, %0\nv_mov_b32 v13, %0\nv_mov_b32 v14, %0\nv_mov_b32 v15, %0\nv_mov_b32 v16, %0\nv_mov_b32 v17, %0\nv_mov_b32 v18, %0\nv_mov_b32 v19, %0\nv_mov_b32 v20, %0\nv_mov_b32 v21, %0\nv_mov_b32 v22, %0\nv_mov_b32 v23, %0\nv_mov_b32 v24, %0\nv_mov_b32 v25, %0\nv_mov_b32 v26, %0\nv_mov_b32 v27, %0\nv_mov_b32 v28, %0\nv_mov_b32 v29, %0\nv_mov_b32 v30, %0\nv_mov_b32 v31, %0\nv_mov_b32 v32, %0\nv_mov_b32 v33, %0\nv_mov_b32 v34, %0\nv_mov_b32 v35, %0\nv_mov_b32 v36, %0\nv_mov_b32 v37, %0\nv_mov_b32 v38, %0\nv_mov_b32 v39, %0\nv_mov_b32 v40, %0\nv_mov_b32 v41, %0\nv_mov_b32 v42, %0\nv_mov_b32 v43, %0\nv_mov_b32 v44, %0\nv_mov_b32 v45, %0\nv_mov_b32 v46, %0\nv_mov_b32 v47, %0\nv_mov_b32 v48, %0\nv_mov_b32 v49, %0\nv_mov_b32 v50, %0\nv_mov_b32 v51, %0\nv_mov_b32 v52, %0\nv_mov_b32 v53, %0\nv_mov_b32 v54, %0\nv_mov_b32 v55, %0\nv_mov_b32 v56, %0\nv_mov_b32 v57, %0\nv_mov_b32 v58, %0\nv_mov_b32 v59, %0\nv_mov_b32 v60, %0\nv_mov_b32 v61, %0\nv_mov_b32 v62, %0\nv_mov_b32 v63, %0\nv_mov_b32 v64, %0\nv_mov_b32 v65, %0\nv_mov_b32 v66, %0\nv_mov_b32 v67, %0\nv_mov_b32 v68, %0\nv_mov_b32 v69, %0\nv_mov_b32 v70, %0\nv_mov_b32 v71, %0\nv_mov_b32 v72, %0\nv_mov_b32 v73, %0\nv_mov_b32 v74, %0\nv_mov_b32 v75, %0\nv_mov_b32 v76, %0\nv_mov_b32 v77, %0\nv_mov_b32 v78, %0\nv_mov_b32 v79, %0\nv_mov_b32 v80, %0\nv_mov_b32 v81, %0\nv_mov_b32 v82, %0\nv_mov_b32 v83, %0\nv_mov_b32 v84, %0\nv_mov_b32 v85, %0\nv_mov_b32 v86, %0\nv_mov_b32 v87, %0\nv_mov_b32 v88, %0\nv_mov_b32 v89, %0\nv_mov_b32 v90, %0\nv_mov_b32 v91, %0\nv_mov_b32 v92, %0\nv_mov_b32 v93, %0\nv_mov_b32 v94, %0\nv_mov_b32 v95, %0\nv_mov_b32 v96, %0\nv_mov_b32 v97, %0\nv_mov_b32 v98, %0\nv_mov_b32 v99, %0\nv_mov_b32 v100, %0\nv_mov_b32 v101, %0\nv_mov_b32 v102, %0\nv_mov_b32 v103, %0\nv_mov_b32 v104, %0\nv_mov_b32 v105, %0\nv_mov_b32 v106, %0\nv_mov_b32 v107, %0\nv_mov_b32 v108, %0\nv_mov_b32 v109, %0\nv_mov_b32 v110, %0\nv_mov_b32 v111, %0\nv_mov_b32 v112, %0\nv_mov_b32 v113, %0\nv_mov_b32 v114, %0\nv_mov_b32 v115, %0\nv_mov_b32 v116, %0\nv_mov_b32 v117, %0\nv_mov_b32 v118, %0\nv_mov_b32 v119, %0\nv_mov_b32 v120, %0\nv_mov_b32 v121, %0\nv_mov_b32 v122, %0\nv_mov_b32 v123, %0\nv_mov_b32 v124, %0\nv_mov_b32 v125, %0\nv_mov_b32 v126, %0\nv_mov_b32 v127, %0\nv_mov_b32 v128, %0\nv_mov_b32 v129, %0\nv_mov_b32 v130, %0\nv_mov_b32 v131, %0\nv_mov_b32 v132, %0\nv_mov_b32 v133, %0\nv_mov_b32 v134, %0\nv_mov_b32 v135, %0\nv_mov_b32 v136, %0\nv_mov_b32 v137, %0\nv_mov_b32 v138, %0\nv_mov_b32 v139, %0\nv_mov_b32 v140, %0\nv_mov_b32 v141, %0\nv_mov_b32 v142, %0\nv_mov_b32 v143, %0\nv_mov_b32 v144, %0\nv_mov_b32 v145, %0\nv_mov_b32 v146, %0\nv_mov_b32 v147, %0\nv_mov_b32 v148, %0\nv_mov_b32 v149, %0\nv_mov_b32 v150, %0\nv_mov_b32 v151, %0\nv_mov_b32 v152, %0\nv_mov_b32 v153, %0\nv_mov_b32 v154, %0\nv_mov_b32 v155, %0\nv_mov_b32 v156, %0\nv_mov_b32 v157, %0\nv_mov_b32 v158, %0\nv_mov_b32 v159, %0\nv_mov_b32 v160, %0\nv_mov_b32 v161, %0\nv_mov_b32 v162, %0\nv_mov_b32 v163, %0\nv_mov_b32 v164, %0\nv_mov_b32 v165, %0\nv_mov_b32 v166, %0\nv_mov_b32 v167, %0\nv_mov_b32 v168, %0\nv_mov_b32 v169, %0\nv_mov_b32 v170, %0\nv_mov_b32 v171, %0\nv_mov_b32 v172, %0\nv_mov_b32 v173, %0\nv_mov_b32 v174, %0\nv_mov_b32 v175, %0\nv_mov_b32 v176, %0\nv_mov_b32 v177, %0\nv_mov_b32 v178, %0\nv_mov_b32 v179, %0\nv_mov_b32 v180, %0\nv_mov_b32 v181, %0\nv_mov_b32 v182, %0\nv_mov_b32 v183, %0\nv_mov_b32 v184, %0\nv_mov_b32 v185, %0\nv_mov_b32 v186, %0\nv_mov_b32 v187, %0\nv_mov_b32 v188, %0\nv_mov_b32 v189, %0\nv_mov_b32 v190, %0\nv_mov_b32 v191, %0\nv_mov_b32 v192, %0\nv_mov_b32 v193, %0\nv_mov_b32 v194, %0\nv_mov_b32 v195, %0\nv_mov_b32 v196, %0\nv_mov_b32 v197, %0\nv_mov_b32 v198, %0\nv_mov_b32 v199, %0\nv_mov_b32 v200, %0\nv_mov_b32 v201, %0\nv_mov_b32 v202, %0\nv_mov_b32 v203, %0\nv_mov_b32 v204, %0\nv_mov_b32 v205, %0\nv_mov_b32 v206, %0\nv_mov_b32 v207, %0\nv_mov_b32 v208, %0\nv_mov_b32 v209, %0\nv_mov_b32 v210, %0\nv_mov_b32 v211, %0\nv_mov_b32 v212, %0\nv_mov_b32 v213, %0\nv_mov_b32 v214, %0\nv_mov_b32 v215, %0\nv_mov_b32 v216, %0\nv_mov_b32 v217, %0\nv_mov_b32 v218, %0\nv_mov_b32 v219, %0\nv_mov_b32 v220, %0\nv_mov_b32 v221, %0\nv_mov_b32 v222, %0\nv_mov_b32 v223, %0\nv_mov_b32 v224, %0\nv_mov_b32 v225, %0\nv_mov_b32 v226, %0\nv_mov_b32 v227, %0\nv_mov_b32 v228, %0\nv_mov_b32 v229, %0\nv_mov_b32 v230, %0\nv_mov_b32 v231, %0\nv_mov_b32 v232, %0\nv_mov_b32 v233, %0\nv_mov_b32 v234, %0\nv_mov_b32 v235, %0\nv_mov_b32 v236, %0\nv_mov_b32 v237, %0\nv_mov_b32 v238, %0\nv_mov_b32 v239, %0\nv_mov_b32 v240, %0\nv_mov_b32 v241, %0\nv_mov_b32 v242, %0\nv_mov_b32 v243, %0\nv_mov_b32 v244, %0\nv_mov_b32 v245, %0\nv_mov_b32 v246, %0\nv_mov_b32 v247, %0\nv_mov_b32 v248, %0\nv_mov_b32 v249, %0\nv_mov_b32 v250, %0\nv_mov_b32 v251, %0\nv_mov_b32 v252, %0\nv_mov_b32 v253, %0\nv_mov_b32 v254, %0\nv_mov_b32 v255, %0\n" :: "v"(pattern) : "v8","v9","v10","v11","v12","v13","v14","v15","v16","v17","v18","v19","v20","v21","v22","v23","v24","v25","v26","v27","v28","v29","v30","v31","v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","v68","v69","v70","v71","v72","v73","v74","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","v88","v89","v90","v91","v92","v93","v94","v95","v96","v97","v98","v99","v100","v101","v102","v103","v104","v105","v106","v107","v108","v109","v110","v111","v112","v113","v114","v115","v116","v117","v118","v119","v120","v121","v122","v123","v124","v125","v126","v127","v128","v129","v130","v131","v132","v133","v134","v135","v136","v137","v138","v139","v140","v141","v142","v143","v144","v145","v146","v147","v148","v149","v150","v151","v152","v153","v154","v155","v156","v157","v158","v159","v160","v161","v162","v163","v164","v165","v166","v167","v168","v169","v170","v171","v172","v173","v174","v175","v176","v177","v178","v179","v180","v181","v182","v183","v184","v185","v186","v187","v188","v189","v190","v191","v192","v193","v194","v195","v196","v197","v198","v199","v200","v201","v202","v203","v204","v205","v206","v207","v208","v209","v210","v211","v212","v213","v214","v215","v216","v217","v218","v219","v220","v221","v222","v223","v224","v225","v226","v227","v228","v229","v230","v231","v232","v233","v234","v235","v236","v237","v238","v239","v240","v241","v242","v243","v244","v245","v246","v247","v248","v249","v250","v251","v252","v253","v254","v255");
+    asm volatile("v_accvgpr_write_b32 a0, %0\nv_accvgpr_write_b32 a1, %0\nv_accvgpr_write_b32 a2, %0\nv_accvgpr_write_b32 a3, %0\nv_accvgpr_write_b32 a4, %0\nv_accvgpr_write_b32 a5, %0\nv_accvgpr_write_b32 a6, %0\nv_accvgpr_write_b32 a7, %0\nv_accvgpr_write_b32 a8, %0\nv_accvgpr_write_b32 a9, %0\nv_accvgpr_write_b32 a10, %0\nv_accvgpr_write_b32 a11, %0\nv_accvgpr_write_b32 a12, %0\nv_accvgpr_write_b32 a13, %0\nv_accvgpr_write_b32 a14, %0\nv_accvgpr_write_b32 a15, %0\nv_accvgpr_write_b32 a16, %0\nv_accvgpr_write_b32 a17, %0\nv_accvgpr_write_b32 a18, %0\nv_accvgpr_write_b32 a19, %0\nv_accvgpr_write_b32 a20, %0\nv_accvgpr_write_b32 a21, %0\nv_accvgpr_write_b32 a22, %0\nv_accvgpr_write_b32 a23, %0\nv_accvgpr_write_b32 a24, %0\nv_accvgpr_write_b32 a25, %0\nv_accvgpr_write_b32 a26, %0\nv_accvgpr_write_b32 a27, %0\nv_accvgpr_write_b32 a28, %0\nv_accvgpr_write_b32 a29, %0\nv_accvgpr_write_b32 a30, %0\nv_accvgpr_write_b32 a31, %0\nv_accvgpr_write_b32 a32, %0\nv_accvgpr_write_b32 a33, %0\nv_accvgpr_write_b32 a34, %0\nv_accvgpr_write_b32 a35, %0\nv_accvgpr_write_b32 a36, %0\nv_accvgpr_write_b32 a37, %0\nv_accvgpr_write_b32 a38, %0\nv_accvgpr_write_b32 a39, %0\nv_accvgpr_write_b32 a40, %0\nv_accvgpr_write_b32 a41, %0\nv_accvgpr_write_b32 a42, %0\nv_accvgpr_write_b32 a43, %0\nv_accvgpr_write_b32 a44, %0\nv_accvgpr_write_b32 a45, %0\nv_accvgpr_write_b32 a46, %0\nv_accvgpr_write_b32 a47, %0\nv_accvgpr_write_b32 a48, %0\nv_accvgpr_write_b32 a49, %0\nv_accvgpr_write_b32 a50, %0\nv_accvgpr_write_b32 a51, %0\nv_accvgpr_write_b32 a52, %0\nv_accvgpr_write_b32 a53, %0\nv_accvgpr_write_b32 a54, %0\nv_accvgpr_write_b32 a55, %0\nv_accvgpr_write_b32 a56, %0\nv_accvgpr_write_b32 a57, %0\nv_accvgpr_write_b32 a58, %0\nv_accvgpr_write_b32 a59, %0\nv_accvgpr_write_b32 a60, %0\nv_accvgpr_write_b32 a61, %0\nv_accvgpr_write_b32 a62, %0\nv_accvgpr_write_b32 a63, %0\nv_accvgpr_write_b32 a64, %0\nv_accvgpr_write_b32 a65, %0\nv_accvgpr_write_b32 a66, %0\nv_accvgpr_write_b32 a67, %0\nv_accvgpr_write_b32 a68, %0\nv_accvgpr_write_b32 a69, %0\nv_accvgpr_write_b32 a70, %0\nv_accvgpr_write_b32 a71, %0\nv_accvgpr_write_b32 a72, %0\nv_accvgpr_write_b32 a73, %0\nv_accvgpr_write_b32 a74, %0\nv_accvgpr_write_b32 a75, %0\nv_accvgpr_write_b32 a76, %0\nv_accvgpr_write_b32 a77, %0\nv_accvgpr_write_b32 a78, %0\nv_accvgpr_write_b32 a79, %0\nv_accvgpr_write_b32 a80, %0\nv_accvgpr_write_b32 a81, %0\nv_accvgpr_write_b32 a82, %0\nv_accvgpr_write_b32 a83, %0\nv_accvgpr_write_b32 a84, %0\nv_accvgpr_write_b32 a85, %0\nv_accvgpr_write_b32 a86, %0\nv_accvgpr_write_b32 a87, %0\nv_accvgpr_write_b32 a88, %0\nv_accvgpr_write_b32 a89, %0\nv_accvgpr_write_b32 a90, %0\nv_accvgpr_write_b32 a91, %0\nv_accvgpr_write_b32 a92, %0\nv_accvgpr_write_b32 a93, %0\nv_accvgpr_write_b32 a94, %0\nv_accvgpr_write_b32 a95, %0\nv_accvgpr_write_b32 a96, %0\nv_accvgpr_write_b32 a97, %0\nv_accvgpr_write_b32 a98, %0\nv_accvgpr_write_b32 a99, %0\nv_accvgpr_write_b32 a100, %0\nv_accvgpr_write_b32 a101, %0\nv_accvgpr_write_b32 a102, %0\nv_accvgpr_write_b32 a103, %0\nv_accvgpr_write_b32 a104, %0\nv_accvgpr_write_b32 a105, %0\nv_accvgpr_write_b32 a106, %0\nv_accvgpr_write_b32 a107, %0\nv_accvgpr_write_b32 a108, %0\nv_accvgpr_write_b32 a109, %0\nv_accvgpr_write_b32 a110, %0\nv_accvgpr_write_b32 a111, %0\nv_accvgpr_write_b32 a112, %0\nv_accvgpr_write_b32 a113, %0\nv_accvgpr_write_b32 a114, %0\nv_accvgpr_write_b32 a115, %0\nv_accvgpr_write_b32 a116, %0\nv_accvgpr_write_b32 a117, %0\nv_accvgpr_write_b32 a118, %0\nv_accvgpr_write_b32 a119, %0\nv_accvgpr_write_b32 a120, %0\nv_accvgpr_write_b32 a121, %0\nv_accvgpr_write_b32 a122, %0\nv_accvgpr_write_b32 a123, %0\nv_accvgpr_write_b32 a124, %0\nv_accvgpr_write_b32 a125, %0\nv_accvgpr_write_b32 a126, %0\nv_accvgpr_write_b32 a127, %0\nv_accvgpr_write_b32 a128, %0\nv_accvgpr_write_b32 a129, %0\nv_accvgpr_write_b32 a130, %0\nv_accvgpr_write_b32 a131, %0\nv_accvgpr_write_b32 a132, %0\nv_accvgpr_write_b32 a133, %0\nv_accvgpr_write_b32 a134, %0\nv_accvgpr_write_b32 a135, %0\nv_accvgpr_write_b32 a136, %0\nv_accvgpr_write_b32 a137, %0\nv_accvgpr_write_b32 a138, %0\nv_accvgpr_write_b32 a139, %0\nv_accvgpr_write_b32 a140, %0\nv_accvgpr_write_b32 a141, %0\nv_accvgpr_write_b32 a142, %0\nv_accvgpr_write_b32 a143, %0\nv_accvgpr_write_b32 a144, %0\nv_accvgpr_write_b32 a145, %0\nv_accvgpr_write_b32 a146, %0\nv_accvgpr_write_b32 a147, %0\nv_accvgpr_write_b32 a148, %0\nv_accvgpr_write_b32 a149, %0\nv_accvgpr_write_b32 a150, %0\nv_accvgpr_write_b32 a151, %0\nv_accvgpr_write_b32 a152, %0\nv_accvgpr_write_b32 a153, %0\nv_accvgpr_write_b32 a154, %0\nv_accvgpr_write_b32 a155, %0\nv_accvgpr_write_b32 a156, %0\nv_accvgpr_write_b32 a157, %0\nv_accvgpr_write_b32 a158, %0\nv_accvgpr_write_b32 a159, %0\nv_accvgpr_write_b32 a160, %0\nv_accvgpr_write_b32 a161, %0\nv_accvgpr_write_b32 a162, %0\nv_accvgpr_write_b32 a163, %0\nv_accvgpr_write_b32 a164, %0\nv_accvgpr_write_b32 a165, %0\nv_accvgpr_write_b32 a166, %0\nv_accvgpr_write_b32 a167, %0\nv_accvgpr_write_b32 a168, %0\nv_accvgpr_write_b32 a169, %0\nv_accvgpr_write_b32 a170, %0\nv_accvgpr_write_b32 a171, %0\nv_accvgpr_write_b32 a172, %0\nv_accvgpr_write_b32 a173, %0\nv_accvgpr_write_b32 a174, %0\nv_accvgpr_write_b32 a175, %0\nv_accvgpr_write_b32 a176, %0\nv_accvgpr_write_b32 a177, %0\nv_accvgpr_write_b32 a178, %0\nv_accvgpr_write_b32 a179, %0\nv_accvgpr_write_b32 a180, %0\nv_accvgpr_write_b32 a181, %0\nv_accvgpr_write_b32 a182, %0\nv_accvgpr_write_b32 a183, %0\nv_accvgpr_write_b32 a184, %0\nv_accvgpr_write_b32 a185, %0\nv_accvgpr_write_b32 a186, %0\nv_accvgpr_write_b32 a187, %0\nv_accvgpr_write_b32 a188, %0\nv_accvgpr_write_b32 a189, %0\nv_accvgpr_write_b32 a190, %0\nv_accvgpr_write_b32 a191, %0\nv_accvgpr_write_b32 a192, %0\nv_accvgpr_write_b32 a193, %0\nv_accvgpr_write_b32 a194, %0\nv_accvgpr_write_b32 a195, %0\nv_accvgpr_write_b32 a196, %0\nv_accvgpr_write_b32 a197, %0\nv_accvgpr_write_b32 a198, %0\nv_accvgpr_write_b32 a199, %0\nv_accvgpr_write_b32 a200, %0\nv_accvgpr_write_b32 a201, %0\nv_accvgpr_write_b32 a202, %0\nv_accvgpr_write_b32 a203, %0\nv_accvgpr_write_b32 a204, %0\nv_accvgpr_write_b32 a205, %0\nv_accvgpr_write_b32 a206, %0\nv_accvgpr_write_b32 a207, %0\nv_accvgpr_write_b32 a208, %0\nv_accvgpr_write_b32 a209, %0\nv_accvgpr_write_b32 a210, %0\nv_accvgpr_write_b32 a211, %0\nv_accvgpr_write_b32 a212, %0\nv_accvgpr_write_b32 a213, %0\nv_accvgpr_write_b32 a214, %0\nv_accvgpr_write_b32 a215, %0\nv_accvgpr_write_b32 a216, %0\nv_accvgpr_write_b32 a217, %0\nv_accvgpr_write_b32 a218, %0\nv_accvgpr_write_b32 a219, %0\nv_accvgpr_write_b32 a220, %0\nv_accvgpr_write_b32 a221, %0\nv_accvgpr_write_b32 a222, %0\nv_accvgpr_write_b32 a223, %0\nv_accvgpr_write_b32 a224, %0\nv_accvgpr_write_b32 a225, %0\nv_accvgpr_write_b32 a226, %0\nv_accvgpr_write_b32 a227, %0\nv_accvgpr_write_b32 a228, %0\nv_accvgpr_write_b32 a229, %0\nv_accvgpr_write_b32 a230, %0\nv_accvgpr_write_b32 a231, %0\nv_accvgpr_write_b32 a232, %0\nv_accvgpr_write_b32 a233, %0\nv_accvgpr_write_b32 a234, %0\nv_accvgpr_write_b32 a235, %0\nv_accvgpr_write_b32 a236, %0\nv_accvgpr_write_b32 a237, %0\nv_accvgpr_write_b32 a238, %0\nv_accvgpr_write_b32 a239, %0\nv_accvgpr_write_b32 a240, %0\nv_accvgpr_write_b32 a241, %0\nv_accvgpr_write_b32 a242, %0\nv_accvgpr_write_b32 a243, %0\nv_accvgpr_write_b32 a244, %0\nv_accvgpr_write_b32 a245, %0\nv_accvgpr_write_b32 a246, %0\nv_accvgpr_write_b32 a247, %0\nv_accvgpr_write_b32 a248, %0\nv_accvgpr_write_b32 a249, %0\nv_accvgpr_write_b32 a250, %0\nv_accvgpr_write_b32 a251, %0\nv_accvgpr_write_b32 a252, %0\nv_accvgpr_write_b32 a253, %0\nv_accvgpr_write_b32 a254, %0\nv_accvgpr_write_b32 a255, %0\n" :: "v"(pattern) : "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255");
+}
+extern "C" int t2amd_debug_poison_regs_(int nwg, unsigned pattern, int launches, void* stream) {
+    T2_REQUIRE(nwg > 0 && nwg <= 8192 && launches > 0 && launches <= 100000, "debug_poison_regs: bad args");
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(t2_poison_regs_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, pattern);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 // A HIP stream whose kernels run on CUs [first, first + count) only (hipExtStreamCreateWithCUMask): lets a latency-bound
 // chain of small launches and a throughput product run side by side without competing for the same CUs.
 extern "C" void* t2amd_debug_stream_cu_range_(int first, int count) {

@@ -1582,6 +1582,19 @@ struct AttnBwdParams {
 // the next ~7 us) instead of in front of this phase: loads return in order, and this phase's dw -- what the utterance's three other
 // workgroups are waiting for -- used to queue behind them.
 struct KbNoHook { __device__ __forceinline__ void operator()() const {} };
+// a * b + c as ONE v_fma_f32 that the vectoriser cannot pair into a v_pk_fma_f32 (round 5).  The f32 form of
+// K_b1 accumulated its rows with packed FMAs whose DESTINATION pair was also a source pair read with a cross-half op_sel
+// (`v_pk_fma_f32 v[34:35], v[10:11], v[34:35], v[66:67] op_sel:[0,1,0]`: both results read v35, one of them overwrites it): correct
+// alone on the GPU in every run of four rounds, WRONG in lanes 48..63 of a wave (one row in two, 16 lanes of its dot product) in
+// 60 % of the launches as soon as another kernel's MFMA waves share the SIMD -- a second process, or a GEMM on a side stream
+// (tools/stress_attn_bwd.py; this is what tests/test_zz9_dp_gpu.py saw once in round 2 and again in round 5).  The library is now
+// built without packed-f32 instructions altogether (build.py); this helper keeps the one place where the fault was PROVEN
+// unpacked even in a build that turns them back on.
+__device__ __forceinline__ float t2_fma_unpacked(float a, float b, float c) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // What K_b1 has in flight between the issue of its loads and their first use (round 5: the two halves are separate functions, so
 // that the one-launch backward can issue this phase's loads -- memory rows, gradient slabs, carries: what its dw, the thing the
 // utterance's three other workgroups wait for, is made of -- as the FIRST loads of the launch, ahead of its own prologue).
@@ -1780,10 +1793,10 @@ __device__ __forceinline__ void kb1_consume(const AttnBwdParams& p, float* smem,
                         const float4 gq = *reinterpret_cast<const float4*>(&dctx_s[c * 4]);
 #pragma unroll
                         for (int i = 0; i < KB1_MAXP; ++i) {
-                            acc[i] = fmaf(pm[g][i].x, gq.x, acc[i]);
-                            acc[i] = fmaf(pm[g][i].y, gq.y, acc[i]);
-                            acc[i] = fmaf(pm[g][i].z, gq.z, acc[i]);
-                            acc[i] = fmaf(pm[g][i].w, gq.w, acc[i]);
+                            acc[i] = t2_fma_unpacked(pm[g][i].x, gq.x, acc[i]);
+                            acc[i] = t2_fma_unpacked(pm[g][i].y, gq.y, acc[i]);
+                            acc[i] = t2_fma_unpacked(pm[g][i].z, gq.z, acc[i]);
+                            acc[i] = t2_fma_unpacked(pm[g][i].w, gq.w, acc[i]);
                         }
                     }
                 }
@@ -1801,10 +1814,10 @@ __device__ __forceinline__ void kb1_consume(const AttnBwdParams& p, float* smem,
                 if constexpr (M16) {
                     acc[i] = dot8_bf16(m, gq, gq1, acc[i]);
                 } else {
-                    acc[i] = fmaf(m.x, gq.x, acc[i]);
-                    acc[i] = fmaf(m.y, gq.y, acc[i]);
-                    acc[i] = fmaf(m.z, gq.z, acc[i]);
-                    acc[i] = fmaf(m.w, gq.w, acc[i]);
+                    acc[i] = t2_fma_unpacked(m.x, gq.x, acc[i]);
+                    acc[i] = t2_fma_unpacked(m.y, gq.y, acc[i]);
+                    acc[i] = t2_fma_unpacked(m.z, gq.z, acc[i]);
+                    acc[i] = t2_fma_unpacked(m.w, gq.w, acc[i]);
                 }
             }
         }

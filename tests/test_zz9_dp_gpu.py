@@ -132,13 +132,27 @@ def _worker(rank, world, port, precision, q):
         # therefore repeated REPEATS more times in this process pair (same weights, same shard, same masks: the same
         # expected mean every time); any repeat that differs is reported with its index and tensor.
         first = {k: g.clone() for k, g in grads.items()}
-        unequal_repeats = 0
+        unequal_repeats, notes = 0, []
         for rep in range(1, 1 + int(os.environ.get("T2AMD_DP_REPEATS", "24"))):
-            _, g2 = run(rank)
+            l2, g2 = run(rank)
             compare(g2, rep)
-            unequal_repeats += int(any(not torch.equal(g2[k], first[k]) for k in first))
-        assert not bad, bad[:12]
-        assert unequal_repeats == 0, "%d repeats of the same exchange were not bit-identical to the first" % unequal_repeats
+            diff = [k for k in first if not torch.equal(g2[k], first[k])]
+            if diff:
+                # what a repeat that differs looked like (round 5 saw ONE in ~30 runs of this test, after the one of round 2):
+                # whether this rank's OWN loss moved (its forward / inputs) or only the exchanged gradients did (the other
+                # rank's step or the exchange), how many tensors and how many elements of the first one
+                unequal_repeats += 1
+                k0 = diff[0]
+                notes.append(dict(repeat=rep, rank=rank, own_loss_equal=bool(torch.equal(l2, loss)), tensors=len(diff), of=len(first),
+                                  names=[k for k in first if k not in diff] if len(diff) > len(first) // 2 else diff, names_are='EQUAL tensors' if len(diff) > len(first) // 2 else 'differing tensors',
+                                  first=k0, elements=int((g2[k0] != first[k0]).sum()), numel=g2[k0].numel(),
+                                  max_rel=float((g2[k0].double() - first[k0].double()).abs().max() / (first[k0].double().abs().max() + 1e-30))))
+        if notes:
+            import json
+            with open(os.path.join(logdir, "dp_unequal_repeats_rank%d_%s.json" % (rank, precision)), "w") as f:
+                json.dump(notes, f, indent=1)
+        assert not bad, (notes[:3], bad[:12])
+        assert unequal_repeats == 0, ("%d repeats of the same exchange were not bit-identical to the first" % unequal_repeats, notes[:3])
         # one optimiser step on the averaged gradients keeps the ranks identical
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)

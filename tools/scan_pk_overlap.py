@@ -1,0 +1,74 @@
+"""Scan the gfx950 ISA of every csrc/*.hip for packed-f32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose
+DESTINATION register pair is also a SOURCE pair that is read with a cross-half selection (op_sel / op_sel_hi): the low result
+reading the pair's high dword, or the high result reading its low dword.  Round 5 found that such an instruction can give wrong
+results in the last lanes of a wave when the SIMD is shared with another kernel's waves; the engine's
+kernels must not contain any.  Exit code 1 when one is found.
+
+    python tools/scan_pk_overlap.py            # compiles every csrc/*.hip to assembly (hipcc -S) and scans it
+"""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAT = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\s+(.*)$")
+
+
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return int(m.group(1)), int(m.group(2))
+    m = re.match(r"v(\d+)$", tok)
+    if m:
+        return int(m.group(1)), int(m.group(1))
+    return None
+
+
+def scan(path):
+    hits, n, fn = [], 0, "?"
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            fn = m.group(1)
+        m = PAT.match(line)
+        if not m:
+            continue
+        n += 1
+        body = m.group(2).split(";")[0]
+        mods = dict((k, [int(x) for x in v.split(",")]) for k, v in re.findall(r"(op_sel_hi|op_sel|neg_lo|neg_hi):\[([\d,]+)\]", body))
+        ops = [t.strip() for t in re.sub(r"\s+(op_sel|op_sel_hi|neg_lo|neg_hi):\[[\d,]+\]", "", body).split(",")]
+        dst, srcs = regs(ops[0]), ops[1:]
+        sel = mods.get("op_sel", [0, 0, 0]) + [0, 0, 0]
+        selhi = mods.get("op_sel_hi", [1, 1, 1]) + [1, 1, 1]
+        for k, stok in enumerate(srcs):
+            r = regs(stok)
+            if r is None or dst is None or r[1] < dst[0] or r[0] > dst[1]:
+                continue
+            if sel[k] == 1 or selhi[k] == 0:            # low result reads the high dword, or high result reads the low dword
+                hits.append((fn, line.strip()))
+    return n, hits
+
+
+def main():
+    out = tempfile.mkdtemp(prefix="pkscan_")
+    total, bad = 0, []
+    extra = sys.argv[1:]
+    for src in sorted(glob.glob(os.path.join(ROOT, "tacotron2_amd", "csrc", "*.hip"))):
+        asm = os.path.join(out, os.path.basename(src)[:-4] + ".s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src] + extra,
+                       check=True, stderr=subprocess.DEVNULL, cwd=out)
+        n, hits = scan(asm)
+        total += n
+        bad += [(os.path.basename(src),) + h for h in hits]
+        print("%-22s %5d packed-f32 instructions, %3d with a swizzled source on the destination pair" % (os.path.basename(src), n, len(hits)))
+    for f, fn, line in bad[:60]:
+        print("  %s  %s\n      %s" % (f, subprocess.run(["c++filt", fn], capture_output=True, text=True).stdout.strip()[:110], line))
+    print("total: %d packed-f32 instructions, %d hazardous" % (total, len(bad)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
