@@ -1,3 +1,8 @@
+"""A second process that keeps the GPU busy for <seconds>: `mm` = 2048^3 bf16 GEMMs (MFMA waves on every SIMD), `ew` = a memory-bound
+elementwise kernel.  Beside tools/stress_attn_bwd.py / tools/stress_lds_poison.py.
+
+    python tools/gpu_hammer.py 60 mm &
+"""
 import sys, time, torch
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30
 kind = sys.argv[2] if len(sys.argv) > 2 else "mm"

@@ -1,5 +1,10 @@
+"""BatchNorm statistics / apply / backward and the column sum at the postnet's size (55 680 x 512), us per call: the 16-byte forms
+(default) or, with T2AMD_ELEMENTWISE_SCALAR=1, the scalar kernels they replaced in round 5.
+
+    python tools/microbench_bn.py; T2AMD_ELEMENTWISE_SCALAR=1 python tools/microbench_bn.py
+"""
 import torch, sys, os
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tacotron2_amd import native as nv
 nv.load()
 dev='cuda'

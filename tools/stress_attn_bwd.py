@@ -1,5 +1,13 @@
+"""One attention-backward step (t2amd_attention_step_bwd_f32) repeated from the same inputs, every output compared bit for bit with
+the first run -- optionally with a side stream of this process multiplying matrices (INPROC=<GEMMs per repeat>), with register-file
+poison kernels beside it (REGPOISON=<launches per repeat>), or while `python tools/gpu_hammer.py <seconds> mm` runs in another
+process.  This is how round 5 pinned the nondeterminism of tests/test_zz9_dp_gpu.py on ONE kernel and ONE instruction pattern
+(DESIGN.md section 5.3).
+
+    INPROC=30 python tools/stress_attn_bwd.py <fused 0|1> <B> <Ti> <repeats> <steps per repeat> [m16]
+"""
 import sys, os, json, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tacotron2_amd import native as nv
 nv.load()
 fused = int(sys.argv[1]) if len(sys.argv) > 1 else 0
@@ -18,7 +26,7 @@ lens = torch.tensor(([Ti, max(1, Ti - 6), max(1, Ti // 2)] * B)[:B], dtype=torch
 if os.environ.get('FULL_LENS'): lens.fill_(Ti)
 w = torch.softmax(rnd(B, Ti), 1); wprev = torch.softmax(rnd(B, Ti), 1); cum = torch.rand(B, Ti, generator=g).to(dev)
 q, dctx, dwx = rnd(B, 128), rnd(B, E), rnd(B, Ti)
-ws0 = torch.zeros(nv.attn_bwd_ws_floats(B, Ti) + 32768, device=dev)
+ws0 = torch.zeros(nv.attn_bwd_ws_floats(B, Ti) , device=dev)
 dwin0, dcum0 = rnd(4, B, 2, Ti), rnd(B, Ti)
 names = ("tot", "dwin", "dcum", "d_pm", "dU", "dv", "dq", "dh", "ws")
 side = torch.cuda.Stream()
@@ -40,7 +48,7 @@ def once():
     for step in range(nsteps):
         nv.attention_step_bwd([dctx], tot, dwx, q, Wq, U, v, pm, mem, lens, w, wprev, cum, dwin, dcum, d_pm, dU, dv_, dq, dh, ws, bf16=m16, memory16=mem.bfloat16() if m16 else None)
     torch.cuda.synchronize()
-    out = [t.clone() for t in (tot, dwin, dcum, d_pm, dU, dv_, dq, dh, ws[:B * Ti + 12 * B], ws[-32768:])]
+    out = [t.clone() for t in (tot, dwin, dcum, d_pm, dU, dv_, dq, dh, ws[:B * Ti + 12 * B])]
     torch.cuda.synchronize()
     return out
 first = once()
@@ -51,24 +59,7 @@ for r in range(reps):
         if not torch.equal(a, b):
             d = (a != b)
             bad.setdefault(n, []).append((r, int(d.sum()), [int(x) for x in d.nonzero()[0].tolist()], float((a - b).abs().max())))
-if os.environ.get('DBG'):
-    shown = 0
-    for r in range(60):
-        o = once()
-        d = (first[8] != o[8]).nonzero().flatten().tolist()
-        d = [i for i in d if i < B * Ti]
-        for i in d[:3]:
-            f, g_ = first[9], o[9]
-            print('idx', i, 'dw', float(first[8][i]), float(o[8][i]), 'halves', f[i*8:i*8+2].tolist(), g_[i*8:i*8+2].tolist(), 's', float(f[i*8+2]), float(g_[i*8+2]), 'base', float(f[i*8+3]), float(g_[i*8+3]))
-            la, lb = f[1024+i*32:1024+i*32+32], g_[1024+i*32:1024+i*32+32]
-            print('   lanes differing', (la != lb).nonzero().flatten().tolist(), [round(float(x), 4) for x in la[la != lb]], [round(float(x), 4) for x in lb[la != lb]])
-            for nm, off in (('pm', 4096), ('gq', 16384)):
-                pa, pb = f[off+i*128:off+i*128+128].view(32, 4), g_[off+i*128:off+i*128+128].view(32, 4)
-                dd = (pa != pb).nonzero().tolist()
-                print('   ', nm, 'differs at (lane,g):', dd[:40])
-            shown += 1
-        if shown >= 3: break
-if 'ws' in bad and not os.environ.get('DBG'):
+if 'ws' in bad:
     o = None
     for r in range(3):
         o = once()

@@ -1,9 +1,12 @@
-"""Does any kernel of the training step depend on what it FINDS in LDS (or on wave timing)?  One process, the tiny three-utterance
+"""Does any kernel of the training step depend on what it FINDS in LDS, on wave timing, or on what shares its SIMD?  One process, the tiny three-utterance
 step of tests/test_zz9_dp_gpu.py run REPEATS times; from the second run on, a side stream keeps launching short kernels that fill
 LDS with NaN patterns beside the step's kernels (t2amd_debug_poison_lds_) -- the stand-in for another process's kernels on the
 same CUs.  Every run must give the bits of the first.
 
-    python tools/stress_lds_poison.py [fp32|bf16] [repeats] [separate|fused]
+    python tools/stress_lds_poison.py [fp32|bf16] [repeats] [separate|fused|<comma list of afwd0,abwd0,fold0,encp0,fwdp0>]
+
+POISON_LAUNCHES=<n> LDS-poison launches per step (default 2000, 0 = none); INPROC=<n> 2048^3 bf16 GEMMs per step on a side stream --
+the disturbance that exposed the packed-FMA fault of DESIGN.md section 5.3; or run `python tools/gpu_hammer.py <s> mm` beside it.
 """
 import ctypes as C
 import json
@@ -54,7 +57,15 @@ f.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
 f.restype = C.c_int
 
 
+ha = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
+hb = torch.randn(2048, 2048, device=dev, dtype=torch.bfloat16)
+
+
 def run(poison):
+    if poison > 0 and os.environ.get("INPROC"):
+        with torch.cuda.stream(side):
+            for _ in range(int(os.environ["INPROC"])):
+                ha @ hb
     model.zero_grad()
     model.dropout_masks = masks
     x, y = model.parse_batch(tuple(t.clone() for t in shard))
