@@ -155,8 +155,11 @@ def cpu_baseline(sample_b, seed, threads=16):
                  "port_over_reference": round(meta["oracle_frames_per_s"] / meta["reference_frames_per_s"], 3)}
     except Exception:                                   # noqa: BLE001
         pass
+    # what the REAL reference would read on these cores: the port's rate divided by the port/reference ratio of the calibration
+    # (print it, do not leave the division to the reader)
+    ref_equiv = round(frames / dt / calib["port_over_reference"], 1) if calib else None
     obj = {"value": frames / dt, "unit": "valid mel-frames/s", "cores": threads, "kind": "port", "calibration": calib,
-           "with_optimizer": frames / (dt + dopt),
+           "reference_equivalent": ref_equiv, "with_optimizer": frames / (dt + dopt),
            "sample": "oracle/tacotron2_oracle.py on %s (Ti_max=%d, To_max=%d, %d valid frames), fp32: 1 warm-up + 2 timed "
                      "fwd+bwd steps of %.1f s each; clip_grad_norm_ + Adam add %.2f s per step (with_optimizer)"
                      % ("the whole batch of BASELINE configs[1] (B=64: the batch the GPU leg times)" if sample_b == 64 else
@@ -168,7 +171,7 @@ def parity_check(ctx, dev):
     """The engine on the cpu_baseline sub-batch with the oracle's dropout masks: loss against the oracle's, both modes."""
     from tacotron2_amd.model import Tacotron2
     from tacotron2_amd.loss_function import Tacotron2Loss
-    out = {"batch": "B=%d of synth_batch(64, 1234)" % ctx['B'], "oracle_loss": ctx['oloss'], "tolerance": {"fp32": 1e-4, "bf16": 2e-2}}
+    out = {"batch": "B=%d of synth_batch(64, 1234)" % ctx['B'], "oracle_loss": ctx['oloss'], "tolerance": {"fp32": 1e-4, "bf16": 1e-4}}   # bf16 measured 2.9e-6 (round 6: was 2e-2)
     ok = True
     for prec in ("fp32", "bf16"):
         m = Tacotron2(ctx['hp'])
@@ -345,6 +348,7 @@ def compact_line(out):
                            "full_gc_collections_ms": tl["full_gc_collections_ms"], "gc_frozen": tl["gc_frozen"],
                            "handoff_give_ups": tl.get("handoff_give_ups"), "device_allocs_ok": tl.get("device_allocs_ok"),
                            "engine": tl.get("engine")}
+        o["retimed"] = "retimed_after_device_alloc" in tl     # top level: the value is the SECOND window when true
         if "retimed_after_device_alloc" in tl:
             o["timed_loop"]["retimed_after_device_alloc"] = {k: _r(v, 2) for k, v in tl["retimed_after_device_alloc"].items()
                                                              if k != "per_step_ms"}
@@ -354,7 +358,12 @@ def compact_line(out):
     if c:
         o["cpu_baseline"] = {"value": _r(c["value"], 1), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
                              "with_optimizer": _r(c["with_optimizer"], 1), "sample": c["sample"].split(", fp32:")[0] + "; 1 warm-up + 2 timed fwd+bwd steps",
+                             "reference_equivalent": c.get("reference_equivalent"),
                              "calibration": c.get("calibration")}
+        if c.get("reference_equivalent"):
+            o["speedup_vs_cpu"] = {"vs_port": _r(out["value"] / c["value"], 1),
+                                   "vs_reference_equivalent": _r(out["value"] / c["reference_equivalent"], 1),
+                                   "target": 30, "note": "reported baseline, not the target of the kernel work: see roofline.frac"}
     pc = out.get("parity_check")
     if pc:
         o["parity_check"] = {k: _r(v, 9) for k, v in pc.items() if k != "tolerance"}

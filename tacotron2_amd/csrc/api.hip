@@ -472,6 +472,36 @@ extern "C" int t2amd_debug_poison_regs_(int nwg, unsigned pattern, int launches,
     return T2AMD_OK;
 }
 
+// tests only (tests/test_zz9c_corun_gpu.py): MFMA waves with NO LDS and a handful of registers -- the one kind of foreign work that
+// fits on a SIMD BESIDE a persistent workgroup holding all 160 KB of its CU's LDS (a library GEMM's workgroups do not: they wait
+// for the CU).  `launches` kernels of `nwg` 256-thread workgroups, each wave issuing 4 x `iters` dependent-free bf16 MFMAs
+// (~17 cycles each per SIMD: iters = 2000 is ~60 us).  DESIGN.md 5.3: a packed-f32 FMA gave wrong lanes exactly beside such waves.
+typedef __bf16 dbg_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void t2_mfma_spin_kernel(int iters, float* sink) {
+    dbg_bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) {
+        a[i] = (__bf16)(0.001f * (float)((threadIdx.x + i) & 7));
+        b[i] = (__bf16)(0.002f * (float)((threadIdx.x * 3 + i) & 7));
+    }
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, b, c3, 0, 0, 0);
+    }
+    const float r = c0[0] + c1[1] + c2[2] + c3[3];
+    if (r == 12345.678f) sink[0] = r;                                             // keeps the MFMAs alive, never true
+}
+extern "C" int t2amd_debug_mfma_spin_(int nwg, int iters, int launches, float* sink, void* stream) {
+    T2_REQUIRE(nwg > 0 && nwg <= 8192 && iters > 0 && iters <= 1000000 && launches > 0 && launches <= 100000 && sink,
+               "debug_mfma_spin: bad args");
+    for (int i = 0; i < launches; ++i)
+        hipLaunchKernelGGL(t2_mfma_spin_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, iters, sink);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 // A HIP stream whose kernels run on CUs [first, first + count) only (hipExtStreamCreateWithCUMask): lets a latency-bound
 // chain of small launches and a throughput product run side by side without competing for the same CUs.
 extern "C" void* t2amd_debug_stream_cu_range_(int first, int count) {

@@ -63,6 +63,22 @@ def test_library_exports_every_header_symbol(native_lib):
     assert [ctypes.sizeof(s) for s in native._STRUCTS] == list(sizes)[:n]
 
 
+def test_shipped_library_has_no_packed_f32_instruction(native_lib):
+    """the library that ships is the one built WITHOUT v_pk_{fma,mul,add}_f32 (one with a swizzled
+    source on its destination pair gave wrong lanes beside another kernel's MFMA waves).  The gate lives in build() (it refuses to
+    leave such a library behind); this holds the LOADED library to it as well, and the scanner to the pattern it must recognise."""
+    from tacotron2_amd import build
+    assert build.NO_PACKED_F32[-1] == "-packed-fp32-ops" and all(f in build.CFLAGS for f in build.NO_PACKED_F32)
+    assert build._pk_hazard("v[34:35], v[10:11], v[34:35], v[66:67] op_sel:[0,1,0]")           # the proven one (round 5)
+    assert build._pk_hazard("v[30:31], v[12:13], v[30:31], 0 op_sel_hi:[1,0,0]")
+    assert not build._pk_hazard("v[34:35], v[10:11], v[34:35], v[66:67]")                        # same pair, no cross-half read
+    assert not build._pk_hazard("v[34:35], v[10:11], v[36:37], v[66:67] op_sel:[0,1,0]")        # swizzle on another pair
+    if not os.path.exists(build.OBJDUMP):
+        pytest.skip("no llvm-objdump on this box")
+    n, hits = build.scan_packed_f32(native.LIB_PATH)
+    assert (n, hits) == (0, []), (n, hits[:3])
+
+
 def test_no_cpu_fallback(native_lib):
     """CPU tensors must be refused: the product has one compute path."""
     m = Tacotron2(create_hparams(gu.TINY_HP))

@@ -221,7 +221,11 @@ def test_train_step_To870_bf16(native_lib, full_train_case):
     c = full_train_case
     model, out, loss = _engine_step(c, 'bf16')
     rows = []
-    lim = [4e-3, 6e-2, 4e-3, 2e-3]
+    # Limits = 3 x what is measured at B = 64 (round 6; measured in rounds 3-5: decoder mel 2.5e-4, postnet mel
+    # 6.7e-3, gate 2.2e-4, alignments 2.1e-5; loss 2.9e-6 relative; whole-gradient cosine 0.99998; worst tensor 5.5 %).  Until
+    # round 5 they were 9-16 x looser: the headline mode could lose an order of magnitude and stay green.
+    lim = [8e-4, 2e-2, 7e-4, 7e-5]
+    full = c['B'] == 64                                # (a T2AMD_FULLSIZE_B subset has other statistics: worst tensor 11 % at B = 16)
     fails = []
     for i, nm in enumerate(("mel", "mel_post", "gate", "align")):
         mean, mx, rmax = _stats(out[i], c['oout'][i])
@@ -246,9 +250,9 @@ def test_train_step_To870_bf16(native_lib, full_train_case):
                      worst_tensor=worst_k))
     _report("train_B%d_bf16" % c['B'], dict(shape=c['shape'], rows=rows, fails=fails))
     assert not fails, fails
-    assert abs(el - ol) < 2e-2 * abs(ol)
-    assert cos > 0.995, cos
-    assert worst < 0.35, (worst_k, worst)
+    assert abs(el - ol) < 1e-4 * abs(ol), (el, ol)
+    assert cos > 0.9999, cos
+    assert worst < (0.15 if full else 0.33), (worst_k, worst)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -6,6 +6,12 @@ kernels must not contain any.  Exit code 1 when one is found.
 
     python tools/scan_pk_overlap.py            # compiles every csrc/*.hip to assembly (hipcc -S) and scans it
     python tools/scan_pk_overlap.py --lines    # ... and groups the instances by the source line they come from
+    python tools/scan_pk_overlap.py --packed   # ... with the packed instructions turned back ON (what round 5 shipped: 117 sites)
+
+Since round 6 the product library is compiled WITHOUT packed-f32 instructions (tacotron2_amd/build.py: NO_PACKED_F32 is part of
+CFLAGS) and `build()` itself disassembles the LINKED library and fails on a single one (`build.scan_packed_f32`,
+`python -m tacotron2_amd.build --scan`); this source-level scanner compiles with the same flags, says where a site comes from, and
+ends with the library scan.
 """
 import glob
 import os
@@ -15,6 +21,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tacotron2_amd import build as _build  # noqa: E402
 PAT = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\s+(.*)$")
 
 
@@ -67,10 +75,12 @@ def main():
     out = tempfile.mkdtemp(prefix="pkscan_")
     total, bad = 0, []
     lines = "--lines" in sys.argv            # also say which source line every instance comes from (-gline-tables-only)
-    extra = [a for a in sys.argv[1:] if a != "--lines"] + (["-gline-tables-only"] if lines else [])
+    packed = "--packed" in sys.argv
+    extra = [a for a in sys.argv[1:] if a not in ("--lines", "--packed")] + (["-gline-tables-only"] if lines else [])
+    cflags = [f for f in _build.CFLAGS if f != "-fPIC"] + (_build.PACKED_F32 if packed else [])
     for src in sorted(glob.glob(os.path.join(ROOT, "tacotron2_amd", "csrc", "*.hip"))):
         asm = os.path.join(out, os.path.basename(src)[:-4] + ".s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", asm, src] + extra,
+        subprocess.run([_build.HIPCC] + cflags + ["-S", "--cuda-device-only", "-o", asm, src] + extra,
                        check=True, stderr=subprocess.DEVNULL, cwd=out)
         n, hits = scan(asm, lines)
         total += n
@@ -86,7 +96,13 @@ def main():
         for f, fn, line in bad[:60]:
             print("  %s  %s\n      %s" % (f, subprocess.run(["c++filt", fn], capture_output=True, text=True).stdout.strip()[:110], line))
     print("total: %d packed-f32 instructions, %d hazardous" % (total, len(bad)))
-    return 1 if bad else 0
+    rc = 1 if bad else 0
+    if os.path.exists(_build.OUT) and not packed:
+        n, hits = _build.scan_packed_f32(_build.OUT)
+        print("linked library %s (sha1 %s): %d packed-f32 instructions, %d hazardous"
+              % (os.path.relpath(_build.OUT, ROOT), (_build.built_sha1() or "?")[:12], n, len(hits)))
+        rc |= int(n > 0)
+    return rc
 
 
 if __name__ == "__main__":
