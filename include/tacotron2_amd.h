@@ -210,6 +210,11 @@ int t2amd_philox_keep_mask(uint8_t* out, long long n, float p, unsigned long lon
 int t2amd_fill_f32(float* p, long long n, float v, void* stream);
 /* dst[i] = bf16(src[i]) (round to nearest even); n % 4 == 0 */
 int t2amd_cast_bf16_f32(const float* src, void* dst, long long n, void* stream);
+/* Split-bf16 operand image (round 6, the 'bf16x3' mode of the LSTM tiles: t2amd_lstm_step.bf16 == 3).  src is f32 [rows][K]
+ * (row stride lds floats), K % 16 == 0; dst takes 4 bytes per k (row stride ldd in k, ldd >= K): for every group of 16
+ * consecutive k, 16 bf16 `hi = bf16(x)` followed by 16 bf16 `lo = bf16(x - hi)` (both round to nearest even), so that one
+ * 64-byte group of a row feeds the 32x32x16 bf16 MFMA its hi and its lo fragment of the same 16 k.  x = hi + lo to ~2^-17. */
+int t2amd_split_bf16x3_f32(const float* src, long long lds, void* dst, long long ldd, long long rows, int K, void* stream);
 /* dst[r][c] = src[r][c] (+ src2[r][c] if src2) for r<rows, c<cols */
 int t2amd_copy2d_f32(const float* src, long long lds, const float* src2, long long lds2, float* dst,
                      long long ldd, int rows, int cols, void* stream);
@@ -276,7 +281,12 @@ typedef struct t2amd_lstm_step {
     /* bf16 operand mode: x[i].p and W point at bf16 (widths / ld / Ktot count ELEMENTS, widths multiples of 128);
      * the product runs on v_mfma_f32_16x16x32_bf16 with f32 accumulation; gin, bias, cell state and all f32
      * outputs are unchanged.  h16_out (optional) receives a bf16 copy of h, the next step's operand.
-     * t2amd_lstm_step_small_f32 accepts 0 or 2: 2 = W alone is bf16, x[i].p stay f32 (matrix-vector path). */
+     * t2amd_lstm_step_small_f32 accepts 0 or 2: 2 = W alone is bf16, x[i].p stay f32 (matrix-vector path).
+     * 3 (round 6, the engine's 'bf16x3' mode): x[i].p and W point at SPLIT-bf16 images (t2amd_split_bf16x3_f32: 4 bytes per k,
+     * every 16 k as 16 hi then 16 lo bf16); widths / ld / Ktot count k as in the f32 form (widths multiples of 64); the
+     * product is Xh.Wh + Xl.Wh + Xh.Wl on v_mfma_f32_32x32x16_bf16 with f32 accumulation (~2^-17 relative per product:
+     * f32-class results at the f32 byte stream and 3/16 of the exact-f32 MFMA time); h16_out receives the split image of h
+     * (ld_h16 in k). */
     int bf16;
     void* h16_out;
     long long ld_h16;
@@ -370,6 +380,7 @@ typedef struct t2amd_lstm_bwd {
     int t;
     void* dgates16;       /* optional bf16 copy of dgates (bf16 operand mode of the dgrad GEMM) */
     long long ld_dgates16;
+    int dgates16_x3;      /* 1: dgates16 receives the SPLIT-bf16 image of dgates instead (t2amd_split_bf16x3_f32 layout, ld_dgates16 in k) */
 } t2amd_lstm_bwd;
 
 int t2amd_lstm_pointwise_bwd_f32(const t2amd_lstm_bwd* a, void* stream);
@@ -427,6 +438,9 @@ typedef struct t2amd_attn_fwd {
      * behind the partial energies zeroed once -- the step may run as ONE launch whose four workgroups per utterance hand
      * the partial energies to each other as 8-byte {launch token, value} granules (t2amd_set_attn_fwd_fused). */
     long long ws_floats;
+    /* 1: ctx16_out receives the SPLIT-bf16 image of the context (t2amd_split_bf16x3_f32 layout, ld_ctx16 in k; E % 16 == 0) --
+     * the operand of the 'bf16x3' LSTM tiles; everything else of the step stays in its exact-f32 form. */
+    int ctx16_x3;
 } t2amd_attn_fwd;
 
 int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* stream);

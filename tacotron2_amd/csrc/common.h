@@ -85,6 +85,15 @@ __device__ __forceinline__ unsigned t2_cvt_pk_bf16(float a, float b) {
     return r;
 }
 
+// ---- split-bf16 operand images (round 6: the 'bf16x3' mode of the LSTM tiles, include/tacotron2_amd.h t2amd_split_bf16x3_f32) ----
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in f32): 16 mantissa bits, |x - hi - lo| <= 2^-17 |x|.
+__device__ __forceinline__ void t2_split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+    hi = t2_f32_to_bf16(x);
+    lo = t2_f32_to_bf16(x - __uint_as_float((unsigned)hi << 16));
+}
+// position (in bf16 units) of k's hi value inside a row of the split image: groups of 16 k = 16 hi then 16 lo; lo sits 16 further
+__device__ __forceinline__ long long t2_x3_pos(long long k) { return ((k >> 4) << 5) + (k & 15); }
+
 __device__ __forceinline__ float t2_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 // sigmoid on v_exp_f32 / v_rcp_f32 (|err| ~1e-7): the bf16-mode kernels' cell; the parity-mode kernels keep libm's
 __device__ __forceinline__ float t2_sigmoid_fast(float x) {

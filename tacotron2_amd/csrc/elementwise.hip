@@ -713,6 +713,35 @@ extern "C" int t2amd_cast_bf16_f32(const float* src, void* dst, long long n, voi
     return T2AMD_OK;
 }
 
+// f32 [rows][K] -> split-bf16 image (header: t2amd_split_bf16x3_f32).  One thread per 4 consecutive k: one float4 in, two 8-byte
+// stores out (4 hi, 4 lo of the same group of 16).
+__global__ void split_bf16x3_kernel(const float* __restrict__ src, long long lds_, unsigned short* __restrict__ dst, long long ldd,
+                                    long long rows, int K4) {
+    const long long total = rows * K4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / K4;
+        const int k = (int)(i - r * K4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + r * lds_ + k);
+        unsigned short h[4], l[4];
+        t2_split_bf16(v.x, h[0], l[0]); t2_split_bf16(v.y, h[1], l[1]);
+        t2_split_bf16(v.z, h[2], l[2]); t2_split_bf16(v.w, h[3], l[3]);
+        unsigned short* const d = dst + r * ldd * 2 + t2_x3_pos(k);
+        *reinterpret_cast<uint2*>(d) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2*>(d + 16) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    }
+}
+extern "C" int t2amd_split_bf16x3_f32(const float* src, long long lds, void* dst, long long ldd, long long rows, int K, void* stream) {
+    T2_REQUIRE(src && dst && rows > 0 && K > 0 && K % 16 == 0, "split_bf16x3: K must be a positive multiple of 16");
+    T2_REQUIRE(lds >= K && lds % 4 == 0 && ldd >= K && ldd % 16 == 0, "split_bf16x3: row strides (lds % 4 == 0, ldd % 16 == 0, both >= K)");
+    T2_REQUIRE(t2_aligned16(src) && t2_aligned16(dst), "split_bf16x3: alignment");
+    int blocks = t2_cdiv(rows * (K / 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    T2_LAUNCH(split_bf16x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, lds, reinterpret_cast<unsigned short*>(dst), ldd,
+              rows, K / 4);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 extern "C" int t2amd_fill_f32(float* p, long long n, float v, void* stream) {
     T2_REQUIRE(p && n > 0, "fill: bad args");
     int blocks = t2_cdiv(n, 256);

@@ -156,12 +156,24 @@ struct NoGate {
 // tile row is still 256 bytes (64 k instead of 128), a 16-byte chunk is four k values instead of eight, the DMA, the swizzle and
 // the fragment reads are the same instructions -- and a chunk pair feeds four MFMAs of k = 2 instead of one of k = 16: element e of
 // the lane's X and W chunks is one k index in both, which is all the instruction asks for.
-template <bool LSTM, bool PERSIST, class Gate, bool XPLAIN = false, bool F32 = false>
+// MODE (round 6; was `bool F32`): SW_BF16 = 0, SW_F32 = 1 as above, SW_X3 = 2 -- SPLIT-bf16 operands (t2amd_split_bf16x3_f32 images: 4
+// bytes per k, every 16 k stored as 16 hi then 16 lo bf16 -- the engine's 'bf16x3' mode).  In bytes such a row IS an f32 row: 64 k per
+// 256-byte tile row, addresses, DMA, swizzle and fragment reads are the f32 form's.  What a wave reads as its two fragments (chunks 4 wk
+// + {0, 1} and 4 wk + {2, 3} of a tile row = one 64-byte group) are then the hi halves and the lo halves of the SAME 16 k, so the
+// step's two bf16 MFMAs X0.W0 + X1.W1 become three: hi.hi into acc0, lo.hi + hi.lo into acc1 (the small terms keep an accumulator
+// of their own; the epilogue adds the two as it always did).  f32-class products (~2^-17 relative each, f32 accumulation) at the f32
+// byte stream and 3 x 32 cycles per SIMD instead of 8 x 64: the k loop is bound by the LDS-DMA rate again, not by the matrix pipe.
+#define SW_BF16 0
+#define SW_F32 1
+#define SW_X3 2
+template <bool LSTM, bool PERSIST, class Gate, bool XPLAIN = false, int MODE = SW_BF16>
 __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const int lb, char* const smem, unsigned long long* const ts_buf,
                                                  Gate& gate, const bool pref = false) {
-    constexpr int BK = F32 ? 64 : 128;       // k per 256-byte tile row
-    constexpr int ES = F32 ? 4 : 2;          // bytes per operand element
-    constexpr int CE = 16 / ES;              // elements per 16-byte chunk
+    constexpr bool F32 = MODE == SW_F32;
+    constexpr bool X3 = MODE == SW_X3;
+    constexpr int BK = MODE == SW_BF16 ? 128 : 64;       // k per 256-byte tile row
+    constexpr int ES = MODE == SW_BF16 ? 2 : 4;          // bytes per k of an operand row (X3: a hi and a lo bf16)
+    constexpr int CE = 16 / ES;              // k per 16-byte chunk (address arithmetic; X3: a chunk HOLDS 8 hi or 8 lo values)
     constexpr int XAUX = (PERSIST && !XPLAIN) ? 16 : 0;       // aux bit 4 = sc1 on the activation DMA
     bool ts_on = false;
     SW_TS(0);
@@ -352,6 +364,14 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((X0)[e_], (W0)[e_], acc0, 0, 0, 0);            \
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((X1)[e_], (W1)[e_], acc1, 0, 0, 0);            \
         }                                                                                              \
+    } else if constexpr (X3) {                                                                         \
+        /* (the two small-term products are kept apart by the big one: no back-to-back dependent pair) */ \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X1)),            \
+                                                       __builtin_bit_cast(sk_bf16x8, (W0)), acc1, 0, 0, 0); \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X0)),            \
+                                                       __builtin_bit_cast(sk_bf16x8, (W0)), acc0, 0, 0, 0); \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X0)),            \
+                                                       __builtin_bit_cast(sk_bf16x8, (W1)), acc1, 0, 0, 0); \
     } else {                                                                                           \
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sk_bf16x8, (X0)),            \
                                                        __builtin_bit_cast(sk_bf16x8, (W0)), acc0, 0, 0, 0); \
@@ -466,7 +486,16 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
                 if (p.keep) o = p.keep[(long long)gr * p.ld_keep + gn] ? o * p.keep_scale : 0.f;
                 if constexpr (PERSIST) __hip_atomic_store(&Y[gn], o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by the next phase of this launch
                 else Y[gn] = o;
-                if (p.h16_out) p.h16_out[(long long)gr * p.ld_h16 + gn] = t2_f32_to_bf16(o);
+                if (p.h16_out) {
+                    if constexpr (X3) {
+                        unsigned short hi_, lo_;
+                        t2_split_bf16(o, hi_, lo_);
+                        unsigned short* const q_ = p.h16_out + (long long)gr * p.ld_h16 * 2 + t2_x3_pos(gn);
+                        q_[0] = hi_; q_[16] = lo_;
+                    } else {
+                        p.h16_out[(long long)gr * p.ld_h16 + gn] = t2_f32_to_bf16(o);
+                    }
+                }
                 if (p.stop_active && gn == p.stop_col) skinny_stop_test(p, gr, o);
             }
         }
@@ -510,6 +539,15 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         // their waits sit on the tile's critical tail, and the drain was not waiting for the NUMBER of writes.
 #ifndef T2AMD_SW_VECTOR_WT
         __hip_atomic_store(&p.h_out[(long long)egr * p.ld_h + ej], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (X3) {
+            if (p.h16_out) {
+                unsigned short hi_, lo_;
+                t2_split_bf16(hn, hi_, lo_);
+                unsigned short* const q_ = p.h16_out + (long long)egr * p.ld_h16 * 2 + t2_x3_pos(ej);
+                __hip_atomic_store(q_, hi_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(q_ + 16, lo_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else
         if (p.h16_out) __hip_atomic_store(&p.h16_out[(long long)egr * p.ld_h16 + ej], t2_f32_to_bf16(hn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
         float hv[8];
@@ -533,6 +571,14 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
 #endif
     } else {
         p.h_out[(long long)egr * p.ld_h + ej] = hn;
+        if constexpr (X3) {
+            if (p.h16_out) {
+                unsigned short hi_, lo_;
+                t2_split_bf16(hn, hi_, lo_);
+                unsigned short* const q_ = p.h16_out + (long long)egr * p.ld_h16 * 2 + t2_x3_pos(ej);
+                q_[0] = hi_; q_[16] = lo_;
+            }
+        } else
         if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
     }
     SW_TS(5);
@@ -545,7 +591,7 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
 // its entry (SW_ISSUE(0..3)): same sources, same LDS image.  `x0`: bf16 rows of segment 0 (read with sc1: another workgroup of
 // this launch wrote them), `ld0` in elements; `wcol0`: W's K column of segment 0; `bx`: the tile's index; B rows (<= 64).
 // ---------------------------------------------------------------------------------------
-// (`bk`: k per tile row -- 128 for bf16 operands, 64 for f32)
+// (`bk`: k per tile row -- 128 for bf16 operands, 64 for f32 and for split-bf16 images, whose rows are f32 rows in bytes: F32 = true)
 __device__ __forceinline__ bool skinny_wide_prefetch_ok(const int width0, const int ntiles, const int bk = 128) { return width0 >= 5 * bk && ntiles >= 8 && (ntiles & 3) == 0; }
 template <bool F32 = false>
 __device__ __forceinline__ void skinny_wide_prefetch4(const void* const x0, const long long ld0, const void* const W,

@@ -106,6 +106,7 @@ class LstmBwd(C.Structure):
         ("dgates", _f32p), ("ld_dgates", _i64),
         ("lens", C.c_void_p), ("t", C.c_int),
         ("dgates16", C.c_void_p), ("ld_dgates16", _i64),
+        ("dgates16_x3", C.c_int),
     ]
 
 
@@ -127,6 +128,7 @@ class AttnFwd(C.Structure):
         ("memory16", C.c_void_p),
         ("Wq16", C.c_void_p),
         ("ws_floats", _i64),
+        ("ctx16_x3", C.c_int),
     ]
 
 
@@ -264,7 +266,7 @@ SYMBOLS = [
     "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
-    "t2amd_copy2d_f32", "t2amd_cast_bf16_f32", "t2amd_transpose_f32", "t2amd_frames_to_time_major_f32",
+    "t2amd_copy2d_f32", "t2amd_cast_bf16_f32", "t2amd_split_bf16x3_f32", "t2amd_transpose_f32", "t2amd_frames_to_time_major_f32",
     "t2amd_split_projection_f32", "t2amd_finalize_outputs_f32", "t2amd_grads_to_channel_last_f32",
     "t2amd_gather_dout_f32", "t2amd_relu_dropout_bwd_f32",
     "t2amd_lstm_step_fwd_f32", "t2amd_skinny_gemm_f32", "t2amd_lstm_pointwise_bwd_f32",
@@ -314,6 +316,7 @@ def _argtypes():
         "t2amd_philox_keep_mask": [_P, _L, _F, _UL, _UL, _P],
         "t2amd_fill_f32": [_P, _L, _F, _P],
         "t2amd_cast_bf16_f32": [_P, _P, _L, _P],
+        "t2amd_split_bf16x3_f32": [_P, _L, _P, _L, _L, _I, _P],
         "t2amd_copy2d_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P],
         "t2amd_transpose_f32": [_P, _L, _P, _L, _I, _I, _I, _L, _L, _P],
         "t2amd_frames_to_time_major_f32": [_P, _P, _I, _I, _I, _P],
@@ -469,6 +472,19 @@ def cast_bf16(src, dst):
     if src.numel() != dst.numel() or dst.dtype != torch.bfloat16:
         raise NativeError("cast_bf16: dst must be a bfloat16 tensor of the same size")
     _check(load().t2amd_cast_bf16_f32(ptr(src), ptr(dst, torch.bfloat16), src.numel(), _stream()), "t2amd_cast_bf16_f32")
+
+
+def split_bf16x3(src, dst):
+    """dst (torch.bfloat16, [rows][2 K], contiguous) = the split-bf16 operand image of src (f32 [rows][K], contiguous, K % 16 == 0):
+    per 16 k, 16 hi = bf16(x) then 16 lo = bf16(x - hi) -- what t2amd_lstm_step.bf16 == 3 / the 'bf16x3' mode multiplies."""
+    _fullc(src), _fullc(dst)
+    K = src.shape[-1]
+    rows = src.numel() // max(K, 1)
+    if dst.dtype != torch.bfloat16 or dst.numel() != 2 * src.numel() or K % 16 != 0:
+        raise NativeError("split_bf16x3: dst must be a bfloat16 tensor of twice the size, K %% 16 == 0 (src %s, dst %s)"
+                          % (tuple(src.shape), tuple(dst.shape)))
+    _check(load().t2amd_split_bf16x3_f32(ptr(src), _i64(K), ptr(dst, torch.bfloat16), _i64(K), _i64(rows), K, _stream()),
+           "t2amd_split_bf16x3_f32")
 
 
 def decoder_persist_mailbox_bytes(Ti, E, H, P):
