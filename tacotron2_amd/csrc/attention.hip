@@ -905,7 +905,18 @@ __device__ __forceinline__ void kc_finish(const AttnFwdParams& p, float* smem, c
         // (PERSIST, fp32 mode: the LSTM tiles of this launch read the f32 context itself -- there is no bf16 copy: write-through)
         if (PERSIST && !a.ctx16_out) st_xwg<PERSIST>(&a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c], s);
         else a.ctx_out[(long long)b * a.ld_ctx + cs * EC + c] = s;
-        if (a.ctx16_out) {
+        if (a.ctx16_out && a.ctx16_x3) {
+            // 'bf16x3' mode (round 6): the LSTM tiles' operand is the split hi/lo image of the context (t2amd_split_bf16x3_f32 layout)
+            unsigned short hi_, lo_;
+            t2_split_bf16(s, hi_, lo_);
+            unsigned short* c16 = reinterpret_cast<unsigned short*>(a.ctx16_out) + (long long)b * a.ld_ctx16 * 2 + t2_x3_pos(cs * EC + c);
+            if constexpr (PERSIST) {
+                __hip_atomic_store(c16, hi_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c16 + 16, lo_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                c16[0] = hi_; c16[16] = lo_;
+            }
+        } else if (a.ctx16_out) {
             unsigned short* c16 = reinterpret_cast<unsigned short*>(a.ctx16_out) + (long long)b * a.ld_ctx16 + cs * EC + c;
             if constexpr (PERSIST) __hip_atomic_store(c16, t2_f32_to_bf16(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else *c16 = t2_f32_to_bf16(s);
@@ -1150,8 +1161,13 @@ struct DtpGate {
     }
 };
 
-template <bool BF>
+// OM = operand mode of the LSTM tiles (t2amd_dec_train.bf16): 0 the f32 slabs themselves, 1 bf16 copies, 3 split-bf16 images
+// (round 6, 'bf16x3': HA16 / HD16 / CTX16 / W*16 hold 4 bytes per k, strides in k as for f32)
+template <int OM>
 __device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t, SkinnyParams& a) {
+    constexpr bool BF = OM == 1;
+    constexpr bool X3 = OM == 3;
+    constexpr int US = X3 ? 2 : 1;                 // bf16 units per k in the operand copies
     // attention LSTM of step t: gates = GA[t] + [ctx_{t-1} | h_att_{t-1}] . Wa_rec^T   (loops.hip fill_a; BF: bf16 operand copies,
     // else the f32 slabs themselves)
     const long long sHa = (long long)d.B * d.Ha, sE = (long long)d.B * d.E;
@@ -1162,9 +1178,9 @@ __device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t
     // visited [h_att | ctx] over Wa_rec = [ctx columns | h_att columns] (explicit weight columns; the chain asks the per-step kernel
     // for the same order, loops.hip): h_att(t-1) has been complete since this workgroup's own attention phase of step t-1, so its
     // eight k-tiles run while the slowest attention workgroup is still producing ctx(t-1) -- the gate sits in front of segment 1.
-    if constexpr (BF) {
-        a.x[0].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr;
-        a.x[1].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr;
+    if constexpr (BF || X3) {
+        a.x[0].p = t ? (const float*)(h16 + (t - 1) * sHa * US) : nullptr;
+        a.x[1].p = t ? (const float*)(c16 + (t - 1) * sE * US) : nullptr;
         a.W = (const float*)d.Wa_rec16;
     } else {
         a.x[0].p = t ? d.HA + (t - 1) * sHa : nullptr;
@@ -1182,12 +1198,15 @@ __device__ __forceinline__ void dtp_fill_a(const t2amd_dec_train& d, const int t
     a.gates_out = d.GA + (long long)t * d.B * 4 * d.Ha; a.ld_gates = 4 * d.Ha;
     a.c_out = d.CA + t * sHa; a.ld_c = d.Ha;
     a.h_out = d.HA + t * sHa; a.ld_h = d.Ha;
-    if constexpr (BF) { a.h16_out = (unsigned short*)d.HA16 + t * sHa; a.ld_h16 = d.Ha; }
+    if constexpr (BF || X3) { a.h16_out = (unsigned short*)d.HA16 + t * sHa * US; a.ld_h16 = d.Ha; }
     a.keep = d.keep_att ? d.keep_att + t * sHa : nullptr; a.ld_keep = d.Ha; a.keep_scale = d.scale_att;
     a.gx = d.Ha / 8; a.gy = 1; a.gz = 1;
 }
-template <bool BF>
+template <int OM>
 __device__ __forceinline__ void dtp_fill_d(const t2amd_dec_train& d, const int u, SkinnyParams& a) {
+    constexpr bool BF = OM == 1;
+    constexpr bool X3 = OM == 3;
+    constexpr int US = X3 ? 2 : 1;
     // decoder LSTM of step u: gates = bias_d + [h_att_u | ctx_u | h_dec_{u-1}] . Wd_cat^T   (loops.hip fill_d, bf16 operands)
     const long long sHa = (long long)d.B * d.Ha, sHd = (long long)d.B * d.Hd, sE = (long long)d.B * d.E;
     const unsigned short* c16 = (const unsigned short*)d.CTX16;
@@ -1195,10 +1214,10 @@ __device__ __forceinline__ void dtp_fill_d(const t2amd_dec_train& d, const int u
     unsigned short* hd16 = (unsigned short*)d.HD16;
     a = SkinnyParams{};
     a.nseg = 3;
-    if constexpr (BF) {
-        a.x[0].p = (const float*)(ha16 + u * sHa);
-        a.x[1].p = (const float*)(c16 + u * sE);
-        a.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd) : nullptr;
+    if constexpr (BF || X3) {
+        a.x[0].p = (const float*)(ha16 + u * sHa * US);
+        a.x[1].p = (const float*)(c16 + u * sE * US);
+        a.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd * US) : nullptr;
         a.W = (const float*)d.Wd_cat16;
     } else {
         a.x[0].p = d.HA + u * sHa;
@@ -1215,7 +1234,7 @@ __device__ __forceinline__ void dtp_fill_d(const t2amd_dec_train& d, const int u
     a.gates_out = d.GD + (long long)u * d.B * 4 * d.Hd; a.ld_gates = 4 * d.Hd;
     a.c_out = d.CD + u * sHd; a.ld_c = d.Hd;
     a.h_out = d.HD + u * sHd; a.ld_h = d.Hd;
-    if constexpr (BF) { a.h16_out = hd16 + u * sHd; a.ld_h16 = d.Hd; }
+    if constexpr (BF || X3) { a.h16_out = hd16 + u * sHd * US; a.ld_h16 = d.Hd; }
     a.keep = d.keep_dec ? d.keep_dec + u * sHd : nullptr; a.ld_keep = d.Hd; a.keep_scale = d.scale_dec;
     a.gx = d.Hd / 8; a.gy = 1; a.gz = 1;
     a.wcol[0] = -1;               // stored order [h_att | ctx | h_dec]: h_att(u) first, what step u's attention made behind the gate
@@ -1263,8 +1282,15 @@ __device__ __forceinline__ const DecTrainPersist& dtp_args_late() {
 // BF: the bf16 compute mode (bf16 copies of the recurrent operands and weights on the bf16 MFMA, bf16 attention streams); else the
 // fp32 parity mode (round 5): the same loop over the f32 slabs themselves -- tiles on the exact-f32 MFMA (skinny_wide.h, F32), the
 // attention phase in its f32 instantiation -- bit-identical to the fp32 launch chain, which runs the same tile.
-template <bool BF>
+// OM (round 6; was `bool BF`): 1 = bf16 mode, 0 = fp32 parity mode, 3 = 'bf16x3': the fp32 mode's loop -- f32 slabs, the attention phase in
+// its exact-f32 instantiation -- with the LSTM tiles on SPLIT-bf16 operand images (skinny_wide.h SW_X3: hi.hi + lo.hi + hi.lo on the bf16
+// MFMA, f32-class products at 3/16 of the exact-f32 matrix time); the tile epilogue and K_c write h / ctx as split images next to the
+// f32 values.  Bit-identical to ITS launch chain (loops.hip, bf16 == 3), like the other two.
+template <int OM>
 __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainPersist P_entry) {
+    constexpr bool BF = OM == 1;
+    constexpr bool X3 = OM == 3;
+    constexpr int SWM = BF ? SW_BF16 : (X3 ? SW_X3 : SW_F32);
     extern __shared__ __attribute__((aligned(16))) char psmem_[];
     const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1313,13 +1339,13 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
         if (tile) {
             // ONE call site for both roles (two inlined copies of the tile body in sibling branches crash hipcc's SimplifyCFG)
             SkinnyParams sp;
-            if (isA) dtp_fill_a<BF>(d, t, sp);
-            else dtp_fill_d<BF>(d, t - DTP_LAG, sp);
+            if (isA) dtp_fill_a<OM>(d, t, sp);
+            else dtp_fill_d<OM>(d, t - DTP_LAG, sp);
             DtpGate gate;
             gate.flags = P.flagT; gate.n = nG; gate.target = (unsigned)t; gate.delay = P.delay_a; gate.status = P.status;
             gate.ticks = P.timeout_ticks; gate.fail_s = fail_s;
             if (t == 0 || (DTP_LAG > 1 && tail)) sp.gate_seg = 0;    // nothing to wait for at the first step; already waited in the tail
-            skinny_wide_body<true, true, DtpGate, false, !BF>(sp, isA ? j : j - nA, psmem, P.ts, gate, pref);
+            skinny_wide_body<true, true, DtpGate, false, SWM>(sp, isA ? j : j - nA, psmem, P.ts, gate, pref);
             if (fail_s[0]) return;
         }
         pref = false;
@@ -1332,9 +1358,9 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             // (the description is read from the kernel-argument segment HERE: nothing of it is carried through the attention phase)
             const t2amd_dec_train& d2 = dtp_args_late().d;
             const bool isA2 = j < d2.Ha / 8;
-            const void* const x0 = BF ? (const void*)((const unsigned short*)d2.HA16 + (long long)t * d2.B * d2.Ha)
-                                      : (const void*)(d2.HA + (long long)t * d2.B * d2.Ha);
-            const void* const W0 = BF ? (isA2 ? d2.Wa_rec16 : d2.Wd_cat16) : (const void*)(isA2 ? d2.Wa_rec : d2.Wd_cat);
+            const void* const x0 = (BF || X3) ? (const void*)((const unsigned short*)d2.HA16 + (long long)t * d2.B * d2.Ha * (X3 ? 2 : 1))
+                                              : (const void*)(d2.HA + (long long)t * d2.B * d2.Ha);
+            const void* const W0 = (BF || X3) ? (isA2 ? d2.Wa_rec16 : d2.Wd_cat16) : (const void*)(isA2 ? d2.Wa_rec : d2.Wd_cat);
             skinny_wide_prefetch4<!BF>(x0, d2.Ha, W0, isA2 ? d2.E + d2.Ha : d2.Ha + d2.E + d2.Hd, isA2 ? d2.Ha : d2.Hd,
                                        isA2 ? d2.E : 0, d2.B, isA2 ? j : j - d2.Ha / 8, psmem);
         };
@@ -1367,6 +1393,9 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
             if constexpr (BF) {
                 ap.a.ctx16_out = (void*)((unsigned short*)d.CTX16 + t * sE); ap.a.ld_ctx16 = d.E;
                 ap.a.loc_split_bf16 = 1; ap.a.memory16 = d.memory16; ap.a.Wq16 = d.Wq16;
+            }
+            if constexpr (X3) {       // the split image of the context for the tiles; the step itself stays exact f32
+                ap.a.ctx16_out = (void*)((unsigned short*)d.CTX16 + t * sE * 2); ap.a.ld_ctx16 = d.E; ap.a.ctx16_x3 = 1;
             }
             ap.tip = P.tip; ap.dbg = 0; ap.ts = P.ts;
             ap.token = P.token0 + (unsigned)t; ap.gran_off = P.gran_off; ap.kc_smem_off = P.kc_smem_off; ap.delay = 0;
@@ -1434,11 +1463,14 @@ extern "C" long long t2amd_decoder_train_fwd_persistent_flag_bytes(int B, int Ha
 
 static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out, int* kc_off_out, int* fail_off_out, int* att_off_out, int* pf_where_out) {
     T2_REQUIRE(p != nullptr, "dec_train_fwd_persistent: null args");
-    T2_REQUIRE(!p->bf16 || (p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16 && p->memory16 && p->Wq16),
+    T2_REQUIRE(p->bf16 == 0 || p->bf16 == 1 || p->bf16 == 3, "dec_train_fwd_persistent: bf16 must be 0 (fp32), 1 (bf16) or 3 (split-bf16 x3)");
+    T2_REQUIRE(p->bf16 != 1 || (p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16 && p->memory16 && p->Wq16),
                "dec_train_fwd_persistent: the bf16 operand mode needs the bf16 copies of the weights, the recurrent slabs, the memory and W_q");
+    T2_REQUIRE(p->bf16 != 3 || (p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16),
+               "dec_train_fwd_persistent: the split-bf16 x3 mode needs the split images of the weights and of the recurrent slabs");
     {
         static const bool f32_env = [] { const char* e = getenv("T2AMD_TRAIN_FWD_PERSISTENT_FP32"); return !(e && e[0] == '0'); }();
-        T2_REQUIRE(p->bf16 || f32_env, "dec_train_fwd_persistent: the fp32 form is switched off (T2AMD_TRAIN_FWD_PERSISTENT_FP32=0)");
+        T2_REQUIRE(p->bf16 == 1 || f32_env, "dec_train_fwd_persistent: the fp32 / bf16x3 forms are switched off (T2AMD_TRAIN_FWD_PERSISTENT_FP32=0)");
     }
     T2_REQUIRE(p->B > 0 && p->B <= SK_ROWS, "dec_train_fwd_persistent: one 64-row tile (B <= 64)");
     T2_REQUIRE(p->Ti > 0 && p->Ti <= KC_NT && p->To > 0, "dec_train_fwd_persistent: one position per thread (Ti <= 512)");
@@ -1447,7 +1479,7 @@ static int dtp_geometry(const t2amd_dec_train* p, size_t* lds_out, int* tip_out,
     const size_t lds_e = sizeof(float) * (2 * (size_t)tip + DSL + DSL * NTAP + (size_t)p->Ha);
     const int EC = p->E / NCS;
     T2_REQUIRE(EC % 8 == 0, "dec_train_fwd_persistent: E a multiple of 32");
-    int parts = KC_NT / (EC / (p->bf16 ? 8 : 4));
+    int parts = KC_NT / (EC / (p->bf16 == 1 ? 8 : 4));
     if (parts > 32) parts = 32;
     T2_REQUIRE(parts >= 1, "dec_train_fwd_persistent: E too large");
     const size_t lds_c = sizeof(float) * ((size_t)((p->Ti + 3) & ~3) + 16 + (size_t)parts * EC);
@@ -1529,18 +1561,20 @@ extern "C" int t2amd_decoder_train_fwd_persistent_f32(const t2amd_dec_train* p, 
     if (hipMemsetAsync(flags, 0, (size_t)t2amd_decoder_train_fwd_persistent_flag_bytes(B, p->Ha), s) != hipSuccess ||
         hipMemsetAsync(status, 0, sizeof(int), s) != hipSuccess)
         T2_FAIL("dec_train_fwd_persistent: memset failed");
-    static size_t lds_set[2] = {0, 0};
-    const int bf = p->bf16 ? 1 : 0;
-    if (lds > lds_set[bf]) {
-        const void* fn = bf ? (const void*)dec_train_fwd_persistent_kernel<true> : (const void*)dec_train_fwd_persistent_kernel<false>;
+    static size_t lds_set[3] = {0, 0, 0};
+    const int om = p->bf16 == 1 ? 1 : (p->bf16 == 3 ? 2 : 0);
+    if (lds > lds_set[om]) {
+        const void* fn = om == 1 ? (const void*)dec_train_fwd_persistent_kernel<1>
+                                 : (om == 2 ? (const void*)dec_train_fwd_persistent_kernel<3> : (const void*)dec_train_fwd_persistent_kernel<0>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             T2_FAIL("dec_train_fwd_persistent: cannot raise the dynamic LDS limit");
-        lds_set[bf] = lds;
+        lds_set[om] = lds;
     }
     const int nL = p->Ha / 8 + p->Hd / 8, nT = NSL * B;
     // role 7 of bench.py's roofline leg: the whole forward loop of the step is this one launch
-    if (bf) T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel<true>, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
-    else T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel<false>, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
+    if (om == 1) T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel<1>, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
+    else if (om == 2) T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel<3>, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
+    else T2_LAUNCH_ROLE(7, dec_train_fwd_persistent_kernel<0>, dim3(nL > nT ? nL : nT), dim3(512), lds, s, P);
     T2_LAUNCH_CHECK();
     if (poison) {
         hipLaunchKernelGGL(dec_train_persist_poison_kernel, dim3(1), dim3(1), 0, s, status, poison);

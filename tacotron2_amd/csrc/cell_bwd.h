@@ -84,6 +84,27 @@ __device__ __forceinline__ CellOperands cell_bwd_issue(const t2amd_lstm_bwd& a, 
 
 #define T2_PK4(o) make_uint2((unsigned)t2_f32_to_bf16(o[0]) | ((unsigned)t2_f32_to_bf16(o[1]) << 16), \
                              (unsigned)t2_f32_to_bf16(o[2]) | ((unsigned)t2_f32_to_bf16(o[3]) << 16))
+// Where the operand copy of gate column k (k % 4 == 0) of row b starts, in bf16 units: a plain bf16 row, or (dgates16_x3, round 6:
+// the 'bf16x3' mode) the split image of t2amd_split_bf16x3_f32 -- the four hi values there, the four lo values 16 further.
+__device__ __forceinline__ unsigned short* cell_d16_at(const t2amd_lstm_bwd& a, int b, int k) {
+    unsigned short* const base = reinterpret_cast<unsigned short*>(a.dgates16);
+    return a.dgates16_x3 ? base + (long long)b * a.ld_dgates16 * 2 + t2_x3_pos(k) : base + (long long)b * a.ld_dgates16 + k;
+}
+// four consecutive gate gradients -> their operand copy (bf16, or hi + lo of the split image)
+template <bool SC1>
+__device__ __forceinline__ void cell_d16_store(const t2amd_lstm_bwd& a, unsigned short* d, const float (&o)[4]) {
+    typedef unsigned long long u64;
+    const uint2 h = T2_PK4(o);
+    if constexpr (SC1) __hip_atomic_store(reinterpret_cast<u64*>(d), (u64)h.x | ((u64)h.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *reinterpret_cast<uint2*>(d) = h;
+    if (a.dgates16_x3) {
+        const float r[4] = {o[0] - __uint_as_float(h.x << 16), o[1] - __uint_as_float(h.x & 0xffff0000u),
+                            o[2] - __uint_as_float(h.y << 16), o[3] - __uint_as_float(h.y & 0xffff0000u)};
+        const uint2 l = T2_PK4(r);
+        if constexpr (SC1) __hip_atomic_store(reinterpret_cast<u64*>(d + 16), (u64)l.x | ((u64)l.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *reinterpret_cast<uint2*>(d + 16) = l;
+    }
+}
 // dh = (d0 + d1) + d2 in that order (the three addends of t2amd_lstm_bwd.dh, each already summed over its slabs)
 // SC1: the bf16 copy of the gate gradients is what the dgrad tiles of the SAME launch read next: write-through stores.
 template <bool SC1 = false>
@@ -95,7 +116,6 @@ __device__ __forceinline__ void cell_bwd_finish(const t2amd_lstm_bwd& a, const C
     const int H = a.H;
     float* dg = a.dgates + (long long)b * a.ld_dgates + j;
     float* dcp = a.dc + (long long)b * a.ld_dc + j;
-    unsigned short* d16 = a.dgates16 ? reinterpret_cast<unsigned short*>(a.dgates16) + (long long)b * a.ld_dgates16 + j : nullptr;
     const float gi_[4] = {r.gi.x, r.gi.y, r.gi.z, r.gi.w}, gf_[4] = {r.gf.x, r.gf.y, r.gf.z, r.gf.w};
     const float gg_[4] = {r.gg.x, r.gg.y, r.gg.z, r.gg.w}, go_[4] = {r.go.x, r.go.y, r.go.z, r.go.w};
     const float c_[4] = {r.c.x, r.c.y, r.c.z, r.c.w}, cp_[4] = {r.cprev.x, r.cprev.y, r.cprev.z, r.cprev.w};
@@ -119,20 +139,11 @@ __device__ __forceinline__ void cell_bwd_finish(const t2amd_lstm_bwd& a, const C
     *reinterpret_cast<float4*>(dg + H) = make_float4(o1[0], o1[1], o1[2], o1[3]);
     *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(o2[0], o2[1], o2[2], o2[3]);
     *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(o3[0], o3[1], o3[2], o3[3]);
-    if (d16) {       // bf16 copy: the dgrad GEMM's MFMA operand in bf16 mode
-        if constexpr (SC1) {
-            typedef unsigned long long u64;
-            const uint2 q0 = T2_PK4(o0), q1 = T2_PK4(o1), q2 = T2_PK4(o2), q3 = T2_PK4(o3);
-            __hip_atomic_store(reinterpret_cast<u64*>(d16), (u64)q0.x | ((u64)q0.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<u64*>(d16 + H), (u64)q1.x | ((u64)q1.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<u64*>(d16 + 2 * H), (u64)q2.x | ((u64)q2.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<u64*>(d16 + 3 * H), (u64)q3.x | ((u64)q3.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            *reinterpret_cast<uint2*>(d16) = T2_PK4(o0);
-            *reinterpret_cast<uint2*>(d16 + H) = T2_PK4(o1);
-            *reinterpret_cast<uint2*>(d16 + 2 * H) = T2_PK4(o2);
-            *reinterpret_cast<uint2*>(d16 + 3 * H) = T2_PK4(o3);
-        }
+    if (a.dgates16) {       // operand copy for the dgrad GEMM's MFMA: bf16 (bf16 mode) or the split hi/lo image ('bf16x3' mode)
+        cell_d16_store<SC1>(a, cell_d16_at(a, b, j), o0);
+        cell_d16_store<SC1>(a, cell_d16_at(a, b, H + j), o1);
+        cell_d16_store<SC1>(a, cell_d16_at(a, b, 2 * H + j), o2);
+        cell_d16_store<SC1>(a, cell_d16_at(a, b, 3 * H + j), o3);
     }
     *reinterpret_cast<float4*>(dcp) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
 }

@@ -89,10 +89,14 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
     T2_REQUIRE(p->HA && p->CA && p->GD && p->HD && p->CD && p->CTX && p->Q && p->ALIGN && p->CUM && p->cum_work &&
                    p->attn_ws,
                "dec_train_fwd: null slabs");
+    T2_REQUIRE(p->bf16 == 0 || p->bf16 == 1 || p->bf16 == 3, "dec_train_fwd: bf16 must be 0 (fp32), 1 (bf16) or 3 (split-bf16 x3)");
     if (p->bf16) {
-        T2_REQUIRE(p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16, "dec_train_fwd: bf16 mode needs the bf16 buffers");
-        T2_REQUIRE(E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0, "dec_train_fwd: bf16 mode needs E, Ha, Hd multiples of 128");
+        T2_REQUIRE(p->Wa_rec16 && p->Wd_cat16 && p->HA16 && p->HD16 && p->CTX16, "dec_train_fwd: bf16 / bf16x3 mode needs the operand copies");
+        T2_REQUIRE(p->bf16 == 3 || (E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0), "dec_train_fwd: bf16 mode needs E, Ha, Hd multiples of 128");
+        T2_REQUIRE(p->bf16 != 3 || (Ha % 8 == 0 && Hd % 8 == 0), "dec_train_fwd: bf16x3 mode needs Ha, Hd multiples of 8 (the wide tile)");
     }
+    // bf16 units per k in the operand copies: 1 = bf16 rows, 2 = split-bf16 images (hi + lo; strides in k as for f32)
+    const int us = p->bf16 == 3 ? 2 : 1;
     T2_PROPAGATE(t2amd_fill_f32(p->cum_work, (long long)B * Ti, 0.f, stream));
     // the granule block of the attention workspace (one-launch form of the step): zero once, tokens are never zero
     const long long fwd_ws_floats = t2amd_attn_fwd_ws_floats(B, Ti);
@@ -119,11 +123,11 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         if (p->bf16) {          // bf16 operands: same geometry, element pointers into the bf16 copies
             const unsigned short* c16 = (const unsigned short*)p->CTX16;
             const unsigned short* h16 = (const unsigned short*)p->HA16;
-            a.x[0].p = t ? (const float*)(c16 + (t - 1) * sE) : nullptr;
-            a.x[1].p = t ? (const float*)(h16 + (t - 1) * sHa) : nullptr;
+            a.x[0].p = t ? (const float*)(c16 + (t - 1) * sE * us) : nullptr;
+            a.x[1].p = t ? (const float*)(h16 + (t - 1) * sHa * us) : nullptr;
             a.W = (const float*)p->Wa_rec16;
-            a.bf16 = 1;
-            a.h16_out = (void*)((unsigned short*)p->HA16 + t * sHa); a.ld_h16 = Ha;
+            a.bf16 = p->bf16;
+            a.h16_out = (void*)((unsigned short*)p->HA16 + t * sHa * us); a.ld_h16 = Ha;
         }
     };
     auto fill_d = [&](int u, t2amd_lstm_step& d) {
@@ -145,12 +149,12 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
             const unsigned short* c16 = (const unsigned short*)p->CTX16;
             const unsigned short* ha16 = (const unsigned short*)p->HA16;
             unsigned short* hd16 = (unsigned short*)p->HD16;
-            d.x[0].p = (const float*)(ha16 + u * sHa);
-            d.x[1].p = (const float*)(c16 + u * sE);
-            d.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd) : nullptr;
+            d.x[0].p = (const float*)(ha16 + u * sHa * us);
+            d.x[1].p = (const float*)(c16 + u * sE * us);
+            d.x[2].p = u ? (const float*)(hd16 + (u - 1) * sHd * us) : nullptr;
             d.W = (const float*)p->Wd_cat16;
-            d.bf16 = 1;
-            d.h16_out = (void*)(hd16 + u * sHd); d.ld_h16 = Hd;
+            d.bf16 = p->bf16;
+            d.h16_out = (void*)(hd16 + u * sHd * us); d.ld_h16 = Hd;
         }
     };
     auto attention = [&](int t, void* st) -> int {
@@ -165,7 +169,9 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)To * Ti;
         at.ctx_out = p->CTX + t * sE; at.ld_ctx = E;
         at.q_out = p->Q + (long long)t * B * T2AMD_ATT_DIM; at.ld_q = T2AMD_ATT_DIM;
-        if (p->bf16) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; at.loc_split_bf16 = 1; at.memory16 = p->memory16; at.Wq16 = p->Wq16; }
+        if (p->bf16 == 1) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; at.loc_split_bf16 = 1; at.memory16 = p->memory16; at.Wq16 = p->Wq16; }
+        // bf16x3: the step itself stays exact f32; K_c also writes the split image of the context for the LSTM tiles
+        if (p->bf16 == 3) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE * 2); at.ld_ctx16 = E; at.ctx16_x3 = 1; }
         return t2amd_attention_step_fwd_f32(&at, st);
     };
 
@@ -173,7 +179,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
     // F32: exact-f32 MFMA) whenever the geometry allows -- the tile the persistent launch of this loop runs, so that chain and
     // persistent launch are the same arithmetic (T2AMD_FP32_WIDE=0: the 64 x 16 kernel, A/B runs).  Bit 2 of the order argument.
     static const bool wide32_env = [] { const char* e = getenv("T2AMD_FP32_WIDE"); return !(e && e[0] == '0'); }();
-    const int wide32 = (!p->bf16 && wide32_env && Ha % 8 == 0 && Hd % 8 == 0) ? 4 : 0;
+    const int wide32 = ((!p->bf16 && wide32_env && Ha % 8 == 0 && Hd % 8 == 0) || p->bf16 == 3) ? 4 : 0;
     if (g_dec_streams == 2) {
         // chain A (caller's stream): LSTM_a(t) -> K_e(t) -> K_c(t);  chain D (side stream): LSTM_d(t), trailing
         hipStream_t main_s = (hipStream_t)stream, side = nullptr;
@@ -236,7 +242,7 @@ struct DbpCtx { void* dev_descs; unsigned* flags; int* status; float* poison; };
 extern "C" int t2amd_decoder_train_bwd_persistent_supported(const t2amd_dec_train_bwd* p, int cus) {
     T2_REQUIRE(p != nullptr, "dec_train_bwd_persistent: null args");
     const t2amd_dec_train& f = p->f;
-    T2_REQUIRE(f.bf16 && p->Wa_recT16 && p->Wd_catT16 && p->DGA16 && p->DGD16 && f.memory16 && f.Wq16,
+    T2_REQUIRE(f.bf16 == 1 && p->Wa_recT16 && p->Wd_catT16 && p->DGA16 && p->DGD16 && f.memory16 && f.Wq16,
                "dec_train_bwd_persistent: bf16 operand mode only (bf16 copies of the transposed weights, the gate gradients, the memory and W_q)");
     T2_REQUIRE(g_cell_fold && g_dec_streams != 2 && t2amd_skinny_wide_enabled_(),
                "dec_train_bwd_persistent: needs the folded cells, one stream and the wide dgrad tile");
@@ -276,14 +282,15 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
                "dec_train_bwd: null pointer");
     T2_REQUIRE((4 * Ha) % 64 == 0 && (4 * Hd) % 64 == 0, "dec_train_bwd: 4H must be a multiple of 64");
     if (f.bf16) {
-        T2_REQUIRE(p->Wa_recT16 && p->Wd_catT16 && p->DGA16 && p->DGD16, "dec_train_bwd: bf16 mode needs the bf16 buffers");
+        T2_REQUIRE(p->Wa_recT16 && p->Wd_catT16 && p->DGA16 && p->DGD16, "dec_train_bwd: bf16 / bf16x3 mode needs the operand copies");
     }
+    const int us = f.bf16 == 3 ? 2 : 1;       // bf16 units per k in the operand copies (2: split-bf16 images)
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sE = (long long)B * E;
     const int Kd = Ha + E + Hd, Ka = E + Ha;
     const long long strXd = (long long)B * Kd, strXa = (long long)B * Ka;
     // fp32 parity mode (round 5): the BPTT data gradients on the wide exact-f32 tile too (T2AMD_FP32_WIDE=0: the 64 x 16 kernel)
     static const bool wide32_env = [] { const char* e = getenv("T2AMD_FP32_WIDE"); return !(e && e[0] == '0'); }();
-    const int wide32b = (!f.bf16 && wide32_env) ? 4 : 0;
+    const int wide32b = ((!f.bf16 && wide32_env) || f.bf16 == 3) ? 4 : 0;
 
     T2_PROPAGATE(t2amd_fill_f32(p->d_pm, (long long)B * Ti * T2AMD_ATT_DIM, 0.f, stream));
     T2_PROPAGATE(t2amd_fill_f32(p->dU_acc, (long long)B * T2AMD_ATT_DIM * T2AMD_LOC_TAPS, 0.f, stream));
@@ -316,7 +323,7 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
         lb.keep = f.keep_dec ? f.keep_dec + t * sHd : nullptr; lb.ld_keep = Hd; lb.keep_scale = f.scale_dec;
         lb.dc = p->dc_d; lb.ld_dc = Hd;
         lb.dgates = p->DGD + (long long)t * B * 4 * Hd; lb.ld_dgates = 4 * Hd;
-        if (f.bf16) { lb.dgates16 = (unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d; lb.ld_dgates16 = 4 * Hd; }
+        if (f.bf16) { lb.dgates16 = (unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d * us; lb.ld_dgates16 = 4 * Hd; lb.dgates16_x3 = f.bf16 == 3; }
     };
     auto dgrad_d = [&](int t, t2amd_skinny_gemm& g) {     // d[h_att_t | ctx_t | h_dec_{t-1}] = dgates_d . Wd_cat
         g = t2amd_skinny_gemm{};
@@ -324,7 +331,7 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
         g.x[0] = seg(p->DGD + (long long)t * B * 4 * Hd, 4 * Hd, 4 * Hd);
         g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
         g.Y = p->dXd + t * stepXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
-        if (f.bf16) { g.x[0].p = (const float*)((const unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d); g.W = (const float*)p->Wd_catT16; g.bf16 = 1; }
+        if (f.bf16) { g.x[0].p = (const float*)((const unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d * us); g.W = (const float*)p->Wd_catT16; g.bf16 = f.bf16; }
     };
     auto attn_desc = [&](int t, t2amd_attn_bwd& ab, const t2amd_lstm_bwd* cq, const t2amd_lstm_bwd* cx) {   // needs dXd(t), dXa(t+1)
         const bool last = (t == To - 1);
@@ -345,9 +352,9 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
         ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;
-        ab.bf16 = f.bf16 ? 1 : 0;
-        ab.memory16 = f.bf16 ? f.memory16 : nullptr;
-        ab.Wq16 = f.bf16 ? f.Wq16 : nullptr;
+        ab.bf16 = f.bf16 == 1 ? 1 : 0;            // (bf16x3: the attention backward stays in its exact-f32 form)
+        ab.memory16 = f.bf16 == 1 ? f.memory16 : nullptr;
+        ab.Wq16 = f.bf16 == 1 ? f.Wq16 : nullptr;
     };
     auto attn_bwd = [&](int t, void* st, const t2amd_lstm_bwd* cq = nullptr, const t2amd_lstm_bwd* cx = nullptr) -> int {
         t2amd_attn_bwd ab;
@@ -367,7 +374,7 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
         la.keep = f.keep_att ? f.keep_att + t * sHa : nullptr; la.ld_keep = Ha; la.keep_scale = f.scale_att;
         la.dc = p->dc_a; la.ld_dc = Ha;
         la.dgates = p->DGA + (long long)t * B * 4 * Ha; la.ld_dgates = 4 * Ha;
-        if (f.bf16) { la.dgates16 = (unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a; la.ld_dgates16 = 4 * Ha; }
+        if (f.bf16) { la.dgates16 = (unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a * us; la.ld_dgates16 = 4 * Ha; la.dgates16_x3 = f.bf16 == 3; }
     };
     auto dgrad_a = [&](int t, t2amd_skinny_gemm& ga) {    // d[ctx_{t-1} | h_att_{t-1}] = dgates_a(t) . Wa_rec
         ga = t2amd_skinny_gemm{};
@@ -375,10 +382,10 @@ static int dec_train_bwd_impl(const t2amd_dec_train_bwd* p, void* stream, const 
         ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
         ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
         ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa; ga.tag = 1;
-        if (f.bf16) { ga.x[0].p = (const float*)((const unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a); ga.W = (const float*)p->Wa_recT16; ga.bf16 = 1; }
+        if (f.bf16) { ga.x[0].p = (const float*)((const unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a * us); ga.W = (const float*)p->Wa_recT16; ga.bf16 = f.bf16; }
     };
 
-    if (pc) T2_REQUIRE(g_dec_streams != 2 && g_cell_fold && f.bf16, "dec_train_bwd_persistent: needs one stream, the folded cells and bf16 operands");
+    if (pc) T2_REQUIRE(g_dec_streams != 2 && g_cell_fold && f.bf16 == 1, "dec_train_bwd_persistent: needs one stream, the folded cells and bf16 operands");
     if (g_dec_streams == 2) {
         // chain D (side stream, leads): cell_d(t) -> dgrad_d(t) for t = To-1 .. 0, nothing else feeds it;
         // chain A (caller's stream): attention bwd -> cell_a -> dgrad_a, consuming dXd(t) a chunk behind.

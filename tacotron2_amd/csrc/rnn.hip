@@ -351,14 +351,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
 }
 
 // the wide tile as a kernel of its own: one launch per step (body: skinny_wide.h)
-template <bool LSTM, int TAG, bool F32 = false>
+// MODE: SW_BF16 / SW_F32 / SW_X3 (skinny_wide.h)
+template <bool LSTM, int TAG, int MODE = SW_BF16>
 __global__ __launch_bounds__(512) void skinny_wide_kernel(SkinnyDual dp) {
     __shared__ __attribute__((aligned(16))) char smem[SW_NBUF * (SW_XB + SW_WB)];
     const bool second = (int)blockIdx.x >= dp.nblk0;
     const SkinnyParams p = skinny_select(dp, second);
     const int lb = (int)blockIdx.x - (second ? dp.nblk0 : 0);
     NoGate ng;
-    skinny_wide_body<LSTM, false, NoGate, false, F32>(p, lb, smem, dp.ts, ng);
+    skinny_wide_body<LSTM, false, NoGate, false, MODE>(p, lb, smem, dp.ts, ng);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -650,11 +651,13 @@ static bool skinny_wide_enabled() {
     return on;
 }
 
+// k per 256-byte tile row by operand mode (t2amd_lstm_step.bf16): bf16 rows hold 128 k, f32 rows and split-bf16 images (3) 64
+static inline int sk_bk(int mode) { return (mode == 1 || mode == 2) ? 128 : 64; }
 static int check_segs(const t2amd_seg* x, int nseg, int Ktot, int bk) {
     if (nseg < 1 || nseg > 3) T2_FAIL("skinny: nseg must be 1..3");
     int sum = 0;
     for (int i = 0; i < nseg; ++i) {
-        if (x[i].width <= 0 || x[i].width % bk != 0) T2_FAIL("skinny: segment widths must be positive multiples of 64 (f32) / 128 (bf16)");
+        if (x[i].width <= 0 || x[i].width % bk != 0) T2_FAIL("skinny: segment widths must be positive multiples of 64 (f32, split-bf16 x3) / 128 (bf16)");
         if (x[i].p && (!t2_aligned16(x[i].p) || x[i].ld % 8 != 0)) T2_FAIL("skinny: segment must be 16-byte aligned with ld % 8 == 0");
         sum += x[i].width;
     }
@@ -664,7 +667,8 @@ static int check_segs(const t2amd_seg* x, int nseg, int Ktot, int bk) {
 
 static int fill_lstm(const t2amd_lstm_step* a, SkinnyParams& p) {
     T2_REQUIRE(a != nullptr, "lstm_step: null args");
-    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot, a->bf16 ? 128 : 64));
+    T2_REQUIRE(a->bf16 >= 0 && a->bf16 <= 3, "lstm_step: bf16 must be 0 (f32), 1 (bf16), 2 (bf16 weights only, small batch) or 3 (split-bf16 x3)");
+    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot, sk_bk(a->bf16)));
     T2_REQUIRE(a->W && t2_aligned16(a->W), "lstm_step: W must be 16-byte aligned");
     T2_REQUIRE(a->H > 0 && a->H % 4 == 0 && a->B > 0, "lstm_step: H must be a multiple of 4");
     T2_REQUIRE(a->gates_out && a->c_out && a->h_out, "lstm_step: null outputs");
@@ -710,10 +714,12 @@ static int lstm_step_fwd2_impl(const t2amd_lstm_step* a, const t2amd_lstm_step* 
         if (prof) hipExtLaunchKernelGGL(K, G, BLK, 0, s, pe0, pe1, 0, d);              \
         else T2_LAUNCH(K, G, BLK, 0, s, d);                                            \
     } while (0)
-    T2_REQUIRE(!b || (a->bf16 != 0) == (b->bf16 != 0), "lstm_step: both problems of a launch must share the operand type");
+    T2_REQUIRE(!b || a->bf16 == b->bf16, "lstm_step: both problems of a launch must share the operand type");
+    const bool x3 = a->bf16 == 3;
+    T2_REQUIRE(!x3 || (skinny_wide_enabled() && a->H % 8 == 0 && (!b || b->H % 8 == 0)), "lstm_step: split-bf16 x3 operands run on the wide tile only (H % 8 == 0)");
     // several rounds of 64 x 32 workgroups (decode batches of 256 and more): one round of 64 x 64 ones instead
     static const int wide64 = [] { const char* e = getenv("T2AMD_LSTM_WIDE64"); return e ? atoi(e) : -1; }();   // A/B runs only
-    if (a->bf16 && skinny_wide_enabled() && !b && a->H % 16 == 0 &&
+    if (a->bf16 && !x3 && skinny_wide_enabled() && !b && a->H % 16 == 0 &&
         (wide64 < 0 ? (long long)d.p[0].gy * (a->H / 8) >= 512 : wide64 != 0)) {
         d.p[0].gx = a->H / 16;
         d.nblk0 = total = d.p[0].gx * d.p[0].gy;
@@ -737,11 +743,17 @@ static int lstm_step_fwd2_impl(const t2amd_lstm_step* a, const t2amd_lstm_step* 
             }
         }
         if (b) { d.p[1].gx = b->H / 8; total += d.p[1].gx * d.p[1].gy; } else { d.p[1] = d.p[0]; }
+        if (x3) {
+            if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1, SW_X3>), dim3(total), dim3(512));
+            else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2, SW_X3>), dim3(total), dim3(512));
+            else if (a->tag == 3) LSTM_LAUNCH((skinny_wide_kernel<true, 3, SW_X3>), dim3(total), dim3(512));
+            else LSTM_LAUNCH((skinny_wide_kernel<true, 0, SW_X3>), dim3(total), dim3(512));
+        } else
         if (!a->bf16) {
-            if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1, true>), dim3(total), dim3(512));
-            else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2, true>), dim3(total), dim3(512));
-            else if (a->tag == 3) LSTM_LAUNCH((skinny_wide_kernel<true, 3, true>), dim3(total), dim3(512));
-            else LSTM_LAUNCH((skinny_wide_kernel<true, 0, true>), dim3(total), dim3(512));
+            if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1, SW_F32>), dim3(total), dim3(512));
+            else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2, SW_F32>), dim3(total), dim3(512));
+            else if (a->tag == 3) LSTM_LAUNCH((skinny_wide_kernel<true, 3, SW_F32>), dim3(total), dim3(512));
+            else LSTM_LAUNCH((skinny_wide_kernel<true, 0, SW_F32>), dim3(total), dim3(512));
         } else
         if (a->tag == 1) LSTM_LAUNCH((skinny_wide_kernel<true, 1>), dim3(total), dim3(512));
         else if (a->tag == 2) LSTM_LAUNCH((skinny_wide_kernel<true, 2>), dim3(total), dim3(512));
@@ -777,7 +789,8 @@ extern "C" int t2amd_lstm_step_fwd_f32(const t2amd_lstm_step* a, void* stream) {
 
 static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
     T2_REQUIRE(a != nullptr, "skinny_gemm: null args");
-    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot, a->bf16 ? 128 : 64));
+    T2_REQUIRE(a->bf16 == 0 || a->bf16 == 1 || a->bf16 == 3, "skinny_gemm: bf16 must be 0 (f32), 1 (bf16) or 3 (split-bf16 x3)");
+    T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot, sk_bk(a->bf16)));
     T2_REQUIRE(a->W && t2_aligned16(a->W) && a->Y, "skinny_gemm: bad pointers");
     T2_REQUIRE(a->N > 0 && a->B > 0 && a->nsplit >= 1, "skinny_gemm: bad dims");
     p = SkinnyParams{};
@@ -794,7 +807,7 @@ static int fill_plain(const t2amd_skinny_gemm* a, SkinnyParams& p) {
                "skinny_gemm: the stop test needs nsplit == 1, its three arrays and a column of Y");
     p.stop_active = a->stop_active; p.stop_lengths = a->stop_lengths; p.stop_done = a->stop_done;
     p.stop_col = a->stop_col; p.stop_max_steps = a->stop_max_steps; p.stop_thr = a->stop_threshold; p.t = a->stop_t;
-    const int ktiles = a->Ktot / (a->bf16 ? 128 : 64);
+    const int ktiles = a->Ktot / sk_bk(a->bf16);
     p.ktiles_per_split = t2_cdiv(ktiles, a->nsplit);
     p.gx = t2_cdiv(a->N, 16); p.gy = t2_cdiv(a->B, SK_ROWS); p.gz = a->nsplit;
     p.wcol[0] = p.wcol[1] = p.wcol[2] = -1;
@@ -824,17 +837,25 @@ static int skinny_gemm2_impl(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm
         d.p[1] = d.p[0];
     }
     hipStream_t s = (hipStream_t)stream;
-    T2_REQUIRE(!b || (a->bf16 != 0) == (b->bf16 != 0), "skinny_gemm: both problems of a launch must share the operand type");
+    T2_REQUIRE(!b || a->bf16 == b->bf16, "skinny_gemm: both problems of a launch must share the operand type");
+    const bool x3 = a->bf16 == 3;
+    T2_REQUIRE(!x3 || skinny_wide_enabled(), "skinny_gemm: split-bf16 x3 operands run on the wide tile only");
     if ((a->bf16 || (order & 4)) && skinny_wide_enabled()) {
         d.p[0].gx = t2_cdiv(a->N, 32);
         d.nblk0 = d.p[0].gx * d.p[0].gy * d.p[0].gz;
         total = d.nblk0;
         if (b) { d.p[1].gx = t2_cdiv(b->N, 32); total += d.p[1].gx * d.p[1].gy * d.p[1].gz; } else { d.p[1] = d.p[0]; }
+        if (x3) {
+            if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<false, 1, SW_X3>), dim3(total), dim3(512), 0, s, d);
+            else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<false, 2, SW_X3>), dim3(total), dim3(512), 0, s, d);
+            else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_wide_kernel<false, 3, SW_X3>), dim3(total), dim3(512), 0, s, d);   // BPTT dgrad pair
+            else T2_LAUNCH((skinny_wide_kernel<false, 0, SW_X3>), dim3(total), dim3(512), 0, s, d);
+        } else
         if (!a->bf16) {
-            if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<false, 1, true>), dim3(total), dim3(512), 0, s, d);
-            else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<false, 2, true>), dim3(total), dim3(512), 0, s, d);
-            else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_wide_kernel<false, 3, true>), dim3(total), dim3(512), 0, s, d);   // BPTT dgrad pair
-            else T2_LAUNCH((skinny_wide_kernel<false, 0, true>), dim3(total), dim3(512), 0, s, d);
+            if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<false, 1, SW_F32>), dim3(total), dim3(512), 0, s, d);
+            else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<false, 2, SW_F32>), dim3(total), dim3(512), 0, s, d);
+            else if (a->tag == 3) T2_LAUNCH_ROLE(6, (skinny_wide_kernel<false, 3, SW_F32>), dim3(total), dim3(512), 0, s, d);   // BPTT dgrad pair
+            else T2_LAUNCH((skinny_wide_kernel<false, 0, SW_F32>), dim3(total), dim3(512), 0, s, d);
         } else
         if (a->tag == 1) T2_LAUNCH((skinny_wide_kernel<false, 1>), dim3(total), dim3(512), 0, s, d);
         else if (a->tag == 2) T2_LAUNCH((skinny_wide_kernel<false, 2>), dim3(total), dim3(512), 0, s, d);
@@ -864,7 +885,7 @@ extern "C" int t2amd_skinny_wide_enabled_(void) { return skinny_wide_enabled() ?
 // t2amd_skinny_gemm2_f32(a, b) would make on the wide bf16 tile -- nothing is launched.  Any other kernel form is an error.
 extern "C" int t2amd_skinny_gemm2_describe_(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, SkinnyDual* d, int* total) {
     T2_REQUIRE(a && b && d && total, "skinny_gemm2_describe: null args");
-    T2_REQUIRE(a->bf16 && b->bf16 && skinny_wide_enabled(), "skinny_gemm2_describe: the wide bf16 tile only");
+    T2_REQUIRE(a->bf16 == 1 && b->bf16 == 1 && skinny_wide_enabled(), "skinny_gemm2_describe: the wide bf16 tile only");
     d->ts = t2amd_debug_ts_();
     T2_PROPAGATE(fill_plain(a, d->p[0]));
     T2_PROPAGATE(fill_plain(b, d->p[1]));
@@ -905,7 +926,6 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
     const int j = (int)(idx - (long long)b * H4) * 4;
     float* dg = a.dgates + (long long)b * a.ld_dgates + j;
     float* dcp = a.dc + (long long)b * a.ld_dc + j;
-    unsigned short* d16 = a.dgates16 ? reinterpret_cast<unsigned short*>(a.dgates16) + (long long)b * a.ld_dgates16 + j : nullptr;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     bool valid = true;
     if (a.lens) valid = a.t < a.lens[b];
@@ -913,7 +933,10 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             *reinterpret_cast<float4*>(dg + q * H) = z4;
-            if (d16) *reinterpret_cast<uint2*>(d16 + q * H) = make_uint2(0u, 0u);
+            if (a.dgates16) {
+                const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+                cell_d16_store<false>(a, cell_d16_at(a, b, q * H + j), zero4);
+            }
         }
         *reinterpret_cast<float4*>(dcp) = z4;
         return;

@@ -468,11 +468,17 @@ class _Run(object):
         self.arena = arena
         self._persist = 0                # > 0 inside `cached`: what is made there outlives the step
         self.cache = cache if cache is not None else {}
-        if precision not in ('fp32', 'bf16'):
-            raise NativeError("precision must be 'fp32' or 'bf16', got %r" % (precision,))
+        if precision not in ('fp32', 'bf16', 'bf16x3'):
+            raise NativeError("precision must be 'fp32', 'bf16' or 'bf16x3', got %r" % (precision,))
         self.bf16 = precision == 'bf16'
+        # 'bf16x3' (round 6): the ACCURATE-FAST mode.  Everything is the fp32 parity mode -- f32 state, slabs,
+        # attention kernels in their exact-f32 forms -- except the matrix products that were bound by the exact-f32 MFMA rate
+        # (157 TF, 1/16 of bf16): the LSTM tiles of both time loops multiply SPLIT-bf16 operand images (x = hi + lo in bf16;
+        # hi.hi + lo.hi + hi.lo on the bf16 MFMA, f32 accumulation: ~2^-17 relative per product, csrc/skinny_wide.h SW_X3) and the
+        # dense forward products use the split-bf16 GEMM the gradient products already use (t2amd_gemm_desc.precision = 1).
+        self.x3 = precision == 'bf16x3'
         # t2amd_gemm_desc.precision: 0 exact f32 MFMA, 1 split-bf16 x3 (f32-class), 2 plain bf16
-        self.fwdp = 2 if self.bf16 else 0
+        self.fwdp = 2 if self.bf16 else (1 if self.x3 else 0)
         self.gradp = 2 if self.bf16 else (1 if FAST_GRAD_GEMM else 0)
 
     def cached(self, tag, deps, fn):
@@ -515,6 +521,12 @@ class _Run(object):
     def cast16(self, t):
         out = self.empty16(*t.shape)
         nv.cast_bf16(t.contiguous(), out)
+        return out
+
+    def split16(self, t):
+        """The split-bf16 operand image of an f32 matrix ([..., K] -> bfloat16 [..., 2 K]; native.split_bf16x3)."""
+        out = self.empty16(*(tuple(t.shape[:-1]) + (2 * t.shape[-1],)))
+        nv.split_bf16x3(t.contiguous(), out)
         return out
 
     def empty(self, *shape):
@@ -1259,11 +1271,21 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
         d.bf16 = 1
         for k_, v_ in c.bf16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
+    elif run.x3:
+        # 'bf16x3' mode: SPLIT-bf16 images (4 bytes per k: hi + lo) of the packed weights and of the three recurrent operand slabs;
+        # the tile epilogues / K_c write the slabs' images next to the f32 values.  No bf16 memory / W_q: the attention stays f32.
+        c.bf16 = dict(Wa_rec16=run.cached('Wa_rec16x3', [Wih_a, Whh_a], lambda: run.split16(Wa_rec)),
+                      Wd_cat16=run.cached('Wd_cat16x3', [Wih_d, Whh_d], lambda: run.split16(Wd_cat)),
+                      HA16=run.empty16(To, B, 2 * Ha), HD16=run.empty16(To, B, 2 * Hd), CTX16=run.empty16(To, B, 2 * E))
+        d.bf16 = 3
+        for k_, v_ in c.bf16.items():
+            setattr(d, k_, nv.ptr(v_, torch.bfloat16))
+    op16 = run.bf16 or run.x3
     model.last_train_decoder_path = _decoder_train_fwd(
         model, run, d, poison=slabs['CTX'] if training else None,                         # model.py:405-411
         reads=[Wa_rec, Wd_cat, bias_d, Wq, U, vvec, memory, pm, lens32, keep_att, keep_dec]
-        + ([c.bf16[k_] for k_ in ('Wa_rec16', 'Wd_cat16', 'memory16', 'Wq16')] if run.bf16 else []),
-        writes=[GA] + list(slabs.values()) + ([c.bf16[k_] for k_ in ('HA16', 'HD16', 'CTX16')] if run.bf16 else []),
+        + ([c.bf16[k_] for k_ in ('Wa_rec16', 'Wd_cat16')] if op16 else []) + ([c.bf16[k_] for k_ in ('memory16', 'Wq16')] if run.bf16 else []),
+        writes=[GA] + list(slabs.values()) + ([c.bf16[k_] for k_ in ('HA16', 'HD16', 'CTX16')] if op16 else []),
         regen_ga=project_ga)
 
     # mel + gate projection over all steps (model.py:373-378)
@@ -1411,12 +1433,21 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
             setattr(bw, k_, nv.ptr(v_, torch.bfloat16))
         if slab16:
             bw.dg16_step_a, bw.dg16_step_d = B * 4 * Ha, B * 4 * Hd
+    elif run.x3:
+        # split-bf16 images of the transposed weights and of ONE step's gate gradients (written by the cell backward)
+        b16 = dict(Wa_recT16=run.cached('Wa_recT16x3', [Wih_a, Whh_a], lambda: run.split16(Wa_recT)),
+                   Wd_catT16=run.cached('Wd_catT16x3', [Wih_d, Whh_d], lambda: run.split16(Wd_catT)),
+                   DGA16=run.empty16(1, B, 8 * Ha), DGD16=run.empty16(1, B, 8 * Hd))
+        for k_, v_ in b16.items():
+            setattr(bw, k_, nv.ptr(v_, torch.bfloat16))
+    op16 = run.bf16 or run.x3
     model.last_train_decoder_bwd_path = _decoder_train_bwd(model, run, bw, out['dv_acc'],
                               reads=[Wa_recT, Wd_catT, DHC, cont(d_align), T['Wq'], T['U'], T['vvec'], T['pm'], c.memory,
                                      T['lens32'], T['GA'], c.keep['att'], c.keep['dec']]
                               + [S[k_] for k_ in ('HA', 'CA', 'GD', 'HD', 'CD', 'CTX', 'Q', 'ALIGN', 'CUM')]
-                              + ([b16['Wa_recT16'], b16['Wd_catT16'], c.bf16['memory16'], c.bf16['Wq16']] if run.bf16 else []),
-                              writes=list(out.values()) + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if run.bf16 else []))
+                              + ([b16['Wa_recT16'], b16['Wd_catT16']] if op16 else [])
+                              + ([c.bf16['memory16'], c.bf16['Wq16']] if run.bf16 else []),
+                              writes=list(out.values()) + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if op16 else []))
     if defer_postnet:
         sync.bucket_ready('postnet')
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))

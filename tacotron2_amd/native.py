@@ -986,30 +986,40 @@ def relu_dropout_bwd(dy, y, scale):
 # ----------------------------------------------------------------------------
 # recurrent / attention single steps (used by the unit tests; the loops call them in C)
 # ----------------------------------------------------------------------------
-def _seg(t, width, dtype=torch.float32):
+def _seg(t, width, dtype=torch.float32, x3=False):
+    """``x3``: t is a split-bf16 image (split_bf16x3: 2 bf16 per k); width and ld count k, as for f32."""
     s = Seg()
     if t is None:
         s.p, s.ld, s.width = None, width, width
     else:
         p, ld, _, cols = _mat(t, dtype)
-        assert cols == width
+        if x3:
+            if cols != 2 * width or ld % 2:
+                raise NativeError("split-bf16 segment: expected %d columns (2 per k), got %d (ld %d)" % (2 * width, cols, ld))
+            ld //= 2
+        else:
+            assert cols == width
         s.p, s.ld, s.width = p, ld, width
     return s
 
 
 def lstm_step_fwd(xs, widths, W, H, B, gates_out, c_out, h_out, gin=None, bias=None, c_prev=None,
                   keep=None, keep_scale=1.0, lens=None, t=0, small=False, bf16=False, h16_out=None):
-    """``bf16=True``: xs and W are torch.bfloat16 (MFMA operands), everything else stays f32."""
+    """``bf16=True``: xs and W are torch.bfloat16 (MFMA operands), everything else stays f32.  ``bf16=3``: xs, W and h16_out are
+    split-bf16 images (split_bf16x3: bfloat16 tensors with two columns per k) -- the 'bf16x3' mode of the wide tile."""
     lib = load()
     a = LstmStep()
     a.nseg = len(xs)
+    x3 = bf16 == 3 and bf16 is not True
     odt = torch.bfloat16 if bf16 else torch.float32
     for i, (x, w) in enumerate(zip(xs, widths)):
-        a.x[i] = _seg(x, w, odt)
+        a.x[i] = _seg(x, w, odt, x3)
     a.W = ptr(_fullc(W), odt)
-    a.bf16 = 1 if bf16 else 0
+    a.bf16 = 3 if x3 else (1 if bf16 else 0)
     if h16_out is not None:
         a.h16_out, a.ld_h16 = _mat(h16_out, torch.bfloat16)[:2]
+        if x3:
+            a.ld_h16 //= 2
     a.Ktot, a.H, a.B = sum(widths), H, B
     if gin is not None:
         a.gin, a.ld_gin = _mat(gin)[:2]
@@ -1046,15 +1056,16 @@ def linear_small(X, W, Y, bias=None, act=0, keep=None, keep_scale=1.0):
 
 
 def skinny_gemm(xs, widths, W, N, B, Y, nsplit=1, bf16=False, bias=None, act=0, keep=None, keep_scale=1.0):
-    """Y[nsplit, B, N] = [xs...] . W[N, K]^T"""
+    """Y[nsplit, B, N] = [xs...] . W[N, K]^T   (``bf16=3``: xs and W are split-bf16 images, see lstm_step_fwd)"""
     lib = load()
     a = SkinnyGemm()
     a.nseg = len(xs)
+    x3 = bf16 == 3 and bf16 is not True
     odt = torch.bfloat16 if bf16 else torch.float32
     for i, (x, w) in enumerate(zip(xs, widths)):
-        a.x[i] = _seg(x, w, odt)
+        a.x[i] = _seg(x, w, odt, x3)
     a.W = ptr(_fullc(W), odt)
-    a.bf16 = 1 if bf16 else 0
+    a.bf16 = 3 if x3 else (1 if bf16 else 0)
     a.Ktot, a.N, a.B = sum(widths), N, B
     _fullc(Y)
     a.Y, a.ldy, a.nsplit, a.split_stride = ptr(Y), N, nsplit, B * N
@@ -1076,7 +1087,7 @@ def _addend(t, nsplit=1, split_stride=0):
     return a
 
 
-def lstm_bwd_desc(B, H, dh_list, gates, c_prev, c, keep, keep_scale, dc, dgates, lens=None, t=0, dgates16=None):
+def lstm_bwd_desc(B, H, dh_list, gates, c_prev, c, keep, keep_scale, dc, dgates, lens=None, t=0, dgates16=None, x3=False):
     """One cell-backward descriptor.  dh_list entries: a tensor, None, or (tensor, nsplit, split_stride) for an addend
     made of partial slabs."""
     a = LstmBwd()
@@ -1096,6 +1107,8 @@ def lstm_bwd_desc(B, H, dh_list, gates, c_prev, c, keep, keep_scale, dc, dgates,
     a.t = t
     if dgates16 is not None:
         a.dgates16, a.ld_dgates16 = ptr(dgates16, torch.bfloat16), dgates16.stride(0)
+        if x3:                           # split-bf16 image of the gate gradients: [B][2 * 4H] bf16, ld in k
+            a.ld_dgates16, a.dgates16_x3 = dgates16.stride(0) // 2, 1
     return a
 
 
@@ -1188,7 +1201,8 @@ def set_attn_bwd_fused(on):
 
 
 def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_out, ctx_out, q_out, ws, active=None,
-                       bf16=False, memory16=None, Wq16=None):
+                       bf16=False, memory16=None, Wq16=None, ctx_x3_out=None):
+    """``ctx_x3_out``: a [B][2 E] bfloat16 tensor that receives the split-bf16 image of the context ('bf16x3' mode)."""
     lib = load()
     a = AttnFwd()
     B, Ti, E = memory.shape
@@ -1214,6 +1228,10 @@ def attention_step_fwd(h, Wq, U, v, pm, memory, lens, w_prev, cum, cum_save, w_o
         a.memory16 = ptr(_fullc(memory16), torch.bfloat16)
     if Wq16 is not None:
         a.Wq16 = ptr(_fullc(Wq16), torch.bfloat16)
+    if ctx_x3_out is not None:
+        if tuple(ctx_x3_out.shape) != (B, 2 * E) or E % 16:
+            raise NativeError("attention_step_fwd: ctx_x3_out must be [B][2 E] bfloat16, E %% 16 == 0")
+        a.ctx16_out, a.ld_ctx16, a.ctx16_x3 = ptr(_fullc(ctx_x3_out), torch.bfloat16), E, 1
     _check(lib.t2amd_attention_step_fwd_f32(C.byref(a), _stream()), "t2amd_attention_step_fwd_f32")
 
 

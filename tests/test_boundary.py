@@ -96,9 +96,10 @@ def test_argument_validation_errors_are_reported(native_lib):
     assert rc == 1 and b"null operand" in native_lib.t2amd_last_error()
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("fold", [0, 1])
 @pytest.mark.parametrize("hpstr,in_lens,out_lens", [(gu.TINY_HP, [12, 9, 5], [20, 16, 11]), ("", [17, 11], [30, 23])])
-def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens, fold):
+def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens, fold, precision):
     """Every host-side check / loop of forward, backward and inference runs (kernels skipped):
     catches shape, stride, alignment and pointer-plumbing errors without a GPU.  fold = 1: the BPTT loop hands the
     step's LSTM cell backwards to the attention-backward call (t2amd_attn_bwd.cell_q / cell_x), whose descriptor checks
@@ -109,6 +110,7 @@ def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens, fold)
     try:
         hp = create_hparams((hpstr + "," if hpstr else "") + "max_decoder_steps=6")
         m = Tacotron2(hp)
+        m.precision = precision          # (all three operand modes of the time loops: f32 slabs, bf16 copies, split-bf16 images)
         batch = gu.make_train_batch(in_lens, out_lens, 80, 1)
         x, y = m.parse_batch(batch)
         out = m(x)

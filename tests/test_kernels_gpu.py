@@ -893,6 +893,140 @@ def test_lstm_step_bf16_operands(nv, B, H, widths):
 
 
 # ------------------------------------------------------------------------------------------------
+# split-bf16 operand images and the 'bf16x3' form of the wide tile (round 6; csrc/skinny_wide.h SW_X3)
+# ------------------------------------------------------------------------------------------------
+def split_image_ref(x):
+    """CPU restatement of t2amd_split_bf16x3_f32: [..., K] f32 -> [..., 2 K] bf16, per 16 k: 16 hi = bf16(x), 16 lo = bf16(x - hi)."""
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    g = x.shape[-1] // 16
+    hi, lo = hi.reshape(x.shape[:-1] + (g, 16)), lo.reshape(x.shape[:-1] + (g, 16))
+    return torch.cat((hi, lo), -1).reshape(x.shape[:-1] + (2 * x.shape[-1],))
+
+
+def unsplit(img):
+    """hi + lo of an image as f32 (what the three products of the tile add up to, to ~2^-17)."""
+    g = img.shape[-1] // 32
+    v = img.float().reshape(img.shape[:-1] + (g, 2, 16))
+    return (v[..., 0, :] + v[..., 1, :]).reshape(img.shape[:-1] + (g * 16,))
+
+
+@pytest.mark.parametrize("rows,K", [(7, 16), (64, 1536), (300, 4096), (1, 80 * 16)])
+def test_split_bf16x3_image(nv, rows, K):
+    x = rnd(rows, K, seed=300) * torch.logspace(-3, 2, K).unsqueeze(0)
+    out = torch.empty(rows, 2 * K, device=DEV, dtype=torch.bfloat16)
+    nv.split_bf16x3(dv(x), out)
+    ref = split_image_ref(x)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    rel = ((unsplit(out.cpu()) - x).abs() / x.abs().clamp_min(1e-30)).max().item()
+    assert rel < 2.0 ** -16, rel                       # 16 mantissa bits: 2^-17 per half, both roundings
+
+
+@pytest.mark.parametrize("B,H,widths", [(64, 256, (256, 128, 256)), (37, 128, (128,)), (3, 64, (128, 256)), (64, 1024, (1024, 512, 1024))])
+def test_lstm_step_bf16x3_operands(nv, B, H, widths):
+    """Split-bf16 X and W (hi.hi + lo.hi + hi.lo on v_mfma_f32_32x32x16_bf16, f32 accumulate) against the f64 product of the f32
+    operands: f32-class -- each product is 2^-17-relative, so the pre-activations agree to ~1e-6 of their scale, 300 x closer than
+    the bf16 mode's -- and the split image of h equals the split of the h it wrote."""
+    K = sum(widths)
+    xs = [rnd(B, w, seed=120 + i) for i, w in enumerate(widths)]
+    W = rnd(4 * H, K, seed=124, scale=0.05) * (1 + torch.arange(4 * H).float().unsqueeze(1) / H)
+    gin, bias, c_prev = rnd(B, 4 * H, seed=125), rnd(4 * H, seed=126), rnd(B, H, seed=127)
+    pre = (torch.cat(xs, 1).double() @ W.double().t() + gin.double() + bias.double())
+    i, f, g, o = pre.chunk(4, 1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c = f * c_prev.double() + i * g
+    h = o * torch.tanh(c)
+    gates = torch.full((B, 4 * H), float('nan'), device=DEV)
+    c_out, h_out = torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+    h3 = torch.empty(B, 2 * H, device=DEV, dtype=torch.bfloat16)
+    x3 = [torch.empty(B, 2 * w, device=DEV, dtype=torch.bfloat16) for w in widths]
+    for xi, x in zip(x3, xs):
+        nv.split_bf16x3(dv(x), xi)
+    W3 = torch.empty(4 * H, 2 * K, device=DEV, dtype=torch.bfloat16)
+    nv.split_bf16x3(dv(W), W3)
+    nv.lstm_step_fwd(x3, list(widths), W3, H, B, gates, c_out, h_out, gin=dv(gin), bias=dv(bias), c_prev=dv(c_prev), bf16=3, h16_out=h3)
+    # K <= 2560 products of |x| ~ 1, |w| ~ 0.05-0.1: pre-activations ~ 3; 2^-17-relative products, random signs
+    assert err(gates, torch.cat((i, f, g, o), 1)) < 3e-6
+    assert err(c_out, c) < 3e-6 and err(h_out, h) < 3e-6
+    assert torch.equal(h3.cpu().view(torch.int16), split_image_ref(h_out.cpu()).view(torch.int16))
+    # and far inside the bf16 mode's own error on the same operands
+    pre16 = torch.cat([x.bfloat16().double() for x in xs], 1) @ W.bfloat16().double().t() + gin.double() + bias.double()
+    e16 = (torch.sigmoid(pre16[:, :H]) - i).abs().max().item()
+    e3 = (gates[:, :H].cpu().double() - i).abs().max().item()
+    assert e3 < 0.02 * e16 + 1e-7, (e3, e16)
+    # dropout mask + finished rows: the epilogue's other branch
+    keep = (torch.rand(B, H, generator=torch.Generator().manual_seed(129)) > 0.3).to(torch.uint8)
+    lens = torch.tensor([(5 if r % 3 else 2) for r in range(B)], dtype=torch.int32)
+    nv.lstm_step_fwd(x3, list(widths), W3, H, B, gates, c_out, h_out, gin=dv(gin), bias=dv(bias), c_prev=dv(c_prev),
+                     keep=keep.to(DEV), keep_scale=1.0 / 0.7, lens=lens.to(DEV), t=3, bf16=3, h16_out=h3)
+    live = (3 < lens).double().unsqueeze(1)
+    assert err(h_out, h * keep.double() / 0.7 * live) < 3e-6
+    assert torch.equal(h3.cpu().view(torch.int16), split_image_ref(h_out.cpu()).view(torch.int16))
+    # plain (dgrad-shaped) product with split-K
+    N = 200
+    W2 = rnd(N, K, seed=128, scale=0.1)
+    W23 = torch.empty(N, 2 * K, device=DEV, dtype=torch.bfloat16)
+    nv.split_bf16x3(dv(W2), W23)
+    for ns in (1, 2, 4):
+        if (K // 64) % ns:
+            continue
+        Y = torch.empty(ns, B, N, device=DEV)
+        nv.skinny_gemm(x3, list(widths), W23, N, B, Y, nsplit=ns, bf16=3)
+        assert err(Y.sum(0), torch.cat(xs, 1).double() @ W2.double().t()) < 3e-6
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_attention_context_leaves_as_a_split_image_too(nv, fused):
+    """t2amd_attn_fwd.ctx16_x3: K_c writes the split-bf16 image of the context next to the f32 context ('bf16x3' mode: the LSTM
+    tiles' operand); the step itself is the exact-f32 form, bit-identical with and without the image."""
+    B, Ti, E, Hq = 5, 150, 512, 1024
+    sd, h, mem, pm, lens, w_prev, cum = _attn_inputs(B, Ti, E, Hq, 70)
+    Wq = dv(sd['decoder.attention_layer.query_layer.linear_layer.weight'])
+    Wd = dv(sd['decoder.attention_layer.location_layer.location_dense.linear_layer.weight'])
+    Wc = dv(sd['decoder.attention_layer.location_layer.location_conv.conv.weight'])
+    v = dv(sd['decoder.attention_layer.v.linear_layer.weight']).view(-1)
+    U = torch.empty(128 * 62, device=DEV)
+    nv.fold_location(Wd, Wc, U)
+    lens32 = dv(lens.to(torch.int32))
+    saved = nv.get_attn_fwd_fused() if hasattr(nv, 'get_attn_fwd_fused') else None
+    nv.set_attn_fwd_fused(fused)
+    try:
+        outs = []
+        for with_img in (False, True):
+            ws = torch.zeros(nv.attn_fwd_ws_floats(B, Ti), device=DEV)
+            cum_d, cum_save = dv(cum.clone()), torch.empty(B, Ti, device=DEV)
+            w_out, ctx_out, q_out = torch.empty(B, Ti, device=DEV), torch.empty(B, E, device=DEV), torch.empty(B, 128, device=DEV)
+            img = torch.full((B, 2 * E), float('nan'), device=DEV, dtype=torch.bfloat16) if with_img else None
+            nv.attention_step_fwd(dv(h), Wq, U, v, dv(pm), dv(mem), lens32, dv(w_prev), cum_d, cum_save, w_out, ctx_out, q_out, ws,
+                                  ctx_x3_out=img)
+            torch.cuda.synchronize()
+            outs.append((w_out, ctx_out, cum_d, img))
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(a, b)
+        assert torch.equal(outs[1][3].cpu().view(torch.int16), split_image_ref(outs[1][1].cpu()).view(torch.int16))
+    finally:
+        nv.set_attn_fwd_fused(-1 if saved is None else saved)
+
+
+def test_cell_backward_writes_the_split_image_of_the_gate_gradients(nv):
+    B, H = 5, 64
+    g = torch.sigmoid(rnd(B, 4 * H, seed=310)).to(DEV)
+    c, cp, dh, dc = (rnd(B, H, seed=311 + k).to(DEV) for k in range(4))
+    dg = torch.empty(B, 4 * H, device=DEV)
+    dg3 = torch.full((B, 8 * H), float('nan'), device=DEV, dtype=torch.bfloat16)
+    a = nv.lstm_bwd_desc(B, H, [dh], g, cp, c, None, 1.0, dc.clone(), dg, dgates16=dg3, x3=True)
+    nv.lstm_pointwise_bwd2(a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dg).all()
+    assert torch.equal(dg3.cpu().view(torch.int16), split_image_ref(dg.cpu()).view(torch.int16))
+    # the plain bf16 copy is untouched by the new flag
+    dg16 = torch.empty(B, 4 * H, device=DEV, dtype=torch.bfloat16)
+    a = nv.lstm_bwd_desc(B, H, [dh], g, cp, c, None, 1.0, dc.clone(), dg, dgates16=dg16)
+    nv.lstm_pointwise_bwd2(a)
+    assert torch.equal(dg16.cpu(), dg.cpu().bfloat16())
+
+
+# ------------------------------------------------------------------------------------------------
 # bf16-resident product (csrc/gemm16.hip)
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,pad", [(256, 256, 64, 0), (300, 520, 192, 64), (1024, 768, 1280, 0), (70, 33, 128, 8)])

@@ -101,7 +101,11 @@ def test_persistent_train_forward_fp32_mode_is_bit_identical_to_its_launch_chain
     same persistent launch, tiles on the exact-f32 MFMA (csrc/skinny_wide.h, F32), attention phase in its f32 instantiation.  Its
     launch chain runs the same wide tile (loops.hip, wide32), so the bar is the bf16 mode's: every bit of the outputs, the loss,
     all 60 gradients and the BatchNorm buffers.  (TINY_HP: widths of 128 -- two k-tiles per segment, nothing to prefetch.)"""
-    m, hp = _model(hp_str, precision="fp32")
+    _chain_vs_persistent(hp_str, "fp32", in_lens, out_lens)
+
+
+def _chain_vs_persistent(hp_str, precision, in_lens, out_lens):
+    m, hp = _model(hp_str, precision=precision)
     batch = tuple(t.to(DEV) for t in gu.make_train_batch(in_lens, out_lens, hp.n_mel_channels, 5))
     state = {k: v.clone() for k, v in m.state_dict().items()}
     native.attn_handoff_timeouts(reset=True)
@@ -114,6 +118,25 @@ def test_persistent_train_forward_fp32_mode_is_bit_identical_to_its_launch_chain
     assert float(l0) == float(l1)
     assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
     assert [k for k in b0 if not torch.equal(b0[k], b1[k])] == []
+    return o0, l0, g0
+
+
+@pytest.mark.parametrize("in_lens,out_lens,hp_str", [([23, 17, 9], [41, 33, 12], ""),
+                                                     ([37] + [30] * 20 + [11] * 12, [55] * 30 + [19] * 3, ""),         # B = 33
+                                                     (list(range(100, 36, -1)), [64 + (i % 7) for i in range(64)], ""),   # B = 64
+                                                     ([14, 12, 9, 9, 6, 5, 5, 3, 2, 2], [20, 11, 18, 7, 13, 20, 5, 9, 12, 6], gu.TINY_HP)])
+def test_persistent_train_forward_bf16x3_mode_is_bit_identical_to_its_launch_chain(native_lib, in_lens, out_lens, hp_str):
+    """Round 6: the accurate-fast mode -- the fp32 mode's loop with the LSTM tiles on split-bf16 operand images
+    (csrc/skinny_wide.h SW_X3) -- runs the same persistent launch; its chain runs the same tile on the same images (loops.hip,
+    bf16 == 3), so the bar is the other modes': every bit of the outputs, the loss, all 60 gradients, the BatchNorm buffers.  And the
+    mode is f32-class: against the fp32 mode on the same batch and dropout stream the outputs agree far inside the 1e-4 tolerance."""
+    o3, l3, g3 = _chain_vs_persistent(hp_str, "bf16x3", in_lens, out_lens)
+    m, hp = _model(hp_str, precision="fp32")
+    batch = tuple(t.to(DEV) for t in gu.make_train_batch(in_lens, out_lens, hp.n_mel_channels, 5))
+    o0, l0, g0, _, _ = _step(m, batch, True, bwd_persistent=False)
+    for i in range(4):
+        assert float((o3[i] - o0[i]).abs().mean()) < 2e-5, i
+    assert abs(float(l3) - float(l0)) < 1e-5 * abs(float(l0))
 
 
 def test_unsupported_geometries_stay_on_the_chain(native_lib):

@@ -11,8 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "tacotron2_amd", "csrc", sys.argv[1] + ".hip")
 filt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ""
 extra = [a for a in sys.argv[2:] if a.startswith("-")]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null",
-       "-Rpass-analysis=kernel-resource-usage"] + extra
+sys.path.insert(0, ROOT)
+from tacotron2_amd import build as _build  # noqa: E402  (the product's own code-generation flags: packed-f32-free since round 6)
+cmd = [_build.HIPCC] + _build.CFLAGS + ["-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + extra
 err = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp").stderr
 cur = None
 rows = {}
