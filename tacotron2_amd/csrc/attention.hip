@@ -1027,7 +1027,10 @@ extern "C" int t2amd_attention_step_fwd_f32(const t2amd_attn_fwd* a, void* strea
     static const int ke_form = [] { const char* e = getenv("T2AMD_KE_FORM"); return e ? atoi(e) : -1; }();
     int form = ke_form >= 0 ? ke_form : ((long long)NSL * a->B > 512 ? 2 : 0);
     const size_t lds_e4 = sizeof(float) * (KE4_U * (2 * (size_t)p.tip + DSL + (size_t)a->Hq) + DSL * NTAP + KE4_U);
-    if (form == 2 && !(a->Wq16 && a->loc_split_bf16 && lds_e4 <= 64 * 1024)) form = 1;      // the four-utterance form is bf16-mode only
+    // the four-utterance form is bf16-mode only.  It hard-codes the one-range tanh, which every other form -- and the backward's
+    // recompute -- selects on memory16: it is taken only when memory16 is there too, so that a caller who sets Wq16 without
+    // memory16 (the public struct allows it) cannot get a forward and a backward that disagree about tanh
+    if (form == 2 && !(a->Wq16 && a->memory16 && a->loc_split_bf16 && lds_e4 <= 64 * 1024)) form = 1;
     // one launch (T2AMD_ATTN_FWD_FUSED=0/1, t2amd_set_attn_fwd_fused): the one-utterance form of K_e only, one position
     // per thread, and the granule block of ws present and 8-byte aligned
     static const bool fused_env = [] { const char* e = getenv("T2AMD_ATTN_FWD_FUSED"); return e ? e[0] != '0' : T2_ATTN_FWD_FUSED_DEFAULT != 0; }();

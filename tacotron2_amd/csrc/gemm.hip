@@ -360,18 +360,9 @@ extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
     dim3 grid(t2_cdiv(d.N, GBN), t2_cdiv(d.M, GBM), d.batch * d.splitk);
     T2_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    if (fast && d.precision == 1) {
-        if (d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, true, true, 128>), grid, dim3(256), 0, s, p);
-        else if (d.a_kcontig && !d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<true, false, true, 128>), grid, dim3(256), 0, s, p);
-        else if (!d.a_kcontig && d.b_kcontig)
-            T2_LAUNCH((gemm_bf16x3_kernel<false, true, true, 128>), grid, dim3(256), 0, s, p);
-        else
-            T2_LAUNCH((gemm_bf16x3_kernel<false, false, true, 128>), grid, dim3(256), 0, s, p);
-        T2_LAUNCH_CHECK();
-        return T2AMD_OK;
-    }
+    // (round 6) The 256-tile split-bf16 branch must stand IN FRONT of the 128-tile one: since the round it was written in it stood
+    // behind it -- behind an unconditional return -- and never ran, while the engine's split-K policy (engine._choose_splitk via
+    // t2amd_gemm_tile_size) sized the weight-gradient launches for 256-tiles.  T2AMD_GEMM_TILE=128 keeps the old behaviour (A/B).
     if (fast && d.precision == 1 && t2amd_gemm_tile_size(d.M, d.N, 1, d.batch * d.splitk, d.a_kcontig, d.b_kcontig) == 256) {
         dim3 g2(t2_cdiv(d.N, 256), t2_cdiv(d.M, 256), d.batch * d.splitk);
         static bool attr_set = false;
@@ -381,6 +372,18 @@ extern "C" int t2amd_gemm_f32(const t2amd_gemm_desc* dp, void* stream) {
             attr_set = true;
         }
         T2_LAUNCH((gemm_bf16x3_kernel<false, false, true, 256>), g2, dim3(512), 0, s, p);
+        T2_LAUNCH_CHECK();
+        return T2AMD_OK;
+    }
+    if (fast && d.precision == 1) {
+        if (d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, true, true, 128>), grid, dim3(256), 0, s, p);
+        else if (d.a_kcontig && !d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<true, false, true, 128>), grid, dim3(256), 0, s, p);
+        else if (!d.a_kcontig && d.b_kcontig)
+            T2_LAUNCH((gemm_bf16x3_kernel<false, true, true, 128>), grid, dim3(256), 0, s, p);
+        else
+            T2_LAUNCH((gemm_bf16x3_kernel<false, false, true, 128>), grid, dim3(256), 0, s, p);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }

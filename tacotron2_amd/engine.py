@@ -298,8 +298,12 @@ def _ng(run, *a, **k):
     return nv.gemm(*a, fast=run.gradp, **k)
 
 
-def _fg(run, *a, **k):          # forward GEMM: exact f32, or plain bf16 in the bf16 compute mode
-    return nv.gemm(*a, fast=run.fwdp, **k)
+def _fg(run, *a, exact=False, **k):
+    """Forward GEMM: exact f32 (fp32 mode), plain bf16 (bf16 mode), split-bf16 x3 ('bf16x3' mode).  ``exact``: a product in front
+    of a ReLU -- the encoder convolutions, the prenet -- stays on the exact-f32 MFMA in the 'bf16x3' mode: a pre-activation that
+    lands on the other side of zero flips relu' for a whole row of the weight gradient (the ReLU-kink rows of the full-size
+    parity test), and 2^-17-relative products do that ten times as often as f32 rounding; these products are 3 % of the step."""
+    return nv.gemm(*a, fast=(0 if (exact and run.x3) else run.fwdp), **k)
 
 
 # Packed / transposed / bf16 weight images are rebuilt only when a weight changed (SURVEY H5): the key is the
@@ -620,7 +624,7 @@ def _halo_image(run, x, T, pad):
     nv.cast_halo_bf16(x, img, T, pad)             # writes every row of the image, halos included
     return img
 
-def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training, lens=None):
+def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training, lens=None, exact=False):
     """x: (rows, C0) channel-last rows (b, t).  Returns the last activation and the saved slabs.
     reference model.py:141-146 (Postnet.forward), :174-175 (Encoder.forward)."""
     saved = []
@@ -650,7 +654,8 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
             # in eval mode where mean is the running mean -- so the product has a plain epilogue and can be split along K.
             sk = max(1, min(10, K // 256))
             part = run.empty(sk, rows * Co)
-            nv.gemm(part[0].view(rows, Co), x, packed(), convA=(T, Ci, pad, 1), splitk=sk, partials=part, fast=run.fwdp)
+            nv.gemm(part[0].view(rows, Co), x, packed(), convA=(T, Ci, pad, 1), splitk=sk, partials=part,
+                    fast=(0 if (exact and run.x3) else run.fwdp))
             nv.splitk_reduce(part, sk, y)
         elif _conv16_ok(run, rows, T, Ci, k):
             # bf16 mode: the convolution as a product of sliding windows of a bf16 image with zero halo rows (csrc/gemm16.hip)
@@ -658,7 +663,7 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
             ximg = _halo_image(run, x, T, pad)
             nv.conv16(y, ximg, W16, rows // T, T, pad, bias=bias)
         else:
-            _fg(run, y, x, packed(), bias=bias, convA=(T, Ci, pad, 1))
+            _fg(run, y, x, packed(), bias=bias, convA=(T, Ci, pad, 1), exact=exact)
         if training:
             mean = run.empty(Co)
             nv.bn_stats(y, run.ws(Co), mean, invstd, rm, rv, BN_MOMENTUM, BN_EPS)
@@ -957,7 +962,10 @@ def _guard_weights(model, run, P):
 # training steps the forms that were selected before the demotion are selected again; if they give up again the interval
 # doubles (up to 64 x).  0 = never re-promote.  T2AMD_REPROMOTE_AFTER sets it.
 TRAIN_FWD_REPROMOTE_AFTER = int(os.environ.get('T2AMD_REPROMOTE_AFTER', '200'))
-_DEMOTION = dict(active=False, count=0, clean=0, need=0, saved=None, repromotions=0)
+_DEMOTION = dict(active=False, count=0, clean=0, need=0, saved=None, repromotions=0, explicit=False, probation=0, given_up=False)
+# After this many CONSECUTIVE failed re-promotions (each one sacrifices a training step: it is NaN-poisoned and skipped) the
+# process stays on the launch chains for good: a GPU that is shared permanently is not going to stop being shared.
+MAX_FAILED_REPROMOTIONS = 8
 
 
 def _demote(saved_now):
@@ -967,15 +975,44 @@ def _demote(saved_now):
     d['active'] = True
     d['count'] += 1
     d['clean'] = 0
+    d['probation'] = 0
     d['need'] = TRAIN_FWD_REPROMOTE_AFTER * (1 << min(d['count'] - 1, 6))
+    if d['count'] > MAX_FAILED_REPROMOTIONS and not d['given_up']:
+        d['given_up'] = True
+        import sys
+        print("tacotron2_amd: %d give-ups in a row, each right after a re-promotion: the launch chains stay selected for the rest "
+              "of this process (the GPU is shared for good?)" % d['count'], file=sys.stderr, flush=True)
+
+
+def note_clean_step():
+    """Call from the training loop after a step whose loss / gradient norm was FINITE (tacotron2_amd/train.py does).  While the
+    process is demoted this is what counts towards re-promotion -- not training forwards, which also count steps that turned out
+    non-finite for other reasons and the extra forwards of gradient accumulation.  A loop that never calls it (the
+    reference's unmodified train.py) keeps the old count by forwards."""
+    d = _DEMOTION
+    d['explicit'] = True
+    if d['active']:
+        d['clean'] += 1
+    elif d['probation'] > 0:
+        d['probation'] -= 1
+        if d['probation'] == 0:
+            d['count'] = 0                 # the re-promoted forms survived as long as they had been away: the streak is over
 
 
 def _note_training_step(log=None):
-    """One training forward is about to run.  Counts clean steps while demoted and restores the demoted forms when due."""
+    """One training forward is about to run.  Restores the demoted forms when enough clean steps have been seen (counted by
+    note_clean_step(), or -- for a loop that does not call it -- by these forwards themselves)."""
     d = _DEMOTION
-    if not d['active'] or TRAIN_FWD_REPROMOTE_AFTER <= 0:
+    if not d['active']:
+        if not d['explicit'] and d['probation'] > 0:
+            d['probation'] -= 1
+            if d['probation'] == 0:
+                d['count'] = 0
         return False
-    d['clean'] += 1
+    if TRAIN_FWD_REPROMOTE_AFTER <= 0 or d['given_up']:
+        return False
+    if not d['explicit']:
+        d['clean'] += 1
     if d['clean'] <= d['need']:
         return False
     global TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT, ENCODER_BATCH_PERSISTENT
@@ -986,8 +1023,10 @@ def _note_training_step(log=None):
     nv.set_bptt_cell_fold(sv['cell_fold'])
     d['active'], d['saved'] = False, None
     d['repromotions'] += 1
+    d['probation'] = d['need']
     msg = ("tacotron2_amd: %d clean training steps since the last abandoned hand-off: the one-launch / persistent forms are "
-           "selected again (a further give-up doubles the interval)" % (d['clean'] - 1))
+           "selected again (re-promotion %d; a further give-up doubles the interval, %d in a row end it)"
+           % (d['clean'] - (0 if d['explicit'] else 1), d['repromotions'], MAX_FAILED_REPROMOTIONS))
     if log is not None:
         log(msg)
     else:
@@ -1000,7 +1039,7 @@ def give_up_counters():
     """What a bench line / run log needs to show that nobody fell back silently."""
     d = _DEMOTION
     return dict(demotions=d['count'], demoted_now=bool(d['active']), repromotions=d['repromotions'],
-                eval_give_ups=EVAL_GIVE_UPS[0])
+                repromotion_given_up=bool(d['given_up']), eval_give_ups=EVAL_GIVE_UPS[0])
 
 
 def handle_nonfinite_step(log=None):
@@ -1159,7 +1198,7 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     nconv = hp.encoder_n_convolutions
     enc_masks = [ms.get('enc', i, (B, Ti, E), 0.5) for i in range(nconv)] if training else None
     x3, c.enc_saved = _conv_stack_fwd(run, P, bufs, 'encoder.convolutions', nconv, emb, Ti,
-                                      [1] * nconv, enc_masks, training)                  # model.py:174-175
+                                      [1] * nconv, enc_masks, training, exact=True)      # model.py:174-175
     memory = run.empty(B, Ti, E)
     c.enc_lstm = []
     for d, sfx in enumerate(('', '_reverse')):                                           # model.py:181-188
@@ -1198,8 +1237,8 @@ def _forward(model, P, bufs, text, in_lens, mels, max_len, out_lens, training):
     k1 = ms.get('prenet', 1, (To, B, Pd), 0.5)
     p1 = run.empty(rowsD, Pd)
     p2 = run.empty(rowsD, Pd)
-    _fg(run, p1, x0.view(rowsD, Cm), W1, act=1, keep=k0.view(rowsD, Pd), keep_scale=2.0)  # model.py:99, 399
-    _fg(run, p2, p1, W2, act=1, keep=k1.view(rowsD, Pd), keep_scale=2.0)
+    _fg(run, p1, x0.view(rowsD, Cm), W1, act=1, keep=k0.view(rowsD, Pd), keep_scale=2.0, exact=True)  # model.py:99, 399
+    _fg(run, p2, p1, W2, act=1, keep=k1.view(rowsD, Pd), keep_scale=2.0, exact=True)
     Wmem = P['decoder.attention_layer.memory_layer.linear_layer.weight']
     pm = run.empty(B, Ti, A)
     _fg(run, pm.view(rowsE, A), memory.view(rowsE, E), Wmem)                              # model.py:288
@@ -1873,7 +1912,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         nv.bn_act_fwd(x, xm, zeros, ones, ones, zeros, 0, None, 1.0, lens32, Ti)
         x = xm
     x3, _ = _conv_stack_fwd(run, P, bufs, 'encoder.convolutions', hp.encoder_n_convolutions, x, Ti,
-                            [1] * hp.encoder_n_convolutions, None, False, lens=lens32 if ragged else None)
+                            [1] * hp.encoder_n_convolutions, None, False, lens=lens32 if ragged else None, exact=True)
     memory = run.empty(B, Ti, E)
     idesc = []
     for d, sfx in enumerate(('', '_reverse')):

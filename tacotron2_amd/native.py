@@ -442,6 +442,12 @@ def load():
             want = None
             if os.environ.get("T2AMD_REQUIRE_SOURCE_HASH", "0") == "1":
                 raise NativeError("tacotron2_amd: cannot hash the kernel sources beside %s (%s)" % (LIB_PATH, e))
+            # csrc/ is here but not everything the hash covers: say that the stale-library check did NOT happen --
+            # silently loading whatever .so lies there would defeat "binary and sources are provably the same tree"
+            import sys
+            print("tacotron2_amd: warning: the kernel sources beside %s could not be hashed (%s); the library (built from %s) "
+                  "is loaded WITHOUT the stale-library check (T2AMD_REQUIRE_SOURCE_HASH=1 makes this an error)"
+                  % (LIB_PATH, e, built or "<unstamped sources>"), file=sys.stderr, flush=True)
         if want is not None and built != want:
             raise NativeError("tacotron2_amd: %s was built from other sources (binary %s, sources %s): run "
                               "`python -m tacotron2_amd.build` (or set T2AMD_ALLOW_STALE_LIB=1 to use it anyway)"

@@ -267,6 +267,7 @@ def train(output_directory, log_directory, checkpoint_path, warm_start, n_gpus, 
                                              "has diverged (last loss %r)" % (bad_steps, reduced_loss))
             else:
                 bad_steps = 0
+                engine.note_clean_step()       # what counts towards re-promoting forms a give-up demoted (engine.note_clean_step)
             if finite and rank == 0:
                 duration = time.perf_counter() - start
                 print("Train loss {} {:.6f} Grad Norm {:.6f} {:.2f}s/it".format(

@@ -293,13 +293,16 @@ def test_train_step_To870_bf16x3(native_lib, full_train_case):
     assert abs(el - ol) < lim['loss'] * abs(ol), (el, ol)
     assert 1.0 - cos < lim['one_minus_cos'], cos
     assert worst < lim['worst'], (worst_k, worst)
-    # the fp32 mode's own gradient bar (1e-3 of the tensor's max) -- with the same ReLU-kink exception, nothing else
-    assert all(k.startswith('encoder.convolutions.') or k.startswith('encoder.') for k, _ in over) and len(over) <= 6, over
+    # per-element bar of the fp32 mode (1e-3 of the tensor's max): held by every tensor outside the encoder convolutions' ReLU-kink
+    # channels (the encoder and the prenet stay on the exact-f32 product in this mode for exactly that reason: engine._fg `exact`)
+    stray = [(k, v) for k, v in over if not k.startswith('encoder.convolutions.')]
+    assert not stray and len(over) <= lim['kink_tensors'] and all(v < lim['kink_max'] for _, v in over), over
 
 
-# first run of round 6: see profiles/r06_*_parity_fullsize_train_B64_bf16x3.json; 3 x measured, and never looser than the
-# verdict's bar (decoder mel 1e-5)
-X3_LIMITS = dict(out=[1e-5, 1e-4, 1e-5, 1e-6], loss=1e-5, one_minus_cos=1e-6, worst=2e-2)
+# Measured on the first runs of round 6 (profiles/r06_c_parity_fullsize_train_B64_bf16x3.json: decoder mel 4.5e-7, postnet mel 1.1e-5,
+# gate 5.0e-7, alignments 4.5e-8; loss equal to the oracle's to every printed digit; whole-gradient cosine 1 - 2.2e-8; worst tensor
+# 2.1e-3 relative L2): limits = 3 x measured, never looser than the verdict's bar for this mode (decoder mel 1e-5).
+X3_LIMITS = dict(out=[1.5e-6, 3.5e-5, 1.5e-6, 1.5e-7], loss=1e-6, one_minus_cos=1e-7, worst=6e-3, kink_tensors=6, kink_max=6e-2)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -240,7 +240,8 @@ def test_the_persistent_forms_come_back_after_clean_steps(native_lib, monkeypatc
         torch.cuda.synchronize()
         return ls.detach().clone(), m.last_train_decoder_path
     try:
-        engine._DEMOTION.update(active=False, count=0, clean=0, need=0, saved=None, repromotions=0)
+        engine._DEMOTION.update(active=False, count=0, clean=0, need=0, saved=None, repromotions=0, explicit=False, probation=0,
+                                given_up=False)
         engine.TRAIN_FWD_PERSISTENT = True
         good, path = one()
         assert path == "persistent" and torch.isfinite(good)
@@ -254,6 +255,26 @@ def test_the_persistent_forms_come_back_after_clean_steps(native_lib, monkeypatc
         assert [p for _, p in paths] == ["launch chain", "launch chain", "persistent", "persistent"]
         assert all(torch.equal(l, good) for l, _ in paths)            # every form gives the same bits
         assert engine.give_up_counters()["repromotions"] == 1 and not engine.give_up_counters()["demoted_now"]
+        # a training loop that reports its clean steps (train.py: engine.note_clean_step after a finite gradient norm) is what
+        # counts from then on: forwards alone (gradient accumulation, steps that went non-finite for other reasons) do not
+        monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
+        bad, path = one()
+        monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
+        assert path == "persistent" and not torch.isfinite(bad)
+        assert engine.handle_nonfinite_step(log=said.append) >= 1 and engine.TRAIN_FWD_PERSISTENT is False
+        need = engine._DEMOTION['need']
+        engine.note_clean_step()                                       # switches to explicit counting
+        assert [one()[1] for _ in range(need + 3)] == ["launch chain"] * (need + 3)       # forwards no longer count
+        for _ in range(need):
+            engine.note_clean_step()
+        assert one()[1] == "persistent" and engine.give_up_counters()["repromotions"] == 2
+        # ... and after MAX_FAILED_REPROMOTIONS give-ups in a row the chains stay
+        engine._DEMOTION.update(count=engine.MAX_FAILED_REPROMOTIONS)
+        engine._demote(dict(fwd=True, bwd=False, enc=True, attn_fwd_fused=-1, attn_bwd_fused=-1, cell_fold=1))
+        assert engine.give_up_counters()["repromotion_given_up"]
+        for _ in range(3 * engine._DEMOTION['need'] // 2 + 2):
+            engine.note_clean_step()
+        assert not engine._note_training_step()
     finally:
         engine._DEMOTION.clear(); engine._DEMOTION.update(state)
         engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry
