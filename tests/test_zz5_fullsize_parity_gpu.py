@@ -299,10 +299,11 @@ def test_train_step_To870_bf16x3(native_lib, full_train_case):
     assert not stray and len(over) <= lim['kink_tensors'] and all(v < lim['kink_max'] for _, v in over), over
 
 
-# Measured on the first runs of round 6 (profiles/r06_c_parity_fullsize_train_B64_bf16x3.json: decoder mel 4.5e-7, postnet mel 1.1e-5,
-# gate 5.0e-7, alignments 4.5e-8; loss equal to the oracle's to every printed digit; whole-gradient cosine 1 - 2.2e-8; worst tensor
-# 2.1e-3 relative L2): limits = 3 x measured, never looser than the verdict's bar for this mode (decoder mel 1e-5).
-X3_LIMITS = dict(out=[1.5e-6, 3.5e-5, 1.5e-6, 1.5e-7], loss=1e-6, one_minus_cos=1e-7, worst=6e-3, kink_tensors=6, kink_max=6e-2)
+# Measured in round 6 (profiles/r06_d_parity_fullsize_train_B64_bf16x3.json: decoder mel 3.7e-7, postnet mel 9.2e-6, gate 3.3e-7,
+# alignments 2.6e-8; loss equal to the oracle's to every printed digit; whole-gradient cosine 1 - 7e-10; worst tensor 3.6e-4 relative
+# L2; beyond 1e-3 of the tensor's max only the three encoder tensors of the fp32 mode's own ReLU-kink rows, at the fp32 mode's values
+# 8.0e-3 / 1.3e-3 / 2.0e-3): limits = 3 x measured, far inside the verdict's bar for this mode (decoder mel 1e-5).
+X3_LIMITS = dict(out=[1.2e-6, 3e-5, 1.1e-6, 8e-8], loss=1e-6, one_minus_cos=5e-9, worst=1.2e-3, kink_tensors=4, kink_max=2.5e-2)
 
 
 # ---------------------------------------------------------------------------------------------------
