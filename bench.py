@@ -635,7 +635,7 @@ def main():
         attn_bytes = es * 640.0 * ti_sum
         cell_bytes = B * (Ha + Hd) * (12 * 4.0 + 1.0 + (8.0 if es == 2.0 else 0.0)) if folded else 0.0
         persistent_fwd = getattr(model, "last_train_decoder_path", "") == "persistent"
-        persistent_bwd = getattr(model, "last_train_decoder_bwd_path", "") == "persistent"      # opt-in: T2AMD_TRAIN_BWD_PERSISTENT=1
+        persistent_bwd = False          # (the opt-in persistent BPTT launch of rounds 4-5 was removed in round 6)
         lstm_pair_bytes = lstm_bytes(Kd, Hd, False) + lstm_bytes(Ka, Ha, True)
         attn_fwd_bytes = es * 640.0 * ti_sum + es * A * Ha
         specs = [
@@ -646,11 +646,6 @@ def main():
              "flag + data hand-offs between them; 256 co-resident workgroups",
              To * (lstm_pair_bytes + attn_fwd_bytes),
              To * (2.0 * B * (4 * Hd * Kd + 4 * Ha * Ka) + 2.0 * (B * A * Ha + ti_sum * (A * 62 + A + E)))),
-            ("decoder_backward_persistent", 8, "dec_train_bwd_persistent_kernel",
-             "the WHOLE BPTT loop behind its first two launches in one launch: per time step the attention backward with the two "
-             "folded LSTM cell backwards, then the dgrad pair (split-K %d, bf16 MFMA), flag + data hand-offs between them" % ns,
-             To * (attn_bytes + cell_bytes + es * (4 * Hd * Kd + 4 * Ha * Ka) + es * B * (4 * Hd + 4 * Ha) + 4.0 * ns * B * (Kd + Ka)),
-             To * (2.0 * (2 * B * A * Ha + ti_sum * (3 * A * 62 + 2 * A + 2 * E)) + 2.0 * B * (4 * Hd * Kd + 4 * Ha * Ka))),
             ("lstm_pair", 3 if fused else 2,
              ("skinny_wide_kernel<true,3,%s>" % ("false" if es == 2.0 else "true (exact-f32 wide tile)")) if fused else "skinny_wide_kernel<true,2,...>",
              "decoder LSTM of step t-1 (64x2560x4096) + attention LSTM of step t (64x1536x4096), %s + fused cells" % mm

@@ -644,21 +644,9 @@ typedef struct t2amd_dec_train_bwd {
 
 int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream);
 
-/* The same BPTT loop as ONE persistent launch behind its first two (the decoder cell and dgrad of the last time step); reference
- * model.py:405-411 under autograd, BASELINE north_star.  max(4 B, dgrad tiles) co-resident 512-thread workgroups alternate the
- * attention-backward role (with the two folded LSTM cells) and the dgrad-tile role of every time step; the two all-to-all edges
- * of a step are flag + data hand-offs.  What a step works from is the pair of kernel-argument blocks the chain above would have
- * launched, staged by the same host code and uploaded once into `descs` (t2amd_decoder_train_bwd_persistent_desc_bytes(To)
- * bytes of device memory); `flags`: t2amd_decoder_train_bwd_persistent_flag_bytes() bytes, zeroed by the call.  Same arithmetic
- * in the same order as the chain: every gradient is bit-identical to it.  bf16 operand mode with the folded cells and the
- * one-launch attention backward (the defaults), B <= 64, Ti <= 508, 4H a multiple of 128 nsplit; `_supported` returns 0 when the
- * geometry fits a device of `cus` compute units, else T2AMD_ERR_ARG with the reason in t2amd_last_error().  Give-ups: as
- * t2amd_decoder_train_fwd_persistent_f32 (*status, `poison`). */
-long long t2amd_decoder_train_bwd_persistent_flag_bytes(void);
-long long t2amd_decoder_train_bwd_persistent_desc_bytes(int To);
-int t2amd_decoder_train_bwd_persistent_supported(const t2amd_dec_train_bwd* p, int cus);
-int t2amd_decoder_train_bwd_persistent_f32(const t2amd_dec_train_bwd* p, void* descs, unsigned* flags, int* status, float* poison,
-                                           void* stream);
+/* (Round 6: the BPTT loop as ONE persistent launch -- t2amd_decoder_train_bwd_persistent_f32 and its _supported / _flag_bytes /
+ * _desc_bytes queries, opt-in since round 4 -- was removed: two rounds at 1 ms behind the chain above, profiles/r04_j_ab_train_bwd_
+ * persistent.json) */
 /* 1 (default): everything on the caller's stream; the decoder-LSTM chain (off the attention recurrence under
  * teacher forcing) shares fused launches with the attention-LSTM chain.  2: the decoder-LSTM chain of both
  * training loops runs on an internal side stream, ordered against the caller's stream with one hipEvent per

@@ -2735,10 +2735,7 @@ extern "C" long long t2amd_attn_bwd_ws_floats(int B, int Ti) {
     return goff + 2ll * B * Ti + 2ll * NTS * B;
 }
 
-// `describe` (the persistent backward loop, below): nothing is launched -- the kernel arguments of the one-launch form with the
-// folded cells and the granule hand-off (the only form the persistent loop runs) are handed back, with its LDS bytes; any other
-// form is an error for that caller.
-static int attn_bwd_step_impl(const t2amd_attn_bwd* a, void* stream, AttnBwdParams* describe, size_t* describe_lds) {
+static int attn_bwd_step_impl(const t2amd_attn_bwd* a, void* stream) {
     T2_REQUIRE(a && a->dctx_total && a->q && a->Wq && a->U && a->v && a->pm && a->memory && a->w &&
                    a->cum_before && a->dwin_part && a->dcum_acc && a->d_pm && a->dU_acc && a->dv_acc &&
                    a->dq_out && a->dh_out && a->ws,
@@ -2822,12 +2819,6 @@ static int attn_bwd_step_impl(const t2amd_attn_bwd* a, void* stream, AttnBwdPara
         const size_t l2a = (lds2c + 15) / 16 * 16;
         p.kb1_smem_off = (int)(l2a / sizeof(float));
         const size_t ldsf = l2a + lds1;
-        if (describe) {
-            T2_REQUIRE(gran && a->memory16, "attn_bwd (persistent loop): needs the granule hand-off and the bf16 memory");
-            *describe = p;
-            *describe_lds = ldsf;
-            return T2AMD_OK;
-        }
         if ((int)ldsf > 64 * 1024 && (int)ldsf > g_attn_bwd_lds_cell && !t2amd_validate_only_flag_()) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
             (void)hipFuncSetAttribute((const void*)attn_bwd_main_kernel<true, false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf);
@@ -2845,7 +2836,6 @@ static int attn_bwd_step_impl(const t2amd_attn_bwd* a, void* stream, AttnBwdPara
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
-    T2_REQUIRE(!describe, "attn_bwd (persistent loop): needs the one-launch form with the folded cells");
     if (fused && lds1 + lds2 <= 160 * 1024) {
         if (++g_attn_bwd_token == 0) ++g_attn_bwd_token;
         p.token = g_attn_bwd_token;
@@ -2882,263 +2872,16 @@ static int attn_bwd_step_impl(const t2amd_attn_bwd* a, void* stream, AttnBwdPara
     return T2AMD_OK;
 }
 extern "C" int t2amd_attention_step_bwd_f32(const t2amd_attn_bwd* a, void* stream) {
-    return attn_bwd_step_impl(a, stream, nullptr, nullptr);
+    return attn_bwd_step_impl(a, stream);
 }
 
-// =========================================================================================
-// The teacher-forced decoder loop, BACKWARD through time, as ONE persistent launch (round 4; BASELINE north_star: "the decode
-// loop is fused into a persistent wavefront-resident kernel"; reference model.py:405-411 under autograd).
-//
-// The launch chain (loops.hip, t2amd_decoder_train_bwd_loop_f32) runs a time step t = To-1 .. 0 as two dependent launches:
-//   K1(t)  attention backward of step t with the two LSTM cell backwards folded in (attn_bwd_main_kernel<1,1,1,1>: cell_a(t),
-//          cell_d(t-1)) -- consumes the gradient slabs dXd(t), dXa of the previous launch pair, produces the gate gradients;
-//   K2(t)  the BPTT dgrad pair (skinny_wide_kernel<false>: dXd(t-1) = dG_d(t-1) . Wd_cat, dXa = dG_a(t) . Wa_rec, split-K slabs).
-// Here the same two bodies (attn_bwd_main_body, skinny_wide_body: device functions shared with those kernels) alternate inside
-// one launch of max(4 B, dgrad tiles) co-resident 512-thread workgroups and the two all-to-all edges of a step are FLAG + DATA
-// hand-offs (Guideline 16 R1), as in the forward loop above:
-//   K1(s):  prologue and the memory-row stream first; right before the gradient slabs are loaded: wait until every workgroup has
-//           finished K2 of step s-1 (flag2 >= s) -> slabs / carries by device-scope loads -> ... -> col2im carries and the bf16
-//           gate gradients out as write-through stores -> every wave drains -> flag1[j] = s+1
-//   K2(s):  wait until every workgroup has finished K1 of step s (flag1 >= s+1), in front of the tile's first DMA -> gate
-//           gradients by sc1 LDS-DMA -> slabs out write-through -> drain -> flag2[j] = s+1
-// (s = To-1-t counts launches-that-were.)  What a step works from -- ~1.2 KB of pointers and strides per step, the very kernel
-// arguments the chain would have passed, built by the SAME host code (attn_bwd_step_impl / t2amd_skinny_gemm2_describe_ in
-// describe mode) -- is uploaded once per loop and read with scalar loads.  Read-modify-write accumulators (d_pm, dU, dv, the
-// cell-state gradients, the running dcum) are touched by the same workgroup in every step: plain loads and stores.
-// Arithmetic and order are the chain's: every gradient is BIT-IDENTICAL to it.
-// =========================================================================================
-struct BwdStepDesc {
-    AttnBwdParams ab;          // K1: attention backward + folded cells of this step
-    SkinnyDual g2;             // K2: the dgrad pair behind it
-    int g2_total;              // its workgroups; 0 = none (the last step, t = 0)
-    int pad_;
-};
-struct DecBwdPersist {
-    const BwdStepDesc* steps;
-    int nsteps, nK1, delay1, delay2, fail_off;
-    unsigned* flag1;           // [workgroups]  workgroup j has finished K1 of step s: s + 1
-    unsigned* flag2;           // [workgroups]  workgroup j has finished K2 of step s: s + 1   (+ the arrival census behind them)
-    int* status;
-    long long timeout_ticks, census_ticks;
-    unsigned long long* ts;
-    unsigned long long* prof;  // tools only (t2amd_debug_dtp_prof_): accumulated wall-clock ticks of workgroup 0: [0] K1 (with its
-                               // wait), [2] K2 (with K1's drain + flag and its wait), [3] K2's drain + flag
-};
-typedef const char __attribute__((address_space(4))) * t2_kptr;
-__device__ __forceinline__ const DecBwdPersist& dbp_args_late() {
-    t2_kptr k = (t2_kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(k));
-    return *reinterpret_cast<const DecBwdPersist*>((const char*)k);
-}
-// the step's descriptor: constant for the whole launch (uploaded before it) -> constant address space, scalar loads
-__device__ __forceinline__ const BwdStepDesc& dbp_step_late(const BwdStepDesc* base, const int s) {
-    t2_kptr k = (t2_kptr)reinterpret_cast<const char*>(base + s);
-    asm volatile("" : "+s"(k));
-    return *reinterpret_cast<const BwdStepDesc*>((const char*)k);
-}
-struct DescCells {
-    const BwdStepDesc* d;
-    __device__ __forceinline__ const t2amd_lstm_bwd& cq() const { return d->ab.cq; }
-    __device__ __forceinline__ const t2amd_lstm_bwd& cx() const { return d->ab.cx; }
-};
-
-__global__ __launch_bounds__(512) void dec_train_bwd_persistent_kernel(DecBwdPersist P_entry) {
-    extern __shared__ __attribute__((aligned(16))) char psmem_[];
-    const int j_ = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nsteps = P_entry.nsteps;
-    bool ts_on = false;
-    if (tid == 0) reinterpret_cast<int*>(psmem_ + P_entry.fail_off)[0] = 0;
-    __syncthreads();
-    persist_census(P_entry.flag2 + gridDim.x, P_entry.status, P_entry.census_ticks, reinterpret_cast<int*>(psmem_ + P_entry.fail_off), wave, lane);
-    if (reinterpret_cast<int*>(psmem_ + P_entry.fail_off)[0]) return;
-    for (int s = 0; s < nsteps; ++s) {
-        const DecBwdPersist& P = dbp_args_late();
-        const BwdStepDesc& S = dbp_step_late(P.steps, s);
-        int zero = 0;
-        asm volatile("" : "+s"(zero));                   // LDS addresses are formed per iteration
-        char* const psmem = psmem_ + zero;
-        int* const fail_s = reinterpret_cast<int*>(psmem + P.fail_off);      // behind both phases' regions (which alias each other)
-        const int nG = (int)gridDim.x;
-        int j = j_;
-        asm volatile("" : "+s"(j));                      // (and the workgroup's roles: nothing derived from them is carried across steps)
-        const bool prof_on = P.prof != nullptr && tid == 0 && j == 0;
-        unsigned long long c0 = prof_on ? wall_clock64() : 0ull, c1;
-#define DBP_PROF(slot) do { if (prof_on) { c1 = wall_clock64(); P.prof[slot] += c1 - c0; c0 = c1; } } while (0)
-        // ---------------- K1(s) ----------------
-        const int tot = S.g2_total;
-        if (j < P.nK1) {
-            DescCells cells;
-            cells.d = &S;
-            // (a give-up lets the phase run on with whatever the slabs hold -- status is set, the step is poisoned behind the launch --
-            // so that the utterance's four workgroups still complete their hand-offs with each other; it leaves right after it)
-            attn_bwd_main_body<true, true, true, true, true>(S.ab, reinterpret_cast<float*>(psmem), j % NSL, j / NSL, ts_on, cells,
-                [&] {
-                    if (s > 0 && wave == 0 && !dtp_wait(P.flag2, nG, (unsigned)s, P.delay1, P.status, P.timeout_ticks, lane) && lane == 0) fail_s[0] = 1;
-                    __syncthreads();
-                });
-        }
-        DBP_PROF(0);
-        // every storing wave drains its write-through stores (R1), then ONE flag per workgroup
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (fail_s[0]) return;
-        if (tid == 0) __hip_atomic_store(P.flag1 + j, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        DBP_PROF(1);
-        // ---------------- K2(s) ----------------
-        if (tot == 0) break;                             // t = 0: nothing left to propagate
-        if (j < tot) {
-            const int nblk0 = S.g2.nblk0;
-            const bool second = j >= nblk0;
-            SkinnyParams sp = skinny_select(S.g2, second);
-            sp.gate_seg = -1;                            // every activation byte is what K1(s) just wrote
-            DtpGate gate;
-            gate.flags = P.flag1; gate.n = nG; gate.target = (unsigned)(s + 1); gate.delay = P.delay2; gate.status = P.status;
-            gate.ticks = P.timeout_ticks; gate.fail_s = fail_s;
-#ifdef T2AMD_DBP_XSC1                              // A/B builds: the gate gradients by sc1 DMA (what any other operand would need)
-            skinny_wide_body<false, true>(sp, second ? j - nblk0 : j, psmem, P.ts, gate);
-#else
-            skinny_wide_body<false, true, DtpGate, true>(sp, second ? j - nblk0 : j, psmem, P.ts, gate);
-#endif
-        }
-        DBP_PROF(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (fail_s[0]) return;
-        if (tid == 0) __hip_atomic_store(P.flag2 + j, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        DBP_PROF(3);
-#undef DBP_PROF
-    }
-}
-
-extern "C" long long t2amd_decoder_train_bwd_persistent_flag_bytes(void) {
-    return 4ll * (1024 + 1024 + 1);      // two counters per workgroup of the launch (at most 1024), the arrival census
-}
-extern "C" long long t2amd_decoder_train_bwd_persistent_desc_bytes(int To) {
-    return (long long)sizeof(BwdStepDesc) * (To > 0 ? To : 0);
-}
-// LDS of the launch for this geometry (the two phases' regions alias), or 0 if K1's does not fit
-static size_t dbp_lds_bytes(int Ti, int E, int Hq, int* fail_off) {
-    const int tip = attn_tip(Ti), np = ((Ti + 15) / 16) * 16;
-    const size_t lds1 = sizeof(float) * ((size_t)E + 2 * (size_t)((Ti + NTS - 1) / NTS) + 8);
-    const size_t lds2 = sizeof(float) * (2 * (size_t)tip + np + DCOL_FLOATS(np) + (size_t)np * DPL + KB2_NW * 2 * DSL + DSL +
-                                         DSL * NTAP + (size_t)Hq);
-    const size_t lds2c = lds2 + sizeof(float) * ((size_t)Hq + AD + 4);
-    size_t k1 = (lds2c + 15) / 16 * 16 + lds1;
-    if (k1 > 160 * 1024) return 0;
-    const size_t ring = (size_t)SW_NBUF * (SW_XB + SW_WB);      // the two phases' regions alias each other
-    size_t lds = k1 > ring ? k1 : ring;
-    lds = (lds + 15) / 16 * 16;
-    *fail_off = (int)lds;
-    return lds + 16;
-}
-// internal (loops.hip): geometry test of the persistent backward loop -- B utterances, Ti positions, `tiles2` dgrad workgroups
-extern "C" int t2amd_dbp_supported_(int B, int Ti, int E, int Hq, int tiles2, int cus) {
-    T2_REQUIRE(B > 0 && B <= SK_ROWS, "dec_train_bwd_persistent: one 64-row tile (B <= 64)");
-    T2_REQUIRE(Ti + NTS <= KB2_NT, "dec_train_bwd_persistent: Ti too large for the granule hand-off");
-    T2_REQUIRE(Hq % 16 == 0 && Hq <= 1024, "dec_train_bwd_persistent: the folded cells need Hq <= 1024, a multiple of 16");
-    int fo = 0;
-    const size_t lds = dbp_lds_bytes(Ti, E, Hq, &fo);
-    T2_REQUIRE(lds > 0 && lds <= 160 * 1024, "dec_train_bwd_persistent: Ti needs more than 160 KiB of LDS");
-    const int grid = NSL * B > tiles2 ? NSL * B : tiles2;
-    T2_REQUIRE(grid <= cus && grid <= 1024, "dec_train_bwd_persistent: more workgroups than compute units (they must all be co-resident)");
-    static const bool fused_env = [] { const char* e = getenv("T2AMD_ATTN_FUSED_BWD"); return !(e && e[0] == '0'); }();
-    static const bool gran_env = [] { const char* e = getenv("T2AMD_ATTN_GRANULES"); return e ? e[0] != '0' : T2_ATTN_GRANULES_DEFAULT != 0; }();
-    T2_REQUIRE((g_attn_bwd_fused < 0 ? fused_env : g_attn_bwd_fused != 0) && (g_attn_gran < 0 ? gran_env : g_attn_gran != 0),
-               "dec_train_bwd_persistent: needs the one-launch attention backward with the granule hand-off");
-    return T2AMD_OK;
-}
-
-// Host staging of the step descriptors: pinned buffers (an asynchronous upload from pageable memory would wait for the stream),
-// reused round-robin, each guarded by the event recorded behind its last upload.
-#define DBP_RING 4
-static struct { void* host[DBP_RING]; size_t bytes[DBP_RING]; hipEvent_t ev[DBP_RING]; bool used[DBP_RING]; int next; } g_dbp = {};
-static std::vector<char> g_dbp_validate;       // validate-only mode (no device): plain memory
-extern "C" int t2amd_dbp_begin_(int nsteps, void** host_descs) {
-    T2_REQUIRE(nsteps > 0 && host_descs, "dec_train_bwd_persistent: bad args");
-    const size_t need = sizeof(BwdStepDesc) * (size_t)nsteps;
-    if (t2amd_validate_only_flag_()) {
-        if (g_dbp_validate.size() < need) g_dbp_validate.resize(need);
-        *host_descs = g_dbp_validate.data();
-        return T2AMD_OK;
-    }
-    const int i = g_dbp.next;
-    g_dbp.next = (i + 1) % DBP_RING;
-    if (g_dbp.used[i] && hipEventSynchronize(g_dbp.ev[i]) != hipSuccess) T2_FAIL("dec_train_bwd_persistent: staging event");
-    if (g_dbp.bytes[i] < need) {
-        if (g_dbp.host[i]) (void)hipHostFree(g_dbp.host[i]);
-        g_dbp.host[i] = nullptr; g_dbp.bytes[i] = 0;
-        const size_t cap = need + need / 4;
-        if (hipHostMalloc(&g_dbp.host[i], cap, hipHostMallocDefault) != hipSuccess) T2_FAIL("dec_train_bwd_persistent: cannot allocate pinned staging memory");
-        g_dbp.bytes[i] = cap;
-    }
-    if (!g_dbp.ev[i] && hipEventCreateWithFlags(&g_dbp.ev[i], hipEventDisableTiming) != hipSuccess) T2_FAIL("dec_train_bwd_persistent: event");
-    *host_descs = g_dbp.host[i];
-    return T2AMD_OK;
-}
-extern "C" int t2amd_skinny_gemm2_describe_(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, SkinnyDual* d, int* total);   // rnn.hip
-// step s of the loop: what the chain would launch as t2amd_attention_step_bwd_f32(ab) and t2amd_skinny_gemm2_f32(gd, ga) (gd NULL: none)
-extern "C" int t2amd_dbp_describe_(void* host_descs, int s, const t2amd_attn_bwd* ab, const t2amd_skinny_gemm* gd, const t2amd_skinny_gemm* ga) {
-    BwdStepDesc* d = reinterpret_cast<BwdStepDesc*>(host_descs) + s;
-    memset(d, 0, sizeof(*d));
-    size_t lds = 0;
-    T2_PROPAGATE(attn_bwd_step_impl(ab, nullptr, &d->ab, &lds));
-    if (gd) T2_PROPAGATE(t2amd_skinny_gemm2_describe_(gd, ga, &d->g2, &d->g2_total));
-    return T2AMD_OK;
-}
-extern "C" int t2amd_dbp_launch_(void* host_descs, int nsteps, int B, int Ti, int E, int Hq, void* dev_descs, unsigned* flags, int* status,
-                                 float* poison, void* stream) {
-    T2_REQUIRE(host_descs && dev_descs && flags && status && nsteps > 0, "dec_train_bwd_persistent: null args");
-    const BwdStepDesc* hd = reinterpret_cast<const BwdStepDesc*>(host_descs);
-    int fo = 0;
-    const size_t lds = dbp_lds_bytes(Ti, E, Hq, &fo);
-    T2_REQUIRE(lds > 0 && lds <= 160 * 1024, "dec_train_bwd_persistent: Ti needs more than 160 KiB of LDS");
-    int tiles2 = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        T2_REQUIRE((hd[s].g2_total > 0) == (s + 1 < nsteps), "dec_train_bwd_persistent: every step but the last has a dgrad pair");
-        if (hd[s].g2_total > tiles2) tiles2 = hd[s].g2_total;
-    }
-    DecBwdPersist P;
-    P.steps = reinterpret_cast<const BwdStepDesc*>(dev_descs);
-    P.nsteps = nsteps; P.nK1 = NSL * B; P.fail_off = fo;
-    { const char* e = getenv("T2AMD_DBP_DELAY_1"); const int v = e ? atoi(e) : 4; P.delay1 = v < 0 ? 0 : (v > 400 ? 400 : v); }
-    { const char* e = getenv("T2AMD_DBP_DELAY_2"); const int v = e ? atoi(e) : 4; P.delay2 = v < 0 ? 0 : (v > 400 ? 400 : v); }
-    P.flag1 = flags; P.flag2 = flags + 1024;
-    P.status = status;
-    const char* te = getenv("T2AMD_DTP_TIMEOUT_TICKS");
-    P.timeout_ticks = te ? atoll(te) : 5000000ll;                   // 50 ms of the 100 MHz wall clock
-    P.census_ticks = P.timeout_ticks < 200000ll ? P.timeout_ticks : 200000ll;      // 2 ms; 0 = give up at once (tests)
-    if (P.timeout_ticks < 1) P.timeout_ticks = 1;
-    P.ts = attn_ts_buffer();
-    P.prof = g_dtp_prof;
-    if (t2amd_validate_only_flag_()) return T2AMD_OK;
-    hipStream_t st = (hipStream_t)stream;
-    int slot = -1;
-    for (int i = 0; i < DBP_RING; ++i) if (g_dbp.host[i] == host_descs) slot = i;
-    T2_REQUIRE(slot >= 0, "dec_train_bwd_persistent: descriptors must be staged in a buffer of t2amd_dbp_begin_");
-    if (hipMemcpyAsync(dev_descs, host_descs, sizeof(BwdStepDesc) * (size_t)nsteps, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipEventRecord(g_dbp.ev[slot], st) != hipSuccess)
-        T2_FAIL("dec_train_bwd_persistent: descriptor upload failed");
-    g_dbp.used[slot] = true;
-    if (hipMemsetAsync(flags, 0, (size_t)t2amd_decoder_train_bwd_persistent_flag_bytes(), st) != hipSuccess ||
-        hipMemsetAsync(status, 0, sizeof(int), st) != hipSuccess)
-        T2_FAIL("dec_train_bwd_persistent: memset failed");
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void*)dec_train_bwd_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            T2_FAIL("dec_train_bwd_persistent: cannot raise the dynamic LDS limit");
-        lds_set = lds;
-    }
-    const int grid = P.nK1 > tiles2 ? P.nK1 : tiles2;
-    // role 8 of bench.py's roofline leg: the whole backward loop of the step is this one launch
-    T2_LAUNCH_ROLE(8, dec_train_bwd_persistent_kernel, dim3(grid), dim3(512), lds, st, P);
-    T2_LAUNCH_CHECK();
-    if (poison) {
-        hipLaunchKernelGGL(dec_train_persist_poison_kernel, dim3(1), dim3(1), 0, st, status, poison);
-        T2_LAUNCH_CHECK();
-    }
-    return T2AMD_OK;
-}
+// (Round 6, VERDICT r05 item 9 "delete or win": the persistent BACKWARD loop -- dec_train_bwd_persistent_kernel, its per-step descriptor
+// staging and its ABI entries, opt-in since round 4 -- stood here.  Two rounds at 1 ms BEHIND the launch chain it was meant to replace
+// (28.45 vs 27.4 ms of backward loop, profiles/r04_j_ab_train_bwd_persistent.json; DESIGN 5.1 / 5.2 say why: the step is two all-to-all
+// edges around an 18 us issue-bound phase, and the hand-offs cost what the kernel boundaries did).  The measurement stays under
+// profiles/, the code is in the history (last present in the commit before this one).  What remains of it are template parameters of
+// shared device functions -- PERSIST in attn_bwd_main_body / kb1_*, SC1 in cell_bwd.h, XPLAIN and the negative gate_seg in
+// skinny_wide.h -- which no kernel instantiates with `true` any more.)
 
 // ---------------------------------------------------------------------------------------
 // Fold / unfold of the location layer:  U[128][62]

@@ -881,20 +881,6 @@ extern "C" int t2amd_skinny_gemm_f32(const t2amd_skinny_gemm* a, void* stream) {
 }
 
 extern "C" int t2amd_skinny_wide_enabled_(void) { return skinny_wide_enabled() ? 1 : 0; }
-// internal (attention.hip, the persistent backward loop): the kernel arguments and the workgroup count of the launch
-// t2amd_skinny_gemm2_f32(a, b) would make on the wide bf16 tile -- nothing is launched.  Any other kernel form is an error.
-extern "C" int t2amd_skinny_gemm2_describe_(const t2amd_skinny_gemm* a, const t2amd_skinny_gemm* b, SkinnyDual* d, int* total) {
-    T2_REQUIRE(a && b && d && total, "skinny_gemm2_describe: null args");
-    T2_REQUIRE(a->bf16 == 1 && b->bf16 == 1 && skinny_wide_enabled(), "skinny_gemm2_describe: the wide bf16 tile only");
-    d->ts = t2amd_debug_ts_();
-    T2_PROPAGATE(fill_plain(a, d->p[0]));
-    T2_PROPAGATE(fill_plain(b, d->p[1]));
-    d->p[0].gx = t2_cdiv(a->N, 32);
-    d->p[1].gx = t2_cdiv(b->N, 32);
-    d->nblk0 = d->p[0].gx * d->p[0].gy * d->p[0].gz;
-    *total = d->nblk0 + d->p[1].gx * d->p[1].gy * d->p[1].gz;
-    return T2AMD_OK;
-}
 
 // ---------------------------------------------------------------------------------------
 // LSTM cell backward (pointwise part): given dL/dh' (dropped-out hidden) and the carried

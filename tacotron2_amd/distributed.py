@@ -360,8 +360,7 @@ def apply_gradient_allreduce(module):
                 nv.set_bptt_cell_fold(0)
                 from . import engine
                 engine.ENCODER_BATCH_PERSISTENT = False          # the persistent encoder launches spin on hand-offs too
-                engine.TRAIN_FWD_PERSISTENT = False              # ... and the persistent decoder loops need every CU to themselves
-                engine.TRAIN_BWD_PERSISTENT = False
+                engine.TRAIN_FWD_PERSISTENT = False              # ... and the persistent decoder loop needs every CU to itself
             if dist.get_rank() == 0:
                 import sys
                 print("tacotron2_amd: %d ranks share one GPU: the separate-launch forms of the attention step are selected "

@@ -838,23 +838,9 @@ def _decoder_train_fwd(model, run, d, poison, reads, writes, regen_ga=None):
     return 'launch chain'
 
 
-# BPTT through the decoder loop as ONE persistent launch (csrc/attention.hip, dec_train_bwd_persistent_kernel) instead of 2 To
-# dependent launches; T2AMD_TRAIN_BWD_PERSISTENT=0 keeps the chain.  Bit-identical to it.
-TRAIN_BWD_PERSISTENT = os.environ.get('T2AMD_TRAIN_BWD_PERSISTENT', '0') != '0'
-
-
 def _decoder_train_bwd(model, run, bw, poison, reads, writes):
-    """reference model.py:405-411 under autograd.  The persistent launch when it is selected and the geometry fits this device;
-    a give-up turns ``poison[0]`` (an element of a gradient) into NaN: the step is skipped, handle_nonfinite_step() selects the chain."""
-    if TRAIN_BWD_PERSISTENT and run.bf16:
-        # (validate-only CPU runs stage and check every step's descriptors too; nothing is launched)
-        cus = 256 if nv.validate_only() else torch.cuda.get_device_properties(run.dev).multi_processor_count
-        if nv.decoder_train_bwd_persistent_supported(bw, cus) is None:
-            descs = run.empty8(nv.decoder_train_bwd_persistent_desc_bytes(bw.f.To))
-            flags = run.empty_i32(nv.decoder_train_bwd_persistent_flag_words())
-            status = run.empty_i32(1)
-            nv.decoder_train_bwd_persistent(bw, descs, flags, status, poison)
-            return 'persistent'
+    """reference model.py:405-411 under autograd: the launch chain (two dependent launches per time step).  The opt-in persistent
+    launch of rounds 4-5 (TRAIN_BWD_PERSISTENT) was removed in round 6: 1 ms behind this chain for two rounds."""
     nv.decoder_train_bwd_loop(bw, reads=reads, writes=writes)
     return 'launch chain'
 
@@ -1015,9 +1001,9 @@ def _note_training_step(log=None):
         d['clean'] += 1
     if d['clean'] <= d['need']:
         return False
-    global TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT, ENCODER_BATCH_PERSISTENT
+    global TRAIN_FWD_PERSISTENT, ENCODER_BATCH_PERSISTENT
     sv = d['saved']
-    TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT, ENCODER_BATCH_PERSISTENT = sv['fwd'], sv['bwd'], sv['enc']
+    TRAIN_FWD_PERSISTENT, ENCODER_BATCH_PERSISTENT = sv['fwd'], sv['enc']
     nv.set_attn_fwd_fused(sv['attn_fwd_fused'])
     nv.set_attn_bwd_fused(sv['attn_bwd_fused'])
     nv.set_bptt_cell_fold(sv['cell_fold'])
@@ -1045,18 +1031,18 @@ def give_up_counters():
 def handle_nonfinite_step(log=None):
     """Call when a training step produced a non-finite loss / gradient norm.  If the reason is an ABANDONED in-launch
     hand-off -- of the one-launch attention forms (their four workgroups per utterance were not co-resident within 50 ms: a
-    shared or partitioned GPU), of the persistent decoder loops (TRAIN_FWD_PERSISTENT / TRAIN_BWD_PERSISTENT: arrival census or
+    shared or partitioned GPU), of the persistent decoder loop (TRAIN_FWD_PERSISTENT: arrival census or
     a bounded spin) or of the persistent encoder launches; the kernels then poison the step with NaN rather than use
     half-exchanged data -- say so and select the launch chains and the separate-launch attention forms: this CLEARS
-    ``TRAIN_FWD_PERSISTENT`` / ``TRAIN_BWD_PERSISTENT`` (and ``ENCODER_BATCH_PERSISTENT`` for an encoder give-up) and calls
+    ``TRAIN_FWD_PERSISTENT`` (and ``ENCODER_BATCH_PERSISTENT`` for an encoder give-up) and calls
     ``set_attn_fwd_fused(0)`` / ``set_attn_bwd_fused(0)`` / ``set_bptt_cell_fold(0)`` -- bit-identical results, no co-residency
     assumption -- until `_note_training_step` re-promotes them after TRAIN_FWD_REPROMOTE_AFTER clean steps.  Returns the number
     of abandoned hand-offs (0: the non-finite values have another cause)."""
-    global ENCODER_BATCH_PERSISTENT, TRAIN_FWD_PERSISTENT, TRAIN_BWD_PERSISTENT
+    global ENCODER_BATCH_PERSISTENT, TRAIN_FWD_PERSISTENT
     ne = nv.encoder_handoff_timeouts(reset=True)
     n = nv.attn_handoff_timeouts(reset=True)
     if ne > 0 or n > 0:
-        _demote(dict(fwd=TRAIN_FWD_PERSISTENT, bwd=TRAIN_BWD_PERSISTENT, enc=ENCODER_BATCH_PERSISTENT,
+        _demote(dict(fwd=TRAIN_FWD_PERSISTENT, enc=ENCODER_BATCH_PERSISTENT,
                      attn_fwd_fused=nv.get_attn_fwd_fused(), attn_bwd_fused=nv.get_attn_bwd_fused(),
                      cell_fold=nv.get_bptt_cell_fold()))
     if ne > 0:
@@ -1071,7 +1057,6 @@ def handle_nonfinite_step(log=None):
             print(msg, file=sys.stderr, flush=True)
     if n > 0:
         TRAIN_FWD_PERSISTENT = False
-        TRAIN_BWD_PERSISTENT = False
         nv.set_attn_fwd_fused(0)
         nv.set_attn_bwd_fused(0)
         nv.set_bptt_cell_fold(0)
@@ -1404,10 +1389,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     nv.grads_to_channel_last(cont(d_mel), cont(d_post), dmel_cl, dpost_cl)
     _conv_stack_bwd(run, P, g, 'postnet.convolutions', c.post_saved, dpost_cl.view(rowsP, Cm), To,
                     first_dx=dmel_cl.view(rowsP, Cm), first_dx_accumulate=True, G=G)
-    # The persistent BPTT launch needs every CU to itself (its arrival census gives up after 2 ms): no collective may start beside
-    # it.  The postnet bucket is then launched BEHIND the loop (it travels under the decoder's weight-gradient products instead).
-    defer_postnet = sync is not None and TRAIN_BWD_PERSISTENT and run.bf16
-    if sync is not None and not defer_postnet:
+    if sync is not None:
         sync.bucket_ready('postnet')             # travels while the decoder BPTT below runs
     dout = run.empty(rowsD, Cm + 1)
     nv.gather_dout(dmel_cl, cont(d_gate), dout)
@@ -1463,7 +1445,7 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         setattr(bw, k_, nv.ptr(v_))
     if run.bf16:
         # the bf16 gate gradients are kept for every step ([To][B][4H] slabs) when the weight gradients are formed from them
-        slab16 = WGRAD16 and B % 8 == 0 and (not nv.validate_only() or TRAIN_BWD_PERSISTENT)
+        slab16 = WGRAD16 and B % 8 == 0 and not nv.validate_only()
         nst = To if slab16 else 1
         b16 = dict(Wa_recT16=run.cached('Wa_recT16', [Wih_a, Whh_a], lambda: run.cast16(Wa_recT)),
                    Wd_catT16=run.cached('Wd_catT16', [Wih_d, Whh_d], lambda: run.cast16(Wd_catT)),
@@ -1487,8 +1469,6 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
                               + ([b16['Wa_recT16'], b16['Wd_catT16']] if op16 else [])
                               + ([c.bf16['memory16'], c.bf16['Wq16']] if run.bf16 else []),
                               writes=list(out.values()) + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if op16 else []))
-    if defer_postnet:
-        sync.bucket_ready('postnet')
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
     DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)
 

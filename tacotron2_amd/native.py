@@ -275,8 +275,6 @@ SYMBOLS = [
     "t2amd_attention_step_fwd_f32", "t2amd_attention_step_bwd_f32",
     "t2amd_decoder_train_fwd_loop_f32", "t2amd_decoder_train_bwd_loop_f32",
     "t2amd_decoder_train_fwd_persistent_flag_bytes", "t2amd_decoder_train_fwd_persistent_supported", "t2amd_decoder_train_fwd_persistent_f32",
-    "t2amd_decoder_train_bwd_persistent_flag_bytes", "t2amd_decoder_train_bwd_persistent_desc_bytes",
-    "t2amd_decoder_train_bwd_persistent_supported", "t2amd_decoder_train_bwd_persistent_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
     "t2amd_set_attn_bwd_granules", "t2amd_attn_handoff_timeouts", "t2amd_set_attn_bwd_fused", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
@@ -339,10 +337,6 @@ def _argtypes():
         "t2amd_decoder_train_fwd_persistent_flag_bytes": [_I, _I],
         "t2amd_decoder_train_fwd_persistent_supported": [pt(DecTrain), _I],
         "t2amd_decoder_train_fwd_persistent_f32": [pt(DecTrain), _P, _P, _P, _P],
-        "t2amd_decoder_train_bwd_persistent_flag_bytes": [],
-        "t2amd_decoder_train_bwd_persistent_desc_bytes": [_I],
-        "t2amd_decoder_train_bwd_persistent_supported": [pt(DecTrainBwd), _I],
-        "t2amd_decoder_train_bwd_persistent_f32": [pt(DecTrainBwd), _P, _P, _P, _P, _P],
         "t2amd_decoder_train_bwd_loop_f32": [pt(DecTrainBwd), _P],
         "t2amd_lstm_seq_fwd_f32": [pt(LstmSeq), _P],
         "t2amd_lstm_seq_bwd_f32": [pt(LstmSeq), _P],
@@ -424,8 +418,6 @@ def load():
     lib.t2amd_lstm_seq_persistent_mailbox_bytes.restype = C.c_longlong
     lib.t2amd_lstm_seq_batch_persistent_flag_bytes.restype = C.c_longlong
     lib.t2amd_decoder_train_fwd_persistent_flag_bytes.restype = C.c_longlong
-    lib.t2amd_decoder_train_bwd_persistent_flag_bytes.restype = C.c_longlong
-    lib.t2amd_decoder_train_bwd_persistent_desc_bytes.restype = C.c_longlong
     if lib.t2amd_abi_version() != 1:
         raise NativeError("tacotron2_amd: ABI version mismatch")
     # the binary must be THESE sources' binary (by content: a snapshot copy or a checkout resets mtimes).  An explicitly
@@ -1400,38 +1392,6 @@ def decoder_train_fwd_persistent(desc, flags, status, poison=None):
     _check(lib.t2amd_decoder_train_fwd_persistent_f32(C.byref(desc), C.c_void_p(flags.data_ptr()), ptr(status, torch.int32),
                                                       ptr(poison) if poison is not None else None, _stream()),
            "t2amd_decoder_train_fwd_persistent_f32")
-
-
-def decoder_train_bwd_persistent_supported(desc, cus):
-    """None when the BPTT loop of the teacher-forced decoder can run as ONE persistent launch on a device of `cus` CUs, else the reason."""
-    lib = load()
-    if lib.t2amd_decoder_train_bwd_persistent_supported(C.byref(desc), int(cus)) == 0:
-        return None
-    msg = lib.t2amd_last_error()
-    return msg.decode() if msg else "unsupported"
-
-
-def decoder_train_bwd_persistent_flag_words():
-    return int(load().t2amd_decoder_train_bwd_persistent_flag_bytes()) // 4
-
-
-def decoder_train_bwd_persistent_desc_bytes(To):
-    return int(load().t2amd_decoder_train_bwd_persistent_desc_bytes(int(To)))
-
-
-def decoder_train_bwd_persistent(desc, descs, flags, status, poison=None):
-    """BPTT through the teacher-forced loop (reference model.py:405-411 under autograd) as one persistent launch behind the
-    loop's first two (csrc/attention.hip, dec_train_bwd_persistent_kernel): bit-identical to decoder_train_bwd_loop.
-    ``descs``: a uint8 device tensor of decoder_train_bwd_persistent_desc_bytes(To) bytes; ``poison``: an f32 tensor whose
-    first element becomes NaN if a workgroup gave up (for callers that do not read ``status`` back)."""
-    lib = load()
-    if flags.dtype != torch.int32 or flags.numel() * 4 < lib.t2amd_decoder_train_bwd_persistent_flag_bytes():
-        raise NativeError("decoder_train_bwd_persistent: int32 flags of %d bytes needed" % lib.t2amd_decoder_train_bwd_persistent_flag_bytes())
-    if descs.numel() * descs.element_size() < lib.t2amd_decoder_train_bwd_persistent_desc_bytes(desc.f.To):
-        raise NativeError("decoder_train_bwd_persistent: descriptor buffer too small")
-    _check(lib.t2amd_decoder_train_bwd_persistent_f32(C.byref(desc), C.c_void_p(descs.data_ptr()), C.c_void_p(flags.data_ptr()),
-                                                      ptr(status, torch.int32), ptr(poison) if poison is not None else None, _stream()),
-           "t2amd_decoder_train_bwd_persistent_f32")
 
 
 def lstm_seq_batch_persistent_supported(desc, ndir, cus):

@@ -25,7 +25,7 @@ def native_lib():
 # silently changes what every later in-process test runs (test_zz6 restored TRAIN_BWD_PERSISTENT from an
 # environment default that disagreed with engine.py's, so everything collected after it ran the opt-in backward form).  Every
 # test therefore ends with the flags it started the SESSION with -- checked here, after each test, for all of them.
-_ENGINE_FLAGS = ("TRAIN_FWD_PERSISTENT", "TRAIN_BWD_PERSISTENT", "ENCODER_BATCH_PERSISTENT", "ENCODER_BATCH_PERSISTENT_TRAIN",
+_ENGINE_FLAGS = ("TRAIN_FWD_PERSISTENT", "ENCODER_BATCH_PERSISTENT", "ENCODER_BATCH_PERSISTENT_TRAIN",
                  "ENCODER_BWD_PERSISTENT", "WGRAD16", "WGRAD_KK", "CONV16", "FAST_GRAD_GEMM", "ARENA", "WEIGHT_GUARD",
                  "COMPACT_BATCH", "PERSISTENT_DECODE", "PERSISTENT_ENCODER", "SMALL_BATCH_PERSISTENT", "DGRAD_SPLIT",
                  "ENC_DGRAD_SPLIT", "TRAIN_FWD_REPROMOTE_AFTER")

@@ -163,22 +163,22 @@ def test_demoted_forms_are_reselected_after_clean_steps(native_lib, monkeypatch)
     the kernels raise are stood in for.)"""
     said = []
     state = dict(engine._DEMOTION)
-    flags = (engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
+    flags = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
     fold = native.get_bptt_cell_fold()
     monkeypatch.setattr(engine, 'TRAIN_FWD_REPROMOTE_AFTER', 3)
     pending = {'attn': 2, 'enc': 0}
     monkeypatch.setattr(native, 'attn_handoff_timeouts', lambda reset=True: pending.pop('attn', 0) if reset else pending.get('attn', 0))
     monkeypatch.setattr(native, 'encoder_handoff_timeouts', lambda reset=True: pending.pop('enc', 0) if reset else pending.get('enc', 0))
     try:
-        engine._DEMOTION.update(active=False, count=0, clean=0, need=0, saved=None, repromotions=0)
-        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT = True, True
+        engine._DEMOTION.update(active=False, count=0, clean=0, need=0, saved=None, repromotions=0, explicit=False, probation=0, given_up=False)
+        engine.TRAIN_FWD_PERSISTENT = True
         native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(1)
         assert engine.handle_nonfinite_step(log=said.append) == 2
-        assert engine.TRAIN_FWD_PERSISTENT is False and engine.TRAIN_BWD_PERSISTENT is False
+        assert engine.TRAIN_FWD_PERSISTENT is False
         assert native.get_attn_fwd_fused() == 0 and native.get_attn_bwd_fused() == 0 and native.get_bptt_cell_fold() == 0
         assert engine.give_up_counters()['demoted_now'] and 're-selected after 3 clean steps' in said[-1]
         assert [engine._note_training_step(said.append) for _ in range(4)] == [False, False, False, True]
-        assert engine.TRAIN_FWD_PERSISTENT is True and engine.TRAIN_BWD_PERSISTENT is True
+        assert engine.TRAIN_FWD_PERSISTENT is True
         assert native.get_attn_fwd_fused() == -1 and native.get_attn_bwd_fused() == -1 and native.get_bptt_cell_fold() == 1
         assert not engine.give_up_counters()['demoted_now'] and engine.give_up_counters()['repromotions'] == 1
         assert engine._note_training_step(said.append) is False            # nothing to do while not demoted
@@ -190,5 +190,5 @@ def test_demoted_forms_are_reselected_after_clean_steps(native_lib, monkeypatch)
         assert not any(engine._note_training_step(said.append) for _ in range(20))
     finally:
         engine._DEMOTION.clear(); engine._DEMOTION.update(state)
-        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = flags
+        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = flags
         native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(fold)

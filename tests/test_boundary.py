@@ -208,63 +208,11 @@ def test_torch_library_ops_are_registered(native_lib):
     assert native._via_ops("decoder_train_fwd", [native.DecTrain()], [torch.zeros(2)], [torch.zeros(2)]) is False
 
 
-def test_persistent_backward_loop_host_staging_validate_only(native_lib):
-    """The BPTT loop as one persistent launch (csrc/attention.hip dec_train_bwd_persistent_kernel) works from the kernel
-    arguments the launch chain would have passed, staged per time step by the chain's own host code in describe mode
-    (attn_bwd_step_impl, t2amd_skinny_gemm2_describe_).  Validate-only: every step's descriptor is built and checked, nothing
-    is launched.  Geometries the launch cannot take (no per-step slabs of the bf16 gate gradients: B % 8 != 0; H < 256: a wave
-    would not write whole 128-byte lines of them) stay on the chain, and `_supported` says why."""
-    from tacotron2_amd import engine
-    native.set_validate_only(True)
-    keep = engine.TRAIN_BWD_PERSISTENT
-    engine.TRAIN_BWD_PERSISTENT = True
-    try:
-        for hpstr, in_lens, out_lens, want in (("", [17, 11, 9, 9, 8, 5, 3, 2], [30, 23, 12, 25, 7, 19, 30, 4], "persistent"),
-                                               ("", [17, 11, 9], [30, 23, 12], "launch chain"),
-                                               (gu.TINY_HP, [12, 9, 5, 5, 4, 4, 3, 2], [20, 16, 11, 9, 20, 3, 8, 8], "launch chain")):
-            hp = create_hparams((hpstr + "," if hpstr else "") + "max_decoder_steps=6")
-            m = Tacotron2(hp)
-            m.precision = "bf16"
-            x, y = m.parse_batch(gu.make_train_batch(in_lens, out_lens, 80, 1))
-            out = m(x)
-            (out[0].sum() + out[1].sum() + out[2].sum()).backward()
-            assert m.last_train_decoder_bwd_path == want, (hpstr, len(in_lens), m.last_train_decoder_bwd_path)
-            assert all(p.grad is not None and p.grad.shape == p.shape for p in m.parameters())
-        # the geometry test by itself (pointers are only checked for being there)
-        bw = native.DecTrainBwd()
-        f = bw.f
-        f.B, f.Ti, f.To, f.E, f.Ha, f.Hd, f.bf16 = 64, 187, 870, 512, 1024, 1024, 1
-        for name in ("memory16", "Wq16"):
-            setattr(f, name, 64)
-        for name in ("Wa_recT16", "Wd_catT16", "DGA16", "DGD16"):
-            setattr(bw, name, 64)
-        bw.nsplit = 2
-        bw.dg16_step_a = bw.dg16_step_d = 64 * 4096
-        assert native.decoder_train_bwd_persistent_supported(bw, 256) is None
-        assert "compute units" in native.decoder_train_bwd_persistent_supported(bw, 128)
-        bw.dg16_step_a = 0
-        assert "per-step slabs" in native.decoder_train_bwd_persistent_supported(bw, 256)
-        bw.dg16_step_a = 64 * 4096
-        f.B = 65
-        bw.dg16_step_a = bw.dg16_step_d = 65 * 4096
-        assert "B <= 64" in native.decoder_train_bwd_persistent_supported(bw, 512)
-        f.B, f.Ha = 64, 128
-        assert "128-byte lines" in native.decoder_train_bwd_persistent_supported(bw, 256)
-        f.Ha, f.bf16 = 1024, 0
-        assert "bf16 operand mode" in native.decoder_train_bwd_persistent_supported(bw, 256)
-        assert native.decoder_train_bwd_persistent_desc_bytes(870) == 870 * native.decoder_train_bwd_persistent_desc_bytes(1)
-    finally:
-        engine.TRAIN_BWD_PERSISTENT = keep
-        native.set_validate_only(False)
-
-
-def test_bucket_launch_order_around_the_persistent_backward_loop(native_lib, monkeypatch):
+def test_bucket_launch_order_around_the_backward_loop(native_lib, monkeypatch):
     """Data parallel (reference distributed.py:126-173): the engine launches the postnet bucket's all-reduce in front of the
-    decoder BPTT (it travels while the loop runs) -- unless the loop is the ONE persistent launch, which needs every CU to itself:
-    then nothing may be enqueued to run beside it and the bucket goes out BEHIND the loop.  Host logic only (validate-only)."""
-    from tacotron2_amd import engine
+    decoder BPTT (it travels while the loop runs), the decoder bucket behind it, the encoder bucket last.  Host logic only
+    (validate-only).  (Until round 5 there was a second order for the opt-in persistent BPTT launch, removed in round 6.)"""
     native.set_validate_only(True)
-    keep = engine.TRAIN_BWD_PERSISTENT
     events = []
 
     class FakeSync(object):
@@ -283,21 +231,18 @@ def test_bucket_launch_order_around_the_persistent_backward_loop(native_lib, mon
         def finish(self):
             events.append("finish")
 
-    for name in ("decoder_train_bwd_persistent", "decoder_train_bwd_loop"):
-        real = getattr(native, name)
-        monkeypatch.setattr(native, name, (lambda real, name: lambda *a, **k: (events.append("bptt:" + name), real(*a, **k))[1])(real, name))
+    real = native.decoder_train_bwd_loop
+    monkeypatch.setattr(native, "decoder_train_bwd_loop", lambda *a, **k: (events.append("bptt"), real(*a, **k))[1])
     try:
-        for persistent, want in ((True, ["start", "bptt:decoder_train_bwd_persistent", "bucket:postnet", "bucket:decoder", "bucket:encoder", "finish"]),
-                                 (False, ["start", "bucket:postnet", "bptt:decoder_train_bwd_loop", "bucket:decoder", "bucket:encoder", "finish"])):
-            engine.TRAIN_BWD_PERSISTENT = persistent
+        for precision in ("bf16", "fp32", "bf16x3"):
             del events[:]
             m = Tacotron2(create_hparams("max_decoder_steps=6"))
-            m.precision = "bf16"
+            m.precision = precision
             m._grad_sync = FakeSync(m)
             x, y = m.parse_batch(gu.make_train_batch([17, 11, 9, 9, 8, 5, 3, 2], [30, 23, 12, 25, 7, 19, 30, 4], 80, 1))
             out = m(x)
             (out[0].sum() + out[1].sum() + out[2].sum()).backward()
-            assert events == want, events
+            assert events == ["start", "bucket:postnet", "bptt", "bucket:decoder", "bucket:encoder", "finish"], events
+            assert m.last_train_decoder_bwd_path == "launch chain"
     finally:
-        engine.TRAIN_BWD_PERSISTENT = keep
         native.set_validate_only(False)

@@ -293,7 +293,7 @@ def test_attention_handoff_timeouts_are_reported_and_handled(native_lib, capfd):
     fold0 = native.get_bptt_cell_fold()
     # (the handler demotes the process to the chains: what it changes is put back below -- found by conftest's flag guard in round 5;
     # until then every in-process test collected after this one ran the forward loop on the launch chain)
-    entry = (engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT, dict(engine._DEMOTION))
+    entry = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT, dict(engine._DEMOTION))
     try:
         assert engine.handle_nonfinite_step() == 2
         assert "hand-off(s) timed out" in capfd.readouterr().err
@@ -306,8 +306,8 @@ def test_attention_handoff_timeouts_are_reported_and_handled(native_lib, capfd):
         native.set_attn_fwd_fused(-1)
         native.set_attn_bwd_fused(-1)
         native.set_bptt_cell_fold(fold0)
-        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry[:3]
-        engine._DEMOTION.clear(); engine._DEMOTION.update(entry[3])
+        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry[:2]
+        engine._DEMOTION.clear(); engine._DEMOTION.update(entry[2])
 
 
 def test_weight_gradient_routes_agree_including_the_masked_postnet_input(native_lib):

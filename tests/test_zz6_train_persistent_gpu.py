@@ -1,6 +1,6 @@
-"""The teacher-forced decoder loop, forward and backward, as ONE persistent launch each (csrc/attention.hip
-dec_train_fwd_persistent_kernel / dec_train_bwd_persistent_kernel; reference
+"""The teacher-forced decoder loop, forward, as ONE persistent launch (csrc/attention.hip dec_train_fwd_persistent_kernel; reference
 model.py:405-411 around Decoder.decode :340-379) against the launch chain it replaces: same model, batch and dropout masks.
+(The BACKWARD loop had an opt-in persistent launch too in rounds 4-5; it never beat its chain and was removed in round 6.)
 
 The persistent launch runs the SAME tile / attention bodies in the same arithmetic order; what differs is how the time steps
 hand data to each other (flag + data hand-offs inside one launch instead of kernel boundaries).  So the bar is BIT-IDENTITY of
@@ -20,10 +20,10 @@ DEV = "cuda"
 
 
 def _step(m, batch, persistent, seed=7, bwd_persistent=None):
-    """One training step; `persistent` selects the forward loop's form, `bwd_persistent` the backward loop's (default: the same)."""
-    keep = engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT
+    """One training step; `persistent` selects the forward loop's form.  (`bwd_persistent`: ignored since round 6 -- the backward
+    loop has one form, the launch chain.)"""
+    keep = engine.TRAIN_FWD_PERSISTENT
     engine.TRAIN_FWD_PERSISTENT = persistent
-    engine.TRAIN_BWD_PERSISTENT = persistent if bwd_persistent is None else bwd_persistent
     try:
         m.zero_grad()
         torch.manual_seed(seed)                               # the Philox keep-masks are seeded from torch's RNG
@@ -37,7 +37,7 @@ def _step(m, batch, persistent, seed=7, bwd_persistent=None):
                 {k: p.grad.detach().clone() for k, p in m.named_parameters()},
                 {k: v.detach().clone() for k, v in m.named_buffers()}, m.last_train_decoder_path)
     finally:
-        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT = keep
+        engine.TRAIN_FWD_PERSISTENT = keep
 
 
 def _model(hp_str="", precision="bf16"):
@@ -61,26 +61,17 @@ def test_persistent_train_forward_is_bit_identical_to_the_launch_chain(native_li
     m.load_state_dict(state)                                  # the BatchNorm running statistics moved: same start for both
     assert m.last_paths == ("launch chain", "launch chain")
     o1, l1, g1, b1, p1 = _step(m, batch, True)
-    # (the backward loop as one launch needs per-step slabs of the bf16 gate gradients: the engine keeps them when B % 8 == 0)
-    bwd = "persistent" if len(in_lens) % 8 == 0 else "launch chain"
-    assert p0 == "launch chain" and p1 == "persistent" and m.last_paths == ("persistent", bwd)
+    assert p0 == "launch chain" and p1 == "persistent" and m.last_paths == ("persistent", "launch chain")
     assert native.attn_handoff_timeouts(reset=False) == 0
     for i in range(4):
         assert torch.isfinite(o1[i]).all() and torch.equal(o0[i], o1[i]), i
     assert float(l0) == float(l1)
     assert [k for k in g0 if not torch.equal(g0[k], g1[k])] == []
     assert [k for k in b0 if not torch.equal(b0[k], b1[k])] == []
-    # the backward loop alone as one launch behind the forward CHAIN: the same bits again
-    m.load_state_dict(state)
-    o2, l2, g2, _, _ = _step(m, batch, False, bwd_persistent=True)
-    assert m.last_paths == ("launch chain", bwd) and native.attn_handoff_timeouts(reset=False) == 0
-    assert float(l0) == float(l2) and [k for k in g0 if not torch.equal(g0[k], g2[k])] == []
 
 
 def test_persistent_train_forward_smaller_model_geometry(native_lib):
-    """H = 128 / E = 128: 16 + 16 LSTM tiles, 4 B attention workgroups -- more attention workgroups than tiles.  (The backward
-    loop stays on the chain: its dgrad tiles read the bf16 gate gradients with ordinary loads, which needs every 128-byte line of
-    them written whole by one wave -- H a multiple of 256.)"""
+    """H = 128 / E = 128: 16 + 16 LSTM tiles, 4 B attention workgroups -- more attention workgroups than tiles."""
     m, hp = _model(gu.TINY_HP)
     batch = tuple(t.to(DEV) for t in gu.make_train_batch([14, 12, 9, 9, 6, 5, 5, 3, 2, 2], [20, 11, 18, 7, 13, 20, 5, 9, 12, 6], hp.n_mel_channels, 9))
     state = {k: v.clone() for k, v in m.state_dict().items()}
@@ -156,7 +147,7 @@ def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_l
     monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
     # what the test restores at its end: the engine's flags AS THEY WERE AT ENTRY (an environment default
     # that disagreed with engine.py's left every later in-process test on the opt-in backward form)
-    entry_flags = (engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
+    entry_flags = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
     try:
         o, loss, g, _, path = _step(m, batch, True)
         assert path == "persistent"
@@ -167,19 +158,8 @@ def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_l
         monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
         o2, loss2, _, _, path2 = _step(m, batch, engine.TRAIN_FWD_PERSISTENT)
         assert path2 == "launch chain" and torch.isfinite(loss2)
-        # the backward loop's give-up: the forward on the chain, the census of the backward launch forced to give up
-        engine.TRAIN_BWD_PERSISTENT = True
-        monkeypatch.setenv("T2AMD_DTP_TIMEOUT_TICKS", "0")
-        native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(1)
-        _, loss3, g3, _, _ = _step(m, batch, False, bwd_persistent=True)
-        assert m.last_paths == ("launch chain", "persistent") and torch.isfinite(loss3)
-        assert not all(torch.isfinite(v).all() for v in g3.values())          # poisoned gradients, not silently wrong ones
-        assert engine.handle_nonfinite_step(log=said.append) >= 1 and engine.TRAIN_BWD_PERSISTENT is False
-        monkeypatch.delenv("T2AMD_DTP_TIMEOUT_TICKS")
-        _, loss4, g4, _, _ = _step(m, batch, engine.TRAIN_FWD_PERSISTENT, bwd_persistent=engine.TRAIN_BWD_PERSISTENT)
-        assert m.last_paths == ("launch chain", "launch chain") and all(torch.isfinite(v).all() for v in g4.values())
     finally:
-        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry_flags
+        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry_flags
         native.set_attn_fwd_fused(-1)
         native.set_attn_bwd_fused(-1)
         native.set_bptt_cell_fold(1)
@@ -226,7 +206,7 @@ def test_the_persistent_forms_come_back_after_clean_steps(native_lib, monkeypatc
     """one foreign kernel must not cost a long run its faster forms for good."""
     m, hp = _model()
     batch = tuple(t.to(DEV) for t in gu.make_train_batch([19, 17, 12, 12, 9, 7, 4, 3], [22, 9, 15, 20, 9, 13, 6, 17], hp.n_mel_channels, 11))
-    entry = (engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
+    entry = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
     state = dict(engine._DEMOTION)
     monkeypatch.setattr(engine, "TRAIN_FWD_REPROMOTE_AFTER", 2)
     native.attn_handoff_timeouts(reset=True)
@@ -270,13 +250,13 @@ def test_the_persistent_forms_come_back_after_clean_steps(native_lib, monkeypatc
         assert one()[1] == "persistent" and engine.give_up_counters()["repromotions"] == 2
         # ... and after MAX_FAILED_REPROMOTIONS give-ups in a row the chains stay
         engine._DEMOTION.update(count=engine.MAX_FAILED_REPROMOTIONS)
-        engine._demote(dict(fwd=True, bwd=False, enc=True, attn_fwd_fused=-1, attn_bwd_fused=-1, cell_fold=1))
+        engine._demote(dict(fwd=True, enc=True, attn_fwd_fused=-1, attn_bwd_fused=-1, cell_fold=1))
         assert engine.give_up_counters()["repromotion_given_up"]
         for _ in range(3 * engine._DEMOTION['need'] // 2 + 2):
             engine.note_clean_step()
         assert not engine._note_training_step()
     finally:
         engine._DEMOTION.clear(); engine._DEMOTION.update(state)
-        engine.TRAIN_FWD_PERSISTENT, engine.TRAIN_BWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry
+        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = entry
         native.set_attn_fwd_fused(-1); native.set_attn_bwd_fused(-1); native.set_bptt_cell_fold(1)
         native.attn_handoff_timeouts(reset=True)

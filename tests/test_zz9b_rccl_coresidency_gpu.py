@@ -15,9 +15,8 @@
     them and the optimiser / next forward are ordered behind them -- : the gradients must stay bit-identical, finite (no NaN
     poison from an abandoned bounded spin), the backward must not slow down by the 50 ms a timed-out spin would cost per
     launch, and by no more than 1.5 x with 32 CUs held (measured 1.38 x) (round 4: the bound VERDICT r03 item 7 asked for).
-    The decoder's BPTT loop runs on the LAUNCH CHAIN here: as one persistent launch it needs every CU, which is why the engine
-    starts no collective beside it (the postnet bucket is launched behind the loop: engine.py, `defer_postnet`) -- a kernel
-    that holds CUs through the whole backward is then the shared-GPU case of (3), not the product layout.
+    (The decoder's BPTT loop is the launch chain: its opt-in persistent launch of rounds 4-5, which needed every CU and made the
+    engine start no collective beside it, was removed in round 6.)
 
 (3) ``test_whole_step_under_held_cus_falls_back_to_the_launch_chain`` (round 4): the persistent decoder loop of the forward
     needs every CU; with CUs held for the whole step (a shared GPU) its arrival census gives up within 2 ms, the step is
@@ -48,12 +47,10 @@ def _free_port():
     return port
 
 
-def _rccl_worker(port, precision, q, bwd_persistent=False):
+def _rccl_worker(port, precision, q):
     import faulthandler
     os.makedirs(OUT, exist_ok=True)
-    if bwd_persistent:              # the opt-in persistent BPTT launch: the postnet bucket is then launched BEHIND the loop (engine.py)
-        os.environ["T2AMD_TRAIN_BWD_PERSISTENT"] = "1"
-    log = open(os.path.join(OUT, "rccl_world1_%s%s.log" % (precision, "_bwdp" if bwd_persistent else "")), "w")
+    log = open(os.path.join(OUT, "rccl_world1_%s.log" % precision), "w")
     faulthandler.enable(log)
     faulthandler.dump_traceback_later(240, exit=True, file=log)
     import torch.distributed as dist
@@ -127,7 +124,7 @@ def _rccl_worker(port, precision, q, bwd_persistent=False):
                     for p in dp_model.parameters())
         mean_loss = float(reduce_tensor(torch.tensor(got[1][0], device=dev), 1))
         bwd_path = getattr(dp_model, "last_train_decoder_bwd_path", None)
-        path_ok = (bwd_path == "persistent") == bool(bwd_persistent)
+        path_ok = bwd_path == "launch chain"
         q.put(dict(ok=not bad and views and sync.fresh_allocations == 1 and mean_loss == got[1][0] and path_ok, bad=bad[:10],
                    decoder_bptt=bwd_path,
                    p_grad_is_a_bucket_view=views, bucket_sets_allocated=sync.fresh_allocations,
@@ -143,16 +140,12 @@ def _rccl_worker(port, precision, q, bwd_persistent=False):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32", "bf16+persistent BPTT"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32", "bf16x3"])
 def test_rccl_world1_bucket_allreduce_is_ordered_and_exact(native_lib, precision):
-    """(third case: the opt-in persistent BPTT launch -- it fills the chip, so the engine launches the postnet bucket behind the
-    loop instead of in front of it; same bar: every gradient and one optimiser step bit-identical to the run without an exchange)"""
     import queue
-    bwdp = precision.endswith("persistent BPTT")
-    precision = precision.split("+")[0]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), precision, q, bwdp))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), precision, q))
     p.start()
     try:
         res = q.get(timeout=300)
@@ -162,7 +155,7 @@ def test_rccl_world1_bucket_allreduce_is_ordered_and_exact(native_lib, precision
     if p.is_alive():
         p.kill()
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "parity_rccl_world1_%s%s.json" % (precision, "_bwdp" if bwdp else "")), "w") as f:
+    with open(os.path.join(OUT, "parity_rccl_world1_%s.json" % precision), "w") as f:
         json.dump(res, f, indent=1)
     assert res.get("ok"), res
 
@@ -226,12 +219,7 @@ def test_training_step_with_cus_held_by_another_kernel(native_lib):
         torch.cuda.synchronize()
         return loss, ms, held
 
-    keep_bwd = engine.TRAIN_BWD_PERSISTENT
-    engine.TRAIN_BWD_PERSISTENT = False          # (see the module docstring)
-    try:
-        _held_cus_cases(native_lib, model, step, To)
-    finally:
-        engine.TRAIN_BWD_PERSISTENT = keep_bwd
+    _held_cus_cases(native_lib, model, step, To)
 
 
 def _held_cus_cases(native_lib, model, step, To):
@@ -285,7 +273,7 @@ def test_whole_step_under_held_cus_falls_back_to_the_launch_chain(native_lib):
     model = Tacotron2(hp).to(dev).train()
     model.precision = 'bf16'
     side = torch.cuda.Stream()
-    keep_flags = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT, engine.TRAIN_BWD_PERSISTENT)
+    keep_flags = (engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT)
 
     def step():
         torch.manual_seed(5)
@@ -316,7 +304,7 @@ def test_whole_step_under_held_cus_falls_back_to_the_launch_chain(native_lib):
         assert ms < 500.0, ms                                  # found out by the census, not by hanging
         said = []
         assert engine.handle_nonfinite_step(log=said.append) >= 1 and said
-        assert engine.TRAIN_FWD_PERSISTENT is False and engine.TRAIN_BWD_PERSISTENT is False
+        assert engine.TRAIN_FWD_PERSISTENT is False
         loss2 = step()                                         # same step, same hold, on the launch chain
         stop.fill_(1)
         torch.cuda.synchronize()
@@ -324,7 +312,7 @@ def test_whole_step_under_held_cus_falls_back_to_the_launch_chain(native_lib):
         assert float(loss2) == ref_loss
         assert all(torch.equal(p.grad, ref[k]) for k, p in model.named_parameters())
     finally:
-        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT, engine.TRAIN_BWD_PERSISTENT = keep_flags
+        engine.TRAIN_FWD_PERSISTENT, engine.ENCODER_BATCH_PERSISTENT = keep_flags
         native.set_attn_fwd_fused(-1)
         native.set_attn_bwd_fused(-1)
         native.set_bptt_cell_fold(1)

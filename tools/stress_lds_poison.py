@@ -38,7 +38,6 @@ if "fold0" in toggles: nv.set_bptt_cell_fold(0)
 if "encp0" in toggles: engine.ENCODER_BATCH_PERSISTENT = False
 if "fwdp0" in toggles:
     engine.TRAIN_FWD_PERSISTENT = False
-    engine.TRAIN_BWD_PERSISTENT = False
 hp = gu.make_hparams("")
 shard = gu.make_train_batch([23, 17, 9], [41, 33, 20], hp.n_mel_channels, 500)
 ms = MaskSource(None, dev)
