@@ -12,12 +12,13 @@ from tacotron2_amd.hparams import create_hparams
 pytestmark = pytest.mark.gpu
 
 
-def test_train_step_without_padding_mask(native_lib):
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_train_step_without_padding_mask(native_lib, precision):
     """hparams.mask_padding=False (reference model.py:490): padded frames keep their decoded values, carry loss
     and gradient.  Same checks as the masked fixtures, against tests/golden/tiny_train_nomask.pt (made by the
     reference) and the live oracle."""
     import test_parity_gpu as tp
-    tp.test_train_step_matches_reference_and_oracle(native_lib, "tiny_train_nomask")
+    tp.test_train_step_matches_reference_and_oracle(native_lib, "tiny_train_nomask", precision)
 
 
 def test_notebook_half_inference(native_lib):
