@@ -495,7 +495,8 @@ typedef struct t2amd_attn_bwd {
     /* 1: the two gradient products of the location layer (dcol = U^T dpre, dU += dpre^T im2col) round their
      * operands to bf16 and run on v_mfma_f32_16x16x32_bf16 (f32 accumulate) -- the engine's bf16 compute mode.
      * 0: exact-f32 MFMA.  The recompute of the location conv uses the forward's split-bf16 form (see
-     * t2amd_attn_fwd.loc_split_bf16) when this is 1, the exact-f32 MFMA otherwise. */
+     * t2amd_attn_fwd.loc_split_bf16) when this is 1, the exact-f32 MFMA otherwise.
+     * 2 (round 6, the 'bf16x3' mode): the recompute in the split-bf16 form, the two gradient products exact f32. */
     int bf16;
     /* optional bf16 copy of `memory`: dw = dctx . memory streams it instead of the f32 rows */
     const void* memory16;

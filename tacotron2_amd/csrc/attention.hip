@@ -1397,8 +1397,10 @@ __global__ __launch_bounds__(512) void dec_train_fwd_persistent_kernel(DecTrainP
                 ap.a.ctx16_out = (void*)((unsigned short*)d.CTX16 + t * sE); ap.a.ld_ctx16 = d.E;
                 ap.a.loc_split_bf16 = 1; ap.a.memory16 = d.memory16; ap.a.Wq16 = d.Wq16;
             }
-            if constexpr (X3) {       // the split image of the context for the tiles; the step itself stays exact f32
+            if constexpr (X3) {       // the split image of the context for the tiles; the step itself stays f32-class: exact f32
+                                      // everywhere but the location conv, which runs as the split-bf16 product (~2^-17 per term)
                 ap.a.ctx16_out = (void*)((unsigned short*)d.CTX16 + t * sE * 2); ap.a.ld_ctx16 = d.E; ap.a.ctx16_x3 = 1;
+                ap.a.loc_split_bf16 = 1;
             }
             ap.tip = P.tip; ap.dbg = 0; ap.ts = P.ts;
             ap.token = P.token0 + (unsigned)t; ap.gran_off = P.gran_off; ap.kc_smem_off = P.kc_smem_off; ap.delay = 0;
@@ -2219,7 +2221,9 @@ __device__ __forceinline__ void attn_bwd_main_body(const AttnBwdParams& p, float
             }
     // bf16 mode: the same operand as one v_mfma_f32_16x16x32_bf16 fragment per tap tile.  MFMA k index 8*lg + e stands
     // for dim (e < 4 ? 4*lg + e : 16 + 4*lg + e - 4), so that the B fragment is exactly this lane's dpre registers.
-    const bool use16 = a.bf16 != 0;
+    // (a.bf16 == 2, round 6, the 'bf16x3' mode: ONLY the recompute of the location conv above runs in its split-bf16 form -- an
+    // f32-class product, ~2^-17 per term, what that mode's forward uses -- the two gradient products here stay exact f32)
+    const bool use16 = a.bf16 == 1;
     // Row stride of dpre_s.  f32 products: 48 (the dU A-fragment reads of the four lane groups, rows lg + 4j, land on four disjoint
     // 16-bank windows).  bf16 products read rows 8 lg + e instead (8 x 48 = 0 mod 64: all four lane groups on the SAME 16 banks,
     // 4-way) and the tile loop's float4 stores of 16 consecutive rows hit 4 distinct bank groups (4-way): a stride of 36 makes the

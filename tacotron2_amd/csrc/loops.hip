@@ -171,7 +171,7 @@ extern "C" int t2amd_decoder_train_fwd_loop_f32(const t2amd_dec_train* p, void* 
         at.q_out = p->Q + (long long)t * B * T2AMD_ATT_DIM; at.ld_q = T2AMD_ATT_DIM;
         if (p->bf16 == 1) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE); at.ld_ctx16 = E; at.loc_split_bf16 = 1; at.memory16 = p->memory16; at.Wq16 = p->Wq16; }
         // bf16x3: the step itself stays exact f32; K_c also writes the split image of the context for the LSTM tiles
-        if (p->bf16 == 3) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE * 2); at.ld_ctx16 = E; at.ctx16_x3 = 1; }
+        if (p->bf16 == 3) { at.ctx16_out = (void*)((unsigned short*)p->CTX16 + t * sE * 2); at.ld_ctx16 = E; at.ctx16_x3 = 1; at.loc_split_bf16 = 1; }
         return t2amd_attention_step_fwd_f32(&at, st);
     };
 
@@ -309,7 +309,9 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.d_pm = p->d_pm; ab.dU_acc = p->dU_acc; ab.dv_acc = p->dv_acc;
         ab.dq_out = p->DQ + (long long)t * B * T2AMD_ATT_DIM; ab.ld_dq = T2AMD_ATT_DIM;
         ab.dh_out = p->dq_h; ab.ld_dh = Ha; ab.dh_split_stride = sHa;
-        ab.bf16 = f.bf16 == 1 ? 1 : 0;            // (bf16x3: the attention backward stays in its exact-f32 form)
+        // (bf16x3: the attention backward stays in its exact-f32 form except the RECOMPUTE of the location conv, which uses the
+        // forward's split-bf16 product: t2amd_attn_bwd.bf16 == 2)
+        ab.bf16 = f.bf16 == 1 ? 1 : (f.bf16 == 3 ? 2 : 0);
         ab.memory16 = f.bf16 == 1 ? f.memory16 : nullptr;
         ab.Wq16 = f.bf16 == 1 ? f.Wq16 : nullptr;
     };

@@ -43,7 +43,7 @@ def _report(name, rows):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", ["tiny_train", "default_train"])
-def test_train_step_matches_reference_and_oracle(native_lib, name, precision="fp32"):
+def test_train_step_matches_reference_and_oracle(native_lib, name, precision):
     """(precision 'bf16x3', round 6: the accurate-fast mode -- split-bf16 LSTM tiles and dense products, everything else the fp32
     mode -- is held to the SAME stated tolerances as the fp32 parity mode: outputs 1e-4 mean, gradients 1e-3 of the tensor's max.)"""
     from tacotron2_amd.loss_function import Tacotron2Loss
