@@ -326,6 +326,7 @@ def compact_line(out):
                    dominant_of="largest total duration among the kernels of the decoder time loops (forward: one persistent launch "
                                "or LSTM pair + attention step; backward: attention backward + dgrad pair), event pairs stamped by the dispatch; "
                                "compared with the event pair's ~1.0 us per-launch constant over rocprofv3's begin/end removed")
+        top["event_pair_us"] = r.get("event_pair_us")
         top["chain"] = {k: kern(v) for k, v in r["chain"].items()}
         top["chain_us_per_time_step"] = _r(r["chain_us_per_time_step"], 2)
         w = r["whole_step"]
@@ -707,7 +708,9 @@ def main():
         # 19.97 vs 19.05) -- nothing for the ONE launch of a persistent loop, 0.9 ms for a kernel launched 870 times, which is what
         # made the persistent forward (17.98 ms by rocprofv3) and the attention backward (16.57 ms) swap places from run to run.
         # The raw event-pair numbers are what is printed for every kernel; only the comparison removes that constant per launch.
-        EVENT_PAIR_US = 1.0
+        # (not a hidden constant any more -- T2AMD_EVENT_PAIR_US overrides it, the value used is printed in the line as
+        # roofline.event_pair_us; it cannot be calibrated at run time because the second clock, rocprofv3's, is not available here)
+        EVENT_PAIR_US = float(os.environ.get("T2AMD_EVENT_PAIR_US", "1.0"))
         for v in chain.values():
             v["total_ms_per_step_profiler_clock"] = v["total_ms_per_step"] - v["launches"] * EVENT_PAIR_US * 1e-3
         dominant = max(chain, key=lambda k: chain[k]["total_ms_per_step_profiler_clock"])
@@ -717,6 +720,7 @@ def main():
                                    "command: profiles/"
                                    % (EVENT_PAIR_US, ", ".join("%s %.1f ms (%.1f)" % (k, v["total_ms_per_step"], v["total_ms_per_step_profiler_clock"])
                                                                for k, v in chain.items())))
+        roofline["event_pair_us"] = EVENT_PAIR_US
         roofline["chain"] = chain
         roofline["chain_us_per_time_step"] = sum(v["us_per_time_step"] for v in chain.values())
         if "lstm_pair" in chain:
