@@ -239,7 +239,11 @@ def inference_leg(dev):
     for name, B, steps, prec, persistent in (("config4_B1_fp32", 1, 1000, "fp32", True), ("config4_B1_bf16", 1, 1000, "bf16", True),
                                              ("config4_B1_bf16_launch_chain", 1, 1000, "bf16", False),
                                              ("config5_B256_bf16", 256, 400, "bf16", True),
-                                             ("config5_B256_bf16_2000", 256, 2000, "bf16", True)):
+                                             ("config5_B256_bf16_2000", 256, 2000, "bf16", True),
+                                             # the two modes that keep gate stops exact on this configuration (tests/test_zz5):
+                                             # the fp32 parity mode and round 6's accurate-fast mode
+                                             ("config5_B256_fp32", 256, 400, "fp32", True),
+                                             ("config5_B256_bf16x3", 256, 400, "bf16x3", True)):
         hp = create_hparams()
         hp.max_decoder_steps = steps
         hp.gate_threshold = 2.0

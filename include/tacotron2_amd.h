@@ -767,6 +767,9 @@ typedef struct t2amd_dec_infer {
      * for B > 8 (MFMA path), of the recurrent operands, written by their producers next to the f32 values; the
      * matrix-vector kernels of B <= 8 read the bf16 weight rows against f32 inputs.  State, gates, attention and
      * outputs stay f32. */
+    /* (3, round 6, B > 8 only: the 'bf16x3' mode -- Wa_cat16 / Wd_cat16 / x_prenet16 / h_a16 / hc16 are SPLIT-bf16 images
+     * (t2amd_split_bf16x3_f32: two bf16 per k), the two LSTM steps run on the wide tile's split form; the optional pointers below
+     * stay NULL: prenet, projection and attention keep their f32 operands) */
     int bf16;
     const void* Wa_cat16;  /* [4Ha][P+E+Ha] bf16 */
     const void* Wd_cat16;  /* [4Hd][Ha+E+Hd] bf16 */

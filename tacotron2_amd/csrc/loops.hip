@@ -535,10 +535,17 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
     T2_REQUIRE(p->W1 && p->W2 && p->Wa_cat && p->bias_a && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->attn_ws &&
                    p->Wpg && p->bias_pg && p->memory && p->pm && p->keep_prenet,
                "dec_infer: null weights/inputs");
+    T2_REQUIRE(p->bf16 == 0 || p->bf16 == 1 || p->bf16 == 3, "dec_infer: bf16 must be 0 (fp32), 1 (bf16) or 3 (split-bf16 x3, B > 8)");
     if (p->bf16 && B > 8) {
-        T2_REQUIRE(p->Wa_cat16 && p->Wd_cat16 && p->x_prenet16 && p->h_a16 && p->hc16, "dec_infer: bf16 mode needs the bf16 buffers");
-        T2_REQUIRE(E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0 && P % 128 == 0, "dec_infer: bf16 mode needs E, Ha, Hd, P multiples of 128");
+        T2_REQUIRE(p->Wa_cat16 && p->Wd_cat16 && p->x_prenet16 && p->h_a16 && p->hc16, "dec_infer: bf16 / bf16x3 mode needs the operand copies");
+        T2_REQUIRE(p->bf16 == 3 || (E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0 && P % 128 == 0), "dec_infer: bf16 mode needs E, Ha, Hd, P multiples of 128");
+        T2_REQUIRE(p->bf16 != 3 || (Ha % 16 == 0 && Hd % 16 == 0), "dec_infer: bf16x3 mode needs Ha, Hd multiples of 16");
     }
+    T2_REQUIRE(p->bf16 != 3 || B > 8, "dec_infer: the bf16x3 operand mode is for B > 8 (the wide tile); B <= 8 runs the fp32 kernels");
+    // round 6, 'bf16x3' mode at B > 8: the two LSTM steps on split-bf16 operand images (4 bytes per k: strides in k as for f32,
+    // pointers into the images advance by 2 bf16 per k); prenet, projection, stop test and attention stay on their f32 forms
+    const bool x3 = p->bf16 == 3;
+    const int us = x3 ? 2 : 1;
     T2_REQUIRE(p->h_a && p->c_a && p->c_d && p->hc && p->cum && p->x_prenet && p->gates && p->zero_frame && p->PG &&
                    p->ALIGN && p->out_lengths && p->active && p->done_count,
                "dec_infer: null state/outputs");
@@ -556,9 +563,9 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         g1.act = 1; g1.keep = p->keep_prenet + ((long long)t * 2 + 0) * sP; g1.ldkeep = P; g1.keep_scale = two;
         const bool small = B <= 8;        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
         const bool use16 = !small && p->bf16 != 0;
-        const bool small16 = small && p->bf16 != 0 && p->Wa_cat16 && p->Wd_cat16;     // bf16 weight rows, f32 inputs
+        const bool small16 = small && p->bf16 == 1 && p->Wa_cat16 && p->Wd_cat16;     // bf16 weight rows, f32 inputs
         // bf16 mode, B > 8: prenet and frame/gate projection on the bf16 MFMA path too (t2amd_dec_infer.Wf16 ...)
-        const bool lin16 = use16 && p->Wf && p->Wf16 && p->Wpg16 && p->W2_16 && p->x_prenet1_16;
+        const bool lin16 = use16 && !x3 && p->Wf && p->Wf16 && p->Wpg16 && p->W2_16 && p->x_prenet1_16;
         t2amd_gemm_desc g2 = {};
         g2.A = p->x_prenet; g2.lda = P; g2.B = p->W2; g2.ldb = P; g2.C = p->x_prenet + sP; g2.ldc = P;
         g2.M = B; g2.N = P; g2.K = P; g2.a_kcontig = 1; g2.b_kcontig = 1; g2.batch = 1; g2.splitk = 1;
@@ -591,9 +598,12 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             s2.W = p->W2; s2.Ktot = P; s2.N = P; s2.B = B;
             s2.Y = p->x_prenet + sP; s2.ldy = P; s2.nsplit = 1;
             s2.act = 1; s2.keep = g2.keep; s2.ld_keep = P; s2.keep_scale = two;
-            if (use16) { s2.Y16 = p->x_prenet16; s2.ldy16 = P; }
+            if (use16 && !x3) { s2.Y16 = p->x_prenet16; s2.ldy16 = P; }
             if (lin16) { s2.x[0].p = (const float*)p->x_prenet1_16; s2.W = (const float*)p->W2_16; s2.bf16 = 1; }
             T2_PROPAGATE(t2amd_skinny_gemm_f32(&s2, stream));
+            // bf16x3: the prenet runs on f32 operands (it stands in front of a ReLU: exact, as in training); the LSTM tile's operand
+            // image of its output is made by one small launch
+            if (x3) T2_PROPAGATE(t2amd_split_bf16x3_f32(p->x_prenet + sP, P, p->x_prenet16, P, B, P, stream));
         }
 
         // attention LSTM on [prenet | ctx_{t-1} | h_att_{t-1}]  (no dropout in eval)
@@ -613,10 +623,10 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
             unsigned short* ha16 = (unsigned short*)p->h_a16;
             unsigned short* hc16 = (unsigned short*)p->hc16;
             a.x[0].p = (const float*)p->x_prenet16;
-            a.x[1].p = (const float*)(hc16 + rd * sHC + Hd);
-            a.x[2].p = (const float*)(ha16 + rd * sHa);
-            a.W = (const float*)p->Wa_cat16; a.bf16 = 1;
-            a.h16_out = (void*)(ha16 + wr * sHa); a.ld_h16 = Ha;
+            a.x[1].p = (const float*)(hc16 + (rd * sHC + Hd) * us);
+            a.x[2].p = (const float*)(ha16 + rd * sHa * us);
+            a.W = (const float*)p->Wa_cat16; a.bf16 = p->bf16;
+            a.h16_out = (void*)(ha16 + wr * sHa * us); a.ld_h16 = Ha;
         }
         if (small16) { a.W = (const float*)p->Wa_cat16; a.bf16 = 2; }
         T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&a, stream) : t2amd_lstm_step_fwd_f32(&a, stream));
@@ -631,7 +641,8 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         at.w_out = p->ALIGN + (long long)t * Ti; at.ld_wout = (long long)p->max_steps * Ti;
         at.ctx_out = p->hc + wr * sHC + Hd; at.ld_ctx = Hd + E;
         at.q_out = nullptr;
-        if (use16) { at.ctx16_out = (void*)((unsigned short*)p->hc16 + wr * sHC + Hd); at.ld_ctx16 = Hd + E; }
+        if (use16) { at.ctx16_out = (void*)((unsigned short*)p->hc16 + (wr * sHC + Hd) * us); at.ld_ctx16 = Hd + E; }
+        if (x3) { at.ctx16_x3 = 1; at.loc_split_bf16 = 1; }      // (the split image of the context; the location conv as in training)
         if (use16 && p->memory16 && p->Wq16) {
             // bf16 compute mode, B > 8: the attention kernels stream bf16 copies of the encoder memory and of W_q and use
             // the split-bf16 location product, as the training loop does (loops.hip above)
@@ -654,11 +665,11 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         if (use16) {
             unsigned short* ha16 = (unsigned short*)p->h_a16;
             unsigned short* hc16 = (unsigned short*)p->hc16;
-            d.x[0].p = (const float*)(ha16 + wr * sHa);
-            d.x[1].p = (const float*)(hc16 + wr * sHC + Hd);
-            d.x[2].p = (const float*)(hc16 + rd * sHC);
-            d.W = (const float*)p->Wd_cat16; d.bf16 = 1;
-            d.h16_out = (void*)(hc16 + wr * sHC); d.ld_h16 = Hd + E;
+            d.x[0].p = (const float*)(ha16 + wr * sHa * us);
+            d.x[1].p = (const float*)(hc16 + (wr * sHC + Hd) * us);
+            d.x[2].p = (const float*)(hc16 + rd * sHC * us);
+            d.W = (const float*)p->Wd_cat16; d.bf16 = p->bf16;
+            d.h16_out = (void*)(hc16 + wr * sHC * us); d.ld_h16 = Hd + E;
         }
         if (small16) { d.W = (const float*)p->Wd_cat16; d.bf16 = 2; }
         T2_PROPAGATE(small ? t2amd_lstm_step_small_f32(&d, stream) : t2amd_lstm_step_fwd_f32(&d, stream));

@@ -2024,6 +2024,22 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         d.bf16 = 1
         for k_, v_ in i16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
+    op16 = run.bf16
+    if run.x3 and B > 8:
+        # 'bf16x3' mode, batched decode (BASELINE configs[4] in the accurate-fast mode): the two LSTM steps multiply split-bf16
+        # operand images on the wide tile (csrc/skinny_wide.h SW_X3) -- weights split once per weight version, h_att / h_dec / ctx
+        # written as images by the tile and K_c epilogues, the prenet output split by a small launch per step; everything else of
+        # the step is the fp32 mode's (prenet, projection and the stop test on f32 operands; attention exact f32 but for its
+        # split-form location conv).  B <= 8 keeps the fp32 mode's kernels (matrix-vector path / persistent single-utterance kernel).
+        i16 = dict(Wa_cat16=run.cached('Wa_cat16x3', [Wih_a, Whh_a], lambda: run.split16(Wa_cat)),
+                   Wd_cat16=run.cached('Wd_cat16x3', [Wih_d, Whh_d], lambda: run.split16(Wd_cat)),
+                   x_prenet16=run.empty16(B, 2 * Pd),
+                   h_a16=torch.zeros(2, B, 2 * Ha, dtype=torch.bfloat16, device=dev),
+                   hc16=torch.zeros(2, B, 2 * (Hd + E), dtype=torch.bfloat16, device=dev))
+        d.bf16 = 3
+        for k_, v_ in i16.items():
+            setattr(d, k_, nv.ptr(v_, torch.bfloat16))
+        op16 = True
     infer_reads = [P['decoder.prenet.layers.0.linear_layer.weight'], P['decoder.prenet.layers.1.linear_layer.weight'],
                    Wa_cat, bias_a, Wd_cat, bias_d, Wq, U, vvec, Wpg, bpg] + ([Wf_, bf_] if B > 8 else [])
     # One utterance: the whole loop as ONE persistent launch, LSTM weights resident on the CUs -- bf16 rows in LDS in the
@@ -2084,7 +2100,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     while t < max_steps and not ran_persistent:
         n = min(poll_steps, max_steps - t)
         d.t0, d.n_steps = t, n
-        nv.decoder_infer_steps(d, reads=infer_reads + [memory, pm, lens32, keep] + (list(i16.values()) if run.bf16 else []),
+        nv.decoder_infer_steps(d, reads=infer_reads + [memory, pm, lens32, keep] + (list(i16.values()) if op16 else []),
                                writes=list(st.values()) + [out_lengths, active, done])
         t += n
         ndone = int(done.item())                # one device->host sync per poll_steps steps
@@ -2123,7 +2139,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
             setattr(d, k_, nv.ptr(v_))
         d.attn_ws_floats = st['attn_ws'].numel()
         d.out_lengths, d.active = nv.ptr(out_lengths, torch.int32), nv.ptr(active, torch.uint8)
-        if run.bf16:
+        if op16:
             i16['x_prenet16'] = i16['x_prenet16'][rows].contiguous()
             if 'x_prenet1_16' in i16:
                 i16['x_prenet1_16'] = i16['x_prenet1_16'][rows].contiguous()

@@ -128,6 +128,23 @@ def test_host_plumbing_validate_only(native_lib, hpstr, in_lens, out_lens, fold,
         native.set_bptt_cell_fold(start)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
+def test_batched_inference_host_plumbing_above_eight_utterances(native_lib, precision):
+    """B > 8 takes the MFMA-tile route of the free-running loop (t2amd_decoder_infer_steps_f32): f32 operands, bf16 copies, or --
+    round 6 -- split-bf16 images for the two LSTM steps ('bf16x3').  Validate-only: every step's descriptors are built and checked."""
+    native.set_validate_only(True)
+    try:
+        hp = create_hparams("max_decoder_steps=5")
+        m = Tacotron2(hp).eval()
+        m.precision = precision
+        lens = [19, 17, 15, 14, 12, 11, 9, 8, 6, 5, 3]
+        text = gu.make_text(lens, 3)
+        o = m.inference(text, torch.tensor(lens))
+        assert o[0].shape[0] == len(lens) and m.last_decode_path.startswith("launch chain")
+    finally:
+        native.set_validate_only(False)
+
+
 def test_attention_workspace_sizes_and_cell_descriptor_checks(native_lib):
     """t2amd_attn_{fwd,bwd}_ws_floats cover every form of the attention step (partial energies / dw slab, token blocks,
     granule blocks at 8-byte-aligned offsets), and the folded-cell descriptors of t2amd_attn_bwd are validated on the
