@@ -19,9 +19,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _step(m, batch, persistent, seed=7, bwd_persistent=None):
-    """One training step; `persistent` selects the forward loop's form.  (`bwd_persistent`: ignored since round 6 -- the backward
-    loop has one form, the launch chain.)"""
+def _step(m, batch, persistent, seed=7):
+    """One training step; `persistent` selects the forward loop's form (the backward loop has one form, the launch chain)."""
     keep = engine.TRAIN_FWD_PERSISTENT
     engine.TRAIN_FWD_PERSISTENT = persistent
     try:
@@ -100,9 +99,9 @@ def _chain_vs_persistent(hp_str, precision, in_lens, out_lens):
     batch = tuple(t.to(DEV) for t in gu.make_train_batch(in_lens, out_lens, hp.n_mel_channels, 5))
     state = {k: v.clone() for k, v in m.state_dict().items()}
     native.attn_handoff_timeouts(reset=True)
-    o0, l0, g0, b0, p0 = _step(m, batch, False, bwd_persistent=False)
+    o0, l0, g0, b0, p0 = _step(m, batch, False)
     m.load_state_dict(state)
-    o1, l1, g1, b1, p1 = _step(m, batch, True, bwd_persistent=False)
+    o1, l1, g1, b1, p1 = _step(m, batch, True)
     assert (p0, p1) == ("launch chain", "persistent") and native.attn_handoff_timeouts(reset=False) == 0
     for i in range(4):
         assert torch.isfinite(o1[i]).all() and torch.equal(o0[i], o1[i]), i
@@ -124,7 +123,7 @@ def test_persistent_train_forward_bf16x3_mode_is_bit_identical_to_its_launch_cha
     o3, l3, g3 = _chain_vs_persistent(hp_str, "bf16x3", in_lens, out_lens)
     m, hp = _model(hp_str, precision="fp32")
     batch = tuple(t.to(DEV) for t in gu.make_train_batch(in_lens, out_lens, hp.n_mel_channels, 5))
-    o0, l0, g0, _, _ = _step(m, batch, True, bwd_persistent=False)
+    o0, l0, g0, _, _ = _step(m, batch, True)
     for i in range(4):
         assert float((o3[i] - o0[i]).abs().mean()) < 2e-5, i
     assert abs(float(l3) - float(l0)) < 1e-5 * abs(float(l0))
