@@ -135,6 +135,32 @@ def test_unsupported_geometries_stay_on_the_chain(native_lib):
     assert _step(m, big, True)[4] == "launch chain" and m.last_paths == ("launch chain", "launch chain")
 
 
+def test_two_row_tiles_on_the_chain_agree_across_the_three_operand_modes(native_lib):
+    """B = 65 (two 64-row tiles of every LSTM / dgrad launch, the second with ONE live row: clamped DMA rows, guarded stores) on the
+    launch chain in all three operand modes: bf16x3 within f32-class distance of fp32 (outputs 2e-5, every gradient 2e-3 relative L2),
+    bf16 within its own tolerance."""
+    lens_in = [9 + (i % 7) for i in range(65)]
+    lens_in.sort(reverse=True)
+    lens_out = [6 + (i * 5) % 11 for i in range(65)]
+    res = {}
+    for prec in ("fp32", "bf16x3", "bf16"):
+        m, hp = _model("", precision=prec)
+        batch = tuple(t.to(DEV) for t in gu.make_train_batch(lens_in, lens_out, hp.n_mel_channels, 3))
+        o, l, g, _, path = _step(m, batch, True)
+        assert path == "launch chain" and all(torch.isfinite(t).all() for t in o) and all(torch.isfinite(v).all() for v in g.values())
+        res[prec] = (o, l, g)
+    (o0, l0, g0), (o3, l3, g3), (o16, l16, g16) = res["fp32"], res["bf16x3"], res["bf16"]
+    for i in range(4):
+        assert float((o3[i] - o0[i]).abs().mean()) < 2e-5, i
+        assert float((o16[i] - o0[i]).abs().mean()) < 3e-2, i
+    assert abs(float(l3) - float(l0)) < 1e-5 * abs(float(l0)) and abs(float(l16) - float(l0)) < 1e-3 * abs(float(l0))
+    for k in g0:
+        if k.endswith('.0.conv.bias'):
+            continue                                              # analytically zero: rounding noise on both sides
+        n0 = float(g0[k].norm())
+        assert float((g3[k] - g0[k]).norm()) < 2e-3 * n0 + 1e-7, k
+
+
 def test_a_give_up_poisons_the_step_and_the_loop_goes_back_to_the_chain(native_lib, monkeypatch):
     """T2AMD_DTP_TIMEOUT_TICKS=0 forces the arrival census to give up (a 1-tick timeout is a race: a small launch can finish
     every wait before its first clock check): status is set, the finishing launch turns the step's data into
