@@ -96,7 +96,9 @@ def prepare_directories_and_logger(output_directory, log_directory, rank):
 
 
 def load_model(hparams):
-    """Build the model on the current GPU (reference train.py:73-81).  ``fp16_run`` -> bf16 compute mode."""
+    """Build the model on the current GPU (reference train.py:73-81).  ``fp16_run`` -> bf16 compute mode.
+    ``T2AMD_PRECISION=fp32|bf16|bf16x3`` in the environment picks the engine's compute mode instead (the reference's
+    hparams have no word for the f32-class 'bf16x3' mode; the variable keeps the 48-field surface unchanged)."""
     model = Tacotron2(hparams)
     if torch.cuda.is_available():
         model = model.cuda()
@@ -105,6 +107,11 @@ def load_model(hparams):
     if hparams.fp16_run:
         model.precision = 'bf16'
         model.decoder.attention_layer.score_mask_value = float(torch.finfo(torch.float16).min)
+    prec = os.environ.get('T2AMD_PRECISION', '')
+    if prec:
+        if prec not in ('fp32', 'bf16', 'bf16x3'):
+            raise native.NativeError("T2AMD_PRECISION must be fp32, bf16 or bf16x3, got %r" % (prec,))
+        model.precision = prec
     if hparams.distributed_run:
         model = apply_gradient_allreduce(model)
     return model

@@ -263,3 +263,22 @@ def test_bucket_launch_order_around_the_backward_loop(native_lib, monkeypatch):
             assert m.last_train_decoder_bwd_path == "launch chain"
     finally:
         native.set_validate_only(False)
+
+
+def test_train_driver_precision_env(native_lib, monkeypatch):
+    """train.load_model: T2AMD_PRECISION picks the compute mode (fp32 / bf16 / bf16x3), anything else is refused; without it
+    fp16_run alone decides, as in the reference (train.py:73-81)."""
+    from tacotron2_amd import train as tr
+    native.set_validate_only(True)
+    try:
+        monkeypatch.delenv("T2AMD_PRECISION", raising=False)
+        assert tr.load_model(create_hparams(gu.TINY_HP)).precision == "fp32"
+        assert tr.load_model(create_hparams(gu.TINY_HP + ",fp16_run=True")).precision == "bf16"
+        for prec in ("fp32", "bf16", "bf16x3"):
+            monkeypatch.setenv("T2AMD_PRECISION", prec)
+            assert tr.load_model(create_hparams(gu.TINY_HP + ",fp16_run=True")).precision == prec
+        monkeypatch.setenv("T2AMD_PRECISION", "fp16")
+        with pytest.raises(native.NativeError, match="T2AMD_PRECISION"):
+            tr.load_model(create_hparams(gu.TINY_HP))
+    finally:
+        native.set_validate_only(False)
