@@ -659,6 +659,15 @@ int t2amd_set_decoder_streams(int n);
  * environment T2AMD_CELL_FOLD, else the library default.  Single-stream loop only (t2amd_set_decoder_streams(1)). */
 int t2amd_set_bptt_cell_fold(int on);
 int t2amd_get_bptt_cell_fold(void);   /* the current value (0 / 1) */
+/* Free-running decoder (t2amd_decoder_infer_steps_f32, reference model.py:418-454): the largest batch served by the matrix-vector
+ * kernels; above it the step runs on the 64-row MFMA tiles, whose cost does not depend on B <= 64.  -1 (default): by operand mode
+ * -- 3 rows with bf16 operands (t2amd_dec_infer.bf16 == 1), 4 otherwise (measured: profiles/r06_s_bench_infer_small_batches.txt);
+ * 0 .. 8: that many rows (the matrix-vector kernels hold at most 8; 0 = tiles at every B).  Start-up value: environment
+ * T2AMD_SMALL_BATCH_MAX.  A caller that sets up t2amd_dec_infer asks t2amd_get_small_batch_max(bf16) for the boundary of its operand
+ * mode to know which operand copies the descriptor needs (bf16 / split-bf16 images and the folded prenet matrix Wf on the tile
+ * path); bf16 == 3 with B at or below the boundary is refused (the split images belong to the tiles: pass 0 there). */
+int t2amd_set_small_batch_max(int n);
+int t2amd_get_small_batch_max(int bf16);
 
 /* Encoder bi-LSTM over [B][T][.] with packed-sequence semantics (reference model.py:180-188).
  * GX [B][T][4H] holds x.W_ih^T + b_ih + b_hh (hoisted dense GEMM) and is overwritten with the
@@ -764,10 +773,10 @@ typedef struct t2amd_dec_infer {
     uint8_t* active;       /* [B] 1 while the utterance is still decoding */
     int* done_count;       /* [1] number of finished utterances */
     /* bf16 operand mode for the two LSTM products (all NULL / 0 for f32): bf16 copies of the packed weights and,
-     * for B > 8 (MFMA path), of the recurrent operands, written by their producers next to the f32 values; the
-     * matrix-vector kernels of B <= 8 read the bf16 weight rows against f32 inputs.  State, gates, attention and
+     * for B > M (MFMA tile path; M = t2amd_get_small_batch_max(bf16): 3 with bf16 operands, 4 otherwise, unless set), of the recurrent operands, written by their producers next to the f32 values; the
+     * matrix-vector kernels of B <= M read the bf16 weight rows against f32 inputs.  State, gates, attention and
      * outputs stay f32. */
-    /* (3, round 6, B > 8 only: the 'bf16x3' mode -- Wa_cat16 / Wd_cat16 / x_prenet16 / h_a16 / hc16 are SPLIT-bf16 images
+    /* (3, round 6, B > M only: the 'bf16x3' mode -- Wa_cat16 / Wd_cat16 / x_prenet16 / h_a16 / hc16 are SPLIT-bf16 images
      * (t2amd_split_bf16x3_f32: two bf16 per k), the two LSTM steps run on the wide tile's split form; the optional pointers below
      * stay NULL: prenet, projection and attention keep their f32 operands) */
     int bf16;
@@ -776,16 +785,16 @@ typedef struct t2amd_dec_infer {
     void* x_prenet16;      /* [B][P] bf16: prenet output of the current step */
     void* h_a16;           /* [2][B][Ha] bf16 ping-pong (zeroed before t0 == 0) */
     void* hc16;            /* [2][B][Hd+E] bf16 ping-pong (zeroed before t0 == 0) */
-    /* B > 8, optional: prenet layer 0 folded through the frame projection, Wf = W1 . Wp [P][Hd+E], bias_f = W1 . bp [P]
+    /* B > M, optional: prenet layer 0 folded through the frame projection, Wf = W1 . Wp [P][Hd+E], bias_f = W1 . bp [P]
      * (p1 = relu(W1 (Wp hc + bp)) = relu(Wf hc + bias_f)): layer 0 of step t+1 then rides in step t's projection launch
      * instead of being a B x 256 x 80 tiled GEMM of its own.  NULL: the unfolded form. */
     const float* Wf;
     const float* bias_f;
-    /* bf16 mode, B > 8, optional: bf16 copies of the encoder memory [B][Ti][E] and of W_q [128][Ha] for the attention
+    /* bf16 mode, B > M, optional: bf16 copies of the encoder memory [B][Ti][E] and of W_q [128][Ha] for the attention
      * kernels (they are bound by those streams); NULL: the f32 arrays are read. */
     const void* memory16;
     const void* Wq16;
-    /* bf16 mode, B > 8, optional (all four or none): bf16 copies of Wf [P][Hd+E], Wpg [C+1][Hd+E] and W2 [P][P] and a
+    /* bf16 mode, B > M, optional (all four or none): bf16 copies of Wf [P][Hd+E], Wpg [C+1][Hd+E] and W2 [P][P] and a
      * [B][P] bf16 buffer for prenet layer 0's output -- the per-step prenet and frame/gate projection then run on the
      * bf16 MFMA path from the bf16 state copies the LSTM / attention kernels already write (f32 accumulation, f32
      * outputs; as the training loop's bf16 mode computes them) */

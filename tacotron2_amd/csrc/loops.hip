@@ -37,6 +37,23 @@ extern "C" int t2amd_set_bptt_cell_fold(int on) {
     return T2AMD_OK;
 }
 extern "C" int t2amd_get_bptt_cell_fold(void) { return g_cell_fold; }
+// ---- free-running decoder: the largest batch served by the matrix-vector kernels (gemv.hip) --------------------------
+// Above it the step runs on the 64-row MFMA tiles (skinny_wide.h), whose cost does not depend on B <= 64.  Measured on MI355X
+// (profiles/r06_s_bench_infer_small_batches.txt, decode steps/s at B = 4 / 5 / 6 / 8): bf16 operands 17.6 k / 13.4 k / 13.3 k /
+// 12.7 k on the matrix-vector kernels against 21.3 k flat on the tiles; f32 operands 16.1 k / 13.2 k / 12.8 k / 12.3 k against
+// 14.5 k flat (split-bf16 tiles 16.0 k flat) -- so the boundary is 3 rows with bf16 operands and 4 otherwise (-1: that rule).
+// T2AMD_SMALL_BATCH_MAX sets the start-up value (-1 .. 8; 0 = the tiles at every B), t2amd_set_small_batch_max() changes it.
+static int g_small_max = [] {
+    const char* e = getenv("T2AMD_SMALL_BATCH_MAX");
+    const int v = e ? atoi(e) : -1;
+    return v < -1 ? -1 : (v > 8 ? 8 : v);
+}();
+extern "C" int t2amd_set_small_batch_max(int n) {
+    T2_REQUIRE(n >= -1 && n <= 8, "set_small_batch_max: -1 (by operand mode) or 0 .. 8 (the matrix-vector kernels hold at most 8 rows)");
+    g_small_max = n;
+    return T2AMD_OK;
+}
+extern "C" int t2amd_get_small_batch_max(int bf16) { return g_small_max >= 0 ? g_small_max : (bf16 == 1 ? 3 : 4); }
 static int side_stream(hipStream_t* out) {
     if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess)
         T2_FAIL("decoder loop: cannot create the side stream");
@@ -535,14 +552,15 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
     T2_REQUIRE(p->W1 && p->W2 && p->Wa_cat && p->bias_a && p->Wd_cat && p->bias_d && p->Wq && p->U && p->v && p->attn_ws &&
                    p->Wpg && p->bias_pg && p->memory && p->pm && p->keep_prenet,
                "dec_infer: null weights/inputs");
-    T2_REQUIRE(p->bf16 == 0 || p->bf16 == 1 || p->bf16 == 3, "dec_infer: bf16 must be 0 (fp32), 1 (bf16) or 3 (split-bf16 x3, B > 8)");
-    if (p->bf16 && B > 8) {
+    T2_REQUIRE(p->bf16 == 0 || p->bf16 == 1 || p->bf16 == 3, "dec_infer: bf16 must be 0 (fp32), 1 (bf16) or 3 (split-bf16 x3, tile path)");
+    const bool small = B <= t2amd_get_small_batch_max(p->bf16);        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
+    if (p->bf16 && !small) {
         T2_REQUIRE(p->Wa_cat16 && p->Wd_cat16 && p->x_prenet16 && p->h_a16 && p->hc16, "dec_infer: bf16 / bf16x3 mode needs the operand copies");
         T2_REQUIRE(p->bf16 == 3 || (E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0 && P % 128 == 0), "dec_infer: bf16 mode needs E, Ha, Hd, P multiples of 128");
         T2_REQUIRE(p->bf16 != 3 || (Ha % 16 == 0 && Hd % 16 == 0), "dec_infer: bf16x3 mode needs Ha, Hd multiples of 16");
     }
-    T2_REQUIRE(p->bf16 != 3 || B > 8, "dec_infer: the bf16x3 operand mode is for B > 8 (the wide tile); B <= 8 runs the fp32 kernels");
-    // round 6, 'bf16x3' mode at B > 8: the two LSTM steps on split-bf16 operand images (4 bytes per k: strides in k as for f32,
+    T2_REQUIRE(p->bf16 != 3 || !small, "dec_infer: the bf16x3 operand mode is for the wide tile (B > t2amd_get_small_batch_max()); the matrix-vector path runs the fp32 kernels");
+    // round 6, 'bf16x3' mode on the tile path: the two LSTM steps on split-bf16 operand images (4 bytes per k: strides in k as for f32,
     // pointers into the images advance by 2 bf16 per k); prenet, projection, stop test and attention stay on their f32 forms
     const bool x3 = p->bf16 == 3;
     const int us = x3 ? 2 : 1;
@@ -561,7 +579,6 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         g1.B = p->W1; g1.ldb = C; g1.C = p->x_prenet; g1.ldc = P;
         g1.M = B; g1.N = P; g1.K = C; g1.a_kcontig = 1; g1.b_kcontig = 1; g1.batch = 1; g1.splitk = 1;
         g1.act = 1; g1.keep = p->keep_prenet + ((long long)t * 2 + 0) * sP; g1.ldkeep = P; g1.keep_scale = two;
-        const bool small = B <= 8;        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
         const bool use16 = !small && p->bf16 != 0;
         const bool small16 = small && p->bf16 == 1 && p->Wa_cat16 && p->Wd_cat16;     // bf16 weight rows, f32 inputs
         // bf16 mode, B > 8: prenet and frame/gate projection on the bf16 MFMA path too (t2amd_dec_infer.Wf16 ...)

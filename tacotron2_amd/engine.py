@@ -1995,19 +1995,22 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     d.out_lengths = nv.ptr(out_lengths, torch.int32)
     d.active = nv.ptr(active, torch.uint8)
     d.done_count = nv.ptr(done, torch.int32)
-    if B > 8:
+    # the launch chain's step: matrix-vector kernels up to nv.small_batch_max() rows, the 64-row MFMA tiles above (csrc/loops.hip)
+    small_max = nv.small_batch_max(1 if run.bf16 else (3 if run.x3 else 0))
+    tiles = B > small_max
+    if tiles:
         Wf_, bf_ = _folded_projection(run, P, hp, Wpg, bpg)     # prenet layer 0 rides in the projection launch
         d.Wf, d.bias_f = nv.ptr(Wf_), nv.ptr(bf_)
 
     if run.bf16:
-        # bf16 operand mode of the two LSTM products: B > 8 reads bf16 weights and bf16 copies of the recurrent
-        # operands (wide MFMA kernel); the matrix-vector path of B <= 8 reads bf16 weight rows against f32 inputs
+        # bf16 operand mode of the two LSTM products: the tile path reads bf16 weights and bf16 copies of the recurrent
+        # operands (wide MFMA kernel); the matrix-vector path reads bf16 weight rows against f32 inputs
         i16 = dict(Wa_cat16=run.cached('Wa_cat16', [Wih_a, Whh_a], lambda: run.cast16(Wa_cat)),
                    Wd_cat16=run.cached('Wd_cat16', [Wih_d, Whh_d], lambda: run.cast16(Wd_cat)),
                    x_prenet16=run.empty16(B, Pd),
                    h_a16=torch.zeros(2, B, Ha, dtype=torch.bfloat16, device=dev),
                    hc16=torch.zeros(2, B, Hd + E, dtype=torch.bfloat16, device=dev))
-        if B > 8:
+        if tiles:
             i16['memory16'] = run.cast16(memory)
             i16['Wq16'] = run.cached('Wq16', [Wq], lambda: run.cast16(Wq))
             # prenet + frame/gate projection on the bf16 MFMA path as well: bf16 images of [W1.Wp ; Wp ; Wg] and of W2
@@ -2025,12 +2028,12 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         for k_, v_ in i16.items():
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
     op16 = run.bf16
-    if run.x3 and B > 8:
+    if run.x3 and tiles:
         # 'bf16x3' mode, batched decode (BASELINE configs[4] in the accurate-fast mode): the two LSTM steps multiply split-bf16
         # operand images on the wide tile (csrc/skinny_wide.h SW_X3) -- weights split once per weight version, h_att / h_dec / ctx
         # written as images by the tile and K_c epilogues, the prenet output split by a small launch per step; everything else of
         # the step is the fp32 mode's (prenet, projection and the stop test on f32 operands; attention exact f32 but for its
-        # split-form location conv).  B <= 8 keeps the fp32 mode's kernels (matrix-vector path / persistent single-utterance kernel).
+        # split-form location conv).  B <= small_max keeps the fp32 mode's kernels (matrix-vector path / persistent single-utterance kernel).
         i16 = dict(Wa_cat16=run.cached('Wa_cat16x3', [Wih_a, Whh_a], lambda: run.split16(Wa_cat)),
                    Wd_cat16=run.cached('Wd_cat16x3', [Wih_d, Whh_d], lambda: run.split16(Wd_cat)),
                    x_prenet16=run.empty16(B, 2 * Pd),
@@ -2041,7 +2044,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
             setattr(d, k_, nv.ptr(v_, torch.bfloat16))
         op16 = True
     infer_reads = [P['decoder.prenet.layers.0.linear_layer.weight'], P['decoder.prenet.layers.1.linear_layer.weight'],
-                   Wa_cat, bias_a, Wd_cat, bias_d, Wq, U, vvec, Wpg, bpg] + ([Wf_, bf_] if B > 8 else [])
+                   Wa_cat, bias_a, Wd_cat, bias_d, Wq, U, vvec, Wpg, bpg] + ([Wf_, bf_] if tiles else [])
     # One utterance: the whole loop as ONE persistent launch, LSTM weights resident on the CUs -- bf16 rows in LDS in the
     # bf16 mode, exact f32 rows split between LDS and registers in the fp32 parity mode (csrc/decode_persist.hip).  Anything it cannot take -- or a timeout because the GPU is shared and H/4 workgroups
     # are not co-resident -- goes through the launch chain below.
@@ -2110,7 +2113,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         if min_rows is not None:
             shrink = ndone >= min_rows
         else:
-            shrink = (left + 63) // 64 < (Bc + 63) // 64 or (Bc > 8 and left <= 8)
+            shrink = (left + 63) // 64 < (Bc + 63) // 64 or (Bc > small_max and left <= small_max)
         if not (COMPACT_BATCH and ragged and t < max_steps and ndone > 0 and shrink) or nv.validate_only():
             continue
         close_segment(t)
@@ -2139,6 +2142,10 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
             setattr(d, k_, nv.ptr(v_))
         d.attn_ws_floats = st['attn_ws'].numel()
         d.out_lengths, d.active = nv.ptr(out_lengths, torch.int32), nv.ptr(active, torch.uint8)
+        if run.x3 and op16 and left <= small_max:
+            # the split operand images belong to the wide tile; the matrix-vector kernels of the rows that are left run the fp32
+            # mode's arithmetic on the f32 state the tiles kept beside the images
+            d.bf16, op16 = 0, False
         if op16:
             i16['x_prenet16'] = i16['x_prenet16'][rows].contiguous()
             if 'x_prenet1_16' in i16:

@@ -277,6 +277,7 @@ SYMBOLS = [
     "t2amd_decoder_train_fwd_persistent_flag_bytes", "t2amd_decoder_train_fwd_persistent_supported", "t2amd_decoder_train_fwd_persistent_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
+    "t2amd_set_small_batch_max", "t2amd_get_small_batch_max",
     "t2amd_set_attn_bwd_granules", "t2amd_attn_handoff_timeouts", "t2amd_set_attn_bwd_fused", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_lstm_seq_persistent_mailbox_bytes", "t2amd_lstm_seq_persistent_supported", "t2amd_lstm_seq_fwd2_persistent_f32",
@@ -357,6 +358,8 @@ def _argtypes():
         "t2amd_set_decoder_streams": [_I],
         "t2amd_set_bptt_cell_fold": [_I],
         "t2amd_get_bptt_cell_fold": [],
+        "t2amd_set_small_batch_max": [_I],
+        "t2amd_get_small_batch_max": [_I],
         "t2amd_attn_bwd_ws_floats": [_I, _I],
         "t2amd_set_attn_bwd_granules": [_I],
         "t2amd_attn_handoff_timeouts": [_I],
@@ -538,6 +541,23 @@ def set_bptt_cell_fold(on):
 
 def get_bptt_cell_fold():
     return int(load().t2amd_get_bptt_cell_fold())
+
+
+def set_small_batch_max(n):
+    """Free-running decoder: the largest batch the matrix-vector kernels serve (0 .. 8; -1 = by operand mode: 3 rows with bf16
+    operands, 4 otherwise); above it the 64-row MFMA tiles."""
+    _check(load().t2amd_set_small_batch_max(int(n)), "t2amd_set_small_batch_max")
+
+
+def small_batch_max(bf16=0):
+    """The boundary in force for operand mode ``bf16`` (t2amd_dec_infer.bf16: 0 f32, 1 bf16, 3 split-bf16)."""
+    return int(load().t2amd_get_small_batch_max(int(bf16)))
+
+
+def small_batch_max_setting():
+    """The raw setting (-1 = by operand mode), for save / restore around a test."""
+    a, b = small_batch_max(0), small_batch_max(1)
+    return -1 if a != b else a
 
 
 def set_validate_only(on):

@@ -282,3 +282,21 @@ def test_train_driver_precision_env(native_lib, monkeypatch):
             tr.load_model(create_hparams(gu.TINY_HP))
     finally:
         native.set_validate_only(False)
+
+
+def test_small_batch_boundary_setting(native_lib):
+    """t2amd_set_small_batch_max: -1 = by operand mode (3 rows with bf16 operands, 4 otherwise), 0 .. 8 = that many rows; anything
+    else is refused.  Pure host state (no GPU)."""
+    old = native.small_batch_max_setting()
+    try:
+        native.set_small_batch_max(-1)
+        assert (native.small_batch_max(0), native.small_batch_max(1), native.small_batch_max(3)) == (4, 3, 4)
+        assert native.small_batch_max_setting() == -1
+        for n in (0, 5, 8):
+            native.set_small_batch_max(n)
+            assert native.small_batch_max(0) == n == native.small_batch_max(1) and native.small_batch_max_setting() == n
+        for bad in (-2, 9):
+            with pytest.raises(native.NativeError, match="small_batch_max"):
+                native.set_small_batch_max(bad)
+    finally:
+        native.set_small_batch_max(old)

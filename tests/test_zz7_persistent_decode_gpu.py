@@ -507,3 +507,77 @@ def test_batched_encoder_bilstm_bptt_persistent_matches_the_launch_chain(native_
         assert float((c - p).abs().max()) < 2e-5 * scale, (d, float((c - p).abs().max()), scale)
         for b in range(B):
             assert float(p[b, int(lens_c[b]):].abs().max()) == 0.0 if int(lens_c[b]) < T else True
+
+
+@pytest.mark.parametrize("B", [6, 12])
+def test_small_batches_on_either_side_of_the_tile_boundary(native_lib, B):
+    """Free-running decode at B = 6 and B = 12, ragged, real gate stops at different frames.  The launch chain serves a batch with
+    the matrix-vector kernels up to t2amd_get_small_batch_max() rows and with the 64-row MFMA tiles above; a batch that shrinks
+    across the boundary is compacted onto the other kernels in mid-sequence (B = 12 -> <= 8 rows with the boundary at 8; in the
+    'bf16x3' mode the rows that are left go on with the fp32 kernels, the split images belong to the tiles).  Every combination
+    must stop every utterance on the oracle's frame (fp32 / bf16x3) and hold the mel bound."""
+    from tacotron2_amd import native as nv
+    steps = 120
+    hp = gu.make_hparams("max_decoder_steps=%d" % steps)
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    in_lens = [97, 83, 77, 64, 58, 51, 45, 38, 33, 27, 21, 15][:B] if B == 12 else [88, 61, 47, 40, 23, 17]
+    text = gu.make_text(in_lens, 9)
+    lens = torch.tensor(in_lens)
+    keep = orc.draw_masks_infer(hp, B, steps, torch.Generator().manual_seed(12))
+    wg = sd['decoder.gate_layer.linear_layer.weight'].clone()
+    wg[:, hp.decoder_rnn_dim:] *= -1.0
+    sd['decoder.gate_layer.linear_layer.weight'] = wg
+    (_, _, ogate, _), _, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, 2.0, input_lengths=lens)
+    sig = torch.sigmoid(ogate.double().reshape(B, steps))
+    best = None
+    for thr_ in torch.linspace(float(sig.min()), float(sig.max()), 600)[1:-1].tolist():
+        over = sig > thr_
+        stop = torch.where(over.any(1), over.float().argmax(1) + 1, torch.full((B,), steps))
+        # at least half of the utterances stop early and at least two keep going 16 steps past the moment B - 8 have stopped
+        early = sorted(int(v) for v in stop.tolist())
+        if early[B // 2] >= steps - 20 or early[0] < 4 or early[-2] < early[max(B - 8, 1)] + 16:
+            continue
+        marg = min(float((sig[b, :int(stop[b])] - thr_).abs().min()) for b in range(B))
+        if best is None or marg > best[0]:
+            best = (marg, thr_, stop.tolist())
+    assert best is not None and best[0] > 2e-4, best
+    marg, thr, want = best
+    hp.gate_threshold = thr
+    (omel, _, _, _), olen, _ = orc.tacotron2_inference(sd, hp, text, keep, steps, thr, input_lengths=lens)
+    assert [int(v) for v in olen.tolist()] == [int(v) for v in want]
+    old = nv.small_batch_max_setting()
+    rows = {}
+    try:
+        for prec in ("fp32", "bf16x3", "bf16"):
+            model = _model(hp, sd, prec)
+            model.dropout_masks = dict(prenet_infer=keep.to(DEV))
+            for small_max in (8, 3):
+                nv.set_small_batch_max(small_max)
+                assert nv.small_batch_max(0) == small_max == nv.small_batch_max(1)
+                with torch.no_grad():
+                    o = model.inference(text.to(DEV), lens.to(DEV))
+                torch.cuda.synchronize()
+                got = model.last_inference_lengths.cpu().tolist()
+                path = model.last_decode_path
+                T = min(o[0].shape[2], omel.shape[2])
+                err = float((o[0].float().cpu()[:, :, :T] - omel[:, :, :T]).abs().max())
+                rows["%s_%d" % (prec, small_max)] = dict(path=path, stops=got, mel_max=err)
+                assert path.startswith('launch chain'), path
+                if B == 12 and small_max == 8:
+                    assert 'compacted' in path, path                      # crossed the boundary in mid-sequence
+                if prec != "bf16":
+                    assert got == [int(v) for v in want], (prec, small_max, got, want)
+                    assert err < 1e-4, (prec, small_max, err)
+                else:
+                    # bf16 operands: the gate noise (~1e-3) is larger than this threshold's margin, so stops may move; the frames
+                    # both runs produced stay within the mode's tolerance
+                    om = o[0].float().cpu()
+                    e16 = max(float((om[b, :, :min(got[b], int(want[b]), T)] - omel[b, :, :min(got[b], int(want[b]), T)]).abs().mean())
+                              for b in range(B))
+                    rows["%s_%d" % (prec, small_max)]["mel_mean_common_frames"] = e16
+                    assert e16 < 2e-2 * max(float(omel.abs().mean()), 1e-3), (got, want, e16)
+                assert all(torch.isfinite(t).all() for t in o)
+    finally:
+        nv.set_small_batch_max(old)
+    with open(os.path.join(OUT, "zz7_tile_boundary_B%d.json" % B), "w") as f:
+        json.dump(dict(threshold=thr, margin=marg, oracle=want, runs=rows), f, indent=1)

@@ -20,7 +20,7 @@ out = {"precision": PREC}
 ONLY = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None      # e.g. --only config5_B256
 CASES = (("config4_B1", 1, 1000), ("B16", 16, 400), ("B64", 64, 400), ("config5_B256", 256, 400))
 if "--small" in sys.argv:        # B = 2 .. 8: the launch chain against consecutive single-utterance persistent decodes
-    CASES = tuple(("B%d" % b, b, 400) for b in (2, 3, 4, 8))
+    CASES = tuple(("B%d" % b, b, 400) for b in (2, 3, 4, 5, 6, 8))
 for name, B, steps in CASES:
     if ONLY and name not in ONLY:
         continue
