@@ -162,8 +162,8 @@ def test_persistent_b1_decoder_is_bit_stable_beside_mfma_waves(nv, precision, ki
 @pytest.mark.parametrize("kind", ["gemm", "mfma_spin"])
 @pytest.mark.parametrize("precision,B", [("bf16", 1), ("bf16", 5), ("fp32", 8)])
 def test_small_batch_launch_chain_is_bit_stable_beside_mfma_waves(nv, precision, B, kind):
-    """gemv.hip + the small-batch attention / loop kernels (loops.hip): B <= 8 inference on the launch chain (the route B = 4...8
-    always takes and B = 1 takes when the persistent kernel is off), repeated beside foreign MFMA waves."""
+    """gemv.hip + the small-batch attention / loop kernels (loops.hip): B <= 8 inference on the matrix-vector launch chain (the route B = 4 took and B = 1
+    takes when the persistent kernel is off; the boundary is set to 8 rows here), repeated beside foreign MFMA waves."""
     import golden_util as gu
     from oracle import tacotron2_oracle as orc
     from tacotron2_amd import engine
@@ -176,6 +176,8 @@ def test_small_batch_launch_chain_is_bit_stable_beside_mfma_waves(nv, precision,
     dist = _Disturb(nv)
     old = (engine.PERSISTENT_DECODE, engine.SMALL_BATCH_PERSISTENT)
     engine.PERSISTENT_DECODE, engine.SMALL_BATCH_PERSISTENT = False, 1
+    old_boundary = nv.small_batch_max_setting()
+    nv.set_small_batch_max(8)                 # the matrix-vector kernels up to 8 rows (the default boundary is 3 / 4 since round 6)
 
     def once(disturb):
         model.dropout_masks = dict(prenet_infer=keep)
@@ -198,6 +200,7 @@ def test_small_batch_launch_chain_is_bit_stable_beside_mfma_waves(nv, precision,
                     bad.setdefault(n, []).append((r, int((a != b).sum())))
         assert not bad, bad
     finally:
+        nv.set_small_batch_max(old_boundary)
         engine.PERSISTENT_DECODE, engine.SMALL_BATCH_PERSISTENT = old
 
 
