@@ -663,11 +663,14 @@ int t2amd_get_bptt_cell_fold(void);   /* the current value (0 / 1) */
  * kernels; above it the step runs on the 64-row MFMA tiles, whose cost does not depend on B <= 64.  -1 (default): by operand mode
  * -- 3 rows with bf16 operands (t2amd_dec_infer.bf16 == 1), 4 otherwise (measured: profiles/r06_s_bench_infer_small_batches.txt);
  * 0 .. 8: that many rows (the matrix-vector kernels hold at most 8; 0 = tiles at every B).  Start-up value: environment
- * T2AMD_SMALL_BATCH_MAX.  A caller that sets up t2amd_dec_infer asks t2amd_get_small_batch_max(bf16) for the boundary of its operand
- * mode to know which operand copies the descriptor needs (bf16 / split-bf16 images and the folded prenet matrix Wf on the tile
+ * T2AMD_SMALL_BATCH_MAX.  A caller that sets up t2amd_dec_infer asks t2amd_dec_infer_uses_tiles (below) to know which operand copies the descriptor needs (bf16 / split-bf16 images and the folded prenet matrix Wf on the tile
  * path); bf16 == 3 with B at or below the boundary is refused (the split images belong to the tiles: pass 0 there). */
 int t2amd_set_small_batch_max(int n);
 int t2amd_get_small_batch_max(int bf16);
+/* 1 when t2amd_decoder_infer_steps_f32 runs a batch of B rows in operand mode `bf16` on the tiles, 0 for the matrix-vector kernels:
+ * B above the boundary -- except that bf16 operands on widths that are not multiples of 128 (which the bf16 tiles refuse) stay on
+ * the matrix-vector kernels up to their limit of 8 rows.  What a caller asks before it fills t2amd_dec_infer. */
+int t2amd_dec_infer_uses_tiles(int B, int bf16, int E, int Ha, int Hd, int P);
 
 /* Encoder bi-LSTM over [B][T][.] with packed-sequence semantics (reference model.py:180-188).
  * GX [B][T][4H] holds x.W_ih^T + b_ih + b_hh (hoisted dense GEMM) and is overwritten with the

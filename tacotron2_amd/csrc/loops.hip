@@ -54,6 +54,13 @@ extern "C" int t2amd_set_small_batch_max(int n) {
     return T2AMD_OK;
 }
 extern "C" int t2amd_get_small_batch_max(int bf16) { return g_small_max >= 0 ? g_small_max : (bf16 == 1 ? 3 : 4); }
+// 1: a batch of B rows in operand mode `bf16` runs on the tiles.  The bf16 tiles need every width to be a multiple of 128; a model
+// that is not keeps the matrix-vector kernels up to their own limit of 8 rows (above that the tile path reports the widths).
+extern "C" int t2amd_dec_infer_uses_tiles(int B, int bf16, int E, int Ha, int Hd, int P) {
+    if (B <= t2amd_get_small_batch_max(bf16)) return 0;
+    if (B <= 8 && bf16 == 1 && (E % 128 || Ha % 128 || Hd % 128 || P % 128)) return 0;
+    return 1;
+}
 static int side_stream(hipStream_t* out) {
     if (!g_side && hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess)
         T2_FAIL("decoder loop: cannot create the side stream");
@@ -553,7 +560,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
                    p->Wpg && p->bias_pg && p->memory && p->pm && p->keep_prenet,
                "dec_infer: null weights/inputs");
     T2_REQUIRE(p->bf16 == 0 || p->bf16 == 1 || p->bf16 == 3, "dec_infer: bf16 must be 0 (fp32), 1 (bf16) or 3 (split-bf16 x3, tile path)");
-    const bool small = B <= t2amd_get_small_batch_max(p->bf16);        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
+    const bool small = !t2amd_dec_infer_uses_tiles(B, p->bf16, E, Ha, Hd, P);        // matrix-vector kernels (gemv.hip) instead of 64-row MFMA tiles
     if (p->bf16 && !small) {
         T2_REQUIRE(p->Wa_cat16 && p->Wd_cat16 && p->x_prenet16 && p->h_a16 && p->hc16, "dec_infer: bf16 / bf16x3 mode needs the operand copies");
         T2_REQUIRE(p->bf16 == 3 || (E % 128 == 0 && Ha % 128 == 0 && Hd % 128 == 0 && P % 128 == 0), "dec_infer: bf16 mode needs E, Ha, Hd, P multiples of 128");

@@ -1996,8 +1996,8 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     d.active = nv.ptr(active, torch.uint8)
     d.done_count = nv.ptr(done, torch.int32)
     # the launch chain's step: matrix-vector kernels up to nv.small_batch_max() rows, the 64-row MFMA tiles above (csrc/loops.hip)
-    small_max = nv.small_batch_max(1 if run.bf16 else (3 if run.x3 else 0))
-    tiles = B > small_max
+    mode16 = 1 if run.bf16 else (3 if run.x3 else 0)
+    tiles = nv.dec_infer_uses_tiles(B, mode16, E, Ha, Hd, Pd)
     if tiles:
         Wf_, bf_ = _folded_projection(run, P, hp, Wpg, bpg)     # prenet layer 0 rides in the projection launch
         d.Wf, d.bias_f = nv.ptr(Wf_), nv.ptr(bf_)
@@ -2033,7 +2033,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         # operand images on the wide tile (csrc/skinny_wide.h SW_X3) -- weights split once per weight version, h_att / h_dec / ctx
         # written as images by the tile and K_c epilogues, the prenet output split by a small launch per step; everything else of
         # the step is the fp32 mode's (prenet, projection and the stop test on f32 operands; attention exact f32 but for its
-        # split-form location conv).  B <= small_max keeps the fp32 mode's kernels (matrix-vector path / persistent single-utterance kernel).
+        # split-form location conv).  Below the tile boundary the fp32 mode's kernels run (matrix-vector path / persistent single-utterance kernel).
         i16 = dict(Wa_cat16=run.cached('Wa_cat16x3', [Wih_a, Whh_a], lambda: run.split16(Wa_cat)),
                    Wd_cat16=run.cached('Wd_cat16x3', [Wih_d, Whh_d], lambda: run.split16(Wd_cat)),
                    x_prenet16=run.empty16(B, 2 * Pd),
@@ -2083,6 +2083,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
     # rows still decoding are gathered into a smaller batch -- state, encoder memory, masks -- and the loop goes on with
     # B' rows; what a segment produced is scattered back to the utterances' own rows of the output arrays.
     t = 0
+    on_tiles = tiles
     Bc = B                                      # rows of the current segment
     cur = None                                  # original utterance of each row (None: identity)
     seg_t0 = 0
@@ -2113,7 +2114,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         if min_rows is not None:
             shrink = ndone >= min_rows
         else:
-            shrink = (left + 63) // 64 < (Bc + 63) // 64 or (Bc > small_max and left <= small_max)
+            shrink = (left + 63) // 64 < (Bc + 63) // 64 or (on_tiles and not nv.dec_infer_uses_tiles(left, mode16, E, Ha, Hd, Pd))
         if not (COMPACT_BATCH and ragged and t < max_steps and ndone > 0 and shrink) or nv.validate_only():
             continue
         close_segment(t)
@@ -2142,7 +2143,8 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
             setattr(d, k_, nv.ptr(v_))
         d.attn_ws_floats = st['attn_ws'].numel()
         d.out_lengths, d.active = nv.ptr(out_lengths, torch.int32), nv.ptr(active, torch.uint8)
-        if run.x3 and op16 and left <= small_max:
+        on_tiles = nv.dec_infer_uses_tiles(left, mode16, E, Ha, Hd, Pd)
+        if run.x3 and op16 and not on_tiles:
             # the split operand images belong to the wide tile; the matrix-vector kernels of the rows that are left run the fp32
             # mode's arithmetic on the f32 state the tiles kept beside the images
             d.bf16, op16 = 0, False

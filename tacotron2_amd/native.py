@@ -277,7 +277,7 @@ SYMBOLS = [
     "t2amd_decoder_train_fwd_persistent_flag_bytes", "t2amd_decoder_train_fwd_persistent_supported", "t2amd_decoder_train_fwd_persistent_f32",
     "t2amd_lstm_seq_fwd_f32", "t2amd_lstm_seq_bwd_f32", "t2amd_decoder_infer_steps_f32",
     "t2amd_set_decoder_streams", "t2amd_set_bptt_cell_fold", "t2amd_get_bptt_cell_fold", "t2amd_attn_bwd_ws_floats",
-    "t2amd_set_small_batch_max", "t2amd_get_small_batch_max",
+    "t2amd_set_small_batch_max", "t2amd_get_small_batch_max", "t2amd_dec_infer_uses_tiles",
     "t2amd_set_attn_bwd_granules", "t2amd_attn_handoff_timeouts", "t2amd_set_attn_bwd_fused", "t2amd_attn_fwd_ws_floats", "t2amd_set_attn_fwd_fused", "t2amd_lstm_step_small_f32", "t2amd_linear_small_f32",
     "t2amd_lstm_seq_fwd2_f32", "t2amd_lstm_seq_bwd2_f32",
     "t2amd_lstm_seq_persistent_mailbox_bytes", "t2amd_lstm_seq_persistent_supported", "t2amd_lstm_seq_fwd2_persistent_f32",
@@ -360,6 +360,7 @@ def _argtypes():
         "t2amd_get_bptt_cell_fold": [],
         "t2amd_set_small_batch_max": [_I],
         "t2amd_get_small_batch_max": [_I],
+        "t2amd_dec_infer_uses_tiles": [_I, _I, _I, _I, _I, _I],
         "t2amd_attn_bwd_ws_floats": [_I, _I],
         "t2amd_set_attn_bwd_granules": [_I],
         "t2amd_attn_handoff_timeouts": [_I],
@@ -552,6 +553,11 @@ def set_small_batch_max(n):
 def small_batch_max(bf16=0):
     """The boundary in force for operand mode ``bf16`` (t2amd_dec_infer.bf16: 0 f32, 1 bf16, 3 split-bf16)."""
     return int(load().t2amd_get_small_batch_max(int(bf16)))
+
+
+def dec_infer_uses_tiles(B, bf16, E, Ha, Hd, P):
+    """True when the free-running decoder's launch chain runs B rows in operand mode ``bf16`` on the 64-row tiles."""
+    return bool(load().t2amd_dec_infer_uses_tiles(int(B), int(bf16), int(E), int(Ha), int(Hd), int(P)))
 
 
 def small_batch_max_setting():

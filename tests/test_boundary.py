@@ -298,5 +298,14 @@ def test_small_batch_boundary_setting(native_lib):
         for bad in (-2, 9):
             with pytest.raises(native.NativeError, match="small_batch_max"):
                 native.set_small_batch_max(bad)
+        # which kernels a batch runs on: above the boundary the tiles -- except bf16 operands on widths the bf16 tiles refuse
+        native.set_small_batch_max(-1)
+        full = (512, 1024, 1024, 256)
+        assert [native.dec_infer_uses_tiles(B, 1, *full) for B in (3, 4, 8, 9)] == [False, True, True, True]
+        assert [native.dec_infer_uses_tiles(B, 0, *full) for B in (4, 5, 9)] == [False, True, True]
+        assert [native.dec_infer_uses_tiles(B, 3, *full) for B in (4, 5)] == [False, True]
+        tiny = (64, 64, 64, 64)
+        assert [native.dec_infer_uses_tiles(B, 1, *tiny) for B in (4, 8, 9)] == [False, False, True]
+        assert [native.dec_infer_uses_tiles(B, 0, *tiny) for B in (4, 5)] == [False, True]
     finally:
         native.set_small_batch_max(old)

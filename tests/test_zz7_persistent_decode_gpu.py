@@ -581,3 +581,29 @@ def test_small_batches_on_either_side_of_the_tile_boundary(native_lib, B):
         nv.set_small_batch_max(old)
     with open(os.path.join(OUT, "zz7_tile_boundary_B%d.json" % B), "w") as f:
         json.dump(dict(threshold=thr, margin=marg, oracle=want, runs=rows), f, indent=1)
+
+
+def test_narrow_model_in_bf16_mode_keeps_the_matrix_vector_kernels_up_to_eight_rows(native_lib):
+    """The bf16 tiles need widths that are multiples of 128; a narrower model (the tiny hparams: 64) decoded in bf16 mode at
+    B = 5 must not be sent to them by the round-6 boundary (3 rows): t2amd_dec_infer_uses_tiles keeps it on the matrix-vector
+    kernels, and the outputs agree with the fp32 mode's to the bf16 tolerance."""
+    steps, B = 24, 5
+    hp = gu.make_hparams(gu.TINY_HP + ",max_decoder_steps=%d" % steps)
+    hp.gate_threshold = 2.0
+    sd = gu.build_state_dict(hp, 1234, perturb_bn=True)
+    in_lens = [19, 16, 12, 9, 7]
+    text = gu.make_text(in_lens, 9)
+    lens = torch.tensor(in_lens)
+    keep = orc.draw_masks_infer(hp, B, steps, torch.Generator().manual_seed(12))
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        model = _model(hp, sd, prec)
+        model.dropout_masks = dict(prenet_infer=keep.to(DEV))
+        with torch.no_grad():
+            o = model.inference(text.to(DEV), lens.to(DEV))
+        torch.cuda.synchronize()
+        assert model.last_decode_path.startswith('launch chain'), model.last_decode_path
+        outs[prec] = o[0].float().cpu()
+        assert torch.isfinite(outs[prec]).all() and outs[prec].shape[2] == steps
+    ref = outs["fp32"]
+    assert float((outs["bf16"] - ref).abs().mean()) < 2e-2 * max(float(ref.abs().mean()), 1e-3)
