@@ -2054,7 +2054,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
         ran_persistent = _decode_persistent(model, run, P, hp, memory, pm, keep, st, out_lengths, Wa_cat, Wd_cat,
                                             bias_a, bias_d, Wq, U, vvec, Wpg, bpg, i16 if run.bf16 else None, Ti)
     elif 2 <= B <= SMALL_BATCH_PERSISTENT and Ha == Hd and PERSISTENT_DECODE and not nv.validate_only():
-        # Two (or three) utterances: the launch chain's matrix-vector step costs ~38 us whatever B <= 8 is, the persistent
+        # Two (or three) utterances: the launch chain's step costs ~38-47 us on either kind of kernel, the persistent
         # kernel 12 us per utterance and step -- so the utterances are decoded ONE AFTER THE OTHER on the persistent kernel,
         # each against its own rows of the encoder memory and of the dropout stream (rows of a batch never interact in
         # Decoder.inference, reference model.py:418-454), and their outputs land in the batch's arrays.
@@ -2079,7 +2079,7 @@ def infer(model, P, bufs, text, input_lengths=None, poll_steps=64):
             out_lengths.zero_()
     # ---- the launch chain, with early-exit compaction of the batch -----------------------------------
     # Finished utterances keep occupying every launch until the slowest one stops.  At a poll, once enough of them
-    # have finished to free a 64-row tile of the LSTM kernels (or to reach the matrix-vector kernels of B <= 8), the
+    # have finished to free a 64-row tile of the LSTM kernels (or to fall below the tile boundary, nv.dec_infer_uses_tiles), the
     # rows still decoding are gathered into a smaller batch -- state, encoder memory, masks -- and the loop goes on with
     # B' rows; what a segment produced is scattered back to the utterances' own rows of the output arrays.
     t = 0
