@@ -190,9 +190,22 @@ int t2amd_bn_act_bwd_f32(float* dy, long long lddy, const float* y, long long ld
                          long long ldx, int M, int N, const float* mean, const float* invstd,
                          const float* gamma, int act, const uint8_t* keep, long long ldkeep,
                          float keep_scale, double* ws, float* dgamma, float* dbeta, void* stream);
+/* The same backward with its two followers folded into stage 2 (round 6; the bf16 mode's convolution backward, reference
+ * layers.py:37-39 + model.py:141-146 under autograd): dx leaves as the bf16 halo image the window products read
+ * (dx_img16: [M/T (T + 2 pad) + 2 pad][N], t2amd_cast_halo_bf16's layout, halo rows zeroed here) and as its column sums
+ * (dbias[N]: the convolution's bias gradient, bit-identical to t2amd_colsum_f32 over dx) -- one pass instead of three over the
+ * slab.  keep_f32 = 0: dy is left holding stage 1's intermediate (no f32 dx is written); 1: dy = dx as above.
+ * Needs N % 4 == 0, 16-byte-aligned rows, M a multiple of T, T >= 2 pad. */
+int t2amd_bn_act_bwd_img_f32(float* dy, long long lddy, const float* y, long long ldy, const float* x, long long ldx, int M, int N,
+                             const float* mean, const float* invstd, const float* gamma, int act, const uint8_t* keep,
+                             long long ldkeep, float keep_scale, double* ws, float* dgamma, float* dbeta, void* dx_img16, int T,
+                             int pad, float* dbias, int keep_f32, void* stream);
 /* column sums: out[N] (+)= sum_m x[m][n]  (bias gradients). ws >= 64*N doubles */
 int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, double* ws, float* out,
                      int accumulate, void* stream);
+/* The same sums over a bf16 slab x16[M][ldx] (round 6: the LSTM bias gradients of the bf16 mode, reference model.py:352-371 under
+ * autograd, from the gate-gradient slabs the weight-gradient products read).  N, ldx multiples of 8; sums in double. */
+int t2amd_colsum_bf16(const void* x16, long long ldx, int M, int N, double* ws, float* out, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * small data-movement kernels (reference model.py:503 embedding, :296-309 / :326-336

@@ -167,6 +167,59 @@ __global__ void colsum_finalize_kernel(const double* __restrict__ ws, int N, flo
     out[n] = accumulate ? out[n] + (float)s : (float)s;
 }
 
+// Column sums of a bf16 slab (round 6: the LSTM bias gradients of the bf16 mode from the gate-gradient slabs the weight-gradient
+// products already read, half the bytes of the f32 slabs: 2 x 456 MB instead of 2 x 912 MB per training step).  Thread = eight
+// columns (one 16-byte load) x a row lane; sums in double, partition [RB][N] as above.
+__global__ __launch_bounds__(256) void colreduce_partial_bf16_kernel(const unsigned short* __restrict__ x, long long ldx, int M, int N,
+                                                                     double* __restrict__ ws) {
+    constexpr int CL = 8, RL = 32;                       // 8 column lanes x 8 columns = 64 columns; 32 row lanes
+    const int cl = threadIdx.x & (CL - 1), rl = threadIdx.x / CL;
+    const int col0 = blockIdx.x * 64, col = col0 + cl * 8;
+    const int rb = blockIdx.y;
+    __shared__ double s1[RL][64];
+    double a[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+    if (col < N) {
+        auto add = [&](const uint4& v) {
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[2 * j] += (double)__uint_as_float(w[j] << 16);
+                a[2 * j + 1] += (double)__uint_as_float(w[j] & 0xffff0000u);
+            }
+        };
+        const long long step = (long long)RB * RL;
+        long long r = (long long)rb * RL + rl;
+        for (; r + 3 * step < M; r += 4 * step) {
+            const uint4 v0 = *reinterpret_cast<const uint4*>(x + r * ldx + col);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(x + (r + step) * ldx + col);
+            const uint4 v2 = *reinterpret_cast<const uint4*>(x + (r + 2 * step) * ldx + col);
+            const uint4 v3 = *reinterpret_cast<const uint4*>(x + (r + 3 * step) * ldx + col);
+            add(v0); add(v1); add(v2); add(v3);
+        }
+        for (; r < M; r += step) add(*reinterpret_cast<const uint4*>(x + r * ldx + col));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[rl][cl * 8 + j] = a[j];
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < 64 && col0 + c < N) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < RL; ++r) t += s1[r][c];
+        ws[(long long)rb * N + col0 + c] = t;
+    }
+}
+
+extern "C" int t2amd_colsum_bf16(const void* x16, long long ldx, int M, int N, double* ws, float* out, int accumulate, void* stream) {
+    T2_REQUIRE(x16 && ws && out && M > 0 && N > 0, "colsum_bf16: bad args");
+    T2_REQUIRE(N % 8 == 0 && ldx % 8 == 0 && t2_aligned16(x16), "colsum_bf16: N, ldx multiples of 8 and a 16-byte-aligned base");
+    hipStream_t s = (hipStream_t)stream;
+    T2_LAUNCH(colreduce_partial_bf16_kernel, dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, (const unsigned short*)x16, ldx, M, N, ws);
+    T2_LAUNCH(colsum_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, out, accumulate);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
 extern "C" int t2amd_colsum_f32(const float* x, long long ldx, int M, int N, double* ws, float* out,
                                 int accumulate, void* stream) {
     T2_REQUIRE(x && ws && out && M > 0 && N > 0, "colsum: bad args");
@@ -460,6 +513,70 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2_vec_kernel(float* __res
         row(r, *reinterpret_cast<const float4*>(dy + (long long)r * lddy + col), *reinterpret_cast<const float4*>(x + (long long)r * ldx + col));
 }
 
+// Stage 2 with its two followers folded in (round 6, bf16 mode's convolution backward): the BatchNorm-backward output dx leaves as the
+// bf16 halo image the window products read (t2amd_cast_halo_bf16's layout, halo rows zeroed here) and as the column sums that are
+// the convolution's bias gradient (t2amd_colsum_f32's partition and order: row lane rl of row block rb sums rows rb*VRL + rl,
+// + RB*VRL, ... in double, then the row lanes, then the row blocks -- bit-identical to the separate pass), instead of as an f32
+// slab that one kernel re-reads to cast and another to sum.  F32OUT: also keep the f32 slab (a consumer that needs it).
+template <bool F32OUT>
+__global__ __launch_bounds__(256) void bn_act_bwd_stage2_img_kernel(float* __restrict__ dy, long long lddy, const float* __restrict__ x,
+                                                                    long long ldx, int M, int N, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                                    unsigned short* __restrict__ img, int T, int pad, int nb,
+                                                                    double* __restrict__ ws) {
+    const int cl = threadIdx.x & (VCL - 1), rl = threadIdx.x / VCL;
+    const int col0 = blockIdx.x * 64, col = col0 + cl * 4;
+    const int rb = blockIdx.y;
+    __shared__ double s1[VRL][64], s2[1][64];
+    Dbl4 a = {}, q = {};
+    if (col < N) {
+        const float invM = 1.0f / (float)M;
+        const int Tp = T + 2 * pad;
+        float mu[4], is[4], ga[4], dg[4], db[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mu[j] = mean[col + j]; is[j] = invstd[col + j]; ga[j] = gamma[col + j]; dg[j] = dgamma[col + j]; db[j] = dbeta[col + j];
+        }
+        auto row = [&](long long r, const float4& g4, const float4& x4) {
+            const float g[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xhat = (xv[j] - mu[j]) * is[j];
+                o[j] = ga[j] * is[j] * (g[j] - db[j] * invM - xhat * dg[j] * invM);
+                a.v[j] += (double)o[j];
+            }
+            if (F32OUT) *reinterpret_cast<float4*>(dy + r * lddy + col) = make_float4(o[0], o[1], o[2], o[3]);
+            const int b = (int)(r / T), t = (int)(r - (long long)b * T);
+            unsigned short* ib = img + ((long long)b * Tp) * N + col;
+            uint2 v;
+            v.x = (unsigned)t2_f32_to_bf16(o[0]) | ((unsigned)t2_f32_to_bf16(o[1]) << 16);
+            v.y = (unsigned)t2_f32_to_bf16(o[2]) | ((unsigned)t2_f32_to_bf16(o[3]) << 16);
+            *reinterpret_cast<uint2*>(ib + (long long)(pad + t) * N) = v;
+            const uint2 z = make_uint2(0u, 0u);
+            if (t < pad) *reinterpret_cast<uint2*>(ib + (long long)t * N) = z;                               // halo in front of the utterance
+            if (t >= T - pad) *reinterpret_cast<uint2*>(ib + (long long)(t + 2 * pad) * N) = z;               // halo behind it
+            if (b == nb - 1 && t < 2 * pad) *reinterpret_cast<uint2*>(ib + (long long)(Tp + t) * N) = z;      // the 2 pad rows past the image
+        };
+        const long long step = (long long)RB * VRL;
+        long long r = (long long)rb * VRL + rl;
+        for (; r + 3 * step < M; r += 4 * step) {
+            float4 g[4], xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = *reinterpret_cast<const float4*>(dy + (r + j * step) * lddy + col);
+                xv[j] = *reinterpret_cast<const float4*>(x + (r + j * step) * ldx + col);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) row(r + j * step, g[j], xv[j]);
+        }
+        for (; r < M; r += step)
+            row(r, *reinterpret_cast<const float4*>(dy + r * lddy + col), *reinterpret_cast<const float4*>(x + r * ldx + col));
+    }
+    vred_finish(s1, s2, a, q, false, cl, rl, rb, col0, N, ws);
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int N, float* dgamma, float* dbeta) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
@@ -513,6 +630,32 @@ extern "C" int t2amd_bn_act_bwd_f32(float* dy, long long lddy, const float* y, l
     if (blocks > 8192) blocks = 8192;
     T2_LAUNCH(bn_act_bwd_stage2_kernel, dim3(blocks), dim3(256), 0, s, dy, lddy, x, ldx, M, N, mean, invstd,
                        gamma, dgamma, dbeta);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// The same backward with stage 2's output leaving as the bf16 halo image + the bias gradient (see bn_act_bwd_stage2_img_kernel).
+extern "C" int t2amd_bn_act_bwd_img_f32(float* dy, long long lddy, const float* y, long long ldy, const float* x, long long ldx, int M,
+                                        int N, const float* mean, const float* invstd, const float* gamma, int act, const uint8_t* keep,
+                                        long long ldkeep, float keep_scale, double* ws, float* dgamma, float* dbeta, void* dx_img16,
+                                        int T, int pad, float* dbias, int keep_f32, void* stream) {
+    T2_REQUIRE(dy && y && x && mean && invstd && gamma && ws && dgamma && dbeta && dx_img16 && dbias && M > 0 && N > 0, "bn_act_bwd_img: bad args");
+    T2_REQUIRE(T > 0 && pad >= 0 && M % T == 0 && T >= 2 * pad, "bn_act_bwd_img: rows must be whole utterances of T >= 2 pad frames");
+    T2_REQUIRE(vec4_ok(dy, lddy, N) && vec4_ok(y, ldy, N) && vec4_ok(x, ldx, N) && t2_aligned16(mean) && t2_aligned16(invstd) &&
+                   (reinterpret_cast<uintptr_t>(dx_img16) & 7u) == 0 &&
+                   (!keep || (ldkeep % 4 == 0 && (reinterpret_cast<uintptr_t>(keep) & 3u) == 0)),
+               "bn_act_bwd_img: needs N % 4 == 0 and 16-byte-aligned rows (the vector kernels)");
+    hipStream_t s = (hipStream_t)stream;
+    T2_LAUNCH(bn_act_bwd_stage1_vec_kernel, dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, y, ldy, x, ldx, M, N, mean, invstd,
+              act, keep, ldkeep, keep_scale, ws);
+    T2_LAUNCH(bn_bwd_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, dgamma, dbeta);
+    if (keep_f32)
+        T2_LAUNCH((bn_act_bwd_stage2_img_kernel<true>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, x, ldx, M, N, mean, invstd,
+                  gamma, dgamma, dbeta, (unsigned short*)dx_img16, T, pad, M / T, ws);
+    else
+        T2_LAUNCH((bn_act_bwd_stage2_img_kernel<false>), dim3(t2_cdiv(N, 64), RB), dim3(256), 0, s, dy, lddy, x, ldx, M, N, mean, invstd,
+                  gamma, dgamma, dbeta, (unsigned short*)dx_img16, T, pad, M / T, ws);
+    T2_LAUNCH(colsum_finalize_kernel, dim3(t2_cdiv(N, 128)), dim3(128), 0, s, ws, N, dbias, 0);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -289,6 +289,12 @@ def _enc_dgrad_split():
 
 ENC_DGRAD_SPLIT = _enc_dgrad_split()
 
+# bf16 mode: the BatchNorm backward of a convolution layer writes its output as the bf16 halo image + the bias gradient directly
+# (T2AMD_BN_BWD_IMAGE=0: the f32 slab and the two separate passes, for A/B runs and the bit-identity test)
+BN_BWD_IMAGE = os.environ.get('T2AMD_BN_BWD_IMAGE', '1') != '0'
+# bf16 mode: the two LSTM bias gradients as column sums of the bf16 gate-gradient slabs (T2AMD_BIAS_GRAD16=0: of the f32 slabs)
+BIAS_GRAD16 = os.environ.get('T2AMD_BIAS_GRAD16', '1') != '0'
+
 
 def _rg(run, *a, **k):
     return run.gemm(*a, fast=run.gradp, **k)
@@ -705,16 +711,27 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
         dgamma = G('%s.%d.1.weight' % (prefix, i), Co)
         dbeta = G('%s.%d.1.bias' % (prefix, i), Co)
         keep = s['keep']
-        nv.bn_act_bwd(g, s['z'], s['y'], s['mean'], s['invstd'], gamma, s['act'],
-                      keep.view(rows, Co) if keep is not None else None, 2.0, run.ws(Co), dgamma, dbeta)
+        dbias = G('%s.%d.0.conv.bias' % (prefix, i), Co)
+        gimg = None
+        need_dx = i > 0 or first_dx is not None
+        # bf16 mode, both followers of the BatchNorm backward on bf16 images (K-major weight gradient, window data gradient): its
+        # output leaves as that image and as the bias gradient, never as an f32 slab (csrc/elementwise.hip
+        # bn_act_bwd_stage2_img_kernel; bit-identical to the three separate passes)
+        fused = (BN_BWD_IMAGE and _conv_wgrad_kk_ok(run, rows, T, Ci, Co) and (not need_dx or _conv16_ok(run, rows, T, Co, k))
+                 and Co % 4 == 0 and T >= 2 * pad)
+        if fused:
+            gimg = run.empty16((rows // T) * (T + 2 * pad) + 2 * pad, Co)
+            nv.bn_act_bwd_img(g, s['z'], s['y'], s['mean'], s['invstd'], gamma, s['act'],
+                              keep.view(rows, Co) if keep is not None else None, 2.0, run.ws(Co), dgamma, dbeta, gimg, T, pad, dbias)
+        else:
+            nv.bn_act_bwd(g, s['z'], s['y'], s['mean'], s['invstd'], gamma, s['act'],
+                          keep.view(rows, Co) if keep is not None else None, 2.0, run.ws(Co), dgamma, dbeta)
+            run.colsum(g, dbias)
         grads['%s.%d.1.weight' % (prefix, i)] = dgamma
         grads['%s.%d.1.bias' % (prefix, i)] = dbeta
-        dbias = G('%s.%d.0.conv.bias' % (prefix, i), Co)
-        run.colsum(g, dbias)
         grads['%s.%d.0.conv.bias' % (prefix, i)] = dbias
         # weight gradient: dW[co][(tap,ci)] = sum_r g[r][co] * x[r + tap - pad][ci]
         dW = G('%s.%d.0.conv.weight' % (prefix, i), Co, Ci, k)
-        gimg = None
         if _conv_wgrad_kk_ok(run, rows, T, Ci, Co):
             # bf16 mode: ONE K-major product over the two halo images (csrc/gemm16.hip, gemm16_kk): K runs over the image rows
             # (b, t) of pitch T + 2 pad, A = g's image from row `pad` on (zero where t >= T), B[k][(tap, ci)] = x's image
@@ -722,13 +739,14 @@ def _conv_stack_bwd(run, P, grads, prefix, saved, g, T, first_dx=None, first_dx_
             ximg = s.get('ximg')
             if ximg is None:
                 ximg = _halo_image(run, s['x'], T, pad)
-            gimg = _halo_image(run, g, T, pad)
+            if gimg is None:
+                gimg = _halo_image(run, g, T, pad)
             _kk_to(run, dW, gimg[pad:], ximg, (rows // T) * (T + 2 * pad), Co, k * Ci, lda=Co, ldb=Ci, perm=(k, Ci))
         else:
             _rg(run, dW.view(Co, Ci * k), g, s['x'], a_km=True, b_kn=True, convB=(T, Ci, pad), perm=(k, Ci))
         grads['%s.%d.0.conv.weight' % (prefix, i)] = dW
         # data gradient
-        if i > 0 or first_dx is not None:
+        if need_dx:
             if i == 0:
                 dx = first_dx
                 acc = first_dx_accumulate
@@ -1512,7 +1530,11 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         z = run.zeros(4 * Ha, E)
         nv.copy2d(dWih_a[:, Pd:], z)
     db_a = G('decoder.attention_rnn.bias_ih', 4 * Ha)
-    run.colsum(DGA2, db_a)
+    bias16 = use16 and BIAS_GRAD16                          # bf16 mode: the bias gradients from the bf16 slabs the weight gradients read
+    if bias16:
+        nv.colsum16(b16['DGA16'].view(rowsD, 4 * Ha), run.ws(4 * Ha), db_a)
+    else:
+        run.colsum(DGA2, db_a)
     db_a2 = G('decoder.attention_rnn.bias_hh', 4 * Ha)
     nv.copy2d(db_a2.view(1, -1), db_a.view(1, -1))
     g['decoder.attention_rnn.weight_ih'] = dWih_a
@@ -1539,7 +1561,10 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
         else:
             nv.fill(dWhh_d, 0.0)
     db_d = G('decoder.decoder_rnn.bias_ih', 4 * Hd)
-    run.colsum(DGD2, db_d)
+    if bias16:
+        nv.colsum16(b16['DGD16'].view(rowsD, 4 * Hd), run.ws(4 * Hd), db_d)
+    else:
+        run.colsum(DGD2, db_d)
     db_d2 = G('decoder.decoder_rnn.bias_hh', 4 * Hd)
     nv.copy2d(db_d2.view(1, -1), db_d.view(1, -1))
     g['decoder.decoder_rnn.weight_ih'] = dWih_d

@@ -263,7 +263,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 SYMBOLS = [
     "t2amd_abi_version", "t2amd_source_sha1", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
     "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_splitk_reduce2d_f32", "t2amd_gemm16_tn", "t2amd_gemm16_kk", "t2amd_gemm16_kk_group", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16", "t2amd_pack_conv_bf16",
-    "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32",
+    "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32", "t2amd_bn_act_bwd_img_f32", "t2amd_colsum_bf16",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
     "t2amd_copy2d_f32", "t2amd_cast_bf16_f32", "t2amd_split_bf16x3_f32", "t2amd_transpose_f32", "t2amd_frames_to_time_major_f32",
@@ -309,7 +309,9 @@ def _argtypes():
         "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
         "t2amd_bn_act_fwd_f32": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _L, _F, _P, _I, _P],
         "t2amd_bn_act_bwd_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P, _P, _P, _I, _P, _L, _F, _P, _P, _P, _P],
+        "t2amd_bn_act_bwd_img_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P, _P, _P, _I, _P, _L, _F, _P, _P, _P, _P, _I, _I, _P, _I, _P],
         "t2amd_colsum_f32": [_P, _L, _I, _I, _P, _P, _I, _P],
+        "t2amd_colsum_bf16": [_P, _L, _I, _I, _P, _P, _I, _P],
         "t2amd_embedding_fwd_f32": [_P, _P, _P, _L, _I, _I, _P],
         "t2amd_embedding_bwd_f32": [_P, _P, _P, _P, _L, _I, _I, _P],
         "t2amd_philox_keep_mask": [_P, _L, _F, _UL, _UL, _P],
@@ -902,12 +904,40 @@ def bn_act_bwd(dy, y, x, mean, invstd, gamma, act, keep, keep_scale, ws, dgamma,
            "t2amd_bn_act_bwd_f32")
 
 
+def bn_act_bwd_img(dy, y, x, mean, invstd, gamma, act, keep, keep_scale, ws, dgamma, dbeta, dx_img, T, pad, dbias, keep_f32=False):
+    """bn_act_bwd with stage 2's output leaving as the bf16 halo image ``dx_img`` ([M/T (T + 2 pad) + 2 pad][N]) and as the bias
+    gradient ``dbias`` [N] (t2amd_bn_act_bwd_img_f32); ``keep_f32``: also as the f32 slab in ``dy``."""
+    lib = load()
+    pd, ldd, M, N = _mat(dy)
+    py, ldy, _, _ = _mat(y)
+    px, ldx, _, _ = _mat(x)
+    pk, ldk = (None, 0)
+    if keep is not None:
+        assert tuple(keep.shape) == (M, N) and keep.stride(1) == 1
+        pk, ldk = ptr(keep, torch.uint8), keep.stride(0)
+    assert dx_img.is_contiguous() and dx_img.dtype == torch.bfloat16 and tuple(dx_img.shape) == ((M // T) * (T + 2 * pad) + 2 * pad, N)
+    assert dbias.numel() == N
+    _check(lib.t2amd_bn_act_bwd_img_f32(pd, _i64(ldd), py, _i64(ldy), px, _i64(ldx), M, N, ptr(mean), ptr(invstd),
+                                        ptr(gamma), act, pk, _i64(ldk), C.c_float(keep_scale),
+                                        ptr(ws, torch.float64), ptr(dgamma), ptr(dbeta), ptr(dx_img, torch.bfloat16), int(T), int(pad),
+                                        ptr(dbias), 1 if keep_f32 else 0, _stream()),
+           "t2amd_bn_act_bwd_img_f32")
+
+
 def colsum(x, ws, out, accumulate=False):
     lib = load()
     px, ldx, M, N = _mat(x)
     assert out.numel() == N
     _check(lib.t2amd_colsum_f32(px, _i64(ldx), M, N, ptr(ws, torch.float64), ptr(out), 1 if accumulate else 0,
                                 _stream()), "t2amd_colsum_f32")
+
+
+def colsum16(x16, ws, out, accumulate=False):
+    """Column sums of a bf16 slab [M][N] (row stride in elements) into f32 ``out`` [N]."""
+    lib = load()
+    assert x16.dtype == torch.bfloat16 and x16.dim() == 2 and x16.stride(1) == 1 and out.numel() == x16.shape[1]
+    _check(lib.t2amd_colsum_bf16(ptr(x16, torch.bfloat16), _i64(x16.stride(0)), x16.shape[0], x16.shape[1], ptr(ws, torch.float64),
+                                 ptr(out), 1 if accumulate else 0, _stream()), "t2amd_colsum_bf16")
 
 
 def embedding_fwd(ids, table, out):

@@ -232,6 +232,60 @@ def test_bn_act_forward_backward(nv, act):
     assert err(yd, ref) < 1e-5
 
 
+@pytest.mark.parametrize("act,N,B,T,pad,keep_f32", [(2, 512, 5, 203, 2, False), (1, 80, 3, 97, 2, True), (0, 128, 4, 64, 0, False),
+                                                     (2, 64, 2, 4, 2, False)])
+def test_bn_backward_writing_the_halo_image_and_the_bias_gradient(nv, act, N, B, T, pad, keep_f32):
+    """t2amd_bn_act_bwd_img_f32 (round 6): stage 2 of the BatchNorm backward writes its output as the bf16 halo image the window
+    products read and as the convolution's bias gradient.  Must be the same BITS as the three separate passes
+    (bn_act_bwd -> cast_halo_bf16, colsum), halo rows zeroed in an image that starts out full of NaNs; with keep_f32 the f32
+    slab as well."""
+    M = B * T
+    x = dv(rnd(M, N, seed=60) * 1.3 + 0.2)
+    gamma, beta = dv(0.5 + torch.rand(N, generator=G(61))), dv(rnd(N, seed=62))
+    keep = dv((torch.rand(M, N, generator=G(63)) >= 0.5).to(torch.uint8))
+    gy = dv(rnd(M, N, seed=64))
+    ws = torch.empty(2 * 64 * N, dtype=torch.float64, device=DEV)
+    mean, invstd = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    nv.bn_stats(x, ws, mean, invstd)
+    y = torch.empty(M, N, device=DEV)
+    nv.bn_act_fwd(x, y, mean, invstd, gamma, beta, act, keep, 2.0)
+    # the three separate passes
+    g = gy.clone()
+    dgamma, dbeta, dbias = (torch.empty(N, device=DEV) for _ in range(3))
+    nv.bn_act_bwd(g, y, x, mean, invstd, gamma, act, keep, 2.0, ws, dgamma, dbeta)
+    nv.colsum(g, ws, dbias)
+    img = torch.empty(B * (T + 2 * pad) + 2 * pad, N, dtype=torch.bfloat16, device=DEV)
+    nv.cast_halo_bf16(g, img, T, pad)
+    # the folded form
+    g2 = gy.clone()
+    dgamma2, dbeta2, dbias2 = (torch.empty(N, device=DEV) for _ in range(3))
+    img2 = torch.full_like(img, float('nan'))
+    nv.bn_act_bwd_img(g2, y, x, mean, invstd, gamma, act, keep, 2.0, ws, dgamma2, dbeta2, img2, T, pad, dbias2, keep_f32=keep_f32)
+    torch.cuda.synchronize()
+    assert torch.equal(dgamma, dgamma2) and torch.equal(dbeta, dbeta2)
+    assert torch.equal(img.view(torch.int16), img2.view(torch.int16))
+    assert torch.equal(dbias, dbias2)
+    if keep_f32:
+        assert torch.equal(g, g2)
+    with pytest.raises(nv.NativeError):                           # rows that are not whole utterances
+        nv.bn_act_bwd_img(g2[:-1], y[:-1], x[:-1], mean, invstd, gamma, act, keep[:-1], 2.0, ws, dgamma2, dbeta2,
+                          torch.empty(((M - 1) // T) * (T + 2 * pad) + 2 * pad, N, dtype=torch.bfloat16, device=DEV), T, pad, dbias2)
+
+
+@pytest.mark.parametrize("M,N", [(55680, 4096), (1031, 64), (7, 8)])
+def test_column_sums_of_a_bf16_slab(nv, M, N):
+    """t2amd_colsum_bf16: the bf16 mode's LSTM bias gradients come from the bf16 gate-gradient slabs (half the bytes of the f32
+    ones).  Against the fp64 sum of the same bf16 values; accumulate adds to what is there."""
+    x = (torch.randn(M, N + 8, generator=G(70)) * 0.3).to(torch.bfloat16).to(DEV)[:, :N]       # a row stride above N
+    ws = torch.empty(2 * 64 * N, dtype=torch.float64, device=DEV)
+    out = torch.empty(N, device=DEV)
+    nv.colsum16(x, ws, out)
+    ref = x.double().sum(0)
+    assert float((out.double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-9
+    nv.colsum16(x, ws, out, accumulate=True)
+    assert float((out.double() - 2 * ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-9
+
+
 @pytest.mark.parametrize("act,N", [(2, 512), (1, 80), (0, 132)])
 def test_bn_16_byte_forms_equal_the_scalar_kernels(nv, act, N):
     """The BatchNorm apply / backward and the column reductions take a 16-byte path when N % 4 == 0 and every base is 16-byte

@@ -357,6 +357,59 @@ def test_weight_gradient_routes_agree_including_the_masked_postnet_input(native_
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
 
 
+def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_passes(native_lib):
+    """bf16 mode, round 6: (i) the BatchNorm backward of a convolution layer writes the bf16 halo image and the bias gradient
+    itself (engine.BN_BWD_IMAGE; no f32 slab, no cast pass, no column-sum pass) -- every gradient of the step must be the same
+    BITS as with the three separate passes; (ii) the two LSTM bias gradients are column sums of the bf16 gate-gradient slabs
+    (engine.BIAS_GRAD16) -- only those four tensors may move, by bf16 rounding of the addends."""
+    from tacotron2_amd import engine
+    from tacotron2_amd.loss_function import Tacotron2Loss
+    from tacotron2_amd.model import Tacotron2
+    from tacotron2_amd.synth import synth_batch
+    dev = torch.device("cuda", 0)
+    hp = create_hparams()
+    hp.batch_size = 24
+    torch.manual_seed(hp.seed)
+    model = Tacotron2(hp).to(dev)
+    model.precision = "bf16"
+    model.train()
+    criterion = Tacotron2Loss()
+    batch = tuple(t.to(dev) for t in synth_batch(24, 4321))
+    assert batch[2].shape[2] * 24 >= 4096 and batch[0].shape[1] * 24 >= 4096      # window / K-major routes in postnet AND encoder
+    start = (engine.BN_BWD_IMAGE, engine.BIAS_GRAD16)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def grads_of(img, b16):
+        engine.BN_BWD_IMAGE, engine.BIAS_GRAD16 = img, b16
+        model.load_state_dict(sd)
+        torch.manual_seed(5)
+        model.zero_grad()
+        x, y = model.parse_batch(batch)
+        loss = criterion(model(x), y)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.item()), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    try:
+        l_sep, g_sep = grads_of(False, False)
+        l_img, g_img = grads_of(True, False)
+        l_all, g_all = grads_of(True, True)
+    finally:
+        engine.BN_BWD_IMAGE, engine.BIAS_GRAD16 = start
+    assert l_sep == l_img == l_all
+    diff = [k for k in g_sep if not torch.equal(g_sep[k], g_img[k])]
+    assert not diff, diff                                          # (i) bit-identical, every tensor
+    lstm_bias = {'decoder.attention_rnn.bias_ih', 'decoder.attention_rnn.bias_hh', 'decoder.decoder_rnn.bias_ih',
+                 'decoder.decoder_rnn.bias_hh'}
+    moved = {k for k in g_sep if not torch.equal(g_sep[k], g_all[k])}
+    assert moved <= lstm_bias, moved - lstm_bias                   # (ii) nothing else changes
+    for k in lstm_bias:
+        rel = float((g_all[k] - g_sep[k]).abs().max() / g_sep[k].abs().max())
+        assert rel < 2e-3, (k, rel)
+        cos = float(torch.nn.functional.cosine_similarity(g_all[k].double().view(1, -1), g_sep[k].double().view(1, -1)))
+        assert cos > 0.999999, (k, cos)
+
+
 def test_encoder_launch_give_up_poisons_the_step_and_is_reported(native_lib, capfd):
     """The training step does not read the persistent encoder launch's status back (a host sync per step); a give-up is
     turned into a NaN in the step's data by a one-thread launch behind the kernel and counted in the library.  Here that

@@ -27,3 +27,18 @@ print(' bn_stats  %.1f us'%t(lambda: nv.bn_stats(x,ws,mean,invstd)))
 print(' bn_act_fwd %.1f us'%t(lambda: nv.bn_act_fwd(x,y,mean,invstd,gamma,beta,2,keep,2.0)))
 print(' bn_act_bwd %.1f us'%t(lambda: nv.bn_act_bwd(gy,y,x,mean,invstd,gamma,2,keep,2.0,ws,dg,db)))
 print(' colsum    %.1f us'%t(lambda: nv.colsum(x,ws,cs)))
+# round 6: the backward with its two followers (bias column sum, bf16 halo image) as three passes and folded into stage 2
+B_, T_, pad = 64, 870, 2
+img = torch.empty(B_ * (T_ + 2 * pad) + 2 * pad, N, dtype=torch.bfloat16, device=dev)
+def separate():
+    nv.bn_act_bwd(gy, y, x, mean, invstd, gamma, 2, keep, 2.0, ws, dg, db)
+    nv.colsum(gy, ws, cs)
+    nv.cast_halo_bf16(gy, img, T_, pad)
+print(' bn_act_bwd + colsum + cast_halo  %.1f us' % t(separate))
+print(' bn_act_bwd_img                   %.1f us' % t(lambda: nv.bn_act_bwd_img(gy, y, x, mean, invstd, gamma, 2, keep, 2.0, ws, dg, db, img, T_, pad, cs)))
+print(' bn_act_bwd_img (keeps f32)       %.1f us' % t(lambda: nv.bn_act_bwd_img(gy, y, x, mean, invstd, gamma, 2, keep, 2.0, ws, dg, db, img, T_, pad, cs, keep_f32=True)))
+print(' cast_halo alone                  %.1f us' % t(lambda: nv.cast_halo_bf16(gy, img, T_, pad)))
+x16 = torch.randn(M, 4096, device=dev).to(torch.bfloat16); x32 = x16.float(); c4 = torch.empty(4096, device=dev)
+ws4 = torch.empty(2 * 64 * 4096, dtype=torch.float64, device=dev)
+print(' colsum f32 55680 x 4096          %.1f us' % t(lambda: nv.colsum(x32, ws4, c4)))
+print(' colsum bf16 55680 x 4096         %.1f us' % t(lambda: nv.colsum16(x16, ws4, c4)))
