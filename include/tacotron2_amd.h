@@ -183,6 +183,12 @@ int t2amd_bn_act_fwd_f32(const float* x, long long ldx, float* y, long long ldy,
                          const float* mean, const float* invstd, const float* gamma,
                          const float* beta, int act, const uint8_t* keep, long long ldkeep,
                          float keep_scale, const int* lens, int row_valid_T, void* stream);
+/* The same, with y leaving ALSO as the bf16 halo image the next convolution's window product reads (round 6; y_img16:
+ * [M/T (T + 2 pad) + 2 pad][N], t2amd_cast_halo_bf16's layout, halo rows zeroed here; same bits as the cast pass over y).
+ * Needs N % 4 == 0, 16-byte-aligned rows, M a multiple of T, T >= 2 pad. */
+int t2amd_bn_act_fwd_img_f32(const float* x, long long ldx, float* y, long long ldy, int M, int N, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, int act, const uint8_t* keep,
+                             long long ldkeep, float keep_scale, void* y_img16, int T, int pad, void* stream);
 /* backward of the above (train mode).  dy is overwritten with dx (grad wrt the conv output x).
  * y = forward output (post activation/dropout).  dgamma/dbeta are written (not accumulated).
  * ws: >= 2*64*N doubles. */

@@ -2908,13 +2908,12 @@ extern "C" int t2amd_fold_location_f32(const float* wdense, const float* wconv, 
     return T2AMD_OK;
 }
 
-__global__ void unfold_location_kernel(const float* __restrict__ dU_acc, const float* __restrict__ dv_acc,
-                                       int nb, const float* __restrict__ wd, const float* __restrict__ wc,
-                                       float* __restrict__ dwd, float* __restrict__ dwc, float* __restrict__ dv,
-                                       float* __restrict__ dUsum) {
-    // single workgroup: first reduce dU over utterances, then the two small products
-    const int tid = threadIdx.x;
-    for (int i = tid; i < AD * NTAP; i += blockDim.x) {
+// Two launches (round 6; one workgroup did all of it in 98 us per training step): (1) dU and dv summed over the utterances, one thread
+// per element, same add order as before; (2) the two small products, one thread per output, the same fmaf chains -- same bits.
+__global__ __launch_bounds__(256) void unfold_location_reduce_kernel(const float* __restrict__ dU_acc, const float* __restrict__ dv_acc,
+                                                                     int nb, float* __restrict__ dv, float* __restrict__ dUsum) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < AD * NTAP) {
         // utterances eight at a time, loads first (a plain loop is one waited load per utterance); same add order
         float s = 0.f;
         int b = 0;
@@ -2926,25 +2925,29 @@ __global__ void unfold_location_kernel(const float* __restrict__ dU_acc, const f
             for (int j = 0; j < 8; ++j) s += v[j];
         }
         for (; b < nb; ++b) s += dU_acc[(long long)b * AD * NTAP + i];
-        dUsum[i] = s;
-    }
-    for (int i = tid; i < AD; i += blockDim.x) {
+        dUsum[i] = s;                  // may alias dU_acc's slot 0: this thread alone reads and writes element i
+    } else if (i < AD * NTAP + AD) {
+        const int d = i - AD * NTAP;
         float s = 0.f;
-        for (int b = 0; b < nb; ++b) s += dv_acc[(long long)b * AD + i];
-        dv[i] = s;
+        for (int b = 0; b < nb; ++b) s += dv_acc[(long long)b * AD + d];
+        dv[d] = s;
     }
-    __syncthreads();
-    for (int i = tid; i < AD * T2AMD_LOC_FILTERS; i += blockDim.x) {
+}
+__global__ __launch_bounds__(256) void unfold_location_products_kernel(const float* __restrict__ dUsum, const float* __restrict__ wd,
+                                                                       const float* __restrict__ wc, float* __restrict__ dwd,
+                                                                       float* __restrict__ dwc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < AD * T2AMD_LOC_FILTERS) {
         const int d = i / T2AMD_LOC_FILTERS, f = i - d * T2AMD_LOC_FILTERS;
         float s = 0.f;
         for (int ck = 0; ck < NTAP; ++ck) s = fmaf(dUsum[d * NTAP + ck], wc[f * NTAP + ck], s);
         dwd[i] = s;
-    }
-    for (int i = tid; i < T2AMD_LOC_FILTERS * NTAP; i += blockDim.x) {
-        const int f = i / NTAP, ck = i - f * NTAP;
+    } else if (i < AD * T2AMD_LOC_FILTERS + T2AMD_LOC_FILTERS * NTAP) {
+        const int o = i - AD * T2AMD_LOC_FILTERS;
+        const int f = o / NTAP, ck = o - f * NTAP;
         float s = 0.f;
         for (int d = 0; d < AD; ++d) s = fmaf(wd[d * T2AMD_LOC_FILTERS + f], dUsum[d * NTAP + ck], s);
-        dwc[i] = s;
+        dwc[o] = s;
     }
 }
 
@@ -2954,8 +2957,11 @@ extern "C" int t2amd_unfold_location_grads_f32(const float* dU_acc, const float*
     T2_REQUIRE(dU_acc && dv_acc && nb > 0 && wdense && wconv && dwdense && dwconv && dv, "unfold_location: bad args");
     // dU_acc[0] is reused as the reduction target after its own contribution has been read:
     // write the sum into slot 0 (the caller treats dU_acc as scratch after this call).
-    T2_LAUNCH(unfold_location_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dU_acc, dv_acc, nb,
-                       wdense, wconv, dwdense, dwconv, dv, const_cast<float*>(dU_acc));
+    float* dUsum = const_cast<float*>(dU_acc);
+    T2_LAUNCH(unfold_location_reduce_kernel, dim3(t2_cdiv(AD * NTAP + AD, 256)), dim3(256), 0, (hipStream_t)stream, dU_acc, dv_acc, nb,
+              dv, dUsum);
+    T2_LAUNCH(unfold_location_products_kernel, dim3(t2_cdiv(AD * T2AMD_LOC_FILTERS + T2AMD_LOC_FILTERS * NTAP, 256)), dim3(256), 0,
+              (hipStream_t)stream, dUsum, wdense, wconv, dwdense, dwconv);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

@@ -261,12 +261,16 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ x, long long ldx, fl
 // 16-byte form: thread = (column lane of four columns, row lane); the per-channel parameters are loaded once per thread, four
 // rows are in flight per thread, and no element pays a 64-bit division (the scalar kernel's i / N).  Same expression per element
 // as above, so the same bits.
+// IMG (round 6): the output also leaves as the bf16 halo image the next convolution's window product reads
+// (t2amd_cast_halo_bf16's layout over utterances of IT rows, halo rows zeroed here) -- the cast pass's re-read of y is gone.
+template <bool IMG>
 __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
                                                              long long ldy, int M, int N, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int act,
                                                              const uint8_t* __restrict__ keep, long long ldkeep, float keep_scale,
-                                                             const int* __restrict__ lens, int T) {
+                                                             const int* __restrict__ lens, int T,
+                                                             unsigned short* __restrict__ img, int IT, int pad, int nb) {
     const int cl = threadIdx.x & (VCL - 1), rl = threadIdx.x / VCL;
     const int col = blockIdx.x * 64 + cl * 4;
     if (col >= N) return;
@@ -292,6 +296,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd_vec_kernel(const float* __rest
         o.z = one(xv.z, mu.z, is.z, ga.z, be.z, (kp >> 16) & 0xffu, dead);
         o.w = one(xv.w, mu.w, is.w, ga.w, be.w, kp >> 24, dead);
         *reinterpret_cast<float4*>(y + (long long)r * ldy + col) = o;
+        if constexpr (IMG) {
+            const int Tp = IT + 2 * pad;
+            const int b = r / IT, t = r - b * IT;
+            unsigned short* ib = img + ((long long)b * Tp) * N + col;
+            uint2 v;
+            v.x = (unsigned)t2_f32_to_bf16(o.x) | ((unsigned)t2_f32_to_bf16(o.y) << 16);
+            v.y = (unsigned)t2_f32_to_bf16(o.z) | ((unsigned)t2_f32_to_bf16(o.w) << 16);
+            *reinterpret_cast<uint2*>(ib + (long long)(pad + t) * N) = v;
+            const uint2 z = make_uint2(0u, 0u);
+            if (t < pad) *reinterpret_cast<uint2*>(ib + (long long)t * N) = z;
+            if (t >= IT - pad) *reinterpret_cast<uint2*>(ib + (long long)(t + 2 * pad) * N) = z;
+            if (b == nb - 1 && t < 2 * pad) *reinterpret_cast<uint2*>(ib + (long long)(Tp + t) * N) = z;
+        }
     };
     int r = blockIdx.y * VRL + rl;
     for (; r + 3 * step < M; r += 4 * step) {
@@ -328,8 +345,8 @@ extern "C" int t2amd_bn_act_fwd_f32(const float* x, long long ldx, float* y, lon
     T2_REQUIRE(!lens || row_valid_T > 0, "bn_act_fwd: lens needs row_valid_T");
     if (!g_ew_scalar && vec4_ok(x, ldx, N) && vec4_ok(y, ldy, N) && t2_aligned16(mean) && t2_aligned16(invstd) && t2_aligned16(gamma) &&
         t2_aligned16(beta) && (!keep || (ldkeep % 4 == 0 && (reinterpret_cast<uintptr_t>(keep) & 3u) == 0))) {
-        T2_LAUNCH(bn_act_fwd_vec_kernel, dim3(t2_cdiv(N, 64), vec_row_blocks(M, N)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
-                  M, N, mean, invstd, gamma, beta, act, keep, ldkeep, keep_scale, lens, row_valid_T);
+        T2_LAUNCH((bn_act_fwd_vec_kernel<false>), dim3(t2_cdiv(N, 64), vec_row_blocks(M, N)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+                  M, N, mean, invstd, gamma, beta, act, keep, ldkeep, keep_scale, lens, row_valid_T, (unsigned short*)nullptr, 0, 0, 0);
         T2_LAUNCH_CHECK();
         return T2AMD_OK;
     }
@@ -337,6 +354,22 @@ extern "C" int t2amd_bn_act_fwd_f32(const float* x, long long ldx, float* y, lon
     if (blocks > 8192) blocks = 8192;
     T2_LAUNCH(bn_act_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, M, N, mean,
                        invstd, gamma, beta, act, keep, ldkeep, keep_scale, lens, row_valid_T);
+    T2_LAUNCH_CHECK();
+    return T2AMD_OK;
+}
+
+// y AND its bf16 halo image in one pass (see bn_act_fwd_vec_kernel<true>); training-mode layers of the bf16 mode's convolution stacks.
+extern "C" int t2amd_bn_act_fwd_img_f32(const float* x, long long ldx, float* y, long long ldy, int M, int N, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int act, const uint8_t* keep,
+                                        long long ldkeep, float keep_scale, void* y_img16, int T, int pad, void* stream) {
+    T2_REQUIRE(x && y && mean && invstd && gamma && beta && y_img16 && M > 0 && N > 0, "bn_act_fwd_img: bad args");
+    T2_REQUIRE(T > 0 && pad >= 0 && M % T == 0 && T >= 2 * pad, "bn_act_fwd_img: rows must be whole utterances of T >= 2 pad frames");
+    T2_REQUIRE(vec4_ok(x, ldx, N) && vec4_ok(y, ldy, N) && t2_aligned16(mean) && t2_aligned16(invstd) && t2_aligned16(gamma) &&
+                   t2_aligned16(beta) && (reinterpret_cast<uintptr_t>(y_img16) & 7u) == 0 &&
+                   (!keep || (ldkeep % 4 == 0 && (reinterpret_cast<uintptr_t>(keep) & 3u) == 0)),
+               "bn_act_fwd_img: needs N % 4 == 0 and 16-byte-aligned rows (the vector kernel)");
+    T2_LAUNCH((bn_act_fwd_vec_kernel<true>), dim3(t2_cdiv(N, 64), vec_row_blocks(M, N)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy,
+              M, N, mean, invstd, gamma, beta, act, keep, ldkeep, keep_scale, (const int*)nullptr, 0, (unsigned short*)y_img16, T, pad, M / T);
     T2_LAUNCH_CHECK();
     return T2AMD_OK;
 }

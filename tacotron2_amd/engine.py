@@ -292,6 +292,7 @@ ENC_DGRAD_SPLIT = _enc_dgrad_split()
 # bf16 mode: the BatchNorm backward of a convolution layer writes its output as the bf16 halo image + the bias gradient directly
 # (T2AMD_BN_BWD_IMAGE=0: the f32 slab and the two separate passes, for A/B runs and the bit-identity test)
 BN_BWD_IMAGE = os.environ.get('T2AMD_BN_BWD_IMAGE', '1') != '0'
+BN_FWD_IMAGE = os.environ.get('T2AMD_BN_FWD_IMAGE', '1') != '0'   # the same fold in the forward: BatchNorm apply writes the next layer's image
 # bf16 mode: the two LSTM bias gradients as column sums of the bf16 gate-gradient slabs (T2AMD_BIAS_GRAD16=0: of the f32 slabs)
 BIAS_GRAD16 = os.environ.get('T2AMD_BIAS_GRAD16', '1') != '0'
 
@@ -639,6 +640,7 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         # same refusal, same exception type as torch.nn.functional.batch_norm under the reference
         raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                          % (torch.Size([1, x.shape[1], 1]),))
+    next_img = None                 # the bf16 halo image of this layer's input, written by the previous layer's BatchNorm apply
     for i in range(n_layers):
         ximg = None
         W = P['%s.%d.0.conv.weight' % (prefix, i)]
@@ -666,7 +668,7 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
         elif _conv16_ok(run, rows, T, Ci, k):
             # bf16 mode: the convolution as a product of sliding windows of a bf16 image with zero halo rows (csrc/gemm16.hip)
             W16 = run.cached('convfwd16.%s.%d' % (prefix, i), [W], lambda W=W: nv.pack_conv_bf16(W))
-            ximg = _halo_image(run, x, T, pad)
+            ximg = next_img if next_img is not None else _halo_image(run, x, T, pad)
             nv.conv16(y, ximg, W16, rows // T, T, pad, bias=bias)
         else:
             _fg(run, y, x, packed(), bias=bias, convA=(T, Ci, pad, 1), exact=exact)
@@ -683,8 +685,20 @@ def _conv_stack_fwd(run, P, bufs, prefix, n_layers, x, T, acts, masks, training,
             nv.bn_eval_invstd(rv, invstd, BN_EPS)
         z = run.empty(rows, Co)
         keep = masks[i] if masks is not None else None
-        nv.bn_act_fwd(y, z, mean, invstd, gamma, beta, acts[i],
-                      keep.view(rows, Co) if keep is not None else None, 2.0, lens, T if lens is not None else 0)
+        next_img = None
+        if BN_FWD_IMAGE and training and lens is None and i + 1 < n_layers and Co % 4 == 0:
+            Wn = P['%s.%d.0.conv.weight' % (prefix, i + 1)]
+            kn = Wn.shape[2]
+            padn = (kn - 1) // 2
+            if _conv16_ok(run, rows, T, Co, kn) and T >= 2 * padn:
+                # the next layer multiplies the bf16 halo image of z: written here, beside z, instead of by a cast pass over z
+                next_img = run.empty16((rows // T) * (T + 2 * padn) + 2 * padn, Co)
+        if next_img is not None:
+            nv.bn_act_fwd_img(y, z, mean, invstd, gamma, beta, acts[i], keep.view(rows, Co) if keep is not None else None, 2.0,
+                              next_img, T, padn)
+        else:
+            nv.bn_act_fwd(y, z, mean, invstd, gamma, beta, acts[i],
+                          keep.view(rows, Co) if keep is not None else None, 2.0, lens, T if lens is not None else 0)
         saved.append(dict(x=x, y=y, z=z, mean=mean, invstd=invstd, keep=keep, W=W, act=acts[i], layer=i,
                           # the weight gradient multiplies the image again -- except the stack's own input: the reference
                           # masks mel_outputs IN PLACE after the postnet has run (model.py:491-495, `.data.masked_fill_`), so

@@ -263,7 +263,7 @@ _STRUCTS = [GemmDesc, Seg, LstmStep, SkinnyGemm, Addend, LstmBwd, AttnFwd, AttnB
 SYMBOLS = [
     "t2amd_abi_version", "t2amd_source_sha1", "t2amd_last_error", "t2amd_struct_sizes", "t2amd_set_validate_only", "t2amd_profile_enable", "t2amd_profile_read", "t2amd_profile_event_overhead",
     "t2amd_gemm_f32", "t2amd_gemm_tile_size", "t2amd_splitk_reduce_f32", "t2amd_splitk_reduce2d_f32", "t2amd_gemm16_tn", "t2amd_gemm16_kk", "t2amd_gemm16_kk_group", "t2amd_transpose_cast_bf16", "t2amd_cast_halo_bf16", "t2amd_pack_conv_bf16",
-    "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32", "t2amd_bn_act_bwd_img_f32", "t2amd_colsum_bf16",
+    "t2amd_bn_stats_f32", "t2amd_bn_eval_invstd_f32", "t2amd_bn_act_fwd_f32", "t2amd_bn_act_bwd_f32", "t2amd_bn_act_bwd_img_f32", "t2amd_colsum_bf16", "t2amd_bn_act_fwd_img_f32",
     "t2amd_colsum_f32",
     "t2amd_embedding_fwd_f32", "t2amd_embedding_bwd_f32", "t2amd_philox_keep_mask", "t2amd_fill_f32",
     "t2amd_copy2d_f32", "t2amd_cast_bf16_f32", "t2amd_split_bf16x3_f32", "t2amd_transpose_f32", "t2amd_frames_to_time_major_f32",
@@ -308,6 +308,7 @@ def _argtypes():
         "t2amd_bn_stats_f32": [_P, _L, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P],
         "t2amd_bn_eval_invstd_f32": [_P, _P, _I, _F, _P],
         "t2amd_bn_act_fwd_f32": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _L, _F, _P, _I, _P],
+        "t2amd_bn_act_fwd_img_f32": [_P, _L, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _L, _F, _P, _I, _I, _P],
         "t2amd_bn_act_bwd_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P, _P, _P, _I, _P, _L, _F, _P, _P, _P, _P],
         "t2amd_bn_act_bwd_img_f32": [_P, _L, _P, _L, _P, _L, _I, _I, _P, _P, _P, _I, _P, _L, _F, _P, _P, _P, _P, _I, _I, _P, _I, _P],
         "t2amd_colsum_f32": [_P, _L, _I, _I, _P, _P, _I, _P],
@@ -887,6 +888,22 @@ def bn_act_fwd(x, y, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0, 
     _check(lib.t2amd_bn_act_fwd_f32(px, _i64(ldx), py, _i64(ldy), M, N, ptr(mean), ptr(invstd), ptr(gamma),
                                     ptr(beta), act, pk, _i64(ldk), C.c_float(keep_scale),
                                     ptr(lens, torch.int32), T, _stream()), "t2amd_bn_act_fwd_f32")
+
+
+def bn_act_fwd_img(x, y, mean, invstd, gamma, beta, act, keep, keep_scale, y_img, T, pad):
+    """bn_act_fwd with y leaving also as the bf16 halo image ``y_img`` ([M/T (T + 2 pad) + 2 pad][N]) the next convolution reads."""
+    lib = load()
+    px, ldx, M, N = _mat(x)
+    py, ldy, M2, N2 = _mat(y)
+    assert (M, N) == (M2, N2)
+    pk, ldk = (None, 0)
+    if keep is not None:
+        assert tuple(keep.shape) == (M, N) and keep.stride(1) == 1
+        pk, ldk = ptr(keep, torch.uint8), keep.stride(0)
+    assert y_img.is_contiguous() and y_img.dtype == torch.bfloat16 and tuple(y_img.shape) == ((M // T) * (T + 2 * pad) + 2 * pad, N)
+    _check(lib.t2amd_bn_act_fwd_img_f32(px, _i64(ldx), py, _i64(ldy), M, N, ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), act, pk,
+                                        _i64(ldk), C.c_float(keep_scale), ptr(y_img, torch.bfloat16), int(T), int(pad), _stream()),
+           "t2amd_bn_act_fwd_img_f32")
 
 
 def bn_act_bwd(dy, y, x, mean, invstd, gamma, act, keep, keep_scale, ws, dgamma, dbeta):

@@ -249,6 +249,13 @@ def test_bn_backward_writing_the_halo_image_and_the_bias_gradient(nv, act, N, B,
     nv.bn_stats(x, ws, mean, invstd)
     y = torch.empty(M, N, device=DEV)
     nv.bn_act_fwd(x, y, mean, invstd, gamma, beta, act, keep, 2.0)
+    # forward: y and its halo image in one pass == bn_act_fwd, then the cast pass
+    y2 = torch.empty(M, N, device=DEV)
+    yimg = torch.empty(B * (T + 2 * pad) + 2 * pad, N, dtype=torch.bfloat16, device=DEV)
+    nv.cast_halo_bf16(y, yimg, T, pad)
+    yimg2 = torch.full_like(yimg, float('nan'))
+    nv.bn_act_fwd_img(x, y2, mean, invstd, gamma, beta, act, keep, 2.0, yimg2, T, pad)
+    assert torch.equal(y, y2) and torch.equal(yimg.view(torch.int16), yimg2.view(torch.int16))
     # the three separate passes
     g = gy.clone()
     dgamma, dbeta, dbias = (torch.empty(N, device=DEV) for _ in range(3))

@@ -359,8 +359,8 @@ def test_weight_gradient_routes_agree_including_the_masked_postnet_input(native_
 
 def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_passes(native_lib):
     """bf16 mode, round 6: (i) the BatchNorm backward of a convolution layer writes the bf16 halo image and the bias gradient
-    itself (engine.BN_BWD_IMAGE; no f32 slab, no cast pass, no column-sum pass) -- every gradient of the step must be the same
-    BITS as with the three separate passes; (ii) the two LSTM bias gradients are column sums of the bf16 gate-gradient slabs
+    itself (engine.BN_BWD_IMAGE; no f32 slab, no cast pass, no column-sum pass) and the BatchNorm apply of the forward writes the
+    next layer's image (engine.BN_FWD_IMAGE) -- loss and every gradient of the step must be the same BITS as with the separate passes; (ii) the two LSTM bias gradients are column sums of the bf16 gate-gradient slabs
     (engine.BIAS_GRAD16) -- only those four tensors may move, by bf16 rounding of the addends."""
     from tacotron2_amd import engine
     from tacotron2_amd.loss_function import Tacotron2Loss
@@ -376,11 +376,11 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
     criterion = Tacotron2Loss()
     batch = tuple(t.to(dev) for t in synth_batch(24, 4321))
     assert batch[2].shape[2] * 24 >= 4096 and batch[0].shape[1] * 24 >= 4096      # window / K-major routes in postnet AND encoder
-    start = (engine.BN_BWD_IMAGE, engine.BIAS_GRAD16)
+    start = (engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
 
     def grads_of(img, b16):
-        engine.BN_BWD_IMAGE, engine.BIAS_GRAD16 = img, b16
+        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16 = img, img, b16
         model.load_state_dict(sd)
         torch.manual_seed(5)
         model.zero_grad()
@@ -395,7 +395,7 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
         l_img, g_img = grads_of(True, False)
         l_all, g_all = grads_of(True, True)
     finally:
-        engine.BN_BWD_IMAGE, engine.BIAS_GRAD16 = start
+        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16 = start
     assert l_sep == l_img == l_all
     diff = [k for k in g_sep if not torch.equal(g_sep[k], g_img[k])]
     assert not diff, diff                                          # (i) bit-identical, every tensor

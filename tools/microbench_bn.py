@@ -42,3 +42,9 @@ x16 = torch.randn(M, 4096, device=dev).to(torch.bfloat16); x32 = x16.float(); c4
 ws4 = torch.empty(2 * 64 * 4096, dtype=torch.float64, device=dev)
 print(' colsum f32 55680 x 4096          %.1f us' % t(lambda: nv.colsum(x32, ws4, c4)))
 print(' colsum bf16 55680 x 4096         %.1f us' % t(lambda: nv.colsum16(x16, ws4, c4)))
+yimg = torch.empty_like(img)
+def fwd_separate():
+    nv.bn_act_fwd(x, y, mean, invstd, gamma, beta, 2, keep, 2.0)
+    nv.cast_halo_bf16(y, yimg, T_, pad)
+print(' bn_act_fwd + cast_halo           %.1f us' % t(fwd_separate))
+print(' bn_act_fwd_img                   %.1f us' % t(lambda: nv.bn_act_fwd_img(x, y, mean, invstd, gamma, beta, 2, keep, 2.0, yimg, T_, pad)))
