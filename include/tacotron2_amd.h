@@ -393,7 +393,7 @@ typedef struct t2amd_lstm_bwd {
     float keep_scale;
     float* dc;            /* [B][H] carry, in: dL/dc_t from step t+1, out: dL/dc_{t-1} */
     long long ld_dc;
-    float* dgates;        /* [B][4H] out */
+    float* dgates;        /* [B][4H] out; may be NULL beside dgates16 (round 6): the operand copy is then the cell's only gate-gradient output */
     long long ld_dgates;
     const int* lens;
     int t;
@@ -638,7 +638,9 @@ typedef struct t2amd_dec_train_bwd {
     int nsplit;              /* split-K factor of the two backward skinny GEMMs */
     /* outputs */
     float* DGA;  /* [To][B][4Ha] */
-    float* DGD;  /* [To][B][4Hd] */
+    float* DGD;  /* [To][B][4Hd]; round 6: DGA and DGD may both be NULL in the bf16 mode when DGA16 / DGD16 below are whole-sequence
+                  * slabs (dg16_step_* > 0): nothing downstream reads the f32 slabs then (weight and bias gradients come from the
+                  * bf16 slabs, t2amd_gemm16_kk_group / t2amd_colsum_bf16) and the cells stop writing them -- 2 MB per time step */
     float* DCTX; /* [To][B][E] */
     float* DQ;   /* [To][B][128] */
     float* d_pm; /* [B][Ti][128] (zeroed by the call) */

@@ -114,7 +114,6 @@ __device__ __forceinline__ void cell_bwd_finish(const t2amd_lstm_bwd& a, const C
     // kernels that share this function must agree bit for bit (tests/test_kernels_gpu.py, folded cells)
 #pragma clang fp contract(off)
     const int H = a.H;
-    float* dg = a.dgates + (long long)b * a.ld_dgates + j;
     float* dcp = a.dc + (long long)b * a.ld_dc + j;
     const float gi_[4] = {r.gi.x, r.gi.y, r.gi.z, r.gi.w}, gf_[4] = {r.gf.x, r.gf.y, r.gf.z, r.gf.w};
     const float gg_[4] = {r.gg.x, r.gg.y, r.gg.z, r.gg.w}, go_[4] = {r.go.x, r.go.y, r.go.z, r.go.w};
@@ -135,10 +134,13 @@ __device__ __forceinline__ void cell_bwd_finish(const t2amd_lstm_bwd& a, const C
         o3[e] = d_o * go_[e] * (1.f - go_[e]);
         dcn[e] = dc * gf_[e];
     }
-    *reinterpret_cast<float4*>(dg) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-    *reinterpret_cast<float4*>(dg + H) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-    *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(o2[0], o2[1], o2[2], o2[3]);
-    *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(o3[0], o3[1], o3[2], o3[3]);
+    if (a.dgates) {         // NULL (round 6): the operand copy below is this cell's only output -- the bf16 mode's whole-sequence slabs
+        float* dg = a.dgates + (long long)b * a.ld_dgates + j;
+        *reinterpret_cast<float4*>(dg) = make_float4(o0[0], o0[1], o0[2], o0[3]);
+        *reinterpret_cast<float4*>(dg + H) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        *reinterpret_cast<float4*>(dg + 2 * H) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        *reinterpret_cast<float4*>(dg + 3 * H) = make_float4(o3[0], o3[1], o3[2], o3[3]);
+    }
     if (a.dgates16) {       // operand copy for the dgrad GEMM's MFMA: bf16 (bf16 mode) or the split hi/lo image ('bf16x3' mode)
         cell_d16_store<SC1>(a, cell_d16_at(a, b, j), o0);
         cell_d16_store<SC1>(a, cell_d16_at(a, b, H + j), o1);

@@ -257,7 +257,9 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     const t2amd_dec_train& f = p->f;
     const int B = f.B, Ti = f.Ti, To = f.To, E = f.E, Ha = f.Ha, Hd = f.Hd;
     const int ns = p->nsplit < 1 ? 1 : p->nsplit;
-    T2_REQUIRE(p->Wa_recT && p->Wd_catT && f.Wq && p->DHC && p->DGA && p->DGD && p->DCTX && p->DQ && p->d_pm &&
+    T2_REQUIRE((p->DGA != nullptr) == (p->DGD != nullptr) && (p->DGA || (f.bf16 == 1 && p->dg16_step_a > 0 && p->dg16_step_d > 0)),
+               "dec_train_bwd: the f32 gate-gradient slabs DGA / DGD may be NULL (both) only in the bf16 mode with whole-sequence DGA16 / DGD16 slabs");
+    T2_REQUIRE(p->Wa_recT && p->Wd_catT && f.Wq && p->DHC && p->DCTX && p->DQ && p->d_pm &&
                    p->dU_acc && p->dv_acc && p->dXd && p->dXa && p->dc_a && p->dc_d && p->dwin_part &&
                    p->dcum_acc && p->dq_h && f.attn_ws,
                "dec_train_bwd: null pointer");
@@ -303,13 +305,13 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         lb.c = f.CD + t * sHd; lb.ld_c = Hd;
         lb.keep = f.keep_dec ? f.keep_dec + t * sHd : nullptr; lb.ld_keep = Hd; lb.keep_scale = f.scale_dec;
         lb.dc = p->dc_d; lb.ld_dc = Hd;
-        lb.dgates = p->DGD + (long long)t * B * 4 * Hd; lb.ld_dgates = 4 * Hd;
+        lb.dgates = p->DGD ? p->DGD + (long long)t * B * 4 * Hd : nullptr; lb.ld_dgates = 4 * Hd;
         if (f.bf16) { lb.dgates16 = (unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d * us; lb.ld_dgates16 = 4 * Hd; lb.dgates16_x3 = f.bf16 == 3; }
     };
     auto dgrad_d = [&](int t, t2amd_skinny_gemm& g) {     // d[h_att_t | ctx_t | h_dec_{t-1}] = dgates_d . Wd_cat
         g = t2amd_skinny_gemm{};
         g.nseg = 1;
-        g.x[0] = seg(p->DGD + (long long)t * B * 4 * Hd, 4 * Hd, 4 * Hd);
+        g.x[0] = seg(p->DGD ? p->DGD + (long long)t * B * 4 * Hd : nullptr, 4 * Hd, 4 * Hd);
         g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
         g.Y = p->dXd + t * stepXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
         if (f.bf16) { g.x[0].p = (const float*)((const unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d * us); g.W = (const float*)p->Wd_catT16; g.bf16 = f.bf16; }
@@ -356,13 +358,13 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         la.c = f.CA + t * sHa; la.ld_c = Ha;
         la.keep = f.keep_att ? f.keep_att + t * sHa : nullptr; la.ld_keep = Ha; la.keep_scale = f.scale_att;
         la.dc = p->dc_a; la.ld_dc = Ha;
-        la.dgates = p->DGA + (long long)t * B * 4 * Ha; la.ld_dgates = 4 * Ha;
+        la.dgates = p->DGA ? p->DGA + (long long)t * B * 4 * Ha : nullptr; la.ld_dgates = 4 * Ha;
         if (f.bf16) { la.dgates16 = (unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a * us; la.ld_dgates16 = 4 * Ha; la.dgates16_x3 = f.bf16 == 3; }
     };
     auto dgrad_a = [&](int t, t2amd_skinny_gemm& ga) {    // d[ctx_{t-1} | h_att_{t-1}] = dgates_a(t) . Wa_rec
         ga = t2amd_skinny_gemm{};
         ga.nseg = 1;
-        ga.x[0] = seg(p->DGA + (long long)t * B * 4 * Ha, 4 * Ha, 4 * Ha);
+        ga.x[0] = seg(p->DGA ? p->DGA + (long long)t * B * 4 * Ha : nullptr, 4 * Ha, 4 * Ha);
         ga.W = p->Wa_recT; ga.Ktot = 4 * Ha; ga.N = Ka; ga.B = B;
         ga.Y = p->dXa; ga.ldy = Ka; ga.nsplit = ns; ga.split_stride = strXa; ga.tag = 1;
         if (f.bf16) { ga.x[0].p = (const float*)((const unsigned short*)p->DGA16 + (long long)t * p->dg16_step_a * us); ga.W = (const float*)p->Wa_recT16; ga.bf16 = f.bf16; }

@@ -910,7 +910,6 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
     if (idx >= n) return;
     const int b = (int)(idx / H4);
     const int j = (int)(idx - (long long)b * H4) * 4;
-    float* dg = a.dgates + (long long)b * a.ld_dgates + j;
     float* dcp = a.dc + (long long)b * a.ld_dc + j;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     bool valid = true;
@@ -918,7 +917,7 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
     if (!valid) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<float4*>(dg + q * H) = z4;
+            if (a.dgates) *reinterpret_cast<float4*>(a.dgates + (long long)b * a.ld_dgates + j + q * H) = z4;
             if (a.dgates16) {
                 const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
                 cell_d16_store<false>(a, cell_d16_at(a, b, q * H + j), zero4);
@@ -937,11 +936,11 @@ __global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(LstmBwdParams p
 }
 
 int t2amd_check_lstm_bwd_(const t2amd_lstm_bwd* a) {
-    T2_REQUIRE(a && a->gates && a->c && a->dc && a->dgates, "lstm_bwd: null args");
+    T2_REQUIRE(a && a->gates && a->c && a->dc && (a->dgates || a->dgates16), "lstm_bwd: null args (dgates may be NULL only beside dgates16)");
     T2_REQUIRE(a->B > 0 && a->H > 0 && a->H % 4 == 0, "lstm_bwd: H must be a positive multiple of 4");
     // 16-byte accesses: every row base and stride must keep 4-float alignment
-    T2_REQUIRE(t2_aligned16(a->gates) && t2_aligned16(a->c) && t2_aligned16(a->dc) && t2_aligned16(a->dgates) &&
-                   a->ld_gates % 4 == 0 && a->ld_c % 4 == 0 && a->ld_dc % 4 == 0 && a->ld_dgates % 4 == 0 &&
+    T2_REQUIRE(t2_aligned16(a->gates) && t2_aligned16(a->c) && t2_aligned16(a->dc) && (!a->dgates || (t2_aligned16(a->dgates) && a->ld_dgates % 4 == 0)) &&
+                   a->ld_gates % 4 == 0 && a->ld_c % 4 == 0 && a->ld_dc % 4 == 0 &&
                    (!a->c_prev || (t2_aligned16(a->c_prev) && a->ld_cprev % 4 == 0)) &&
                    (!a->keep || ((reinterpret_cast<uintptr_t>(a->keep) & 3u) == 0 && a->ld_keep % 4 == 0)),
                "lstm_bwd: operands must be 16-byte aligned with strides % 4 == 0");

@@ -295,6 +295,8 @@ BN_BWD_IMAGE = os.environ.get('T2AMD_BN_BWD_IMAGE', '1') != '0'
 BN_FWD_IMAGE = os.environ.get('T2AMD_BN_FWD_IMAGE', '1') != '0'   # the same fold in the forward: BatchNorm apply writes the next layer's image
 # bf16 mode: the two LSTM bias gradients as column sums of the bf16 gate-gradient slabs (T2AMD_BIAS_GRAD16=0: of the f32 slabs)
 BIAS_GRAD16 = os.environ.get('T2AMD_BIAS_GRAD16', '1') != '0'
+# ... and then nothing reads the f32 gate-gradient slabs: not allocated, not written (T2AMD_GATE_GRADS_BF16_ONLY=0 keeps them)
+GATE_GRADS_BF16_ONLY = os.environ.get('T2AMD_GATE_GRADS_BF16_ONLY', '1') != '0'
 
 
 def _rg(run, *a, **k):
@@ -1468,7 +1470,10 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     bw.DHC = nv.ptr(DHC)
     bw.d_align = nv.ptr(cont(d_align))
     bw.nsplit = ns
-    out = dict(DGA=run.empty(To, B, 4 * Ha), DGD=run.empty(To, B, 4 * Hd), DCTX=run.empty(To, B, E),
+    # bf16 mode with whole-sequence bf16 gate-gradient slabs: weight gradients, bias gradients and the prenet's data gradient all
+    # read THOSE, so the f32 slabs are neither allocated nor written (2 x 912 MB of stores per step at B = 64 / To = 870)
+    drop32 = GATE_GRADS_BF16_ONLY and BIAS_GRAD16 and run.bf16 and WGRAD16 and B % 8 == 0 and not nv.validate_only()
+    out = dict(DGA=None if drop32 else run.empty(To, B, 4 * Ha), DGD=None if drop32 else run.empty(To, B, 4 * Hd), DCTX=run.empty(To, B, E),
                DQ=run.empty(To, B, A), d_pm=run.empty(B, Ti, A), dU_acc=run.empty(B, A, nv.LOC_TAPS),
                dv_acc=run.empty(B, A), dXd=run.empty(To, ns, B, Ha + E + Hd), dXa=run.empty(ns, B, E + Ha),
                dc_a=run.empty(B, Ha), dc_d=run.empty(B, Hd), dwin_part=run.empty(nv.ATT_SLICES, B, 2, Ti),
@@ -1500,9 +1505,9 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
                               + [S[k_] for k_ in ('HA', 'CA', 'GD', 'HD', 'CD', 'CTX', 'Q', 'ALIGN', 'CUM')]
                               + ([b16['Wa_recT16'], b16['Wd_catT16']] if op16 else [])
                               + ([c.bf16['memory16'], c.bf16['Wq16']] if run.bf16 else []),
-                              writes=list(out.values()) + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if op16 else []))
+                              writes=[v_ for v_ in out.values() if v_ is not None] + [S['attn_ws']] + ([b16['DGA16'], b16['DGD16']] if op16 else []))
     DGA, DGD, DCTX, DQ, d_pm = (out[k_] for k_ in ('DGA', 'DGD', 'DCTX', 'DQ', 'd_pm'))
-    DGA2, DGD2 = DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd)
+    DGA2, DGD2 = (None, None) if drop32 else (DGA.view(rowsD, 4 * Ha), DGD.view(rowsD, 4 * Hd))
 
     # location layer + v
     Wdense = P['decoder.attention_layer.location_layer.location_dense.linear_layer.weight']

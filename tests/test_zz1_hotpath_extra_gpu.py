@@ -361,7 +361,8 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
     """bf16 mode, round 6: (i) the BatchNorm backward of a convolution layer writes the bf16 halo image and the bias gradient
     itself (engine.BN_BWD_IMAGE; no f32 slab, no cast pass, no column-sum pass) and the BatchNorm apply of the forward writes the
     next layer's image (engine.BN_FWD_IMAGE) -- loss and every gradient of the step must be the same BITS as with the separate passes; (ii) the two LSTM bias gradients are column sums of the bf16 gate-gradient slabs
-    (engine.BIAS_GRAD16) -- only those four tensors may move, by bf16 rounding of the addends."""
+    (engine.BIAS_GRAD16) -- only those four tensors may move, by bf16 rounding of the addends; (iii) the f32 gate-gradient slabs,
+    which nothing reads any more, are dropped (engine.GATE_GRADS_BF16_ONLY) -- same bits."""
     from tacotron2_amd import engine
     from tacotron2_amd.loss_function import Tacotron2Loss
     from tacotron2_amd.model import Tacotron2
@@ -376,11 +377,11 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
     criterion = Tacotron2Loss()
     batch = tuple(t.to(dev) for t in synth_batch(24, 4321))
     assert batch[2].shape[2] * 24 >= 4096 and batch[0].shape[1] * 24 >= 4096      # window / K-major routes in postnet AND encoder
-    start = (engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16)
+    start = (engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
 
-    def grads_of(img, b16):
-        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16 = img, img, b16
+    def grads_of(img, b16, drop32=False):
+        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY = img, img, b16, drop32
         model.load_state_dict(sd)
         torch.manual_seed(5)
         model.zero_grad()
@@ -394,9 +395,13 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
         l_sep, g_sep = grads_of(False, False)
         l_img, g_img = grads_of(True, False)
         l_all, g_all = grads_of(True, True)
+        l_drop, g_drop = grads_of(True, True, True)
     finally:
-        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16 = start
-    assert l_sep == l_img == l_all
+        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY = start
+    assert l_sep == l_img == l_all == l_drop
+    # (iii) with every consumer on the bf16 slabs, the f32 gate-gradient slabs are neither allocated nor written: same bits
+    diff = [k for k in g_all if not torch.equal(g_all[k], g_drop[k])]
+    assert not diff, diff
     diff = [k for k in g_sep if not torch.equal(g_sep[k], g_img[k])]
     assert not diff, diff                                          # (i) bit-identical, every tensor
     lstm_bias = {'decoder.attention_rnn.bias_ih', 'decoder.attention_rnn.bias_hh', 'decoder.decoder_rnn.bias_ih',
