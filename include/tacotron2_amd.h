@@ -662,6 +662,11 @@ typedef struct t2amd_dec_train_bwd {
     /* 0: DGA16 / DGD16 are one step's scratch, reused by every step; B*4Ha / B*4Hd: they are [To][B][4H] slabs and step t
      * writes (and its dgrad reads) its own rows -- the engine then builds the weight-gradient operands from them */
     long long dg16_step_a, dg16_step_d;
+    /* (round 6) 0: dXd holds To step slabs (needed when the decoder-LSTM chain runs ahead on its own stream,
+     * t2amd_set_decoder_streams(2)); R >= 3: dXd holds R step slabs used as a ring (step t -> slab t % R) -- a slab is read
+     * one step after it is written and never again, and a ring stays in L2 / MALL instead of streaming To slabs to HBM.
+     * Single-stream loop only. */
+    int dXd_ring;
 } t2amd_dec_train_bwd;
 
 int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, void* stream);

@@ -293,12 +293,15 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
     // software-pipelined: cell_d(t-1) shares a launch with cell_a(t), dgrad_d(t-1) with dgrad_a(t).
     // dXd is a per-step slab [To][ns][B][Kd]: the decoder-LSTM chain may run far ahead of its consumers.
     const long long stepXd = (long long)ns * strXd;
+    const int ring = p->dXd_ring;
+    T2_REQUIRE(ring == 0 || (ring >= 3 && g_dec_streams == 1), "dec_train_bwd: dXd_ring is 0 or >= 3, and a ring needs the single-stream loop");
+    auto xd = [&](int t) -> float* { return p->dXd + (long long)(ring ? t % ring : t) * stepXd; };
     auto cell_d = [&](int t, t2amd_lstm_bwd& lb) {
         const bool last = (t == To - 1);
         lb = t2amd_lstm_bwd{};
         lb.B = B; lb.H = Hd;
         lb.dh[0] = addend(p->DHC + (long long)t * B * (Hd + E), Hd + E, 1, 0);
-        lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXd + (t + 1) * stepXd + Ha + E, Kd, ns, strXd);
+        lb.dh[1] = last ? addend(nullptr, 0, 1, 0) : addend(xd(t + 1) + Ha + E, Kd, ns, strXd);
         lb.dh[2] = addend(nullptr, 0, 1, 0);
         lb.gates = f.GD + (long long)t * B * 4 * Hd; lb.ld_gates = 4 * Hd;
         lb.c_prev = t ? f.CD + (t - 1) * sHd : nullptr; lb.ld_cprev = Hd;
@@ -313,7 +316,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         g.nseg = 1;
         g.x[0] = seg(p->DGD ? p->DGD + (long long)t * B * 4 * Hd : nullptr, 4 * Hd, 4 * Hd);
         g.W = p->Wd_catT; g.Ktot = 4 * Hd; g.N = Kd; g.B = B;
-        g.Y = p->dXd + t * stepXd; g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
+        g.Y = xd(t); g.ldy = Kd; g.nsplit = ns; g.split_stride = strXd; g.tag = 2;
         if (f.bf16) { g.x[0].p = (const float*)((const unsigned short*)p->DGD16 + (long long)t * p->dg16_step_d * us); g.W = (const float*)p->Wd_catT16; g.bf16 = f.bf16; }
     };
     auto attn_desc = [&](int t, t2amd_attn_bwd& ab, const t2amd_lstm_bwd* cq, const t2amd_lstm_bwd* cx) {   // needs dXd(t), dXa(t+1)
@@ -322,7 +325,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         ab.cell_q = cq; ab.cell_x = cx;
         ab.B = B; ab.Ti = Ti; ab.E = E; ab.Hq = Ha;
         ab.dctx[0] = addend(p->DHC + (long long)t * B * (Hd + E) + Hd, Hd + E, 1, 0);
-        ab.dctx[1] = addend(p->dXd + t * stepXd + Ha, Kd, ns, strXd);
+        ab.dctx[1] = addend(xd(t) + Ha, Kd, ns, strXd);
         ab.dctx[2] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXa, Ka, ns, strXa);
         ab.dctx_total = p->DCTX + t * sE; ab.ld_dctx_total = E;
         ab.d_w_extra = p->d_align ? p->d_align + (long long)t * Ti : nullptr; ab.ld_dwextra = (long long)To * Ti;
@@ -350,7 +353,7 @@ extern "C" int t2amd_decoder_train_bwd_loop_f32(const t2amd_dec_train_bwd* p, vo
         const bool last = (t == To - 1);
         la = t2amd_lstm_bwd{};
         la.B = B; la.H = Ha;
-        la.dh[0] = addend(p->dXd + t * stepXd, Kd, ns, strXd);
+        la.dh[0] = addend(xd(t), Kd, ns, strXd);
         la.dh[1] = addend(p->dq_h, Ha, T2AMD_ATT_SLICES, sHa);
         la.dh[2] = last ? addend(nullptr, 0, 1, 0) : addend(p->dXa + E, Ka, ns, strXa);
         la.gates = f.GA + (long long)t * B * 4 * Ha; la.ld_gates = 4 * Ha;

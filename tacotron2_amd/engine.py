@@ -297,6 +297,8 @@ BN_FWD_IMAGE = os.environ.get('T2AMD_BN_FWD_IMAGE', '1') != '0'   # the same fol
 BIAS_GRAD16 = os.environ.get('T2AMD_BIAS_GRAD16', '1') != '0'
 # ... and then nothing reads the f32 gate-gradient slabs: not allocated, not written (T2AMD_GATE_GRADS_BF16_ONLY=0 keeps them)
 GATE_GRADS_BF16_ONLY = os.environ.get('T2AMD_GATE_GRADS_BF16_ONLY', '1') != '0'
+# slabs of the decoder-LSTM input gradients kept by the BPTT loop: a ring of this many (>= 3), 0 = one per time step
+DXD_RING = int(os.environ.get('T2AMD_DXD_RING', '3'))
 
 
 def _rg(run, *a, **k):
@@ -1472,14 +1474,18 @@ def _backward(model, P, c, d_mel, d_post, d_gate, d_align):
     bw.nsplit = ns
     # bf16 mode with whole-sequence bf16 gate-gradient slabs: weight gradients, bias gradients and the prenet's data gradient all
     # read THOSE, so the f32 slabs are neither allocated nor written (2 x 912 MB of stores per step at B = 64 / To = 870)
+    # the decoder LSTM's input gradients of step t are read one step later and never again: a ring of slabs (stays in L2 / MALL)
+    # instead of To of them, unless the two-stream loop lets that chain run ahead
+    ring = DXD_RING if (DXD_RING >= 3 and nv.decoder_streams() == 1) else 0
     drop32 = GATE_GRADS_BF16_ONLY and BIAS_GRAD16 and run.bf16 and WGRAD16 and B % 8 == 0 and not nv.validate_only()
     out = dict(DGA=None if drop32 else run.empty(To, B, 4 * Ha), DGD=None if drop32 else run.empty(To, B, 4 * Hd), DCTX=run.empty(To, B, E),
                DQ=run.empty(To, B, A), d_pm=run.empty(B, Ti, A), dU_acc=run.empty(B, A, nv.LOC_TAPS),
-               dv_acc=run.empty(B, A), dXd=run.empty(To, ns, B, Ha + E + Hd), dXa=run.empty(ns, B, E + Ha),
+               dv_acc=run.empty(B, A), dXd=run.empty(ring or To, ns, B, Ha + E + Hd), dXa=run.empty(ns, B, E + Ha),
                dc_a=run.empty(B, Ha), dc_d=run.empty(B, Hd), dwin_part=run.empty(nv.ATT_SLICES, B, 2, Ti),
                dcum_acc=run.empty(B, Ti), dq_h=run.empty(nv.ATT_SLICES, B, Ha))
     for k_, v_ in out.items():
         setattr(bw, k_, nv.ptr(v_))
+    bw.dXd_ring = ring
     if run.bf16:
         # the bf16 gate gradients are kept for every step ([To][B][4H] slabs) when the weight gradients are formed from them
         slab16 = WGRAD16 and B % 8 == 0 and not nv.validate_only()

@@ -183,6 +183,7 @@ class DecTrainBwd(C.Structure):
         ("dwin_part", _f32p), ("dcum_acc", _f32p), ("dq_h", _f32p),
         ("Wa_recT16", C.c_void_p), ("Wd_catT16", C.c_void_p), ("DGA16", C.c_void_p), ("DGD16", C.c_void_p),
         ("dg16_step_a", _i64), ("dg16_step_d", _i64),
+        ("dXd_ring", C.c_int),
     ]
 
 
@@ -532,9 +533,18 @@ def loss_workspace_doubles():
     return int(load().t2amd_loss_workspace_doubles())
 
 
+_decoder_streams = 1
+
+
 def set_decoder_streams(n):
     """1 (default): single stream, fused launches; 2: decoder-LSTM chain of the training loops on a side stream."""
+    global _decoder_streams
     _check(load().t2amd_set_decoder_streams(int(n)), "t2amd_set_decoder_streams")
+    _decoder_streams = int(n)
+
+
+def decoder_streams():
+    return _decoder_streams
 
 
 def set_bptt_cell_fold(on):

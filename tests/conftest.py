@@ -28,7 +28,7 @@ def native_lib():
 _ENGINE_FLAGS = ("TRAIN_FWD_PERSISTENT", "ENCODER_BATCH_PERSISTENT", "ENCODER_BATCH_PERSISTENT_TRAIN",
                  "ENCODER_BWD_PERSISTENT", "WGRAD16", "WGRAD_KK", "CONV16", "FAST_GRAD_GEMM", "ARENA", "WEIGHT_GUARD",
                  "COMPACT_BATCH", "PERSISTENT_DECODE", "PERSISTENT_ENCODER", "SMALL_BATCH_PERSISTENT", "DGRAD_SPLIT",
-                 "ENC_DGRAD_SPLIT", "TRAIN_FWD_REPROMOTE_AFTER", "BN_BWD_IMAGE", "BN_FWD_IMAGE", "BIAS_GRAD16", "GATE_GRADS_BF16_ONLY")
+                 "ENC_DGRAD_SPLIT", "TRAIN_FWD_REPROMOTE_AFTER", "BN_BWD_IMAGE", "BN_FWD_IMAGE", "BIAS_GRAD16", "GATE_GRADS_BF16_ONLY", "DXD_RING")
 _engine_flags_at_import = {}
 
 

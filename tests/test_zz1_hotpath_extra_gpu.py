@@ -377,11 +377,11 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
     criterion = Tacotron2Loss()
     batch = tuple(t.to(dev) for t in synth_batch(24, 4321))
     assert batch[2].shape[2] * 24 >= 4096 and batch[0].shape[1] * 24 >= 4096      # window / K-major routes in postnet AND encoder
-    start = (engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY)
+    start = (engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY, engine.DXD_RING)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
 
-    def grads_of(img, b16, drop32=False):
-        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY = img, img, b16, drop32
+    def grads_of(img, b16, drop32=False, ring=0):
+        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY, engine.DXD_RING = img, img, b16, drop32, ring
         model.load_state_dict(sd)
         torch.manual_seed(5)
         model.zero_grad()
@@ -396,9 +396,13 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
         l_img, g_img = grads_of(True, False)
         l_all, g_all = grads_of(True, True)
         l_drop, g_drop = grads_of(True, True, True)
+        l_ring, g_ring = grads_of(True, True, True, 3)
     finally:
-        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY = start
-    assert l_sep == l_img == l_all == l_drop
+        engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY, engine.DXD_RING = start
+    assert l_sep == l_img == l_all == l_drop == l_ring
+    # (iv) the decoder LSTM's input-gradient slabs as a ring of three instead of one per time step: same bits
+    diff = [k for k in g_drop if not torch.equal(g_drop[k], g_ring[k])]
+    assert not diff, diff
     # (iii) with every consumer on the bf16 slabs, the f32 gate-gradient slabs are neither allocated nor written: same bits
     diff = [k for k in g_all if not torch.equal(g_all[k], g_drop[k])]
     assert not diff, diff

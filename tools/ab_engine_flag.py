@@ -26,8 +26,13 @@ ap.add_argument("flag")
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--blocks", type=int, default=4)
 ap.add_argument("--tag", default=None)
+ap.add_argument("--values", default=None, help="off,on values of a non-boolean switch, e.g. --values 0,3")
 a = ap.parse_args()
-assert isinstance(getattr(engine, a.flag), bool), "engine.%s is not a bool switch" % a.flag
+VALS = (False, True)
+if a.values:
+    VALS = tuple(int(v) for v in a.values.split(","))
+else:
+    assert isinstance(getattr(engine, a.flag), bool), "engine.%s is not a bool switch (use --values)" % a.flag
 native.load()
 dev = torch.device("cuda", 0)
 hp = create_hparams()
@@ -51,7 +56,7 @@ def step(i):
 def same_loss():
     state = {k: v.clone() for k, v in m.state_dict().items()}
     vals = []
-    for on in (False, True):
+    for on in VALS:
         setattr(engine, a.flag, on)
         m.load_state_dict(state)
         torch.manual_seed(5)
@@ -76,8 +81,8 @@ def block(on):
 losses = same_loss()
 res = {"flag": a.flag, "loss_off_on": losses, "loss_bit_identical": losses[0] == losses[1], "off": [], "on": []}
 for _ in range(a.blocks):
-    res["off"].append(block(False))
-    res["on"].append(block(True))
+    res["off"].append(block(VALS[0]))
+    res["on"].append(block(VALS[1]))
 res["mean_off"], res["mean_on"] = sum(res["off"]) / a.blocks, sum(res["on"]) / a.blocks
 res["give_ups"] = native.attn_handoff_timeouts(reset=False) + native.encoder_handoff_timeouts(reset=False)
 print(json.dumps(res))
