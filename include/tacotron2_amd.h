@@ -285,7 +285,7 @@ typedef struct t2amd_lstm_step {
     const float* bias;  /* [4H] or NULL */
     const float* c_prev; /* [B][H] or NULL (zeros) */
     long long ld_cprev;
-    float* gates_out;   /* [B][4H] activated gates i,f,g,o (may alias gin) */
+    float* gates_out;   /* [B][4H] activated gates i,f,g,o (may alias gin); NULL (round 6): not stored -- only a backward reads them */
     long long ld_gates;
     float* c_out;
     long long ld_c;
@@ -792,7 +792,7 @@ typedef struct t2amd_dec_infer {
     float* hc;             /* [2][B][Hd+E] = [h_dec | ctx] ping-pong */
     float* cum;            /* [B][Ti] */
     float* x_prenet;       /* [2][B][P] scratch */
-    float* gates;          /* [B][4*max(Ha,Hd)] scratch */
+    float* gates;          /* unused since round 6 (was: [B][4*max(Ha,Hd)] scratch for gate activations nobody read; may be NULL) */
     const float* zero_frame; /* [B][C] zeros (go frame) */
     float* attn_ws;        /* >= T2AMD_ATT_SLICES*B*Ti floats */
     /* outputs */

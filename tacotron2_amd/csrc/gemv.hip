@@ -232,11 +232,13 @@ __global__ __launch_bounds__(256) void small_batch_kernel(SmallParams p) {
             hn = go * tanhf(cn);
             if (p.keep) hn = p.keep[(long long)b * p.ld_keep + j] ? hn * p.keep_scale : 0.f;
         }
-        float* go_ = p.gates_out + (long long)b * p.ld_gates;
-        go_[j] = gi;
-        go_[H + j] = gf;
-        go_[2 * H + j] = gg;
-        go_[3 * H + j] = go;
+        if (p.gates_out) {
+            float* go_ = p.gates_out + (long long)b * p.ld_gates;
+            go_[j] = gi;
+            go_[H + j] = gf;
+            go_[2 * H + j] = gg;
+            go_[3 * H + j] = go;
+        }
         p.c_out[(long long)b * p.ld_c + j] = cn;
         p.h_out[(long long)b * p.ld_h + j] = hn;
     }
@@ -292,7 +294,7 @@ extern "C" int t2amd_lstm_step_small_f32(const t2amd_lstm_step* a, void* stream)
     T2_PROPAGATE(small_check_segs(a->x, a->nseg, a->Ktot));
     T2_REQUIRE(a->W && t2_aligned16(a->W) && a->Ktot % 4 == 0, "lstm_step_small: W must be 16-byte aligned, K % 4 == 0");
     T2_REQUIRE(a->H > 0 && a->H % 4 == 0 && a->B > 0 && a->B <= 8, "lstm_step_small: H % 4 == 0 and 1 <= B <= 8");
-    T2_REQUIRE(a->gates_out && a->c_out && a->h_out, "lstm_step_small: null outputs");
+    T2_REQUIRE(a->c_out && a->h_out, "lstm_step_small: null outputs");       // gates_out may be NULL
     SmallParams p = {};
     for (int i = 0; i < 3; ++i) p.x[i] = a->x[i];
     p.nseg = a->nseg;

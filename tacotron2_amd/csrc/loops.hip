@@ -576,7 +576,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
     // pointers into the images advance by 2 bf16 per k); prenet, projection, stop test and attention stay on their f32 forms
     const bool x3 = p->bf16 == 3;
     const int us = x3 ? 2 : 1;
-    T2_REQUIRE(p->h_a && p->c_a && p->c_d && p->hc && p->cum && p->x_prenet && p->gates && p->zero_frame && p->PG &&
+    T2_REQUIRE(p->h_a && p->c_a && p->c_d && p->hc && p->cum && p->x_prenet && p->zero_frame && p->PG &&
                    p->ALIGN && p->out_lengths && p->active && p->done_count,
                "dec_infer: null state/outputs");
     const long long sHa = (long long)B * Ha, sHd = (long long)B * Hd, sHC = (long long)B * (Hd + E);
@@ -644,7 +644,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         a.W = p->Wa_cat; a.Ktot = P + E + Ha; a.H = Ha; a.B = B;
         a.bias = p->bias_a;
         a.c_prev = p->c_a + rd * sHa; a.ld_cprev = Ha;
-        a.gates_out = p->gates; a.ld_gates = 4 * Ha;
+        a.gates_out = nullptr; a.ld_gates = 4 * Ha;      // (round 6) nobody reads the gate activations of a free-running step: not stored
         a.c_out = p->c_a + wr * sHa; a.ld_c = Ha;
         a.h_out = p->h_a + wr * sHa; a.ld_h = Ha;
         a.tag = 1;
@@ -687,7 +687,7 @@ extern "C" int t2amd_decoder_infer_steps_f32(const t2amd_dec_infer* p, void* str
         d.W = p->Wd_cat; d.Ktot = Ha + E + Hd; d.H = Hd; d.B = B;
         d.bias = p->bias_d;
         d.c_prev = p->c_d + rd * sHd; d.ld_cprev = Hd;
-        d.gates_out = p->gates; d.ld_gates = 4 * Hd;
+        d.gates_out = nullptr; d.ld_gates = 4 * Hd;
         d.c_out = p->c_d + wr * sHd; d.ld_c = Hd;
         d.h_out = p->hc + wr * sHC; d.ld_h = Hd + E;
         d.tag = 2;

@@ -340,11 +340,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyDual dp) {
         hn = go * tanhf(cn);
         if (p.keep) hn = e_keep ? hn * p.keep_scale : 0.f;
     }
-    float* go_ = p.gates_out + (long long)egr * p.ld_gates;
-    go_[ej] = gi;
-    go_[H + ej] = gf;
-    go_[2 * H + ej] = gg;
-    go_[3 * H + ej] = go;
+    if (p.gates_out) {
+        float* go_ = p.gates_out + (long long)egr * p.ld_gates;
+        go_[ej] = gi;
+        go_[H + ej] = gf;
+        go_[2 * H + ej] = gg;
+        go_[3 * H + ej] = go;
+    }
     p.c_out[(long long)egr * p.ld_c + ej] = cn;
     p.h_out[(long long)egr * p.ld_h + ej] = hn;
     if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
@@ -635,10 +637,12 @@ __global__ __launch_bounds__(512) void skinny_wide64_kernel(SkinnyDual dp) {
             hn = go * t2_tanh(cn);
             if (p.keep) hn = e_keep_raw[u] != 0 ? hn * p.keep_scale : 0.f;
         }
-        go_[ej] = gi;
-        go_[H + ej] = gf;
-        go_[2 * H + ej] = gg;
-        go_[3 * H + ej] = go;
+        if (p.gates_out) {
+            go_[ej] = gi;
+            go_[H + ej] = gf;
+            go_[2 * H + ej] = gg;
+            go_[3 * H + ej] = go;
+        }
         p.c_out[(long long)egr * p.ld_c + ej] = cn;
         p.h_out[(long long)egr * p.ld_h + ej] = hn;
         if (p.h16_out) p.h16_out[(long long)egr * p.ld_h16 + ej] = t2_f32_to_bf16(hn);
@@ -671,7 +675,7 @@ static int fill_lstm(const t2amd_lstm_step* a, SkinnyParams& p) {
     T2_PROPAGATE(check_segs(a->x, a->nseg, a->Ktot, sk_bk(a->bf16)));
     T2_REQUIRE(a->W && t2_aligned16(a->W), "lstm_step: W must be 16-byte aligned");
     T2_REQUIRE(a->H > 0 && a->H % 4 == 0 && a->B > 0, "lstm_step: H must be a multiple of 4");
-    T2_REQUIRE(a->gates_out && a->c_out && a->h_out, "lstm_step: null outputs");
+    T2_REQUIRE(a->c_out && a->h_out, "lstm_step: null outputs");       // gates_out may be NULL: the gate activations are not kept
     p = SkinnyParams{};
     for (int i = 0; i < 3; ++i) p.x[i] = a->x[i];
     p.nseg = a->nseg;

@@ -523,11 +523,13 @@ __device__ __forceinline__ void skinny_wide_body(const SkinnyParams& p, const in
         hn = go * t2_tanh(cn);
         if (p.keep) hn = e_keep ? hn * p.keep_scale : 0.f;
     }
-    float* go_ = p.gates_out + (long long)egr * p.ld_gates;
-    go_[ej] = gi;
-    go_[H + ej] = gf;
-    go_[2 * H + ej] = gg;
-    go_[3 * H + ej] = go;
+    if (p.gates_out) {           // NULL (round 6): free-running decode -- only a backward reads the gate activations
+        float* go_ = p.gates_out + (long long)egr * p.ld_gates;
+        go_[ej] = gi;
+        go_[H + ej] = gf;
+        go_[2 * H + ej] = gg;
+        go_[3 * H + ej] = go;
+    }
     p.c_out[(long long)egr * p.ld_c + ej] = cn;
     if constexpr (PERSIST) {
         // read by other workgroups of this launch (attention: h; the next step's LSTM tiles: the bf16 copy): write-through.
