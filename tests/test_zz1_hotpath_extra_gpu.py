@@ -397,12 +397,21 @@ def test_folded_batchnorm_backward_and_bf16_bias_sums_agree_with_the_separate_pa
         l_all, g_all = grads_of(True, True)
         l_drop, g_drop = grads_of(True, True, True)
         l_ring, g_ring = grads_of(True, True, True, 3)
+        from tacotron2_amd import native
+        native.set_decoder_streams(2)             # the decoder-LSTM chain on its side stream: one slab per time step again, no f32 slabs
+        try:
+            l_two, g_two = grads_of(True, True, True, 3)
+        finally:
+            native.set_decoder_streams(1)
     finally:
         engine.BN_BWD_IMAGE, engine.BN_FWD_IMAGE, engine.BIAS_GRAD16, engine.GATE_GRADS_BF16_ONLY, engine.DXD_RING = start
     assert l_sep == l_img == l_all == l_drop == l_ring
     # (iv) the decoder LSTM's input-gradient slabs as a ring of three instead of one per time step: same bits
     diff = [k for k in g_drop if not torch.equal(g_drop[k], g_ring[k])]
     assert not diff, diff
+    assert l_two == l_ring
+    diff = [k for k in g_ring if not torch.equal(g_ring[k], g_two[k])]
+    assert not diff, diff                                          # (v) and the two-stream loop agrees bit for bit
     # (iii) with every consumer on the bf16 slabs, the f32 gate-gradient slabs are neither allocated nor written: same bits
     diff = [k for k in g_all if not torch.equal(g_all[k], g_drop[k])]
     assert not diff, diff
